@@ -1,0 +1,378 @@
+/*
+ * moog_engine.h -- C ABI of the MI355X batched MOOG step engine.
+ *
+ * The reference (jazlab/moog.github.io, pure Python) has no FFI for this path;
+ * its boundary is the config dict consumed by
+ *   moog.environment.Environment.__init__   (moog/environment.py:28-80)
+ * and the dm_env surface reset()/step()/observation() (moog/environment.py:82-131).
+ * This header is the C boundary a binding for that surface talks to: a config
+ * dict is lowered (host side, Python) to the plain-old-data `moog_program_t`
+ * below, sprite state lives in two caller-owned device buffers per engine
+ * (`moog_state_view_t`), and every entry point takes raw device pointers plus a
+ * HIP stream.  No C++ / torch types cross the boundary.
+ *
+ * The same structs and the `moog_layout()` helper are shared with the CPU
+ * oracle (oracle/moog_oracle.c), which operates on host buffers of the same
+ * layout so that parity tests can compare records word for word.
+ *
+ * Conventions: every function returns 0 on success, a negative MOOG_E_* code on
+ * failure; the message is available from moog_last_error() (thread local).
+ */
+#ifndef MOOG_ENGINE_H_
+#define MOOG_ENGINE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOOG_ABI_VERSION 3
+
+/* ---- capacity limits of the program blob -------------------------------- */
+#define MOOG_MAX_LAYERS 16
+#define MOOG_MAX_FORCES 16
+#define MOOG_MAX_CORRECTIVE 4
+#define MOOG_MAX_RULES 8
+#define MOOG_MAX_TASKS 8
+#define MOOG_MAX_OPS 64
+#define MOOG_MAX_SHAPES 32
+#define MOOG_MAX_SHAPE_VERTS 512
+#define MOOG_MAX_CAND 128
+#define MOOG_MAX_SLOTS 128
+#define MOOG_NUM_FACTORS 14
+
+/* ---- error codes --------------------------------------------------------- */
+#define MOOG_OK 0
+#define MOOG_E_INVALID (-1)   /* bad argument / malformed program            */
+#define MOOG_E_HIP (-2)       /* HIP runtime error (message has the detail)  */
+#define MOOG_E_NOMEM (-3)
+#define MOOG_E_UNSUPPORTED (-4)
+
+/* ---- per-env fault bits (i32 record, word o_fault) ----------------------- */
+/* sprite_generators.py:92-98  -> RecursionError */
+#define MOOG_FAULT_SAMPLER_EXHAUSTED 1
+/* portal.py:51-54            -> ValueError (odd number of portals) */
+#define MOOG_FAULT_ODD_PORTALS 2
+/* collisions.py:322-326      -> ValueError (collision normal not unit) */
+#define MOOG_FAULT_BAD_NORMAL 4
+/* injected-uniform buffer ran dry (test harness error) */
+#define MOOG_FAULT_INJECT_UNDERRUN 8
+
+/* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
+#define MOOG_F_ALIVE 1
+#define MOOG_F_SYM_CIRCLE 2 /* sprite.py:501-502 is_symmetric_circle          */
+#define MOOG_F_VEL_F32 4    /* velocity is a float32 ndarray in the reference */
+#define MOOG_F_ANGVEL_F32 8 /* angle_vel is a float32 0-d array               */
+
+/* ---- factor indices: Sprite.FACTOR_NAMES order (sprite.py:237-253),
+ *      metadata dropped ----------------------------------------------------- */
+enum {
+  MOOG_FAC_X = 0, MOOG_FAC_Y, MOOG_FAC_SHAPE, MOOG_FAC_ANGLE, MOOG_FAC_SCALE,
+  MOOG_FAC_ASPECT, MOOG_FAC_C0, MOOG_FAC_C1, MOOG_FAC_C2, MOOG_FAC_OPACITY,
+  MOOG_FAC_XVEL, MOOG_FAC_YVEL, MOOG_FAC_ANGVEL, MOOG_FAC_MASS
+};
+
+/* factor distribution kinds (state_initialization/distributions.py) */
+enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2 };
+
+typedef struct {
+  int32_t kind;     /* MOOG_DIST_*                                            */
+  int32_t f32;      /* CONTINUOUS: sample is cast to float32 (:81,99)          */
+  int32_t n_cand;   /* DISCRETE: number of candidates                         */
+  int32_t cand_off; /* DISCRETE: first candidate in program.cand[]            */
+  double a, b;      /* CONST: a ; CONTINUOUS: [a, b)                           */
+} moog_factor_t;
+
+/* One sprite-generation op = one `generate_sprites(...)._generate(...)` call
+ * (sprite_generators.py:77-105), one direct `Sprite(**dist.sample())`, or one
+ * static sprite built at config time.  Ops run in the order the reference's
+ * state_initializer consumes randomness. */
+typedef struct {
+  int32_t slot0;        /* first sprite slot filled                           */
+  int32_t count_min;    /* n ~ randint(count_min, count_max + 1)              */
+  int32_t count_max;    /* slots reserved                                     */
+  int32_t disjoint;     /* _generate(disjoint=True)                           */
+  int32_t max_tries;    /* max_recursion_depth (default 1e4)                  */
+  int32_t n_sampled;    /* number of random factors                           */
+  int32_t sample_order[MOOG_NUM_FACTORS]; /* factor ids in draw order         */
+  uint64_t avoid_ops;   /* without_overlapping: bitmask of earlier ops        */
+  moog_factor_t factors[MOOG_NUM_FACTORS];
+} moog_genop_t;
+
+/* unit shape table entry (sprite.py:329-409 precomputed per distinct shape) */
+typedef struct {
+  int32_t nverts;
+  int32_t voff;        /* first vertex in program.shape_verts                 */
+  int32_t is_circle;   /* shape name == 'circle' (sprite.py:259)              */
+  int32_t pad_;
+  double centroid[2];  /* centroid of the raw shape (added to position, :406) */
+  double inertia[2];   /* (I_x, I_y) / area about the centroid (:400-401)     */
+} moog_shape_t;
+
+/* ---- forces (moog/physics) ----------------------------------------------- */
+enum {
+  MOOG_FORCE_DRAG = 1,          /* friction.py:54-56   p0 = coeff_friction    */
+  MOOG_FORCE_KINETIC_FRICTION,  /* friction.py:25-33   p0 = coeff_friction    */
+  MOOG_FORCE_DOWN_GRAVITY,      /* gravity.py:21-23    p0 = g                 */
+  MOOG_FORCE_GRAVITY,           /* gravity.py:44-60    p0 = g, symmetric      */
+  MOOG_FORCE_DISTANCE_LINEAR,   /* distance_fn_force.py:30-74 p0 = zero_intercept,
+                                   p1 = slope, i0 = apply_distant, i1 = apply_nearby */
+  MOOG_FORCE_DISTANCE_SPRING,   /* distance_fn_force.py:77-89 p0 = k, p1 = equilibrium */
+  MOOG_FORCE_RANDOM,            /* random_force.py:22-26 p0 = max magnitude   */
+  MOOG_FORCE_COLLISION          /* collisions.py:457-584 p0 = elasticity,
+                                   symmetric, i0 = update_angle_vel,
+                                   i1 = max_recursion_depth                   */
+};
+
+typedef struct {
+  int32_t kind;
+  int32_t n_a, n_b;     /* layer-list lengths; n_b = 0 for one-sprite forces  */
+  int32_t symmetric;
+  int32_t i0, i1;
+  int32_t layers_a[MOOG_MAX_LAYERS];
+  int32_t layers_b[MOOG_MAX_LAYERS];
+  double p0, p1;
+} moog_force_t;
+
+/* corrective physics: ConstantSpeed (constant_speed.py:34-46) */
+typedef struct {
+  int32_t n_layers;
+  int32_t layers[MOOG_MAX_LAYERS];
+  double speed;
+} moog_corrective_t;
+
+/* ---- game rules ----------------------------------------------------------- */
+enum {
+  MOOG_RULE_VANISH_ON_CONTACT = 1, /* vanish.py:63-86 l0 vanishing, l1 contacting */
+  MOOG_RULE_TORUS_WRAP,            /* ModifySprites(pos = remainder(pos,1)),
+                                      modify_sprites.py:35-52 + chase_avoid_torus.py:144-149 */
+  MOOG_RULE_PORTAL,                /* portal.py:41-76 l0 teleporting, l1 portals */
+  MOOG_RULE_BOOSTER                /* functional_maze.py:23-78 l0 agent, l1 boosters,
+                                      p0 mass mult, p1 c2 mult, p2 duration   */
+};
+
+typedef struct {
+  int32_t kind;
+  int32_t l0, l1;
+  int32_t n_layers;
+  int32_t layers[MOOG_MAX_LAYERS];
+  double p0, p1, p2;
+} moog_rule_t;
+
+/* ---- tasks ---------------------------------------------------------------- */
+enum {
+  MOOG_TASK_CONTACT_REWARD = 1, /* contact_reward.py:70-102 p0 reward, p1 reset_steps_after_contact */
+  MOOG_TASK_RESET,              /* reset.py:48-61 cond, p0 reward, p1 steps_after_condition */
+  MOOG_TASK_STAY_ALIVE          /* stay_alive.py:22-32 i0 period, p0 value    */
+};
+enum {
+  MOOG_COND_LAYER_EMPTY = 1,    /* lambda state: len(state[L]) == 0           */
+  MOOG_COND_ALL_Y_LT            /* lambda state: all(s.y < c for s in state[L]) */
+};
+
+typedef struct {
+  int32_t kind;
+  int32_t n0, n1;
+  int32_t layers0[MOOG_MAX_LAYERS];
+  int32_t layers1[MOOG_MAX_LAYERS];
+  int32_t cond, cond_layer;
+  int32_t i0;
+  int32_t pad_;
+  double cond_value;
+  double p0, p1;
+} moog_task_t;
+
+/* ---- action space ---------------------------------------------------------- */
+enum { MOOG_ACTION_JOYSTICK = 1, /* joystick.py:45-70 */
+       MOOG_ACTION_GRID = 2 };   /* grid.py:15-21,52-75 */
+
+typedef struct {
+  int32_t kind;
+  int32_t n_layers;
+  int32_t layers[MOOG_MAX_LAYERS];
+  int32_t constrained_lr;
+  int32_t control_velocity;
+  double scaling_factor;
+  double momentum;
+} moog_action_t;
+
+/* ---- renderer (observers/pil_renderer.py:37-120) --------------------------- */
+enum { MOOG_CMAP_IDENTITY = 0, MOOG_CMAP_HSV = 1 };     /* color_maps.py:21-23 */
+enum { MOOG_POLYMOD_NONE = 0, MOOG_POLYMOD_TORUS = 1 }; /* polygon_modifiers.py:32-38,67-98 */
+
+typedef struct {
+  int32_t width, height; /* PIL canvas (image_size[0], image_size[1])          */
+  int32_t cmap;
+  int32_t polymod;
+  int32_t bg[3];
+  int32_t pad_;
+} moog_render_t;
+
+/* ---- the lowered config ----------------------------------------------------- */
+typedef struct {
+  int32_t abi_version;
+  int32_t n_layers;
+  int32_t n_slots;                 /* S                                        */
+  int32_t n_total_verts;           /* TOTV = sum of slot vertex capacities     */
+  int32_t layer_slot0[MOOG_MAX_LAYERS];
+  int32_t layer_nslots[MOOG_MAX_LAYERS];
+  int32_t slot_layer[MOOG_MAX_SLOTS];
+  int32_t slot_voff[MOOG_MAX_SLOTS];
+  int32_t slot_vcap[MOOG_MAX_SLOTS];
+
+  int32_t updates_per_env_step;    /* K, physics.py:15                         */
+  int32_t n_forces;
+  int32_t n_corrective;
+  int32_t n_rules;
+  int32_t n_tasks;
+  int32_t n_ops;
+  int32_t n_shapes;
+  int32_t n_cand;
+  double timeout_steps;            /* CompositeTask timeout (inf allowed)      */
+
+  moog_force_t forces[MOOG_MAX_FORCES];
+  moog_corrective_t corrective[MOOG_MAX_CORRECTIVE];
+  moog_rule_t rules[MOOG_MAX_RULES];
+  moog_task_t tasks[MOOG_MAX_TASKS];
+  moog_action_t action;
+  moog_render_t render;
+  moog_genop_t ops[MOOG_MAX_OPS];
+  moog_shape_t shapes[MOOG_MAX_SHAPES];
+  double shape_verts[MOOG_MAX_SHAPE_VERTS][2]; /* centred, CCW, unit shapes    */
+  double cand[MOOG_MAX_CAND];                  /* DISCRETE candidates          */
+} moog_program_t;
+
+/* ---- state record layout ------------------------------------------------------
+ * Per env one f64 record and one i32 record, env-major:
+ *   f64[n_envs][f64_per_env], i32[n_envs][i32_per_env].
+ * One wavefront owns one env, so a record is one contiguous, coalesced block.
+ * Offsets below are in elements from the start of the env's record. */
+typedef struct {
+  int32_t S, TOTV, T, R;
+  int32_t f64_per_env, i32_per_env;
+  /* f64 record */
+  int32_t o_pos;      /* [S][2]   sprite.position                              */
+  int32_t o_vel;      /* [S][2]   sprite.velocity                              */
+  int32_t o_angle;    /* [S]                                                   */
+  int32_t o_angvel;   /* [S]                                                   */
+  int32_t o_mass;     /* [S]                                                   */
+  int32_t o_color;    /* [S][3]   c0,c1,c2                                     */
+  int32_t o_inertia;  /* [S][2]   _x_y_rotational_inertia                      */
+  int32_t o_maxr;     /* [S]      _max_radius                                  */
+  int32_t o_action;   /* [2]      action-space memory (_action)                */
+  int32_t o_task;     /* [T]      per-task _steps_until_reset (inf sentinel)   */
+  int32_t o_rule;     /* [R]      per-rule scalar (Booster countdown)          */
+  int32_t o_verts;    /* [TOTV][2] world vertices (sprite.vertices)            */
+  /* i32 record */
+  int32_t o_flags;    /* [S] MOOG_F_*                                          */
+  int32_t o_nverts;   /* [S]                                                   */
+  int32_t o_opacity;  /* [S]                                                   */
+  int32_t o_shape;    /* [S] shape-table id                                    */
+  int32_t o_tele;     /* [S] bit r set: slot is in rule r's _currently_teleporting */
+  int32_t o_step_count;
+  int32_t o_reset_next;
+  int32_t o_fault;
+  int32_t o_rng;      /* [4] rng draw counter lo/hi, injected cursor, spare    */
+} moog_layout_t;
+
+static inline int32_t moog_align_(int32_t x, int32_t a) { return (x + a - 1) / a * a; }
+
+static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
+  int32_t S = p->n_slots, o = 0;
+  L->S = S; L->TOTV = p->n_total_verts; L->T = p->n_tasks; L->R = p->n_rules;
+  L->o_pos = o; o += 2 * S;
+  L->o_vel = o; o += 2 * S;
+  L->o_angle = o; o += S;
+  L->o_angvel = o; o += S;
+  L->o_mass = o; o += S;
+  L->o_color = o; o += 3 * S;
+  L->o_inertia = o; o += 2 * S;
+  L->o_maxr = o; o += S;
+  L->o_action = o; o += 2;
+  L->o_task = o; o += p->n_tasks;
+  L->o_rule = o; o += p->n_rules;
+  o = moog_align_(o, 2);
+  L->o_verts = o; o += 2 * p->n_total_verts;
+  L->f64_per_env = moog_align_(o, 2);          /* 16-byte multiple */
+  o = 0;
+  L->o_flags = o; o += S;
+  L->o_nverts = o; o += S;
+  L->o_opacity = o; o += S;
+  L->o_shape = o; o += S;
+  L->o_tele = o; o += S;
+  L->o_step_count = o; o += 1;
+  L->o_reset_next = o; o += 1;
+  L->o_fault = o; o += 1;
+  L->o_rng = o; o += 4;
+  L->i32_per_env = moog_align_(o, 4);          /* 16-byte multiple */
+}
+
+/* Borrowed device pointers (owned by the caller, e.g. torch tensors). */
+typedef struct {
+  double* f64;   /* [n_envs][f64_per_env] */
+  int32_t* i32;  /* [n_envs][i32_per_env] */
+} moog_state_view_t;
+
+/* Per-call outputs, device pointers, any may be NULL. */
+typedef struct {
+  double* reward;     /* [n_envs]  NaN encodes dm_env's None (FIRST steps)      */
+  double* discount;   /* [n_envs]  NaN = None, 1.0 MID, 0.0 LAST                */
+  int32_t* step_type; /* [n_envs]  0 FIRST, 1 MID, 2 LAST                       */
+  uint8_t* image;     /* [n_envs][height][width][3]                             */
+} moog_step_out_t;
+
+/* Optional per-call randomness injection for parity runs:
+ * uniforms in [0,1) consumed in the reference's draw order.  NULL = the
+ * engine's own counter RNG (Philox4x32-10, key = (seed, env_index0 + env)). */
+typedef struct {
+  const double* uniforms; /* [n_envs][per_env] device pointer or NULL          */
+  int32_t per_env;
+} moog_inject_t;
+
+typedef struct moog_engine moog_engine_t;
+
+/* kernel ids for moog_engine_kernel_time() */
+enum { MOOG_K_STEP = 0, MOOG_K_RASTER = 1, MOOG_K_RESET = 2, MOOG_K_COUNT = 3 };
+
+int moog_abi_version(void);
+const char* moog_last_error(void);
+/* sizeof(moog_program_t) as compiled, for binding self-checks */
+int64_t moog_program_sizeof(void);
+
+/* Replaces Environment.__init__ (environment.py:28-80). `seed`/`env_index0`
+ * key the per-env RNG streams (global env index = env_index0 + local index so
+ * results do not depend on how envs are sharded over GPUs). */
+int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t device_id,
+                       uint64_t seed, int64_t env_index0, moog_engine_t** out);
+int moog_engine_destroy(moog_engine_t* e);
+int moog_engine_layout(const moog_engine_t* e, moog_layout_t* out);
+int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view);
+
+/* Replaces Environment.reset (environment.py:82-96) for the envs whose mask
+ * byte is non-zero (NULL = all).  Writes FIRST timesteps + images to `out`. */
+int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev,
+                      const moog_inject_t* inject, const moog_step_out_t* out,
+                      void* hip_stream);
+/* Replaces Environment.step (environment.py:98-126).  actions: f64 [n_envs][2]
+ * (Joystick) or i32 [n_envs] (Grid).  Envs with reset_next set are reset
+ * instead (auto-reset, :100-101). */
+int moog_engine_step(moog_engine_t* e, const void* actions_dev,
+                     const moog_inject_t* inject, const moog_step_out_t* out,
+                     void* hip_stream);
+/* env.physics.step(env.state) only (tests/runtime_benchmark.py:101-107). */
+int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject,
+                             void* hip_stream);
+/* env.observation() only (environment.py:128-131, runtime_benchmark.py:113-130). */
+int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
+
+/* Per-kernel device timing: when enabled every launch is bracketed by HIP
+ * events on the launch stream; totals are read back (synchronising) here. */
+int moog_engine_set_timing(moog_engine_t* e, int32_t enabled);
+int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_ms,
+                            int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOOG_ENGINE_H_ */

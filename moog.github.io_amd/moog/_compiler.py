@@ -1,0 +1,364 @@
+"""Lowering of a MOOG config dict to the engine's `moog_program_t`.
+
+Input: the kwargs of `moog.environment.Environment.__init__`
+(reference environment.py:28-80): state_initializer, physics, task,
+action_space, observers, game_rules.  Output: a filled `_abi.Program` plus the
+layer-name table.  The state_initializer closure is traced once (see _trace.py);
+every other component is a parameter record.
+"""
+import collections
+
+import numpy as np
+
+from . import _abi
+from . import _trace
+from . import action_spaces
+from . import game_rules as rules_lib
+from . import observers as observers_lib
+from . import physics as physics_lib
+from . import shapes as shapes_lib
+from . import sprite as sprite_lib
+from . import tasks as tasks_lib
+from .observers import polygon_modifiers
+from .state_initialization import distributions as distribs
+
+Compiled = collections.namedtuple(
+    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout'])
+
+
+class _ShapeTable(object):
+    def __init__(self, program):
+        self.p = program
+        self.entries = []   # (key, id)
+        self.nverts_total = 0
+
+    def intern(self, shape):
+        """Returns shape id for a named shape or a raw [n,2] vertex array."""
+        if isinstance(shape, str):
+            if shape not in shapes_lib.SHAPES:
+                raise ValueError('unknown shape name %r' % (shape,))
+            key = ('name', shape)
+            raw = shapes_lib.SHAPES[shape]
+        else:
+            raw = np.asarray(shape, dtype=np.float64)
+            key = ('raw', raw.shape, raw.tobytes())
+        for k, sid in self.entries:
+            if k == key:
+                return sid
+        sid = len(self.entries)
+        if sid >= _abi.MOOG_MAX_SHAPES:
+            raise ValueError('too many distinct shapes (max %d)' % _abi.MOOG_MAX_SHAPES)
+        centred, centroid, inertia = sprite_lib.shape_record(raw)
+        n = centred.shape[0]
+        if self.nverts_total + n > _abi.MOOG_MAX_SHAPE_VERTS:
+            raise ValueError('shape table overflow')
+        rec = self.p.shapes[sid]
+        rec.nverts = n
+        rec.voff = self.nverts_total
+        rec.is_circle = int(isinstance(shape, str) and shape == 'circle')
+        rec.centroid[0], rec.centroid[1] = centroid
+        rec.inertia[0], rec.inertia[1] = inertia
+        for k in range(n):
+            self.p.shape_verts[self.nverts_total + k][0] = centred[k, 0]
+            self.p.shape_verts[self.nverts_total + k][1] = centred[k, 1]
+        self.nverts_total += n
+        self.entries.append((key, sid))
+        self.p.n_shapes = len(self.entries)
+        return sid
+
+    def nverts(self, sid):
+        return self.p.shapes[sid].nverts
+
+
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def _fill_layers(dst, names, layer_index):
+    names = _as_list(names)
+    if len(names) > _abi.MOOG_MAX_LAYERS:
+        raise ValueError('too many layers in one component')
+    for i, n in enumerate(names):
+        dst[i] = layer_index(n)
+    return len(names)
+
+
+def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
+                   meta_state_initializer=None):
+    if meta_state_initializer is not None:
+        raise NotImplementedError('meta_state is not supported by the batched engine')
+    P = _abi.Program()
+    P.abi_version = _abi.MOOG_ABI_VERSION
+    shapes = _ShapeTable(P)
+
+    # ---- trace the state initializer (environment.py:86) -----------------------
+    with _trace.tracing() as tr:
+        state = state_initializer()
+    if not isinstance(state, dict):
+        raise TypeError('state_initializer must return an OrderedDict of sprite lists')
+    layer_names = list(state.keys())
+    if len(layer_names) > _abi.MOOG_MAX_LAYERS:
+        raise ValueError('too many layers (max %d)' % _abi.MOOG_MAX_LAYERS)
+
+    def layer_index(name):
+        if name not in layer_names:
+            raise KeyError('layer %r is not a key of the environment state' % (name,))
+        return layer_names.index(name)
+
+    # slots: layer order, list order
+    slot_of = {}
+    slot_sprite = []
+    P.n_layers = len(layer_names)
+    for li, name in enumerate(layer_names):
+        P.layer_slot0[li] = len(slot_sprite)
+        for s in state[name]:
+            if id(s) in slot_of:
+                raise ValueError('the same sprite object appears twice in the state')
+            slot_of[id(s)] = len(slot_sprite)
+            P.slot_layer[len(slot_sprite)] = li
+            slot_sprite.append(s)
+        P.layer_nslots[li] = len(slot_sprite) - P.layer_slot0[li]
+    S = len(slot_sprite)
+    if S > _abi.MOOG_MAX_SLOTS:
+        raise ValueError('too many sprites (max %d)' % _abi.MOOG_MAX_SLOTS)
+    P.n_slots = S
+
+    # ---- generation ops: traced ops in draw order, statics as 1-sprite ops ------
+    ops = []            # (GenOp-like, [sprites])
+    op_index_of_sprite = {}
+    traced_ids = set()
+    for op in tr.ops:
+        for s in op.sprites:
+            traced_ids.add(id(s))
+    pending_static = [s for s in slot_sprite if id(s) not in traced_ids]
+    # statics consume no randomness: put them first so that they can be avoided
+    for s in pending_static:
+        if s.is_symbolic:
+            raise ValueError('symbolic sprite created outside a traced generator')
+        ops.append((None, [s]))
+    for op in tr.ops:
+        ops.append((op, op.sprites))
+    if len(ops) > _abi.MOOG_MAX_OPS:
+        raise ValueError('too many sprite generation ops (max %d)' % _abi.MOOG_MAX_OPS)
+    for oi, (_, sprites) in enumerate(ops):
+        for s in sprites:
+            op_index_of_sprite[id(s)] = oi
+    P.n_ops = len(ops)
+
+    cand_n = 0
+    vcap = [0] * S
+    for oi, (op, sprites) in enumerate(ops):
+        G = P.ops[oi]
+        for s in sprites:
+            if id(s) not in slot_of:
+                raise ValueError('a generated sprite is missing from the returned state')
+        slots = [slot_of[id(s)] for s in sprites]
+        if slots != list(range(slots[0], slots[0] + len(slots))):
+            raise ValueError('sprites of one generator call must stay contiguous and ordered')
+        G.slot0 = slots[0]
+        G.count_max = len(sprites)
+        G.count_min = len(sprites) if op is None else op.count_min
+        G.disjoint = 0 if op is None else int(op.disjoint)
+        G.max_tries = 0 if op is None else int(op.max_tries)
+        avoid = 0
+        if op is not None:
+            for a in op.avoid:
+                if id(a) not in op_index_of_sprite:
+                    raise ValueError('without_overlapping refers to a sprite that is not in the state')
+                aj = op_index_of_sprite[id(a)]
+                if aj >= oi:
+                    raise ValueError('without_overlapping refers to a later generator')
+                avoid |= (1 << aj)
+        G.avoid_ops = avoid
+        proto = sprites[0]
+        order = list(proto.sample_order)
+        G.n_sampled = len(order)
+        max_nv = 0
+        for fi, fname in enumerate(_abi.FACTOR_NAMES):
+            F = G.factors[fi]
+            val = proto.factors[fname]
+            if isinstance(val, sprite_lib.SymbolicFactor):
+                d = val.dist
+                if isinstance(d, distribs.Continuous):
+                    F.kind = _abi.MOOG_DIST_CONTINUOUS
+                    F.a, F.b = float(d.minval), float(d.maxval)
+                    if str(d.dtype) not in ('float32', 'float64'):
+                        raise NotImplementedError('Continuous dtype %r' % (d.dtype,))
+                    F.f32 = int(str(d.dtype) == 'float32')
+                elif isinstance(d, distribs.Discrete):
+                    F.kind = _abi.MOOG_DIST_DISCRETE
+                    F.n_cand = len(d.candidates)
+                    F.cand_off = cand_n
+                    if cand_n + F.n_cand > _abi.MOOG_MAX_CAND:
+                        raise ValueError('too many Discrete candidates')
+                    for c in d.candidates:
+                        if fname == 'shape':
+                            sid = shapes.intern(c)
+                            max_nv = max(max_nv, shapes.nverts(sid))
+                            P.cand[cand_n] = float(sid)
+                        else:
+                            P.cand[cand_n] = float(c)
+                        cand_n += 1
+                else:
+                    raise NotImplementedError('distribution %r' % (type(d).__name__,))
+            else:
+                F.kind = _abi.MOOG_DIST_CONST
+                if fname == 'shape':
+                    sid = shapes.intern(val)
+                    max_nv = max(max_nv, shapes.nverts(sid))
+                    F.a = float(sid)
+                else:
+                    F.a = float(val)
+        for k, fname in enumerate(order):
+            G.sample_order[k] = _abi.FACTOR_NAMES.index(fname)
+        for sl in slots:
+            vcap[sl] = max_nv
+    P.n_cand = cand_n
+    voff = 0
+    for sl in range(S):
+        P.slot_voff[sl] = voff
+        P.slot_vcap[sl] = vcap[sl]
+        voff += vcap[sl]
+    P.n_total_verts = voff
+
+    # ---- physics (physics.py:15, :88-117) -------------------------------------------
+    if not isinstance(physics, physics_lib.Physics):
+        raise NotImplementedError('physics must be a moog.physics.Physics instance')
+    P.updates_per_env_step = int(physics.updates_per_env_step)
+    if len(physics._forces) > _abi.MOOG_MAX_FORCES:
+        raise ValueError('too many forces')
+    for fi, entry in enumerate(physics._forces):
+        force, args = entry[0], entry[1:]
+        F = P.forces[fi]
+        F.n_a = _fill_layers(F.layers_a, args[0], layer_index)
+        F.n_b = _fill_layers(F.layers_b, args[1], layer_index) if len(args) > 1 else 0
+        if len(args) > 2:
+            raise NotImplementedError('forces over more than two sprites')
+        pair = False
+        if isinstance(force, physics_lib.Drag):
+            F.kind, F.p0 = _abi.MOOG_FORCE_DRAG, force._coeff_friction
+        elif isinstance(force, physics_lib.KineticFriction):
+            F.kind, F.p0 = _abi.MOOG_FORCE_KINETIC_FRICTION, force._coeff_friction
+        elif isinstance(force, physics_lib.DownGravity):
+            F.kind, F.p0 = _abi.MOOG_FORCE_DOWN_GRAVITY, force._g
+        elif isinstance(force, physics_lib.RandomForce):
+            F.kind, F.p0 = _abi.MOOG_FORCE_RANDOM, force._max_force_magnitude
+        elif isinstance(force, physics_lib.Gravity):
+            F.kind, F.p0, F.symmetric, pair = _abi.MOOG_FORCE_GRAVITY, force._g, int(force._symmetric), True
+        elif isinstance(force, physics_lib.DistanceForce):
+            fn = force._force_fn
+            pair = True
+            F.symmetric = int(force._symmetric)
+            if fn.kind == 'linear':
+                F.kind = _abi.MOOG_FORCE_DISTANCE_LINEAR
+                F.p0, F.p1 = fn.params['zero_intercept'], fn.params['slope']
+                F.i0, F.i1 = int(fn.params['apply_distant_force']), int(fn.params['apply_nearby_force'])
+            else:
+                F.kind = _abi.MOOG_FORCE_DISTANCE_SPRING
+                F.p0, F.p1 = fn.params['spring_constant'], fn.params['equilibrium']
+        elif isinstance(force, physics_lib.Collision):
+            pair = True
+            F.kind = _abi.MOOG_FORCE_COLLISION
+            F.p0 = force._elasticity
+            F.symmetric = int(force._symmetric)
+            F.i0 = int(force._update_angle_vel)
+            F.i1 = int(force._max_recursion_depth)
+        else:
+            raise NotImplementedError('force %r is not lowered' % (type(force).__name__,))
+        if pair != (F.n_b > 0):
+            raise ValueError('%s applied to the wrong number of layer arguments' % type(force).__name__)
+    P.n_forces = len(physics._forces)
+    for ci, c in enumerate(physics._corrective_physics):
+        if not isinstance(c, physics_lib.ConstantSpeed):
+            raise NotImplementedError('corrective physics %r is not lowered' % (type(c).__name__,))
+        C = P.corrective[ci]
+        C.n_layers = _fill_layers(C.layers, c._layer_names, layer_index)
+        C.speed = c._speed
+    P.n_corrective = len(physics._corrective_physics)
+
+    # ---- game rules ---------------------------------------------------------------
+    game_rules = tuple(game_rules)
+    if len(game_rules) > _abi.MOOG_MAX_RULES:
+        raise ValueError('too many game rules')
+    for ri, r in enumerate(game_rules):
+        R = P.rules[ri]
+        low = rules_lib.lookup_lowering(r)
+        if isinstance(r, rules_lib.VanishOnContact):
+            R.kind = _abi.MOOG_RULE_VANISH_ON_CONTACT
+            R.l0, R.l1 = layer_index(r._layer), layer_index(r._contacting_layer)
+        elif isinstance(r, rules_lib.ModifySprites):
+            R.kind = r.classify()
+            R.n_layers = _fill_layers(R.layers, r._layers, layer_index)
+        elif isinstance(r, rules_lib.Portal):
+            R.kind = _abi.MOOG_RULE_PORTAL
+            R.l0, R.l1 = layer_index(r._teleporting_layer), layer_index(r._portal_layer)
+        elif low is not None:
+            d = low(r, layer_index)
+            R.kind, R.l0, R.l1 = d['kind'], d.get('l0', 0), d.get('l1', 0)
+            R.p0, R.p1, R.p2 = d.get('p0', 0.), d.get('p1', 0.), d.get('p2', 0.)
+        else:
+            raise NotImplementedError(
+                'game rule %r has no device lowering (see game_rules.register_lowering)'
+                % (type(r).__name__,))
+    P.n_rules = len(game_rules)
+
+    # ---- task -----------------------------------------------------------------------
+    if isinstance(task, tasks_lib.CompositeTask):
+        subtasks, P.timeout_steps = list(task._tasks), float(task._timeout_steps)
+    else:
+        subtasks, P.timeout_steps = [task], float('inf')
+    if len(subtasks) > _abi.MOOG_MAX_TASKS:
+        raise ValueError('too many tasks')
+    for ti, t in enumerate(subtasks):
+        T = P.tasks[ti]
+        if isinstance(t, tasks_lib.ContactReward):
+            T.kind = _abi.MOOG_TASK_CONTACT_REWARD
+            T.n0 = _fill_layers(T.layers0, t._layers_0, layer_index)
+            T.n1 = _fill_layers(T.layers1, t._layers_1, layer_index)
+            T.p0, T.p1 = float(t._reward), float(t._reset_steps_after_contact)
+        elif isinstance(t, tasks_lib.Reset):
+            T.kind = _abi.MOOG_TASK_RESET
+            cond, lname, val = t.classify(layer_names)
+            T.cond, T.cond_layer, T.cond_value = cond, layer_index(lname), val
+            T.p0, T.p1 = float(t.reward_value()), float(t._steps_after_condition)
+        elif isinstance(t, tasks_lib.StayAlive):
+            T.kind = _abi.MOOG_TASK_STAY_ALIVE
+            T.i0, T.p0 = int(t._reward_period), float(t._reward_value)
+        else:
+            raise NotImplementedError('task %r is not lowered' % (type(t).__name__,))
+    P.n_tasks = len(subtasks)
+
+    # ---- action space -----------------------------------------------------------------
+    A = P.action
+    if isinstance(action_space, action_spaces.Joystick):
+        A.kind = _abi.MOOG_ACTION_JOYSTICK
+        A.constrained_lr = int(action_space._constrained_lr)
+    elif isinstance(action_space, action_spaces.Grid):
+        A.kind = _abi.MOOG_ACTION_GRID
+    else:
+        raise NotImplementedError('action space %r is not lowered' % (type(action_space).__name__,))
+    A.n_layers = _fill_layers(A.layers, action_space._action_layers, layer_index)
+    A.control_velocity = int(action_space._control_velocity)
+    A.scaling_factor = float(action_space._scaling_factor)
+    A.momentum = float(action_space._momentum)
+
+    # ---- observer -----------------------------------------------------------------------
+    obs_items = list(observers.items()) if observers else []
+    renderers = [(k, o) for k, o in obs_items if isinstance(o, observers_lib.PILRenderer)]
+    if len(renderers) != 1 or len(obs_items) != 1:
+        raise NotImplementedError('exactly one PILRenderer observer is supported')
+    obs_key, ren = renderers[0]
+    Rn = P.render
+    Rn.width, Rn.height = int(ren._canvas_size[0]), int(ren._canvas_size[1])
+    Rn.cmap = _abi.MOOG_CMAP_HSV if ren._cmap == 'hsv' else _abi.MOOG_CMAP_IDENTITY
+    if isinstance(ren._polygon_modifier, polygon_modifiers.TorusGeometry):
+        Rn.polymod = _abi.MOOG_POLYMOD_TORUS
+    elif isinstance(ren._polygon_modifier, polygon_modifiers.DoNothing):
+        Rn.polymod = _abi.MOOG_POLYMOD_NONE
+    else:
+        raise NotImplementedError('polygon modifier %r' % (type(ren._polygon_modifier).__name__,))
+    for c in range(3):
+        Rn.bg[c] = int(ren._bg_color[c])
+
+    layer_slots = {name: (P.layer_slot0[i], P.layer_nslots[i]) for i, name in enumerate(layer_names)}
+    return Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P))

@@ -1,0 +1,289 @@
+"""Environment (reference: moog/environment.py:28-158), batched on one MI355X.
+
+`BatchedEnvironment(**config, num_envs=N)` keeps the reference's method names
+(`reset`, `step`, `observation`, `observation_spec`, `action_spec`,
+`state`-like accessors) with a leading env axis: step_type int32[N], reward
+float64[N] (NaN where the reference returns None), discount float64[N],
+observation {'image': uint8[N,H,W,3]} -- all torch tensors on the device.
+Auto-reset follows environment.py:100-101 per env: the call after a LAST
+timestep ignores that env's action and returns a FIRST timestep.
+
+`Environment(**config)` is the single-env facade with numpy/scalar outputs.
+"""
+import collections
+import ctypes
+
+import numpy as np
+
+from . import _abi
+from . import _compiler
+from . import _dm_env as dm_env
+from . import _engine
+
+_FAULT_EXC = (
+    (_abi.MOOG_FAULT_SAMPLER_EXHAUSTED, RecursionError,
+     'max_recursion_depth exceeded trying to initialize a non-overlapping sprite.'),
+    (_abi.MOOG_FAULT_ODD_PORTALS, ValueError, 'There must be an even number of portals.'),
+    (_abi.MOOG_FAULT_BAD_NORMAL, ValueError, 'collision_normal_norm is not close to 1.'),
+    (_abi.MOOG_FAULT_INJECT_UNDERRUN, RuntimeError, 'injected uniform buffer exhausted.'),
+)
+
+
+class BatchedEnvironment(object):
+    """N independent MOOG environments stepped by one HIP engine handle."""
+
+    def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
+                 meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0):
+        import torch
+        self._torch = torch
+        self._lib = _engine.load_library()  # raises when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
+        self.compiled = _compiler.compile_config(
+            state_initializer, physics, task, action_space, observers, game_rules,
+            meta_state_initializer)
+        self.physics = physics
+        self.task = task
+        self.action_space = action_space
+        self.observers = observers
+        self.game_rules = game_rules
+        self.num_envs = int(num_envs)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        P, L = self.compiled.program, self.compiled.layout
+        self.layout = L
+        n = self.num_envs
+        with torch.cuda.device(self.device):
+            self.state_f64 = torch.zeros((n, L.f64_per_env), dtype=torch.float64, device=self.device)
+            self.state_i32 = torch.zeros((n, L.i32_per_env), dtype=torch.int32, device=self.device)
+            self.reward = torch.full((n,), float('nan'), dtype=torch.float64, device=self.device)
+            self.discount = torch.full((n,), float('nan'), dtype=torch.float64, device=self.device)
+            self.step_type = torch.zeros((n,), dtype=torch.int32, device=self.device)
+            self.image = torch.zeros((n, P.render.height, P.render.width, 3), dtype=torch.uint8,
+                                     device=self.device)
+        self._handle = ctypes.c_void_p()
+        _engine.check(self._lib, self._lib.moog_engine_create(
+            ctypes.byref(P), n, self.device.index or 0, int(seed), int(env_index0),
+            ctypes.byref(self._handle)))
+        view = _abi.StateView()
+        view.f64 = ctypes.cast(self.state_f64.data_ptr(), ctypes.POINTER(ctypes.c_double))
+        view.i32 = ctypes.cast(self.state_i32.data_ptr(), ctypes.POINTER(ctypes.c_int32))
+        _engine.check(self._lib, self._lib.moog_engine_load_state(self._handle, ctypes.byref(view)))
+        self._out = _abi.StepOut()
+        self._out.reward = ctypes.cast(self.reward.data_ptr(), ctypes.POINTER(ctypes.c_double))
+        self._out.discount = ctypes.cast(self.discount.data_ptr(), ctypes.POINTER(ctypes.c_double))
+        self._out.step_type = ctypes.cast(self.step_type.data_ptr(), ctypes.POINTER(ctypes.c_int32))
+        self._out.image = ctypes.cast(self.image.data_ptr(), ctypes.POINTER(ctypes.c_uint8))
+        self._is_grid = P.action.kind == _abi.MOOG_ACTION_GRID
+        self.check_faults = True
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _inject(self, uniforms):
+        if uniforms is None:
+            return None, None
+        t = self._torch.as_tensor(uniforms, dtype=self._torch.float64, device=self.device).contiguous()
+        assert t.dim() == 2 and t.shape[0] == self.num_envs
+        inj = _abi.Inject()
+        inj.uniforms = ctypes.cast(t.data_ptr(), ctypes.POINTER(ctypes.c_double))
+        inj.per_env = t.shape[1]
+        return inj, t
+
+    def _timestep(self):
+        obs = {self.compiled.observer_key: self.image}
+        return dm_env.TimeStep(self.step_type, self.reward, self.discount, obs)
+
+    def raise_faults(self):
+        """Re-raises device-side per-env faults with the reference's exception types."""
+        faults = self.state_i32[:, self.layout.o_fault]
+        if not bool((faults != 0).any().item()):
+            return
+        allbits = 0
+        for v in faults.unique().tolist():
+            allbits |= int(v)
+        for bit, exc, msg in _FAULT_EXC:
+            if allbits & bit:
+                env = int((faults & bit).nonzero()[0].item())
+                raise exc('%s (env %d)' % (msg, env))
+
+    # -- dm_env surface (environment.py:82-131) ------------------------------------------
+    def reset(self, env_mask=None, injected_uniforms=None):
+        mask_t = None
+        mask_ptr = None
+        if env_mask is not None:
+            mask_t = self._torch.as_tensor(env_mask, device=self.device).to(self._torch.uint8).contiguous()
+            mask_ptr = ctypes.c_void_p(mask_t.data_ptr())
+        inj, keep = self._inject(injected_uniforms)
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_reset(
+                self._handle, mask_ptr, ctypes.byref(inj) if inj else None,
+                ctypes.byref(self._out), self._stream()))
+        if self.check_faults:
+            self.raise_faults()
+        del keep, mask_t
+        return self._timestep()
+
+    def step(self, action, injected_uniforms=None):
+        torch = self._torch
+        if self._is_grid:
+            a = torch.as_tensor(action, device=self.device).to(torch.int32).contiguous()
+            assert a.shape == (self.num_envs,)
+        else:
+            a = torch.as_tensor(action, device=self.device).to(torch.float64).contiguous()
+            assert a.shape == (self.num_envs, 2)
+        inj, keep = self._inject(injected_uniforms)
+        with torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_step(
+                self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,
+                ctypes.byref(self._out), self._stream()))
+        self._last_action = a
+        if self.check_faults and injected_uniforms is not None:
+            self.raise_faults()
+        del keep
+        return self._timestep()
+
+    def physics_step(self, injected_uniforms=None):
+        """`env.physics.step(env.state)` (tests/runtime_benchmark.py:101-107)."""
+        inj, keep = self._inject(injected_uniforms)
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_physics_only(
+                self._handle, ctypes.byref(inj) if inj else None, self._stream()))
+        del keep
+
+    def observation(self):
+        """Renders the current state (environment.py:128-131)."""
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_render(
+                self._handle, ctypes.c_void_p(self.image.data_ptr()), self._stream()))
+        return {self.compiled.observer_key: self.image}
+
+    def observation_spec(self):
+        return {k: o.observation_spec() for k, o in self.observers.items()}
+
+    def action_spec(self):
+        return self.action_space.action_spec()
+
+    def random_action(self):
+        torch = self._torch
+        if self._is_grid:
+            return torch.randint(0, 5, (self.num_envs,), dtype=torch.int32, device=self.device)
+        return torch.rand((self.num_envs, 2), dtype=torch.float64, device=self.device) * 2 - 1
+
+    @property
+    def reset_next_step(self):
+        return self.state_i32[:, self.layout.o_reset_next].bool()
+
+    @property
+    def step_count(self):
+        return self.state_i32[:, self.layout.o_step_count]
+
+    # -- kernel timing -------------------------------------------------------------------
+    def set_timing(self, enabled):
+        _engine.check(self._lib, self._lib.moog_engine_set_timing(self._handle, int(bool(enabled))))
+
+    def kernel_time(self, kernel_id):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        _engine.check(self._lib, self._lib.moog_engine_kernel_time(
+            self._handle, kernel_id, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
+    # -- state views (sprite table as tensors) ----------------------------------------------
+    def field(self, name):
+        """Tensor view [N, S, ...] of one sprite field of the state record."""
+        L, S = self.layout, self.layout.S
+        f, q = self.state_f64, self.state_i32
+        two = lambda o: f[:, o:o + 2 * S].view(-1, S, 2)
+        one = lambda o: f[:, o:o + S]
+        if name == 'position':
+            return two(L.o_pos)
+        if name == 'velocity':
+            return two(L.o_vel)
+        if name == 'angle':
+            return one(L.o_angle)
+        if name == 'angle_vel':
+            return one(L.o_angvel)
+        if name == 'mass':
+            return one(L.o_mass)
+        if name == 'color':
+            return f[:, L.o_color:L.o_color + 3 * S].view(-1, S, 3)
+        if name == 'inertia':
+            return two(L.o_inertia)
+        if name == 'max_radius':
+            return one(L.o_maxr)
+        if name == 'vertices':
+            return f[:, L.o_verts:L.o_verts + 2 * L.TOTV].view(-1, L.TOTV, 2)
+        if name == 'flags':
+            return q[:, L.o_flags:L.o_flags + S]
+        if name == 'alive':
+            return (q[:, L.o_flags:L.o_flags + S] & _abi.MOOG_F_ALIVE).bool()
+        if name == 'nverts':
+            return q[:, L.o_nverts:L.o_nverts + S]
+        if name == 'opacity':
+            return q[:, L.o_opacity:L.o_opacity + S]
+        raise KeyError(name)
+
+    def close(self):
+        if self._handle:
+            self._lib.moog_engine_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class Environment(object):
+    """Single-env facade with the reference's dm_env semantics (environment.py:28-158):
+    numpy observation, Python-scalar reward, `None` reward/discount on FIRST."""
+
+    def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
+                 meta_state_initializer=None, **engine_kwargs):
+        self._batched = BatchedEnvironment(
+            state_initializer, physics, task, action_space, observers, game_rules,
+            meta_state_initializer, num_envs=1, **engine_kwargs)
+        self.physics = physics
+        self.task = task
+        self.action_space = action_space
+        self.observers = observers
+        self.game_rules = game_rules
+        self.step_count = 0
+
+    def _unbatch(self, ts):
+        st = dm_env.StepType(int(ts.step_type[0].item()))
+        obs = {k: v[0].cpu().numpy() for k, v in ts.observation.items()}
+        self.step_count = int(self._batched.step_count[0].item())
+        if st == dm_env.StepType.FIRST:
+            return dm_env.TimeStep(st, None, None, obs)
+        return dm_env.TimeStep(st, float(ts.reward[0].item()), float(ts.discount[0].item()), obs)
+
+    def reset(self):
+        return self._unbatch(self._batched.reset())
+
+    def step(self, action):
+        a = np.asarray(action)
+        if self._batched._is_grid:
+            a = a.reshape(1)
+        else:
+            a = a.reshape(1, 2).astype(np.float64)
+        return self._unbatch(self._batched.step(a))
+
+    def observation(self):
+        return {k: v[0].cpu().numpy() for k, v in self._batched.observation().items()}
+
+    def observation_spec(self):
+        return self._batched.observation_spec()
+
+    def action_spec(self):
+        return self._batched.action_spec()
+
+    @property
+    def reset_next_step(self):
+        return bool(self._batched.reset_next_step[0].item())
+
+    @property
+    def batched(self):
+        return self._batched

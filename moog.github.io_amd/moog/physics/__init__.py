@@ -1,0 +1,129 @@
+"""Physics components (reference: moog/physics/__init__.py:3-21).
+
+Parameter records only -- the integrators and the collision response run in the
+HIP step kernel (csrc/moog_step.hip).  Constructor signatures follow the
+reference: physics.py:15, collisions.py:466-467, friction.py:20,46,
+gravity.py:13,36, distance_fn_force.py:17,50-53,77, random_force.py:11,
+constant_speed.py:18.
+"""
+import numpy as np
+
+
+class AbstractForce(object):
+    """abstract_force.py:10-41"""
+
+    def reset(self, state):
+        pass
+
+
+class AbstractNewtonianForce(AbstractForce):
+    """abstract_force.py:44-74"""
+
+
+class AbstractPhysics(object):
+    """abstract_physics.py:6-47"""
+
+    def __init__(self, updates_per_env_step=1):
+        self._updates_per_env_step = updates_per_env_step
+
+    def reset(self, state):
+        pass
+
+    @property
+    def updates_per_env_step(self):
+        return self._updates_per_env_step
+
+
+class Drag(AbstractNewtonianForce):
+    def __init__(self, coeff_friction=1.):
+        self._coeff_friction = coeff_friction
+
+
+class KineticFriction(AbstractNewtonianForce):
+    def __init__(self, coeff_friction=1.):
+        self._coeff_friction = coeff_friction
+
+
+class DownGravity(AbstractNewtonianForce):
+    def __init__(self, g=-1.):
+        self._g = g
+
+
+class Gravity(AbstractNewtonianForce):
+    def __init__(self, g=-1., symmetric=True):
+        self._g = g
+        self._symmetric = symmetric
+
+
+class _ForceFn(object):
+    """Declarative distance->magnitude function (callable for API parity)."""
+
+    def __init__(self, kind, **params):
+        self.kind = kind
+        self.params = params
+
+    def __call__(self, distance):
+        p = self.params
+        if self.kind == 'linear':
+            horizon = -1. * p['zero_intercept'] / p['slope']
+            mag = p['zero_intercept'] + p['slope'] * distance
+            if not p['apply_distant_force'] and distance > horizon:
+                mag = 0
+            if not p['apply_nearby_force'] and distance < horizon:
+                mag = 0
+            return mag
+        return -1. * p['spring_constant'] * (distance - p['equilibrium'])
+
+
+def linear_force_fn(zero_intercept, slope, apply_distant_force=False, apply_nearby_force=True):
+    """distance_fn_force.py:50-74"""
+    return _ForceFn('linear', zero_intercept=zero_intercept, slope=slope,
+                    apply_distant_force=apply_distant_force,
+                    apply_nearby_force=apply_nearby_force)
+
+
+def spring_force_fn(spring_constant, equilibrium=0):
+    """distance_fn_force.py:77-89"""
+    return _ForceFn('spring', spring_constant=spring_constant, equilibrium=equilibrium)
+
+
+class DistanceForce(AbstractNewtonianForce):
+    def __init__(self, force_fn, symmetric=False):
+        if not isinstance(force_fn, _ForceFn):
+            raise NotImplementedError(
+                'DistanceForce needs linear_force_fn(...) or spring_force_fn(...); arbitrary '
+                'Python force functions cannot be lowered to the device')
+        self._force_fn = force_fn
+        self._symmetric = symmetric
+
+
+class RandomForce(AbstractNewtonianForce):
+    def __init__(self, max_force_magnitude):
+        self._max_force_magnitude = max_force_magnitude
+
+
+class Collision(AbstractForce):
+    def __init__(self, elasticity=1., symmetric=False, update_angle_vel=True,
+                 max_recursion_depth=0):
+        self._elasticity = elasticity
+        self._symmetric = symmetric
+        self._update_angle_vel = update_angle_vel
+        self._max_recursion_depth = max_recursion_depth
+
+
+class ConstantSpeed(AbstractPhysics):
+    def __init__(self, layer_names, speed):
+        super(ConstantSpeed, self).__init__(1)
+        if not isinstance(layer_names, (list, tuple)):
+            layer_names = [layer_names]
+        self._layer_names = list(layer_names)
+        self._speed = speed
+
+
+class Physics(AbstractPhysics):
+    def __init__(self, *forces, updates_per_env_step=1, corrective_physics=()):
+        super(Physics, self).__init__(updates_per_env_step=updates_per_env_step)
+        self._forces = forces
+        if not isinstance(corrective_physics, (list, tuple)):
+            corrective_physics = [corrective_physics]
+        self._corrective_physics = list(corrective_physics)

@@ -1,0 +1,37 @@
+"""Sprite generators (reference: moog/state_initialization/sprite_generators.py:24-105).
+
+`generate_sprites(...)` returns `_generate(disjoint=False, without_overlapping=[])`
+exactly as in the reference; inside a traced state_initializer the call records
+a generation op (rejection sampling runs on the device at every reset).
+"""
+from .. import _trace
+from .. import sprite as sprite_lib
+
+
+def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
+                     fail_gracefully=False):
+    def _generate(disjoint=False, without_overlapping=[]):
+        t = _trace.active()
+        if t is None:
+            raise RuntimeError(
+                'sprite generators only run inside an environment (the state_initializer is '
+                'lowered to the device-side sampler; there is no host sampling path)')
+        if fail_gracefully:
+            raise NotImplementedError('fail_gracefully=True is not supported by the device sampler')
+        n_calls = len(t.randint_calls)
+        n = num_sprites() if callable(num_sprites) else num_sprites
+        if len(t.randint_calls) > n_calls:
+            lo, hi = t.randint_calls[-1]
+            count_min, count_max = lo, hi - 1
+        else:
+            count_min = count_max = int(n)
+        t.suspend = True
+        try:
+            sprites = [sprite_lib.Sprite(**factor_dist.sample()) for _ in range(count_max)]
+        finally:
+            t.suspend = False
+        t.add_op(_trace.GenOp(factor_dist, count_min, count_max, bool(disjoint),
+                              list(without_overlapping), int(max_recursion_depth), sprites))
+        return sprites
+
+    return _generate

@@ -1,0 +1,116 @@
+"""Tasks (reference: moog/tasks/__init__.py:3-7): CompositeTask
+(composite_task.py:17-42), ContactReward (contact_reward.py:20-102), Reset
+(reset.py:19-61), StayAlive (stay_alive.py:9-32).  Parameter records; rewards
+and reset bookkeeping are computed in the step kernel.
+"""
+import inspect
+
+import numpy as np
+
+from .. import _abi
+
+
+class AbstractTask(object):
+    pass
+
+
+class CompositeTask(AbstractTask):
+    def __init__(self, *tasks, timeout_steps=np.inf):
+        self._tasks = tasks
+        self._timeout_steps = timeout_steps
+
+
+class ContactReward(AbstractTask):
+    def __init__(self, reward_fn, layers_0, layers_1, condition=None,
+                 reset_steps_after_contact=np.inf):
+        if callable(reward_fn):
+            raise NotImplementedError('ContactReward with a callable reward_fn is not lowered')
+        if condition is not None:
+            raise NotImplementedError('ContactReward(condition=...) is not lowered')
+        self._reward = reward_fn
+        if not isinstance(layers_0, (list, tuple)):
+            layers_0 = [layers_0]
+        if not isinstance(layers_1, (list, tuple)):
+            layers_1 = [layers_1]
+        self._layers_0 = list(layers_0)
+        self._layers_1 = list(layers_1)
+        self._reset_steps_after_contact = reset_steps_after_contact
+
+
+class _Probe(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class Reset(AbstractTask):
+    def __init__(self, condition, reward_fn=None, steps_after_condition=np.inf):
+        if len(inspect.signature(condition).parameters.values()) != 1:
+            raise NotImplementedError('Reset(condition(state, meta_state)) is not lowered')
+        self._condition = condition
+        self._steps_after_condition = steps_after_condition
+        self._reward_fn = reward_fn
+
+    def classify(self, layer_names):
+        """Recognise `condition` by probing it on synthetic states.
+
+        Recognised forms: "layer L is empty" (chase_avoid_torus.py:114,
+        functional_maze.py:202) and "all sprites of layer L have y < c"
+        (pong.py:87).  Returns (cond_kind, layer_name, value).
+        """
+        cond = self._condition
+
+        def state_with(empty=(), y=None):
+            return {l: ([] if l in empty else [_Probe(y=(0.5 if y is None else y), x=0.5)])
+                    for l in layer_names}
+
+        try:
+            base = bool(cond(state_with()))
+            flips = [l for l in layer_names if bool(cond(state_with(empty=(l,)))) != base]
+            all_empty = bool(cond(state_with(empty=tuple(layer_names))))
+        except Exception as exc:  # pylint: disable=broad-except
+            raise NotImplementedError('Reset condition not recognised: %r' % (exc,))
+        # y-threshold form: true for very low y, false for very high y
+        lo = bool(cond(state_with(y=-1e9)))
+        hi = bool(cond(state_with(y=1e9)))
+        if lo and not hi:
+            layer = None
+            for l in layer_names:
+                st = {k: [_Probe(y=(-1e9 if k != l else 1e9), x=0.5)] for k in layer_names}
+                if not bool(cond(st)):
+                    if layer is not None:
+                        raise NotImplementedError('Reset condition depends on several layers')
+                    layer = l
+            a, b = -1e9, 1e9
+            for _ in range(200):
+                mid = 0.5 * (a + b)
+                st = {k: [_Probe(y=(mid if k == layer else -1e9), x=0.5)] for k in layer_names}
+                if bool(cond(st)):
+                    a = mid
+                else:
+                    b = mid
+            c = b
+            if abs(c) < 1e-12:
+                c = 0.0
+            st = {k: [_Probe(y=(c if k == layer else -1e9), x=0.5)] for k in layer_names}
+            if bool(cond(st)):
+                raise NotImplementedError('Reset condition is not a strict y < c test')
+            st = {k: [_Probe(y=-1e9, x=0.5), _Probe(y=(1e9 if k == layer else -1e9), x=0.5)]
+                  for k in layer_names}
+            if bool(cond(st)):
+                raise NotImplementedError('Reset condition is not all(y < c)')
+            return _abi.MOOG_COND_ALL_Y_LT, layer, float(c)
+        if (not base) and len(flips) == 1 and all_empty:
+            return _abi.MOOG_COND_LAYER_EMPTY, flips[0], 0.0
+        raise NotImplementedError(
+            'Reset condition not recognised (supported: layer empty, all(y < c))')
+
+    def reward_value(self):
+        if self._reward_fn is None:
+            return 0.
+        raise NotImplementedError('Reset(reward_fn=...) is not lowered')
+
+
+class StayAlive(AbstractTask):
+    def __init__(self, reward_period, reward_value=1.):
+        self._reward_period = reward_period
+        self._reward_value = reward_value

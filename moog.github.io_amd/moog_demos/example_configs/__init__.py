@@ -1,0 +1,18 @@
+"""Task recipes for the batched engine.
+
+Each module exposes `get_config(level) -> dict` whose keys are the kwargs of
+`moog.environment.Environment` -- the same "plugin API" as the reference's
+`moog_demos/example_configs/*.py`.  The five recipes named in BASELINE.json are
+re-stated here (parameters cited per file) so that tests and the benchmark can
+run on machines where the reference checkout is absent; the reference's own
+config files also load unchanged (tests/test_configs.py).  `*_32` / `*_64` are
+the scaled variants of SURVEY.md 8(d).
+"""
+import importlib
+
+NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
+         'colliding_predators_32', 'falling_balls_64')
+
+
+def load(name, level=0):
+    return importlib.import_module(__name__ + '.' + name).get_config(level)
