@@ -1,0 +1,176 @@
+"""Headline benchmark: env steps/sec of the batched MOOG step path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" = one `BatchedEnvironment.step(actions)` over the whole batch: auto-reset
+kernel + step kernel (rules -> action -> K physics substeps -> task) + raster
+kernel writing the uint8 frame batch, with random actions generated on device.
+Workload (BASELINE.json configs[2], the one the metric is quoted on):
+colliding_predators scaled to 32 sprites, 4096 envs per GPU, 64x64 observations.
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); envs are
+independent, so ranks shard the env axis with no data-path collective (weak
+scaling: 4096 envs per GPU, global env index = rank * 4096 + local).
+
+The JSON line also carries
+  roofline     achieved algorithmic GB/s of the raster kernel (HIP events around
+               every launch of the timed region) against the 8 TB/s HBM3E peak
+  cpu_baseline the CPU oracle (a C port of the reference algorithm) timed on this
+               box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'moog.github.io_amd'))
+
+WORKLOAD = 'colliding_predators_32'
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def raster_bytes_per_env(env):
+    """Algorithmic bytes of one frame: H*W*3 written once + per live
+    sprite copy nverts*2*4 B int vertices + 4 B RGBA, averaged over the batch."""
+    import torch
+    from moog import _abi
+    P = env.compiled.program
+    ncopy = 9 if P.render.polymod == _abi.MOOG_POLYMOD_TORUS else 1
+    alive = env.field('alive')
+    nv = env.field('nverts').to(torch.float64)
+    per_env = ((nv * 8 + 4) * alive.to(torch.float64)).sum(dim=1) * ncopy
+    return float(P.render.height * P.render.width * 3 + per_env.mean().item())
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Times the CPU oracle (oracle/moog_oracle.c, single thread) on a bounded
+    sample of the same workload: 256 envs stepped until ~seconds_target."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import numpy as np
+    import helpers
+    n = 256
+    c = helpers.compiled(WORKLOAD)
+    o = helpers.OracleEnv(c, n_envs=n, seed=1)
+    o.reset()
+    rs = np.random.RandomState(0)
+    for _ in range(2):
+        o.step(rs.uniform(-1, 1, size=(n, 2)))
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds_target and steps < 400:
+        o.step(rs.uniform(-1, 1, size=(n, 2)))
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {'value': n * steps / dt, 'unit': 'env steps/sec', 'cores': 1, 'kind': 'port',
+            'sample': '%s, %d envs x %d steps (physics + 64x64 raster), single thread, %.1f s'
+                      % (WORKLOAD, n, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--workload', default=WORKLOAD)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from moog import _abi, environment
+    from moog_demos import example_configs
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    n = args.envs_per_gpu
+
+    env = environment.BatchedEnvironment(
+        num_envs=n, device=dev, seed=2024, env_index0=rank * n, **example_configs.load(args.workload))
+    env.check_faults = False
+    env.reset()
+    is_grid = env._is_grid
+
+    def one_step():
+        if is_grid:
+            a = torch.randint(0, 5, (n,), dtype=torch.int32, device=dev)
+        else:
+            a = torch.rand((n, 2), dtype=torch.float64, device=dev) * 2 - 1
+        env.step(a)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    env.set_timing(True)
+    for k in range(_abi.MOOG_K_COUNT):
+        env.kernel_time(k)   # clear
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    env.set_timing(False)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # off the timed path
+    dt_max = float(t.item())
+
+    k_ms = {name: env.kernel_time(kid) for name, kid in
+            (('step', _abi.MOOG_K_STEP), ('raster', _abi.MOOG_K_RASTER), ('reset', _abi.MOOG_K_RESET))}
+    faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
+    if rank == 0:
+        total_steps = n * world * args.steps
+        rb = raster_bytes_per_env(env)
+        r_ms, r_n = k_ms['raster']
+        r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
+        achieved = (n * rb / r_avg_s) / 1e9 if r_avg_s > 0 else 0.0
+        P = env.compiled.program
+        line = {
+            'metric': 'env steps/sec (whole node), 4096 envs x 32 sprites, 64x64 obs',
+            'value': total_steps / dt_max,
+            'unit': 'env steps/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt_max / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': '%s: %d envs/GPU x %d sprites, K=%d substeps, %dx%d raster, '
+                                   'random joystick actions, auto-reset on' % (
+                                       args.workload, n, P.n_slots, P.updates_per_env_step,
+                                       P.render.height, P.render.width),
+                       'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
+                       'parallelism': 'env-sharded x%d, no collective' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'kernel': 'moog_raster_kernel', 'avg_kernel_us': r_avg_s * 1e6,
+                         'algorithmic_bytes_per_env': rb},
+            'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items()},
+            'faulted_envs': faults,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

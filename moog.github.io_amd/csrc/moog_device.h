@@ -1,0 +1,1146 @@
+// moog_device.h -- device-side MOOG step logic for gfx950 (CDNA4).
+//
+// Execution model: ONE WAVEFRONT (64 lanes) OWNS ONE ENV.  The env's whole state
+// record (include/moog_engine.h layout) is staged in LDS; the reference's
+// sequential, order-dependent pair loop (physics.py:103-108) is kept as a
+// wave-uniform scalar loop, and the lanes parallelise *inside* each step:
+//   - broad phase: lanes = candidate partner sprites, __ballot -> candidate mask
+//   - Path.intersects_path: lanes = segment pairs / vertices, __ballot any/all
+//   - contact search: lanes = contained vertices (rows of the crossing matrix),
+//     argmin per lane, numpy-ordered argmax by lane scan
+//   - path translate / rotate: lanes = vertices
+// No MFMA: the work is O(S^2) geometry with data-dependent branches.
+// All arithmetic is IEEE fp64 without contraction (-ffp-contract=off) so that
+// discrete decisions (argmin/argmax, >, isclose) match numpy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moog_engine.h"
+
+#define EPS_INTERP 1e-8  // sprite.py:35
+#define EPS_COLL 1e-2    // collisions.py:46
+#define MOOG_F_TMP 0x100 // scratch flag bit (vanish marks)
+#define DINF (__builtin_inf())
+
+struct Env {
+  double* f;               // LDS f64 record
+  int32_t* q;              // LDS i32 record
+  const moog_program_t* P; // global
+  moog_layout_t L;
+  const double* inj;
+  int inj_n;
+  uint64_t seed;
+  int64_t env_index;
+  int lane;
+};
+
+#define PX(s) (e.f[e.L.o_pos + 2 * (s)])
+#define PY(s) (e.f[e.L.o_pos + 2 * (s) + 1])
+#define VELX(s) (e.f[e.L.o_vel + 2 * (s)])
+#define VELY(s) (e.f[e.L.o_vel + 2 * (s) + 1])
+#define ANG(s) (e.f[e.L.o_angle + (s)])
+#define ANGV(s) (e.f[e.L.o_angvel + (s)])
+#define MASS(s) (e.f[e.L.o_mass + (s)])
+#define COL(s, c) (e.f[e.L.o_color + 3 * (s) + (c)])
+#define INER(s, c) (e.f[e.L.o_inertia + 2 * (s) + (c)])
+#define MAXR(s) (e.f[e.L.o_maxr + (s)])
+#define FLAGS(s) (e.q[e.L.o_flags + (s)])
+#define NV(s) (e.q[e.L.o_nverts + (s)])
+#define OPAC(s) (e.q[e.L.o_opacity + (s)])
+#define SHAPEID(s) (e.q[e.L.o_shape + (s)])
+#define TELE(s) (e.q[e.L.o_tele + (s)])
+#define VERT(s) (&e.f[e.L.o_verts + 2 * e.P->slot_voff[s]])
+#define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
+
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Single-wave workgroup: LDS operations of one wave execute in order, so
+// cross-lane visibility only needs the compiler/waitcnt fence.
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double f32r(double x) { return (double)(float)x; }
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
+
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  int lo = __shfl(__double2loint(v), src);
+  int hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- RNG: Philox4x32-10, bit-identical to oracle/moog_oracle.c ---------------
+__device__ inline void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Wave-uniform draw: every lane computes the same value; lane 0 commits the counter.
+__device__ inline double next_uniform(Env& e) {
+  int32_t* r = &e.q[e.L.o_rng];
+  double out;
+  if (e.inj) {
+    int cur = r[2];
+    if (cur >= e.inj_n) {
+      wsync();
+      if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+      wsync();
+      return 0.0;
+    }
+    out = e.inj[cur];
+    wsync();
+    if (e.lane == 0) r[2] = cur + 1;
+    wsync();
+    return out;
+  }
+  uint64_t ctr = (uint32_t)r[0] | ((uint64_t)(uint32_t)r[1] << 32);
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)e.env_index,
+                   (uint32_t)((uint64_t)e.env_index >> 32)};
+  philox4x32(c, (uint32_t)e.seed, (uint32_t)(e.seed >> 32));
+  ctr += 1;
+  wsync();
+  if (e.lane == 0) { r[0] = (int32_t)(uint32_t)ctr; r[1] = (int32_t)(uint32_t)(ctr >> 32); }
+  wsync();
+  return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) / 9007199254740992.0;
+}
+
+// ---- matplotlib _path restatements (see oracle for the citations) ------------
+__device__ __forceinline__ bool mpl_isclose(double a, double b) {
+  return fabs(a - b) <= fmax(1e-10 * fmax(fabs(a), fabs(b)), 1e-13);
+}
+
+__device__ inline bool segments_intersect(double x1, double y1, double x2, double y2, double x3,
+                                          double y3, double x4, double y4) {
+  double den = ((y4 - y3) * (x2 - x1)) - ((x4 - x3) * (y2 - y1));
+  if (mpl_isclose(den, 0.0)) {
+    double t_area = (x2 * y3 - x3 * y2) - x1 * (y3 - y2) + y1 * (x3 - x2);
+    if (mpl_isclose(t_area, 0.0)) {
+      if (x1 == x2 && x2 == x3) {
+        return (fmin(y1, y2) <= fmin(y3, y4) && fmin(y3, y4) <= fmax(y1, y2)) ||
+               (fmin(y3, y4) <= fmin(y1, y2) && fmin(y1, y2) <= fmax(y3, y4));
+      }
+      return (fmin(x1, x2) <= fmin(x3, x4) && fmin(x3, x4) <= fmax(x1, x2)) ||
+             (fmin(x3, x4) <= fmin(x1, x2) && fmin(x1, x2) <= fmax(x3, x4));
+    }
+    return false;
+  }
+  double n1 = ((x4 - x3) * (y1 - y3)) - ((y4 - y3) * (x1 - x3));
+  double n2 = ((x2 - x1) * (y1 - y3)) - ((y2 - y1) * (x1 - x3));
+  double u1 = n1 / den, u2 = n2 / den;
+  return (u1 > 0.0 || mpl_isclose(u1, 0.0)) && (u1 < 1.0 || mpl_isclose(u1, 1.0)) &&
+         (u2 > 0.0 || mpl_isclose(u2, 0.0)) && (u2 < 1.0 || mpl_isclose(u2, 1.0));
+}
+
+// even-odd crossing test, one lane, polygon vertices in LDS
+__device__ inline bool point_in_poly(const double* v, int n, double tx, double ty) {
+  if (!(isfinite(tx) && isfinite(ty))) return false;
+  int inside = 0;
+  double x0 = v[0], y0 = v[1];
+  for (int i = 0; i < n; ++i) {
+    int j = (i + 1 == n) ? 0 : i + 1;
+    double x1 = v[2 * j], y1 = v[2 * j + 1];
+    int f0 = (y0 >= ty), f1 = (y1 >= ty);
+    if (f0 != f1) {
+      if (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == (bool)f1) inside ^= 1;
+    }
+    x0 = x1; y0 = y1;
+  }
+  return inside != 0;
+}
+
+// Path.intersects_path(a, b, filled=True); lanes = segment pairs, then vertices.
+// Wave-uniform result.
+__device__ inline bool paths_intersect_filled(const Env& e, const double* va, int na,
+                                              const double* vb, int nb) {
+  int total = na * nb;
+  for (int base = 0; base < total; base += 64) {
+    int idx = base + e.lane;
+    bool hit = false;
+    if (idx < total) {
+      int i = idx / nb, j = idx - i * nb;
+      int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
+      double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
+      double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
+      bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
+      bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
+      if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
+    }
+    if (__ballot(hit) != 0ull) return true;
+  }
+  if (na + 1 >= 3 && nb > 0) {
+    bool out = false;
+    if (e.lane < nb) out = !point_in_poly(va, na, vb[2 * e.lane], vb[2 * e.lane + 1]);
+    if (__ballot(out) == 0ull) return true;
+  }
+  if (nb + 1 >= 3 && na > 0) {
+    bool out = false;
+    if (e.lane < na) out = !point_in_poly(vb, nb, va[2 * e.lane], va[2 * e.lane + 1]);
+    if (__ballot(out) == 0ull) return true;
+  }
+  return false;
+}
+
+// sprite.py:462-484
+__device__ inline bool overlaps(const Env& e, int s0, int s1) {
+  double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
+  if (norm2(dx, dy) > MAXR(s0) + MAXR(s1)) return false;
+  return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1));
+}
+
+// sprite.py:442-460 (one point, one lane)
+__device__ inline bool contains_points1(const Env& e, int s, double x, double y) {
+  if (FLAGS(s) & MOOG_F_SYM_CIRCLE) return norm2(x - PX(s), y - PY(s)) <= MAXR(s);
+  return point_in_poly(VERT(s), NV(s), x, y);
+}
+// sprite.py:432-440
+__device__ inline bool contains_point(const Env& e, int s, double x, double y) {
+  if (FLAGS(s) & MOOG_F_SYM_CIRCLE) return norm2(x - PX(s), y - PY(s)) < MAXR(s);
+  return point_in_poly(VERT(s), NV(s), x, y);
+}
+
+// sprite.py:616-633 position setter; lanes = vertices
+__device__ inline void set_position(Env& e, int s, double nx, double ny) {
+  double dx = nx - PX(s), dy = ny - PY(s);
+  double* v = VERT(s);
+  int n = NV(s);
+  wsync();
+  if (e.lane < n) {
+    v[2 * e.lane] = v[2 * e.lane] + dx;
+    v[2 * e.lane + 1] = v[2 * e.lane + 1] + dy;
+  }
+  if (e.lane == 0) { PX(s) = nx; PY(s) = ny; }
+  wsync();
+}
+
+// sprite.py:531-540 angle setter (matplotlib rotate_around); lanes = vertices
+__device__ inline void rotate_path(Env& e, int s, double d_theta) {
+  double a = cos(d_theta), b = sin(d_theta);
+  double x = PX(s), y = PY(s);
+  double tx = (a * (-x) - b * (-y)) + x;
+  double ty = (b * (-x) + a * (-y)) + y;
+  double* v = VERT(s);
+  int n = NV(s);
+  wsync();
+  if (e.lane < n) {
+    double vx = v[2 * e.lane], vy = v[2 * e.lane + 1];
+    v[2 * e.lane] = (a * vx + (-b) * vy) + tx;
+    v[2 * e.lane + 1] = (b * vx + a * vy) + ty;
+  }
+  wsync();
+}
+
+// sprite.py:426-430 with the reference's float32 propagation (see oracle)
+__device__ inline void update_pos_from_vel(Env& e, int s, double dt) {
+  double dx, dy;
+  int fl = FLAGS(s);
+  if (fl & MOOG_F_VEL_F32) {
+    float dtf = (float)dt;
+    dx = (double)(dtf * (float)VELX(s));
+    dy = (double)(dtf * (float)VELY(s));
+  } else {
+    dx = dt * VELX(s);
+    dy = dt * VELY(s);
+  }
+  set_position(e, s, PX(s) + dx, PY(s) + dy);
+  double w = ANGV(s);
+  if (w != 0.0) {
+    if (fl & MOOG_F_ANGVEL_F32) {
+      float t = (float)dt * (float)w;
+      float a_old = (float)ANG(s);
+      float a_new = a_old + t;
+      float d = a_new - a_old;
+      rotate_path(e, s, (double)d);
+      if (e.lane == 0) ANG(s) = (double)a_new;
+    } else {
+      double a_old = ANG(s);
+      double a_new = a_old + dt * w;
+      rotate_path(e, s, a_new - a_old);
+      if (e.lane == 0) ANG(s) = a_new;
+    }
+    wsync();
+  }
+}
+
+__device__ inline void vel_iadd(Env& e, int s, double dx, double dy) {
+  double vx = VELX(s), vy = VELY(s);
+  if (FLAGS(s) & MOOG_F_VEL_F32) { vx = f32r(vx + dx); vy = f32r(vy + dy); }
+  else { vx = vx + dx; vy = vy + dy; }
+  wsync();
+  if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
+  wsync();
+}
+
+__device__ inline void angvel_iadd(Env& e, int s, double dw) {
+  double w = ANGV(s);
+  if (FLAGS(s) & MOOG_F_ANGVEL_F32) w = f32r(w + dw);
+  else w = w + dw;
+  wsync();
+  if (e.lane == 0) ANGV(s) = w;
+  wsync();
+}
+
+// ---- collisions -----------------------------------------------------------------
+enum { CV_NONE = 0, CV_OK = 1, CV_FUTURE = 2 };
+struct CVec { int status; double px, py, nx, ny, sx, sy, qx, qy; };
+
+__device__ inline void compose(double o[6], const double s[6], const double f[6]) {
+  double r0 = s[0] * f[0] + s[1] * f[3];
+  double r1 = s[0] * f[1] + s[1] * f[4];
+  double r2 = (s[0] * f[2] + s[1] * f[5]) + s[2];
+  double r3 = s[3] * f[0] + s[4] * f[3];
+  double r4 = s[3] * f[1] + s[4] * f[4];
+  double r5 = (s[3] * f[2] + s[4] * f[5]) + s[5];
+  o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5;
+}
+__device__ inline void rot_around(double m[6], double x, double y, double th) {
+  double a = cos(th), b = sin(th);
+  m[0] = a; m[1] = -b; m[2] = (a * (-x) - b * (-y)) + x;
+  m[3] = b; m[4] = a; m[5] = (b * (-x) + a * (-y)) + y;
+}
+
+// collisions.py:62-98
+__device__ inline void relative_motion_matrix(const Env& e, int ps, int as, double dt, double m[6]) {
+  double th0, tx0, ty0, th1, tx1, ty1;
+  float dtf = (float)dt;
+  int fp = FLAGS(ps), fa = FLAGS(as);
+  if (fp & MOOG_F_ANGVEL_F32) th0 = (double)((float)(-ANGV(ps)) * dtf);
+  else th0 = (-1 * ANGV(ps)) * dt;
+  if (fp & MOOG_F_VEL_F32) {
+    tx0 = (double)((float)(-VELX(ps)) * dtf); ty0 = (double)((float)(-VELY(ps)) * dtf);
+  } else { tx0 = (-1 * VELX(ps)) * dt; ty0 = (-1 * VELY(ps)) * dt; }
+  if (fa & MOOG_F_ANGVEL_F32) th1 = (double)((float)ANGV(as) * dtf);
+  else th1 = ANGV(as) * dt;
+  if (fa & MOOG_F_VEL_F32) {
+    tx1 = (double)((float)VELX(as) * dtf); ty1 = (double)((float)VELY(as) * dtf);
+  } else { tx1 = VELX(as) * dt; ty1 = VELY(as) * dt; }
+  double A[6], B[6] = {1, 0, tx0, 0, 1, ty0}, C[6], D[6] = {1, 0, tx1, 0, 1, ty1};
+  rot_around(A, PX(ps), PY(ps), th0);
+  rot_around(C, PX(as), PY(as), th1);
+  compose(m, B, A);
+  compose(m, C, m);
+  compose(m, D, m);
+}
+
+// collisions.py:101-232.  Lane i < n0 owns vertex i of s0 (a row of the
+// crossing-coefficient matrix when contained in s1).
+__device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, double dt, CVec& out) {
+  out.status = CV_NONE;
+  const double* v0 = VERT(s0);
+  const double* v1 = VERT(s1);
+  int n0 = NV(s0), n1 = NV(s1);
+  double cx = 0, cy = 0;
+  bool contained = false;
+  if (e.lane < n0) {
+    cx = v0[2 * e.lane]; cy = v0[2 * e.lane + 1];
+    contained = contains_points1(e, s1, cx, cy);
+  }
+  uint64_t cmask = __ballot(contained);
+  if (cmask == 0ull) return;
+  double m[6];
+  relative_motion_matrix(e, s0, s1, dt, m);
+  double pvx = (m[0] * cx + m[1] * cy) + m[2];
+  double pvy = (m[3] * cx + m[4] * cy) + m[5];
+  double ds0x = cx - pvx, ds0y = cy - pvy;
+  // row scan: np.argmin(|1 - cross_a|) with non-crossings at -inf (first index, NaN wins)
+  bool rowany = false, nanfound = false;
+  int best = 0;
+  double bestabs = 0, bestca = 0;
+  if (contained) {
+    for (int j = 0; j < n1; ++j) {
+      int j2 = (j + 1 == n1) ? 0 : j + 1;
+      double ds1x = v1[2 * j2] - v1[2 * j], ds1y = v1[2 * j2 + 1] - v1[2 * j + 1];
+      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
+      double mx = v1[2 * j] - pvx, my = v1[2 * j + 1] - pvy;
+      double A = (mx * ds1y - my * ds1x) / den;
+      double B = (mx * ds0y - my * ds0x) / den;
+      bool crossing = (B >= 0) && (B <= 1);
+      rowany |= crossing;
+      double ca = crossing ? A : -DINF;
+      double ab = fabs(1. - ca);
+      if (j == 0) { bestabs = ab; bestca = ca; nanfound = isnan(ab); }
+      else if (!nanfound) {
+        if (isnan(ab)) { best = j; bestabs = ab; bestca = ca; nanfound = true; }
+        else if (ab < bestabs) { best = j; bestabs = ab; bestca = ca; }
+      }
+    }
+  }
+  if (__ballot(rowany) == 0ull) return;
+  double cpx = pvx + bestca * (cx - pvx), cpy = pvy + bestca * (cy - pvy);
+  double dfx = cx - cpx, dfy = cy - cpy;
+  double dist = norm2(dfx, dfy);
+  if (dist == DINF) dist = 0;
+  // np.argmax over contained rows in vertex order (first max, NaN wins)
+  int ci = -1;
+  double bv = 0;
+  bool cnan = false;
+  uint64_t mm = cmask;
+  while (mm) {
+    int l = __ffsll((long long)mm) - 1;
+    mm &= mm - 1;
+    double d = shfl_d(dist, l);
+    if (ci < 0) { ci = l; bv = d; cnan = isnan(d); }
+    else if (!cnan) {
+      if (isnan(d)) { ci = l; cnan = true; }
+      else if (d > bv) { ci = l; bv = d; }
+    }
+  }
+  int e1 = __shfl(best, ci);
+  double ca = shfl_d(bestca, ci);
+  out.px = shfl_d(cpx, ci); out.py = shfl_d(cpy, ci);
+  out.sx = shfl_d(dfx, ci); out.sy = shfl_d(dfy, ci);
+  out.nx = out.ny = out.qx = out.qy = 0;
+  if (ca > 1) { out.status = CV_FUTURE; return; }
+  int e2 = (e1 + 1 == n1) ? 0 : e1 + 1;
+  double dvx = v1[2 * e2] - v1[2 * e1], dvy = v1[2 * e2 + 1] - v1[2 * e1 + 1];
+  double nx = dvy, ny = -1 * dvx;
+  double nn = sqrt(nx * nx + ny * ny);
+  out.nx = nx / nn; out.ny = ny / nn;
+  double sc = (out.sx * dvx + out.sy * dvy) / (dvx * dvx + dvy * dvy);
+  out.qx = out.sx - dvx * sc;
+  out.qy = out.sy - dvy * sc;
+  out.status = CV_OK;
+}
+
+// collisions.py:235-289
+__device__ inline void get_collision_vectors(const Env& e, int s0, int s1, double dt, CVec& out) {
+  CVec r0, r1;
+  directed_collision_vectors(e, s1, s0, dt, r0);
+  directed_collision_vectors(e, s0, s1, dt, r1);
+  double a0x = 0, a0y = 0, a1x = 0, a1y = 0;
+  if (r0.status != CV_NONE) {
+    r0.nx = -1. * r0.nx; r0.ny = -1. * r0.ny;
+    r0.sx = -1. * r0.sx; r0.sy = -1. * r0.sy;
+    a0x = r0.sx; a0y = r0.sy;
+  }
+  if (r1.status != CV_NONE) { a1x = r1.sx; a1y = r1.sy; }
+  if (norm2(a0x, a0y) > norm2(a1x, a1y)) out = r0;
+  else out = r1;
+}
+
+// collisions.py:292-350
+__device__ inline void collide_without_update_angle_vel(Env& e, int s0, int s1, const CVec& c,
+                                                        double elasticity, int symmetric) {
+  double nx = c.nx, ny = c.ny;
+  double nn = sqrt(nx * nx + ny * ny);
+  if (!(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.)) {
+    wsync();
+    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    wsync();
+    return;
+  }
+  double m0 = MASS(s0), m1 = MASS(s1);
+  double d0 = VELX(s0) * nx + VELY(s0) * ny;
+  double d1 = VELX(s1) * nx + VELY(s1) * ny;
+  double v0nx = d0 * nx, v0ny = d0 * ny, v1nx = d1 * nx, v1ny = d1 * ny;
+  double cmx, cmy;
+  if (symmetric) {
+    cmx = (v0nx * m0 + v1nx * m1) / (m0 + m1);
+    cmy = (v0ny * m0 + v1ny * m1) / (m0 + m1);
+  } else { cmx = v1nx; cmy = v1ny; }
+  double f = 1 + elasticity;
+  double a0 = f * (cmx - v0nx), a1 = f * (cmy - v0ny), b0 = f * (cmx - v1nx), b1 = f * (cmy - v1ny);
+  vel_iadd(e, s0, a0, a1);
+  vel_iadd(e, s1, b0, b1);
+}
+
+// collisions.py:353-454
+__device__ inline void collide_with_update_angle_vel(Env& e, int s0, int s1, const CVec& c,
+                                                     double elasticity, int symmetric) {
+  double nx = c.nx, ny = c.ny;
+  double m0 = MASS(s0), m1 = MASS(s1), w0 = ANGV(s0), w1 = ANGV(s1);
+  double i0 = (0 + m0 * INER(s0, 0)) + m0 * INER(s0, 1);
+  double i1 = (0 + m1 * INER(s1, 0)) + m1 * INER(s1, 1);
+  double v0 = VELX(s0) * nx + VELY(s0) * ny;
+  double v1 = VELX(s1) * nx + VELY(s1) * ny;
+  double c0x = c.px - PX(s0), c0y = c.py - PY(s0);
+  double c1x = c.px - PX(s1), c1y = c.py - PY(s1);
+  double r0 = sqrt(c0x * c0x + c0y * c0y), r1 = sqrt(c1x * c1x + c1y * c1y);
+  double sin0 = (c0x * ny - c0y * nx) / r0, sin1 = (c1x * ny - c1y * nx) / r1;
+  double S0 = r0 * sin0, S1 = r1 * sin1;
+  double a = m0 + m1 + m0 * m1 * ((S0 * S0 / i0) + (S1 * S1 / i1));
+  double b = (1 + elasticity) * (v0 - v1 + w0 * S0 - w1 * S1);
+  double dv0, dv1;
+  if (symmetric) { dv0 = -1 * m1 * b / a; dv1 = m0 * b / a; }
+  else { dv0 = -1 * m1 * b / (a - m0); dv1 = 0.; }
+  double dw0 = m0 * dv0 * S0 / i0, dw1 = m1 * dv1 * S1 / i1;
+  vel_iadd(e, s0, dv0 * nx, dv0 * ny);
+  vel_iadd(e, s1, dv1 * nx, dv1 * ny);
+  angvel_iadd(e, s0, dw0);
+  angvel_iadd(e, s1, dw1);
+}
+
+// collisions.py:658-748 _position_correction, given the crossing point closest
+// to sA's centre (p0), its edge index on sA (fwd) and on sB (b0).  Wave-uniform.
+__device__ inline void position_correction(const Env& e, double p0x, double p0y, int sA, int fwd,
+                                           int sB, int b0, double out[2]) {
+  const double* va = VERT(sA);
+  const double* vb = VERT(sB);
+  int nA = NV(sA), nB = NV(sB);
+  int b1 = ((b0 - 1) % nB + nB) % nB;
+  double q0x = vb[2 * b1], q0y = vb[2 * b1 + 1];
+  double bx = vb[2 * b0] - q0x, by = vb[2 * b0 + 1] - q0y;
+  double bn = sqrt(bx * bx + by * by);
+  bx /= bn; by /= bn;
+  double sg = (PX(sB) - q0x) * bx + (PY(sB) - q0y) * by;
+  double sgn = isnan(sg) ? sg : (sg > 0 ? 1. : (sg < 0 ? -1. : 0.));
+  double nvx = bx * -1 * sgn, nvy = by * -1 * sgn;
+  int bwd = ((fwd - 1) % nA + nA) % nA;
+  int parity, curi;
+  if ((va[2 * fwd] - p0x) * nvx + (va[2 * fwd + 1] - p0y) * nvy > 0) { parity = 1; curi = fwd; }
+  else if ((va[2 * bwd] - p0x) * nvx + (va[2 * bwd + 1] - p0y) * nvy > 0) { parity = -1; curi = bwd; }
+  else { out[0] = DINF; out[1] = DINF; return; }
+  double worst = 0;
+  for (int it = 0; it < 4 * nA; ++it) {
+    double pen = (va[2 * curi] - p0x) * nvx + (va[2 * curi + 1] - p0y) * nvy;
+    if (!(pen > 0)) break;
+    if (pen > worst) worst = pen;
+    curi = ((curi + parity) % nA + nA) % nA;
+  }
+  out[0] = worst * nvx; out[1] = worst * nvy;
+}
+
+// collisions.py:586-655.  Lanes = edge pairs; only the crossing closest to each
+// sprite's centre (lowest row-major index on ties) and the crossing count are needed.
+__device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
+  const double* va = VERT(s0);
+  const double* vb = VERT(s1);
+  int n0 = NV(s0), n1 = NV(s1);
+  int total = n0 * n1;
+  int cnt = 0;
+  double bdA = DINF, bdB = DINF, bxA = 0, byA = 0, bxB = 0, byB = 0;
+  int biA = -1, biB = -1;
+  double ax = PX(s0), ay = PY(s0), bxc = PX(s1), byc = PY(s1);
+  for (int base = 0; base < total; base += 64) {
+    int idx = base + e.lane;
+    if (idx < total) {
+      int i = idx / n1, j = idx - i * n1;
+      int i2 = (i + 1 == n0) ? 0 : i + 1, j2 = (j + 1 == n1) ? 0 : j + 1;
+      double ds0x = va[2 * i2] - va[2 * i], ds0y = va[2 * i2 + 1] - va[2 * i + 1];
+      double ds1x = vb[2 * j2] - vb[2 * j], ds1y = vb[2 * j2 + 1] - vb[2 * j + 1];
+      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
+      double mx = vb[2 * j] - va[2 * i], my = vb[2 * j + 1] - va[2 * i + 1];
+      double A = (mx * ds1y - my * ds1x) / den;
+      double B = (mx * ds0y - my * ds0x) / den;
+      if ((A > 0) && (A < 1) && (B > 0) && (B < 1)) {
+        double cpx = va[2 * i] + A * ds0x, cpy = va[2 * i + 1] + A * ds0y;
+        ++cnt;
+        double dA = norm2(cpx - ax, cpy - ay), dB = norm2(cpx - bxc, cpy - byc);
+        if (biA < 0 || dA < bdA) { bdA = dA; biA = idx; bxA = cpx; byA = cpy; }
+        if (biB < 0 || dB < bdB) { bdB = dB; biB = idx; bxB = cpx; byB = cpy; }
+      }
+    }
+  }
+  // wave reductions: total count; argmin (distance, then index)
+  int tot = cnt;
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if (tot <= 1) return;
+  for (int o = 32; o > 0; o >>= 1) {
+    double od = shfl_d(bdA, e.lane ^ o), ox = shfl_d(bxA, e.lane ^ o), oy = shfl_d(byA, e.lane ^ o);
+    int oi = __shfl_xor(biA, o);
+    bool take = (oi >= 0) && (biA < 0 || od < bdA || (od == bdA && oi < biA));
+    if (take) { bdA = od; biA = oi; bxA = ox; byA = oy; }
+    od = shfl_d(bdB, e.lane ^ o); ox = shfl_d(bxB, e.lane ^ o); oy = shfl_d(byB, e.lane ^ o);
+    oi = __shfl_xor(biB, o);
+    take = (oi >= 0) && (biB < 0 || od < bdB || (od == bdB && oi < biB));
+    if (take) { bdB = od; biB = oi; bxB = ox; byB = oy; }
+  }
+  biA = uni(biA); biB = uni(biB);
+  double c0[2], c1[2];
+  position_correction(e, bxA, byA, s0, biA / n1, s1, biA % n1, c0);
+  position_correction(e, bxB, byB, s1, biB % n1, s0, biB / n1, c1);
+  double cx, cy;
+  if (norm2(c0[0], c0[1]) > norm2(c1[0], c1[1])) {
+    cx = -1 * (1 + EPS_COLL) * c0[0]; cy = -1 * (1 + EPS_COLL) * c0[1];
+  } else {
+    cx = (1 + EPS_COLL) * c0[0]; cy = (1 + EPS_COLL) * c0[1];
+  }
+  if (!(isfinite(cx) && isfinite(cy))) { cx = 0; cy = 0; }
+  if (symmetric) {
+    set_position(e, s0, PX(s0) + 0.5 * cx, PY(s0) + 0.5 * cy);
+    set_position(e, s1, PX(s1) - 0.5 * cx, PY(s1) - 0.5 * cy);
+  } else {
+    set_position(e, s0, PX(s0) + cx, PY(s0) + cy);
+  }
+}
+
+// collisions.py:494-584.  Returns true when the pair overlapped (state may have moved).
+__device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int s1, int K) {
+  int symmetric = F->symmetric, upd = F->i0, maxdepth = F->i1;
+  bool touched = false;
+  for (int depth = 0; depth <= maxdepth; ++depth) {
+    if (s0 == s1) return touched;
+    if (!overlaps(e, s0, s1)) return touched;
+    touched = true;
+    double dt = 1. / K;
+    CVec c;
+    get_collision_vectors(e, s0, s1, dt, c);
+    if (c.status == CV_NONE) {
+      make_disjoint(e, s0, s1, symmetric);
+    } else if (c.status == CV_FUTURE) {
+      return touched;
+    } else {
+      if (symmetric) {
+        set_position(e, s0, PX(s0) - (0.5 + EPS_COLL) * c.qx, PY(s0) - (0.5 + EPS_COLL) * c.qy);
+        set_position(e, s1, PX(s1) + (0.5 + EPS_COLL) * c.qx, PY(s1) + (0.5 + EPS_COLL) * c.qy);
+      } else {
+        set_position(e, s0, PX(s0) - (1. + EPS_COLL) * c.qx, PY(s0) - (1. + EPS_COLL) * c.qy);
+      }
+      if (upd) collide_with_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
+      else collide_without_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
+    }
+  }
+  return touched;
+}
+
+// ---- Newtonian forces --------------------------------------------------------------
+__device__ inline void newton_apply(Env& e, int s, double fx, double fy, int K) {
+  double m = MASS(s);
+  if (!isfinite(m)) return;
+  double den = m * (double)K;
+  vel_iadd(e, s, fx / den, fy / den);
+}
+
+__device__ inline void force_single(Env& e, const moog_force_t* F, int s, int K) {
+  switch (F->kind) {
+    case MOOG_FORCE_DRAG: {
+      double m = MASS(s);
+      if (FLAGS(s) & MOOG_F_VEL_F32) {
+        if (!isfinite(m)) return;
+        float c = (float)(-1 * F->p0), mf = (float)m, den = (float)(m * (double)K);
+        float fx = (c * (float)VELX(s)) * mf, fy = (c * (float)VELY(s)) * mf;
+        double vx = (double)((float)VELX(s) + fx / den);
+        double vy = (double)((float)VELY(s) + fy / den);
+        wsync();
+        if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
+        wsync();
+      } else {
+        double c = -1 * F->p0;
+        newton_apply(e, s, (c * VELX(s)) * m, (c * VELY(s)) * m, K);
+      }
+      break;
+    }
+    case MOOG_FORCE_KINETIC_FRICTION: {
+      double vn = sqrt(VELX(s) * VELX(s) + VELY(s) * VELY(s));
+      double nx = 0, ny = 0;
+      if (vn != 0) { nx = VELX(s) / vn; ny = VELY(s) / vn; }
+      double c = -1 * F->p0;
+      newton_apply(e, s, (c * nx) * MASS(s), (c * ny) * MASS(s), K);
+      break;
+    }
+    case MOOG_FORCE_DOWN_GRAVITY: {
+      double gm = F->p0 * MASS(s);
+      newton_apply(e, s, gm * 0, gm * 1, K);
+      break;
+    }
+    case MOOG_FORCE_RANDOM: {
+      double r = 0 + (F->p0 - 0) * next_uniform(e);
+      double th = 0 + (2 * 3.14159265358979323846 - 0) * next_uniform(e);
+      newton_apply(e, s, r * cos(th), r * sin(th), K);
+      break;
+    }
+    default: break;
+  }
+}
+
+__device__ inline void force_pair_newton(Env& e, const moog_force_t* F, int s0, int s1, int K) {
+  double dx = PX(s1) - PX(s0), dy = PY(s1) - PY(s0);
+  double dist = sqrt(dx * dx + dy * dy);
+  double f0x = 0, f0y = 0, f1x = 0, f1y = 0;
+  if (dist != 0.) {
+    double ux = dx / dist, uy = dy / dist, mag = 0;
+    if (F->kind == MOOG_FORCE_GRAVITY) {
+      mag = F->p0 * MASS(s0) * MASS(s1) * dist;
+    } else if (F->kind == MOOG_FORCE_DISTANCE_LINEAR) {
+      double eh = -1. * F->p0 / F->p1;
+      mag = F->p0 + F->p1 * dist;
+      if (!F->i0 && dist > eh) mag = 0;
+      if (!F->i1 && dist < eh) mag = 0;
+    } else if (F->kind == MOOG_FORCE_DISTANCE_SPRING) {
+      mag = -1. * F->p0 * (dist - F->p1);
+    }
+    f1x = mag * ux; f1y = mag * uy;
+    if (F->symmetric) { f0x = -1 * f1x; f0y = -1 * f1y; }
+  }
+  newton_apply(e, s0, f0x, f0y, K);
+  newton_apply(e, s1, f1x, f1y, K);
+}
+
+// constant_speed.py:34-46
+__device__ inline void constant_speed(Env& e, const moog_corrective_t* C) {
+  const moog_program_t* P = e.P;
+  for (int a = 0; a < C->n_layers; ++a) {
+    int l = C->layers[a];
+    int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
+    for (int s = s0; s < s1; ++s) {
+      if (!ALIVE(s)) continue;
+      double ox = VELX(s), oy = VELY(s);
+      bool wr = false;
+      if (FLAGS(s) & MOOG_F_VEL_F32) {
+        float vx = (float)ox, vy = (float)oy;
+        float n = sqrtf(vx * vx + vy * vy);
+        if (n != 0.0f) {
+          float sp = (float)C->speed;
+          ox = (double)((sp * vx) / n); oy = (double)((sp * vy) / n); wr = true;
+        }
+      } else {
+        double n = sqrt(ox * ox + oy * oy);
+        if (n != 0.0) { ox = (C->speed * ox) / n; oy = (C->speed * oy) / n; wr = true; }
+      }
+      wsync();
+      if (wr && e.lane == 0) { VELX(s) = ox; VELY(s) = oy; }
+      wsync();
+    }
+  }
+}
+
+// Collision force over (layer la) x (layer lb): the reference visits ordered pairs
+// (s0, s1) sequentially (physics.py:103-108).  The bounding-circle reject of
+// overlaps_sprite is evaluated for 64 partners at once; only surviving partners
+// run the narrow phase, in index order; the mask is rebuilt after any pair that
+// overlapped (it may have moved s0).
+__device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a0, int a1, int b0,
+                                            int b1, int K) {
+  for (int s0 = a0; s0 < a1; ++s0) {
+    if (!ALIVE(s0)) continue;
+    for (int cb = b0; cb < b1; cb += 64) {
+      int cursor = cb;
+      int cend = (cb + 64 < b1) ? cb + 64 : b1;
+      while (cursor < cend) {
+        int s1 = cb + e.lane;
+        bool cand = false;
+        if (s1 >= cursor && s1 < cend && s1 != s0 && ALIVE(s1)) {
+          double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
+          cand = !(norm2(dx, dy) > MAXR(s0) + MAXR(s1));
+        }
+        uint64_t mask = __ballot(cand);
+        bool rebuilt = false;
+        while (mask) {
+          int l = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          int t = cb + l;
+          cursor = t + 1;
+          if (collision_step(e, F, s0, t, K)) { rebuilt = true; break; }
+        }
+        if (!rebuilt) cursor = cend;
+      }
+    }
+  }
+}
+
+// physics.py:88-117 (one substep)
+__device__ inline void apply_physics(Env& e) {
+  const moog_program_t* P = e.P;
+  int K = P->updates_per_env_step;
+  for (int fi = 0; fi < P->n_forces; ++fi) {
+    const moog_force_t* F = &P->forces[fi];
+    for (int a = 0; a < F->n_a; ++a) {
+      int la = F->layers_a[a];
+      int a0 = P->layer_slot0[la], a1 = a0 + P->layer_nslots[la];
+      if (F->n_b == 0) {
+        for (int s = a0; s < a1; ++s)
+          if (ALIVE(s)) force_single(e, F, s, K);
+      } else {
+        for (int b = 0; b < F->n_b; ++b) {
+          int lb = F->layers_b[b];
+          int b0 = P->layer_slot0[lb], b1 = b0 + P->layer_nslots[lb];
+          if (F->kind == MOOG_FORCE_COLLISION) {
+            collision_layer_pair(e, F, a0, a1, b0, b1, K);
+          } else {
+            for (int s0 = a0; s0 < a1; ++s0) {
+              if (!ALIVE(s0)) continue;
+              for (int s1 = b0; s1 < b1; ++s1)
+                if (ALIVE(s1)) force_pair_newton(e, F, s0, s1, K);
+            }
+          }
+        }
+      }
+    }
+  }
+  for (int c = 0; c < P->n_corrective; ++c) constant_speed(e, &P->corrective[c]);
+  double dt = 1. / K;
+  for (int s = 0; s < P->n_slots; ++s)
+    if (ALIVE(s)) update_pos_from_vel(e, s, dt);
+}
+
+// ---- game rules ------------------------------------------------------------------------
+__device__ inline double np_remainder1(double a) {
+  double m = fmod(a, 1.0);
+  if (m != 0) { if (m < 0) m += 1.0; }
+  else m = 0.0;
+  return m;
+}
+
+__device__ inline void rule_step(Env& e, int ri) {
+  const moog_program_t* P = e.P;
+  const moog_rule_t* R = &P->rules[ri];
+  switch (R->kind) {
+    case MOOG_RULE_VANISH_ON_CONTACT: {
+      int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      int b0 = P->layer_slot0[R->l1], b1 = b0 + P->layer_nslots[R->l1];
+      for (int s = a0; s < a1; ++s) {
+        if (!ALIVE(s)) continue;
+        bool kill = false;
+        for (int t = b0; t < b1; ++t)
+          if (ALIVE(t) && overlaps(e, s, t)) kill = true;
+        if (kill) {
+          wsync();
+          if (e.lane == 0) FLAGS(s) |= MOOG_F_TMP;
+          wsync();
+        }
+      }
+      wsync();
+      for (int s = a0 + e.lane; s < a1; s += 64)
+        if (FLAGS(s) & MOOG_F_TMP) FLAGS(s) &= ~(MOOG_F_TMP | MOOG_F_ALIVE);
+      wsync();
+      break;
+    }
+    case MOOG_RULE_TORUS_WRAP: {
+      for (int a = 0; a < R->n_layers; ++a) {
+        int l = R->layers[a];
+        int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
+        for (int s = s0; s < s1; ++s)
+          if (ALIVE(s)) set_position(e, s, np_remainder1(PX(s)), np_remainder1(PY(s)));
+      }
+      break;
+    }
+    case MOOG_RULE_PORTAL: {
+      int p0 = P->layer_slot0[R->l1], p1 = p0 + P->layer_nslots[R->l1];
+      int np_ = 0;
+      for (int s = p0; s < p1; ++s) if (ALIVE(s)) ++np_;
+      if (np_ % 2 != 0) {
+        wsync();
+        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_ODD_PORTALS;
+        wsync();
+        break;
+      }
+      int t0 = P->layer_slot0[R->l0], t1 = t0 + P->layer_nslots[R->l0];
+      for (int s = t0; s < t1; ++s) {
+        if (!ALIVE(s)) continue;
+        int entry = -1, k = 0, entry_slot = -1;
+        for (int p = p0; p < p1; ++p) {
+          if (!ALIVE(p)) continue;
+          if (entry < 0 && contains_point(e, p, PX(s), PY(s))) { entry = k; entry_slot = p; }
+          ++k;
+        }
+        (void)entry_slot;
+        int tele = TELE(s);
+        if (entry < 0) {
+          wsync();
+          if (e.lane == 0) TELE(s) = tele & ~(1 << ri);
+          wsync();
+          continue;
+        }
+        if (tele & (1 << ri)) continue;
+        int ex = (entry % 2) ? entry - 1 : entry + 1;
+        int exs = -1;
+        k = 0;
+        for (int p = p0; p < p1; ++p) {
+          if (!ALIVE(p)) continue;
+          if (k == ex) exs = p;
+          ++k;
+        }
+        set_position(e, s, PX(exs), PY(exs));
+        if (e.lane == 0) TELE(s) = tele | (1 << ri);
+        wsync();
+      }
+      break;
+    }
+    case MOOG_RULE_BOOSTER: {
+      double cnt = e.f[e.L.o_rule + ri] - 1;
+      int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      int agent = -1;
+      for (int s = a0; s < a1 && agent < 0; ++s) if (ALIVE(s)) agent = s;
+      if (agent >= 0) {
+        if (cnt == DINF) {
+          int b0 = P->layer_slot0[R->l1], b1 = b0 + P->layer_nslots[R->l1];
+          bool any = false;
+          for (int t = b0; t < b1; ++t)
+            if (ALIVE(t) && overlaps(e, agent, t)) any = true;
+          if (any) {
+            double m = MASS(agent) * R->p0;
+            double c2 = 1. - (1. - COL(agent, 2)) * R->p1;
+            wsync();
+            if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+            cnt = R->p2;
+          }
+        } else if (cnt <= 0) {
+          double m = MASS(agent) / R->p0;
+          double c2 = 1. - (1. - COL(agent, 2)) / R->p1;
+          wsync();
+          if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+          cnt = DINF;
+        }
+      }
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_rule + ri] = cnt;
+      wsync();
+      break;
+    }
+    default: break;
+  }
+}
+
+__device__ inline void rule_reset(Env& e, int ri) {
+  const moog_rule_t* R = &e.P->rules[ri];
+  wsync();
+  if (R->kind == MOOG_RULE_PORTAL)
+    for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
+  if (e.lane == 0) e.f[e.L.o_rule + ri] = DINF;
+  wsync();
+}
+
+// ---- tasks ---------------------------------------------------------------------------------
+__device__ inline bool task_condition(const Env& e, const moog_task_t* T) {
+  const moog_program_t* P = e.P;
+  int l = T->cond_layer;
+  int a0 = P->layer_slot0[l], a1 = a0 + P->layer_nslots[l];
+  if (T->cond == MOOG_COND_LAYER_EMPTY) {
+    for (int s = a0; s < a1; ++s) if (ALIVE(s)) return false;
+    return true;
+  }
+  if (T->cond == MOOG_COND_ALL_Y_LT) {
+    for (int s = a0; s < a1; ++s) if (ALIVE(s) && !(PY(s) < T->cond_value)) return false;
+    return true;
+  }
+  return false;
+}
+
+__device__ inline double task_reward(Env& e, int step_count, int* should_reset) {
+  const moog_program_t* P = e.P;
+  double reward = 0;
+  int sr = ((double)step_count >= P->timeout_steps);
+  for (int ti = 0; ti < P->n_tasks; ++ti) {
+    const moog_task_t* T = &P->tasks[ti];
+    double cnt = e.f[e.L.o_task + ti];
+    double r = 0;
+    int tsr = 0;
+    if (T->kind == MOOG_TASK_CONTACT_REWARD) {
+      for (int a = 0; a < T->n0; ++a) {
+        int la = T->layers0[a];
+        int a0 = P->layer_slot0[la], a1 = a0 + P->layer_nslots[la];
+        for (int s0 = a0; s0 < a1; ++s0) {
+          if (!ALIVE(s0)) continue;
+          for (int b = 0; b < T->n1; ++b) {
+            int lb = T->layers1[b];
+            int b0 = P->layer_slot0[lb], b1 = b0 + P->layer_nslots[lb];
+            for (int s1 = b0; s1 < b1; ++s1) {
+              if (!ALIVE(s1)) continue;
+              if (overlaps(e, s0, s1)) {
+                r = T->p0;
+                if (cnt == DINF) cnt = T->p1;
+              }
+            }
+          }
+        }
+      }
+      cnt -= 1;
+      tsr = (cnt < 0);
+    } else if (T->kind == MOOG_TASK_RESET) {
+      if (cnt == DINF && task_condition(e, T)) { r = T->p0; cnt = T->p1; }
+      else r = 0.;
+      cnt -= 1;
+      tsr = (cnt < 0);
+    } else if (T->kind == MOOG_TASK_STAY_ALIVE) {
+      r = ((step_count + 1) % T->i0 == 0) ? T->p0 : 0;
+    }
+    wsync();
+    if (e.lane == 0) e.f[e.L.o_task + ti] = cnt;
+    wsync();
+    reward += r;
+    sr = sr || tsr;
+  }
+  *should_reset = sr;
+  return reward;
+}
+
+// ---- action spaces ---------------------------------------------------------------------------
+__device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_action) {
+  const moog_program_t* P = e.P;
+  const moog_action_t* A = &P->action;
+  double m0 = e.f[e.L.o_action], m1 = e.f[e.L.o_action + 1];
+  if (A->kind == MOOG_ACTION_JOYSTICK) {
+    double ax = ax_in, ay = A->constrained_lr ? 0. : ay_in;
+    m0 *= A->momentum; m1 *= A->momentum;
+    m0 += A->scaling_factor * ax; m1 += A->scaling_factor * ay;
+  } else {
+    double mx = (grid_action == 0) ? -1. : (grid_action == 1 ? 1. : 0.);
+    double my = (grid_action == 2) ? -1. : (grid_action == 3 ? 1. : 0.);
+    m0 *= A->momentum; m1 *= A->momentum;
+    m0 += mx; m1 += my;
+  }
+  double sc = A->scaling_factor;
+  if (m0 < -sc) m0 = -sc;
+  if (m0 > sc) m0 = sc;
+  if (m1 < -sc) m1 = -sc;
+  if (m1 > sc) m1 = sc;
+  wsync();
+  if (e.lane == 0) { e.f[e.L.o_action] = m0; e.f[e.L.o_action + 1] = m1; }
+  wsync();
+  for (int a = 0; a < A->n_layers; ++a) {
+    int l = A->layers[a];
+    int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
+    for (int s = s0; s < s1; ++s) {
+      if (!ALIVE(s)) continue;
+      double m = MASS(s);
+      if (A->control_velocity) {
+        wsync();
+        if (e.lane == 0) { VELX(s) = m0 / m; VELY(s) = m1 / m; FLAGS(s) &= ~MOOG_F_VEL_F32; }
+        wsync();
+      } else {
+        vel_iadd(e, s, m0 / m, m1 / m);
+      }
+    }
+  }
+}
+
+// ---- reset path (sprite.py:261-424, distributions.py, sprite_generators.py:77-105) ----------
+__device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32) {
+  const moog_program_t* P = e.P;
+  int sid = (int)fac[MOOG_FAC_SHAPE];
+  const moog_shape_t* sh = &P->shapes[sid];
+  double x = fac[MOOG_FAC_X], y = fac[MOOG_FAC_Y];
+  double angle = fac[MOOG_FAC_ANGLE], scale = fac[MOOG_FAC_SCALE], aspect = fac[MOOG_FAC_ASPECT];
+  double sx = scale, sy = scale * aspect;
+  double c = cos(angle), sn = sin(angle);
+  double m00 = c * sx, m01 = (-sn) * sy, m10 = sn * sx, m11 = c * sy;
+  int n = sh->nverts;
+  if (n > P->slot_vcap[s]) n = P->slot_vcap[s];
+  double* v = VERT(s);
+  double r = -1.0;
+  wsync();
+  if (e.lane < n) {
+    double ux = P->shape_verts[sh->voff + e.lane][0], uy = P->shape_verts[sh->voff + e.lane][1];
+    double vx = (m00 * ux + m01 * uy) + x;
+    double vy = (m10 * ux + m11 * uy) + y;
+    v[2 * e.lane] = vx; v[2 * e.lane + 1] = vy;
+    r = norm2(vx - x, vy - y);
+  }
+  // np.max over the vertex radii (NaN-free in practice; fmax is order independent)
+  for (int o = 32; o > 0; o >>= 1) r = fmax(r, shfl_d(r, e.lane ^ o));
+  if (e.lane == 0) {
+    NV(s) = n;
+    SHAPEID(s) = sid;
+    MAXR(s) = r;
+    INER(s, 0) = sh->inertia[0] * (sx * sx);
+    INER(s, 1) = sh->inertia[1] * (sy * sy);
+    PX(s) = x; PY(s) = y;
+    ANG(s) = angle;
+    VELX(s) = fac[MOOG_FAC_XVEL]; VELY(s) = fac[MOOG_FAC_YVEL];
+    ANGV(s) = fac[MOOG_FAC_ANGVEL];
+    MASS(s) = fac[MOOG_FAC_MASS];
+    COL(s, 0) = fac[MOOG_FAC_C0]; COL(s, 1) = fac[MOOG_FAC_C1]; COL(s, 2) = fac[MOOG_FAC_C2];
+    OPAC(s) = (int32_t)fac[MOOG_FAC_OPACITY];
+    TELE(s) = 0;
+    int fl = 0;
+    if (sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
+    if (vel_f32) fl |= MOOG_F_VEL_F32;
+    if (angvel_f32) fl |= MOOG_F_ANGVEL_F32;
+    FLAGS(s) = fl;
+  }
+  wsync();
+  set_position(e, s, x + sh->centroid[0], y + sh->centroid[1]);
+}
+
+__device__ inline void sample_factors(Env& e, const moog_genop_t* op, double* fac) {
+  for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
+  for (int k = 0; k < op->n_sampled; ++k) {
+    int fi = op->sample_order[k];
+    const moog_factor_t* F = &op->factors[fi];
+    double val = F->a;
+    if (F->kind == MOOG_DIST_CONTINUOUS) {
+      double u = next_uniform(e);
+      val = F->a + (F->b - F->a) * u;
+      if (F->f32) val = f32r(val);
+    } else if (F->kind == MOOG_DIST_DISCRETE) {
+      double u = next_uniform(e);
+      int idx = (int)(u * F->n_cand);
+      if (idx >= F->n_cand) idx = F->n_cand - 1;
+      val = e.P->cand[F->cand_off + idx];
+    }
+    // static indexing keeps `fac` in registers
+#pragma unroll
+    for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == fi) fac[q] = val;
+  }
+}
+
+__device__ inline void run_genop(Env& e, int oi) {
+  const moog_program_t* P = e.P;
+  const moog_genop_t* op = &P->ops[oi];
+  int n = op->count_max;
+  if (op->count_min < op->count_max) {
+    double u = next_uniform(e);
+    int span = op->count_max + 1 - op->count_min;
+    int k = (int)(u * span);
+    if (k >= span) k = span - 1;
+    n = op->count_min + k;
+  }
+  const moog_factor_t* FX = &op->factors[MOOG_FAC_XVEL];
+  const moog_factor_t* FY = &op->factors[MOOG_FAC_YVEL];
+  const moog_factor_t* FW = &op->factors[MOOG_FAC_ANGVEL];
+  int vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
+  int angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
+  for (int k = 0; k < op->count_max; ++k) {
+    int s = op->slot0 + k;
+    if (k >= n) {
+      wsync();
+      if (e.lane == 0) { FLAGS(s) = 0; NV(s) = 0; }
+      wsync();
+      continue;
+    }
+    int count = 0;
+    for (;;) {
+      double fac[MOOG_NUM_FACTORS];
+      sample_factors(e, op, fac);
+      create_sprite(e, s, fac, vel_f32, angvel_f32);
+      bool ov = false;
+      for (int oj = 0; oj < oi && !ov; ++oj) {
+        if (!((op->avoid_ops >> oj) & 1)) continue;
+        const moog_genop_t* o2 = &P->ops[oj];
+        for (int t = o2->slot0; t < o2->slot0 + o2->count_max && !ov; ++t)
+          if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+      }
+      if (op->disjoint)
+        for (int t = op->slot0; t < s && !ov; ++t)
+          if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+      if (!ov) break;
+      if (count > op->max_tries) {
+        wsync();
+        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+        wsync();
+        break;
+      }
+      ++count;
+    }
+    wsync();
+    if (e.lane == 0) FLAGS(s) |= MOOG_F_ALIVE;
+    wsync();
+  }
+}
+
+// environment.py:82-96
+__device__ inline void env_reset(Env& e) {
+  const moog_program_t* P = e.P;
+  wsync();
+  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; }
+  if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
+  wsync();
+  for (int oi = 0; oi < P->n_ops; ++oi) run_genop(e, oi);
+  wsync();
+  if (e.lane == 0) {
+    for (int t = 0; t < P->n_tasks; ++t) e.f[e.L.o_task + t] = DINF;
+    e.f[e.L.o_action] = 0; e.f[e.L.o_action + 1] = 0;
+  }
+  wsync();
+  for (int r = 0; r < P->n_rules; ++r) { rule_reset(e, r); rule_step(e, r); }
+}

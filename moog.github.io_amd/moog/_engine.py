@@ -31,6 +31,10 @@ def load_library(path=None):
     if _LIB is not None and path is None:
         return _LIB
     path = path or os.environ.get('MOOG_HIP_LIB', LIB_PATH)
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the
+    # one already resident when the engine library resolves libamdhip64, so that
+    # both share one runtime (streams, device pointers).
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise EngineError(
             'HIP engine library not found at %s -- build it with '

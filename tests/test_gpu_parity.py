@@ -1,0 +1,222 @@
+"""HIP engine vs the CPU oracle / the reference golden vectors (needs an MI355X).
+Everything goes through the C ABI (moog.environment.BatchedEnvironment -> ctypes)."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import compiled, fixture, records_from_fixture, state_diff
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
+        ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
+        ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
+        ('falling_balls_64', 0)]
+
+
+def make_env(name, n, seed=0, **kw):
+    import torch  # noqa: F401
+    from moog import environment
+    from moog_demos import example_configs
+    return environment.BatchedEnvironment(num_envs=n, seed=seed, **example_configs.load(name), **kw)
+
+
+def upload(env, f64, i32):
+    import torch
+    env.state_f64.copy_(torch.from_numpy(f64))
+    env.state_i32.copy_(torch.from_numpy(i32))
+
+
+def download(env):
+    import torch
+    torch.cuda.synchronize()
+    return env.state_f64.cpu().numpy(), env.state_i32.cpu().numpy()
+
+
+def padded_uniforms(fx, ts):
+    width = max(1, int(fx['uniforms'].shape[1]))
+    u = np.zeros((len(ts), width))
+    for i, t in enumerate(ts):
+        n = int(fx['n_uniforms'][t])
+        u[i, :n] = fx['uniforms'][t, :n]
+    return u
+
+
+@pytest.mark.parametrize('name,seed', RUNS)
+def test_teacher_forced_vs_reference(name, seed):
+    """All recorded calls at once: env i starts from the reference state of call
+    i and must land on the reference state of call i+1 (floats <= 1e-5, ints,
+    rewards, step types and frames exact)."""
+    c, fx = compiled(name), fixture(name, seed)
+    T = len(fx['step_type'])
+    ts = list(range(1, T))
+    env = make_env(name, len(ts))
+    L = c.layout
+    f64 = np.zeros((len(ts), L.f64_per_env))
+    i32 = np.zeros((len(ts), L.i32_per_env), np.int32)
+    for i, t in enumerate(ts):
+        records_from_fixture(fx, t - 1, c, f64, i32, env=i)
+    upload(env, f64, i32)
+    actions = np.stack([np.asarray(fx['action'][t]) for t in ts])
+    env.check_faults = False
+    out = env.step(actions, injected_uniforms=padded_uniforms(fx, ts))
+    f, q = download(env)
+    img = out.observation['image'].cpu().numpy()
+    worst = 0.0
+    for i, t in enumerate(ts):
+        d = state_diff(fx, t, c, f, q, env=i)
+        assert d['ints_ok'], (t, d)
+        assert d['float'] <= TOL, (t, d)
+        worst = max(worst, d['float'])
+        assert int(out.step_type[i]) == int(fx['step_type'][t]), t
+        assert helpers.same_or_nan(float(out.reward[i]), fx['reward'][t]), t
+        assert helpers.same_or_nan(float(out.discount[i]), fx['discount'][t]), t
+        assert np.array_equal(img[i], fx['image'][t]), 'frame %d differs' % t
+        assert int(q[i, L.o_fault]) == 0
+    print(name, seed, 'worst teacher-forced error vs reference', worst)
+
+
+@pytest.mark.parametrize('name,seed', RUNS)
+def test_free_running_vs_reference(name, seed):
+    """One env free-running from the first reference state for <= 64 calls."""
+    c, fx = compiled(name), fixture(name, seed)
+    env = make_env(name, 1)
+    T = min(len(fx['step_type']), 65)
+    f64, i32 = records_from_fixture(fx, 0, c)
+    upload(env, f64, i32)
+    env.check_faults = False
+    for t in range(1, T):
+        out = env.step(np.asarray(fx['action'][t]).reshape((1, 2) if not fx['is_grid'] else (1,)),
+                       injected_uniforms=padded_uniforms(fx, [t]))
+        f, q = download(env)
+        d = state_diff(fx, t, c, f, q)
+        assert d['ints_ok'], (t, d)
+        assert d['float'] <= TOL, (t, d)
+        assert int(out.step_type[0]) == int(fx['step_type'][t])
+        assert helpers.same_or_nan(float(out.reward[0]), fx['reward'][t])
+    assert np.array_equal(out.observation['image'][0].cpu().numpy(), fx['image'][T - 1])
+
+
+@pytest.mark.parametrize('name,seed', RUNS)
+def test_reset_sampler_vs_reference(name, seed):
+    """Device-side state initialisation replaying the reference's recorded draws."""
+    c, fx = compiled(name), fixture(name, seed)
+    env = make_env(name, 1)
+    out = env.reset(injected_uniforms=padded_uniforms(fx, [0]))
+    f, q = download(env)
+    d = state_diff(fx, 0, c, f, q)
+    assert d['ints_ok'] and d['float'] <= TOL, d
+    assert np.array_equal(out.observation['image'][0].cpu().numpy(), fx['image'][0])
+    assert int(out.step_type[0]) == 0 and np.isnan(float(out.reward[0]))
+
+
+@pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
+                                  'functional_maze', 'falling_balls', 'colliding_predators_32'])
+def test_engine_vs_oracle_own_rng(name):
+    """Same Philox streams on both sides, 64 envs, resets included: integer
+    records bit-exact, floats <= 1e-9, frames bit-exact from the engine state."""
+    import torch
+    n, steps = 64, 24
+    env = make_env(name, n, seed=11, env_index0=1000)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=11, env_index0=1000)
+    env.reset()
+    o.reset(render=False)
+    rs = np.random.RandomState(5)
+    grid = env._is_grid
+    for k in range(steps):
+        a = rs.randint(0, 5, size=n) if grid else rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.step(a, render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.abs(f - o.f64)
+        err = np.where(np.isnan(f) & np.isnan(o.f64), 0, err)
+        err = np.where(f == o.f64, 0, err)
+        assert float(np.max(err)) <= 1e-9, (k, float(np.max(err)))
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+        assert helpers.same_or_nan(out.discount.cpu().numpy(), o.discount)
+        # keep the two in lock step (removes 1-ulp libm/ocml cos/sin drift)
+        o.f64[:], o.i32[:] = f, q
+    assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
+
+
+def test_philox_bit_exact():
+    """The device RNG stream equals the oracle's: a reset driven by it gives the
+    same integer records (shape ids, counts, rng counters)."""
+    env = make_env('functional_maze', 32, seed=99, env_index0=7)
+    o = helpers.OracleEnv(env.compiled, n_envs=32, seed=99, env_index0=7)
+    env.reset()
+    o.reset(render=False)
+    f, q = download(env)
+    assert np.array_equal(q, o.i32)
+    with np.errstate(invalid='ignore'):
+        err = np.where(f == o.f64, 0.0, np.abs(f - o.f64))
+    assert float(np.max(err)) <= 1e-12
+
+
+def test_raster_corpus_vs_pillow():
+    """The 3000-polygon Pillow corpus through the HIP rasteriser (one polygon per env)."""
+    import collections
+    import torch
+    from moog import environment, action_spaces, observers, physics as physics_lib, sprite, tasks
+    z = dict(np.load(helpers.GOLDEN + '/raster.npz'))
+    for W in (64, 128):
+        idx = np.nonzero(z['size'] == W)[0]
+        cfg = dict(
+            state_initializer=lambda: collections.OrderedDict(
+                [('a', [sprite.Sprite(shape='circle', c0=200, c1=100, c2=50, opacity=128)]),
+                 ('agent', [])]),
+            physics=physics_lib.Physics(updates_per_env_step=1),
+            task=tasks.CompositeTask(),
+            action_space=action_spaces.Grid(action_layers='agent'),
+            observers={'image': observers.PILRenderer(image_size=(W, W), bg_color=tuple(z['bg']))})
+        env = environment.BatchedEnvironment(num_envs=len(idx), **cfg)
+        env.reset()
+        f, q = download(env)
+        L, P = env.layout, env.compiled.program
+        for i, k in enumerate(idx):
+            nv = int(z['nv'][k])
+            xy = z['xy'][k, :nv].astype(np.float64)
+            v = (xy + np.where(xy >= 0, 0.5, -0.5)) / W   # (int)(W * v) == xy exactly
+            q[i, L.o_nverts] = nv
+            f[i, L.o_verts:L.o_verts + 2 * nv] = v.ravel()
+        upload(env, f, q)
+        img = env.observation()['image'].cpu().numpy()
+        bad = [int(k) for i, k in enumerate(idx)
+               if not np.array_equal(img[i, ::-1, :, 0], z['red'][k, :W, :W])]
+        assert not bad, ('polygons that differ from Pillow at %d^2' % W, bad[:10], len(bad))
+
+
+def test_full_size_properties():
+    """BASELINE size (4096 envs x 32 sprites): determinism (same seed twice ->
+    bit-identical records and frames), independence of batch position, and
+    physical sanity (finite state, sprites stay in the arena)."""
+    import torch
+    outs = []
+    for rep in range(2):
+        env = make_env('colliding_predators_32', 4096, seed=1)
+        env.reset()
+        g = torch.Generator(device='cpu').manual_seed(0)
+        for _ in range(5):
+            a = (torch.rand((4096, 2), generator=g, dtype=torch.float64) * 2 - 1)
+            out = env.step(a)
+        f, q = download(env)
+        outs.append((f, q, out.observation['image'].cpu().numpy()))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    assert np.array_equal(outs[0][2], outs[1][2])
+    f, q, img = outs[0]
+    L = env.layout
+    pos = f[:, L.o_pos:L.o_pos + 2 * L.S].reshape(-1, L.S, 2)[:, 4:]
+    assert np.isfinite(pos).all() and pos.min() > -0.1 and pos.max() < 1.1
+    # a shard of the same global env indices reproduces the same envs
+    env2 = make_env('colliding_predators_32', 64, seed=1, env_index0=128)
+    env2.reset()
+    g = torch.Generator(device='cpu').manual_seed(0)
+    for _ in range(5):
+        a = (torch.rand((4096, 2), generator=g, dtype=torch.float64) * 2 - 1)
+        env2.step(a[128:192])
+    f2, q2 = download(env2)
+    assert np.array_equal(q2, q[128:192]) and np.array_equal(f2, f[128:192], equal_nan=True)

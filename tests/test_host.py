@@ -1,0 +1,96 @@
+"""CPU-only checks of the host side: config lowering, ABI symbols, layout."""
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from moog import _abi, _compiler, _engine
+from moog_demos import example_configs
+
+REF = '/root/reference/moog_demos/example_configs'
+
+
+def test_layout_matches_header():
+    """Python layout_of() == the header's moog_layout() (as compiled into the oracle)."""
+    for name in example_configs.NAMES:
+        c = helpers.compiled(name)
+        L = c.layout
+        assert L.f64_per_env % 2 == 0 and L.i32_per_env % 4 == 0
+        o = helpers.OracleEnv(c)
+        assert o.f64.shape[1] == L.f64_per_env
+    assert helpers.oracle().oracle_program_sizeof() == ctypes.sizeof(_abi.Program)
+
+
+def test_hip_library_exports_abi():
+    """The C-ABI library loads and exports every symbol include/moog_engine.h declares."""
+    lib = _engine.load_library()
+    for sym in _engine.SYMBOLS:
+        assert hasattr(lib, sym), sym
+    assert lib.moog_abi_version() == _abi.MOOG_ABI_VERSION
+    assert lib.moog_program_sizeof() == ctypes.sizeof(_abi.Program)
+    import re
+    hdr = open(_abi.HEADER).read()
+    declared = set(re.findall(r'\b(moog_\w+)\s*\(', hdr)) - {'moog_layout', 'moog_align_'}
+    assert declared == set(_engine.SYMBOLS), declared ^ set(_engine.SYMBOLS)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_engine.EngineError):
+        _engine.load_library(str(tmp_path / 'nope.so'))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+@pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
+                                  'functional_maze', 'falling_balls'])
+def test_reference_configs_load_unchanged(name):
+    """The reference's own config files import this repo's `moog` and lower to the
+    same program as the re-stated recipes."""
+    spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ref = _compiler.compile_config(**m.get_config(0))
+    assert bytes(ref.program) == bytes(helpers.compiled(name).program)
+
+
+def test_program_contents():
+    c = helpers.compiled('colliding_predators_32')
+    P = c.program
+    assert P.n_slots == 32 and c.layer_names == ['walls', 'predators', 'agent']
+    assert P.updates_per_env_step == 10 and P.n_forces == 4
+    kinds = [P.forces[i].kind for i in range(4)]
+    assert kinds == [_abi.MOOG_FORCE_DRAG] + [_abi.MOOG_FORCE_COLLISION] * 3
+    assert [P.forces[i].symmetric for i in range(1, 4)] == [1, 0, 0]
+    assert P.timeout_steps == 200
+    c = helpers.compiled('pong')
+    T = c.program.tasks[1]
+    assert (T.kind, T.cond, T.cond_value) == (_abi.MOOG_TASK_RESET, _abi.MOOG_COND_ALL_Y_LT, 0.0)
+    assert c.layer_names[T.cond_layer] == 'prey'
+    c = helpers.compiled('functional_maze')
+    assert [c.program.rules[i].kind for i in range(3)] == [
+        _abi.MOOG_RULE_VANISH_ON_CONTACT, _abi.MOOG_RULE_PORTAL, _abi.MOOG_RULE_BOOSTER]
+    prey = c.program.ops[c.program.n_ops - 1]
+    assert (prey.count_min, prey.count_max) == (2, 4)
+
+
+def test_unsupported_components_raise():
+    from moog import tasks, physics
+    with pytest.raises(NotImplementedError):
+        tasks.ContactReward(lambda a, b: 1., 'a', 'b')
+    with pytest.raises(NotImplementedError):
+        physics.DistanceForce(lambda d: d)
+    with pytest.raises(NotImplementedError):
+        tasks.Reset(condition=lambda state: len(state['x']) > 3).classify(['x', 'y'])
+
+
+def test_shape_table_matches_reference_fixture():
+    """Host-side shape records (centroid shift, inertia) reproduce the reference's
+    sprites: the reset of every fixture already pins them (test_oracle_golden),
+    here the unit-area property of the named shapes is checked directly."""
+    from moog import shapes
+    for name, v in shapes.SHAPES.items():
+        x, y = v[:, 0], v[:, 1]
+        area = 0.5 * np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y)
+        assert abs(area - 1.0) < 1e-12, name
