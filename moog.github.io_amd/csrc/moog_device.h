@@ -33,6 +33,9 @@ struct Env {
   uint64_t seed;
   int64_t env_index;
   int lane;
+  double* bb;              // LDS scratch [S][4]: conservative AABB (xmin, ymin, xmax, ymax)
+  double* xf;              // LDS scratch [S][8]: per-sprite integrate transform
+  const int16_t* vslot;    // global [TOTV]: vertex index -> slot
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -191,10 +194,63 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
   return false;
 }
 
+// ---- conservative bounding boxes (engine-side broad phase) --------------------------
+// Path.intersects_path(filled) can only be true when the two polygons' bounding
+// boxes touch within matplotlib's isclose tolerances (rtol 1e-10, atol 1e-13), so
+// rejecting pairs whose boxes are more than BB_MARGIN apart never changes a result.
+// A box is exact (min/max of the cached vertices, moved with every translation)
+// until the sprite rotates; from then on it is the box of the bounding circle
+// (position +- max_radius, inflated), which rigid motion cannot leave.
+#define BB_MARGIN 1e-6
+#define BB(s, c) (e.bb[4 * (s) + (c)])
+
+__device__ inline void bbox_from_circle(Env& e, int s) {  // lane 0 writes
+  double r = MAXR(s) * (1.0 + 1e-6) + 1e-9;
+  double x = PX(s), y = PY(s);
+  BB(s, 0) = x - r; BB(s, 1) = y - r; BB(s, 2) = x + r; BB(s, 3) = y + r;
+}
+
+// lanes = vertices of sprite s (wave reduction); used after (re)creation
+__device__ inline void bbox_exact_wave(Env& e, int s) {
+  const double* v = VERT(s);
+  int n = NV(s);
+  double x0 = DINF, y0 = DINF, x1 = -DINF, y1 = -DINF;
+  if (e.lane < n) { x0 = x1 = v[2 * e.lane]; y0 = y1 = v[2 * e.lane + 1]; }
+  for (int o = 32; o > 0; o >>= 1) {
+    x0 = fmin(x0, shfl_d(x0, e.lane ^ o)); y0 = fmin(y0, shfl_d(y0, e.lane ^ o));
+    x1 = fmax(x1, shfl_d(x1, e.lane ^ o)); y1 = fmax(y1, shfl_d(y1, e.lane ^ o));
+  }
+  wsync();
+  if (e.lane == 0) { BB(s, 0) = x0; BB(s, 1) = y0; BB(s, 2) = x1; BB(s, 3) = y1; }
+  wsync();
+}
+
+// lanes = sprites; each lane scans its own vertex list (kernel prologue)
+__device__ inline void bbox_build_all(Env& e) {
+  const moog_program_t* P = e.P;
+  for (int s = e.lane; s < P->n_slots; s += 64) {
+    const double* v = VERT(s);
+    int n = NV(s);
+    double x0 = DINF, y0 = DINF, x1 = -DINF, y1 = -DINF;
+    for (int k = 0; k < n; ++k) {
+      double x = v[2 * k], y = v[2 * k + 1];
+      x0 = fmin(x0, x); y0 = fmin(y0, y); x1 = fmax(x1, x); y1 = fmax(y1, y);
+    }
+    BB(s, 0) = x0; BB(s, 1) = y0; BB(s, 2) = x1; BB(s, 3) = y1;
+  }
+  wsync();
+}
+
+__device__ __forceinline__ bool bbox_apart(const Env& e, int s0, int s1) {
+  return BB(s0, 0) > BB(s1, 2) + BB_MARGIN || BB(s1, 0) > BB(s0, 2) + BB_MARGIN ||
+         BB(s0, 1) > BB(s1, 3) + BB_MARGIN || BB(s1, 1) > BB(s0, 3) + BB_MARGIN;
+}
+
 // sprite.py:462-484
 __device__ inline bool overlaps(const Env& e, int s0, int s1) {
   double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
   if (norm2(dx, dy) > MAXR(s0) + MAXR(s1)) return false;
+  if (bbox_apart(e, s0, s1)) return false;
   return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1));
 }
 
@@ -219,57 +275,90 @@ __device__ inline void set_position(Env& e, int s, double nx, double ny) {
     v[2 * e.lane] = v[2 * e.lane] + dx;
     v[2 * e.lane + 1] = v[2 * e.lane + 1] + dy;
   }
-  if (e.lane == 0) { PX(s) = nx; PY(s) = ny; }
-  wsync();
-}
-
-// sprite.py:531-540 angle setter (matplotlib rotate_around); lanes = vertices
-__device__ inline void rotate_path(Env& e, int s, double d_theta) {
-  double a = cos(d_theta), b = sin(d_theta);
-  double x = PX(s), y = PY(s);
-  double tx = (a * (-x) - b * (-y)) + x;
-  double ty = (b * (-x) + a * (-y)) + y;
-  double* v = VERT(s);
-  int n = NV(s);
-  wsync();
-  if (e.lane < n) {
-    double vx = v[2 * e.lane], vy = v[2 * e.lane + 1];
-    v[2 * e.lane] = (a * vx + (-b) * vy) + tx;
-    v[2 * e.lane + 1] = (b * vx + a * vy) + ty;
+  if (e.lane == 0) {
+    PX(s) = nx; PY(s) = ny;
+    BB(s, 0) = BB(s, 0) + dx; BB(s, 2) = BB(s, 2) + dx;
+    BB(s, 1) = BB(s, 1) + dy; BB(s, 3) = BB(s, 3) + dy;
   }
   wsync();
 }
 
-// sprite.py:426-430 with the reference's float32 propagation (see oracle)
-__device__ inline void update_pos_from_vel(Env& e, int s, double dt) {
-  double dx, dy;
-  int fl = FLAGS(s);
-  if (fl & MOOG_F_VEL_F32) {
-    float dtf = (float)dt;
-    dx = (double)(dtf * (float)VELX(s));
-    dy = (double)(dtf * (float)VELY(s));
-  } else {
-    dx = dt * VELX(s);
-    dy = dt * VELY(s);
-  }
-  set_position(e, s, PX(s) + dx, PY(s) + dy);
-  double w = ANGV(s);
-  if (w != 0.0) {
-    if (fl & MOOG_F_ANGVEL_F32) {
-      float t = (float)dt * (float)w;
-      float a_old = (float)ANG(s);
-      float a_new = a_old + t;
-      float d = a_new - a_old;
-      rotate_path(e, s, (double)d);
-      if (e.lane == 0) ANG(s) = (double)a_new;
+// sprite.py:426-430 update_pos_from_vel for EVERY live sprite (physics.py:114-117),
+// including the reference's float32 propagation (see oracle).  Phase 1, lanes =
+// sprites: new position, translation delta, rotation coefficients (the per-sprite
+// sin/cos run in parallel).  Phase 2, lanes = vertices of all sprites: translate
+// (position setter, sprite.py:616-633) then rotate about the new position (angle
+// setter, :531-540, matplotlib rotate_around).  Per-vertex arithmetic is exactly
+// the reference's; sprites are independent so the order does not matter.
+__device__ inline void integrate_all(Env& e, double dt) {
+  const moog_program_t* P = e.P;
+  const int S = P->n_slots;
+  wsync();
+  for (int s = e.lane; s < S; s += 64) {
+    double* x = &e.xf[8 * s];
+    int fl = FLAGS(s);
+    if (!(fl & MOOG_F_ALIVE)) { x[6] = 0.0; continue; }
+    double dx, dy;
+    if (fl & MOOG_F_VEL_F32) {
+      float dtf = (float)dt;
+      dx = (double)(dtf * (float)VELX(s));
+      dy = (double)(dtf * (float)VELY(s));
     } else {
-      double a_old = ANG(s);
-      double a_new = a_old + dt * w;
-      rotate_path(e, s, a_new - a_old);
-      if (e.lane == 0) ANG(s) = a_new;
+      dx = dt * VELX(s);
+      dy = dt * VELY(s);
     }
-    wsync();
+    double ox = PX(s), oy = PY(s);
+    double nx = ox + dx, ny = oy + dy;
+    double ddx = nx - ox, ddy = ny - oy;
+    double w = ANGV(s);
+    double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0;
+    if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
+      double dth;
+      if (fl & MOOG_F_ANGVEL_F32) {
+        float t = (float)dt * (float)w;
+        float a_old = (float)ANG(s);
+        float a_new = a_old + t;
+        dth = (double)(a_new - a_old);
+        ANG(s) = (double)a_new;
+      } else {
+        double a_old = ANG(s);
+        double a_new = a_old + dt * w;
+        dth = a_new - a_old;
+        ANG(s) = a_new;
+      }
+      a = cos(dth); b = sin(dth);
+      tx = (a * (-nx) - b * (-ny)) + nx;
+      ty = (b * (-nx) + a * (-ny)) + ny;
+      mode = 2.0;
+    }
+    x[0] = ddx; x[1] = ddy; x[2] = a; x[3] = b; x[4] = tx; x[5] = ty; x[6] = mode;
+    PX(s) = nx; PY(s) = ny;
+    if (mode == 2.0) {
+      double r = MAXR(s) * (1.0 + 1e-6) + 1e-9;
+      BB(s, 0) = nx - r; BB(s, 1) = ny - r; BB(s, 2) = nx + r; BB(s, 3) = ny + r;
+    } else {
+      BB(s, 0) = BB(s, 0) + ddx; BB(s, 2) = BB(s, 2) + ddx;
+      BB(s, 1) = BB(s, 1) + ddy; BB(s, 3) = BB(s, 3) + ddy;
+    }
   }
+  wsync();
+  double* vall = &e.f[e.L.o_verts];
+  for (int idx = e.lane; idx < e.L.TOTV; idx += 64) {
+    int s = e.vslot[idx];
+    const double* x = &e.xf[8 * s];
+    double mode = x[6];
+    int k = idx - P->slot_voff[s];
+    if (mode == 0.0 || k >= NV(s)) continue;
+    double vx = vall[2 * idx] + x[0], vy = vall[2 * idx + 1] + x[1];
+    if (mode == 2.0) {
+      double a = x[2], b = x[3];
+      double rx = (a * vx + (-b) * vy) + x[4];
+      double ry = (b * vx + a * vy) + x[5];
+      vx = rx; vy = ry;
+    }
+    vall[2 * idx] = vx; vall[2 * idx + 1] = vy;
+  }
+  wsync();
 }
 
 __device__ inline void vel_iadd(Env& e, int s, double dx, double dy) {
@@ -721,7 +810,7 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
         bool cand = false;
         if (s1 >= cursor && s1 < cend && s1 != s0 && ALIVE(s1)) {
           double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
-          cand = !(norm2(dx, dy) > MAXR(s0) + MAXR(s1));
+          cand = !(norm2(dx, dy) > MAXR(s0) + MAXR(s1)) && !bbox_apart(e, s0, s1);
         }
         uint64_t mask = __ballot(cand);
         bool rebuilt = false;
@@ -768,9 +857,7 @@ __device__ inline void apply_physics(Env& e) {
     }
   }
   for (int c = 0; c < P->n_corrective; ++c) constant_speed(e, &P->corrective[c]);
-  double dt = 1. / K;
-  for (int s = 0; s < P->n_slots; ++s)
-    if (ALIVE(s)) update_pos_from_vel(e, s, dt);
+  integrate_all(e, 1. / K);
 }
 
 // ---- game rules ------------------------------------------------------------------------
@@ -1050,6 +1137,7 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
   }
   wsync();
   set_position(e, s, x + sh->centroid[0], y + sh->centroid[1]);
+  bbox_exact_wave(e, s);
 }
 
 __device__ inline void sample_factors(Env& e, const moog_genop_t* op, double* fac) {

@@ -58,6 +58,7 @@ struct KArgs {
   double* discount;
   int32_t* step_type;
   int32_t mode;
+  const int16_t* vslot;
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_RESET_AUTO = 3 };
@@ -69,6 +70,9 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.L = a.L;
   e.f = reinterpret_cast<double*>(moog_lds);
   e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
+  e.bb = reinterpret_cast<double*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
+  e.xf = e.bb + 4 * a.L.S;
+  e.vslot = a.vslot;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
   e.seed = a.seed;
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(64) void moog_step_kernel(KArgs a) {
   load_record(e, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
+  bbox_build_all(e);
   const moog_program_t* P = a.P;
   if (a.mode == MODE_PHYSICS) {
     for (int k = 0; k < P->updates_per_env_step; ++k) apply_physics(e);
@@ -505,6 +510,7 @@ struct moog_engine {
   moog_program_t prog;
   moog_layout_t L;
   moog_program_t* d_prog = nullptr;
+  int16_t* d_vslot = nullptr;
   int32_t n_envs = 0;
   int device = 0;
   uint64_t seed = 0;
@@ -556,7 +562,17 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   if (err != hipSuccess) { delete e; return fail(MOOG_E_NOMEM, "hipMalloc(program) failed"); }
   err = hipMemcpy(e->d_prog, prog, sizeof(moog_program_t), hipMemcpyHostToDevice);
   if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_HIP, "hipMemcpy(program) failed"); }
-  e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4;
+  {
+    std::vector<int16_t> vs((size_t)(prog->n_total_verts > 0 ? prog->n_total_verts : 1), 0);
+    for (int sl = 0; sl < prog->n_slots; ++sl)
+      for (int k = 0; k < prog->slot_vcap[sl]; ++k) vs[prog->slot_voff[sl] + k] = (int16_t)sl;
+    err = hipMalloc(&e->d_vslot, vs.size() * sizeof(int16_t));
+    if (err == hipSuccess)
+      err = hipMemcpy(e->d_vslot, vs.data(), vs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
+  }
+  e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
+                (size_t)e->L.S * 12 * 8;
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
@@ -607,6 +623,7 @@ int moog_engine_destroy(moog_engine_t* e) {
   if (!e) return MOOG_OK;
   for (int k = 0; k < MOOG_K_COUNT; ++k) drain(e->timed[k]);
   if (e->d_prog) hipFree(e->d_prog);
+  if (e->d_vslot) hipFree(e->d_vslot);
   delete e;
   return MOOG_OK;
 }
@@ -648,6 +665,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.discount = out ? out->discount : nullptr;
   a.step_type = out ? out->step_type : nullptr;
   a.mode = mode;
+  a.vslot = e->d_vslot;
   return a;
 }
 
