@@ -155,338 +155,7 @@ __global__ __launch_bounds__(64) void moog_step_kernel(KArgs a) {
   store_record(e, gf, gq);
 }
 
-// =====================================================================================
-// rasteriser: Pillow ImageDraw.polygon (RGBA blend) + PILRenderer painter's loop
-// (pil_renderer.py:88-120; Draw.c polygon_generic / add_edge / hline32rgba as
-// restated and fuzz-validated in oracle/moog_oracle.c)
-// =====================================================================================
-#define R_THREADS 256
-#define R_MAXE 32   // max edges per polygon (31-vertex cap for rendering)
-#define R_XX 24     // max crossings per scanline
-
-struct REdge { short x0, y0, x1, y1; float dx; };   // 12 bytes
-struct RItem { int n_edges; int ymin, ymax; unsigned rgba; };
-
-struct RArgs {
-  const moog_program_t* P;
-  moog_layout_t L;
-  const double* f64;
-  const int32_t* i32;
-  uint8_t* image;
-  int32_t n_envs;
-  int32_t items_per_chunk;
-  int32_t words_per_row;
-};
-
-__device__ inline int pil_round_up(float f) {
-  return (int)((f >= 0.0f) ? floorf(f + 0.5f) : -floorf(fabsf(f) + 0.5f));
-}
-__device__ inline int pil_round_down(float f) {
-  return (int)((f >= 0.0f) ? ceilf(f - 0.5f) : -ceilf(fabsf(f) - 0.5f));
-}
-
-__device__ inline void hsv_to_rgb_u8(double h, double s, double v, unsigned& r8, unsigned& g8,
-                                     unsigned& b8) {
-  double r, g, b;
-  if (s == 0.0) { r = g = b = v; }
-  else {
-    int i = (int)(h * 6.0);
-    double f = (h * 6.0) - i;
-    double p = v * (1.0 - s), q = v * (1.0 - s * f), t = v * (1.0 - s * (1.0 - f));
-    i = ((i % 6) + 6) % 6;
-    switch (i) {
-      case 0: r = v; g = t; b = p; break;
-      case 1: r = q; g = v; b = p; break;
-      case 2: r = p; g = v; b = t; break;
-      case 3: r = p; g = q; b = v; break;
-      case 4: r = t; g = p; b = v; break;
-      default: r = v; g = p; b = q; break;
-    }
-  }
-  r8 = (unsigned)(int)(255 * r) & 255u; g8 = (unsigned)(int)(255 * g) & 255u;
-  b8 = (unsigned)(int)(255 * b) & 255u;
-}
-
-__device__ inline short clamp16(int v) { return (short)(v < -32000 ? -32000 : (v > 32000 ? 32000 : v)); }
-
-// One thread builds the edge list of one draw item (ImagingDrawPolygon's loop,
-// including the merge of consecutive collinear horizontal edges).
-__device__ inline void build_item(const RArgs& a, const double* gf, const int32_t* gq, int slot,
-                                  int copy, RItem* item, REdge* edges) {
-  const moog_program_t* P = a.P;
-  int W = P->render.width, H = P->render.height;
-  int n = gq[a.L.o_nverts + slot];
-  const double* v = gf + a.L.o_verts + 2 * P->slot_voff[slot];
-  double ox = 0, oy = 0;
-  bool torus = (P->render.polymod == MOOG_POLYMOD_TORUS);
-  if (torus) { ox = (double)(copy / 3 - 1); oy = (double)(copy % 3 - 1); }
-  unsigned r8, g8, b8;
-  const double* col = gf + a.L.o_color + 3 * slot;
-  if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
-  else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
-  unsigned a8 = (unsigned)gq[a.L.o_opacity + slot] & 255u;
-  item->rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-  int ne = 0, ymin = H - 1, ymax = 0;
-  int fx = 0, fy = 0, px = 0, py = 0, ppx = 0, ppy = 0;
-  for (int i = 0; i <= n; ++i) {
-    int cx, cy;
-    if (i < n) {
-      double vx = v[2 * i], vy = v[2 * i + 1];
-      if (torus) { vx = vx + ox; vy = vy + oy; }
-      cx = (int)((double)W * vx);
-      cy = (int)((double)H * vy);
-    } else {  // closing edge if last != first
-      if (px == fx && py == fy) break;
-      cx = fx; cy = fy;
-    }
-    if (i == 0) { fx = cx; fy = cy; px = cx; py = cy; continue; }
-    // edge (px,py) -> (cx,cy); the vertex before px is (ppx,ppy) when i >= 2
-    bool merged = false;
-    if (i < n + 0 && py == cy && i >= 2 && py == ppy && ne > 0) {
-      // horizontal edge right after another horizontal edge (not the closing edge)
-      if (cx > px && px > ppx) { edges[ne - 1].x1 = clamp16(cx); merged = true; }
-      else if (cx < px && px < ppx) { edges[ne - 1].x1 = clamp16(cx); merged = true; }
-    }
-    if (!merged && ne < R_MAXE) {
-      REdge ed;
-      ed.x0 = clamp16(px); ed.y0 = clamp16(py); ed.x1 = clamp16(cx); ed.y1 = clamp16(cy);
-      ed.dx = (py == cy) ? 0.0f : ((float)(cx - px)) / (float)(cy - py);
-      edges[ne++] = ed;
-      int lo = py < cy ? py : cy, hi = py < cy ? cy : py;
-      if (ymin > lo) ymin = lo;
-      if (ymax < hi) ymax = hi;
-    }
-    ppx = px; ppy = py; px = cx; py = cy;
-  }
-  if (ymin < 0) ymin = 0;
-  if (ymax > H) ymax = H;
-  item->n_edges = ne;
-  item->ymin = ymin;
-  item->ymax = ymax;
-}
-
-__device__ inline void mask_fill(unsigned long long* m, int words, int W, int x0, int x1) {
-  if (x0 < 0) x0 = 0; else if (x0 >= W) return;
-  if (x1 < 0) return; else if (x1 >= W) x1 = W - 1;
-  if (x0 > x1) return;
-  for (int w = x0 >> 6; w <= (x1 >> 6) && w < words; ++w) {
-    int lo = (w == (x0 >> 6)) ? (x0 & 63) : 0;
-    int hi = (w == (x1 >> 6)) ? (x1 & 63) : 63;
-    unsigned long long bits = (hi - lo == 63) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << lo);
-    m[w] |= bits;
-  }
-}
-
-__device__ inline void draw_horizontal(const RItem& it, const REdge* ed, int y, int* x_pos,
-                                       unsigned long long* m, int words, int W) {
-  for (int i = 0; i < it.n_edges; ++i) {
-    if (ed[i].y0 == y && ed[i].y1 == y) {
-      int xa = ed[i].x0, xb = ed[i].x1;
-      int xmin = xa < xb ? xa : xb, xmax = xa < xb ? xb : xa;
-      if (*x_pos != -1 && *x_pos < xmin) continue;
-      if (*x_pos > xmin) {
-        xmin = *x_pos;
-        if (xmax < xmin) continue;
-      }
-      mask_fill(m, words, W, xmin, xmax);
-      *x_pos = xmax + 1;
-    }
-  }
-}
-
-// Coverage of one scanline of one polygon: polygon_generic(hasAlpha=1), one row.
-__device__ inline void scanline_mask(const RItem& it, const REdge* ed, int y, int poly_ymax,
-                                     float* xx, unsigned long long* m, int words, int W) {
-  int j = 0;
-  for (int i = 0; i < it.n_edges; ++i) {
-    int y0 = ed[i].y0, y1 = ed[i].y1;
-    if (y0 == y1) continue;
-    int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
-    if (y < emin || y > emax) continue;
-    float dx = ed[i].dx;
-    float x = (float)(y - y0) * dx + (float)ed[i].x0;
-    if (j < R_XX) xx[j] = x;
-    int myj = j;
-    ++j;
-    if (y == emax && y < poly_ymax) {
-      if (j < R_XX) xx[j] = x;
-      ++j;
-    } else if (dx != 0.0f) {
-      // connect discontiguous corners (tip whose two edges lean the same way)
-      int jj = 0;
-      for (int k = 0; k < i; ++k) {
-        int ky0 = ed[k].y0, ky1 = ed[k].y1;
-        if (ky0 == ky1) continue;
-        int kmin = ky0 < ky1 ? ky0 : ky1, kmax = ky0 < ky1 ? ky1 : ky0;
-        if (y < kmin || y > kmax) continue;
-        int kpos = jj;
-        jj += (y == kmax && y < poly_ymax) ? 2 : 1;
-        float kdx = ed[k].dx;
-        if ((dx > 0 && kdx <= 0) || (dx < 0 && kdx >= 0)) continue;
-        bool top = (y == emin && y == kmin), bot = (y == emax && y == kmax);
-        if (!(top || bot)) continue;
-        if (x != (float)(y - ky0) * kdx + (float)ed[k].x0) continue;
-        int off = top ? 1 : -1;
-        float adj = (float)(y + off - y0) * dx + (float)ed[i].x0;
-        float adjo = (float)(y + off - ky0) * kdx + (float)ed[k].x0;
-        if (adj > x && adjo > x) {
-          float vv = (float)(pil_round_up(fminf(adj, adjo)) - 1);
-          if (vv > x && kpos < R_XX) xx[kpos] = vv;
-        } else if (adj < x && adjo < x) {
-          float vv = (float)(pil_round_up(fmaxf(adj, adjo)) + 1);
-          if (vv < x && kpos < R_XX) xx[kpos] = vv;
-        }
-        break;
-      }
-      (void)myj;
-    }
-  }
-  if (j > R_XX) j = R_XX;
-  for (int p = 1; p < j; ++p) {  // insertion sort (qsort with x_cmp)
-    float key = xx[p];
-    int q = p - 1;
-    while (q >= 0 && xx[q] > key) { xx[q + 1] = xx[q]; --q; }
-    xx[q + 1] = key;
-  }
-  int x_pos = (j == 0) ? -1 : 0;
-  for (int i = 1; i < j; i += 2) {
-    int x_end = pil_round_down(xx[i]);
-    if (x_end < x_pos) continue;
-    draw_horizontal(it, ed, y, &x_pos, m, words, W);
-    if (x_end < x_pos) continue;
-    int x_start = pil_round_up(xx[i - 1]);
-    if (x_pos > x_start) {
-      x_start = x_pos;
-      if (x_end < x_start) continue;
-    }
-    mask_fill(m, words, W, x_start, x_end);
-    x_pos = x_end + 1;
-  }
-  draw_horizontal(it, ed, y, &x_pos, m, words, W);
-}
-
-__device__ inline unsigned blend8(unsigned bg, unsigned fg, unsigned al) {
-  unsigned t = bg * (255u - al) + fg * al + 128u;
-  return ((t >> 8) + t) >> 8;
-}
-
-// LDS carve-up (dynamic): items | edges | xx scratch | coverage masks | frame staging
-__global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
-  int env = blockIdx.x;
-  if (env >= a.n_envs) return;
-  const moog_program_t* P = a.P;
-  const int W = P->render.width, H = P->render.height;
-  const int S = P->n_slots;
-  const int ncopy = (P->render.polymod == MOOG_POLYMOD_TORUS) ? 9 : 1;
-  const int words = a.words_per_row;
-  const int chunk = a.items_per_chunk;
-  const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  const int tid = threadIdx.x;
-
-  unsigned char* p = moog_lds;
-  RItem* items = reinterpret_cast<RItem*>(p); p += (size_t)chunk * sizeof(RItem);
-  REdge* edges = reinterpret_cast<REdge*>(p); p += (size_t)chunk * R_MAXE * sizeof(REdge);
-  float* xxs = reinterpret_cast<float*>(p); p += (size_t)R_THREADS * R_XX * sizeof(float);
-  p = reinterpret_cast<unsigned char*>(((uintptr_t)p + 15) & ~(uintptr_t)15);
-  unsigned long long* masks = reinterpret_cast<unsigned long long*>(p);
-  p += (size_t)chunk * H * words * 8;
-  uint8_t* frame = p;  // H*W*3 bytes, flipped rows
-  int* slot_list = reinterpret_cast<int*>(frame + (((size_t)H * W * 3 + 15) & ~(size_t)15));
-  // live sprites in slot (= layer, list) order; count kept at slot_list[S]
-  if (tid == 0) {
-    int c = 0;
-    for (int s = 0; s < S; ++s)
-      if (gq[a.L.o_flags + s] & MOOG_F_ALIVE) slot_list[c++] = s;
-    slot_list[S] = c;
-  }
-  // background (pil_renderer.py:100)
-  const int segs = (H * W) / 16;   // 16-pixel row segments
-  const unsigned bgr = (unsigned)P->render.bg[0] & 255u, bgg = (unsigned)P->render.bg[1] & 255u,
-                 bgb = (unsigned)P->render.bg[2] & 255u;
-  __syncthreads();
-  const int total_items = slot_list[S] * ncopy;
-
-  // each thread owns up to 4 row segments of 16 pixels, composed in registers
-  unsigned pr[4][12];  // 16 px * 3 B = 48 B = 12 dwords per segment
-  const int my_segs = (segs + R_THREADS - 1) / R_THREADS;
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-      // bytes: pixel i channel c at byte 3*i+c
-      unsigned b0 = (d * 4 + 0) % 3, b1 = (d * 4 + 1) % 3, b2 = (d * 4 + 2) % 3, b3 = (d * 4 + 3) % 3;
-      unsigned c0 = b0 == 0 ? bgr : (b0 == 1 ? bgg : bgb);
-      unsigned c1 = b1 == 0 ? bgr : (b1 == 1 ? bgg : bgb);
-      unsigned c2 = b2 == 0 ? bgr : (b2 == 1 ? bgg : bgb);
-      unsigned c3 = b3 == 0 ? bgr : (b3 == 1 ? bgg : bgb);
-      pr[k][d] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-    }
-  }
-
-  for (int base = 0; base < total_items; base += chunk) {
-    int nit = total_items - base;
-    if (nit > chunk) nit = chunk;
-    __syncthreads();
-    // phase A1: edge lists, one thread per item
-    for (int it = tid; it < nit; it += R_THREADS) {
-      int g = base + it;
-      build_item(a, gf, gq, slot_list[g / ncopy], g % ncopy, &items[it], &edges[it * R_MAXE]);
-    }
-    __syncthreads();
-    // phase A2: coverage masks, one thread per (item, row)
-    for (int w = tid; w < nit * H; w += R_THREADS) {
-      int it = w / H, y = w - it * H;
-      unsigned long long m[4] = {0ull, 0ull, 0ull, 0ull};
-      const RItem item = items[it];
-      if (y >= item.ymin && y <= item.ymax && y < H)
-        scanline_mask(item, &edges[it * R_MAXE], y, item.ymax, &xxs[tid * R_XX], m, words, W);
-      for (int q = 0; q < words; ++q) masks[((size_t)it * H + y) * words + q] = m[q];
-    }
-    __syncthreads();
-    // phase B: compose this chunk's items over the owned pixels, painter's order
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int seg = tid + k * R_THREADS;
-      if (k < my_segs && seg < segs) {
-        int y = (seg * 16) / W, x0 = (seg * 16) % W;
-        for (int it = 0; it < nit; ++it) {
-          unsigned long long mw = masks[((size_t)it * H + y) * words + (x0 >> 6)];
-          unsigned bits = (unsigned)(mw >> (x0 & 63)) & 0xFFFFu;
-          if (!bits) continue;
-          unsigned rgba = items[it].rgba;
-          unsigned fg[3] = {rgba & 255u, (rgba >> 8) & 255u, (rgba >> 16) & 255u};
-          unsigned al = rgba >> 24;
-#pragma unroll
-          for (int b = 0; b < 48; ++b) {
-            int px = b / 3, ch = b % 3;
-            if (bits & (1u << px)) {
-              unsigned sh = (b & 3) * 8;
-              unsigned old = (pr[k][b >> 2] >> sh) & 255u;
-              unsigned nw = blend8(old, fg[ch], al);
-              pr[k][b >> 2] = (pr[k][b >> 2] & ~(255u << sh)) | (nw << sh);
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // phase C: stage the frame in LDS with rows flipped (np.flipud), then stream out
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int seg = tid + k * R_THREADS;
-    if (k < my_segs && seg < segs) {
-      int y = (seg * 16) / W, x0 = (seg * 16) % W;
-      unsigned* dst = reinterpret_cast<unsigned*>(frame + ((size_t)(H - 1 - y) * W + x0) * 3);
-#pragma unroll
-      for (int d = 0; d < 12; ++d) dst[d] = pr[k][d];
-    }
-  }
-  __syncthreads();
-  const uint4* src = reinterpret_cast<const uint4*>(frame);
-  uint4* out = reinterpret_cast<uint4*>(a.image + (size_t)env * H * W * 3);
-  for (int i = tid; i < (H * W * 3) / 16; i += R_THREADS) out[i] = src[i];
-}
+#include "moog_raster.h"
 
 // =====================================================================================
 // host side: engine object + C ABI
@@ -517,7 +186,7 @@ struct moog_engine {
   int64_t env_index0 = 0;
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
-  int raster_chunk = 0, raster_words = 0;
+  int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0;
   bool timing = false;
   TimedKernel timed[MOOG_K_COUNT];
 };
@@ -535,11 +204,11 @@ static int validate(const moog_program_t* p) {
   if (p->n_layers < 0 || p->n_layers > MOOG_MAX_LAYERS) return fail(MOOG_E_INVALID, "n_layers out of range");
   if (p->updates_per_env_step < 1) return fail(MOOG_E_INVALID, "updates_per_env_step < 1");
   for (int s = 0; s < p->n_slots; ++s)
-    if (p->slot_vcap[s] > R_MAXE - 1) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 31 vertices");
+    if (p->slot_vcap[s] > 64) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 64 vertices");
   for (int l = 0; l < p->n_layers; ++l)
     if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
-  if (p->render.width % 16 != 0 || p->render.width > 256 || p->render.height > 1024 ||
-      (p->render.width * p->render.height) / 16 > 4 * R_THREADS)
+  if (p->render.width % 16 != 0 || p->render.width > 128 || p->render.height > 1024 ||
+      (p->render.width * p->render.height) / 16 > R_MAXSEG * R_THREADS)
     return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, <= 128x128)");
   return MOOG_OK;
 }
@@ -577,21 +246,28 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
   }
-  // raster LDS plan
-  int W = prog->render.width, H = prog->render.height;
-  e->raster_words = (W + 63) / 64;
-  int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
-  int max_items = prog->n_slots * ncopy;
-  size_t fixed = (size_t)R_THREADS * R_XX * 4 + 16 + (((size_t)H * W * 3 + 15) & ~(size_t)15) +
-                 (size_t)prog->n_slots * 4 + 64;
-  size_t per_item = sizeof(RItem) + (size_t)R_MAXE * sizeof(REdge) + (size_t)H * e->raster_words * 8;
-  size_t budget = 150 * 1024;
-  int chunk = (int)((budget - fixed) / per_item);
-  if (chunk < 1) { hipFree(e->d_prog); delete e; return fail(MOOG_E_UNSUPPORTED, "raster LDS plan"); }
-  if (chunk > max_items) chunk = max_items > 0 ? max_items : 1;
-  // keep two workgroups per CU when everything fits in one chunk of <= 64 KB
-  e->raster_chunk = chunk;
-  e->raster_lds = fixed + per_item * chunk;
+  // raster LDS plan (moog_raster.h): masks for `chunk` items per pass
+  {
+    int W = prog->render.width, H = prog->render.height;
+    int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
+    e->raster_words = (W + 63) / 64;
+    e->raster_items = prog->n_slots * ncopy;
+    if (e->raster_items < 1) e->raster_items = 1;
+    e->raster_iwords = (e->raster_items + 31) / 32;
+    RPlan pl;
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, 0, e->raster_words, e->raster_iwords, &pl);
+    size_t budget = 60 * 1024, per_item = (size_t)H * e->raster_words * 8;
+    int chunk = pl.total + per_item > budget ? 1 : (int)((budget - pl.total) / per_item);
+    if (chunk > e->raster_items) chunk = e->raster_items;
+    if (chunk < 1) chunk = 1;
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, chunk, e->raster_words, e->raster_iwords, &pl);
+    if (pl.total > 160 * 1024) {
+      hipFree(e->d_prog); hipFree(e->d_vslot); delete e;
+      return fail(MOOG_E_UNSUPPORTED, "raster working set does not fit in LDS");
+    }
+    e->raster_chunk = chunk;
+    e->raster_lds = pl.total;
+  }
   err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
   if (err == hipSuccess)
@@ -672,7 +348,9 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
 static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   RArgs r;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
-  r.n_envs = e->n_envs; r.items_per_chunk = e->raster_chunk; r.words_per_row = e->raster_words;
+  r.vslot = e->d_vslot;
+  r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
+  r.iwords = e->raster_iwords; r.max_items = e->raster_items;
   {
     Bracket br(e, MOOG_K_RASTER, s);
     hipLaunchKernelGGL(moog_raster_kernel, dim3(e->n_envs), dim3(R_THREADS), e->raster_lds, s, r);
