@@ -208,8 +208,8 @@ static int validate(const moog_program_t* p) {
   for (int l = 0; l < p->n_layers; ++l)
     if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
   if (p->render.width % 16 != 0 || p->render.width > 128 || p->render.height > 1024 ||
-      (p->render.width * p->render.height) / 16 > R_MAXSEG * R_THREADS)
-    return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, <= 128x128)");
+      p->render.height > 1024)
+    return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, width <= 128)");
   return MOOG_OK;
 }
 
@@ -255,12 +255,12 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (e->raster_items < 1) e->raster_items = 1;
     e->raster_iwords = (e->raster_items + 31) / 32;
     RPlan pl;
-    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, 0, e->raster_words, e->raster_iwords, &pl);
-    size_t budget = 60 * 1024, per_item = (size_t)H * e->raster_words * 8;
-    int chunk = pl.total + per_item > budget ? 1 : (int)((budget - pl.total) / per_item);
-    if (chunk > e->raster_items) chunk = e->raster_items;
-    if (chunk < 1) chunk = 1;
-    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, chunk, e->raster_words, e->raster_iwords, &pl);
+    // coverage-mask buffer: at most 512 rows per pass (>= H so any item fits)
+    int cap = e->raster_items * H;
+    if (cap > 512) cap = 512;
+    if (cap < H) cap = H;
+    int chunk = cap;
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_words, e->raster_iwords, &pl);
     if (pl.total > 160 * 1024) {
       hipFree(e->d_prog); hipFree(e->d_vslot); delete e;
       return fail(MOOG_E_UNSUPPORTED, "raster working set does not fit in LDS");
@@ -351,6 +351,7 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   r.vslot = e->d_vslot;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
   r.iwords = e->raster_iwords; r.max_items = e->raster_items;
+  { const char* ds = getenv("MOOG_RASTER_STOP"); r.debug_stop = ds ? atoi(ds) : 0; }
   {
     Bracket br(e, MOOG_K_RASTER, s);
     hipLaunchKernelGGL(moog_raster_kernel, dim3(e->n_envs), dim3(R_THREADS), e->raster_lds, s, r);

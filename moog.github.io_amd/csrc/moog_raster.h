@@ -4,24 +4,26 @@
 // ImagingDrawPolygon / polygon_generic(hasAlpha=1) / hline32rgba as restated and
 // fuzz-validated against Pillow 12.2.0 in oracle/moog_oracle.c).
 //
-// One 256-thread workgroup renders one env's frame; everything between reading
-// the sprite vertices (coalesced 16 B/lane) and writing the uint8 frame
-// (coalesced 16 B/lane, written exactly once) stays in LDS / registers:
+// One wavefront (a 64-thread workgroup) renders one env's frame -- the phases
+// below have very different widths, and with one wave per env nobody waits at a
+// workgroup barrier: latency is hidden by the other envs' waves on the CU.
+// Everything between reading the sprite vertices (coalesced 16 B/lane) and
+// writing the uint8 frame (each byte written exactly once, 3 x dwordx4 per lane
+// over a contiguous 3 KB span per wave) stays in LDS / registers:
 //   1  vertices -> integer canvas coordinates ((int)(W*x), one thread per vertex
 //      per polygon copy), per-item row ranges by LDS atomics, per-item RGBA
 //   2  one thread per edge: slope, horizontal-run merging (ImagingDrawPolygon)
 //   3  compact work list of (item, row) pairs that actually intersect the canvas
 //   4  one thread per (item, row): Pillow's scanline -> 64/128-bit coverage mask
 //   5  one thread per 16-pixel row segment: compose the covering items in
-//      painter's order (one blend per covered pixel), RGBX in registers
-//   6  pack to RGB, flip rows (np.flipud) in LDS, stream out with dwordx4 stores
+//      painter's order (one blend per covered pixel), RGBX in registers, pack
+//      to RGB and store to the flipped row (np.flipud)
 // HBM-bound by construction: algorithmic bytes = H*W*3 + live vertices * 16.
 #pragma once
 #include "moog_device.h"
 
-#define R_THREADS 256
+#define R_THREADS 64
 #define R_XX 24      // max crossings kept per scanline
-#define R_MAXSEG 4   // 16-pixel segments per thread (<= 128x128 frames)
 
 struct RArgs {
   const moog_program_t* P;
@@ -31,39 +33,49 @@ struct RArgs {
   uint8_t* image;
   const int16_t* vslot;
   int32_t n_envs;
-  int32_t chunk;       // items per pass (masks are sized for chunk * H rows)
+  int32_t chunk;       // row capacity of the coverage-mask buffer (rows per pass)
   int32_t words;       // 64-bit words per row mask
   int32_t iwords;      // 32-bit words of the per-row item bitmask
   int32_t max_items;   // S * copies
+  int32_t debug_stop;  // >0: return after that phase (profiling aid)
 };
 
 // LDS plan shared by host (sizes) and device (carve-up)
 struct RPlan {
-  size_t o_ivert, o_dx, o_eflag, o_hx1, o_slotinfo, o_item_slot, o_item_y, o_item_rgba, o_rowoff,
-      o_rowitems, o_masks, o_xx, o_frame, o_misc, total;
+  size_t o_ivert, o_edge, o_eflag, o_slotinfo, o_item_slot, o_item_y, o_item_rgba, o_item_cnt,
+      o_rowoff, o_rowitems, o_masks, o_xx, o_frame, o_misc, total;
 };
+
+// Edge record, 16 bytes.  Table (non-horizontal) edges: x0, y0, y1, dx.
+// Horizontal heads: x0 = xmin, y0 = y, y1 = xmax (dx unused).  Per polygon the
+// table edges are packed from the front of its region (in edge order), the
+// horizontal heads from the back (in edge order going backwards).
+struct REdge { short x0, y0, y1, x1; float dx; float pad; };
 
 __host__ __device__ inline size_t r_align(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, int H, int chunk,
+__host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, int H, int cap_rows,
                                             int words, int iwords, RPlan* p) {
   size_t o = 0;
   size_t nv = (size_t)TOTV * ncopy, items = (size_t)S * ncopy;
-  p->o_ivert = o; o = r_align(o + nv * 4);            // short2 per copy-vertex
-  p->o_dx = o; o = r_align(o + nv * 4);               // float slope of edge k -> k+1
-  p->o_hx1 = o; o = r_align(o + nv * 2);              // short: merged end x of horizontal heads
-  p->o_eflag = o; o = r_align(o + nv);                // 0 none, 1 table edge, 2 horizontal head
+  p->o_edge = o; o = r_align(o + nv * sizeof(REdge)); // packed edge records
   p->o_slotinfo = o; o = r_align(o + (size_t)S * 8);  // per slot: rank (int), nverts (int)
   p->o_item_slot = o; o = r_align(o + items * 4);     // slot | copy << 16
   p->o_item_y = o; o = r_align(o + items * 8);        // ymin, ymax (ints, atomics)
   p->o_item_rgba = o; o = r_align(o + items * 4);
+  p->o_item_cnt = o; o = r_align(o + items * 4);      // n_table | n_heads << 16
   p->o_rowoff = o; o = r_align(o + (items + 1) * 4);
   p->o_rowitems = o; o = r_align(o + (size_t)H * iwords * 4);
-  p->o_masks = o; o = r_align(o + (size_t)chunk * H * words * 8);
-  p->o_xx = o; o = r_align(o + (size_t)R_XX * R_THREADS * 4);
-  p->o_frame = o; o = r_align(o + (size_t)H * W * 3);
   p->o_misc = o; o = r_align(o + 64);
-  p->total = o;
+  // union: {integer vertices, edge classes} are dead once the edge records are
+  // packed; {coverage masks, crossing lists} live only afterwards
+  size_t u = o;
+  p->o_ivert = u; size_t e1 = r_align(u + nv * 4);
+  p->o_eflag = e1; e1 = r_align(e1 + nv);
+  p->o_masks = u; size_t e2 = r_align(u + (size_t)cap_rows * words * 8);
+  p->o_xx = e2; e2 = r_align(e2 + (size_t)R_XX * R_THREADS * 4);
+  p->o_frame = 0;
+  p->total = e1 > e2 ? e1 : e2;
 }
 
 __device__ inline int pil_round_up(float f) {
@@ -117,23 +129,20 @@ __device__ inline void mask_fill(RMask& m, int W, int x0, int x1) {
   }
 }
 
-// view of one polygon's edge data in LDS (edge k runs vertex k -> (k+1) % n)
+// view of one polygon's packed edge records in LDS
 struct RPoly {
-  const short2* v;
-  const float* dx;
-  const short* hx1;
-  const unsigned char* fl;
-  int n;
+  const REdge* e;   // region of n records
+  int n;            // region size (= vertex count)
+  int nt;           // table edges  e[0 .. nt)
+  int nh;           // horizontal heads e[n-1], e[n-2], ... (nh of them)
 };
 
-// Draw.c draw_horizontal_lines
+// Draw.c draw_horizontal_lines (heads visited in edge order)
 __device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask& m, int W) {
-  for (int i = 0; i < p.n; ++i) {
-    if (p.fl[i] != 2) continue;
-    short2 a = p.v[i];
-    if (a.y != y) continue;
-    int xa = a.x, xb = p.hx1[i];
-    int xmin = xa < xb ? xa : xb, xmax = xa < xb ? xb : xa;
+  for (int i = 0; i < p.nh; ++i) {
+    REdge h = p.e[p.n - 1 - i];
+    if (h.y0 != y) continue;
+    int xmin = h.x0, xmax = h.y1;
     if (*x_pos != -1 && *x_pos < xmin) continue;
     if (*x_pos > xmin) {
       xmin = *x_pos;
@@ -144,68 +153,96 @@ __device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask&
   }
 }
 
+// polygon_generic's corner fix-up for table edge i on row y (its first row when
+// `top`, else its last row): the first earlier table edge k that is active on the
+// row, leans the same way, shares the tip and crosses the row at the same x gets
+// its entry replaced so that the tip row's span meets the adjacent row's span.
+// Returns k (or -1) and the replacement value.
+__device__ inline int tip_partner(const REdge* e, int i, bool top, float* vv_out) {
+  REdge E = e[i];
+  float dx = E.dx;
+  if (dx == 0.0f) return -1;
+  int y0 = E.y0, y1 = E.y1;
+  int y = top ? (y0 < y1 ? y0 : y1) : (y0 < y1 ? y1 : y0);
+  float x = (float)(y - y0) * dx + (float)E.x0;
+  // An edge's crossing of its own end row is within 1e-3 of that end point, so
+  // only edges ending at the same integer point can compare equal below.
+  const int tipx = (y == y0) ? E.x0 : E.x1;
+  const short* raw = reinterpret_cast<const short*>(e);
+  for (int k = 0; k < i; ++k) {
+    int ky0 = raw[8 * k + 1], ky1 = raw[8 * k + 2];
+    int ktip = top ? (ky0 < ky1 ? ky0 : ky1) : (ky0 < ky1 ? ky1 : ky0);
+    if (ktip != y) continue;
+    int ktx = (ktip == ky0) ? raw[8 * k] : raw[8 * k + 3];
+    if (ktx != tipx) continue;
+    REdge K = e[k];
+    float kdx = K.dx;
+    if ((dx > 0 && kdx <= 0) || (dx < 0 && kdx >= 0)) continue;
+    if (x != (float)(y - ky0) * kdx + (float)K.x0) continue;
+    int off = top ? 1 : -1;
+    float adj = (float)(y + off - y0) * dx + (float)E.x0;
+    float adjo = (float)(y + off - ky0) * kdx + (float)K.x0;
+    if (adj > x && adjo > x) {
+      float vv = (float)(pil_round_up(fminf(adj, adjo)) - 1);
+      if (vv > x) { *vv_out = vv; return k; }
+    } else if (adj < x && adjo < x) {
+      float vv = (float)(pil_round_up(fmaxf(adj, adjo)) + 1);
+      if (vv < x) { *vv_out = vv; return k; }
+    }
+    return -1;   // the reference stops at the first matching edge
+  }
+  return -1;
+}
+
 // Coverage of scanline y of one polygon: polygon_generic(hasAlpha=1), one row.
 // xx: this thread's crossing list, element j at xx[j * R_THREADS].
-__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, float* xx, int W) {
+__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, float* xx, int W, int dbg) {
   RMask m = {0ull, 0ull};
   int j = 0;
-  for (int i = 0; i < p.n; ++i) {
-    if (p.fl[i] != 1) continue;
-    int i2 = (i + 1 == p.n) ? 0 : i + 1;
-    short2 a = p.v[i], b = p.v[i2];
-    int y0 = a.y, y1 = b.y;
+  if (dbg == 51) return m;
+  for (int i = 0; i < p.nt; ++i) {
+    REdge E = p.e[i];
+    int y0 = E.y0, y1 = E.y1;
     int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
     if (y < emin || y > emax) continue;
-    float dx = p.dx[i];
-    float x = (float)(y - y0) * dx + (float)a.x;
+    float dx = E.dx;
+    float x = (float)(y - y0) * dx + (float)E.x0;
     if (j < R_XX) xx[j * R_THREADS] = x;
     ++j;
     if (y == emax && y < poly_ymax) {
       if (j < R_XX) xx[j * R_THREADS] = x;
       ++j;
-    } else if (dx != 0.0f) {
-      // connect discontiguous corners (a tip whose two edges lean the same way)
-      int jj = 0;
-      for (int k = 0; k < i; ++k) {
-        if (p.fl[k] != 1) continue;
-        int k2 = (k + 1 == p.n) ? 0 : k + 1;
-        short2 ka = p.v[k], kb = p.v[k2];
-        int ky0 = ka.y, ky1 = kb.y;
-        int kmin = ky0 < ky1 ? ky0 : ky1, kmax = ky0 < ky1 ? ky1 : ky0;
-        if (y < kmin || y > kmax) continue;
-        int kpos = jj;
-        jj += (y == kmax && y < poly_ymax) ? 2 : 1;
-        float kdx = p.dx[k];
-        if ((dx > 0 && kdx <= 0) || (dx < 0 && kdx >= 0)) continue;
-        bool top = (y == emin && y == kmin), bot = (y == emax && y == kmax);
-        if (!(top || bot)) continue;
-        if (x != (float)(y - ky0) * kdx + (float)ka.x) continue;
-        int off = top ? 1 : -1;
-        float adj = (float)(y + off - y0) * dx + (float)a.x;
-        float adjo = (float)(y + off - ky0) * kdx + (float)ka.x;
-        if (adj > x && adjo > x) {
-          float vv = (float)(pil_round_up(fminf(adj, adjo)) - 1);
-          if (vv > x && kpos < R_XX) xx[kpos * R_THREADS] = vv;
-        } else if (adj < x && adjo < x) {
-          float vv = (float)(pil_round_up(fmaxf(adj, adjo)) + 1);
-          if (vv < x && kpos < R_XX) xx[kpos * R_THREADS] = vv;
+    } else if (dx != 0.0f && (y == emin || y == emax)) {
+      // connect discontiguous corners: only a row at an end point of this edge can
+      // share a tip; the partner's entry on this row is overwritten
+      float vv = 0.0f;
+      int kt = tip_partner(p.e, i, y == emin, &vv);
+      if (kt >= 0) {
+        int kpos = 0;
+        for (int k = 0; k < kt; ++k) {
+          REdge K = p.e[k];
+          int kmin = K.y0 < K.y1 ? K.y0 : K.y1, kmax = K.y0 < K.y1 ? K.y1 : K.y0;
+          if (y < kmin || y > kmax) continue;
+          kpos += (y == kmax && y < poly_ymax) ? 2 : 1;
         }
-        break;
+        if (kpos < R_XX) xx[kpos * R_THREADS] = vv;
       }
     }
   }
   if (j > R_XX) j = R_XX;
+  if (dbg == 52) { m.w0 = j; return m; }
   for (int q = 1; q < j; ++q) {  // insertion sort (qsort with x_cmp)
     float key = xx[q * R_THREADS];
     int r = q - 1;
     while (r >= 0 && xx[r * R_THREADS] > key) { xx[(r + 1) * R_THREADS] = xx[r * R_THREADS]; --r; }
     xx[(r + 1) * R_THREADS] = key;
   }
+  if (dbg == 53) { m.w0 = j; return m; }
   int x_pos = (j == 0) ? -1 : 0;
   for (int i = 1; i < j; i += 2) {
     int x_end = pil_round_down(xx[i * R_THREADS]);
     if (x_end < x_pos) continue;
-    draw_horizontal(p, y, &x_pos, m, W);
+    if (p.nh) draw_horizontal(p, y, &x_pos, m, W);
     if (x_end < x_pos) continue;
     int x_start = pil_round_up(xx[(i - 1) * R_THREADS]);
     if (x_pos > x_start) {
@@ -215,7 +252,7 @@ __device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, floa
     mask_fill(m, W, x_start, x_end);
     x_pos = x_end + 1;
   }
-  draw_horizontal(p, y, &x_pos, m, W);
+  if (p.nh) draw_horizontal(p, y, &x_pos, m, W);
   return m;
 }
 
@@ -233,61 +270,56 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const int S = P->n_slots, TOTV = a.L.TOTV;
   const bool torus = (P->render.polymod == MOOG_POLYMOD_TORUS);
   const int ncopy = torus ? 9 : 1;
-  const int words = a.words, iwords = a.iwords, chunk = a.chunk;
+  const int words = a.words, iwords = a.iwords, cap_rows = a.chunk;
   const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   const int tid = threadIdx.x;
 
   RPlan pl;
-  raster_plan(S, TOTV, ncopy, W, H, chunk, words, iwords, &pl);
+  raster_plan(S, TOTV, ncopy, W, H, cap_rows, words, iwords, &pl);
   short2* ivert = reinterpret_cast<short2*>(moog_lds + pl.o_ivert);
-  float* edx = reinterpret_cast<float*>(moog_lds + pl.o_dx);
-  short* hx1 = reinterpret_cast<short*>(moog_lds + pl.o_hx1);
+  REdge* edges = reinterpret_cast<REdge*>(moog_lds + pl.o_edge);
   unsigned char* eflag = moog_lds + pl.o_eflag;
   int* slotinfo = reinterpret_cast<int*>(moog_lds + pl.o_slotinfo);
   int* item_slot = reinterpret_cast<int*>(moog_lds + pl.o_item_slot);
   int* item_y = reinterpret_cast<int*>(moog_lds + pl.o_item_y);
   unsigned* item_rgba = reinterpret_cast<unsigned*>(moog_lds + pl.o_item_rgba);
+  int* item_cnt = reinterpret_cast<int*>(moog_lds + pl.o_item_cnt);
   int* rowoff = reinterpret_cast<int*>(moog_lds + pl.o_rowoff);
   unsigned* rowitems = reinterpret_cast<unsigned*>(moog_lds + pl.o_rowitems);
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(moog_lds + pl.o_masks);
   float* xxs = reinterpret_cast<float*>(moog_lds + pl.o_xx);
-  uint8_t* frame = moog_lds + pl.o_frame;
-  int* misc = reinterpret_cast<int*>(moog_lds + pl.o_misc);  // [0] n_live
 
   // ---- 0: live sprites in slot (= layer, list) order; per-sprite colour ----------------
-  if (tid < 64) {
-    int base = 0;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-      int s = s0 + tid;
-      bool live = false;
-      int nv = 0;
-      if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
-      unsigned long long bal = __ballot(live);
-      int rank = base + __popcll(bal & ((1ull << tid) - 1ull));
-      if (s < S) { slotinfo[2 * s] = live ? rank : -1; slotinfo[2 * s + 1] = nv; }
-      if (live) {
-        unsigned r8, g8, b8;
-        const double* col = gf + a.L.o_color + 3 * s;
-        if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
-        else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
-        unsigned a8 = (unsigned)gq[a.L.o_opacity + s] & 255u;
-        unsigned rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-        for (int c = 0; c < ncopy; ++c) {
-          int it = rank * ncopy + c;
-          item_slot[it] = s | (c << 16);
-          item_rgba[it] = rgba;
-          item_y[2 * it] = 0x7fffffff;
-          item_y[2 * it + 1] = -0x7fffffff;
-        }
+  int n_live = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    int s = s0 + tid;
+    bool live = false;
+    int nv = 0;
+    if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
+    unsigned long long bal = __ballot(live);
+    int rank = n_live + __popcll(bal & ((1ull << tid) - 1ull));
+    if (s < S) { slotinfo[2 * s] = live ? rank : -1; slotinfo[2 * s + 1] = nv; }
+    if (live) {
+      unsigned r8, g8, b8;
+      const double* col = gf + a.L.o_color + 3 * s;
+      if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
+      else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
+      unsigned a8 = (unsigned)gq[a.L.o_opacity + s] & 255u;
+      unsigned rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+      for (int c = 0; c < ncopy; ++c) {
+        int it = rank * ncopy + c;
+        item_slot[it] = s | (c << 16);
+        item_rgba[it] = rgba;
+        item_y[2 * it] = 0x7fffffff;
+        item_y[2 * it + 1] = -0x7fffffff;
       }
-      base += __popcll(bal);
     }
-    if (tid == 0) misc[0] = base;
+    n_live += __popcll(bal);
   }
-  __syncthreads();
-  const int n_live = misc[0];
+  wsync();
   const int total_items = n_live * ncopy;
+  if (a.debug_stop == 1) return;
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
@@ -307,8 +339,9 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       atomicMax(&item_y[2 * it + 1], (int)o.y);
     }
   }
-  __syncthreads();
-  // ---- 2: edges (ImagingDrawPolygon: add_edge + merge of consecutive horizontal runs) ---
+  wsync();
+  if (a.debug_stop == 2) return;
+  // ---- 2a: classify edges (ImagingDrawPolygon: add_edge + merge of horizontal runs) -----
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     int s = a.vslot[idx];
     int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
@@ -321,158 +354,189 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       short2 p0 = pv[k], p1 = pv[k2];
       bool closing = (k == nv - 1);
       unsigned char fl;
-      float dx = 0.0f;
-      short hx = p1.x;
       bool horiz = (p0.y == p1.y);
       if (closing && p0.x == p1.x && p0.y == p1.y) fl = 0;   // last == first: no closing edge
-      else if (!horiz) { fl = 1; dx = ((float)(p1.x - p0.x)) / (float)(p1.y - p0.y); }
+      else if (!horiz) fl = 1;
       else {
         bool absorbed = false;
         if (k >= 1 && !closing) {
           short2 pp = pv[k - 1];
           if (pp.y == p0.y) absorbed = (p1.x > p0.x && p0.x > pp.x) || (p1.x < p0.x && p0.x < pp.x);
         }
-        if (absorbed) fl = 0;
-        else {
-          fl = 2;
-          // extend over the following absorbed horizontal edges (never the closing edge)
-          int j = k + 1;
-          short2 prev = p0, cur = p1;
-          while (j <= nv - 2) {
-            short2 nxt = pv[j + 1];
-            bool ab = (cur.y == nxt.y) && (prev.y == cur.y) &&
-                      ((nxt.x > cur.x && cur.x > prev.x) || (nxt.x < cur.x && cur.x < prev.x));
-            if (!ab) break;
-            hx = nxt.x; prev = cur; cur = nxt; ++j;
-          }
-        }
+        fl = absorbed ? 0 : 2;
       }
       eflag[c * TOTV + idx] = fl;
-      edx[c * TOTV + idx] = dx;
-      hx1[c * TOTV + idx] = hx;
     }
   }
+  wsync();
+  // ---- 2b: pack edge records: table edges from the front, horizontal heads from the back ---
+  for (int idx = tid; idx < TOTV; idx += R_THREADS) {
+    int s = a.vslot[idx];
+    int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
+    int v0 = P->slot_voff[s];
+    int k = idx - v0;
+    if (rank < 0 || k >= nv) continue;
+    for (int c = 0; c < ncopy; ++c) {
+      const short2* pv = ivert + c * TOTV + v0;
+      const unsigned char* pf = eflag + c * TOTV + v0;
+      int nt = 0, nh = 0;
+      for (int q = 0; q < k; ++q) { unsigned char f = pf[q]; nt += (f == 1); nh += (f == 2); }
+      unsigned char fl = pf[k];
+      int k2 = (k + 1 == nv) ? 0 : k + 1;
+      short2 p0 = pv[k], p1 = pv[k2];
+      REdge* reg = edges + c * TOTV + v0;
+      if (fl == 1) {
+        REdge E; E.x0 = p0.x; E.y0 = p0.y; E.y1 = p1.y; E.x1 = p1.x; E.pad = 0.0f;
+        E.dx = ((float)(p1.x - p0.x)) / (float)(p1.y - p0.y);
+        reg[nt] = E;
+      } else if (fl == 2) {
+        short hx = p1.x;
+        int q = k + 1;   // extend over the following absorbed edges (never the closing edge)
+        while (q <= nv - 2 && pf[q] == 0) { hx = pv[q + 1].x; ++q; }
+        REdge E;
+        E.x0 = p0.x < hx ? p0.x : hx; E.y0 = p0.y; E.y1 = p0.x < hx ? hx : p0.x; E.dx = 0.0f;
+        E.x1 = 0; E.pad = 0.0f;
+        reg[nv - 1 - nh] = E;
+      }
+      if (k == nv - 1) item_cnt[rank * ncopy + c] = (nt + (fl == 1)) | ((nh + (fl == 2)) << 16);
+    }
+  }
+  if (a.debug_stop == 3) return;
 
-  // 16-pixel row segments owned by this thread, RGBX per pixel
-  const int segs = (H * W) / 16;
+  // ---- 3: exclusive scan of the clamped row counts of all items -------------------------
+  {
+    int run = 0;
+    for (int i0 = 0; i0 < total_items; i0 += 64) {
+      int it = i0 + tid;
+      int cnt = 0;
+      if (it < total_items) {
+        int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
+        if (y0 < 0) y0 = 0;
+        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
+        cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
+      }
+      int inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (tid >= o) inc += t;
+      }
+      if (it < total_items) rowoff[it] = run + inc - cnt;
+      run += __shfl(inc, 63);
+    }
+    if (tid == 0) rowoff[total_items] = run;
+  }
+  wsync();   // also: ivert / eflag are dead from here on (masks / xx alias them)
+  if (a.debug_stop == 4) return;
+
+  const int segs = (H * W) / 16;   // 16-pixel row segments
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
                        (((unsigned)P->render.bg[2] & 255u) << 16);
-  unsigned px[R_MAXSEG][16];
-#pragma unroll
-  for (int k = 0; k < R_MAXSEG; ++k)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) px[k][i] = bgx;
+  uint8_t* out = a.image + (size_t)env * H * W * 3;
+  const bool single_pass = (rowoff[total_items] <= cap_rows);
 
-  for (int base = 0; base < total_items; base += chunk) {
-    int nit = total_items - base;
-    if (nit > chunk) nit = chunk;
-    __syncthreads();
-    // ---- 3: compact (item, row) work list: exclusive scan of clamped row counts ---------
-    for (int i = tid; i < H * iwords; i += R_THREADS) rowitems[i] = 0u;
-    if (tid < 64) {
-      int run = 0;
-      for (int i0 = 0; i0 < nit; i0 += 64) {
-        int it = i0 + tid;
-        int cnt = 0;
-        if (it < nit) {
-          int y0 = item_y[2 * (base + it)], y1 = item_y[2 * (base + it) + 1];
-          if (y0 < 0) y0 = 0;
-          if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
-          cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
-        }
-        int inc = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-          int t = __shfl_up(inc, o);
-          if (tid >= o) inc += t;
-        }
-        if (it < nit) rowoff[it] = run + inc - cnt;
-        run += __shfl(inc, 63);
-      }
-      if (tid == 0) rowoff[nit] = run;
+  // passes: as many whole items as fit in the mask buffer (cap_rows >= H); with more
+  // than one pass the partially composed frame round-trips through `out` (L2)
+  for (int base = 0; base < total_items || base == 0;) {
+    const int r0 = rowoff[base];
+    int lo = base + 1, hi = total_items;   // largest end with rowoff[end] - r0 <= cap_rows
+    if (total_items == 0) { lo = hi = 0; }
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (rowoff[mid] - r0 <= cap_rows) lo = mid; else hi = mid - 1;
     }
-    __syncthreads();
-    const int total_rows = rowoff[nit];
+    const int end = lo;
+    const int total_rows = rowoff[end] - r0;
+    for (int i = tid; i < H * iwords; i += R_THREADS) rowitems[i] = 0u;
+    wsync();
     // ---- 4: coverage masks, one thread per (item, row) ------------------------------------
     for (int w = tid; w < total_rows; w += R_THREADS) {
-      int lo = 0, hi = nit - 1;   // last item with rowoff <= w
-      while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (rowoff[mid] <= w) lo = mid; else hi = mid - 1;
+      int l2 = base, h2 = end - 1;   // last item with rowoff <= r0 + w
+      while (l2 < h2) {
+        int mid = (l2 + h2 + 1) >> 1;
+        if (rowoff[mid] - r0 <= w) l2 = mid; else h2 = mid - 1;
       }
-      int it = lo, g = base + it;
+      int g = l2, it = g - base;
       int ymin = item_y[2 * g], ymax = item_y[2 * g + 1];
       int ystart = ymin < 0 ? 0 : ymin;
-      int y = ystart + (w - rowoff[it]);
+      int y = ystart + (w - (rowoff[g] - r0));
       int pymax = ymax > H ? H : ymax;              // polygon_generic clamps ymax to ysize
       int sc = item_slot[g];
       int s = sc & 0xffff, c = sc >> 16;
-      int v0 = c * TOTV + P->slot_voff[s];
-      RPoly poly = {ivert + v0, edx + v0, hx1 + v0, eflag + v0, slotinfo[2 * s + 1]};
-      RMask m = scanline_mask(poly, y, pymax, xxs + tid, W);
+      int cnt = item_cnt[g];
+      RPoly poly = {edges + c * TOTV + P->slot_voff[s], slotinfo[2 * s + 1], cnt & 0xffff, cnt >> 16};
+      RMask m = scanline_mask(poly, y, pymax, xxs + tid, W, a.debug_stop);
       masks[(size_t)w * words] = m.w0;
       if (words > 1) masks[(size_t)w * words + 1] = m.w1;
       if (m.w0 | m.w1) atomicOr(&rowitems[y * iwords + (it >> 5)], 1u << (it & 31));
     }
-    __syncthreads();
-    // ---- 5: compose, painter's order = item order -------------------------------------------
+    wsync();
+    if (a.debug_stop == 5 || a.debug_stop > 50) return;
+    // ---- 5: compose (painter's order = item order), pack RGB, store flipped ------------------
+    for (int seg = tid; seg < segs; seg += R_THREADS) {
+      int y = (seg * 16) / W, x0 = (seg * 16) % W;
+      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(H - 1 - y) * W + x0) * 3);
+      unsigned px[16];
+      if (base == 0) {
 #pragma unroll
-    for (int k = 0; k < R_MAXSEG; ++k) {
-      int seg = tid + k * R_THREADS;
-      if (seg < segs) {
-        int y = (seg * 16) / W, x0 = (seg * 16) % W;
-        for (int iw = 0; iw < iwords; ++iw) {
-          unsigned bitsw = rowitems[y * iwords + iw];
-          while (bitsw) {
-            int b = __ffs((int)bitsw) - 1;
-            bitsw &= bitsw - 1;
-            int it = iw * 32 + b, g = base + it;
-            int ymin = item_y[2 * g];
-            int ystart = ymin < 0 ? 0 : ymin;
-            size_t w = (size_t)rowoff[it] + (y - ystart);
-            unsigned long long mw = masks[w * words + (x0 >> 6)];
-            unsigned bits = (unsigned)(mw >> (x0 & 63)) & 0xFFFFu;
-            if (!bits) continue;
-            unsigned rgba = item_rgba[g];
-            unsigned al = rgba >> 24;
-            if (al == 255u) {
-              unsigned fg = rgba & 0xFFFFFFu;
+        for (int i = 0; i < 16; ++i) px[i] = bgx;
+      } else {  // continue from the previous pass
+        uint4 q0 = dst[0], q1 = dst[1], q2 = dst[2];
+        unsigned d[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
-              for (int i = 0; i < 16; ++i) px[k][i] = (bits & (1u << i)) ? fg : px[k][i];
-            } else {
-              unsigned f0 = rgba & 255u, f1 = (rgba >> 8) & 255u, f2 = (rgba >> 16) & 255u;
+        for (int q = 0; q < 4; ++q) {
+          px[4 * q] = d[3 * q] & 0xFFFFFFu;
+          px[4 * q + 1] = (d[3 * q] >> 24) | ((d[3 * q + 1] & 0xFFFFu) << 8);
+          px[4 * q + 2] = (d[3 * q + 1] >> 16) | ((d[3 * q + 2] & 0xFFu) << 16);
+          px[4 * q + 3] = d[3 * q + 2] >> 8;
+        }
+      }
+      for (int iw = 0; iw < iwords; ++iw) {
+        unsigned bitsw = rowitems[y * iwords + iw];
+        while (bitsw) {
+          int b = __ffs((int)bitsw) - 1;
+          bitsw &= bitsw - 1;
+          int g = base + iw * 32 + b;
+          int ymin = item_y[2 * g];
+          int ystart = ymin < 0 ? 0 : ymin;
+          size_t w = (size_t)(rowoff[g] - r0) + (y - ystart);
+          unsigned long long mw = masks[w * words + (x0 >> 6)];
+          unsigned bits = (unsigned)(mw >> (x0 & 63)) & 0xFFFFu;
+          if (!bits) continue;
+          unsigned rgba = item_rgba[g];
+          unsigned al = rgba >> 24;
+          if (al == 255u) {
+            unsigned fg = rgba & 0xFFFFFFu;
 #pragma unroll
-              for (int i = 0; i < 16; ++i) {
-                if (bits & (1u << i)) {
-                  unsigned o = px[k][i];
-                  px[k][i] = blend8(o & 255u, f0, al) | (blend8((o >> 8) & 255u, f1, al) << 8) |
-                             (blend8((o >> 16) & 255u, f2, al) << 16);
-                }
+            for (int i = 0; i < 16; ++i) px[i] = (bits & (1u << i)) ? fg : px[i];
+          } else {
+            unsigned f0 = rgba & 255u, f1 = (rgba >> 8) & 255u, f2 = (rgba >> 16) & 255u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              if (bits & (1u << i)) {
+                unsigned o = px[i];
+                px[i] = blend8(o & 255u, f0, al) | (blend8((o >> 8) & 255u, f1, al) << 8) |
+                        (blend8((o >> 16) & 255u, f2, al) << 16);
               }
             }
           }
         }
       }
-    }
-  }
-  __syncthreads();
-  // ---- 6: RGBX -> RGB, rows flipped (np.flipud), then 16-byte coalesced stores --------------
-#pragma unroll
-  for (int k = 0; k < R_MAXSEG; ++k) {
-    int seg = tid + k * R_THREADS;
-    if (seg < segs) {
-      int y = (seg * 16) / W, x0 = (seg * 16) % W;
-      unsigned* dst = reinterpret_cast<unsigned*>(frame + ((size_t)(H - 1 - y) * W + x0) * 3);
+      unsigned d[12];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {   // 4 pixels (RGBX) -> 3 dwords (RGB)
-        unsigned p0 = px[k][4 * q], p1 = px[k][4 * q + 1], p2 = px[k][4 * q + 2], p3 = px[k][4 * q + 3];
-        dst[3 * q] = (p0 & 0xFFFFFFu) | (p1 << 24);
-        dst[3 * q + 1] = ((p1 >> 8) & 0xFFFFu) | (p2 << 16);
-        dst[3 * q + 2] = ((p2 >> 16) & 0xFFu) | (p3 << 8);
+        unsigned p0 = px[4 * q], p1 = px[4 * q + 1], p2 = px[4 * q + 2], p3 = px[4 * q + 3];
+        d[3 * q] = (p0 & 0xFFFFFFu) | (p1 << 24);
+        d[3 * q + 1] = ((p1 >> 8) & 0xFFFFu) | (p2 << 16);
+        d[3 * q + 2] = ((p2 >> 16) & 0xFFu) | (p3 << 8);
       }
+      dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+      dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+      dst[2] = make_uint4(d[8], d[9], d[10], d[11]);
     }
+    (void)single_pass;
+    if (end >= total_items) break;
+    base = end;
+    __threadfence_block();
+    wsync();
   }
-  __syncthreads();
-  const uint4* src = reinterpret_cast<const uint4*>(frame);
-  uint4* out = reinterpret_cast<uint4*>(a.image + (size_t)env * H * W * 3);
-  for (int i = tid; i < (H * W * 3) / 16; i += R_THREADS) out[i] = src[i];
 }

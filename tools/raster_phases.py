@@ -1,0 +1,21 @@
+"""Times the raster kernel truncated after each phase (MOOG_RASTER_STOP)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'moog.github.io_amd'))
+import torch
+from moog import environment, _abi
+from moog_demos import example_configs
+name = sys.argv[1] if len(sys.argv) > 1 else 'colliding_predators_32'
+env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.load(name))
+env.reset()
+for _ in range(3):
+    env.step(env.random_action())
+for stop in (2, 3, 5, 0):
+    os.environ['MOOG_RASTER_STOP'] = str(stop)
+    for _ in range(3):
+        env.observation()
+    env.set_timing(True); env.kernel_time(_abi.MOOG_K_RASTER)
+    for _ in range(20):
+        env.observation()
+    ms, n = env.kernel_time(_abi.MOOG_K_RASTER)
+    env.set_timing(False)
+    print('stop after phase %d: %.1f us' % (stop, ms / n * 1e3))
