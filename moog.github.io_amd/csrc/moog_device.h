@@ -36,6 +36,7 @@ struct Env {
   double* bb;              // LDS scratch [S][4]: conservative AABB (xmin, ymin, xmax, ymax)
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
+  int32_t* lst;            // LDS scratch [128]: compacted edge index lists
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -162,31 +163,70 @@ __device__ inline bool point_in_poly(const double* v, int n, double tx, double t
   return inside != 0;
 }
 
-// Path.intersects_path(a, b, filled=True); lanes = segment pairs, then vertices.
-// Wave-uniform result.
+// Path.intersects_path(a, b, filled=True).  Wave-uniform result.
+// Exact shortcuts (never change the result, see BB_MARGIN below): only edges of a
+// whose own box reaches b's box (and vice versa) can intersect anything, so those
+// are compacted first and the lanes enumerate just the surviving edge pairs; the
+// "every vertex of b inside a" test needs b's box inside a's box.
+#define BB_MARGIN 1e-6
 __device__ inline bool paths_intersect_filled(const Env& e, const double* va, int na,
-                                              const double* vb, int nb) {
-  int total = na * nb;
-  for (int base = 0; base < total; base += 64) {
-    int idx = base + e.lane;
-    bool hit = false;
-    if (idx < total) {
-      int i = idx / nb, j = idx - i * nb;
-      int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
-      double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
-      double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
-      bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
-      bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
-      if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
-    }
-    if (__ballot(hit) != 0ull) return true;
+                                              const double* vb, int nb, const double* ba,
+                                              const double* bbx) {
+  // ba / bbx: conservative boxes (xmin, ymin, xmax, ymax) of a and b
+  bool ka = false, kb = false;
+  if (e.lane < na) {
+    int i2 = (e.lane + 1 == na) ? 0 : e.lane + 1;
+    double x1 = va[2 * e.lane], y1 = va[2 * e.lane + 1], x2 = va[2 * i2], y2 = va[2 * i2 + 1];
+    ka = !(fmin(x1, x2) > bbx[2] + BB_MARGIN || fmax(x1, x2) < bbx[0] - BB_MARGIN ||
+           fmin(y1, y2) > bbx[3] + BB_MARGIN || fmax(y1, y2) < bbx[1] - BB_MARGIN);
+    // NaN coordinates: comparisons are false -> edge kept (conservative)
   }
-  if (na + 1 >= 3 && nb > 0) {
+  if (e.lane < nb) {
+    int j2 = (e.lane + 1 == nb) ? 0 : e.lane + 1;
+    double x1 = vb[2 * e.lane], y1 = vb[2 * e.lane + 1], x2 = vb[2 * j2], y2 = vb[2 * j2 + 1];
+    kb = !(fmin(x1, x2) > ba[2] + BB_MARGIN || fmax(x1, x2) < ba[0] - BB_MARGIN ||
+           fmin(y1, y2) > ba[3] + BB_MARGIN || fmax(y1, y2) < ba[1] - BB_MARGIN);
+  }
+  unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+  int ca = __popcll(ma), cb = __popcll(mb);
+  int total = ca * cb;
+  if (total > 0) {
+    unsigned long long below = (1ull << e.lane) - 1ull;
+    if (ka) e.lst[__popcll(ma & below)] = e.lane;
+    if (kb) e.lst[64 + __popcll(mb & below)] = e.lane;
+    wsync();
+    for (int base = 0; base < total; base += 64) {
+      int idx = base + e.lane;
+      bool hit = false;
+      if (idx < total) {
+        int ia = idx / cb, ib = idx - ia * cb;
+        int i = e.lst[ia], j = e.lst[64 + ib];
+        int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
+        double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
+        double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
+        bool apart = fmin(x11, x12) > fmax(x21, x22) + BB_MARGIN || fmin(x21, x22) > fmax(x11, x12) + BB_MARGIN ||
+                     fmin(y11, y12) > fmax(y21, y22) + BB_MARGIN || fmin(y21, y22) > fmax(y11, y12) + BB_MARGIN;
+        if (!apart) {
+          bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
+          bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
+          if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
+        }
+      }
+      if (__ballot(hit) != 0ull) { wsync(); return true; }
+    }
+    wsync();
+  }
+  // path_in_path: all vertices of b inside a (possible only if box(b) within box(a))
+  if (na + 1 >= 3 && nb > 0 &&
+      !(bbx[0] < ba[0] - BB_MARGIN || bbx[1] < ba[1] - BB_MARGIN || bbx[2] > ba[2] + BB_MARGIN ||
+        bbx[3] > ba[3] + BB_MARGIN)) {
     bool out = false;
     if (e.lane < nb) out = !point_in_poly(va, na, vb[2 * e.lane], vb[2 * e.lane + 1]);
     if (__ballot(out) == 0ull) return true;
   }
-  if (nb + 1 >= 3 && na > 0) {
+  if (nb + 1 >= 3 && na > 0 &&
+      !(ba[0] < bbx[0] - BB_MARGIN || ba[1] < bbx[1] - BB_MARGIN || ba[2] > bbx[2] + BB_MARGIN ||
+        ba[3] > bbx[3] + BB_MARGIN)) {
     bool out = false;
     if (e.lane < na) out = !point_in_poly(vb, nb, va[2 * e.lane], va[2 * e.lane + 1]);
     if (__ballot(out) == 0ull) return true;
@@ -201,7 +241,6 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
 // A box is exact (min/max of the cached vertices, moved with every translation)
 // until the sprite rotates; from then on it is the box of the bounding circle
 // (position +- max_radius, inflated), which rigid motion cannot leave.
-#define BB_MARGIN 1e-6
 #define BB(s, c) (e.bb[4 * (s) + (c)])
 
 __device__ inline void bbox_from_circle(Env& e, int s) {  // lane 0 writes
@@ -246,12 +285,22 @@ __device__ __forceinline__ bool bbox_apart(const Env& e, int s0, int s1) {
          BB(s0, 1) > BB(s1, 3) + BB_MARGIN || BB(s1, 1) > BB(s0, 3) + BB_MARGIN;
 }
 
+// `np.linalg.norm(p0 - p1) > r0 + r1` (sprite.py:464-466).  The square root is only
+// taken when the squared distance is within 1e-9 (relative) of the threshold, where
+// its rounding could matter; elsewhere the comparison of squares decides identically.
+__device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
+  double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
+  double d2 = dx * dx + dy * dy, r = MAXR(s0) + MAXR(s1), r2 = r * r;
+  if (d2 > r2 * (1.0 + 1e-9) && r >= 0) return true;
+  if (d2 < r2 * (1.0 - 1e-9)) return false;
+  return sqrt(d2) > r;
+}
+
 // sprite.py:462-484
 __device__ inline bool overlaps(const Env& e, int s0, int s1) {
-  double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
-  if (norm2(dx, dy) > MAXR(s0) + MAXR(s1)) return false;
+  if (circles_apart(e, s0, s1)) return false;
   if (bbox_apart(e, s0, s1)) return false;
-  return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1));
+  return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
 }
 
 // sprite.py:442-460 (one point, one lane)
@@ -333,10 +382,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
     }
     x[0] = ddx; x[1] = ddy; x[2] = a; x[3] = b; x[4] = tx; x[5] = ty; x[6] = mode;
     PX(s) = nx; PY(s) = ny;
-    if (mode == 2.0) {
-      double r = MAXR(s) * (1.0 + 1e-6) + 1e-9;
-      BB(s, 0) = nx - r; BB(s, 1) = ny - r; BB(s, 2) = nx + r; BB(s, 3) = ny + r;
-    } else {
+    if (mode != 2.0) {
       BB(s, 0) = BB(s, 0) + ddx; BB(s, 2) = BB(s, 2) + ddx;
       BB(s, 1) = BB(s, 1) + ddy; BB(s, 3) = BB(s, 3) + ddy;
     }
@@ -357,6 +403,19 @@ __device__ inline void integrate_all(Env& e, double dt) {
       vx = rx; vy = ry;
     }
     vall[2 * idx] = vx; vall[2 * idx + 1] = vy;
+  }
+  wsync();
+  // exact boxes of the sprites that rotated (lanes = sprites, each scans its vertices)
+  for (int s = e.lane; s < S; s += 64) {
+    if (e.xf[8 * s + 6] != 2.0) continue;
+    const double* v = VERT(s);
+    int n = NV(s);
+    double x0 = DINF, y0 = DINF, x1 = -DINF, y1 = -DINF;
+    for (int k = 0; k < n; ++k) {
+      double x = v[2 * k], y = v[2 * k + 1];
+      x0 = fmin(x0, x); y0 = fmin(y0, y); x1 = fmax(x1, x); y1 = fmax(y1, y);
+    }
+    BB(s, 0) = x0; BB(s, 1) = y0; BB(s, 2) = x1; BB(s, 3) = y1;
   }
   wsync();
 }
@@ -809,8 +868,7 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
         int s1 = cb + e.lane;
         bool cand = false;
         if (s1 >= cursor && s1 < cend && s1 != s0 && ALIVE(s1)) {
-          double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
-          cand = !(norm2(dx, dy) > MAXR(s0) + MAXR(s1)) && !bbox_apart(e, s0, s1);
+          cand = !bbox_apart(e, s0, s1) && !circles_apart(e, s0, s1);
         }
         uint64_t mask = __ballot(cand);
         bool rebuilt = false;

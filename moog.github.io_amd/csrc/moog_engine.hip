@@ -72,6 +72,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
   e.bb = reinterpret_cast<double*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
   e.xf = e.bb + 4 * a.L.S;
+  e.lst = reinterpret_cast<int32_t*>(e.xf + 8 * a.L.S);
   e.vslot = a.vslot;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   store_record(e, gf, gq);
 }
 
-__global__ __launch_bounds__(64) void moog_step_kernel(KArgs a) {
+__global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
   int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
@@ -241,7 +242,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
-                (size_t)e->L.S * 12 * 8;
+                (size_t)e->L.S * 12 * 8 + 128 * 4;
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
