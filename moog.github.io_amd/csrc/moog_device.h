@@ -37,6 +37,7 @@ struct Env {
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   int32_t* lst;            // LDS scratch [128]: compacted edge index lists
+  int32_t* voff;           // LDS copy of program.slot_voff [S]
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -54,7 +55,7 @@ struct Env {
 #define OPAC(s) (e.q[e.L.o_opacity + (s)])
 #define SHAPEID(s) (e.q[e.L.o_shape + (s)])
 #define TELE(s) (e.q[e.L.o_tele + (s)])
-#define VERT(s) (&e.f[e.L.o_verts + 2 * e.P->slot_voff[s]])
+#define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -393,7 +394,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
     int s = e.vslot[idx];
     const double* x = &e.xf[8 * s];
     double mode = x[6];
-    int k = idx - P->slot_voff[s];
+    int k = idx - e.voff[s];
     if (mode == 0.0 || k >= NV(s)) continue;
     double vx = vall[2 * idx] + x[0], vy = vall[2 * idx + 1] + x[1];
     if (mode == 2.0) {
@@ -724,7 +725,8 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
 
 // collisions.py:494-584.  Returns true when the pair overlapped (state may have moved).
 __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int s1, int K) {
-  int symmetric = F->symmetric, upd = F->i0, maxdepth = F->i1;
+  const int symmetric = uni(F->symmetric), upd = uni(F->i0), maxdepth = uni(F->i1);
+  s0 = uni(s0); s1 = uni(s1);
   bool touched = false;
   for (int depth = 0; depth <= maxdepth; ++depth) {
     if (s0 == s1) return touched;
@@ -888,20 +890,22 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
 // physics.py:88-117 (one substep)
 __device__ inline void apply_physics(Env& e) {
   const moog_program_t* P = e.P;
-  int K = P->updates_per_env_step;
-  for (int fi = 0; fi < P->n_forces; ++fi) {
+  const int K = uni(P->updates_per_env_step);
+  const int n_forces = uni(P->n_forces);
+  for (int fi = 0; fi < n_forces; ++fi) {
     const moog_force_t* F = &P->forces[fi];
-    for (int a = 0; a < F->n_a; ++a) {
-      int la = F->layers_a[a];
-      int a0 = P->layer_slot0[la], a1 = a0 + P->layer_nslots[la];
-      if (F->n_b == 0) {
+    const int n_a = uni(F->n_a), n_b = uni(F->n_b), kind = uni(F->kind);
+    for (int a = 0; a < n_a; ++a) {
+      int la = uni(F->layers_a[a]);
+      int a0 = uni(P->layer_slot0[la]), a1 = a0 + uni(P->layer_nslots[la]);
+      if (n_b == 0) {
         for (int s = a0; s < a1; ++s)
           if (ALIVE(s)) force_single(e, F, s, K);
       } else {
-        for (int b = 0; b < F->n_b; ++b) {
-          int lb = F->layers_b[b];
-          int b0 = P->layer_slot0[lb], b1 = b0 + P->layer_nslots[lb];
-          if (F->kind == MOOG_FORCE_COLLISION) {
+        for (int b = 0; b < n_b; ++b) {
+          int lb = uni(F->layers_b[b]);
+          int b0 = uni(P->layer_slot0[lb]), b1 = b0 + uni(P->layer_nslots[lb]);
+          if (kind == MOOG_FORCE_COLLISION) {
             collision_layer_pair(e, F, a0, a1, b0, b1, K);
           } else {
             for (int s0 = a0; s0 < a1; ++s0) {
@@ -914,7 +918,8 @@ __device__ inline void apply_physics(Env& e) {
       }
     }
   }
-  for (int c = 0; c < P->n_corrective; ++c) constant_speed(e, &P->corrective[c]);
+  const int n_corr = uni(P->n_corrective);
+  for (int c = 0; c < n_corr; ++c) constant_speed(e, &P->corrective[c]);
   integrate_all(e, 1. / K);
 }
 

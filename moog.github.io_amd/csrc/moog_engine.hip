@@ -29,6 +29,7 @@ __device__ inline void load_record(const Env& e, const double* gf, const int32_t
   const int4* srci = reinterpret_cast<const int4*>(gq);
   int4* dsti = reinterpret_cast<int4*>(e.q);
   for (int i = e.lane; i < e.L.i32_per_env / 4; i += 64) dsti[i] = srci[i];
+  for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
   wsync();
 }
 
@@ -73,6 +74,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.bb = reinterpret_cast<double*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
   e.xf = e.bb + 4 * a.L.S;
   e.lst = reinterpret_cast<int32_t*>(e.xf + 8 * a.L.S);
+  e.voff = e.lst + 128;
   e.vslot = a.vslot;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
@@ -124,13 +126,15 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   wsync();
   bbox_build_all(e);
   const moog_program_t* P = a.P;
+  const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
-    for (int k = 0; k < P->updates_per_env_step; ++k) apply_physics(e);
+    for (int k = 0; k < K; ++k) apply_physics(e);
     store_record(e, gf, gq);
     return;
   }
   // environment.py:98-126
-  for (int r = 0; r < P->n_rules; ++r) rule_step(e, r);
+  const int n_rules = uni(P->n_rules);
+  for (int r = 0; r < n_rules; ++r) rule_step(e, r);
   double ax = 0, ay = 0;
   int ga = 4;
   if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
     ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
   }
   action_step(e, ax, ay, ga);
-  for (int k = 0; k < P->updates_per_env_step; ++k) apply_physics(e);
+  for (int k = 0; k < K; ++k) apply_physics(e);
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();
   if (e.lane == 0) e.q[e.L.o_step_count] = sc;
@@ -242,7 +246,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
-                (size_t)e->L.S * 12 * 8 + 128 * 4;
+                (size_t)e->L.S * 12 * 8 + 128 * 4 + (size_t)e->L.S * 4 + 16;
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
