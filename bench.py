@@ -80,7 +80,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from moog import _abi, environment
+    from moog import _abi, environment, sharding
     from moog_demos import example_configs
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -94,7 +94,8 @@ def main():
     n = args.envs_per_gpu
 
     env = environment.BatchedEnvironment(
-        num_envs=n, device=dev, seed=2024, env_index0=rank * n, **example_configs.load(args.workload))
+        num_envs=n, device=dev, seed=2024, env_index0=sharding.shard_range(n * world, rank, world)[0],
+        **example_configs.load(args.workload))
     env.check_faults = False
     env.reset()
     is_grid = env._is_grid
@@ -124,10 +125,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)   # off the timed path
-    dt_max = float(t.item())
+    dt_max = sharding.max_over_ranks(dt, device=dev)   # MAX over ranks, off the timed path
 
     k_ms = {name: env.kernel_time(kid) for name, kid in
             (('step', _abi.MOOG_K_STEP), ('raster', _abi.MOOG_K_RASTER), ('reset', _abi.MOOG_K_RESET))}

@@ -1,0 +1,77 @@
+"""N > 1 path on CPU: two gloo ranks, each owning a shard of the env axis, must
+reproduce the single-process run bit for bit (global-index RNG keys, no data-path
+collective); the timing reduction is a MAX all-reduce."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+from moog import sharding
+
+N_ENVS, STEPS, NAME = 12, 6, 'functional_maze'
+
+
+def test_shard_range_partitions():
+    for total in (1, 7, 64, 4096, 65536):
+        for world in (1, 2, 3, 8):
+            blocks = [sharding.shard_range(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == total
+            for (s0, c0), (s1, _) in zip(blocks, blocks[1:]):
+                assert s0 + c0 == s1
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_range(8, 2, 2)
+
+
+def _run_shard(start, count, actions):
+    c = helpers.compiled(NAME)
+    o = helpers.OracleEnv(c, n_envs=count, seed=5, env_index0=start)
+    o.reset(render=False)
+    for t in range(STEPS):
+        o.step(actions[t, start:start + count], render=False)
+    return o.f64.copy(), o.i32.copy(), o.reward.copy()
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        actions = np.random.RandomState(0).uniform(-1, 1, size=(STEPS, N_ENVS, 2))
+        start, count = sharding.shard_range(N_ENVS, rank, world)
+        f, q, r = _run_shard(start, count, actions)
+        # timing reduction helper: MAX over ranks
+        t = sharding.max_over_ranks(1.0 + rank)
+        assert t == float(world)
+        # collect every shard on rank 0 (test-only gather; the hot path has no collective)
+        parts = [None] * world
+        dist.all_gather_object(parts, (start, f, q, r))
+        if rank == 0:
+            parts.sort(key=lambda p: p[0])
+            ret['f'] = np.concatenate([p[1] for p in parts])
+            ret['q'] = np.concatenate([p[2] for p in parts])
+            ret['r'] = np.concatenate([p[3] for p in parts])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    world = 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    helpers.oracle()  # build before forking
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    actions = np.random.RandomState(0).uniform(-1, 1, size=(STEPS, N_ENVS, 2))
+    f, q, r = _run_shard(0, N_ENVS, actions)
+    assert np.array_equal(ret['q'], q)
+    assert np.array_equal(ret['f'], f, equal_nan=True)
+    assert np.array_equal(ret['r'], r, equal_nan=True)
