@@ -220,3 +220,33 @@ def test_full_size_properties():
         env2.step(a[128:192])
     f2, q2 = download(env2)
     assert np.array_equal(q2, q[128:192]) and np.array_equal(f2, f[128:192], equal_nan=True)
+
+
+def test_gym_wrapper_contract():
+    """The Gym surface pinned by the reference's tests/moog/env_wrappers/test_gym_wrapper.py:49-131:
+    spaces, uint8 image observations, `done` exactly at the timeout step and False on
+    the auto-reset step that follows."""
+    import collections
+    from moog import action_spaces, environment, observers, physics as physics_lib, sprite, tasks
+    from moog.env_wrappers import gym_wrapper
+    cfg = dict(
+        state_initializer=lambda: collections.OrderedDict(
+            [('agent', [sprite.Sprite(x=0.5, y=0.5, shape='square', scale=0.1, c0=255)])]),
+        physics=physics_lib.Physics((physics_lib.Drag(coeff_friction=0.25), 'agent'),
+                                    updates_per_env_step=5),
+        task=tasks.CompositeTask(timeout_steps=5),
+        action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))})
+    env = gym_wrapper.GymWrapper(environment.Environment(**cfg))
+    assert env.observation_space['image'].shape == (64, 64, 3)
+    assert env.observation_space['image'].dtype == np.uint8
+    assert env.action_space.shape == (2,)
+    obs = env.reset()
+    assert obs['image'].dtype == np.uint8 and obs['image'].shape == (64, 64, 3)
+    for t in range(1, 6):
+        obs, reward, done, info = env.step(np.array([0.5, -0.5]))
+        assert done == (t == 5) and reward == 0
+        assert info['discount'] == (0.0 if t == 5 else 1.0)
+    obs, reward, done, info = env.step(np.array([0.5, -0.5]))   # auto-reset: FIRST timestep
+    assert not done and reward == 0 and info['discount'] is None
+    assert np.array_equal(env.render(), obs['image'])
