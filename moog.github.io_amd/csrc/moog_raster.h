@@ -4,12 +4,13 @@
 // ImagingDrawPolygon / polygon_generic(hasAlpha=1) / hline32rgba as restated and
 // fuzz-validated against Pillow 12.2.0 in oracle/moog_oracle.c).
 //
-// One wavefront (a 64-thread workgroup) renders one env's frame -- the phases
-// below have very different widths, and with one wave per env nobody waits at a
-// workgroup barrier: latency is hidden by the other envs' waves on the CU.
+// One 256-thread workgroup renders one env's frame.  The kernel is bound by LDS /
+// issue latency of short dependent chains, so the design goal is occupancy: the LDS
+// working set is ~15 KB per env (integer vertices, 16-byte edge records, row masks;
+// no per-thread scratch), which lets 8 workgroups = 32 waves share a CU.
 // Everything between reading the sprite vertices (coalesced 16 B/lane) and
 // writing the uint8 frame (each byte written exactly once, 3 x dwordx4 per lane
-// over a contiguous 3 KB span per wave) stays in LDS / registers:
+// over contiguous 3 KB spans per wave) stays in LDS / registers:
 //   1  vertices -> integer canvas coordinates ((int)(W*x), one thread per vertex
 //      per polygon copy), per-item row ranges by LDS atomics, per-item RGBA
 //   2  one thread per edge: slope, horizontal-run merging (ImagingDrawPolygon)
@@ -22,7 +23,8 @@
 #pragma once
 #include "moog_device.h"
 
-#define R_THREADS 64
+#define R_THREADS 256
+#define R_SLOW 16     // lanes that run the generic scanline concurrently (bounds its LDS scratch)
 #define R_XX 24      // max crossings kept per scanline
 
 struct RArgs {
@@ -43,7 +45,7 @@ struct RArgs {
 // LDS plan shared by host (sizes) and device (carve-up)
 struct RPlan {
   size_t o_ivert, o_edge, o_eflag, o_slotinfo, o_item_slot, o_item_y, o_item_rgba, o_item_cnt,
-      o_rowoff, o_rowitems, o_masks, o_xx, o_frame, o_misc, total;
+      o_rowoff, o_rowitems, o_masks, o_xx, o_frame, o_misc, o_carry, o_queue, total;
 };
 
 // Edge record, 16 bytes.  Table (non-horizontal) edges: x0, y0, y1, dx.
@@ -67,22 +69,25 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   p->o_rowoff = o; o = r_align(o + (items + 1) * 4);
   p->o_rowitems = o; o = r_align(o + (size_t)H * iwords * 4);
   p->o_misc = o; o = r_align(o + 64);
-  // union: {integer vertices, edge classes} are dead once the edge records are
-  // packed; {coverage masks, crossing lists} live only afterwards
+  p->o_carry = o; o = r_align(o + (size_t)S * 8);     // counts carried over a 64-vertex chunk
+  p->o_queue = o; o = r_align(o + (size_t)cap_rows * 2 + 16);   // rows that need the generic scanline
+  p->o_xx = o; o = r_align(o + (size_t)R_XX * R_SLOW * 4);
+  // union: the integer vertices are dead once the edge records are packed; the
+  // coverage masks live only afterwards
   size_t u = o;
   p->o_ivert = u; size_t e1 = r_align(u + nv * 4);
-  p->o_eflag = e1; e1 = r_align(e1 + nv);
+  p->o_eflag = e1;
   p->o_masks = u; size_t e2 = r_align(u + (size_t)cap_rows * words * 8);
-  p->o_xx = e2; e2 = r_align(e2 + (size_t)R_XX * R_THREADS * 4);
   p->o_frame = 0;
   p->total = e1 > e2 ? e1 : e2;
 }
 
-__device__ inline int pil_round_up(float f) {
-  return (int)((f >= 0.0f) ? floorf(f + 0.5f) : -floorf(fabsf(f) + 0.5f));
+// Draw.c ROUND_UP / ROUND_DOWN: sign-symmetric, so branch-free with copysign
+__device__ __forceinline__ int pil_round_up(float f) {
+  return (int)copysignf(floorf(fabsf(f) + 0.5f), f);
 }
-__device__ inline int pil_round_down(float f) {
-  return (int)((f >= 0.0f) ? ceilf(f - 0.5f) : -ceilf(fabsf(f) - 0.5f));
+__device__ __forceinline__ int pil_round_down(float f) {
+  return (int)copysignf(ceilf(fabsf(f) - 0.5f), f);
 }
 
 // color_maps.py:21-23 (colorsys.hsv_to_rgb, then uint8 truncation)
@@ -194,12 +199,11 @@ __device__ inline int tip_partner(const REdge* e, int i, bool top, float* vv_out
   return -1;
 }
 
-// Coverage of scanline y of one polygon: polygon_generic(hasAlpha=1), one row.
-// xx: this thread's crossing list, element j at xx[j * R_THREADS].
-__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, float* xx, int W, int dbg) {
+// Generic scanline (any number of crossings, corner fix-ups): crossing list in LDS.
+// xx: this thread's crossing list, element j at xx[j * R_SLOW].
+__device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ymax, float* xx, int W) {
   RMask m = {0ull, 0ull};
   int j = 0;
-  if (dbg == 51) return m;
   for (int i = 0; i < p.nt; ++i) {
     REdge E = p.e[i];
     int y0 = E.y0, y1 = E.y1;
@@ -207,10 +211,10 @@ __device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, floa
     if (y < emin || y > emax) continue;
     float dx = E.dx;
     float x = (float)(y - y0) * dx + (float)E.x0;
-    if (j < R_XX) xx[j * R_THREADS] = x;
+    if (j < R_XX) xx[j * R_SLOW] = x;
     ++j;
     if (y == emax && y < poly_ymax) {
-      if (j < R_XX) xx[j * R_THREADS] = x;
+      if (j < R_XX) xx[j * R_SLOW] = x;
       ++j;
     } else if (dx != 0.0f && (y == emin || y == emax)) {
       // connect discontiguous corners: only a row at an end point of this edge can
@@ -225,26 +229,24 @@ __device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, floa
           if (y < kmin || y > kmax) continue;
           kpos += (y == kmax && y < poly_ymax) ? 2 : 1;
         }
-        if (kpos < R_XX) xx[kpos * R_THREADS] = vv;
+        if (kpos < R_XX) xx[kpos * R_SLOW] = vv;
       }
     }
   }
   if (j > R_XX) j = R_XX;
-  if (dbg == 52) { m.w0 = j; return m; }
   for (int q = 1; q < j; ++q) {  // insertion sort (qsort with x_cmp)
-    float key = xx[q * R_THREADS];
+    float key = xx[q * R_SLOW];
     int r = q - 1;
-    while (r >= 0 && xx[r * R_THREADS] > key) { xx[(r + 1) * R_THREADS] = xx[r * R_THREADS]; --r; }
-    xx[(r + 1) * R_THREADS] = key;
+    while (r >= 0 && xx[r * R_SLOW] > key) { xx[(r + 1) * R_SLOW] = xx[r * R_SLOW]; --r; }
+    xx[(r + 1) * R_SLOW] = key;
   }
-  if (dbg == 53) { m.w0 = j; return m; }
   int x_pos = (j == 0) ? -1 : 0;
   for (int i = 1; i < j; i += 2) {
-    int x_end = pil_round_down(xx[i * R_THREADS]);
+    int x_end = pil_round_down(xx[i * R_SLOW]);
     if (x_end < x_pos) continue;
     if (p.nh) draw_horizontal(p, y, &x_pos, m, W);
     if (x_end < x_pos) continue;
-    int x_start = pil_round_up(xx[(i - 1) * R_THREADS]);
+    int x_start = pil_round_up(xx[(i - 1) * R_SLOW]);
     if (x_pos > x_start) {
       x_start = x_pos;
       if (x_end < x_start) continue;
@@ -253,6 +255,91 @@ __device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, floa
     x_pos = x_end + 1;
   }
   if (p.nh) draw_horizontal(p, y, &x_pos, m, W);
+  return m;
+}
+
+// Coverage of scanline y of one polygon: polygon_generic(hasAlpha=1), one row.
+// Fast path: up to 8 crossings kept sorted in registers (insertion by a min/max
+// chain; the sorted multiset is all the span loop needs).  A corner fix-up replaces
+// the partner's entry, whose value equals this edge's crossing x, so it is "remove
+// one x, insert vv" on the sorted registers.  More than 8 crossings or a second
+// fix-up on the same row (the partner's entry might already be modified) are queued
+// for the generic routine.
+#define R_INSERT(val)                                  \
+  {                                                    \
+    float t_ = (val), lo_;                             \
+    lo_ = fminf(r0, t_); t_ = fmaxf(r0, t_); r0 = lo_; \
+    lo_ = fminf(r1, t_); t_ = fmaxf(r1, t_); r1 = lo_; \
+    lo_ = fminf(r2, t_); t_ = fmaxf(r2, t_); r2 = lo_; \
+    lo_ = fminf(r3, t_); t_ = fmaxf(r3, t_); r3 = lo_; \
+    lo_ = fminf(r4, t_); t_ = fmaxf(r4, t_); r4 = lo_; \
+    lo_ = fminf(r5, t_); t_ = fmaxf(r5, t_); r5 = lo_; \
+    lo_ = fminf(r6, t_); t_ = fmaxf(r6, t_); r6 = lo_; \
+    r7 = fminf(r7, t_);                                \
+  }
+
+__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int W, bool* need_generic) {
+  const float INF = __builtin_inff();
+  float r0 = INF, r1 = INF, r2 = INF, r3 = INF, r4 = INF, r5 = INF, r6 = INF, r7 = INF;
+  int j = 0, nfix = 0;
+  for (int i = 0; i < p.nt; ++i) {
+    REdge E = p.e[i];
+    int y0 = E.y0, y1 = E.y1;
+    int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
+    if (y < emin || y > emax) continue;
+    float x = (float)(y - y0) * E.dx + (float)E.x0;
+    bool dup = (y == emax && y < poly_ymax);
+    ++j;
+    R_INSERT(x);
+    if (dup) { ++j; R_INSERT(x); }
+    else {
+      int flag = __float_as_int(E.pad);
+      if (flag && ((y == emin && (flag & 1)) || (y == emax && (flag & 2)))) {
+        float vv = 0.0f;
+        int kt = tip_partner(p.e, i, y == emin, &vv);
+        if (kt >= 0) {
+          ++nfix;
+          // remove one instance of x (the partner's entry), then insert vv
+          bool f = false;
+          f = f || (r0 == x); r0 = f ? r1 : r0;
+          f = f || (r1 == x); r1 = f ? r2 : r1;
+          f = f || (r2 == x); r2 = f ? r3 : r2;
+          f = f || (r3 == x); r3 = f ? r4 : r3;
+          f = f || (r4 == x); r4 = f ? r5 : r4;
+          f = f || (r5 == x); r5 = f ? r6 : r5;
+          f = f || (r6 == x); r6 = f ? r7 : r6;
+          r7 = INF;
+          R_INSERT(vv);
+        }
+      }
+    }
+  }
+  RMask m = {0ull, 0ull};
+  *need_generic = (nfix > 1 || j > 8);
+  if (*need_generic) return m;
+  bool head_here = false;
+  for (int i = 0; i < p.nh; ++i) head_here = head_here || (p.e[p.n - 1 - i].y0 == y);
+  int x_pos = (j == 0) ? -1 : 0;
+  const float lo4[4] = {r0, r2, r4, r6}, hi4[4] = {r1, r3, r5, r7};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (2 * q + 1 < j) {
+      int x_end = pil_round_down(hi4[q]);
+      if (x_end >= x_pos) {
+        if (head_here) draw_horizontal(p, y, &x_pos, m, W);
+        if (x_end >= x_pos) {
+          int x_start = pil_round_up(lo4[q]);
+          bool skip = false;
+          if (x_pos > x_start) { x_start = x_pos; skip = (x_end < x_start); }
+          if (!skip) {
+            mask_fill(m, W, x_start, x_end);   // empty when x_start > x_end, x_pos still moves
+            x_pos = x_end + 1;
+          }
+        }
+      }
+    }
+  }
+  if (head_here) draw_horizontal(p, y, &x_pos, m, W);
   return m;
 }
 
@@ -273,13 +360,12 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const int words = a.words, iwords = a.iwords, cap_rows = a.chunk;
   const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
 
   RPlan pl;
   raster_plan(S, TOTV, ncopy, W, H, cap_rows, words, iwords, &pl);
   short2* ivert = reinterpret_cast<short2*>(moog_lds + pl.o_ivert);
   REdge* edges = reinterpret_cast<REdge*>(moog_lds + pl.o_edge);
-  unsigned char* eflag = moog_lds + pl.o_eflag;
   int* slotinfo = reinterpret_cast<int*>(moog_lds + pl.o_slotinfo);
   int* item_slot = reinterpret_cast<int*>(moog_lds + pl.o_item_slot);
   int* item_y = reinterpret_cast<int*>(moog_lds + pl.o_item_y);
@@ -289,36 +375,42 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   unsigned* rowitems = reinterpret_cast<unsigned*>(moog_lds + pl.o_rowitems);
   unsigned long long* masks = reinterpret_cast<unsigned long long*>(moog_lds + pl.o_masks);
   float* xxs = reinterpret_cast<float*>(moog_lds + pl.o_xx);
+  int* misc = reinterpret_cast<int*>(moog_lds + pl.o_misc);   // [0] n_live, [1] queue length
+  int* carry = reinterpret_cast<int*>(moog_lds + pl.o_carry);
+  unsigned short* queue = reinterpret_cast<unsigned short*>(moog_lds + pl.o_queue);
 
-  // ---- 0: live sprites in slot (= layer, list) order; per-sprite colour ----------------
-  int n_live = 0;
-  for (int s0 = 0; s0 < S; s0 += 64) {
-    int s = s0 + tid;
-    bool live = false;
-    int nv = 0;
-    if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
-    unsigned long long bal = __ballot(live);
-    int rank = n_live + __popcll(bal & ((1ull << tid) - 1ull));
-    if (s < S) { slotinfo[2 * s] = live ? rank : -1; slotinfo[2 * s + 1] = nv; }
-    if (live) {
-      unsigned r8, g8, b8;
-      const double* col = gf + a.L.o_color + 3 * s;
-      if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
-      else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
-      unsigned a8 = (unsigned)gq[a.L.o_opacity + s] & 255u;
-      unsigned rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
-      for (int c = 0; c < ncopy; ++c) {
-        int it = rank * ncopy + c;
-        item_slot[it] = s | (c << 16);
-        item_rgba[it] = rgba;
-        item_y[2 * it] = 0x7fffffff;
-        item_y[2 * it + 1] = -0x7fffffff;
+  // ---- 0: live sprites in slot (= layer, list) order; per-sprite colour (wave 0) --------
+  if (tid < 64) {
+    int n_live = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      int s = s0 + tid;
+      bool live = false;
+      int nv = 0;
+      if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
+      unsigned long long bal = __ballot(live);
+      int rank = n_live + __popcll(bal & ((1ull << tid) - 1ull));
+      if (s < S) { slotinfo[2 * s] = live ? rank : -1; slotinfo[2 * s + 1] = nv; carry[2 * s] = 0; carry[2 * s + 1] = 0; }
+      if (live) {
+        unsigned r8, g8, b8;
+        const double* col = gf + a.L.o_color + 3 * s;
+        if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
+        else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
+        unsigned a8 = (unsigned)gq[a.L.o_opacity + s] & 255u;
+        unsigned rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+        for (int c = 0; c < ncopy; ++c) {
+          int it = rank * ncopy + c;
+          item_slot[it] = s | (c << 16);
+          item_rgba[it] = rgba;
+          item_y[2 * it] = 0x7fffffff;
+          item_y[2 * it + 1] = -0x7fffffff;
+        }
       }
+      n_live += __popcll(bal);
     }
-    n_live += __popcll(bal);
+    if (tid == 0) misc[0] = n_live;
   }
-  wsync();
-  const int total_items = n_live * ncopy;
+  __syncthreads();
+  const int total_items = misc[0] * ncopy;
   if (a.debug_stop == 1) return;
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
@@ -339,72 +431,118 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       atomicMax(&item_y[2 * it + 1], (int)o.y);
     }
   }
-  wsync();
+  __syncthreads();
   if (a.debug_stop == 2) return;
-  // ---- 2a: classify edges (ImagingDrawPolygon: add_edge + merge of horizontal runs) -----
-  for (int idx = tid; idx < TOTV; idx += R_THREADS) {
-    int s = a.vslot[idx];
-    int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
-    int v0 = P->slot_voff[s];
-    int k = idx - v0;
-    if (rank < 0 || k >= nv) continue;
-    for (int c = 0; c < ncopy; ++c) {
+  // ---- 2: edges (ImagingDrawPolygon: add_edge + merge of horizontal runs), packed per
+  //         polygon: table edges from the front, horizontal heads from the back.  The
+  //         in-polygon ranks come from wave ballots (a polygon's vertices are contiguous
+  //         lanes); a polygon straddling a 64-vertex chunk gets the counts of its first
+  //         part through `carry` (it spans at most two chunks: <= 64 vertices).
+  for (int c = 0; c < ncopy; ++c) {
+    for (int base0 = 0; base0 < TOTV; base0 += R_THREADS) {
+      const int base = base0 + (tid & ~63);   // this wave's 64-vertex chunk
+      int idx = base + lane;
+      int s = (idx < TOTV) ? (int)a.vslot[idx] : 0;
+      int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
+      int v0 = P->slot_voff[s];
+      int k = idx - v0;
+      bool valid = (idx < TOTV) && rank >= 0 && k < nv;
       const short2* pv = ivert + c * TOTV + v0;
-      int k2 = (k + 1 == nv) ? 0 : k + 1;
-      short2 p0 = pv[k], p1 = pv[k2];
-      bool closing = (k == nv - 1);
-      unsigned char fl;
-      bool horiz = (p0.y == p1.y);
-      if (closing && p0.x == p1.x && p0.y == p1.y) fl = 0;   // last == first: no closing edge
-      else if (!horiz) fl = 1;
-      else {
-        bool absorbed = false;
-        if (k >= 1 && !closing) {
-          short2 pp = pv[k - 1];
-          if (pp.y == p0.y) absorbed = (p1.x > p0.x && p0.x > pp.x) || (p1.x < p0.x && p0.x < pp.x);
+      unsigned char fl = 0;
+      short2 p0 = make_short2(0, 0), p1 = p0;
+      bool closing = false;
+      if (valid) {
+        int k2 = (k + 1 == nv) ? 0 : k + 1;
+        p0 = pv[k]; p1 = pv[k2];
+        closing = (k == nv - 1);
+        bool horiz = (p0.y == p1.y);
+        if (closing && p0.x == p1.x && p0.y == p1.y) fl = 0;   // last == first: no closing edge
+        else if (!horiz) fl = 1;
+        else {
+          bool absorbed = false;
+          if (k >= 1 && !closing) {
+            short2 pp = pv[k - 1];
+            if (pp.y == p0.y) absorbed = (p1.x > p0.x && p0.x > pp.x) || (p1.x < p0.x && p0.x < pp.x);
+          }
+          fl = absorbed ? 0 : 2;
         }
-        fl = absorbed ? 0 : 2;
       }
-      eflag[c * TOTV + idx] = fl;
+      unsigned long long m1 = __ballot(valid && fl == 1), m2 = __ballot(valid && fl == 2);
+      int lo_lane = v0 - base;
+      if (lo_lane < 0) lo_lane = 0;
+      unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << lo_lane) - 1ull);
+      int nt = __popcll(m1 & below), nh = __popcll(m2 & below);
+      // the polygon of the chunk's last lane may continue in the next chunk
+      if (lane == 63 && valid && (v0 + nv > base + 64)) {
+        carry[2 * s] = nt + (fl == 1);
+        carry[2 * s + 1] = nh + (fl == 2);
+      }
+      __syncthreads();
+      if (valid) {
+        if (v0 < base) { nt += carry[2 * s]; nh += carry[2 * s + 1]; }
+        REdge* reg = edges + c * TOTV + v0;
+        if (fl == 1) {
+          REdge E; E.x0 = p0.x; E.y0 = p0.y; E.y1 = p1.y; E.x1 = p1.x; E.pad = 0.0f;
+          E.dx = ((float)(p1.x - p0.x)) / (float)(p1.y - p0.y);
+          reg[nt] = E;
+        } else if (fl == 2) {
+          // extend over the following absorbed edges (never the closing edge)
+          short hx = p1.x;
+          int q = k + 1;
+          short2 prev = p0, cur = p1;
+          while (q <= nv - 2) {
+            short2 nxt = pv[q + 1];
+            bool ab = (cur.y == nxt.y) && (prev.y == cur.y) &&
+                      ((nxt.x > cur.x && cur.x > prev.x) || (nxt.x < cur.x && cur.x < prev.x));
+            if (!ab) break;
+            hx = nxt.x; prev = cur; cur = nxt; ++q;
+          }
+          REdge E;
+          E.x0 = p0.x < hx ? p0.x : hx; E.y0 = p0.y; E.y1 = p0.x < hx ? hx : p0.x; E.dx = 0.0f;
+          E.x1 = 0; E.pad = 0.0f;
+          reg[nv - 1 - nh] = E;
+        }
+        if (closing) item_cnt[rank * ncopy + c] = (nt + (fl == 1)) | ((nh + (fl == 2)) << 16);
+      }
+      __syncthreads();   // carries are consumed before the next chunk round overwrites them
     }
   }
-  wsync();
-  // ---- 2b: pack edge records: table edges from the front, horizontal heads from the back ---
-  for (int idx = tid; idx < TOTV; idx += R_THREADS) {
-    int s = a.vslot[idx];
-    int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
-    int v0 = P->slot_voff[s];
-    int k = idx - v0;
-    if (rank < 0 || k >= nv) continue;
-    for (int c = 0; c < ncopy; ++c) {
-      const short2* pv = ivert + c * TOTV + v0;
-      const unsigned char* pf = eflag + c * TOTV + v0;
-      int nt = 0, nh = 0;
-      for (int q = 0; q < k; ++q) { unsigned char f = pf[q]; nt += (f == 1); nh += (f == 2); }
-      unsigned char fl = pf[k];
-      int k2 = (k + 1 == nv) ? 0 : k + 1;
-      short2 p0 = pv[k], p1 = pv[k2];
+  // ---- 2c: flag table edges that can take part in polygon_generic's corner fix-up: an
+  //         earlier table edge with the same lean whose top (bit 0) / bottom (bit 1) end
+  //         point is the same integer point.  Rows without a flagged event take the
+  //         register fast path in scanline_mask().
+  for (int c = 0; c < ncopy; ++c) {
+    for (int idx = tid; idx < TOTV; idx += R_THREADS) {
+      int s = a.vslot[idx];
+      int rank = slotinfo[2 * s];
+      if (rank < 0) continue;
+      int v0 = P->slot_voff[s];
+      int k = idx - v0;
+      int nt = item_cnt[rank * ncopy + c] & 0xffff;
+      if (k >= nt) continue;
       REdge* reg = edges + c * TOTV + v0;
-      if (fl == 1) {
-        REdge E; E.x0 = p0.x; E.y0 = p0.y; E.y1 = p1.y; E.x1 = p1.x; E.pad = 0.0f;
-        E.dx = ((float)(p1.x - p0.x)) / (float)(p1.y - p0.y);
-        reg[nt] = E;
-      } else if (fl == 2) {
-        short hx = p1.x;
-        int q = k + 1;   // extend over the following absorbed edges (never the closing edge)
-        while (q <= nv - 2 && pf[q] == 0) { hx = pv[q + 1].x; ++q; }
-        REdge E;
-        E.x0 = p0.x < hx ? p0.x : hx; E.y0 = p0.y; E.y1 = p0.x < hx ? hx : p0.x; E.dx = 0.0f;
-        E.x1 = 0; E.pad = 0.0f;
-        reg[nv - 1 - nh] = E;
+      REdge E = reg[k];
+      if (E.dx == 0.0f) continue;
+      bool up = E.y0 < E.y1;
+      int tx = up ? E.x0 : E.x1, ty = up ? E.y0 : E.y1;   // top end point
+      int bx = up ? E.x1 : E.x0, by = up ? E.y1 : E.y0;   // bottom end point
+      int flag = 0;
+      for (int q = 0; q < k; ++q) {
+        REdge K = reg[q];
+        if ((E.dx > 0 && K.dx <= 0) || (E.dx < 0 && K.dx >= 0)) continue;
+        bool kup = K.y0 < K.y1;
+        int ktx = kup ? K.x0 : K.x1, kty = kup ? K.y0 : K.y1;
+        int kbx = kup ? K.x1 : K.x0, kby = kup ? K.y1 : K.y0;
+        if (ktx == tx && kty == ty) flag |= 1;
+        if (kbx == bx && kby == by) flag |= 2;
       }
-      if (k == nv - 1) item_cnt[rank * ncopy + c] = (nt + (fl == 1)) | ((nh + (fl == 2)) << 16);
+      if (flag) reg[k].pad = __int_as_float(flag);
     }
   }
   if (a.debug_stop == 3) return;
 
-  // ---- 3: exclusive scan of the clamped row counts of all items -------------------------
-  {
+  // ---- 3: exclusive scan of the clamped row counts of all items (wave 0) ----------------
+  if (tid < 64) {
     int run = 0;
     for (int i0 = 0; i0 < total_items; i0 += 64) {
       int it = i0 + tid;
@@ -425,18 +563,17 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
     }
     if (tid == 0) rowoff[total_items] = run;
   }
-  wsync();   // also: ivert / eflag are dead from here on (masks / xx alias them)
+  __syncthreads();   // also: the integer vertices are dead from here on (masks alias them)
   if (a.debug_stop == 4) return;
 
   const int segs = (H * W) / 16;   // 16-pixel row segments
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
                        (((unsigned)P->render.bg[2] & 255u) << 16);
   uint8_t* out = a.image + (size_t)env * H * W * 3;
-  const bool single_pass = (rowoff[total_items] <= cap_rows);
 
   // passes: as many whole items as fit in the mask buffer (cap_rows >= H); with more
   // than one pass the partially composed frame round-trips through `out` (L2)
-  for (int base = 0; base < total_items || base == 0;) {
+  for (int base = 0;;) {
     const int r0 = rowoff[base];
     int lo = base + 1, hi = total_items;   // largest end with rowoff[end] - r0 <= cap_rows
     if (total_items == 0) { lo = hi = 0; }
@@ -447,7 +584,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
     const int end = lo;
     const int total_rows = rowoff[end] - r0;
     for (int i = tid; i < H * iwords; i += R_THREADS) rowitems[i] = 0u;
-    wsync();
+    if (tid == 0) misc[1] = 0;
+    __syncthreads();
     // ---- 4: coverage masks, one thread per (item, row) ------------------------------------
     for (int w = tid; w < total_rows; w += R_THREADS) {
       int l2 = base, h2 = end - 1;   // last item with rowoff <= r0 + w
@@ -464,13 +602,44 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       int s = sc & 0xffff, c = sc >> 16;
       int cnt = item_cnt[g];
       RPoly poly = {edges + c * TOTV + P->slot_voff[s], slotinfo[2 * s + 1], cnt & 0xffff, cnt >> 16};
-      RMask m = scanline_mask(poly, y, pymax, xxs + tid, W, a.debug_stop);
-      masks[(size_t)w * words] = m.w0;
-      if (words > 1) masks[(size_t)w * words + 1] = m.w1;
-      if (m.w0 | m.w1) atomicOr(&rowitems[y * iwords + (it >> 5)], 1u << (it & 31));
+      bool generic = false;
+      RMask m = scanline_mask(poly, y, pymax, W, &generic);
+      if (generic) {
+        queue[atomicAdd(&misc[1], 1)] = (unsigned short)w;
+      } else {
+        masks[(size_t)w * words] = m.w0;
+        if (words > 1) masks[(size_t)w * words + 1] = m.w1;
+        if (m.w0 | m.w1) atomicOr(&rowitems[y * iwords + (it >> 5)], 1u << (it & 31));
+      }
     }
-    wsync();
-    if (a.debug_stop == 5 || a.debug_stop > 50) return;
+    __syncthreads();
+    // rows that need the generic scanline (corner fix-ups, > 8 crossings): R_SLOW lanes
+    if (tid < R_SLOW) {
+      const int qn = misc[1];
+      for (int qi = tid; qi < qn; qi += R_SLOW) {
+        int w = queue[qi];
+        int l2 = base, h2 = end - 1;
+        while (l2 < h2) {
+          int mid = (l2 + h2 + 1) >> 1;
+          if (rowoff[mid] - r0 <= w) l2 = mid; else h2 = mid - 1;
+        }
+        int g = l2, it = g - base;
+        int ymin = item_y[2 * g], ymax = item_y[2 * g + 1];
+        int ystart = ymin < 0 ? 0 : ymin;
+        int y = ystart + (w - (rowoff[g] - r0));
+        int pymax = ymax > H ? H : ymax;
+        int sc = item_slot[g];
+        int s = sc & 0xffff, c = sc >> 16;
+        int cnt = item_cnt[g];
+        RPoly poly = {edges + c * TOTV + P->slot_voff[s], slotinfo[2 * s + 1], cnt & 0xffff, cnt >> 16};
+        RMask m = scanline_mask_generic(poly, y, pymax, xxs + tid, W);
+        masks[(size_t)w * words] = m.w0;
+        if (words > 1) masks[(size_t)w * words + 1] = m.w1;
+        if (m.w0 | m.w1) atomicOr(&rowitems[y * iwords + (it >> 5)], 1u << (it & 31));
+      }
+    }
+    __syncthreads();
+    if (a.debug_stop == 5) return;
     // ---- 5: compose (painter's order = item order), pack RGB, store flipped ------------------
     for (int seg = tid; seg < segs; seg += R_THREADS) {
       int y = (seg * 16) / W, x0 = (seg * 16) % W;
@@ -533,10 +702,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
       dst[2] = make_uint4(d[8], d[9], d[10], d[11]);
     }
-    (void)single_pass;
     if (end >= total_items) break;
     base = end;
-    __threadfence_block();
-    wsync();
+    __syncthreads();
   }
 }
