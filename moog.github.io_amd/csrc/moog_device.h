@@ -38,6 +38,8 @@ struct Env {
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   int32_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
+  int32_t* cand;           // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
+  int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -301,6 +303,7 @@ __device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
 __device__ inline bool overlaps(const Env& e, int s0, int s1) {
   if (circles_apart(e, s0, s1)) return false;
   if (bbox_apart(e, s0, s1)) return false;
+  if (e.dbg & 8) return false;
   return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
 }
 
@@ -723,22 +726,25 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
   }
 }
 
-// collisions.py:494-584.  Returns true when the pair overlapped (state may have moved).
+// collisions.py:494-584.  Returns true when a sprite position changed (the broad
+// phase must then be redone for the following pairs); velocity-only outcomes and
+// "future contact" no-ops return false.
 __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int s1, int K) {
   const int symmetric = uni(F->symmetric), upd = uni(F->i0), maxdepth = uni(F->i1);
   s0 = uni(s0); s1 = uni(s1);
-  bool touched = false;
+  bool moved = false;
   for (int depth = 0; depth <= maxdepth; ++depth) {
-    if (s0 == s1) return touched;
-    if (!overlaps(e, s0, s1)) return touched;
-    touched = true;
+    if (s0 == s1) return moved;
+    if (!overlaps(e, s0, s1)) return moved;
+    if (e.dbg & 16) return moved;
     double dt = 1. / K;
     CVec c;
     get_collision_vectors(e, s0, s1, dt, c);
     if (c.status == CV_NONE) {
       make_disjoint(e, s0, s1, symmetric);
+      moved = true;
     } else if (c.status == CV_FUTURE) {
-      return touched;
+      return moved;
     } else {
       if (symmetric) {
         set_position(e, s0, PX(s0) - (0.5 + EPS_COLL) * c.qx, PY(s0) - (0.5 + EPS_COLL) * c.qy);
@@ -746,11 +752,12 @@ __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int
       } else {
         set_position(e, s0, PX(s0) - (1. + EPS_COLL) * c.qx, PY(s0) - (1. + EPS_COLL) * c.qy);
       }
+      moved = true;
       if (upd) collide_with_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
       else collide_without_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
     }
   }
-  return touched;
+  return moved;
 }
 
 // ---- Newtonian forces --------------------------------------------------------------
@@ -855,35 +862,50 @@ __device__ inline void constant_speed(Env& e, const moog_corrective_t* C) {
 }
 
 // Collision force over (layer la) x (layer lb): the reference visits ordered pairs
-// (s0, s1) sequentially (physics.py:103-108).  The bounding-circle reject of
-// overlaps_sprite is evaluated for 64 partners at once; only surviving partners
-// run the narrow phase, in index order; the mask is rebuilt after any pair that
-// overlapped (it may have moved s0).
+// (s0, s1), s0 outer, sequentially (physics.py:103-108) and every resolved contact
+// moves sprites, so later pairs must see the new state.  Broad phase: the flattened
+// pair index space is scanned 64 pairs per wave instruction (bounding circles as in
+// overlaps_sprite + conservative boxes) and the survivors are appended, in
+// reference order, to a candidate list in LDS.  The list is consumed sequentially by
+// the narrow phase; as soon as a pair actually overlapped (state may have changed),
+// the list is discarded and rebuilt from the next pair on.
+#define CAND_CAP 128
 __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a0, int a1, int b0,
                                             int b1, int K) {
-  for (int s0 = a0; s0 < a1; ++s0) {
-    if (!ALIVE(s0)) continue;
-    for (int cb = b0; cb < b1; cb += 64) {
-      int cursor = cb;
-      int cend = (cb + 64 < b1) ? cb + 64 : b1;
-      while (cursor < cend) {
-        int s1 = cb + e.lane;
-        bool cand = false;
-        if (s1 >= cursor && s1 < cend && s1 != s0 && ALIVE(s1)) {
-          cand = !bbox_apart(e, s0, s1) && !circles_apart(e, s0, s1);
-        }
-        uint64_t mask = __ballot(cand);
-        bool rebuilt = false;
-        while (mask) {
-          int l = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          int t = cb + l;
-          cursor = t + 1;
-          if (collision_step(e, F, s0, t, K)) { rebuilt = true; break; }
-        }
-        if (!rebuilt) cursor = cend;
+  const int nB = b1 - b0, total = (a1 - a0) * nB;
+  int start = 0;
+  while (start < total) {
+    // ---- build: candidates with flattened index >= start --------------------------------
+    int count = 0, scanned = start;
+    wsync();
+    while (scanned < total && count <= CAND_CAP - 64) {
+      int idx = scanned + e.lane;
+      bool cand = false;
+      int s0 = 0, t = 0;
+      if (idx < total) {
+        int i = idx / nB;
+        s0 = a0 + i; t = b0 + (idx - i * nB);
+        if (s0 != t && ALIVE(s0) && ALIVE(t)) cand = !bbox_apart(e, s0, t) && !circles_apart(e, s0, t);
+      }
+      uint64_t m = __ballot(cand);
+      if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (s0 << 8) | t;
+      count += __popcll(m);
+      scanned += 64;
+    }
+    wsync();
+    if (scanned > total) scanned = total;
+    // ---- consume ----------------------------------------------------------------------------
+    bool rebuilt = false;
+    for (int c = 0; c < count; ++c) {
+      int pr = uni(e.cand[c]);
+      int s0 = pr >> 8, t = pr & 255;
+      if (!(e.dbg & 4) && collision_step(e, F, s0, t, K)) {
+        start = (s0 - a0) * nB + (t - b0) + 1;
+        rebuilt = true;
+        break;
       }
     }
+    if (!rebuilt) start = scanned;
   }
 }
 
@@ -906,7 +928,7 @@ __device__ inline void apply_physics(Env& e) {
           int lb = uni(F->layers_b[b]);
           int b0 = uni(P->layer_slot0[lb]), b1 = b0 + uni(P->layer_nslots[lb]);
           if (kind == MOOG_FORCE_COLLISION) {
-            collision_layer_pair(e, F, a0, a1, b0, b1, K);
+            if (!(e.dbg & 1)) collision_layer_pair(e, F, a0, a1, b0, b1, K);
           } else {
             for (int s0 = a0; s0 < a1; ++s0) {
               if (!ALIVE(s0)) continue;
@@ -920,7 +942,7 @@ __device__ inline void apply_physics(Env& e) {
   }
   const int n_corr = uni(P->n_corrective);
   for (int c = 0; c < n_corr; ++c) constant_speed(e, &P->corrective[c]);
-  integrate_all(e, 1. / K);
+  if (!(e.dbg & 2)) integrate_all(e, 1. / K);
 }
 
 // ---- game rules ------------------------------------------------------------------------

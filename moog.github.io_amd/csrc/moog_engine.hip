@@ -60,6 +60,7 @@ struct KArgs {
   int32_t* step_type;
   int32_t mode;
   const int16_t* vslot;
+  int32_t dbg;
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_RESET_AUTO = 3 };
@@ -75,7 +76,9 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.xf = e.bb + 4 * a.L.S;
   e.lst = reinterpret_cast<int32_t*>(e.xf + 8 * a.L.S);
   e.voff = e.lst + 128;
+  e.cand = e.voff + ((a.L.S + 3) & ~3);
   e.vslot = a.vslot;
+  e.dbg = a.dbg;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
   e.seed = a.seed;
@@ -246,7 +249,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
-                (size_t)e->L.S * 12 * 8 + 128 * 4 + (size_t)e->L.S * 4 + 16;
+                (size_t)e->L.S * 12 * 8 + 128 * 4 + (size_t)e->L.S * 4 + 16 + 128 * 4;
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
@@ -347,6 +350,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.step_type = out ? out->step_type : nullptr;
   a.mode = mode;
   a.vslot = e->d_vslot;
+  { const char* ds = getenv("MOOG_STEP_DEBUG"); a.dbg = ds ? atoi(ds) : 0; }
   return a;
 }
 

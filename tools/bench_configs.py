@@ -1,0 +1,32 @@
+"""Per-config throughput of the engine (BASELINE.json configs 2-5), kernel times."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'moog.github.io_amd'))
+import torch
+from moog import environment, _abi
+from moog_demos import example_configs
+
+def run(name, n, steps=30, observers=True, **kw):
+    cfg = example_configs.load(name) if not kw else __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, **kw)
+    env = environment.BatchedEnvironment(num_envs=n, seed=1, **cfg)
+    env.check_faults = False
+    env.reset()
+    for _ in range(5):
+        env.step(env.random_action())
+    env.set_timing(True)
+    for k in range(3): env.kernel_time(k)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(steps):
+        env.step(env.random_action())
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    ks = {nm: env.kernel_time(k) for nm, k in (('step', 0), ('raster', 1), ('reset', 2))}
+    faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
+    print('%-24s N=%6d  %10.0f env-steps/s  step %.0f us  raster %.0f us  reset %.0f us  faults %d' % (
+        name, n, n * steps / dt, *(ks[k][0] / max(ks[k][1], 1) * 1e3 for k in ('step', 'raster', 'reset')), faults), flush=True)
+
+run('chase_avoid_torus', 4096)
+run('colliding_predators_32', 4096)
+run('functional_maze', 8192, image_size=(128, 128))
+run('falling_balls_64', 8192, steps=10)
+run('pong', 4096)
+run('colliding_predators', 4096)
+run('falling_balls', 4096)
