@@ -44,6 +44,19 @@ def raster_bytes_per_env(env):
     return float(P.render.height * P.render.width * 3 + per_env.mean().item())
 
 
+def raster_traffic(workload, n_envs):
+    """HBM bytes per raster launch from the committed rocprofv3 PMC passes
+    (profiles/raster_traffic.json; collected with tools/prof.sh), or None."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'raster_traffic.json')) as f:
+            rec = json.load(f).get(workload)
+        if rec and rec.get('n_envs') == n_envs:
+            return rec['traffic_bytes']
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(seconds_target=12.0):
     """Times the CPU oracle (oracle/moog_oracle.c, single thread) on a bounded
     sample of the same workload: 256 envs stepped until ~seconds_target."""
@@ -157,7 +170,9 @@ def main():
                        'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
                        'parallelism': 'env-sharded x%d, no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': raster_traffic(args.workload, n),
+                         'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_current.txt)',
+                         'algorithmic_bytes_per_launch': n * rb,
                          'kernel': 'moog_raster_kernel', 'avg_kernel_us': r_avg_s * 1e6,
                          'algorithmic_bytes_per_env': rb},
             'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items()},
