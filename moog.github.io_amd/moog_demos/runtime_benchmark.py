@@ -1,0 +1,69 @@
+"""Batched counterpart of the reference's tests/runtime_benchmark.py:64-157.
+
+Times the same five phases, per batch of N envs on the GPU (HIP events around the
+engine's kernels plus wall clock):
+  1. full step without rendering       (runtime_benchmark.py:75-84; here: step + reset kernels)
+  2. reset only                         (:90-95)
+  3. physics only                       (:101-107, env.physics.step(env.state))
+  4. rendering only                     (:113-130, env.observation())
+  5. full step with rendering           (:136-157)
+
+    python -m moog_demos.runtime_benchmark --config colliding_predators_32 --num_envs 4096
+"""
+import argparse
+import time
+
+import torch
+
+from moog import _abi, environment
+from moog_demos import example_configs
+
+
+def _timed(fn, reps, sync):
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', default='colliding_predators_32')
+    ap.add_argument('--level', type=int, default=0)
+    ap.add_argument('--num_envs', type=int, default=4096)
+    ap.add_argument('--reps', type=int, default=50)
+    args = ap.parse_args()
+    env = environment.BatchedEnvironment(
+        num_envs=args.num_envs, **example_configs.load(args.config, args.level))
+    env.check_faults = False
+    sync = torch.cuda.synchronize
+    env.reset()
+    for _ in range(5):
+        env.step(env.random_action())
+    n = args.num_envs
+    out_img = env._out.image
+    rows = []
+    # 5. full step with rendering
+    rows.append(('step + render', _timed(lambda: env.step(env.random_action()), args.reps, sync)))
+    # 1. full step, observers disabled
+    env._out.image = None
+    rows.append(('step, no render', _timed(lambda: env.step(env.random_action()), args.reps, sync)))
+    # 2. reset only
+    rows.append(('reset only', _timed(lambda: env.reset(), max(args.reps // 5, 1), sync)))
+    env._out.image = out_img
+    # 3. physics only
+    rows.append(('physics only', _timed(env.physics_step, args.reps, sync)))
+    # 4. rendering only
+    rows.append(('render only', _timed(env.observation, args.reps, sync)))
+    P = env.compiled.program
+    print('%s: %d envs x %d sprites, K=%d, %dx%d' % (args.config, n, P.n_slots,
+                                                     P.updates_per_env_step, P.render.height,
+                                                     P.render.width))
+    for name, ms in rows:
+        print('  %-16s %9.3f ms / batch   %12.0f env-calls/s' % (name, ms, n / ms * 1e3))
+
+
+if __name__ == '__main__':
+    main()
