@@ -72,6 +72,26 @@ __device__ __forceinline__ void wsync() {
 __device__ __forceinline__ double f32r(double x) { return (double)(float)x; }
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
 
+// sin / cos of the small per-substep rotation angles (|th| = |angle_vel| / K, typically
+// < 0.01 rad).  For |th| < 2^-5 the Taylor series through th^9 / th^8 is accurate to
+// below one ulp (next terms < 1e-22), i.e. as good as the library routines without
+// their argument reduction; larger angles use the library.
+__device__ __forceinline__ void sincos_small(double th, double* s, double* c) {
+  if (fabs(th) < 0.03125) {
+    double x2 = th * th;
+    *s = th * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880)))));
+    *c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320))));
+  } else {
+    *s = sin(th); *c = cos(th);
+  }
+}
+
+// exact n / d for 0 <= n < 4096, 1 <= d <= 128 without the integer-division sequence
+__device__ __forceinline__ int div_small(int n, int d) {
+  unsigned m = ((1u << 19) + (unsigned)d - 1u) / (unsigned)d;   // d is wave-uniform: scalar
+  return (int)(((unsigned)n * m) >> 19);
+}
+
 __device__ __forceinline__ double shfl_d(double v, int src) {
   int lo = __shfl(__double2loint(v), src);
   int hi = __shfl(__double2hiint(v), src);
@@ -202,7 +222,7 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
       int idx = base + e.lane;
       bool hit = false;
       if (idx < total) {
-        int ia = idx / cb, ib = idx - ia * cb;
+        int ia = (total <= 4096) ? div_small(idx, cb) : idx / cb, ib = idx - ia * cb;
         int i = e.lst[ia], j = e.lst[64 + ib];
         int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
         double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
@@ -299,10 +319,13 @@ __device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
   return sqrt(d2) > r;
 }
 
-// sprite.py:462-484
-__device__ inline bool overlaps(const Env& e, int s0, int s1) {
-  if (circles_apart(e, s0, s1)) return false;
-  if (bbox_apart(e, s0, s1)) return false;
+// sprite.py:462-484.  `prechecked`: the caller has already evaluated the bounding
+// circle / box rejects on the current state (broad phase).
+__device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = false) {
+  if (!prechecked) {
+    if (circles_apart(e, s0, s1)) return false;
+    if (bbox_apart(e, s0, s1)) return false;
+  }
   if (e.dbg & 8) return false;
   return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
 }
@@ -379,7 +402,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
         dth = a_new - a_old;
         ANG(s) = a_new;
       }
-      a = cos(dth); b = sin(dth);
+      sincos_small(dth, &b, &a);
       tx = (a * (-nx) - b * (-ny)) + nx;
       ty = (b * (-nx) + a * (-ny)) + ny;
       mode = 2.0;
@@ -456,7 +479,8 @@ __device__ inline void compose(double o[6], const double s[6], const double f[6]
   o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5;
 }
 __device__ inline void rot_around(double m[6], double x, double y, double th) {
-  double a = cos(th), b = sin(th);
+  double a, b;
+  sincos_small(th, &b, &a);
   m[0] = a; m[1] = -b; m[2] = (a * (-x) - b * (-y)) + x;
   m[3] = b; m[4] = a; m[5] = (b * (-x) + a * (-y)) + y;
 }
@@ -735,7 +759,7 @@ __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int
   bool moved = false;
   for (int depth = 0; depth <= maxdepth; ++depth) {
     if (s0 == s1) return moved;
-    if (!overlaps(e, s0, s1)) return moved;
+    if (!overlaps(e, s0, s1, depth == 0)) return moved;
     if (e.dbg & 16) return moved;
     double dt = 1. / K;
     CVec c;
@@ -883,7 +907,7 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
       bool cand = false;
       int s0 = 0, t = 0;
       if (idx < total) {
-        int i = idx / nB;
+        int i = (total <= 4096 && nB <= 128) ? div_small(idx, nB) : idx / nB;
         s0 = a0 + i; t = b0 + (idx - i * nB);
         if (s0 != t && ALIVE(s0) && ALIVE(t)) cand = !bbox_apart(e, s0, t) && !circles_apart(e, s0, t);
       }
