@@ -61,7 +61,7 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   size_t o = 0;
   size_t nv = (size_t)TOTV * ncopy, items = (size_t)S * ncopy;
   p->o_edge = o; o = r_align(o + nv * sizeof(REdge)); // packed edge records
-  p->o_slotinfo = o; o = r_align(o + (size_t)S * 8);  // per slot: rank (int), nverts (int)
+  p->o_slotinfo = o; o = r_align(o + (size_t)S * 16); // per slot: rank, nverts, vertex offset, -
   p->o_item_slot = o; o = r_align(o + items * 4);     // slot | copy << 16
   p->o_item_y = o; o = r_align(o + items * 8);        // ymin, ymax (ints, atomics)
   p->o_item_rgba = o; o = r_align(o + items * 4);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
       unsigned long long bal = __ballot(live);
       int rank = n_live + __popcll(bal & ((1ull << tid) - 1ull));
-      if (s < S) { slotinfo[2 * s] = live ? rank : -1; slotinfo[2 * s + 1] = nv; carry[2 * s] = 0; carry[2 * s + 1] = 0; }
+      if (s < S) { slotinfo[4 * s] = live ? rank : -1; slotinfo[4 * s + 1] = nv; slotinfo[4 * s + 2] = P->slot_voff[s]; carry[2 * s] = 0; carry[2 * s + 1] = 0; }
       if (live) {
         unsigned r8, g8, b8;
         const double* col = gf + a.L.o_color + 3 * s;
@@ -416,8 +416,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     int s = a.vslot[idx];
-    int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
-    int k = idx - P->slot_voff[s];
+    int rank = slotinfo[4 * s], nv = slotinfo[4 * s + 1];
+    int k = idx - slotinfo[4 * s + 2];
     if (rank < 0 || k >= nv) continue;
     double2 v = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * idx);
     for (int c = 0; c < ncopy; ++c) {
@@ -443,8 +443,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       const int base = base0 + (tid & ~63);   // this wave's 64-vertex chunk
       int idx = base + lane;
       int s = (idx < TOTV) ? (int)a.vslot[idx] : 0;
-      int rank = slotinfo[2 * s], nv = slotinfo[2 * s + 1];
-      int v0 = P->slot_voff[s];
+      int rank = slotinfo[4 * s], nv = slotinfo[4 * s + 1];
+      int v0 = slotinfo[4 * s + 2];
       int k = idx - v0;
       bool valid = (idx < TOTV) && rank >= 0 && k < nv;
       const short2* pv = ivert + c * TOTV + v0;
@@ -514,9 +514,9 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   for (int c = 0; c < ncopy; ++c) {
     for (int idx = tid; idx < TOTV; idx += R_THREADS) {
       int s = a.vslot[idx];
-      int rank = slotinfo[2 * s];
+      int rank = slotinfo[4 * s];
       if (rank < 0) continue;
-      int v0 = P->slot_voff[s];
+      int v0 = slotinfo[4 * s + 2];
       int k = idx - v0;
       int nt = item_cnt[rank * ncopy + c] & 0xffff;
       if (k >= nt) continue;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       int sc = item_slot[g];
       int s = sc & 0xffff, c = sc >> 16;
       int cnt = item_cnt[g];
-      RPoly poly = {edges + c * TOTV + P->slot_voff[s], slotinfo[2 * s + 1], cnt & 0xffff, cnt >> 16};
+      RPoly poly = {edges + c * TOTV + slotinfo[4 * s + 2], slotinfo[4 * s + 1], cnt & 0xffff, cnt >> 16};
       bool generic = false;
       RMask m = scanline_mask(poly, y, pymax, W, &generic);
       if (generic) {
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         int sc = item_slot[g];
         int s = sc & 0xffff, c = sc >> 16;
         int cnt = item_cnt[g];
-        RPoly poly = {edges + c * TOTV + P->slot_voff[s], slotinfo[2 * s + 1], cnt & 0xffff, cnt >> 16};
+        RPoly poly = {edges + c * TOTV + slotinfo[4 * s + 2], slotinfo[4 * s + 1], cnt & 0xffff, cnt >> 16};
         RMask m = scanline_mask_generic(poly, y, pymax, xxs + tid, W);
         masks[(size_t)w * words] = m.w0;
         if (words > 1) masks[(size_t)w * words + 1] = m.w1;
