@@ -194,7 +194,7 @@ struct moog_engine {
   int64_t env_index0 = 0;
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
-  int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0;
+  int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
   bool timing = false;
   TimedKernel timed[MOOG_K_COUNT];
 };
@@ -262,13 +262,16 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_items = prog->n_slots * ncopy;
     if (e->raster_items < 1) e->raster_items = 1;
     e->raster_iwords = (e->raster_items + 31) / 32;
+    int maxv = 2;
+    for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
+    e->raster_xxcap = 2 * maxv;
     RPlan pl;
     // coverage-mask buffer: at most 512 rows per pass (>= H so any item fits)
     int cap = e->raster_items * H;
     if (cap > 512) cap = 512;
     if (cap < H) cap = H;
     int chunk = cap;
-    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_words, e->raster_iwords, &pl);
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_words, e->raster_iwords, e->raster_xxcap, &pl);
     if (pl.total > 160 * 1024) {
       hipFree(e->d_prog); hipFree(e->d_vslot); delete e;
       return fail(MOOG_E_UNSUPPORTED, "raster working set does not fit in LDS");
@@ -359,7 +362,7 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
   r.vslot = e->d_vslot;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
-  r.iwords = e->raster_iwords; r.max_items = e->raster_items;
+  r.iwords = e->raster_iwords; r.max_items = e->raster_items; r.xxcap = e->raster_xxcap;
   { const char* ds = getenv("MOOG_RASTER_STOP"); r.debug_stop = ds ? atoi(ds) : 0; }
   {
     Bracket br(e, MOOG_K_RASTER, s);

@@ -25,7 +25,6 @@
 
 #define R_THREADS 256
 #define R_SLOW 16     // lanes that run the generic scanline concurrently (bounds its LDS scratch)
-#define R_XX 24      // max crossings kept per scanline
 
 struct RArgs {
   const moog_program_t* P;
@@ -40,6 +39,7 @@ struct RArgs {
   int32_t iwords;      // 32-bit words of the per-row item bitmask
   int32_t max_items;   // S * copies
   int32_t debug_stop;  // >0: return after that phase (profiling aid)
+  int32_t xxcap;       // crossing-list capacity of the generic scanline = 2 * max vertices per sprite
 };
 
 // LDS plan shared by host (sizes) and device (carve-up)
@@ -57,7 +57,7 @@ struct REdge { short x0, y0, y1, x1; float dx; float pad; };
 __host__ __device__ inline size_t r_align(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, int H, int cap_rows,
-                                            int words, int iwords, RPlan* p) {
+                                            int words, int iwords, int xxcap, RPlan* p) {
   size_t o = 0;
   size_t nv = (size_t)TOTV * ncopy, items = (size_t)S * ncopy;
   p->o_edge = o; o = r_align(o + nv * sizeof(REdge)); // packed edge records
@@ -71,7 +71,7 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   p->o_misc = o; o = r_align(o + 64);
   p->o_carry = o; o = r_align(o + (size_t)S * 8);     // counts carried over a 64-vertex chunk
   p->o_queue = o; o = r_align(o + (size_t)cap_rows * 2 + 16);   // rows that need the generic scanline
-  p->o_xx = o; o = r_align(o + (size_t)R_XX * R_SLOW * 4);
+  p->o_xx = o; o = r_align(o + (size_t)xxcap * R_SLOW * 4);
   // union: the integer vertices are dead once the edge records are packed; the
   // coverage masks live only afterwards
   size_t u = o;
@@ -201,7 +201,8 @@ __device__ inline int tip_partner(const REdge* e, int i, bool top, float* vv_out
 
 // Generic scanline (any number of crossings, corner fix-ups): crossing list in LDS.
 // xx: this thread's crossing list, element j at xx[j * R_SLOW].
-__device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ymax, float* xx, int W) {
+__device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ymax, float* xx, int W,
+                                              const int R_XX) {
   RMask m = {0ull, 0ull};
   int j = 0;
   for (int i = 0; i < p.nt; ++i) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
 
   RPlan pl;
-  raster_plan(S, TOTV, ncopy, W, H, cap_rows, words, iwords, &pl);
+  raster_plan(S, TOTV, ncopy, W, H, cap_rows, words, iwords, a.xxcap, &pl);
   short2* ivert = reinterpret_cast<short2*>(moog_lds + pl.o_ivert);
   REdge* edges = reinterpret_cast<REdge*>(moog_lds + pl.o_edge);
   int* slotinfo = reinterpret_cast<int*>(moog_lds + pl.o_slotinfo);
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         int s = sc & 0xffff, c = sc >> 16;
         int cnt = item_cnt[g];
         RPoly poly = {edges + c * TOTV + slotinfo[4 * s + 2], slotinfo[4 * s + 1], cnt & 0xffff, cnt >> 16};
-        RMask m = scanline_mask_generic(poly, y, pymax, xxs + tid, W);
+        RMask m = scanline_mask_generic(poly, y, pymax, xxs + tid, W, a.xxcap);
         masks[(size_t)w * words] = m.w0;
         if (words > 1) masks[(size_t)w * words + 1] = m.w1;
         if (m.w0 | m.w1) atomicOr(&rowitems[y * iwords + (it >> 5)], 1u << (it & 31));

@@ -316,6 +316,36 @@ def make_raster(n_poly=3000, seed=11):
             angle=rs.uniform(0, 2 * np.pi) if i % 5 else 0.,
             scale=rs.uniform(0.02, 0.6), aspect_ratio=rs.uniform(0.4, 1.6))
         v = s.vertices * W
+        kind = i % 10
+        if kind == 7:      # comb: > 8 crossings per scanline (generic scanline path)
+            teeth = rs.randint(4, 8)
+            x0, y0 = rs.uniform(-0.1, 0.5) * W, rs.uniform(-0.1, 0.5) * W
+            tw, th = rs.uniform(2, 7), rs.uniform(5, 40)
+            pts_ = [(x0, y0)]
+            for t in range(teeth):
+                xa = x0 + (2 * t) * tw
+                pts_ += [(xa + rs.uniform(0, 1), y0 + th + rs.uniform(-2, 2)), (xa + tw, y0 + th * rs.uniform(0.2, 0.6)),
+                         (xa + 2 * tw, y0 + th + rs.uniform(-2, 2))][:3]
+            pts_.append((x0 + 2 * teeth * tw, y0))
+            v = np.array(pts_[:VMAX])
+            if i % 20 == 7:
+                ang = rs.uniform(0, 2 * np.pi)
+                R = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+                v = (v - v.mean(0)) @ R.T + v.mean(0)
+        elif kind == 8:    # fan of same-lean spikes sharing tips (repeated corner fix-ups)
+            cx, cy = rs.uniform(0.2, 0.8) * W, rs.uniform(0.2, 0.8) * W
+            n_sp = rs.randint(2, 5)
+            pts_ = []
+            for t in range(n_sp):
+                pts_ += [(cx + rs.randint(-3, 4), cy + rs.randint(-2, 3)),
+                         (cx + rs.uniform(5, 30), cy + rs.uniform(5, 30) * (1 if t % 2 else -1)),
+                         (cx + rs.uniform(8, 40), cy + rs.uniform(2, 20) * (1 if t % 2 else -1))]
+            v = np.array(pts_)
+        elif kind == 9:    # tiny sprites: coincident integer vertices, merged horizontal runs
+            s2 = ref_sprite.Sprite(x=rs.uniform(0.05, 0.95), y=rs.uniform(0.05, 0.95), shape=shape,
+                                   angle=rs.uniform(0, 2 * np.pi), scale=rs.uniform(0.01, 0.06),
+                                   aspect_ratio=rs.uniform(0.5, 1.5))
+            v = s2.vertices * W
         pts = [tuple(p) for p in v]
         canvas = Image.new('RGB', (W, W), (10, 20, 30))
         draw = ImageDraw.Draw(canvas, 'RGBA')
