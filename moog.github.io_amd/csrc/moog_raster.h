@@ -260,76 +260,65 @@ __device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ym
 }
 
 // Coverage of scanline y of one polygon: polygon_generic(hasAlpha=1), one row.
-// Fast path: up to 8 crossings kept sorted in registers (insertion by a min/max
-// chain; the sorted multiset is all the span loop needs).  A corner fix-up replaces
-// the partner's entry, whose value equals this edge's crossing x, so it is "remove
-// one x, insert vv" on the sorted registers.  More than 8 crossings or a second
-// fix-up on the same row (the partner's entry might already be modified) are queued
-// for the generic routine.
-#define R_INSERT(val)                                  \
-  {                                                    \
-    float t_ = (val), lo_;                             \
-    lo_ = fminf(r0, t_); t_ = fmaxf(r0, t_); r0 = lo_; \
-    lo_ = fminf(r1, t_); t_ = fmaxf(r1, t_); r1 = lo_; \
-    lo_ = fminf(r2, t_); t_ = fmaxf(r2, t_); r2 = lo_; \
-    lo_ = fminf(r3, t_); t_ = fmaxf(r3, t_); r3 = lo_; \
-    lo_ = fminf(r4, t_); t_ = fmaxf(r4, t_); r4 = lo_; \
-    lo_ = fminf(r5, t_); t_ = fmaxf(r5, t_); r5 = lo_; \
-    lo_ = fminf(r6, t_); t_ = fmaxf(r6, t_); r6 = lo_; \
-    r7 = fminf(r7, t_);                                \
-  }
-
-__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int W, bool* need_generic) {
+// Fast path: up to N crossings kept sorted in registers (insertion by a min/max
+// chain; the sorted multiset is all the span loop needs).  The edge loop is branch
+// free: an inactive edge inserts +inf, which leaves the registers unchanged, so lanes
+// working on different polygons do not diverge.  A corner fix-up replaces the
+// partner's entry, whose value equals this edge's crossing x, i.e. "remove one x,
+// insert vv".  More than N crossings or a second fix-up on the same row (the
+// partner's entry might already be modified) report `overflow`.
+template <int N>
+__device__ inline RMask scanline_regs(const RPoly& p, int y, int poly_ymax, int W, bool* overflow) {
   const float INF = __builtin_inff();
-  float r0 = INF, r1 = INF, r2 = INF, r3 = INF, r4 = INF, r5 = INF, r6 = INF, r7 = INF;
+  float r[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) r[q] = INF;
   int j = 0, nfix = 0;
   for (int i = 0; i < p.nt; ++i) {
     REdge E = p.e[i];
     int y0 = E.y0, y1 = E.y1;
     int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
-    if (y < emin || y > emax) continue;
+    bool active = (y >= emin) && (y <= emax);
     float x = (float)(y - y0) * E.dx + (float)E.x0;
-    bool dup = (y == emax && y < poly_ymax);
-    ++j;
-    R_INSERT(x);
-    if (dup) { ++j; R_INSERT(x); }
-    else {
-      int flag = __float_as_int(E.pad);
-      if (flag && ((y == emin && (flag & 1)) || (y == emax && (flag & 2)))) {
-        float vv = 0.0f;
-        int kt = tip_partner(p.e, i, y == emin, &vv);
-        if (kt >= 0) {
-          ++nfix;
-          // remove one instance of x (the partner's entry), then insert vv
-          bool f = false;
-          f = f || (r0 == x); r0 = f ? r1 : r0;
-          f = f || (r1 == x); r1 = f ? r2 : r1;
-          f = f || (r2 == x); r2 = f ? r3 : r2;
-          f = f || (r3 == x); r3 = f ? r4 : r3;
-          f = f || (r4 == x); r4 = f ? r5 : r4;
-          f = f || (r5 == x); r5 = f ? r6 : r5;
-          f = f || (r6 == x); r6 = f ? r7 : r6;
-          r7 = INF;
-          R_INSERT(vv);
-        }
+    bool dup = active && (y == emax) && (y < poly_ymax);
+    j += (active ? 1 : 0) + (dup ? 1 : 0);
+    float ta = active ? x : INF, td = dup ? x : INF;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      float lo = fminf(r[q], ta); ta = fmaxf(r[q], ta);
+      float lo2 = fminf(lo, td); td = fmaxf(lo, td);
+      r[q] = lo2;
+    }
+    int flag = __float_as_int(E.pad);
+    if (active && !dup && flag && ((y == emin && (flag & 1)) || (y == emax && (flag & 2)))) {
+      float vv = 0.0f;
+      int kt = tip_partner(p.e, i, y == emin, &vv);
+      if (kt >= 0) {
+        ++nfix;
+        bool f = false;   // remove one instance of x (the partner's entry) ...
+#pragma unroll
+        for (int q = 0; q < N - 1; ++q) { f = f || (r[q] == x); r[q] = f ? r[q + 1] : r[q]; }
+        r[N - 1] = INF;
+        float t = vv;     // ... then insert vv
+#pragma unroll
+        for (int q = 0; q < N; ++q) { float lo = fminf(r[q], t); t = fmaxf(r[q], t); r[q] = lo; }
       }
     }
   }
   RMask m = {0ull, 0ull};
-  *need_generic = (nfix > 1 || j > 8);
-  if (*need_generic) return m;
+  *overflow = (nfix > 1 || j > N);
+  if (*overflow) return m;
   bool head_here = false;
   for (int i = 0; i < p.nh; ++i) head_here = head_here || (p.e[p.n - 1 - i].y0 == y);
   int x_pos = (j == 0) ? -1 : 0;
-  const float lo4[4] = {r0, r2, r4, r6}, hi4[4] = {r1, r3, r5, r7};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < N / 2; ++q) {
     if (2 * q + 1 < j) {
-      int x_end = pil_round_down(hi4[q]);
+      int x_end = pil_round_down(r[2 * q + 1]);
       if (x_end >= x_pos) {
         if (head_here) draw_horizontal(p, y, &x_pos, m, W);
         if (x_end >= x_pos) {
-          int x_start = pil_round_up(lo4[q]);
+          int x_start = pil_round_up(r[2 * q]);
           bool skip = false;
           if (x_pos > x_start) { x_start = x_pos; skip = (x_end < x_start); }
           if (!skip) {
@@ -341,6 +330,16 @@ __device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int 
     }
   }
   if (head_here) draw_horizontal(p, y, &x_pos, m, W);
+  return m;
+}
+
+// 8 sorted registers cover ~99 % of the rows; rows with 9..16 crossings (spoked
+// shapes) re-run with 16; anything beyond is queued for the generic LDS routine.
+__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int W, bool* need_generic) {
+  bool over = false;
+  RMask m = scanline_regs<8>(p, y, poly_ymax, W, &over);
+  if (over) m = scanline_regs<16>(p, y, poly_ymax, W, &over);
+  *need_generic = over;
   return m;
 }
 
