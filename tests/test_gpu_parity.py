@@ -250,3 +250,55 @@ def test_gym_wrapper_contract():
     obs, reward, done, info = env.step(np.array([0.5, -0.5]))   # auto-reset: FIRST timestep
     assert not done and reward == 0 and info['discount'] is None
     assert np.array_equal(env.render(), obs['image'])
+
+
+def test_multi_device_sharding_matches_single_engine():
+    """Two engine handles (here on the same GPU) over a split env axis reproduce the
+    single-engine batch: global-index RNG keys, no exchange between shards."""
+    import torch
+    from moog import sharding
+    from moog_demos import example_configs
+    n = 96
+    cfg = example_configs.load('chase_avoid_torus')
+    multi = sharding.MultiDeviceEnvironment(n, ['cuda:0', 'cuda:0'], seed=4, **cfg)
+    single = make_env('chase_avoid_torus', n, seed=4)
+    a = multi.gather(multi.reset())
+    b = single.reset()
+    assert np.array_equal(a.observation['image'].numpy(), b.observation['image'].cpu().numpy())
+    rs = np.random.RandomState(1)
+    for _ in range(12):
+        act = rs.uniform(-1, 1, size=(n, 2))
+        a = multi.gather(multi.step(act))
+        b = single.step(act)
+    assert np.array_equal(a.step_type.numpy(), b.step_type.cpu().numpy())
+    assert helpers.same_or_nan(a.reward.numpy(), b.reward.cpu().numpy())
+    assert np.array_equal(a.observation['image'].numpy(), b.observation['image'].cpu().numpy())
+    f = torch.cat([s.state_f64 for s in multi.shards]).cpu().numpy()
+    assert np.array_equal(f, single.state_f64.cpu().numpy(), equal_nan=True)
+
+
+def test_edge_cases_empty_and_dead_layers():
+    """Empty layers, every prey vanished, a single env, and an env count that is not a
+    multiple of anything: engine == oracle."""
+    import torch
+    for name, n in (('falling_balls', 1), ('pong', 3), ('functional_maze', 5)):
+        env = make_env(name, n, seed=2)
+        o = helpers.OracleEnv(env.compiled, n_envs=n, seed=2)
+        env.reset()
+        o.reset(render=False)
+        L = env.layout
+        if name == 'functional_maze':   # kill all prey: Reset(condition=layer empty) must arm
+            s0, cnt = env.compiled.layer_slots['prey']
+            env.state_i32[:, L.o_flags + s0:L.o_flags + s0 + cnt] = 0
+            o.i32[:, L.o_flags + s0:L.o_flags + s0 + cnt] = 0
+        rs = np.random.RandomState(3)
+        for k in range(10):
+            a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+            out = env.step(a)
+            o.step(a, render=False)
+            f, q = download(env)
+            assert np.array_equal(q, o.i32), (name, k)
+            assert np.array_equal(out.step_type.cpu().numpy(), o.step_type), (name, k)
+            assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward), (name, k)
+            o.f64[:], o.i32[:] = f, q
+        assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
