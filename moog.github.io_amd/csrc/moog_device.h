@@ -519,10 +519,16 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
   bool contained = false;
   if (e.lane < n0) {
     cx = v0[2 * e.lane]; cy = v0[2 * e.lane + 1];
-    contained = contains_points1(e, s1, cx, cy);
+    // a point outside s1's vertex box cannot be inside the polygon; symmetric circles
+    // are tested against the full disc (sprite.py:453-456), which bulges out of that box
+    bool maybe = (FLAGS(s1) & MOOG_F_SYM_CIRCLE) ||
+                 !(cx < BB(s1, 0) - BB_MARGIN || cx > BB(s1, 2) + BB_MARGIN ||
+                   cy < BB(s1, 1) - BB_MARGIN || cy > BB(s1, 3) + BB_MARGIN);
+    if (maybe) contained = contains_points1(e, s1, cx, cy);
   }
   uint64_t cmask = __ballot(contained);
   if (cmask == 0ull) return;
+  if (e.dbg & 32) return;
   double m[6];
   relative_motion_matrix(e, s0, s1, dt, m);
   double pvx = (m[0] * cx + m[1] * cy) + m[2];
@@ -538,11 +544,11 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
       double ds1x = v1[2 * j2] - v1[2 * j], ds1y = v1[2 * j2 + 1] - v1[2 * j + 1];
       double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
       double mx = v1[2 * j] - pvx, my = v1[2 * j + 1] - pvy;
-      double A = (mx * ds1y - my * ds1x) / den;
       double B = (mx * ds0y - my * ds0x) / den;
       bool crossing = (B >= 0) && (B <= 1);
       rowany |= crossing;
-      double ca = crossing ? A : -DINF;
+      double ca = -DINF;   // cross_a only matters where the edge is crossed (collisions.py:185)
+      if (crossing) ca = (mx * ds1y - my * ds1x) / den;
       double ab = fabs(1. - ca);
       if (j == 0) { bestabs = ab; bestca = ca; nanfound = isnan(ab); }
       else if (!nanfound) {
@@ -552,6 +558,7 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
     }
   }
   if (__ballot(rowany) == 0ull) return;
+  if (e.dbg & 64) return;
   double cpx = pvx + bestca * (cx - pvx), cpy = pvy + bestca * (cy - pvy);
   double dfx = cx - cpx, dfy = cy - cpy;
   double dist = norm2(dfx, dfy);

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   }
   Env e;
   bind_env(e, a, env);
+  const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   load_record(e, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
   store_record(e, gf, gq);
+  if ((a.dbg & 128) && e.lane == 0 && a.discount) a.discount[env] = (double)(clock64() - t_begin);  // profiling aid
 }
 
 #include "moog_raster.h"

@@ -1,0 +1,17 @@
+"""Per-env cycle counts of the step kernel (MOOG_STEP_DEBUG=128 writes clock64 deltas into `discount`)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'moog.github.io_amd'))
+os.environ['MOOG_STEP_DEBUG'] = '128'
+import numpy as np, torch
+from moog import environment
+from moog_demos import example_configs
+env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.load('colliding_predators_32'))
+env.check_faults = False
+env.reset()
+for k in range(60):
+    ts = env.step(env.random_action())
+    if k % 10 == 9:
+        c = ts.discount.cpu().numpy()
+        c = c[ts.step_type.cpu().numpy() != 0]
+        q = np.percentile(c, [0, 10, 50, 90, 99, 99.9, 100])
+        print('step %d cycles/env: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f  mean %.0f' % ((k,) + tuple(q) + (c.mean(),)))
