@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 3
+#define MOOG_ABI_VERSION 4
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -199,14 +199,15 @@ typedef struct {
 
 /* ---- renderer (observers/pil_renderer.py:37-120) --------------------------- */
 enum { MOOG_CMAP_IDENTITY = 0, MOOG_CMAP_HSV = 1 };     /* color_maps.py:21-23 */
-enum { MOOG_POLYMOD_NONE = 0, MOOG_POLYMOD_TORUS = 1 }; /* polygon_modifiers.py:32-38,67-98 */
+enum { MOOG_POLYMOD_NONE = 0, MOOG_POLYMOD_TORUS = 1,   /* polygon_modifiers.py:32-38,67-98 */
+       MOOG_POLYMOD_FIRST_PERSON = 2 };                  /* polygon_modifiers.py:41-64 */
 
 typedef struct {
   int32_t width, height; /* PIL canvas (image_size[0], image_size[1])          */
   int32_t cmap;
   int32_t polymod;
   int32_t bg[3];
-  int32_t pad_;
+  int32_t polymod_layer; /* FIRST_PERSON: agent layer (its first sprite is drawn at (0.5, 0.5)) */
 } moog_render_t;
 
 /* ---- the lowered config ----------------------------------------------------- */

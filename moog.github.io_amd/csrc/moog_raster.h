@@ -413,6 +413,18 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const int total_items = misc[0] * ncopy;
   if (a.debug_stop == 1) return;
 
+  // FirstPersonAgent (polygon_modifiers.py:41-64): every polygon is translated so that the
+  // agent layer's first sprite sits at (0.5, 0.5)
+  const bool first_person = (P->render.polymod == MOOG_POLYMOD_FIRST_PERSON);
+  double fpx = 0, fpy = 0;
+  if (first_person) {
+    int l = P->render.polymod_layer;
+    for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+      if (slotinfo[4 * s] >= 0) {
+        fpx = 0.5 - gf[a.L.o_pos + 2 * s]; fpy = 0.5 - gf[a.L.o_pos + 2 * s + 1];
+        break;
+      }
+  }
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     int s = a.vslot[idx];
@@ -423,6 +435,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
     for (int c = 0; c < ncopy; ++c) {
       double vx = v.x, vy = v.y;
       if (torus) { vx = vx + (double)(c / 3 - 1); vy = vy + (double)(c % 3 - 1); }
+      if (first_person) { vx = vx + fpx; vy = vy + fpy; }
       int ix = (int)((double)W * vx), iy = (int)((double)H * vy);
       short2 o; o.x = clamp16(ix); o.y = clamp16(iy);
       ivert[c * TOTV + idx] = o;

@@ -353,6 +353,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     Rn.cmap = _abi.MOOG_CMAP_HSV if ren._cmap == 'hsv' else _abi.MOOG_CMAP_IDENTITY
     if isinstance(ren._polygon_modifier, polygon_modifiers.TorusGeometry):
         Rn.polymod = _abi.MOOG_POLYMOD_TORUS
+    elif isinstance(ren._polygon_modifier, polygon_modifiers.FirstPersonAgent):
+        Rn.polymod = _abi.MOOG_POLYMOD_FIRST_PERSON
+        Rn.polymod_layer = layer_index(ren._polygon_modifier._agent_layer)
     elif isinstance(ren._polygon_modifier, polygon_modifiers.DoNothing):
         Rn.polymod = _abi.MOOG_POLYMOD_NONE
     else:

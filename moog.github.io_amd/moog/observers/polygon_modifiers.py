@@ -1,4 +1,4 @@
-"""Polygon modifiers (reference: moog/observers/polygon_modifiers.py:32-38,67-98)."""
+"""Polygon modifiers (reference: moog/observers/polygon_modifiers.py:32-98)."""
 
 
 class AbstractPolygonModifier(object):
@@ -7,6 +7,14 @@ class AbstractPolygonModifier(object):
 
 class DoNothing(AbstractPolygonModifier):
     pass
+
+
+class FirstPersonAgent(AbstractPolygonModifier):
+    """Translates every polygon so that the first sprite of `agent_layer` is drawn
+    at (0.5, 0.5) (polygon_modifiers.py:41-64)."""
+
+    def __init__(self, agent_layer):
+        self._agent_layer = agent_layer
 
 
 class TorusGeometry(AbstractPolygonModifier):

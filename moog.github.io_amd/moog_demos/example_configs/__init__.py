@@ -11,8 +11,10 @@ the scaled variants of SURVEY.md 8(d).
 import importlib
 
 NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
-         'colliding_predators_32', 'falling_balls_64')
+         'colliding_predators_32', 'falling_balls_64', 'forces_zoo')
 
 
 def load(name, level=0):
+    if name.endswith('_l1'):   # e.g. chase_avoid_torus_l1 = level 1 of chase_avoid_torus
+        name, level = name[:-3], 1
     return importlib.import_module(__name__ + '.' + name).get_config(level)

@@ -93,6 +93,8 @@ def load_amd_config(name):
     variants from this repo's recipes, run against the reference package."""
     if name in SHIPPED:
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
+    if name == 'chase_avoid_torus_l1':   # level 1: 1-2 prey and 1-2 predators (randint counts)
+        return importlib.import_module('moog_demos.example_configs.chase_avoid_torus').get_config(1)
     pkg = 'amd_configs'
     if pkg not in sys.modules:
         spec = importlib.util.spec_from_file_location(
@@ -440,6 +442,8 @@ def main():
         ('falling_balls', 48, {}, (0,)),
         ('colliding_predators_32', 40, {}, (0,)),
         ('falling_balls_64', 12, {}, (0,)),
+        ('forces_zoo', 96, {}, (0, 1)),
+        ('chase_avoid_torus_l1', 48, {'prey': 2, 'predators': 2}, (0,)),
     ]
     only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:

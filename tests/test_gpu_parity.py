@@ -11,7 +11,7 @@ TOL = 1e-5
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
         ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
-        ('falling_balls_64', 0)]
+        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0)]
 
 
 def make_env(name, n, seed=0, **kw):

@@ -13,7 +13,7 @@ from helpers import OracleEnv, compiled, fixture, records_from_fixture, state_di
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
         ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
-        ('falling_balls_64', 0)]
+        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0)]
 TOL = 1e-5   # BASELINE.json: float sprite state within 1e-5 abs
 
 
