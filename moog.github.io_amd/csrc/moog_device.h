@@ -34,11 +34,11 @@ struct Env {
   int64_t env_index;
   int lane;
   double* bb;              // LDS scratch [S][4]: conservative AABB (xmin, ymin, xmax, ymax)
-  double* xf;              // LDS scratch [S][8]: per-sprite integrate transform
+  double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
-  int32_t* lst;            // LDS scratch [128]: compacted edge index lists
+  uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
-  int32_t* cand;           // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
+  uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
 };
 
@@ -215,8 +215,8 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
   int total = ca * cb;
   if (total > 0) {
     unsigned long long below = (1ull << e.lane) - 1ull;
-    if (ka) e.lst[__popcll(ma & below)] = e.lane;
-    if (kb) e.lst[64 + __popcll(mb & below)] = e.lane;
+    if (ka) e.lst[__popcll(ma & below)] = (uint8_t)e.lane;
+    if (kb) e.lst[64 + __popcll(mb & below)] = (uint8_t)e.lane;
     wsync();
     for (int base = 0; base < total; base += 64) {
       int idx = base + e.lane;
@@ -369,64 +369,80 @@ __device__ inline void set_position(Env& e, int s, double nx, double ny) {
 __device__ inline void integrate_all(Env& e, double dt) {
   const moog_program_t* P = e.P;
   const int S = P->n_slots;
+  const bool in_regs = (S <= 64);   // per-sprite transform lives in lane s and is fetched by shuffles
   wsync();
+  double r0 = 0, r1 = 0, r2 = 1, r3 = 0, r4 = 0, r5 = 0, r6 = 0;   // ddx, ddy, a, b, tx, ty, mode
   for (int s = e.lane; s < S; s += 64) {
-    double* x = &e.xf[8 * s];
+    double x0 = 0, x1 = 0, x2 = 1, x3 = 0, x4 = 0, x5 = 0, x6 = 0;
     int fl = FLAGS(s);
-    if (!(fl & MOOG_F_ALIVE)) { x[6] = 0.0; continue; }
-    double dx, dy;
-    if (fl & MOOG_F_VEL_F32) {
-      float dtf = (float)dt;
-      dx = (double)(dtf * (float)VELX(s));
-      dy = (double)(dtf * (float)VELY(s));
-    } else {
-      dx = dt * VELX(s);
-      dy = dt * VELY(s);
-    }
-    double ox = PX(s), oy = PY(s);
-    double nx = ox + dx, ny = oy + dy;
-    double ddx = nx - ox, ddy = ny - oy;
-    double w = ANGV(s);
-    double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0;
-    if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
-      double dth;
-      if (fl & MOOG_F_ANGVEL_F32) {
-        float t = (float)dt * (float)w;
-        float a_old = (float)ANG(s);
-        float a_new = a_old + t;
-        dth = (double)(a_new - a_old);
-        ANG(s) = (double)a_new;
+    if (fl & MOOG_F_ALIVE) {
+      double dx, dy;
+      if (fl & MOOG_F_VEL_F32) {
+        float dtf = (float)dt;
+        dx = (double)(dtf * (float)VELX(s));
+        dy = (double)(dtf * (float)VELY(s));
       } else {
-        double a_old = ANG(s);
-        double a_new = a_old + dt * w;
-        dth = a_new - a_old;
-        ANG(s) = a_new;
+        dx = dt * VELX(s);
+        dy = dt * VELY(s);
       }
-      sincos_small(dth, &b, &a);
-      tx = (a * (-nx) - b * (-ny)) + nx;
-      ty = (b * (-nx) + a * (-ny)) + ny;
-      mode = 2.0;
+      double ox = PX(s), oy = PY(s);
+      double nx = ox + dx, ny = oy + dy;
+      double ddx = nx - ox, ddy = ny - oy;
+      double w = ANGV(s);
+      double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0;
+      if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
+        double dth;
+        if (fl & MOOG_F_ANGVEL_F32) {
+          float t = (float)dt * (float)w;
+          float a_old = (float)ANG(s);
+          float a_new = a_old + t;
+          dth = (double)(a_new - a_old);
+          ANG(s) = (double)a_new;
+        } else {
+          double a_old = ANG(s);
+          double a_new = a_old + dt * w;
+          dth = a_new - a_old;
+          ANG(s) = a_new;
+        }
+        sincos_small(dth, &b, &a);
+        tx = (a * (-nx) - b * (-ny)) + nx;
+        ty = (b * (-nx) + a * (-ny)) + ny;
+        mode = 2.0;
+      }
+      x0 = ddx; x1 = ddy; x2 = a; x3 = b; x4 = tx; x5 = ty; x6 = mode;
+      PX(s) = nx; PY(s) = ny;
+      if (mode != 2.0) {
+        BB(s, 0) = BB(s, 0) + ddx; BB(s, 2) = BB(s, 2) + ddx;
+        BB(s, 1) = BB(s, 1) + ddy; BB(s, 3) = BB(s, 3) + ddy;
+      }
     }
-    x[0] = ddx; x[1] = ddy; x[2] = a; x[3] = b; x[4] = tx; x[5] = ty; x[6] = mode;
-    PX(s) = nx; PY(s) = ny;
-    if (mode != 2.0) {
-      BB(s, 0) = BB(s, 0) + ddx; BB(s, 2) = BB(s, 2) + ddx;
-      BB(s, 1) = BB(s, 1) + ddy; BB(s, 3) = BB(s, 3) + ddy;
+    if (in_regs) { r0 = x0; r1 = x1; r2 = x2; r3 = x3; r4 = x4; r5 = x5; r6 = x6; }
+    else {
+      double* x = &e.xf[8 * s];
+      x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3; x[4] = x4; x[5] = x5; x[6] = x6;
     }
   }
   wsync();
   double* vall = &e.f[e.L.o_verts];
-  for (int idx = e.lane; idx < e.L.TOTV; idx += 64) {
-    int s = e.vslot[idx];
-    const double* x = &e.xf[8 * s];
-    double mode = x[6];
+  const int TOTV = e.L.TOTV;
+  for (int base = 0; base < TOTV; base += 64) {
+    int idx = base + e.lane;
+    bool in = idx < TOTV;
+    int s = in ? (int)e.vslot[idx] : 0;
+    double x0, x1, x2, x3, x4, x5, mode;
+    if (in_regs) {
+      x0 = shfl_d(r0, s); x1 = shfl_d(r1, s); x2 = shfl_d(r2, s); x3 = shfl_d(r3, s);
+      x4 = shfl_d(r4, s); x5 = shfl_d(r5, s); mode = shfl_d(r6, s);
+    } else {
+      const double* x = &e.xf[8 * s];
+      x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3]; x4 = x[4]; x5 = x[5]; mode = x[6];
+    }
     int k = idx - e.voff[s];
-    if (mode == 0.0 || k >= NV(s)) continue;
-    double vx = vall[2 * idx] + x[0], vy = vall[2 * idx + 1] + x[1];
+    if (!in || mode == 0.0 || k >= NV(s)) continue;
+    double vx = vall[2 * idx] + x0, vy = vall[2 * idx + 1] + x1;
     if (mode == 2.0) {
-      double a = x[2], b = x[3];
-      double rx = (a * vx + (-b) * vy) + x[4];
-      double ry = (b * vx + a * vy) + x[5];
+      double rx = (x2 * vx + (-x3) * vy) + x4;
+      double ry = (x3 * vx + x2 * vy) + x5;
       vx = rx; vy = ry;
     }
     vall[2 * idx] = vx; vall[2 * idx + 1] = vy;
@@ -434,7 +450,8 @@ __device__ inline void integrate_all(Env& e, double dt) {
   wsync();
   // exact boxes of the sprites that rotated (lanes = sprites, each scans its vertices)
   for (int s = e.lane; s < S; s += 64) {
-    if (e.xf[8 * s + 6] != 2.0) continue;
+    double mode = in_regs ? r6 : e.xf[8 * s + 6];
+    if (mode != 2.0) continue;
     const double* v = VERT(s);
     int n = NV(s);
     double x0 = DINF, y0 = DINF, x1 = -DINF, y1 = -DINF;
@@ -900,7 +917,7 @@ __device__ inline void constant_speed(Env& e, const moog_corrective_t* C) {
 // reference order, to a candidate list in LDS.  The list is consumed sequentially by
 // the narrow phase; as soon as a pair actually overlapped (state may have changed),
 // the list is discarded and rebuilt from the next pair on.
-#define CAND_CAP 128
+#define CAND_CAP 128   // list entries; a full list is consumed before the scan continues
 __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a0, int a1, int b0,
                                             int b1, int K) {
   const int nB = b1 - b0, total = (a1 - a0) * nB;
@@ -919,7 +936,7 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
         if (s0 != t && ALIVE(s0) && ALIVE(t)) cand = !bbox_apart(e, s0, t) && !circles_apart(e, s0, t);
       }
       uint64_t m = __ballot(cand);
-      if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (s0 << 8) | t;
+      if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (uint16_t)((s0 << 8) | t);
       count += __popcll(m);
       scanned += 64;
     }
@@ -928,7 +945,7 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
     // ---- consume ----------------------------------------------------------------------------
     bool rebuilt = false;
     for (int c = 0; c < count; ++c) {
-      int pr = uni(e.cand[c]);
+      int pr = uni((int)e.cand[c]);
       int s0 = pr >> 8, t = pr & 255;
       if (!(e.dbg & 4) && collision_step(e, F, s0, t, K)) {
         start = (s0 - a0) * nB + (t - b0) + 1;

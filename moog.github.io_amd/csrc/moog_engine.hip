@@ -73,10 +73,11 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.f = reinterpret_cast<double*>(moog_lds);
   e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
   e.bb = reinterpret_cast<double*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
-  e.xf = e.bb + 4 * a.L.S;
-  e.lst = reinterpret_cast<int32_t*>(e.xf + 8 * a.L.S);
-  e.voff = e.lst + 128;
-  e.cand = e.voff + ((a.L.S + 3) & ~3);
+  e.xf = e.bb + 4 * a.L.S;                                  // [S][8] only when S > 64
+  double* after_xf = (a.L.S > 64) ? e.xf + 8 * a.L.S : e.xf;
+  e.voff = reinterpret_cast<int32_t*>(after_xf);
+  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((a.L.S + 3) & ~3));
+  e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
@@ -251,7 +252,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
-                (size_t)e->L.S * 12 * 8 + 128 * 4 + (size_t)e->L.S * 4 + 16 + 128 * 4;
+                (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
+                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 16;
+  { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
