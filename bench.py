@@ -89,6 +89,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
     args = ap.parse_args()
 
     import torch
@@ -110,6 +111,8 @@ def main():
         num_envs=n, device=dev, seed=2024, env_index0=sharding.shard_range(n * world, rank, world)[0],
         **example_configs.load(args.workload))
     env.check_faults = False
+    if not args.no_schedule:
+        env.enable_cost_schedule()
     env.reset()
     is_grid = env._is_grid
 

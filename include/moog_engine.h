@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 4
+#define MOOG_ABI_VERSION 5
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -366,6 +366,13 @@ int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject,
                              void* hip_stream);
 /* env.observation() only (environment.py:128-131, runtime_benchmark.py:113-130). */
 int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
+
+/* Optional launch-order schedule for the step kernel (pure performance hint, results
+ * do not depend on it).  `cost_dev` (float[n_envs], borrowed) receives every env's
+ * shader-clock cycles of the last step; `perm_dev` (int32[n_envs], borrowed) is the order
+ * in which workgroups pick envs -- the host typically keeps it sorted by descending
+ * cost so that the expensive envs (clustered contacts) start first.  NULLs disable. */
+int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* cost_dev);
 
 /* Per-kernel device timing: when enabled every launch is bracketed by HIP
  * events on the launch stream; totals are read back (synchronising) here. */

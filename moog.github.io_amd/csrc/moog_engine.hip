@@ -61,6 +61,8 @@ struct KArgs {
   int32_t mode;
   const int16_t* vslot;
   int32_t dbg;
+  const int32_t* perm;   // launch order (or null)
+  float* cost;           // per-env cycles of this step (or null)
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_RESET_AUTO = 3 };
@@ -117,6 +119,8 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
 __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
+  if (a.perm) env = a.perm[env];
+  const long long t_sched = a.cost ? clock64() : 0;
   int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   if (a.mode == MODE_STEP && gq[a.L.o_reset_next] == 2) {  // reset earlier in this call
     if (threadIdx.x == 0) gq[a.L.o_reset_next] = 0;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
   store_record(e, gf, gq);
+  if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) a.discount[env] = (double)(clock64() - t_begin);  // profiling aid
 }
 
@@ -199,6 +204,8 @@ struct moog_engine {
   size_t step_lds = 0, raster_lds = 0;
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
   bool timing = false;
+  const int32_t* perm = nullptr;
+  float* cost = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
 };
 
@@ -358,6 +365,8 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.step_type = out ? out->step_type : nullptr;
   a.mode = mode;
   a.vslot = e->d_vslot;
+  a.perm = (mode == MODE_STEP) ? e->perm : nullptr;
+  a.cost = (mode == MODE_STEP) ? e->cost : nullptr;
   { const char* ds = getenv("MOOG_STEP_DEBUG"); a.dbg = ds ? atoi(ds) : 0; }
   return a;
 }
@@ -411,6 +420,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     hipLaunchKernelGGL(moog_reset_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
   }
   a.mode = MODE_STEP;
+  a.perm = e->perm;
+  a.cost = e->cost;
   {
     Bracket br(e, MOOG_K_STEP, s);
     hipLaunchKernelGGL(moog_step_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
@@ -438,6 +449,13 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream) {
   if (rc) return rc;
   if (!image_dev) return fail(MOOG_E_INVALID, "null image");
   return launch_raster(e, image_dev, (hipStream_t)hip_stream);
+}
+
+int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* cost_dev) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  e->perm = perm_dev;
+  e->cost = cost_dev;
+  return MOOG_OK;
 }
 
 int moog_engine_set_timing(moog_engine_t* e, int32_t enabled) {

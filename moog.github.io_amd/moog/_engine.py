@@ -15,7 +15,7 @@ SYMBOLS = (
     'moog_abi_version', 'moog_last_error', 'moog_program_sizeof', 'moog_engine_create',
     'moog_engine_destroy', 'moog_engine_layout', 'moog_engine_load_state', 'moog_engine_reset',
     'moog_engine_step', 'moog_engine_physics_only', 'moog_engine_render',
-    'moog_engine_set_timing', 'moog_engine_kernel_time',
+    'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
 )
 
 _LIB = None
@@ -56,6 +56,7 @@ def load_library(path=None):
                                      ctypes.POINTER(_abi.StepOut), vp]
     lib.moog_engine_physics_only.argtypes = [vp, ctypes.POINTER(_abi.Inject), vp]
     lib.moog_engine_render.argtypes = [vp, vp, vp]
+    lib.moog_engine_set_schedule.argtypes = [vp, vp, vp]
     lib.moog_engine_set_timing.argtypes = [vp, i32]
     lib.moog_engine_kernel_time.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(i64)]

@@ -76,6 +76,23 @@ class BatchedEnvironment(object):
         self._out.image = ctypes.cast(self.image.data_ptr(), ctypes.POINTER(ctypes.c_uint8))
         self._is_grid = P.action.kind == _abi.MOOG_ACTION_GRID
         self.check_faults = True
+        self._cost = self._perm = None
+
+    def enable_cost_schedule(self, enabled=True):
+        """Launch the step kernel's workgroups in order of descending per-env cost of the
+        previous step (longest-processing-time first): the envs with clustered contacts
+        start first instead of landing in the under-filled tail of the launch.  A pure
+        scheduling hint -- results are identical."""
+        torch = self._torch
+        if enabled:
+            self._cost = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
+            self._perm = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
+            _engine.check(self._lib, self._lib.moog_engine_set_schedule(
+                self._handle, ctypes.c_void_p(self._perm.data_ptr()),
+                ctypes.c_void_p(self._cost.data_ptr())))
+        else:
+            self._cost = self._perm = None
+            _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
 
     # -- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -134,6 +151,8 @@ class BatchedEnvironment(object):
             a = torch.as_tensor(action, device=self.device).to(torch.float64).contiguous()
             assert a.shape == (self.num_envs, 2)
         inj, keep = self._inject(injected_uniforms)
+        if self._perm is not None:   # refresh the launch order from last step's per-env cycles
+            self._perm.copy_(torch.argsort(self._cost, descending=True))
         with torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_step(
                 self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,

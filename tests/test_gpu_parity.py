@@ -302,3 +302,25 @@ def test_edge_cases_empty_and_dead_layers():
             assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward), (name, k)
             o.f64[:], o.i32[:] = f, q
         assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
+
+
+def test_cost_schedule_is_result_neutral():
+    """Cost-ordered launch of the step kernel (a scheduling hint) changes nothing."""
+    import torch
+    outs = []
+    for sched in (False, True):
+        env = make_env('colliding_predators_32', 512, seed=8)
+        if sched:
+            env.enable_cost_schedule()
+        env.reset()
+        g = torch.Generator(device='cpu').manual_seed(1)
+        for _ in range(12):
+            out = env.step(torch.rand((512, 2), generator=g, dtype=torch.float64) * 2 - 1)
+        f, q = download(env)
+        outs.append((f, q, out.observation['image'].cpu().numpy(), out.reward.cpu().numpy()))
+        if sched:
+            assert float(env._cost.min()) > 0 and sorted(env._perm.cpu().tolist()) == list(range(512))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][3], outs[1][3], equal_nan=True)
