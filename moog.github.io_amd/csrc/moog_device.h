@@ -39,6 +39,7 @@ struct Env {
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
+  int n_path, n_resp;      // profiling counters (path tests, contact searches)
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
 };
 
@@ -65,7 +66,8 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 // Single-wave workgroup: LDS operations of one wave execute in order, so
 // cross-lane visibility only needs the compiler/waitcnt fence.
 __device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // LDS only ("local"): do not also drain outstanding global loads (vmcnt) here
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -327,6 +329,7 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
     if (bbox_apart(e, s0, s1)) return false;
   }
   if (e.dbg & 8) return false;
+  if (e.dbg & 128) const_cast<Env&>(e).n_path++;
   return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
 }
 
@@ -532,73 +535,101 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
   const double* v0 = VERT(s0);
   const double* v1 = VERT(s1);
   int n0 = NV(s0), n1 = NV(s1);
+  // lanes j < n1 hold edge j of s1 for both the containment tests and the row scan below
+  const int j = e.lane;
+  double e1x = 0, e1y = 0, e2x = 0, e2y = 0;
+  if (j < n1) {
+    int j2 = (j + 1 == n1) ? 0 : j + 1;
+    e1x = v1[2 * j]; e1y = v1[2 * j + 1]; e2x = v1[2 * j2]; e2y = v1[2 * j2 + 1];
+  }
+  // sprite_1.contains_points(vertices_0) (collisions.py:139): lanes = vertices of s0
   double cx = 0, cy = 0;
-  bool contained = false;
+  bool contained = false, maybe = false;
+  const bool disc = (FLAGS(s1) & MOOG_F_SYM_CIRCLE) != 0;
   if (e.lane < n0) {
     cx = v0[2 * e.lane]; cy = v0[2 * e.lane + 1];
-    // a point outside s1's vertex box cannot be inside the polygon; symmetric circles
-    // are tested against the full disc (sprite.py:453-456), which bulges out of that box
-    bool maybe = (FLAGS(s1) & MOOG_F_SYM_CIRCLE) ||
-                 !(cx < BB(s1, 0) - BB_MARGIN || cx > BB(s1, 2) + BB_MARGIN ||
-                   cy < BB(s1, 1) - BB_MARGIN || cy > BB(s1, 3) + BB_MARGIN);
-    if (maybe) contained = contains_points1(e, s1, cx, cy);
+    if (disc) contained = norm2(cx - PX(s1), cy - PY(s1)) <= MAXR(s1);   // sprite.py:453-456
+    else  // a point outside s1's vertex box (or non-finite) cannot be inside the polygon
+      maybe = isfinite(cx) && isfinite(cy) &&
+              !(cx < BB(s1, 0) - BB_MARGIN || cx > BB(s1, 2) + BB_MARGIN ||
+                cy < BB(s1, 1) - BB_MARGIN || cy > BB(s1, 3) + BB_MARGIN);
+  }
+  // even-odd test of the few remaining points, one at a time, lanes = edges of s1
+  // (matplotlib point_in_path_impl: parity of the edge toggles, order independent)
+  uint64_t mb = __ballot(maybe);
+  while (mb) {
+    int l = __ffsll((long long)mb) - 1;
+    mb &= mb - 1;
+    double tx = shfl_d(cx, l), ty = shfl_d(cy, l);
+    bool toggle = false;
+    if (j < n1) {
+      bool f0 = (e1y >= ty), f1 = (e2y >= ty);
+      if (f0 != f1) toggle = (((e2y - ty) * (e1x - e2x) >= (e2x - tx) * (e1y - e2y)) == f1);
+    }
+    int par = __popcll(__ballot(toggle)) & 1;
+    if (e.lane == l) contained = (par != 0);
   }
   uint64_t cmask = __ballot(contained);
   if (cmask == 0ull) return;
   if (e.dbg & 32) return;
   double m[6];
   relative_motion_matrix(e, s0, s1, dt, m);
-  double pvx = (m[0] * cx + m[1] * cy) + m[2];
-  double pvy = (m[3] * cx + m[4] * cy) + m[5];
-  double ds0x = cx - pvx, ds0y = cy - pvy;
-  // row scan: np.argmin(|1 - cross_a|) with non-crossings at -inf (first index, NaN wins)
-  bool rowany = false, nanfound = false;
-  int best = 0;
-  double bestabs = 0, bestca = 0;
-  if (contained) {
-    for (int j = 0; j < n1; ++j) {
-      int j2 = (j + 1 == n1) ? 0 : j + 1;
-      double ds1x = v1[2 * j2] - v1[2 * j], ds1y = v1[2 * j2 + 1] - v1[2 * j + 1];
-      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
-      double mx = v1[2 * j] - pvx, my = v1[2 * j + 1] - pvy;
-      double B = (mx * ds0y - my * ds0x) / den;
-      bool crossing = (B >= 0) && (B <= 1);
-      rowany |= crossing;
-      double ca = -DINF;   // cross_a only matters where the edge is crossed (collisions.py:185)
-      if (crossing) ca = (mx * ds1y - my * ds1x) / den;
-      double ab = fabs(1. - ca);
-      if (j == 0) { bestabs = ab; bestca = ca; nanfound = isnan(ab); }
-      else if (!nanfound) {
-        if (isnan(ab)) { best = j; bestabs = ab; bestca = ca; nanfound = true; }
-        else if (ab < bestabs) { best = j; bestabs = ab; bestca = ca; }
-      }
-    }
-  }
-  if (__ballot(rowany) == 0ull) return;
-  if (e.dbg & 64) return;
-  double cpx = pvx + bestca * (cx - pvx), cpy = pvy + bestca * (cy - pvy);
-  double dfx = cx - cpx, dfy = cy - cpy;
-  double dist = norm2(dfx, dfy);
-  if (dist == DINF) dist = 0;
-  // np.argmax over contained rows in vertex order (first max, NaN wins)
-  int ci = -1;
-  double bv = 0;
+  // Rows of the crossing-coefficient matrix = contained vertices, visited in vertex order by
+  // a wave-uniform loop; within a row the lanes are the edges of s1 (sprite.py:108-163).  Per
+  // row: np.argmin(|1 - cross_a|) with non-crossings at -inf (first index, NaN wins), the
+  // crossing point and its distance; across rows: np.argmax (first max, NaN wins).
+  const double ds1x = e2x - e1x, ds1y = e2y - e1y;
+  bool anycross = false;
+  int ci = -1, e1 = 0;
+  double bv = 0, ca = 0, bpx = 0, bpy = 0, bsx = 0, bsy = 0;
   bool cnan = false;
   uint64_t mm = cmask;
   while (mm) {
     int l = __ffsll((long long)mm) - 1;
     mm &= mm - 1;
-    double d = shfl_d(dist, l);
-    if (ci < 0) { ci = l; bv = d; cnan = isnan(d); }
-    else if (!cnan) {
-      if (isnan(d)) { ci = l; cnan = true; }
-      else if (d > bv) { ci = l; bv = d; }
+    double rcx = shfl_d(cx, l), rcy = shfl_d(cy, l);
+    double pvx = (m[0] * rcx + m[1] * rcy) + m[2];
+    double pvy = (m[3] * rcx + m[4] * rcy) + m[5];
+    double ds0x = rcx - pvx, ds0y = rcy - pvy;
+    bool crossing = false;
+    double cav = -DINF;   // cross_a only matters where the edge is crossed (collisions.py:185)
+    if (j < n1) {
+      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
+      double mx = e1x - pvx, my = e1y - pvy;
+      double B = (mx * ds0y - my * ds0x) / den;
+      crossing = (B >= 0) && (B <= 1);
+      if (crossing) cav = (mx * ds1y - my * ds1x) / den;
     }
+    double ab = fabs(1. - cav);
+    uint64_t crossm = __ballot(crossing);
+    anycross = anycross || (crossm != 0ull);
+    // argmin over the lanes j < n1
+    uint64_t inrow = (n1 >= 64) ? ~0ull : ((1ull << n1) - 1ull);
+    uint64_t nanm = __ballot(isnan(ab)) & inrow;
+    int best;
+    if (nanm) best = __ffsll((long long)nanm) - 1;
+    else {
+      double v = (j < n1) ? ab : DINF, mn = v;
+      for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, shfl_d(mn, e.lane ^ o));
+      uint64_t eq = __ballot(v == mn) & inrow;
+      best = __ffsll((long long)eq) - 1;
+    }
+    double bca = shfl_d(cav, best);
+    double cpx = pvx + bca * (rcx - pvx), cpy = pvy + bca * (rcy - pvy);
+    double dfx = rcx - cpx, dfy = rcy - cpy;
+    double dist = norm2(dfx, dfy);
+    if (dist == DINF) dist = 0;
+    bool take;
+    if (ci < 0) { take = true; cnan = isnan(dist); }
+    else if (cnan) take = false;
+    else if (isnan(dist)) { take = true; cnan = true; }
+    else take = dist > bv;
+    if (take) { ci = l; bv = dist; e1 = best; ca = bca; bpx = cpx; bpy = cpy; bsx = dfx; bsy = dfy; }
   }
-  int e1 = __shfl(best, ci);
-  double ca = shfl_d(bestca, ci);
-  out.px = shfl_d(cpx, ci); out.py = shfl_d(cpy, ci);
-  out.sx = shfl_d(dfx, ci); out.sy = shfl_d(dfy, ci);
+  if (!anycross) return;   // `if not np.any(crossings)` (collisions.py:177-179)
+  if (e.dbg & 64) return;
+  out.px = bpx; out.py = bpy;
+  out.sx = bsx; out.sy = bsy;
   out.nx = out.ny = out.qx = out.qy = 0;
   if (ca > 1) { out.status = CV_FUTURE; return; }
   int e2 = (e1 + 1 == n1) ? 0 : e1 + 1;
@@ -785,6 +816,7 @@ __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int
     if (s0 == s1) return moved;
     if (!overlaps(e, s0, s1, depth == 0)) return moved;
     if (e.dbg & 16) return moved;
+    if (e.dbg & 128) e.n_resp++;
     double dt = 1. / K;
     CVec c;
     get_collision_vectors(e, s0, s1, dt, c);

@@ -82,6 +82,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
   e.vslot = a.vslot;
   e.dbg = a.dbg;
+  e.n_path = 0; e.n_resp = 0;
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
   e.seed = a.seed;
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   }
   store_record(e, gf, gq);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
-  if ((a.dbg & 128) && e.lane == 0 && a.discount) a.discount[env] = (double)(clock64() - t_begin);  // profiling aid
+  if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
+    a.discount[env] = (double)(clock64() - t_begin);
+    if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp);
+  }
 }
 
 #include "moog_raster.h"

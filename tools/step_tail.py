@@ -12,6 +12,15 @@ for k in range(60):
     ts = env.step(env.random_action())
     if k % 10 == 9:
         c = ts.discount.cpu().numpy()
-        c = c[ts.step_type.cpu().numpy() != 0]
+        r = ts.reward.cpu().numpy()
+        keep = ts.step_type.cpu().numpy() != 0
+        c, r = c[keep], r[keep]
+        npath, nresp = r % 100000, r // 100000
+        A = np.stack([np.ones_like(c), npath, nresp], 1)
+        coef = np.linalg.lstsq(A, c, rcond=None)[0]
+        order = np.argsort(-c)[:5]
+        print('  fit cycles = %.0f + %.0f*path_tests + %.0f*contact_searches; mean path %.1f resp %.1f; slowest:' % (
+            coef[0], coef[1], coef[2], npath.mean(), nresp.mean()),
+            [(int(c[i]), int(npath[i]), int(nresp[i])) for i in order])
         q = np.percentile(c, [0, 10, 50, 90, 99, 99.9, 100])
         print('step %d cycles/env: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f  mean %.0f' % ((k,) + tuple(q) + (c.mean(),)))
