@@ -36,6 +36,7 @@ struct Env {
   double* bb;              // LDS scratch [S][4]: conservative AABB (xmin, ymin, xmax, ymax)
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
+  uint8_t* vsl;            // LDS copy of vslot [TOTV]
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -392,7 +393,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
       double nx = ox + dx, ny = oy + dy;
       double ddx = nx - ox, ddy = ny - oy;
       double w = ANGV(s);
-      double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0;
+      double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0, dth_abs = 0;
       if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
         double dth;
         if (fl & MOOG_F_ANGVEL_F32) {
@@ -411,6 +412,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
         tx = (a * (-nx) - b * (-ny)) + nx;
         ty = (b * (-nx) + a * (-ny)) + ny;
         mode = 2.0;
+        dth_abs = dth;
       }
       x0 = ddx; x1 = ddy; x2 = a; x3 = b; x4 = tx; x5 = ty; x6 = mode;
       PX(s) = nx; PY(s) = ny;
@@ -418,6 +420,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
         BB(s, 0) = BB(s, 0) + ddx; BB(s, 2) = BB(s, 2) + ddx;
         BB(s, 1) = BB(s, 1) + ddy; BB(s, 3) = BB(s, 3) + ddy;
       }
+      (void)dth_abs;
     }
     if (in_regs) { r0 = x0; r1 = x1; r2 = x2; r3 = x3; r4 = x4; r5 = x5; r6 = x6; }
     else {
@@ -431,7 +434,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
   for (int base = 0; base < TOTV; base += 64) {
     int idx = base + e.lane;
     bool in = idx < TOTV;
-    int s = in ? (int)e.vslot[idx] : 0;
+    int s = in ? (int)e.vsl[idx] : 0;
     double x0, x1, x2, x3, x4, x5, mode;
     if (in_regs) {
       x0 = shfl_d(r0, s); x1 = shfl_d(r1, s); x2 = shfl_d(r2, s); x3 = shfl_d(r3, s);

@@ -30,6 +30,7 @@ __device__ inline void load_record(const Env& e, const double* gf, const int32_t
   int4* dsti = reinterpret_cast<int4*>(e.q);
   for (int i = e.lane; i < e.L.i32_per_env / 4; i += 64) dsti[i] = srci[i];
   for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
+  for (int i = e.lane; i < e.L.TOTV; i += 64) e.vsl[i] = (uint8_t)e.vslot[i];
   wsync();
 }
 
@@ -80,6 +81,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.voff = reinterpret_cast<int32_t*>(after_xf);
   e.cand = reinterpret_cast<uint16_t*>(e.voff + ((a.L.S + 3) & ~3));
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
+  e.vsl = e.lst + 128;
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0;
@@ -264,7 +266,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   }
   e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
                 (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
-                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 16;
+                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + (size_t)((e->L.TOTV + 15) & ~15) + 16;
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
