@@ -75,8 +75,8 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.L = a.L;
   e.f = reinterpret_cast<double*>(moog_lds);
   e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
-  e.bb = reinterpret_cast<double*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
-  e.xf = e.bb + 4 * a.L.S;                                  // [S][8] only when S > 64
+  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
+  e.xf = reinterpret_cast<double*>(e.bb + 8 * a.L.S);       // [S][8] only when S > 64
   double* after_xf = (a.L.S > 64) ? e.xf + 8 * a.L.S : e.xf;
   e.voff = reinterpret_cast<int32_t*>(after_xf);
   e.cand = reinterpret_cast<uint16_t*>(e.voff + ((a.L.S + 3) & ~3));
