@@ -802,6 +802,91 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
   }
 }
 
+// collisions.py:548-576: position pop-out by `perpendicular` followed by the impulse
+// (_collide_with / _collide_without_update_angle_vel, :292-454).  The reference does this
+// as six in-place updates; here every new value is computed from registers first (same
+// arithmetic, same order) and the state is written once: lanes = vertices for the two
+// path translations, lane 0 for the scalars.
+__device__ inline void resolve_contact(Env& e, const moog_force_t* F, int s0, int s1, const CVec& c,
+                                       int symmetric, int upd) {
+  const double elasticity = F->p0;
+  const int f0 = FLAGS(s0), f1 = FLAGS(s1);
+  // --- pop-out (collisions.py:548-555)
+  double p0x = PX(s0), p0y = PY(s0), p1x = PX(s1), p1y = PY(s1);
+  double n0x, n0y, n1x = p1x, n1y = p1y;
+  if (symmetric) {
+    n0x = p0x - (0.5 + EPS_COLL) * c.qx; n0y = p0y - (0.5 + EPS_COLL) * c.qy;
+    n1x = p1x + (0.5 + EPS_COLL) * c.qx; n1y = p1y + (0.5 + EPS_COLL) * c.qy;
+  } else {
+    n0x = p0x - (1. + EPS_COLL) * c.qx; n0y = p0y - (1. + EPS_COLL) * c.qy;
+  }
+  const double d0x = n0x - p0x, d0y = n0y - p0y, d1x = n1x - p1x, d1y = n1y - p1y;
+  // --- impulse, evaluated on the displaced positions
+  const double nx = c.nx, ny = c.ny;
+  double v0x = VELX(s0), v0y = VELY(s0), v1x = VELX(s1), v1y = VELY(s1);
+  double w0 = ANGV(s0), w1 = ANGV(s1);
+  const double m0 = MASS(s0), m1 = MASS(s1);
+  double a0x, a0y, a1x, a1y, dw0 = 0, dw1 = 0;
+  bool fault = false;
+  if (upd) {  // collisions.py:353-454
+    double i0 = (0 + m0 * INER(s0, 0)) + m0 * INER(s0, 1);
+    double i1 = (0 + m1 * INER(s1, 0)) + m1 * INER(s1, 1);
+    double v0 = v0x * nx + v0y * ny;
+    double v1 = v1x * nx + v1y * ny;
+    double c0x = c.px - n0x, c0y = c.py - n0y;
+    double c1x = c.px - n1x, c1y = c.py - n1y;
+    double r0 = sqrt(c0x * c0x + c0y * c0y), r1 = sqrt(c1x * c1x + c1y * c1y);
+    double sin0 = (c0x * ny - c0y * nx) / r0, sin1 = (c1x * ny - c1y * nx) / r1;
+    double S0 = r0 * sin0, S1 = r1 * sin1;
+    double a = m0 + m1 + m0 * m1 * ((S0 * S0 / i0) + (S1 * S1 / i1));
+    double b = (1 + elasticity) * (v0 - v1 + w0 * S0 - w1 * S1);
+    double dv0, dv1;
+    if (symmetric) { dv0 = -1 * m1 * b / a; dv1 = m0 * b / a; }
+    else { dv0 = -1 * m1 * b / (a - m0); dv1 = 0.; }
+    dw0 = m0 * dv0 * S0 / i0; dw1 = m1 * dv1 * S1 / i1;
+    a0x = dv0 * nx; a0y = dv0 * ny; a1x = dv1 * nx; a1y = dv1 * ny;
+  } else {    // collisions.py:292-350
+    double nn = sqrt(nx * nx + ny * ny);
+    fault = !(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.);   // np.isclose(norm, 1., atol=1e-4) -> ValueError
+    double q0 = v0x * nx + v0y * ny;
+    double q1 = v1x * nx + v1y * ny;
+    double v0nx = q0 * nx, v0ny = q0 * ny, v1nx = q1 * nx, v1ny = q1 * ny;
+    double cmx, cmy;
+    if (symmetric) {
+      cmx = (v0nx * m0 + v1nx * m1) / (m0 + m1);
+      cmy = (v0ny * m0 + v1ny * m1) / (m0 + m1);
+    } else { cmx = v1nx; cmy = v1ny; }
+    double f = 1 + elasticity;
+    a0x = f * (cmx - v0nx); a0y = f * (cmy - v0ny); a1x = f * (cmx - v1nx); a1y = f * (cmy - v1ny);
+  }
+  if (!fault) {   // in-place adds with the reference's float32 rounding (see vel_iadd)
+    if (f0 & MOOG_F_VEL_F32) { v0x = f32r(v0x + a0x); v0y = f32r(v0y + a0y); } else { v0x = v0x + a0x; v0y = v0y + a0y; }
+    if (f1 & MOOG_F_VEL_F32) { v1x = f32r(v1x + a1x); v1y = f32r(v1y + a1y); } else { v1x = v1x + a1x; v1y = v1y + a1y; }
+    if (upd) {
+      w0 = (f0 & MOOG_F_ANGVEL_F32) ? f32r(w0 + dw0) : w0 + dw0;
+      w1 = (f1 & MOOG_F_ANGVEL_F32) ? f32r(w1 + dw1) : w1 + dw1;
+    }
+  }
+  // --- commit
+  double* va = VERT(s0);
+  double* vb = VERT(s1);
+  const int na = NV(s0), nb = NV(s1);
+  wsync();
+  if (e.lane < na) { va[2 * e.lane] = va[2 * e.lane] + d0x; va[2 * e.lane + 1] = va[2 * e.lane + 1] + d0y; }
+  if (symmetric && e.lane < nb) { vb[2 * e.lane] = vb[2 * e.lane] + d1x; vb[2 * e.lane + 1] = vb[2 * e.lane + 1] + d1y; }
+  if (e.lane == 0) {
+    PX(s0) = n0x; PY(s0) = n0y;
+    dop_translate(&BB(s0, 0), d0x, d0y);
+    if (symmetric) { PX(s1) = n1x; PY(s1) = n1y; dop_translate(&BB(s1, 0), d1x, d1y); }
+    if (fault) e.q[e.L.o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    else {
+      VELX(s0) = v0x; VELY(s0) = v0y; VELX(s1) = v1x; VELY(s1) = v1y;
+      if (upd) { ANGV(s0) = w0; ANGV(s1) = w1; }
+    }
+  }
+  wsync();
+}
+
 // collisions.py:494-584.  Returns true when a sprite position changed (the broad
 // phase must then be redone for the following pairs); velocity-only outcomes and
 // "future contact" no-ops return false.
@@ -823,15 +908,8 @@ __device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int
     } else if (c.status == CV_FUTURE) {
       return moved;
     } else {
-      if (symmetric) {
-        set_position(e, s0, PX(s0) - (0.5 + EPS_COLL) * c.qx, PY(s0) - (0.5 + EPS_COLL) * c.qy);
-        set_position(e, s1, PX(s1) + (0.5 + EPS_COLL) * c.qx, PY(s1) + (0.5 + EPS_COLL) * c.qy);
-      } else {
-        set_position(e, s0, PX(s0) - (1. + EPS_COLL) * c.qx, PY(s0) - (1. + EPS_COLL) * c.qy);
-      }
+      resolve_contact(e, F, s0, s1, c, symmetric, upd);
       moved = true;
-      if (upd) collide_with_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
-      else collide_without_update_angle_vel(e, s0, s1, c, F->p0, symmetric);
     }
   }
   return moved;
