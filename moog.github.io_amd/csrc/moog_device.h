@@ -18,6 +18,23 @@
 
 #include "../../include/moog_engine.h"
 
+// The lowered config is read-only device memory.  Reading it through the constant
+// address space lets wave-uniform accesses compile to scalar loads (s_load, scalar
+// cache) instead of per-lane vector loads.
+#define MOOG_CONST __attribute__((address_space(4)))
+typedef const MOOG_CONST moog_program_t* PProg;
+typedef const MOOG_CONST moog_force_t* PForce;
+typedef const MOOG_CONST moog_corrective_t* PCorr;
+typedef const MOOG_CONST moog_rule_t* PRule;
+typedef const MOOG_CONST moog_task_t* PTask;
+typedef const MOOG_CONST moog_action_t* PAction;
+typedef const MOOG_CONST moog_shape_t* PShape;
+typedef const MOOG_CONST moog_genop_t* PGenop;
+typedef const MOOG_CONST moog_factor_t* PFactor;
+__device__ __forceinline__ PProg as_const_prog(const moog_program_t* p) {
+  return (PProg)(unsigned long long)p;
+}
+
 #define EPS_INTERP 1e-8  // sprite.py:35
 #define EPS_COLL 1e-2    // collisions.py:46
 #define MOOG_F_TMP 0x100 // scratch flag bit (vanish marks)
@@ -26,7 +43,7 @@
 struct Env {
   double* f;               // LDS f64 record
   int32_t* q;              // LDS i32 record
-  const moog_program_t* P; // global
+  PProg P;                 // lowered config (constant address space)
   moog_layout_t L;
   const double* inj;
   int inj_n;
@@ -305,7 +322,7 @@ __device__ inline void bbox_exact_wave(Env& e, int s) {
 
 // lanes = sprites; each lane scans its own vertex list (kernel prologue)
 __device__ inline void bbox_build_all(Env& e) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   for (int s = e.lane; s < P->n_slots; s += 64) dop_scan(VERT(s), NV(s), &BB(s, 0));
   wsync();
 }
@@ -377,7 +394,7 @@ __device__ inline void set_position(Env& e, int s, double nx, double ny) {
 // setter, :531-540, matplotlib rotate_around).  Per-vertex arithmetic is exactly
 // the reference's; sprites are independent so the order does not matter.
 __device__ inline void integrate_all(Env& e, double dt) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   const int S = P->n_slots;
   const bool in_regs = (S <= 64);   // per-sprite transform lives in lane s and is fetched by shuffles
   wsync();
@@ -807,7 +824,7 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
 // as six in-place updates; here every new value is computed from registers first (same
 // arithmetic, same order) and the state is written once: lanes = vertices for the two
 // path translations, lane 0 for the scalars.
-__device__ inline void resolve_contact(Env& e, const moog_force_t* F, int s0, int s1, const CVec& c,
+__device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const CVec& c,
                                        int symmetric, int upd) {
   const double elasticity = F->p0;
   const int f0 = FLAGS(s0), f1 = FLAGS(s1);
@@ -890,7 +907,7 @@ __device__ inline void resolve_contact(Env& e, const moog_force_t* F, int s0, in
 // collisions.py:494-584.  Returns true when a sprite position changed (the broad
 // phase must then be redone for the following pairs); velocity-only outcomes and
 // "future contact" no-ops return false.
-__device__ inline bool collision_step(Env& e, const moog_force_t* F, int s0, int s1, int K) {
+__device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K) {
   const int symmetric = uni(F->symmetric), upd = uni(F->i0), maxdepth = uni(F->i1);
   s0 = uni(s0); s1 = uni(s1);
   bool moved = false;
@@ -923,7 +940,7 @@ __device__ inline void newton_apply(Env& e, int s, double fx, double fy, int K) 
   vel_iadd(e, s, fx / den, fy / den);
 }
 
-__device__ inline void force_single(Env& e, const moog_force_t* F, int s, int K) {
+__device__ inline void force_single(Env& e, PForce F, int s, int K) {
   switch (F->kind) {
     case MOOG_FORCE_DRAG: {
       double m = MASS(s);
@@ -965,7 +982,7 @@ __device__ inline void force_single(Env& e, const moog_force_t* F, int s, int K)
   }
 }
 
-__device__ inline void force_pair_newton(Env& e, const moog_force_t* F, int s0, int s1, int K) {
+__device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K) {
   double dx = PX(s1) - PX(s0), dy = PY(s1) - PY(s0);
   double dist = sqrt(dx * dx + dy * dy);
   double f0x = 0, f0y = 0, f1x = 0, f1y = 0;
@@ -989,8 +1006,8 @@ __device__ inline void force_pair_newton(Env& e, const moog_force_t* F, int s0, 
 }
 
 // constant_speed.py:34-46
-__device__ inline void constant_speed(Env& e, const moog_corrective_t* C) {
-  const moog_program_t* P = e.P;
+__device__ inline void constant_speed(Env& e, PCorr C) {
+  PProg P = e.P;
   for (int a = 0; a < C->n_layers; ++a) {
     int l = C->layers[a];
     int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
@@ -1025,7 +1042,7 @@ __device__ inline void constant_speed(Env& e, const moog_corrective_t* C) {
 // the narrow phase; as soon as a pair actually overlapped (state may have changed),
 // the list is discarded and rebuilt from the next pair on.
 #define CAND_CAP 128   // list entries; a full list is consumed before the scan continues
-__device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a0, int a1, int b0,
+__device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, int b0,
                                             int b1, int K) {
   const int nB = b1 - b0, total = (a1 - a0) * nB;
   int start = 0;
@@ -1066,11 +1083,11 @@ __device__ inline void collision_layer_pair(Env& e, const moog_force_t* F, int a
 
 // physics.py:88-117 (one substep)
 __device__ inline void apply_physics(Env& e) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   const int K = uni(P->updates_per_env_step);
   const int n_forces = uni(P->n_forces);
   for (int fi = 0; fi < n_forces; ++fi) {
-    const moog_force_t* F = &P->forces[fi];
+    PForce F = &P->forces[fi];
     const int n_a = uni(F->n_a), n_b = uni(F->n_b), kind = uni(F->kind);
     for (int a = 0; a < n_a; ++a) {
       int la = uni(F->layers_a[a]);
@@ -1109,8 +1126,8 @@ __device__ inline double np_remainder1(double a) {
 }
 
 __device__ inline void rule_step(Env& e, int ri) {
-  const moog_program_t* P = e.P;
-  const moog_rule_t* R = &P->rules[ri];
+  PProg P = e.P;
+  PRule R = &P->rules[ri];
   switch (R->kind) {
     case MOOG_RULE_VANISH_ON_CONTACT: {
       int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
@@ -1219,7 +1236,7 @@ __device__ inline void rule_step(Env& e, int ri) {
 }
 
 __device__ inline void rule_reset(Env& e, int ri) {
-  const moog_rule_t* R = &e.P->rules[ri];
+  PRule R = &e.P->rules[ri];
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
@@ -1228,8 +1245,8 @@ __device__ inline void rule_reset(Env& e, int ri) {
 }
 
 // ---- tasks ---------------------------------------------------------------------------------
-__device__ inline bool task_condition(const Env& e, const moog_task_t* T) {
-  const moog_program_t* P = e.P;
+__device__ inline bool task_condition(const Env& e, PTask T) {
+  PProg P = e.P;
   int l = T->cond_layer;
   int a0 = P->layer_slot0[l], a1 = a0 + P->layer_nslots[l];
   if (T->cond == MOOG_COND_LAYER_EMPTY) {
@@ -1244,11 +1261,11 @@ __device__ inline bool task_condition(const Env& e, const moog_task_t* T) {
 }
 
 __device__ inline double task_reward(Env& e, int step_count, int* should_reset) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   double reward = 0;
   int sr = ((double)step_count >= P->timeout_steps);
   for (int ti = 0; ti < P->n_tasks; ++ti) {
-    const moog_task_t* T = &P->tasks[ti];
+    PTask T = &P->tasks[ti];
     double cnt = e.f[e.L.o_task + ti];
     double r = 0;
     int tsr = 0;
@@ -1293,8 +1310,8 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
 
 // ---- action spaces ---------------------------------------------------------------------------
 __device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_action) {
-  const moog_program_t* P = e.P;
-  const moog_action_t* A = &P->action;
+  PProg P = e.P;
+  PAction A = &P->action;
   double m0 = e.f[e.L.o_action], m1 = e.f[e.L.o_action + 1];
   if (A->kind == MOOG_ACTION_JOYSTICK) {
     double ax = ax_in, ay = A->constrained_lr ? 0. : ay_in;
@@ -1333,9 +1350,9 @@ __device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_
 
 // ---- reset path (sprite.py:261-424, distributions.py, sprite_generators.py:77-105) ----------
 __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   int sid = (int)fac[MOOG_FAC_SHAPE];
-  const moog_shape_t* sh = &P->shapes[sid];
+  PShape sh = &P->shapes[sid];
   double x = fac[MOOG_FAC_X], y = fac[MOOG_FAC_Y];
   double angle = fac[MOOG_FAC_ANGLE], scale = fac[MOOG_FAC_SCALE], aspect = fac[MOOG_FAC_ASPECT];
   double sx = scale, sy = scale * aspect;
@@ -1380,11 +1397,11 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
   bbox_exact_wave(e, s);
 }
 
-__device__ inline void sample_factors(Env& e, const moog_genop_t* op, double* fac) {
+__device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
   for (int k = 0; k < op->n_sampled; ++k) {
     int fi = op->sample_order[k];
-    const moog_factor_t* F = &op->factors[fi];
+    PFactor F = &op->factors[fi];
     double val = F->a;
     if (F->kind == MOOG_DIST_CONTINUOUS) {
       double u = next_uniform(e);
@@ -1403,8 +1420,8 @@ __device__ inline void sample_factors(Env& e, const moog_genop_t* op, double* fa
 }
 
 __device__ inline void run_genop(Env& e, int oi) {
-  const moog_program_t* P = e.P;
-  const moog_genop_t* op = &P->ops[oi];
+  PProg P = e.P;
+  PGenop op = &P->ops[oi];
   int n = op->count_max;
   if (op->count_min < op->count_max) {
     double u = next_uniform(e);
@@ -1413,9 +1430,9 @@ __device__ inline void run_genop(Env& e, int oi) {
     if (k >= span) k = span - 1;
     n = op->count_min + k;
   }
-  const moog_factor_t* FX = &op->factors[MOOG_FAC_XVEL];
-  const moog_factor_t* FY = &op->factors[MOOG_FAC_YVEL];
-  const moog_factor_t* FW = &op->factors[MOOG_FAC_ANGVEL];
+  PFactor FX = &op->factors[MOOG_FAC_XVEL];
+  PFactor FY = &op->factors[MOOG_FAC_YVEL];
+  PFactor FW = &op->factors[MOOG_FAC_ANGVEL];
   int vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
   int angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
   for (int k = 0; k < op->count_max; ++k) {
@@ -1434,7 +1451,7 @@ __device__ inline void run_genop(Env& e, int oi) {
       bool ov = false;
       for (int oj = 0; oj < oi && !ov; ++oj) {
         if (!((op->avoid_ops >> oj) & 1)) continue;
-        const moog_genop_t* o2 = &P->ops[oj];
+        PGenop o2 = &P->ops[oj];
         for (int t = o2->slot0; t < o2->slot0 + o2->count_max && !ov; ++t)
           if (ALIVE(t) && overlaps(e, s, t)) ov = true;
       }
@@ -1458,7 +1475,7 @@ __device__ inline void run_genop(Env& e, int oi) {
 
 // environment.py:82-96
 __device__ inline void env_reset(Env& e) {
-  const moog_program_t* P = e.P;
+  PProg P = e.P;
   wsync();
   for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; }
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }

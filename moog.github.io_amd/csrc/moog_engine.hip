@@ -71,7 +71,7 @@ enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_RESET_AUTO = 3
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
 __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
-  e.P = a.P;
+  e.P = as_const_prog(a.P);
   e.L = a.L;
   e.f = reinterpret_cast<double*>(moog_lds);
   e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
   bbox_build_all(e);
-  const moog_program_t* P = a.P;
+  PProg P = as_const_prog(a.P);
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
     for (int k = 0; k < K; ++k) apply_physics(e);

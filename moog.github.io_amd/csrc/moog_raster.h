@@ -352,7 +352,7 @@ __device__ __forceinline__ unsigned blend8(unsigned bg, unsigned fg, unsigned al
 __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const int env = blockIdx.x;
   if (env >= a.n_envs) return;
-  const moog_program_t* P = a.P;
+  PProg P = as_const_prog(a.P);
   const int W = P->render.width, H = P->render.height;
   const int S = P->n_slots, TOTV = a.L.TOTV;
   const bool torus = (P->render.polymod == MOOG_POLYMOD_TORUS);

@@ -151,8 +151,10 @@ class BatchedEnvironment(object):
             a = torch.as_tensor(action, device=self.device).to(torch.float64).contiguous()
             assert a.shape == (self.num_envs, 2)
         inj, keep = self._inject(injected_uniforms)
-        if self._perm is not None:   # refresh the launch order from last step's per-env cycles
-            self._perm.copy_(torch.argsort(self._cost, descending=True))
+        if self._perm is not None:   # refresh the launch order from the last per-env cycle counts
+            self._sched_tick = getattr(self, '_sched_tick', 0) + 1
+            if self._sched_tick % 4 == 1:   # per-env cost changes slowly: re-sort every 4th step
+                self._perm.copy_(torch.argsort(self._cost, descending=True))
         with torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_step(
                 self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,
