@@ -85,8 +85,8 @@ def _fill_layers(dst, names, layer_index):
 
 def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
                    meta_state_initializer=None):
-    if meta_state_initializer is not None:
-        raise NotImplementedError('meta_state is not supported by the batched engine')
+    # meta_state lives on the host (environment.py keeps it for `ModifyMetaState`)
+    del meta_state_initializer
     P = _abi.Program()
     P.abi_version = _abi.MOOG_ABI_VERSION
     shapes = _ShapeTable(P)
@@ -277,7 +277,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     P.n_corrective = len(physics._corrective_physics)
 
     # ---- game rules ---------------------------------------------------------------
-    game_rules = tuple(game_rules)
+    game_rules = tuple(r for r in game_rules if not getattr(r, 'host_side', False))
     if len(game_rules) > _abi.MOOG_MAX_RULES:
         raise ValueError('too many game rules')
     for ri, r in enumerate(game_rules):

@@ -48,6 +48,14 @@ class BatchedEnvironment(object):
         self.observers = observers
         self.game_rules = game_rules
         self.num_envs = int(num_envs)
+        # meta_state (environment.py:60-63,87): a host-side Python object shared by the
+        # `ModifyMetaState` rules.  It is per environment in the reference, so it is only
+        # available for a batch of one.
+        self._host_rules = [r for r in game_rules if getattr(r, 'host_side', False)]
+        self._meta_state_initializer = meta_state_initializer
+        if (self._host_rules or meta_state_initializer is not None) and self.num_envs != 1:
+            raise NotImplementedError('meta_state / ModifyMetaState need num_envs == 1')
+        self._meta_state = None
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
         P, L = self.compiled.program, self.compiled.layout
@@ -140,6 +148,7 @@ class BatchedEnvironment(object):
         if self.check_faults:
             self.raise_faults()
         del keep, mask_t
+        self._host_reset()
         return self._timestep()
 
     def step(self, action, injected_uniforms=None):
@@ -150,6 +159,14 @@ class BatchedEnvironment(object):
         else:
             a = torch.as_tensor(action, device=self.device).to(torch.float64).contiguous()
             assert a.shape == (self.num_envs, 2)
+        if self._host_rules or self._meta_state_initializer is not None:
+            # environment.py:100-104: an auto-reset re-initialises the meta-state; either way
+            # every rule steps once per call
+            if bool(self.reset_next_step[0].item()):
+                self._host_reset()
+            else:
+                for r in self._host_rules:
+                    r.step(None, self._meta_state)
         inj, keep = self._inject(injected_uniforms)
         if self._perm is not None:   # refresh the launch order from the last per-env cycle counts
             self._sched_tick = getattr(self, '_sched_tick', 0) + 1
@@ -164,6 +181,38 @@ class BatchedEnvironment(object):
             self.raise_faults()
         del keep
         return self._timestep()
+
+    def _host_reset(self):
+        if self._meta_state_initializer is not None:
+            self._meta_state = self._meta_state_initializer()
+        elif self._host_rules:
+            self._meta_state = None
+        for r in self._host_rules:
+            r.step(None, self._meta_state)
+
+    @property
+    def meta_state(self):
+        return self._meta_state
+
+    # -- snapshot / restore (env_wrappers/simulation.py:64-91) ---------------------------------
+    def snapshot(self):
+        """Everything the reference's SimulationEnvironment deep-copies (state, action-space
+        memory, task / rule counters, step_count, reset_next_step) lives in the two state
+        records: a snapshot is a copy of them plus the host meta-state."""
+        import copy
+        return {'f64': self.state_f64.clone(), 'i32': self.state_i32.clone(),
+                'meta_state': copy.deepcopy(self._meta_state)}
+
+    def restore(self, snap):
+        """Restores a snapshot.  The per-env random draw counters keep running (the
+        reference does not rewind numpy's global RNG either), so repeated
+        sim_step / sim_pop cycles sample different continuations."""
+        o = self.layout.o_rng
+        rng = self.state_i32[:, o:o + 4].clone()
+        self.state_f64.copy_(snap['f64'])
+        self.state_i32.copy_(snap['i32'])
+        self.state_i32[:, o:o + 4] = rng
+        self._meta_state = snap['meta_state']
 
     def physics_step(self, injected_uniforms=None):
         """`env.physics.step(env.state)` (tests/runtime_benchmark.py:101-107)."""
@@ -304,6 +353,10 @@ class Environment(object):
     @property
     def reset_next_step(self):
         return bool(self._batched.reset_next_step[0].item())
+
+    @property
+    def meta_state(self):
+        return self._batched.meta_state
 
     @property
     def batched(self):

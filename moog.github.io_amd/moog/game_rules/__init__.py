@@ -27,6 +27,21 @@ class VanishOnContact(AbstractRule):
         self._contacting_layer = contacting_layer
 
 
+class ModifyMetaState(AbstractRule):
+    """modify_meta_state.py:7-24: calls `meta_state_modifier(meta_state)` every step.  The
+    meta-state is a host-side Python object, so this rule runs on the host; it never
+    touches sprites and is skipped by the device lowering."""
+
+    host_side = True
+
+    def __init__(self, meta_state_modifier):
+        self._meta_state_modifier = meta_state_modifier
+
+    def step(self, state, meta_state):
+        del state
+        self._meta_state_modifier(meta_state)
+
+
 class _ProbeSprite(object):
     def __init__(self, pos):
         self.position = np.array(pos, dtype=float)

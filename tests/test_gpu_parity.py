@@ -324,3 +324,104 @@ def test_cost_schedule_is_result_neutral():
     assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
     assert np.array_equal(outs[0][2], outs[1][2])
     assert np.array_equal(outs[0][3], outs[1][3], equal_nan=True)
+
+
+def _simulation_env():
+    """The environment of the reference's tests/moog/env_wrappers/test_simulation.py:32-58."""
+    import collections
+    from moog import action_spaces, environment, game_rules, observers, physics as physics_lib
+    from moog import sprite, tasks
+    from moog.env_wrappers import simulation
+
+    def _state_initializer():
+        agent = sprite.Sprite(x=0.5, y=0.5, scale=0.1, c0=128)
+        target = sprite.Sprite(x=0.75, y=0.5, scale=0.1, c1=128)
+        return collections.OrderedDict([('agent', [agent]), ('target', [target])])
+
+    def _modify_meta_state(meta_state):
+        meta_state['key'] = meta_state['key'] + 1
+
+    env = environment.Environment(
+        state_initializer=_state_initializer,
+        physics=physics_lib.Physics(),
+        task=tasks.ContactReward(1., 'agent', 'target', reset_steps_after_contact=2),
+        action_space=action_spaces.Grid(0.1, action_layers='agent', control_velocity=True),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))},
+        meta_state_initializer=lambda: {'key': 0},
+        game_rules=(game_rules.ModifyMetaState(_modify_meta_state),))
+    return simulation.SimulationEnvironment(env)
+
+
+def test_simulation_wrapper_reference_known_answers():
+    """tests/moog/env_wrappers/test_simulation.py:64-119 (testStep, testSimStepSimPop):
+    the same action scripts reach LAST on the same steps through real steps, simulated
+    steps and pops, and the meta-state counter ends at 7."""
+    env = _simulation_env()
+    episode_actions = [1, 4, 3, 1, 2, 0]
+    env.reset()
+    for a in episode_actions[:-1]:
+        assert not env.step(a).last()
+    assert env.step(episode_actions[-1]).last()
+
+    env = _simulation_env()
+    env.reset()
+    for a in [1, 4, 3]:
+        assert not env.sim_step(a).last()
+    env.sim_pop(-1)
+    for a in [3, 1, 2]:
+        assert not env.sim_step(a).last()
+    assert env.sim_step(0).last()
+    for i in [-1, -2]:
+        env.sim_pop(i)
+    for a in [1, 2]:
+        assert not env.sim_step(a).last()
+    assert env.sim_step(0).last()
+    assert env.sim_step(0) is None          # no simulation across the episode boundary
+    for a in episode_actions[:-1]:
+        assert not env.step(a).last()
+    assert env.step(episode_actions[-1]).last()
+    assert env.meta_state['key'] == 7
+
+
+def test_simulation_wrapper_batched_snapshot_restore():
+    """Batched sim_step / sim_pop: popping to level 0 restores the state records exactly
+    (RNG counters aside), and re-simulating the same actions reproduces the same states."""
+    from moog.env_wrappers import simulation
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(3)
+    acts = [(torch.rand((256, 2), generator=g, dtype=torch.float64) * 2 - 1) for _ in range(6)]
+    for seed in range(5, 25):                # a batch in which no episode ends within the script
+        probe = make_env('colliding_predators_32', 256, seed=seed)
+        probe.reset()
+        if not any(bool((probe.step(a).step_type == 2).any().item()) for a in acts):
+            break
+    env = make_env('colliding_predators_32', 256, seed=seed)
+    sim = simulation.SimulationEnvironment(env)
+    sim.reset()
+    sim.step(acts[0])
+    f0, q0 = download(env)
+    o = env.layout.o_rng
+    for a in acts[1:4]:
+        assert sim.sim_step(a) is not None
+    f3, q3 = download(env)
+    sim.sim_pop(0)
+    f, q = download(env)
+    q[:, o:o + 4] = q0[:, o:o + 4]
+    assert np.array_equal(f, f0, equal_nan=True) and np.array_equal(q, q0)
+    for a in acts[1:4]:
+        sim.sim_step(a)
+    f, q = download(env)
+    q[:, o:o + 4] = q3[:, o:o + 4]
+    assert np.array_equal(f, f3, equal_nan=True) and np.array_equal(q, q3)
+    sim.sim_pop(1)                           # back to the state after the first sim_step
+    assert len(sim.stack) == 1
+    ts = sim.step(acts[1])                   # a real step rewinds to level 0 first
+    assert sim.stack == []
+    env2 = make_env('colliding_predators_32', 256, seed=seed)
+    env2.reset()
+    env2.step(acts[0]); env2.step(acts[1])
+    f2, q2 = download(env2)
+    f, q = download(env)
+    q[:, o:o + 4] = q2[:, o:o + 4]
+    assert np.array_equal(f, f2, equal_nan=True) and np.array_equal(q, q2)
+    del ts

@@ -94,3 +94,24 @@ def test_shape_table_matches_reference_fixture():
         x, y = v[:, 0], v[:, 1]
         area = 0.5 * np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y)
         assert abs(area - 1.0) < 1e-12, name
+
+
+def test_meta_state_rules_stay_on_the_host():
+    """ModifyMetaState (modify_meta_state.py:7-24) never touches sprites: the lowering skips
+    it and accepts a meta_state_initializer (environment.py:60-63)."""
+    import collections
+    from moog import _compiler, action_spaces, game_rules, observers, physics as physics_lib
+    from moog import sprite, tasks
+    bump = game_rules.ModifyMetaState(lambda m: m.__setitem__('key', m['key'] + 1))
+    c = _compiler.compile_config(
+        state_initializer=lambda: collections.OrderedDict(
+            [('agent', [sprite.Sprite(x=0.5, y=0.5, scale=0.1, c0=128)])]),
+        physics=physics_lib.Physics(),
+        task=tasks.ContactReward(1., 'agent', 'agent'),
+        action_space=action_spaces.Grid(0.1, action_layers='agent', control_velocity=True),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))},
+        game_rules=(bump,), meta_state_initializer=lambda: {'key': 0})
+    assert c.program.n_rules == 0
+    m = {'key': 0}
+    bump.step(None, m)
+    assert m['key'] == 1

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for st in 4 5; do
+for st in ${STOPS:-4 41 42 43 44 0}; do
 rm -rf $R/gpurun_out/prof_r && mkdir -p $R/gpurun_out/prof_r
 MOOG_RASTER_STOP=$st rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $R/gpurun_out/prof_r/pmc_sq -o r1 -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_r/log1 2>&1
 echo "== stop $st"; python3 $R/tools/prof_summary.py $R/gpurun_out/prof_r | grep -E "raster" | awk "{print \$2, \$3, \$4/16384}"
