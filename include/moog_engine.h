@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 5
+#define MOOG_ABI_VERSION 6
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -58,6 +58,8 @@ extern "C" {
 #define MOOG_FAULT_BAD_NORMAL 4
 /* injected-uniform buffer ran dry (test harness error) */
 #define MOOG_FAULT_INJECT_UNDERRUN 8
+/* TetherZippedLayers over layers of different lengths (tether_physics.py:192-198) */
+#define MOOG_FAULT_TETHER_ZIP 16
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -135,11 +137,19 @@ typedef struct {
   double p0, p1;
 } moog_force_t;
 
-/* corrective physics: ConstantSpeed (constant_speed.py:34-46) */
+/* corrective physics (physics.py:110-111), applied after the forces of a substep:
+ * ConstantSpeed (constant_speed.py:34-46), Tether and TetherZippedLayers
+ * (tether_physics.py:43-201) */
+enum { MOOG_CORR_CONSTANT_SPEED = 0, MOOG_CORR_TETHER = 1, MOOG_CORR_TETHER_ZIPPED = 2 };
+
 typedef struct {
+  int32_t kind;              /* MOOG_CORR_*                                      */
   int32_t n_layers;
   int32_t layers[MOOG_MAX_LAYERS];
-  double speed;
+  int32_t update_angle_vel;  /* TETHER*: tether_physics.py:70-91                 */
+  int32_t has_anchor;        /* TETHER*: anchor given                            */
+  double speed;              /* CONSTANT_SPEED                                   */
+  double anchor[2];          /* TETHER*                                          */
 } moog_corrective_t;
 
 /* ---- game rules ----------------------------------------------------------- */
@@ -223,6 +233,9 @@ typedef struct {
   int32_t slot_vcap[MOOG_MAX_SLOTS];
 
   int32_t updates_per_env_step;    /* K, physics.py:15                         */
+  int32_t vel_alias;               /* some Tether has update_angle_vel=False: its
+                                    * sprites share ONE velocity ndarray afterwards
+                                    * (tether_physics.py:90), tracked in o_valias  */
   int32_t n_forces;
   int32_t n_corrective;
   int32_t n_rules;
@@ -271,6 +284,9 @@ typedef struct {
   int32_t o_opacity;  /* [S]                                                   */
   int32_t o_shape;    /* [S] shape-table id                                    */
   int32_t o_tele;     /* [S] bit r set: slot is in rule r's _currently_teleporting */
+  int32_t o_valias;   /* [S] 0, or 1 + id of the group of slots whose velocity is one
+                       *     shared ndarray in the reference; -1 when the program has
+                       *     no such tether (vel_alias == 0)                          */
   int32_t o_step_count;
   int32_t o_reset_next;
   int32_t o_fault;
@@ -302,6 +318,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_opacity = o; o += S;
   L->o_shape = o; o += S;
   L->o_tele = o; o += S;
+  if (p->vel_alias) { L->o_valias = o; o += S; } else L->o_valias = -1;
   L->o_step_count = o; o += 1;
   L->o_reset_next = o; o += 1;
   L->o_fault = o; o += 1;

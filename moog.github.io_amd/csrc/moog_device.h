@@ -78,6 +78,7 @@ struct Env {
 #define TELE(s) (e.q[e.L.o_tele + (s)])
 #define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
+#define VALIAS(s) (e.q[e.L.o_valias + (s)])
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -483,6 +484,25 @@ __device__ inline void integrate_all(Env& e, double dt) {
   wsync();
 }
 
+// Tether(update_angle_vel=False) hands every tethered sprite the SAME ndarray
+// (tether_physics.py:90): an in-place update through one sprite is seen through all of
+// them until a velocity is assigned afresh.  VALIAS(s) names the sharing group; after an
+// in-place update the value is copied to the other members.  Programs without such a
+// tether (vel_alias == 0, a scalar branch) have no o_valias words at all.
+__device__ inline void vel_share(Env& e, int s) {
+  if (!e.P->vel_alias) return;
+  const int g = VALIAS(s);
+  if (!g) return;
+  const double vx = VELX(s), vy = VELY(s);
+  const int S = e.P->n_slots;
+  for (int t = e.lane; t < S; t += 64)
+    if (t != s && ALIVE(t) && VALIAS(t) == g) { VELX(t) = vx; VELY(t) = vy; }
+  wsync();
+}
+__device__ inline void vel_unshare(Env& e, int s) {   // caller: lane 0
+  if (e.P->vel_alias) VALIAS(s) = 0;
+}
+
 __device__ inline void vel_iadd(Env& e, int s, double dx, double dy) {
   double vx = VELX(s), vy = VELY(s);
   if (FLAGS(s) & MOOG_F_VEL_F32) { vx = f32r(vx + dx); vy = f32r(vy + dy); }
@@ -490,6 +510,7 @@ __device__ inline void vel_iadd(Env& e, int s, double dx, double dy) {
   wsync();
   if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
   wsync();
+  vel_share(e, s);
 }
 
 __device__ inline void angvel_iadd(Env& e, int s, double dw) {
@@ -878,6 +899,7 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
   }
   if (!fault) {   // in-place adds with the reference's float32 rounding (see vel_iadd)
     if (f0 & MOOG_F_VEL_F32) { v0x = f32r(v0x + a0x); v0y = f32r(v0y + a0y); } else { v0x = v0x + a0x; v0y = v0y + a0y; }
+    if (e.P->vel_alias && VALIAS(s0) && VALIAS(s0) == VALIAS(s1)) { v1x = v0x; v1y = v0y; }   // one shared ndarray
     if (f1 & MOOG_F_VEL_F32) { v1x = f32r(v1x + a1x); v1y = f32r(v1y + a1y); } else { v1x = v1x + a1x; v1y = v1y + a1y; }
     if (upd) {
       w0 = (f0 & MOOG_F_ANGVEL_F32) ? f32r(w0 + dw0) : w0 + dw0;
@@ -902,6 +924,10 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
     }
   }
   wsync();
+  if (e.P->vel_alias && !fault) {
+    if (VALIAS(s0) != VALIAS(s1)) vel_share(e, s0);
+    vel_share(e, s1);
+  }
 }
 
 // collisions.py:494-584.  Returns true when a sprite position changed (the broad
@@ -953,6 +979,7 @@ __device__ inline void force_single(Env& e, PForce F, int s, int K) {
         wsync();
         if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
         wsync();
+        vel_share(e, s);
       } else {
         double c = -1 * F->p0;
         newton_apply(e, s, (c * VELX(s)) * m, (c * VELY(s)) * m, K);
@@ -1005,6 +1032,130 @@ __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K
   newton_apply(e, s1, f1x, f1y, K);
 }
 
+// ---- rigid tethers (tether_physics.py:16-201) ----------------------------------------------
+// The i-th live sprite of layer l (list order), or -1.
+__device__ inline int nth_alive(Env& e, int l, int i) {
+  PProg P = e.P;
+  for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+    if (ALIVE(s) && i-- == 0) return s;
+  return -1;
+}
+
+// Visits the members of one tether group in the reference's order: every live sprite of
+// the layers (Tether, :129-131) or the zi-th live sprite of each layer (zipped, :199).
+template <class F>
+__device__ inline void tether_members(Env& e, PCorr C, int zi, F f) {
+  PProg P = e.P;
+  if (C->kind == MOOG_CORR_TETHER) {
+    for (int a = 0; a < C->n_layers; ++a) {
+      int l = C->layers[a];
+      for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+        if (ALIVE(s)) f(s);
+    }
+  } else {
+    for (int a = 0; a < C->n_layers; ++a) f(nth_alive(e, C->layers[a], zi));
+  }
+}
+
+// _tether_sprites (:43-91) for one group, run by lane 0.  Masses are Python floats (the
+// lowering rejects sampled masses); the velocity sums follow numpy's float32 / float64
+// promotion exactly as the oracle restates it.
+__device__ inline void tether_group(Env& e, PCorr C, int zi, int K, int group) {
+  int n = 0;
+  double total_mass = 0;
+  tether_members(e, C, zi, [&](int s) { ++n; total_mass = total_mass + MASS(s); });
+  if (n == 0 || isinf(total_mass)) return;
+  double cx = 0, cy = 0, mx = 0, my = 0;
+  bool f32 = true;
+  int i = 0;
+  tether_members(e, C, zi, [&](int s) {
+    cx = cx + MASS(s) * PX(s); cy = cy + MASS(s) * PY(s);
+    const bool tf32 = (FLAGS(s) & MOOG_F_VEL_F32) != 0;
+    double tx, ty;
+    if (tf32) { tx = (double)((float)MASS(s) * (float)VELX(s)); ty = (double)((float)MASS(s) * (float)VELY(s)); }
+    else { tx = MASS(s) * VELX(s); ty = MASS(s) * VELY(s); }
+    if (i == 0) { mx = 0 + tx; my = 0 + ty; f32 = tf32; }
+    else if (f32 && tf32) { mx = (double)((float)mx + (float)tx); my = (double)((float)my + (float)ty); }
+    else { mx = mx + tx; my = my + ty; f32 = false; }
+    ++i;
+  });
+  cx = cx / total_mass; cy = cy / total_mass;
+  double tvx, tvy;
+  if (f32) { tvx = (double)((float)mx / (float)total_mass); tvy = (double)((float)my / (float)total_mass); }
+  else { tvx = mx / total_mass; tvy = my / total_mass; }
+  if (C->has_anchor) { cx = C->anchor[0]; cy = C->anchor[1]; tvx = 0; tvy = 0; f32 = false; }
+  if (C->update_angle_vel) {
+    // _change_rotation_coordinates (:16-40): radius and perpendicular about the origin
+    auto arm = [&](int s, double& radius, double& perpx, double& perpy) {
+      double hx, hy;
+      if (FLAGS(s) & MOOG_F_VEL_F32) {
+        float dxf = (float)VELX(s) / (float)K, dyf = (float)VELY(s) / (float)K;
+        hx = (double)(0.5f * dxf); hy = (double)(0.5f * dyf);
+      } else { hx = 0.5 * (VELX(s) / (double)K); hy = 0.5 * (VELY(s) / (double)K); }
+      double parx = (PX(s) + hx) - cx, pary = (PY(s) + hy) - cy;
+      radius = sqrt(parx * parx + pary * pary);
+      parx = parx / radius; pary = pary / radius;
+      perpx = 0.0 * parx + (-1.0) * pary; perpy = 1.0 * parx + 0.0 * pary;
+    };
+    double Ltot = 0, Itot = 0;
+    tether_members(e, C, zi, [&](int s) {
+      double radius, perpx, perpy;
+      arm(s, radius, perpx, perpy);
+      double rx, ry;
+      if ((FLAGS(s) & MOOG_F_VEL_F32) && f32) { rx = (double)((float)VELX(s) - (float)tvx); ry = (double)((float)VELY(s) - (float)tvy); }
+      else { rx = VELX(s) - tvx; ry = VELY(s) - tvy; }
+      double perp_vel = rx * perpx + ry * perpy;
+      double moi = 0 + MASS(s) * INER(s, 0);
+      moi = moi + MASS(s) * INER(s, 1);
+      double L = perp_vel * MASS(s) * radius;
+      L += ANGV(s) * moi;
+      double I = moi + MASS(s) * radius * radius;
+      Ltot = Ltot + L; Itot = Itot + I;
+    });
+    const double w = Ltot / Itot;
+    tether_members(e, C, zi, [&](int s) {
+      double radius, perpx, perpy;
+      arm(s, radius, perpx, perpy);   // position and this sprite's velocity are still the old ones
+      VELX(s) = tvx + radius * perpx * w;
+      VELY(s) = tvy + radius * perpy * w;
+      ANGV(s) = w;
+      FLAGS(s) &= ~(MOOG_F_VEL_F32 | MOOG_F_ANGVEL_F32);
+      vel_unshare(e, s);
+    });
+  } else {
+    tether_members(e, C, zi, [&](int s) {
+      VELX(s) = tvx; VELY(s) = tvy;
+      ANGV(s) = 0.;
+      int fl = FLAGS(s) & ~(MOOG_F_VEL_F32 | MOOG_F_ANGVEL_F32);
+      FLAGS(s) = f32 ? (fl | MOOG_F_VEL_F32) : fl;
+      VALIAS(s) = group;
+    });
+  }
+}
+
+// Tether.apply_physics (:122-136), TetherZippedLayers.apply_physics (:176-201)
+__device__ inline void tether(Env& e, PCorr C, int ci) {
+  PProg P = e.P;
+  const int K = P->updates_per_env_step;
+  wsync();
+  if (e.lane == 0) {
+    if (C->kind == MOOG_CORR_TETHER) {
+      tether_group(e, C, 0, K, 1 + ci * MOOG_MAX_SLOTS);
+    } else if (C->n_layers > 0) {
+      int cnt0 = 0;
+      bool same = true;
+      for (int a = 0; a < C->n_layers; ++a) {
+        int l = C->layers[a], cnt = 0;
+        for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) cnt += ALIVE(s) ? 1 : 0;
+        if (a == 0) cnt0 = cnt; else same = same && (cnt == cnt0);
+      }
+      if (!same) e.q[e.L.o_fault] |= MOOG_FAULT_TETHER_ZIP;
+      else for (int i = 0; i < cnt0; ++i) tether_group(e, C, i, K, 1 + ci * MOOG_MAX_SLOTS + i);
+    }
+  }
+  wsync();
+}
+
 // constant_speed.py:34-46
 __device__ inline void constant_speed(Env& e, PCorr C) {
   PProg P = e.P;
@@ -1027,7 +1178,7 @@ __device__ inline void constant_speed(Env& e, PCorr C) {
         if (n != 0.0) { ox = (C->speed * ox) / n; oy = (C->speed * oy) / n; wr = true; }
       }
       wsync();
-      if (wr && e.lane == 0) { VELX(s) = ox; VELY(s) = oy; }
+      if (wr && e.lane == 0) { VELX(s) = ox; VELY(s) = oy; vel_unshare(e, s); }
       wsync();
     }
   }
@@ -1113,7 +1264,10 @@ __device__ inline void apply_physics(Env& e) {
     }
   }
   const int n_corr = uni(P->n_corrective);
-  for (int c = 0; c < n_corr; ++c) constant_speed(e, &P->corrective[c]);
+  for (int c = 0; c < n_corr; ++c) {
+    if (P->corrective[c].kind == MOOG_CORR_CONSTANT_SPEED) constant_speed(e, &P->corrective[c]);
+    else tether(e, &P->corrective[c], c);
+  }
   if (!(e.dbg & 2)) integrate_all(e, 1. / K);
 }
 
@@ -1339,7 +1493,7 @@ __device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_
       double m = MASS(s);
       if (A->control_velocity) {
         wsync();
-        if (e.lane == 0) { VELX(s) = m0 / m; VELY(s) = m1 / m; FLAGS(s) &= ~MOOG_F_VEL_F32; }
+        if (e.lane == 0) { VELX(s) = m0 / m; VELY(s) = m1 / m; FLAGS(s) &= ~MOOG_F_VEL_F32; vel_unshare(e, s); }
         wsync();
       } else {
         vel_iadd(e, s, m0 / m, m1 / m);
@@ -1386,6 +1540,7 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     COL(s, 0) = fac[MOOG_FAC_C0]; COL(s, 1) = fac[MOOG_FAC_C1]; COL(s, 2) = fac[MOOG_FAC_C2];
     OPAC(s) = (int32_t)fac[MOOG_FAC_OPACITY];
     TELE(s) = 0;
+    vel_unshare(e, s);
     int fl = 0;
     if (sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
     if (vel_f32) fl |= MOOG_F_VEL_F32;
@@ -1477,7 +1632,7 @@ __device__ inline void run_genop(Env& e, int oi) {
 __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
-  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; }
+  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; vel_unshare(e, s); }
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();
   for (int oi = 0; oi < P->n_ops; ++oi) run_genop(e, oi);

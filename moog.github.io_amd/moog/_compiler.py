@@ -268,12 +268,33 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if pair != (F.n_b > 0):
             raise ValueError('%s applied to the wrong number of layer arguments' % type(force).__name__)
     P.n_forces = len(physics._forces)
+    if len(physics._corrective_physics) > _abi.MOOG_MAX_CORRECTIVE:
+        raise ValueError('too many corrective physics entries')
     for ci, c in enumerate(physics._corrective_physics):
-        if not isinstance(c, physics_lib.ConstantSpeed):
-            raise NotImplementedError('corrective physics %r is not lowered' % (type(c).__name__,))
         C = P.corrective[ci]
-        C.n_layers = _fill_layers(C.layers, c._layer_names, layer_index)
-        C.speed = c._speed
+        if isinstance(c, physics_lib.ConstantSpeed):
+            C.kind = _abi.MOOG_CORR_CONSTANT_SPEED
+            C.n_layers = _fill_layers(C.layers, c._layer_names, layer_index)
+            C.speed = c._speed
+        elif isinstance(c, physics_lib.Tether):
+            C.kind = (_abi.MOOG_CORR_TETHER_ZIPPED if isinstance(c, physics_lib.TetherZippedLayers)
+                      else _abi.MOOG_CORR_TETHER)
+            C.n_layers = _fill_layers(C.layers, c._layer_names, layer_index)
+            C.update_angle_vel = int(bool(c._update_angle_vel))
+            if c._anchor is not None:
+                C.has_anchor = 1
+                C.anchor[0], C.anchor[1] = float(c._anchor[0]), float(c._anchor[1])
+            if not c._update_angle_vel:
+                P.vel_alias = 1   # the tethered sprites share one velocity ndarray afterwards
+            # the device restates numpy's promotion for Python-float masses only
+            for name in c._layer_names:
+                for sp in state[name]:
+                    m = sp.factors['mass']
+                    if isinstance(m, sprite_lib.SymbolicFactor) or not isinstance(m, (int, float)):
+                        raise NotImplementedError(
+                            'tethered sprites must have constant Python-number masses')
+        else:
+            raise NotImplementedError('corrective physics %r is not lowered' % (type(c).__name__,))
     P.n_corrective = len(physics._corrective_physics)
 
     # ---- game rules ---------------------------------------------------------------

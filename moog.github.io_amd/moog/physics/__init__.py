@@ -120,6 +120,25 @@ class ConstantSpeed(AbstractPhysics):
         self._speed = speed
 
 
+class Tether(AbstractPhysics):
+    """Rigidly tethers all sprites of the given layers (tether_physics.py:94-136): after
+    the forces of every substep their velocities / angular velocities are replaced by the
+    rigid-body motion about the centre of mass (or about `anchor`)."""
+
+    def __init__(self, layer_names, update_angle_vel=True, anchor=None):
+        super(Tether, self).__init__(1)
+        if not isinstance(layer_names, (list, tuple)):
+            layer_names = [layer_names]
+        self._layer_names = list(layer_names)
+        self._update_angle_vel = update_angle_vel
+        self._anchor = anchor
+
+
+class TetherZippedLayers(Tether):
+    """Tethers {i-th sprite of every layer} for each i (tether_physics.py:139-201); the
+    layers must hold the same number of sprites (ValueError otherwise)."""
+
+
 class Physics(AbstractPhysics):
     def __init__(self, *forces, updates_per_env_step=1, corrective_physics=()):
         super(Physics, self).__init__(updates_per_env_step=updates_per_env_step)

@@ -9,12 +9,14 @@ config files also load unchanged (tests/test_configs.py).  `*_32` / `*_64` are
 the scaled variants of SURVEY.md 8(d).
 """
 import importlib
+import re
 
 NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
-         'colliding_predators_32', 'falling_balls_64', 'forces_zoo')
+         'colliding_predators_32', 'falling_balls_64', 'forces_zoo', 'tether_zoo')
 
 
 def load(name, level=0):
-    if name.endswith('_l1'):   # e.g. chase_avoid_torus_l1 = level 1 of chase_avoid_torus
-        name, level = name[:-3], 1
+    m = re.match(r'(.*)_l(\d+)$', name)   # e.g. chase_avoid_torus_l1 = level 1 of chase_avoid_torus
+    if m:
+        name, level = m.group(1), int(m.group(2))
     return importlib.import_module(__name__ + '.' + name).get_config(level)

@@ -24,6 +24,7 @@ choice(n) = int(u*n), randint(a,b) = a + int(u*(b-a)).
 """
 import importlib.util
 import os
+import re
 import sys
 
 import numpy as np
@@ -95,6 +96,10 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name == 'chase_avoid_torus_l1':   # level 1: 1-2 prey and 1-2 predators (randint counts)
         return importlib.import_module('moog_demos.example_configs.chase_avoid_torus').get_config(1)
+    level = 0
+    m = re.match(r'(.*)_l(\d+)$', name)
+    if m:
+        name, level = m.group(1), int(m.group(2))
     pkg = 'amd_configs'
     if pkg not in sys.modules:
         spec = importlib.util.spec_from_file_location(
@@ -102,7 +107,7 @@ def load_amd_config(name):
         mod = importlib.util.module_from_spec(spec)
         sys.modules[pkg] = mod
         spec.loader.exec_module(mod)
-    return importlib.import_module(pkg + '.' + name).get_config(0)
+    return importlib.import_module(pkg + '.' + name).get_config(level)
 
 
 def snapshot(env, layer_names, caps, slot_of):
@@ -114,7 +119,9 @@ def snapshot(env, layer_names, caps, slot_of):
         nverts=np.zeros(S, np.int32), verts=np.full((S, VMAX, 2), np.nan),
         inertia=np.full((S, 2), np.nan), maxr=np.full(S, np.nan),
         vel_f32=np.zeros(S, np.uint8), angvel_f32=np.zeros(S, np.uint8),
-        sym_circle=np.zeros(S, np.uint8), tele=np.zeros(S, np.uint8))
+        sym_circle=np.zeros(S, np.uint8), tele=np.zeros(S, np.uint8),
+        vel_group=np.zeros(S, np.int32))   # 1 + lowest slot among sprites sharing ONE velocity ndarray
+    owners = {}
     tele_ids = set()
     for r in getattr(env, 'game_rules', ()):
         tele_ids |= set(getattr(r, '_currently_teleporting', set()))
@@ -138,6 +145,10 @@ def snapshot(env, layer_names, caps, slot_of):
             d['angvel_f32'][k] = getattr(s.angle_vel, 'dtype', None) == np.float32
             d['sym_circle'][k] = bool(s.is_symmetric_circle)
             d['tele'][k] = s.id in tele_ids
+            owners.setdefault(id(s.velocity), []).append(k)
+    for ks in owners.values():
+        if len(ks) > 1:
+            d['vel_group'][ks] = 1 + min(ks)
     return d
 
 
@@ -444,6 +455,11 @@ def main():
         ('falling_balls_64', 12, {}, (0,)),
         ('forces_zoo', 96, {}, (0, 1)),
         ('chase_avoid_torus_l1', 48, {'prey': 2, 'predators': 2}, (0,)),
+        ('tether_zoo_l0', 45, {}, (0,)),
+        ('tether_zoo_l1', 45, {}, (0,)),
+        ('tether_zoo_l2', 45, {}, (0,)),
+        ('tether_zoo_l3', 45, {}, (0,)),
+        ('tether_zoo_l4', 45, {}, (0,)),
     ]
     only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:

@@ -166,6 +166,8 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
         q[L.o_nverts + s] = nv if fx['alive'][t][s] else 0
         q[L.o_opacity + s] = fx['opacity'][t][s]
         q[L.o_tele + s] = pm if fx['tele'][t][s] else 0
+        if P.vel_alias:
+            q[L.o_valias + s] = fx['vel_group'][t][s] if 'vel_group' in fx else 0
     q[L.o_step_count] = fx['step_count'][t]
     q[L.o_reset_next] = fx['reset_next'][t]
     return f64, i32
@@ -230,6 +232,15 @@ def state_diff(fx, t, c, f64, i32, env=0):
             ints_ok = False
             detail.append('opacity slot %d' % s)
     err['verts'] = verr
+    if P.vel_alias and 'vel_group' in fx:
+        # sprites sharing one velocity ndarray: same partition (the group ids are arbitrary)
+        def canon(g):
+            g = np.where(live, np.asarray(g), 0)
+            return [0 if g[s] == 0 else 1 + int(np.flatnonzero(g == g[s])[0]) for s in range(S)]
+        if canon(q[L.o_valias:L.o_valias + S]) != canon(fx['vel_group'][t]):
+            ints_ok = False
+            detail.append('shared-velocity groups %s vs %s' % (
+                canon(q[L.o_valias:L.o_valias + S]), canon(fx['vel_group'][t])))
     if int(q[L.o_step_count]) != int(fx['step_count'][t]) or \
             int(q[L.o_reset_next]) != int(fx['reset_next'][t]):
         ints_ok = False

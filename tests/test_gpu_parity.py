@@ -11,7 +11,9 @@ TOL = 1e-5
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
         ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
-        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0)]
+        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
+        ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
+        ('tether_zoo_l4', 0)]
 
 
 def make_env(name, n, seed=0, **kw):
@@ -425,3 +427,41 @@ def test_simulation_wrapper_batched_snapshot_restore():
     q[:, o:o + 4] = q2[:, o:o + 4]
     assert np.array_equal(f, f2, equal_nan=True) and np.array_equal(q, q2)
     del ts
+
+
+@pytest.mark.parametrize('level', [10, 11, 12])
+def test_tether_known_answers(level):
+    """The reference's own tether scenarios (tests/moog/physics/test_tether_physics.py:109-215)
+    through `physics.step` on the engine, 1e-3 as there."""
+    from test_oracle_golden import check_tether_kat
+    env = make_env('tether_zoo_l%d' % level, 1)
+    env.reset()
+    s0 = env.compiled.layer_slots['sprites'][0]
+
+    def sprite_state():
+        pos = env.field('position')[0].cpu().numpy()
+        vel = env.field('velocity')[0].cpu().numpy()
+        w = env.field('angle_vel')[0].cpu().numpy()
+        return [(pos[s], vel[s], w[s]) for s in range(s0, s0 + 3)]
+    check_tether_kat(level, sprite_state, env.physics_step)
+
+
+def test_tether_zipped_layer_mismatch_raises():
+    """TetherZippedLayers over layers of different lengths raises ValueError
+    (tether_physics.py:192-198)."""
+    import collections
+    from moog import action_spaces, environment, observers, physics as physics_lib, sprite, tasks
+    cfg = dict(
+        state_initializer=lambda: collections.OrderedDict([
+            ('a', [sprite.Sprite(x=0.3, y=0.5, scale=0.1), sprite.Sprite(x=0.7, y=0.5, scale=0.1)]),
+            ('b', [sprite.Sprite(x=0.5, y=0.2, scale=0.1)])]),
+        physics=physics_lib.Physics(
+            corrective_physics=[physics_lib.TetherZippedLayers(('a', 'b'))], updates_per_env_step=2),
+        task=tasks.CompositeTask(timeout_steps=5),
+        action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='a'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))})
+    env = environment.BatchedEnvironment(num_envs=2, **cfg)
+    env.reset()
+    env.step(np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        env.raise_faults()

@@ -13,7 +13,9 @@ from helpers import OracleEnv, compiled, fixture, records_from_fixture, state_di
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
         ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
-        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0)]
+        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
+        ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
+        ('tether_zoo_l4', 0)]
 TOL = 1e-5   # BASELINE.json: float sprite state within 1e-5 abs
 
 
@@ -259,3 +261,52 @@ def test_hsv_known_answers():
         out = (ctypes.c_uint8 * 3)()
         lib.oracle_hsv_to_rgb(*[float(x) for x in hsv], out)
         assert tuple(out) == rgb, (hsv, tuple(out), rgb)
+
+
+# tests/moog/physics/test_tether_physics.py:154-215: [position, velocity, angle_vel] of the
+# three tethered triangles after 1 and after 45 physics steps (data of the reference's test)
+TETHER_KAT = {
+    11: ([[[0.5133, 0.6933], [0.0133, -0.0067], 0.], [[0.2133, 0.5933], [0.0133, -0.0067], 0.],
+          [[0.6133, 0.2933], [0.0133, -0.0067], 0.]],
+         [[[0.7710, 0.4900], [-0.0005, 0.], 0.], [[0.4710, 0.3900], [-0.0005, 0.], 0.],
+          [[0.8671, 0.0939], [-0.0005, 0.], 0.]]),
+    10: ([[[0.5206, 0.6900], [0.0205, -0.0103], -0.0447], [[0.2165, 0.6035], [0.0166, 0.0033], -0.0447],
+          [[0.6027, 0.2860], [0.0025, -0.0140], -0.0447]],
+         [[[0.8341, 0.3401], [-0.0028, -0.0046], -0.0229], [[0.7139, 0.6271], [0.0037, -0.0018], -0.0229],
+          [[0.4545, 0.2062], [-0.0059, 0.0041], -0.0229]]),
+    12: ([[[0.5190, 0.6881], [0.0188, -0.0122], -0.0385], [[0.2154, 0.5997], [0.0154, -0.0006], -0.0385],
+          [[0.6036, 0.2845], [0.0033, -0.0155], -0.0385]],
+         [[[0.6927, 0.5118], [0., 0.], 0.], [[0.3798, 0.5573], [0., 0.], 0.],
+          [[0.6025, 0.1233], [0., 0.], 0.]]),
+}
+
+
+def check_tether_kat(level, sprite_state, physics_step):
+    """Shared by the oracle test here and the HIP test (test_gpu_parity.py)."""
+    step_1, final = TETHER_KAT[level]
+    physics_step()
+    for got, pred in zip(sprite_state(), step_1):
+        for g, p in zip(got, pred):
+            assert np.allclose(g, p, atol=1e-3), (level, 'step 1', got, pred)
+    for _ in range(44):
+        physics_step()
+    for got, pred in zip(sprite_state(), final):
+        for g, p in zip(got, pred):
+            assert np.allclose(g, p, atol=1e-3), (level, 'final', got, pred)
+
+
+@pytest.mark.parametrize('level', [10, 11, 12])
+def test_tether_known_answers(level):
+    """The reference's own tether scenarios (test_tether_physics.py:109-215), 1e-3 as there."""
+    c = compiled('tether_zoo_l%d' % level)
+    o = OracleEnv(c)
+    o.reset()
+    L, S = c.layout, c.layout.S
+    s0 = c.layer_slots['sprites'][0]
+
+    def sprite_state():
+        f = o.f64[0]
+        return [(f[L.o_pos + 2 * s:L.o_pos + 2 * s + 2], f[L.o_vel + 2 * s:L.o_vel + 2 * s + 2],
+                 f[L.o_angvel + s]) for s in range(s0, s0 + 3)]
+    check_tether_kat(level, sprite_state, o.physics)
+    del S
