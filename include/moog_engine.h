@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 6
+#define MOOG_ABI_VERSION 7
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -39,6 +39,7 @@ extern "C" {
 #define MOOG_MAX_SHAPES 32
 #define MOOG_MAX_SHAPE_VERTS 512
 #define MOOG_MAX_CAND 128
+#define MOOG_MAX_DCODE 192
 #define MOOG_MAX_SLOTS 128
 #define MOOG_NUM_FACTORS 14
 
@@ -60,6 +61,9 @@ extern "C" {
 #define MOOG_FAULT_INJECT_UNDERRUN 8
 /* TetherZippedLayers over layers of different lengths (tether_physics.py:192-198) */
 #define MOOG_FAULT_TETHER_ZIP 16
+/* distributions.py:242-249,344-351: Intersection / SetMinus / Selection exceeded
+ * _MAX_TRIES = 1e5 rejections (ValueError)                                      */
+#define MOOG_FAULT_DIST_EXHAUSTED 32
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -75,8 +79,48 @@ enum {
   MOOG_FAC_XVEL, MOOG_FAC_YVEL, MOOG_FAC_ANGVEL, MOOG_FAC_MASS
 };
 
-/* factor distribution kinds (state_initialization/distributions.py) */
-enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2 };
+/* factor distribution kinds (state_initialization/distributions.py).  TREE: the
+ * factor is written by the op's distribution program (moog_dinstr_t below). */
+enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2, MOOG_DIST_TREE = 3 };
+
+/* Distribution programs.  A factor distribution that is not a flat Product of
+ * Continuous / Discrete / constants (distributions.py:159-420: Mixture, Intersection,
+ * SetMinus, Selection, Discrete with probs) is lowered to a small branching program
+ * that draws uniforms in exactly the order the reference's recursive `.sample()`
+ * does.  `contains()` predicates are postfix boolean programs in the same table.
+ *
+ *   sampling ops
+ *   CONT    fac[a] = x + (y - x) * u, cast to float32 when b           (:95-100)
+ *   DISC    fac[a] = cand[c + int(u * b)]; no draw when b == 1          (:137-140)
+ *   DISCP   as DISC with probabilities cand[d .. d + b): index =
+ *           searchsorted(cumsum(p) / sum(p), u, side='right')           (numpy choice)
+ *   CONST   fac[a] = x                                                   (Product constants)
+ *   CHOICE  Mixture: index as DISCP over b components with probs cand[d..]; the next b
+ *           instructions are JUMPs to the components                     (:176-180)
+ *   JUMP    pc = a
+ *   LOOP    tries[a] = 0 (a = nesting depth of the rejection loop, 0 or 1)
+ *   TEST    evaluate the predicate code[c .. c + b); accepted when its value == d;
+ *           otherwise ++tries[a], fault at 1e5, pc = loop body start (x as int)
+ *   END
+ *   predicate ops (value stack of booleans)
+ *   P_RANGE push x <= fac[a] < y, compared in float32 when fac[a] is a float32 sample
+ *   P_SET   push fac[a] in cand[c .. c + b)
+ *   P_AND / P_OR  pop b values, push their conjunction / disjunction
+ *   P_NOT
+ */
+enum {
+  MOOG_D_CONT = 0, MOOG_D_DISC, MOOG_D_DISCP, MOOG_D_CONST, MOOG_D_CHOICE, MOOG_D_JUMP,
+  MOOG_D_LOOP, MOOG_D_TEST, MOOG_D_END,
+  MOOG_P_RANGE = 16, MOOG_P_SET, MOOG_P_AND, MOOG_P_OR, MOOG_P_NOT
+};
+#define MOOG_DIST_MAX_TRIES 100000
+
+typedef struct {
+  int32_t op;
+  int32_t a, b, c, d;
+  int32_t pad_;
+  double x, y;
+} moog_dinstr_t;
 
 typedef struct {
   int32_t kind;     /* MOOG_DIST_*                                            */
@@ -99,6 +143,8 @@ typedef struct {
   int32_t n_sampled;    /* number of random factors                           */
   int32_t sample_order[MOOG_NUM_FACTORS]; /* factor ids in draw order         */
   uint64_t avoid_ops;   /* without_overlapping: bitmask of earlier ops        */
+  int32_t code_off;     /* distribution program in program.dcode, or -1       */
+  int32_t pad_;
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;
 
@@ -254,7 +300,10 @@ typedef struct {
   moog_genop_t ops[MOOG_MAX_OPS];
   moog_shape_t shapes[MOOG_MAX_SHAPES];
   double shape_verts[MOOG_MAX_SHAPE_VERTS][2]; /* centred, CCW, unit shapes    */
-  double cand[MOOG_MAX_CAND];                  /* DISCRETE candidates          */
+  double cand[MOOG_MAX_CAND];                  /* DISCRETE candidates / probs  */
+  int32_t n_dcode;
+  int32_t pad_;
+  moog_dinstr_t dcode[MOOG_MAX_DCODE];         /* distribution programs        */
 } moog_program_t;
 
 /* ---- state record layout ------------------------------------------------------

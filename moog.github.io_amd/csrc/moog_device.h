@@ -1574,6 +1574,109 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   }
 }
 
+// ---- distribution programs (moog_dinstr_t): Mixture / Intersection / SetMinus / Selection /
+//      Discrete(probs) sampling in the reference's draw order (distributions.py:159-405).
+//      Wave-uniform: every lane runs the same program on the same uniforms; `fac` stays in
+//      registers (static indexing through select chains).
+typedef const MOOG_CONST moog_dinstr_t* PDinstr;
+
+__device__ inline double fac_get(const double* fac, int a) {
+  double v = 0;
+#pragma unroll
+  for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == a) v = fac[q];
+  return v;
+}
+__device__ inline void fac_set(double* fac, int a, double v) {
+#pragma unroll
+  for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == a) fac[q] = v;
+}
+
+// numpy legacy choice(n, p): searchsorted(cumsum(p) / cumsum(p)[-1], u, side='right')
+__device__ inline int choice_p(Env& e, int poff, int n, double u) {
+  PProg P = e.P;
+  double last = 0;
+  for (int i = 0; i < n; ++i) last = (i == 0) ? P->cand[poff] : last + P->cand[poff + i];
+  double acc = 0;
+  int idx = 0;
+  for (int i = 0; i < n; ++i) {
+    acc = (i == 0) ? P->cand[poff] : acc + P->cand[poff + i];
+    if (acc / last <= u) idx = i + 1;
+  }
+  return idx >= n ? n - 1 : idx;
+}
+
+__device__ inline int dist_pred(Env& e, int off, int len, const double* fac, unsigned f32mask) {
+  PProg P = e.P;
+  unsigned stack = 0;
+  for (int pc = off; pc < off + len; ++pc) {
+    PDinstr I = &P->dcode[pc];
+    const int op = I->op, a = I->a, b = I->b;
+    if (op == MOOG_P_RANGE) {
+      double v = fac_get(fac, a);
+      bool in = ((f32mask >> a) & 1u) ? ((float)v >= (float)I->x && (float)v < (float)I->y)
+                                      : (v >= I->x && v < I->y);
+      stack = (stack << 1) | (in ? 1u : 0u);
+    } else if (op == MOOG_P_SET) {
+      double v = fac_get(fac, a);
+      bool in = false;
+      for (int k = 0; k < b; ++k) {
+        double c = P->cand[I->c + k];
+        in = in || (((f32mask >> a) & 1u) ? ((float)c == (float)v) : (c == v));
+      }
+      stack = (stack << 1) | (in ? 1u : 0u);
+    } else if (op == MOOG_P_AND || op == MOOG_P_OR) {
+      unsigned m = (1u << b) - 1u, top = stack & m;
+      bool v = (op == MOOG_P_AND) ? (top == m) : (top != 0u);
+      stack = ((stack >> b) << 1) | (v ? 1u : 0u);
+    } else if (op == MOOG_P_NOT) {
+      stack ^= 1u;
+    }
+  }
+  return (int)(stack & 1u);
+}
+
+__device__ inline void run_dist_program(Env& e, int pc, double* fac, unsigned& f32mask) {
+  PProg P = e.P;
+  int tries0 = 0, tries1 = 0;
+  for (;;) {
+    PDinstr I = &P->dcode[pc];
+    const int op = I->op, a = I->a, b = I->b;
+    if (op == MOOG_D_CONT) {
+      double u = next_uniform(e);
+      double v = I->x + (I->y - I->x) * u;
+      if (b) { v = f32r(v); f32mask |= 1u << a; } else f32mask &= ~(1u << a);
+      fac_set(fac, a, v); ++pc;
+    } else if (op == MOOG_D_DISC) {
+      double u = next_uniform(e);
+      int idx = (int)(u * b);
+      if (idx >= b) idx = b - 1;
+      fac_set(fac, a, P->cand[I->c + idx]); f32mask &= ~(1u << a); ++pc;
+    } else if (op == MOOG_D_DISCP) {
+      int idx = choice_p(e, I->d, b, next_uniform(e));
+      fac_set(fac, a, P->cand[I->c + idx]); f32mask &= ~(1u << a); ++pc;
+    } else if (op == MOOG_D_CONST) {
+      fac_set(fac, a, I->x); f32mask &= ~(1u << a); ++pc;
+    } else if (op == MOOG_D_CHOICE) {
+      int idx = choice_p(e, I->d, b, next_uniform(e));
+      pc = P->dcode[pc + 1 + idx].a;
+    } else if (op == MOOG_D_JUMP) {
+      pc = a;
+    } else if (op == MOOG_D_LOOP) {
+      if (a == 0) tries0 = 0; else tries1 = 0;
+      ++pc;
+    } else if (op == MOOG_D_TEST) {
+      int t = (a == 0) ? ++tries0 : ++tries1;
+      if (dist_pred(e, I->c, b, fac, f32mask) == I->d) { ++pc; }
+      else if (t >= MOOG_DIST_MAX_TRIES) {
+        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_DIST_EXHAUSTED;
+        ++pc;
+      } else pc = (int)I->x;
+    } else {
+      return;   // MOOG_D_END
+    }
+  }
+}
+
 __device__ inline void run_genop(Env& e, int oi) {
   PProg P = e.P;
   PGenop op = &P->ops[oi];
@@ -1602,6 +1705,13 @@ __device__ inline void run_genop(Env& e, int oi) {
     for (;;) {
       double fac[MOOG_NUM_FACTORS];
       sample_factors(e, op, fac);
+      if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
+        unsigned m = 0;
+        run_dist_program(e, op->code_off, fac, m);
+        const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
+        vel_f32 = (m & vb) == vb;
+        angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
+      }
       create_sprite(e, s, fac, vel_f32, angvel_f32);
       bool ov = false;
       for (int oj = 0; oj < oi && !ov; ++oj) {

@@ -11,6 +11,7 @@ import collections
 import numpy as np
 
 from . import _abi
+from . import _distcode
 from . import _trace
 from . import action_spaces
 from . import game_rules as rules_lib
@@ -174,9 +175,29 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         order = list(proto.sample_order)
         G.n_sampled = len(order)
         max_nv = 0
+        G.code_off = -1
+        tree_keys = set()
+        if op is not None and op.dist is not None and not distribs.is_flat(op.dist):
+            # Mixture / Intersection / SetMinus / Selection / Discrete(probs): the whole
+            # factor distribution of this generator becomes a distribution program
+            nv_box = [0]
+
+            def factor_value(key, v):
+                if key == 'shape':
+                    sid = shapes.intern(v)
+                    nv_box[0] = max(nv_box[0], shapes.nverts(sid))
+                    return float(sid)
+                return float(v)
+            G.code_off, tree_keys, cand_n = _distcode.lower(P, op.dist, cand_n, factor_value)
+            max_nv = nv_box[0]
+            order = []
+            G.n_sampled = 0
         for fi, fname in enumerate(_abi.FACTOR_NAMES):
             F = G.factors[fi]
             val = proto.factors[fname]
+            if fname in tree_keys:
+                F.kind = _abi.MOOG_DIST_TREE
+                continue
             if isinstance(val, sprite_lib.SymbolicFactor):
                 d = val.dist
                 if isinstance(d, distribs.Continuous):
@@ -200,7 +221,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                             P.cand[cand_n] = float(c)
                         cand_n += 1
                 else:
-                    raise NotImplementedError('distribution %r' % (type(d).__name__,))
+                    raise NotImplementedError(
+                        'distribution %r is only lowered inside a generate_sprites() generator'
+                        % (type(d).__name__,))
             else:
                 F.kind = _abi.MOOG_DIST_CONST
                 if fname == 'shape':

@@ -26,6 +26,8 @@ _FAULT_EXC = (
     (_abi.MOOG_FAULT_ODD_PORTALS, ValueError, 'There must be an even number of portals.'),
     (_abi.MOOG_FAULT_BAD_NORMAL, ValueError, 'collision_normal_norm is not close to 1.'),
     (_abi.MOOG_FAULT_INJECT_UNDERRUN, RuntimeError, 'injected uniform buffer exhausted.'),
+    (_abi.MOOG_FAULT_DIST_EXHAUSTED, ValueError,
+     'Maximum number of tried exceeded when trying to sample from a distribution.'),
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
 )

@@ -1,9 +1,12 @@
 """Factor distributions (reference: moog/state_initialization/distributions.py).
 
-Supported on the device sampler: `Continuous` (:78-116), `Discrete` (:119-156)
-and `Product` (:251-330).  While an environment traces its state_initializer
-`.sample()` returns symbolic factors; outside tracing it samples with numpy so
-configs that draw constants at build time keep working.
+The device sampler runs `Continuous` (:78-116), `Discrete` (:119-156) and `Product`
+(:251-330) directly, and `Mixture` (:159-204), `Intersection` (:207-258), `SetMinus`
+(:304-352), `Selection` (:355-405) and `Discrete(probs=...)` through a distribution
+program (`_distcode.py` -> `moog_dinstr_t`) that draws uniforms in the order the
+reference's recursive `.sample()` does.  While an environment traces its
+state_initializer `.sample()` returns symbolic factors; outside tracing it samples with
+numpy (same algorithm as the reference) so configs that draw at build time keep working.
 """
 import numpy as np
 
@@ -44,9 +47,7 @@ class Discrete(AbstractDistribution):
 
     def sample(self, rng=None):
         if _trace.active() is not None:
-            if self.probs is not None:
-                raise NotImplementedError('Discrete(probs=...) is not lowered to the device sampler')
-            if len(self.candidates) == 1:
+            if len(self.candidates) == 1 and self.probs is None:
                 return {self.key: self.candidates[0]}
             return {self.key: SymbolicFactor(self)}
         idx = self._get_rng(rng).choice(len(self.candidates), p=self.probs)
@@ -82,3 +83,140 @@ class Product(AbstractDistribution):
     @property
     def keys(self):
         return self._keys
+
+
+_MAX_TRIES = int(1e5)   # distributions.py:43
+
+
+class _Composite(AbstractDistribution):
+    """Distributions lowered as a whole: while tracing every key is a symbolic factor
+    bound to this node (the enclosing generator's root distribution is what gets
+    compiled)."""
+
+    def _symbolic(self):
+        return {k: SymbolicFactor(self) for k in self.keys}
+
+
+class Mixture(_Composite):
+    """Mixture of components with identical key sets (distributions.py:162-184)."""
+
+    def __init__(self, components, probs=None):
+        self.components = list(components)
+        self.probs = (np.ones(len(self.components)) / len(self.components) if probs is None
+                      else np.array(probs))
+        self._keys = self.components[0].keys
+        for c in self.components[1:]:
+            if c.keys != self._keys:
+                raise ValueError('All components must have the same key sets. However detected '
+                                 'key sets {} and {}'.format(self._keys, c.keys))
+
+    def sample(self, rng=None):
+        if _trace.active() is not None:
+            return self._symbolic()
+        rng = self._get_rng(rng)
+        return self.components[rng.choice(len(self.components), p=self.probs)].sample(rng=rng)
+
+    def contains(self, spec):
+        return any(c.contains(spec) for c in self.components)
+
+    @property
+    def keys(self):
+        return self._keys
+
+
+class Intersection(_Composite):
+    """Samples components[index_for_sampling], rejects unless every component contains
+    the sample (distributions.py:210-249)."""
+
+    def __init__(self, components, index_for_sampling=0):
+        self.components = list(components)
+        self.index_for_sampling = index_for_sampling
+        self._keys = self.components[0].keys
+        for c in self.components[1:]:
+            if c.keys != self._keys:
+                raise ValueError('All components must have the same key sets. However detected '
+                                 'key sets {} and {}'.format(self._keys, c.keys))
+
+    def sample(self, rng=None):
+        if _trace.active() is not None:
+            return self._symbolic()
+        rng = self._get_rng(rng)
+        for _ in range(_MAX_TRIES):
+            sample = self.components[self.index_for_sampling].sample(rng=rng)
+            if all(c.contains(sample) for c in self.components):
+                return sample
+        raise ValueError('Maximum number of tried exceeded when trying to sample from Intersection.')
+
+    def contains(self, spec):
+        return all(c.contains(spec) for c in self.components)
+
+    @property
+    def keys(self):
+        return self._keys
+
+
+class SetMinus(_Composite):
+    """Samples `base`, rejects samples contained in `hold_out` (distributions.py:307-343)."""
+
+    def __init__(self, base, hold_out):
+        self.base, self.hold_out = base, hold_out
+        self._keys = base.keys
+        if not hold_out.keys.issubset(self._keys):
+            raise ValueError('Keys {} of hold_out is not a subset of keys {} of SetMinus base '
+                             'distribution.'.format(hold_out.keys, base.keys))
+
+    def sample(self, rng=None):
+        if _trace.active() is not None:
+            return self._symbolic()
+        rng = self._get_rng(rng)
+        for _ in range(_MAX_TRIES):
+            sample = self.base.sample(rng=rng)
+            if not self.hold_out.contains(sample):
+                return sample
+        raise ValueError('Maximum number of tried exceeded when trying to sample from SetMinus.')
+
+    def contains(self, spec):
+        return self.base.contains(spec) and not self.hold_out.contains(spec)
+
+    @property
+    def keys(self):
+        return self._keys
+
+
+class Selection(_Composite):
+    """Samples `base`, keeps samples contained in `filtering` (distributions.py:358-397)."""
+
+    def __init__(self, base, filtering):
+        self.base, self.filtering = base, filtering
+        self._keys = base.keys
+        if not filtering.keys.issubset(self._keys):
+            raise ValueError('Keys {} of filtering is not a subset of keys {} of Selection base '
+                             'distribution.'.format(filtering.keys, base.keys))
+
+    def sample(self, rng=None):
+        if _trace.active() is not None:
+            return self._symbolic()
+        rng = self._get_rng(rng)
+        for _ in range(_MAX_TRIES):
+            sample = self.base.sample(rng=rng)
+            if self.filtering.contains(sample):
+                return sample
+        raise ValueError('Maximum number of tried exceeded when trying to sample from Selection.')
+
+    def contains(self, spec):
+        return self.base.contains(spec) and self.filtering.contains(spec)
+
+    @property
+    def keys(self):
+        return self._keys
+
+
+def is_flat(dist):
+    """True when the flat per-factor sampler (moog_factor_t) covers `dist`."""
+    if isinstance(dist, Continuous):
+        return True
+    if isinstance(dist, Discrete):
+        return dist.probs is None
+    if isinstance(dist, Product):
+        return all(is_flat(c) for c in dist.components)
+    return False

@@ -20,7 +20,8 @@ Randomness: the reference draws from numpy's global MT19937.  To
 make runs reproducible by an engine with a different generator, np.random.uniform
 / choice / randint are replaced by equivalents that consume one recorded uniform
 u in [0,1) each: uniform = low + (high-low)*u (numpy's own formula),
-choice(n) = int(u*n), randint(a,b) = a + int(u*(b-a)).
+choice(n) = int(u*n), choice(n, p) = searchsorted(cumsum(p)/sum(p), u, 'right') (numpy's
+own formula), randint(a,b) = a + int(u*(b-a)).
 """
 import importlib.util
 import os
@@ -66,8 +67,13 @@ def _uniform(low=0.0, high=1.0, size=None):
 
 
 def _choice(a, size=None, replace=True, p=None):
-    assert size is None and p is None
+    assert size is None
     n = a if isinstance(a, (int, np.integer)) else len(a)
+    if p is not None:   # numpy's own algorithm (legacy RandomState.choice with p)
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        idx = int(np.searchsorted(cdf, TAPE.u(), side='right'))
+        return idx if isinstance(a, (int, np.integer)) else a[idx]
     if n == 1:
         return 0
     return int(TAPE.u() * n)
@@ -460,6 +466,7 @@ def main():
         ('tether_zoo_l2', 45, {}, (0,)),
         ('tether_zoo_l3', 45, {}, (0,)),
         ('tether_zoo_l4', 45, {}, (0,)),
+        ('distrib_zoo', 60, {}, (0, 1)),
     ]
     only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:

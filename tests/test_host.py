@@ -115,3 +115,32 @@ def test_meta_state_rules_stay_on_the_host():
     m = {'key': 0}
     bump.step(None, m)
     assert m['key'] == 1
+
+
+def test_composite_distributions_lower_to_programs():
+    """Mixture / Intersection / SetMinus / Selection / Discrete(probs) become distribution
+    programs (include/moog_engine.h moog_dinstr_t); flat Products keep the per-factor path."""
+    from moog import _abi
+    from moog.state_initialization import distributions as distribs
+    c = helpers.compiled('distrib_zoo')
+    P = c.program
+    tree_ops = [P.ops[i] for i in range(P.n_ops) if P.ops[i].code_off >= 0]
+    assert len(tree_ops) == 2 and P.n_dcode > 20
+    ops = [P.dcode[i].op for i in range(P.n_dcode)]
+    for need in (_abi.MOOG_D_CHOICE, _abi.MOOG_D_LOOP, _abi.MOOG_D_TEST, _abi.MOOG_D_DISCP,
+                 _abi.MOOG_P_RANGE, _abi.MOOG_P_AND, _abi.MOOG_P_OR, _abi.MOOG_D_END):
+        assert need in ops
+    for i in range(P.n_dcode):       # every jump / loop target stays inside the table
+        I = P.dcode[i]
+        if I.op == _abi.MOOG_D_JUMP:
+            assert 0 <= I.a < P.n_dcode
+        if I.op == _abi.MOOG_D_TEST:
+            assert 0 <= int(I.x) < i and I.c + I.b <= P.n_dcode
+    assert all(helpers.compiled('colliding_predators').program.ops[i].code_off == -1
+               for i in range(helpers.compiled('colliding_predators').program.n_ops))
+    # outside a traced initializer the classes sample with numpy, by the reference's algorithm
+    d = distribs.SetMinus(distribs.Continuous('x', 0., 1.), distribs.Continuous('x', 0.2, 0.9))
+    xs = [float(d.sample()['x']) for _ in range(50)]
+    assert all((0. <= x < 0.2) or (0.9 <= x < 1.) for x in xs)
+    m = distribs.Mixture([distribs.Discrete('k', [1]), distribs.Discrete('k', [2])], probs=[0., 1.])
+    assert m.sample()['k'] == 2 and m.contains({'k': 1}) and not m.contains({'k': 3})
