@@ -100,9 +100,21 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    # Test hooks for 1-GPU boxes (tools/bench_ranks.sh): MOOG_BENCH_ONE_DEVICE=1 puts every
+    # rank on cuda:0 (with MOOG_BENCH_BACKEND=gloo, RCCL refuses two ranks on one GPU);
+    # MOOG_BENCH_FORCE_DIST=1 initialises the process group even for a world of one.
+    backend = os.environ.get('MOOG_BENCH_BACKEND', 'nccl')
+    if os.environ.get('MOOG_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
+    use_dist = world > 1 or os.environ.get('MOOG_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29517')
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     n = args.envs_per_gpu
@@ -125,7 +137,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -141,7 +153,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     env.set_timing(False)
-    dt_max = sharding.max_over_ranks(dt, device=dev)   # MAX over ranks, off the timed path
+    # MAX over ranks, off the timed path (RCCL needs the tensor on the GPU, gloo on the host)
+    dt_max = sharding.max_over_ranks(dt, device=dev if backend == 'nccl' else None)
 
     k_ms = {name: env.kernel_time(kid) for name, kid in
             (('step', _abi.MOOG_K_STEP), ('raster', _abi.MOOG_K_RASTER), ('reset', _abi.MOOG_K_RESET))}
@@ -184,7 +197,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
