@@ -27,13 +27,13 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 7
+#define MOOG_ABI_VERSION 8
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
 #define MOOG_MAX_FORCES 16
 #define MOOG_MAX_CORRECTIVE 4
-#define MOOG_MAX_RULES 8
+#define MOOG_MAX_RULES 16
 #define MOOG_MAX_TASKS 8
 #define MOOG_MAX_OPS 64
 #define MOOG_MAX_SHAPES 32
@@ -64,6 +64,9 @@ extern "C" {
 /* distributions.py:242-249,344-351: Intersection / SetMinus / Selection exceeded
  * _MAX_TRIES = 1e5 rejections (ValueError)                                      */
 #define MOOG_FAULT_DIST_EXHAUSTED 32
+/* CreateSprites / ChangeLayer appended to a layer whose slot capacity is used up (the
+ * reference's lists are unbounded; the engine's layers have a fixed capacity)      */
+#define MOOG_FAULT_LAYER_FULL 64
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -144,7 +147,8 @@ typedef struct {
   int32_t sample_order[MOOG_NUM_FACTORS]; /* factor ids in draw order         */
   uint64_t avoid_ops;   /* without_overlapping: bitmask of earlier ops        */
   int32_t code_off;     /* distribution program in program.dcode, or -1       */
-  int32_t pad_;
+  int32_t runtime;      /* 1: run by a CREATE_SPRITES rule, not at reset; slot0
+                         * is unused (sprites are appended to the rule's layer) */
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;
 
@@ -204,15 +208,36 @@ enum {
   MOOG_RULE_TORUS_WRAP,            /* ModifySprites(pos = remainder(pos,1)),
                                       modify_sprites.py:35-52 + chase_avoid_torus.py:144-149 */
   MOOG_RULE_PORTAL,                /* portal.py:41-76 l0 teleporting, l1 portals */
-  MOOG_RULE_BOOSTER                /* functional_maze.py:23-78 l0 agent, l1 boosters,
+  MOOG_RULE_BOOSTER,               /* functional_maze.py:23-78 l0 agent, l1 boosters,
                                       p0 mass mult, p1 c2 mult, p2 duration   */
+  MOOG_RULE_VANISH_BY_FILTER,      /* vanish.py:42-61 l0 layer, filter             */
+  MOOG_RULE_CHANGE_LAYER,          /* change_layer.py:36-46 l0 old, l1 new, filter */
+  MOOG_RULE_CREATE_SPRITES,        /* create_sprites.py:31-37 l0 layer, op = runtime
+                                      generation op, layers[] = without_overlapping */
+  MOOG_RULE_TIMED,                 /* timing.py:46-59 TimedRule / DelayedRule /
+                                      TemporaryRule: p0 start, p1 stop (inf allowed);
+                                      steps its children while start <= 0 < stop  */
+  MOOG_RULE_CONDITIONAL            /* conditional.py:60-63: steps its children
+                                      cond(state) times                           */
 };
+/* sprite filters of VANISH_BY_FILTER / CHANGE_LAYER */
+enum { MOOG_FILTER_ALWAYS = 0 };
+/* conditions of CONDITIONAL */
+enum { MOOG_RCOND_BERNOULLI = 1 /* np.random.binomial(1, p0): one uniform u, value u < p0 */ };
 
+/* Rules form a forest in pre-order: `parent` is the index of the enclosing TIMED /
+ * CONDITIONAL rule or -1; the children of rule r are the later entries whose parent
+ * is r, in order.  Nesting depth is at most 2 combinators.  Per-rule scalar state
+ * (f64 record, o_rule[r]): BOOSTER countdown, TIMED _steps_until_start. */
 typedef struct {
   int32_t kind;
   int32_t l0, l1;
   int32_t n_layers;
   int32_t layers[MOOG_MAX_LAYERS];
+  int32_t parent;
+  int32_t filter;      /* MOOG_FILTER_*                                           */
+  int32_t cond;        /* MOOG_RCOND_*                                            */
+  int32_t op;          /* CREATE_SPRITES: index of the runtime op in program.ops  */
   double p0, p1, p2;
 } moog_rule_t;
 
@@ -274,6 +299,9 @@ typedef struct {
   int32_t n_total_verts;           /* TOTV = sum of slot vertex capacities     */
   int32_t layer_slot0[MOOG_MAX_LAYERS];
   int32_t layer_nslots[MOOG_MAX_LAYERS];
+  int32_t layer_dynamic[MOOG_MAX_LAYERS]; /* 1: the layer is a Python list that rules
+                                    * append to / pop from; its live sprites are kept
+                                    * packed at the front of its slots, in list order */
   int32_t slot_layer[MOOG_MAX_SLOTS];
   int32_t slot_voff[MOOG_MAX_SLOTS];
   int32_t slot_vcap[MOOG_MAX_SLOTS];

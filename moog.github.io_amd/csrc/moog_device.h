@@ -1279,9 +1279,139 @@ __device__ inline double np_remainder1(double a) {
   return m;
 }
 
-__device__ inline void rule_step(Env& e, int ri) {
+// ---- layers that rules append to / pop from (CreateSprites, ChangeLayer): the reference's
+//      Python lists.  Live sprites stay packed at the front of the layer's slots, in list order.
+__device__ inline void move_slot(Env& e, int dst, int src) {
+  wsync();
+  const moog_layout_t& L = e.L;
+  const int n2 = 2 * NV(src);
+  double* vd = VERT(dst);
+  const double* vs = VERT(src);
+  for (int k = e.lane; k < n2; k += 64) vd[k] = vs[k];
+  if (e.lane < 8) BB(dst, e.lane) = BB(src, e.lane);
+  if (e.lane == 0) {
+    for (int c = 0; c < 2; ++c) {
+      e.f[L.o_pos + 2 * dst + c] = e.f[L.o_pos + 2 * src + c];
+      e.f[L.o_vel + 2 * dst + c] = e.f[L.o_vel + 2 * src + c];
+      e.f[L.o_inertia + 2 * dst + c] = e.f[L.o_inertia + 2 * src + c];
+    }
+    for (int c = 0; c < 3; ++c) COL(dst, c) = COL(src, c);
+    ANG(dst) = ANG(src); ANGV(dst) = ANGV(src); MASS(dst) = MASS(src); MAXR(dst) = MAXR(src);
+    FLAGS(dst) = FLAGS(src); NV(dst) = NV(src); OPAC(dst) = OPAC(src); SHAPEID(dst) = SHAPEID(src);
+    TELE(dst) = TELE(src);
+    if (e.P->vel_alias) VALIAS(dst) = VALIAS(src);
+    FLAGS(src) = 0; NV(src) = 0;
+  }
+  wsync();
+}
+
+__device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the vanished entries
+  PProg P = e.P;
+  if (!P->layer_dynamic[l]) return;
+  int j = P->layer_slot0[l];
+  const int s1 = P->layer_slot0[l] + P->layer_nslots[l];
+  for (int s = P->layer_slot0[l]; s < s1; ++s) {
+    if (!ALIVE(s)) continue;
+    if (s != j) move_slot(e, j, s);
+    ++j;
+  }
+}
+
+__device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the slot after the last entry
+  PProg P = e.P;
+  int n = 0;
+  for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) n += ALIVE(s) ? 1 : 0;
+  if (n >= P->layer_nslots[l]) {
+    wsync();
+    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_LAYER_FULL;
+    wsync();
+    return -1;
+  }
+  return P->layer_slot0[l] + n;
+}
+
+__device__ inline bool sprite_filter(Env& e, PRule R, int s) {
+  (void)e; (void)s;
+  return R->filter == MOOG_FILTER_ALWAYS;
+}
+
+__device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32);
+__device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& vel_f32, int& angvel_f32);
+__device__ inline int genop_count(Env& e, PGenop op);
+
+// DYN: the program has rules that create / move sprites at run time; the plain step kernel is
+// compiled without them so that the common configs do not carry the sampler.
+template <bool DYN>
+__device__ inline void rule_leaf_step(Env& e, int ri) {
   PProg P = e.P;
   PRule R = &P->rules[ri];
+  if constexpr (DYN) {
+    if (R->kind == MOOG_RULE_VANISH_BY_FILTER) {   // vanish.py:31-39,58-61
+      const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      wsync();
+      for (int s = a0 + e.lane; s < a1; s += 64)
+        if (ALIVE(s) && sprite_filter(e, R, s)) FLAGS(s) &= ~MOOG_F_ALIVE;
+      wsync();
+      layer_compact(e, R->l0);
+      return;
+    }
+    if (R->kind == MOOG_RULE_CHANGE_LAYER) {       // change_layer.py:36-46
+      const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      wsync();
+      for (int s = a0 + e.lane; s < a1; s += 64)
+        if (ALIVE(s) && sprite_filter(e, R, s)) FLAGS(s) |= MOOG_F_TMP;
+      wsync();
+      for (int s = a0; s < a1; ++s) {
+        if (!(FLAGS(s) & MOOG_F_TMP)) continue;
+        int dst = layer_append_slot(e, R->l1);
+        wsync();
+        if (e.lane == 0) FLAGS(s) &= ~MOOG_F_TMP;
+        wsync();
+        if (dst < 0) continue;
+        move_slot(e, dst, s);
+      }
+      layer_compact(e, R->l0);
+      return;
+    }
+    if (R->kind == MOOG_RULE_CREATE_SPRITES) {     // create_sprites.py:31-37 + sprite_generators.py:77-105
+      PGenop op = &P->ops[R->op];
+      const int n = genop_count(e, op);
+      int first = -1;
+      for (int k = 0; k < n; ++k) {
+        const int s = layer_append_slot(e, R->l0);
+        if (s < 0) break;
+        if (first < 0) first = s;
+        int count = 0;
+        for (;;) {
+          double fac[MOOG_NUM_FACTORS];
+          int vel_f32, angvel_f32;
+          sample_op_factors(e, op, fac, vel_f32, angvel_f32);
+          create_sprite(e, s, fac, vel_f32, angvel_f32);
+          bool ov = false;
+          for (int a = 0; a < R->n_layers && !ov; ++a) {
+            int l = R->layers[a];
+            for (int t = P->layer_slot0[l]; t < P->layer_slot0[l] + P->layer_nslots[l] && !ov; ++t)
+              if (t != s && ALIVE(t) && overlaps(e, s, t)) ov = true;
+          }
+          if (op->disjoint)
+            for (int t = first; t < s && !ov; ++t)
+              if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+          if (!ov) break;
+          if (count > op->max_tries) {
+            wsync();
+            if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+            wsync();
+            break;
+          }
+          ++count;
+        }
+        wsync();
+        if (e.lane == 0) FLAGS(s) |= MOOG_F_ALIVE;
+        wsync();
+      }
+      return;
+    }
+  }
   switch (R->kind) {
     case MOOG_RULE_VANISH_ON_CONTACT: {
       int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
@@ -1301,6 +1431,7 @@ __device__ inline void rule_step(Env& e, int ri) {
       for (int s = a0 + e.lane; s < a1; s += 64)
         if (FLAGS(s) & MOOG_F_TMP) FLAGS(s) &= ~(MOOG_F_TMP | MOOG_F_ALIVE);
       wsync();
+      if constexpr (DYN) layer_compact(e, R->l0);
       break;
     }
     case MOOG_RULE_TORUS_WRAP: {
@@ -1389,13 +1520,62 @@ __device__ inline void rule_step(Env& e, int ri) {
   }
 }
 
+// rule.reset() of one table entry; combinators also reset their children (rules_reset_tree)
 __device__ inline void rule_reset(Env& e, int ri) {
   PRule R = &e.P->rules[ri];
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
-  if (e.lane == 0) e.f[e.L.o_rule + ri] = DINF;
+  if (e.lane == 0) e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 : DINF;   // timing.py:47
   wsync();
+}
+
+// TimedRule.reset / ConditionalRule.reset (timing.py:46-49, conditional.py:56-58): the whole
+// subtree of a top-level rule is the contiguous run of entries that follows it.
+__device__ inline void rule_reset_tree(Env& e, int ri) {
+  PProg P = e.P;
+  rule_reset(e, ri);
+  for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) rule_reset(e, c);
+}
+
+// Combinator gate of rule ri for this call: how many times its children run
+// (timing.py:51-59, conditional.py:60-63).  Steps the TimedRule countdown.
+__device__ inline int rule_gate(Env& e, int ri) {
+  PRule R = &e.P->rules[ri];
+  if (R->kind == MOOG_RULE_TIMED) {
+    const double start = e.f[e.L.o_rule + ri];
+    const int n = (start <= 0 && start + (R->p1 - R->p0) > 0) ? 1 : 0;
+    wsync();
+    if (e.lane == 0) e.f[e.L.o_rule + ri] = start - 1;
+    wsync();
+    return n;
+  }
+  if (R->cond == MOOG_RCOND_BERNOULLI) return next_uniform(e) < R->p0 ? 1 : 0;
+  return 0;
+}
+
+// rule.step() of a top-level rule.  Nesting is at most two combinators deep, so the walk is
+// three explicit levels (no device recursion).  A TimedRule counts down AFTER its children ran.
+template <bool DYN>
+__device__ inline void rule_step(Env& e, int ri) {
+  PProg P = e.P;
+  const int k0 = P->rules[ri].kind;
+  if (k0 != MOOG_RULE_TIMED && k0 != MOOG_RULE_CONDITIONAL) { rule_leaf_step<DYN>(e, ri); return; }
+  const int nr = P->n_rules;
+  // the countdown of a TimedRule happens after its children in the reference; children never
+  // read the parent's counter, so taking the gate first is equivalent
+  const int n0 = rule_gate(e, ri);
+  for (int i0 = 0; i0 < n0; ++i0) {
+    for (int c = ri + 1; c < nr && P->rules[c].parent >= ri; ++c) {
+      if (P->rules[c].parent != ri) continue;
+      const int k1 = P->rules[c].kind;
+      if (k1 != MOOG_RULE_TIMED && k1 != MOOG_RULE_CONDITIONAL) { rule_leaf_step<DYN>(e, c); continue; }
+      const int n1 = rule_gate(e, c);
+      for (int i1 = 0; i1 < n1; ++i1)
+        for (int d = c + 1; d < nr && P->rules[d].parent >= c; ++d)
+          if (P->rules[d].parent == c) rule_leaf_step<DYN>(e, d);
+    }
+  }
 }
 
 // ---- tasks ---------------------------------------------------------------------------------
@@ -1677,9 +1857,8 @@ __device__ inline void run_dist_program(Env& e, int pc, double* fac, unsigned& f
   }
 }
 
-__device__ inline void run_genop(Env& e, int oi) {
-  PProg P = e.P;
-  PGenop op = &P->ops[oi];
+// n ~ randint(count_min, count_max + 1) when the generator's num_sprites is a range
+__device__ inline int genop_count(Env& e, PGenop op) {
   int n = op->count_max;
   if (op->count_min < op->count_max) {
     double u = next_uniform(e);
@@ -1688,11 +1867,31 @@ __device__ inline void run_genop(Env& e, int oi) {
     if (k >= span) k = span - 1;
     n = op->count_min + k;
   }
+  return n;
+}
+
+// one `factor_dist.sample()`: the factors and which of them are float32 samples
+__device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& vel_f32, int& angvel_f32) {
   PFactor FX = &op->factors[MOOG_FAC_XVEL];
   PFactor FY = &op->factors[MOOG_FAC_YVEL];
   PFactor FW = &op->factors[MOOG_FAC_ANGVEL];
-  int vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
-  int angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
+  vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
+  angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
+  sample_factors(e, op, fac);
+  if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
+    unsigned m = 0;
+    run_dist_program(e, op->code_off, fac, m);
+    const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
+    vel_f32 = (m & vb) == vb;
+    angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
+  }
+}
+
+__device__ inline void run_genop(Env& e, int oi) {
+  PProg P = e.P;
+  PGenop op = &P->ops[oi];
+  if (op->runtime) return;   // CreateSprites generators run at rule time
+  const int n = genop_count(e, op);
   for (int k = 0; k < op->count_max; ++k) {
     int s = op->slot0 + k;
     if (k >= n) {
@@ -1704,14 +1903,8 @@ __device__ inline void run_genop(Env& e, int oi) {
     int count = 0;
     for (;;) {
       double fac[MOOG_NUM_FACTORS];
-      sample_factors(e, op, fac);
-      if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
-        unsigned m = 0;
-        run_dist_program(e, op->code_off, fac, m);
-        const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
-        vel_f32 = (m & vb) == vb;
-        angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
-      }
+      int vel_f32, angvel_f32;
+      sample_op_factors(e, op, fac, vel_f32, angvel_f32);
       create_sprite(e, s, fac, vel_f32, angvel_f32);
       bool ov = false;
       for (int oj = 0; oj < oi && !ov; ++oj) {
@@ -1752,5 +1945,6 @@ __device__ inline void env_reset(Env& e) {
     e.f[e.L.o_action] = 0; e.f[e.L.o_action + 1] = 0;
   }
   wsync();
-  for (int r = 0; r < P->n_rules; ++r) { rule_reset(e, r); rule_step(e, r); }
+  for (int r = 0; r < P->n_rules; ++r)
+    if (P->rules[r].parent < 0) { rule_reset_tree(e, r); rule_step<true>(e, r); }
 }

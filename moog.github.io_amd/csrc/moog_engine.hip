@@ -119,6 +119,10 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   store_record(e, gf, gq);
 }
 
+// DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
+// ChangeLayer, VanishByFilter): that variant carries the reset path's sampler; the plain one
+// is what the benchmark configs run.
+template <bool DYN>
 __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   }
   // environment.py:98-126
   const int n_rules = uni(P->n_rules);
-  for (int r = 0; r < n_rules; ++r) rule_step(e, r);
+  for (int r = 0; r < n_rules; ++r)
+    if (P->rules[r].parent < 0) rule_step<DYN>(e, r);
   double ax = 0, ay = 0;
   int ga = 4;
   if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
@@ -208,6 +213,7 @@ struct moog_engine {
   int64_t env_index0 = 0;
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
+  bool dynamic_rules = false;
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
   bool timing = false;
   const int32_t* perm = nullptr;
@@ -297,8 +303,17 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_chunk = chunk;
     e->raster_lds = pl.total;
   }
-  err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel),
+  err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+  for (int r = 0; r < prog->n_rules; ++r) {
+    int k = prog->rules[r].kind;
+    if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES)
+      e->dynamic_rules = true;
+  }
+  for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_reset_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
@@ -430,7 +445,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   a.cost = e->cost;
   {
     Bracket br(e, MOOG_K_STEP, s);
-    hipLaunchKernelGGL(moog_step_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    if (e->dynamic_rules) hipLaunchKernelGGL(moog_step_kernel<true>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    else hipLaunchKernelGGL(moog_step_kernel<false>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
   if (out && out->image) return launch_raster(e, out->image, s);
@@ -444,7 +460,8 @@ int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject, void
   KArgs a = make_args(e, nullptr, inject, nullptr, MODE_PHYSICS, nullptr);
   {
     Bracket br(e, MOOG_K_STEP, s);
-    hipLaunchKernelGGL(moog_step_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    if (e->dynamic_rules) hipLaunchKernelGGL(moog_step_kernel<true>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    else hipLaunchKernelGGL(moog_step_kernel<false>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
   return MOOG_OK;

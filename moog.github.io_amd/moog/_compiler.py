@@ -84,8 +84,22 @@ def _fill_layers(dst, names, layer_index):
     return len(names)
 
 
+def _flatten_rules(rules, parent=-1, depth=0, out=None):
+    """Pre-order list of (rule, parent index) over TimedRule / ConditionalRule nesting."""
+    out = [] if out is None else out
+    for r in rules:
+        if getattr(r, 'host_side', False):
+            continue
+        out.append((r, parent))
+        if isinstance(r, (rules_lib.TimedRule, rules_lib.ConditionalRule)):
+            if depth >= 2:
+                raise NotImplementedError('rule combinators nested deeper than 2')
+            _flatten_rules(r._rules, len(out) - 1, depth + 1, out)
+    return out
+
+
 def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
-                   meta_state_initializer=None):
+                   meta_state_initializer=None, layer_capacity=None):
     # meta_state lives on the host (environment.py keeps it for `ModifyMetaState`)
     del meta_state_initializer
     P = _abi.Program()
@@ -106,6 +120,20 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             raise KeyError('layer %r is not a key of the environment state' % (name,))
         return layer_names.index(name)
 
+    # Layers that rules append to (CreateSprites, ChangeLayer's new_layer) behave like the
+    # reference's Python lists: live sprites stay packed at the front of the layer's slots
+    # in list order, and the layer gets spare slots (`layer_capacity`, default +8).
+    flat_rules = _flatten_rules(tuple(game_rules))
+    dynamic = []
+    for r, _ in flat_rules:
+        if isinstance(r, rules_lib.CreateSprites):
+            dynamic.append(r._layer)
+        elif isinstance(r, rules_lib.ChangeLayer):
+            dynamic.append(r._new_layer)
+    layer_capacity = dict(layer_capacity or {})
+    for name in layer_capacity:
+        layer_index(name)
+
     # slots: layer order, list order
     slot_of = {}
     slot_sprite = []
@@ -118,6 +146,18 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             slot_of[id(s)] = len(slot_sprite)
             P.slot_layer[len(slot_sprite)] = li
             slot_sprite.append(s)
+        n_init = len(slot_sprite) - P.layer_slot0[li]
+        cap = n_init
+        if name in dynamic:
+            P.layer_dynamic[li] = 1
+            cap = int(layer_capacity.get(name, n_init + 8))
+        elif name in layer_capacity:
+            cap = int(layer_capacity[name])
+        if cap < n_init:
+            raise ValueError('layer_capacity[%r] is below its initial sprite count' % (name,))
+        for _ in range(cap - n_init):   # spare slots: no recipe, dead after reset
+            P.slot_layer[len(slot_sprite)] = li
+            slot_sprite.append(None)
         P.layer_nslots[li] = len(slot_sprite) - P.layer_slot0[li]
     S = len(slot_sprite)
     if S > _abi.MOOG_MAX_SLOTS:
@@ -131,7 +171,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     for op in tr.ops:
         for s in op.sprites:
             traced_ids.add(id(s))
-    pending_static = [s for s in slot_sprite if id(s) not in traced_ids]
+    pending_static = [s for s in slot_sprite if s is not None and id(s) not in traced_ids]
     # statics consume no randomness: put them first so that they can be avoided
     for s in pending_static:
         if s.is_symbolic:
@@ -139,6 +179,16 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         ops.append((None, [s]))
     for op in tr.ops:
         ops.append((op, op.sprites))
+    n_reset_ops = len(ops)
+    runtime_op_of_rule = {}
+    for ri, (r, _) in enumerate(flat_rules):   # CreateSprites generators run at rule time
+        if isinstance(r, rules_lib.CreateSprites):
+            with _trace.tracing() as tr2:
+                r._generator(without_overlapping=[])
+            if len(tr2.ops) != 1:
+                raise NotImplementedError('CreateSprites generator must be one generate_sprites()')
+            runtime_op_of_rule[ri] = len(ops)
+            ops.append((tr2.ops[0], tr2.ops[0].sprites))
     if len(ops) > _abi.MOOG_MAX_OPS:
         raise ValueError('too many sprite generation ops (max %d)' % _abi.MOOG_MAX_OPS)
     for oi, (_, sprites) in enumerate(ops):
@@ -148,21 +198,29 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
 
     cand_n = 0
     vcap = [0] * S
+    op_max_nv = {}
     for oi, (op, sprites) in enumerate(ops):
         G = P.ops[oi]
-        for s in sprites:
-            if id(s) not in slot_of:
-                raise ValueError('a generated sprite is missing from the returned state')
-        slots = [slot_of[id(s)] for s in sprites]
-        if slots != list(range(slots[0], slots[0] + len(slots))):
-            raise ValueError('sprites of one generator call must stay contiguous and ordered')
-        G.slot0 = slots[0]
+        runtime = oi >= n_reset_ops
+        G.runtime = int(runtime)
+        if runtime:
+            slots = []
+            if op.avoid:
+                raise ValueError('CreateSprites passes without_overlapping itself')
+        else:
+            for s in sprites:
+                if id(s) not in slot_of:
+                    raise ValueError('a generated sprite is missing from the returned state')
+            slots = [slot_of[id(s)] for s in sprites]
+            if slots != list(range(slots[0], slots[0] + len(slots))):
+                raise ValueError('sprites of one generator call must stay contiguous and ordered')
+            G.slot0 = slots[0]
         G.count_max = len(sprites)
         G.count_min = len(sprites) if op is None else op.count_min
         G.disjoint = 0 if op is None else int(op.disjoint)
         G.max_tries = 0 if op is None else int(op.max_tries)
         avoid = 0
-        if op is not None:
+        if op is not None and not runtime:
             for a in op.avoid:
                 if id(a) not in op_index_of_sprite:
                     raise ValueError('without_overlapping refers to a sprite that is not in the state')
@@ -236,7 +294,23 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             G.sample_order[k] = _abi.FACTOR_NAMES.index(fname)
         for sl in slots:
             vcap[sl] = max_nv
+        op_max_nv[oi] = max_nv
     P.n_cand = cand_n
+    # every slot of a dynamic layer can hold any sprite that may end up in that layer
+    layer_nv = [max([vcap[sl] for sl in range(P.layer_slot0[li], P.layer_slot0[li] + P.layer_nslots[li])]
+                    or [0]) for li in range(P.n_layers)]
+    for _ in range(P.n_layers):   # ChangeLayer chains: propagate to a fixed point
+        for ri, (r, _p) in enumerate(flat_rules):
+            if isinstance(r, rules_lib.CreateSprites):
+                li = layer_index(r._layer)
+                layer_nv[li] = max(layer_nv[li], op_max_nv[runtime_op_of_rule[ri]])
+            elif isinstance(r, rules_lib.ChangeLayer):
+                lo, ln = layer_index(r._old_layer), layer_index(r._new_layer)
+                layer_nv[ln] = max(layer_nv[ln], layer_nv[lo])
+    for li in range(P.n_layers):
+        if P.layer_dynamic[li]:
+            for sl in range(P.layer_slot0[li], P.layer_slot0[li] + P.layer_nslots[li]):
+                vcap[sl] = layer_nv[li]
     voff = 0
     for sl in range(S):
         P.slot_voff[sl] = voff
@@ -321,15 +395,34 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     P.n_corrective = len(physics._corrective_physics)
 
     # ---- game rules ---------------------------------------------------------------
-    game_rules = tuple(r for r in game_rules if not getattr(r, 'host_side', False))
-    if len(game_rules) > _abi.MOOG_MAX_RULES:
+    if len(flat_rules) > _abi.MOOG_MAX_RULES:
         raise ValueError('too many game rules')
-    for ri, r in enumerate(game_rules):
+    for ri, (r, parent) in enumerate(flat_rules):
         R = P.rules[ri]
+        R.parent = parent
         low = rules_lib.lookup_lowering(r)
         if isinstance(r, rules_lib.VanishOnContact):
             R.kind = _abi.MOOG_RULE_VANISH_ON_CONTACT
             R.l0, R.l1 = layer_index(r._layer), layer_index(r._contacting_layer)
+        elif isinstance(r, rules_lib.VanishByFilter):
+            R.kind = _abi.MOOG_RULE_VANISH_BY_FILTER
+            R.l0 = layer_index(r._layer)
+            R.filter = rules_lib._classify_filter(r._filter_fn)
+        elif isinstance(r, rules_lib.ChangeLayer):
+            R.kind = _abi.MOOG_RULE_CHANGE_LAYER
+            R.l0, R.l1 = layer_index(r._old_layer), layer_index(r._new_layer)
+            R.filter = rules_lib._classify_filter(r._filter_fn)
+        elif isinstance(r, rules_lib.CreateSprites):
+            R.kind = _abi.MOOG_RULE_CREATE_SPRITES
+            R.l0 = layer_index(r._layer)
+            R.op = runtime_op_of_rule[ri]
+            R.n_layers = _fill_layers(R.layers, list(r._without_overlapping), layer_index)
+        elif isinstance(r, rules_lib.TimedRule):
+            R.kind = _abi.MOOG_RULE_TIMED
+            R.p0, R.p1 = r._step_interval
+        elif isinstance(r, rules_lib.ConditionalRule):
+            R.kind = _abi.MOOG_RULE_CONDITIONAL
+            R.cond, R.p0 = r.classify()
         elif isinstance(r, rules_lib.ModifySprites):
             R.kind = r.classify()
             R.n_layers = _fill_layers(R.layers, r._layers, layer_index)
@@ -344,7 +437,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             raise NotImplementedError(
                 'game rule %r has no device lowering (see game_rules.register_lowering)'
                 % (type(r).__name__,))
-    P.n_rules = len(game_rules)
+    P.n_rules = len(flat_rules)
 
     # ---- task -----------------------------------------------------------------------
     if isinstance(task, tasks_lib.CompositeTask):

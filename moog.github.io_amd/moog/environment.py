@@ -28,6 +28,8 @@ _FAULT_EXC = (
     (_abi.MOOG_FAULT_INJECT_UNDERRUN, RuntimeError, 'injected uniform buffer exhausted.'),
     (_abi.MOOG_FAULT_DIST_EXHAUSTED, ValueError,
      'Maximum number of tried exceeded when trying to sample from a distribution.'),
+    (_abi.MOOG_FAULT_LAYER_FULL, RuntimeError,
+     'a rule appended to a layer whose slot capacity is used up (raise layer_capacity).'),
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
 )
@@ -37,7 +39,8 @@ class BatchedEnvironment(object):
     """N independent MOOG environments stepped by one HIP engine handle."""
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
-                 meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0):
+                 meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0,
+                 layer_capacity=None):
         import torch
         self._torch = torch
         self._lib = _engine.load_library()  # raises when the HIP extension is missing
@@ -45,7 +48,7 @@ class BatchedEnvironment(object):
             raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
         self.compiled = _compiler.compile_config(
             state_initializer, physics, task, action_space, observers, game_rules,
-            meta_state_initializer)
+            meta_state_initializer, layer_capacity=layer_capacity)
         self.physics = physics
         self.task = task
         self.action_space = action_space

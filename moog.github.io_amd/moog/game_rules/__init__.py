@@ -1,6 +1,8 @@
 """Game rules (reference: moog/game_rules/__init__.py:3-23).
 
-Lowered to the device: VanishOnContact (vanish.py:63-86), ModifySprites whose
+Lowered to the device: VanishOnContact (vanish.py:63-86), VanishByFilter (:42-61),
+ChangeLayer (change_layer.py), CreateSprites (create_sprites.py), TimedRule / DelayedRule /
+TemporaryRule (timing.py), ConditionalRule (conditional.py), ModifySprites whose
 modifier is the torus position wrap (modify_sprites.py:8-52 with
 chase_avoid_torus.py:144-149), Portal (portal.py:11-76) and config-local rules
 that register a lowering (`register_lowering`), e.g. functional_maze.py's
@@ -77,6 +79,123 @@ class Portal(AbstractRule):
     def __init__(self, teleporting_layer, portal_layer):
         self._teleporting_layer = teleporting_layer
         self._portal_layer = portal_layer
+
+
+class _NoAttributes(object):
+    """Probe argument: a filter that returns a constant without looking at the sprite."""
+
+    def __getattr__(self, name):
+        raise _TouchedSprite(name)
+
+
+class _TouchedSprite(Exception):
+    pass
+
+
+def _classify_filter(filter_fn):
+    """MOOG_FILTER_* of a `sprite -> bool` function.  None and functions that ignore
+    their argument and return True (e.g. `lambda _: True`) are ALWAYS."""
+    if filter_fn is None:
+        return _abi.MOOG_FILTER_ALWAYS
+    try:
+        if filter_fn(_NoAttributes()) is True:
+            return _abi.MOOG_FILTER_ALWAYS
+    except _TouchedSprite:
+        pass
+    raise NotImplementedError('sprite filter functions other than "always True" are not lowered')
+
+
+class VanishByFilter(AbstractRule):
+    """vanish.py:42-61: every sprite of `layer` for which filter_fn is True is popped."""
+
+    def __init__(self, layer, filter_fn=None):
+        self._layer = layer
+        self._filter_fn = filter_fn
+
+
+class ChangeLayer(AbstractRule):
+    """change_layer.py:16-46: sprites of old_layer passing filter_fn are popped and appended
+    to new_layer, in order."""
+
+    def __init__(self, old_layer, new_layer, filter_fn=None):
+        self._old_layer, self._new_layer = old_layer, new_layer
+        self._filter_fn = filter_fn
+
+
+class CreateSprites(AbstractRule):
+    """create_sprites.py:10-37: `generator(without_overlapping=<sprites of those layers>)`
+    at rule time; the new sprites are appended to `layer`."""
+
+    def __init__(self, layer, generator, without_overlapping=()):
+        self._layer = layer
+        self._generator = generator
+        if isinstance(without_overlapping, str):
+            without_overlapping = (without_overlapping,)
+        self._without_overlapping = tuple(without_overlapping)
+
+
+class TimedRule(AbstractRule):
+    """timing.py:18-59: steps `rules` while _steps_until_start <= 0 < _steps_until_stop;
+    both count down once per call.  Callable (random) intervals are not lowered."""
+
+    def __init__(self, step_interval, rules):
+        if callable(step_interval):
+            raise NotImplementedError('TimedRule with a callable step_interval is not lowered')
+        self._step_interval = (float(step_interval[0]), float(step_interval[1]))
+        if not isinstance(rules, (list, tuple)):
+            rules = (rules,)
+        self._rules = tuple(rules)
+
+
+class DelayedRule(TimedRule):
+    """timing.py:62-90"""
+
+    def __init__(self, steps_until_start, rules, duration=np.inf):
+        if callable(steps_until_start) or callable(duration):
+            raise NotImplementedError('DelayedRule with callable arguments is not lowered')
+        super(DelayedRule, self).__init__((steps_until_start, steps_until_start + duration), rules)
+
+
+class TemporaryRule(TimedRule):
+    """timing.py:93-109"""
+
+    def __init__(self, steps_until_stop, rules):
+        if callable(steps_until_stop):
+            raise NotImplementedError('TemporaryRule with a callable argument is not lowered')
+        super(TemporaryRule, self).__init__((0, steps_until_stop), rules)
+
+
+class _BinomialProbe(object):
+    def __init__(self, n, p):
+        self.n, self.p = n, p
+
+
+class ConditionalRule(AbstractRule):
+    """conditional.py:16-63: steps `rules` condition(state) times.  Lowered conditions:
+    `lambda state: np.random.binomial(1, p)` (first_person_predators_prey.py:181,189),
+    recognised by running the condition once with np.random.binomial recording its
+    arguments."""
+
+    def __init__(self, condition, rules):
+        self._condition = condition
+        if not isinstance(rules, (list, tuple)):
+            rules = [rules]
+        self._rules = tuple(rules)
+
+    def classify(self):
+        import inspect
+        real = np.random.binomial
+        np.random.binomial = lambda n, p, size=None: _BinomialProbe(n, p)
+        try:
+            nargs = len(inspect.signature(self._condition).parameters)
+            out = self._condition(*([None] * nargs))
+        except Exception as exc:  # pylint: disable=broad-except
+            raise NotImplementedError('ConditionalRule condition not recognised: %r' % (exc,))
+        finally:
+            np.random.binomial = real
+        if isinstance(out, _BinomialProbe) and out.n == 1:
+            return _abi.MOOG_RCOND_BERNOULLI, float(out.p)
+        raise NotImplementedError('ConditionalRule condition is not np.random.binomial(1, p)')
 
 
 # ---- lowering registry for config-local rule classes --------------------------

@@ -20,7 +20,7 @@ Randomness: the reference draws from numpy's global MT19937.  To
 make runs reproducible by an engine with a different generator, np.random.uniform
 / choice / randint are replaced by equivalents that consume one recorded uniform
 u in [0,1) each: uniform = low + (high-low)*u (numpy's own formula),
-choice(n) = int(u*n), choice(n, p) = searchsorted(cumsum(p)/sum(p), u, 'right') (numpy's
+binomial(1, p) = int(u < p), choice(n) = int(u*n), choice(n, p) = searchsorted(cumsum(p)/sum(p), u, 'right') (numpy's
 own formula), randint(a,b) = a + int(u*(b-a)).
 """
 import importlib.util
@@ -59,6 +59,7 @@ class Tape(object):
 
 
 TAPE = None
+DYNAMIC_LAYERS = ()
 
 
 def _uniform(low=0.0, high=1.0, size=None):
@@ -86,10 +87,16 @@ def _randint(low, high=None, size=None, dtype=int):
     return low + int(TAPE.u() * (high - low))
 
 
+def _binomial(n, p, size=None):
+    assert n == 1 and size is None
+    return int(TAPE.u() < p)
+
+
 def patch_numpy_random():
     np.random.uniform = _uniform
     np.random.choice = _choice
     np.random.randint = _randint
+    np.random.binomial = _binomial
 
 
 SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls')
@@ -131,9 +138,12 @@ def snapshot(env, layer_names, caps, slot_of):
     tele_ids = set()
     for r in getattr(env, 'game_rules', ()):
         tele_ids |= set(getattr(r, '_currently_teleporting', set()))
+    offs = dict(zip(layer_names, np.concatenate([[0], np.cumsum(caps)[:-1]])))
     for name in layer_names:
-        for s in env.state[name]:
-            k = slot_of[s.id]
+        for i, s in enumerate(env.state[name]):
+            # layers that rules append to are Python lists: slot = list position
+            k = int(offs[name]) + i if name in DYNAMIC_LAYERS else slot_of[s.id]
+            assert k < int(offs[name]) + caps[layer_names.index(name)], (name, i)
             d['alive'][k] = 1
             d['pos'][k] = s.position
             d['vel'][k] = s.velocity
@@ -161,7 +171,8 @@ def snapshot(env, layer_names, caps, slot_of):
 def bookkeeping(env):
     subtasks = getattr(env.task, '_tasks', (env.task,))
     tc = [float(getattr(t, '_steps_until_reset', np.nan)) for t in subtasks]
-    rc = [float(getattr(r, '_steps_until_expire', np.nan)) for r in env.game_rules]
+    rc = [float(getattr(r, '_steps_until_expire', getattr(r, '_steps_until_start', np.nan)))
+          for r in env.game_rules]
     return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
                 action_mem=np.array(env.action_space._action, dtype=float),
                 task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float))
@@ -178,7 +189,9 @@ def make_slot_map(env, layer_names, caps):
 
 
 def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
-    global TAPE
+    global TAPE, DYNAMIC_LAYERS
+    caps_by_layer = dict(caps_by_layer)
+    DYNAMIC_LAYERS = tuple(caps_by_layer.pop('__dynamic__', ()))
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -467,6 +480,8 @@ def main():
         ('tether_zoo_l3', 45, {}, (0,)),
         ('tether_zoo_l4', 45, {}, (0,)),
         ('distrib_zoo', 60, {}, (0, 1)),
+        ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
+        ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
     ]
     only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:

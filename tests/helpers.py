@@ -144,9 +144,14 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
     tc = np.asarray(fx['task_counters'][t], np.float64).reshape(-1)
     for k in range(P.n_tasks):
         f[L.o_task + k] = tc[k] if k < len(tc) and not np.isnan(tc[k]) else np.inf
+    # the fixture lists env.game_rules (top level); the program table is the pre-order forest
     rc = np.asarray(fx['rule_counters'][t], np.float64).reshape(-1)
-    for k in range(P.n_rules):
-        f[L.o_rule + k] = rc[k] if k < len(rc) and not np.isnan(rc[k]) else np.inf
+    tops = [r for r in range(P.n_rules) if P.rules[r].parent < 0]
+    for r in range(P.n_rules):
+        f[L.o_rule + r] = np.inf
+    for k, r in enumerate(tops):
+        if k < len(rc) and not np.isnan(rc[k]):
+            f[L.o_rule + r] = rc[k]
     pm = portal_rule_mask(P)
     for s in range(S):
         nv = int(fx['nverts'][t][s])
@@ -254,10 +259,11 @@ def state_diff(fx, t, c, f64, i32, env=0):
             ints_ok = False
             detail.append('task counter %d: %r vs %r' % (k, f[L.o_task + k], tc[k]))
     rc = np.asarray(fx['rule_counters'][t], np.float64).reshape(-1)
-    for k in range(min(P.n_rules, len(rc))):
-        if not np.isnan(rc[k]) and f[L.o_rule + k] != rc[k]:
+    tops = [r for r in range(P.n_rules) if P.rules[r].parent < 0]
+    for k, r in enumerate(tops[:len(rc)]):
+        if not np.isnan(rc[k]) and f[L.o_rule + r] != rc[k]:
             ints_ok = False
-            detail.append('rule counter %d: %r vs %r' % (k, f[L.o_rule + k], rc[k]))
+            detail.append('rule counter %d: %r vs %r' % (k, f[L.o_rule + r], rc[k]))
     return dict(float=max(err.values()), err=err, ints_ok=ints_ok, detail='; '.join(detail))
 
 
