@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 8
+#define MOOG_ABI_VERSION 9
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -39,7 +39,8 @@ extern "C" {
 #define MOOG_MAX_SHAPES 32
 #define MOOG_MAX_SHAPE_VERTS 512
 #define MOOG_MAX_CAND 128
-#define MOOG_MAX_DCODE 192
+#define MOOG_MAX_DCODE 512
+#define MOOG_X_STACK 16
 #define MOOG_MAX_SLOTS 128
 #define MOOG_NUM_FACTORS 14
 
@@ -117,6 +118,30 @@ enum {
   MOOG_P_RANGE = 16, MOOG_P_SET, MOOG_P_AND, MOOG_P_OR, MOOG_P_NOT
 };
 #define MOOG_DIST_MAX_TRIES 100000
+
+/* Sprite expressions.  Config callables (sprite filters, modifiers, pair conditions, reward
+ * functions; e.g. modify_sprites.py:41-52, vanish.py:58-61, contact_reward.py:85-92) are run
+ * once at build time on symbolic sprites (moog/_symbolic.py) and stored as postfix code in
+ * the same table.  Every value carries a dtype tag so that scalar arithmetic follows numpy 2
+ * promotion (NEP 50): 0 = weak Python scalar, 1 = float32, 2 = float64; an operation is
+ * carried out in float32 when an operand is float32 and none is float64.
+ *   X_CONST  push x (tag 2 when b, else 0)     X_ATTR  push attribute a of sprite b
+ *   binary   ADD SUB MUL DIV REM(np.remainder) MIN MAX  LT LE GT GE EQ NE  AND OR
+ *   unary    NEG ABS SQRT SIN COS FLOOR NOT SIGN
+ *   X_SELECT pop b, a, c; push c ? a : b       X_STORE pop v; sprite 0 attribute a := v
+ *   X_END
+ */
+enum {
+  MOOG_X_CONST = 32, MOOG_X_ATTR, MOOG_X_ADD, MOOG_X_SUB, MOOG_X_MUL, MOOG_X_DIV, MOOG_X_REM,
+  MOOG_X_MIN, MOOG_X_MAX, MOOG_X_LT, MOOG_X_LE, MOOG_X_GT, MOOG_X_GE, MOOG_X_EQ, MOOG_X_NE,
+  MOOG_X_AND, MOOG_X_OR, MOOG_X_NEG, MOOG_X_ABS, MOOG_X_SQRT, MOOG_X_SIN, MOOG_X_COS,
+  MOOG_X_FLOOR, MOOG_X_NOT, MOOG_X_SIGN, MOOG_X_SELECT, MOOG_X_STORE, MOOG_X_END
+};
+/* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
+enum {
+  MOOG_XA_X = 0, MOOG_XA_Y, MOOG_XA_XVEL, MOOG_XA_YVEL, MOOG_XA_ANGLE, MOOG_XA_ANGVEL, MOOG_XA_MASS,
+  MOOG_XA_C0, MOOG_XA_C1, MOOG_XA_C2, MOOG_XA_OPACITY, MOOG_XA_SCALE, MOOG_XA_ASPECT
+};
 
 typedef struct {
   int32_t op;
@@ -217,11 +242,16 @@ enum {
   MOOG_RULE_TIMED,                 /* timing.py:46-59 TimedRule / DelayedRule /
                                       TemporaryRule: p0 start, p1 stop (inf allowed);
                                       steps its children while start <= 0 < stop  */
-  MOOG_RULE_CONDITIONAL            /* conditional.py:60-63: steps its children
+  MOOG_RULE_CONDITIONAL,           /* conditional.py:60-63: steps its children
                                       cond(state) times                           */
+  MOOG_RULE_MODIFY_SPRITES,        /* modify_sprites.py:35-52: layers[], filter,
+                                      i0 = sample_one, modifier = expression xmod  */
+  MOOG_RULE_MODIFY_ON_CONTACT      /* contact_rules.py:112-141: layers[] x layers1[];
+                                      xmod / filter for side 0, xmod1 / filter1 for
+                                      side 1 (xmod < 0: no modifier on that side)  */
 };
-/* sprite filters of VANISH_BY_FILTER / CHANGE_LAYER */
-enum { MOOG_FILTER_ALWAYS = 0 };
+/* sprite filters: ALWAYS, or the expression at rule.xfilter */
+enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };
 /* conditions of CONDITIONAL */
 enum { MOOG_RCOND_BERNOULLI = 1 /* np.random.binomial(1, p0): one uniform u, value u < p0 */ };
 
@@ -238,6 +268,13 @@ typedef struct {
   int32_t filter;      /* MOOG_FILTER_*                                           */
   int32_t cond;        /* MOOG_RCOND_*                                            */
   int32_t op;          /* CREATE_SPRITES: index of the runtime op in program.ops  */
+  int32_t xfilter;     /* filter == EXPR: expression offset in program.dcode      */
+  int32_t xmod;        /* MODIFY_*: modifier code (X_STORE ...), or -1            */
+  int32_t filter1, xfilter1, xmod1;   /* MODIFY_ON_CONTACT, side 1                */
+  int32_t i0;          /* MODIFY_SPRITES: sample_one; velocity assigned as a whole
+                        * by xmod (bit 1) / xmod1 (bit 2)                          */
+  int32_t n_layers1;
+  int32_t layers1[MOOG_MAX_LAYERS];
   double p0, p1, p2;
 } moog_rule_t;
 
@@ -259,6 +296,9 @@ typedef struct {
   int32_t layers1[MOOG_MAX_LAYERS];
   int32_t cond, cond_layer;
   int32_t i0;
+  int32_t xcond;       /* CONTACT_REWARD: pair condition(s0, s1) expression, or -1
+                        * (contact_reward.py:52-58)                               */
+  int32_t xreward;     /* CONTACT_REWARD: reward_fn(s0, s1) expression, or -1 (p0) */
   int32_t pad_;
   double cond_value;
   double p0, p1;
@@ -307,6 +347,9 @@ typedef struct {
   int32_t slot_vcap[MOOG_MAX_SLOTS];
 
   int32_t updates_per_env_step;    /* K, physics.py:15                         */
+  int32_t sprite_factors;          /* some expression reads scale / aspect_ratio or the
+                                    * float32-ness of mass / colours: the records carry
+                                    * o_scale, o_aspect, o_fmask                       */
   int32_t vel_alias;               /* some Tether has update_angle_vel=False: its
                                     * sprites share ONE velocity ndarray afterwards
                                     * (tether_physics.py:90), tracked in o_valias  */
@@ -354,6 +397,9 @@ typedef struct {
   int32_t o_action;   /* [2]      action-space memory (_action)                */
   int32_t o_task;     /* [T]      per-task _steps_until_reset (inf sentinel)   */
   int32_t o_rule;     /* [R]      per-rule scalar (Booster countdown)          */
+  int32_t o_scale;    /* [S] sprite.scale, [S] sprite.aspect_ratio at o_aspect; -1 when
+                       *     program.sprite_factors == 0                              */
+  int32_t o_aspect;
   int32_t o_verts;    /* [TOTV][2] world vertices (sprite.vertices)            */
   /* i32 record */
   int32_t o_flags;    /* [S] MOOG_F_*                                          */
@@ -361,6 +407,9 @@ typedef struct {
   int32_t o_opacity;  /* [S]                                                   */
   int32_t o_shape;    /* [S] shape-table id                                    */
   int32_t o_tele;     /* [S] bit r set: slot is in rule r's _currently_teleporting */
+  int32_t o_fmask;    /* [S] bit MOOG_FAC_* set: that factor currently holds a float32
+                       *     sample (numpy scalar promotion in expressions); -1 when
+                       *     program.sprite_factors == 0                              */
   int32_t o_valias;   /* [S] 0, or 1 + id of the group of slots whose velocity is one
                        *     shared ndarray in the reference; -1 when the program has
                        *     no such tether (vel_alias == 0)                          */
@@ -386,6 +435,8 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_action = o; o += 2;
   L->o_task = o; o += p->n_tasks;
   L->o_rule = o; o += p->n_rules;
+  if (p->sprite_factors) { L->o_scale = o; o += S; L->o_aspect = o; o += S; }
+  else { L->o_scale = -1; L->o_aspect = -1; }
   o = moog_align_(o, 2);
   L->o_verts = o; o += 2 * p->n_total_verts;
   L->f64_per_env = moog_align_(o, 2);          /* 16-byte multiple */
@@ -396,6 +447,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_shape = o; o += S;
   L->o_tele = o; o += S;
   if (p->vel_alias) { L->o_valias = o; o += S; } else L->o_valias = -1;
+  if (p->sprite_factors) { L->o_fmask = o; o += S; } else L->o_fmask = -1;
   L->o_step_count = o; o += 1;
   L->o_reset_next = o; o += 1;
   L->o_fault = o; o += 1;

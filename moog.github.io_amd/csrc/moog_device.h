@@ -25,6 +25,7 @@
 typedef const MOOG_CONST moog_program_t* PProg;
 typedef const MOOG_CONST moog_force_t* PForce;
 typedef const MOOG_CONST moog_corrective_t* PCorr;
+typedef const MOOG_CONST moog_dinstr_t* PDinstr;
 typedef const MOOG_CONST moog_rule_t* PRule;
 typedef const MOOG_CONST moog_task_t* PTask;
 typedef const MOOG_CONST moog_action_t* PAction;
@@ -54,6 +55,7 @@ struct Env {
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   uint8_t* vsl;            // LDS copy of vslot [TOTV]
+  unsigned cur_fmask;      // float32 factors of the sprite being created
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -79,6 +81,9 @@ struct Env {
 #define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
 #define VALIAS(s) (e.q[e.L.o_valias + (s)])
+#define SCALE(s) (e.f[e.L.o_scale + (s)])
+#define ASPECT(s) (e.f[e.L.o_aspect + (s)])
+#define FMASK(s) (e.q[e.L.o_fmask + (s)])
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -1279,6 +1284,173 @@ __device__ inline double np_remainder1(double a) {
   return m;
 }
 
+// ---- sprite expressions (MOOG_X_*): config callables traced at build time by
+//      moog/_symbolic.py, evaluated wave-uniformly with numpy 2 scalar promotion.  The value
+//      stack (16 doubles) and the pending attribute writes (13 doubles) live in the LDS words
+//      of the collision candidate list, which is idle outside apply_physics.
+struct XStores { unsigned mask; unsigned tags; };   // tags: 2 bits per attribute
+
+__device__ inline double xattr(Env& e, int s, int a, int& tag) {
+  const bool has = e.P->sprite_factors != 0;
+  const int fm = has ? FMASK(s) : 0;
+  const int fl = FLAGS(s);
+  switch (a) {
+    case MOOG_XA_X: tag = 2; return PX(s);
+    case MOOG_XA_Y: tag = 2; return PY(s);
+    case MOOG_XA_XVEL: tag = (fl & MOOG_F_VEL_F32) ? 1 : 2; return VELX(s);
+    case MOOG_XA_YVEL: tag = (fl & MOOG_F_VEL_F32) ? 1 : 2; return VELY(s);
+    case MOOG_XA_ANGLE: tag = ((fm >> MOOG_FAC_ANGLE) & 1) ? 1 : 2; return ANG(s);
+    case MOOG_XA_ANGVEL: tag = (fl & MOOG_F_ANGVEL_F32) ? 1 : 2; return ANGV(s);
+    case MOOG_XA_MASS: tag = (fm >> MOOG_FAC_MASS) & 1; return MASS(s);
+    case MOOG_XA_C0: tag = (fm >> MOOG_FAC_C0) & 1; return COL(s, 0);
+    case MOOG_XA_C1: tag = (fm >> MOOG_FAC_C1) & 1; return COL(s, 1);
+    case MOOG_XA_C2: tag = (fm >> MOOG_FAC_C2) & 1; return COL(s, 2);
+    case MOOG_XA_OPACITY: tag = 0; return (double)OPAC(s);
+    case MOOG_XA_SCALE: tag = (fm >> MOOG_FAC_SCALE) & 1; return has ? SCALE(s) : __builtin_nan("");
+    case MOOG_XA_ASPECT: tag = (fm >> MOOG_FAC_ASPECT) & 1; return has ? ASPECT(s) : __builtin_nan("");
+    default: tag = 0; return __builtin_nan("");
+  }
+}
+
+__device__ inline double np_rem(double a, double b) {   // numpy remainder (npy_divmod)
+  double mod = fmod(a, b);
+  if (b == 0) return mod;
+  if (mod != 0) { if ((b < 0) != (mod < 0)) mod += b; }
+  else mod = copysign(0.0, b);
+  return mod;
+}
+__device__ inline float np_remf(float a, float b) {
+  float mod = fmodf(a, b);
+  if (b == 0) return mod;
+  if (mod != 0) { if ((b < 0) != (mod < 0)) mod += b; }
+  else mod = copysignf(0.0f, b);
+  return mod;
+}
+
+__device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
+  PProg P = e.P;
+  double* v = reinterpret_cast<double*>(e.cand);          // [MOOG_X_STACK]
+  double* sv = v + MOOG_X_STACK;                           // pending writes [13]
+  unsigned tags = 0;                                       // 2 bits per stack entry
+  int n = 0;
+  wsync();
+#define XTAG(i) ((int)((tags >> (2 * (i))) & 3u))
+#define XSETTAG(i, t) tags = (tags & ~(3u << (2 * (i)))) | ((unsigned)(t) << (2 * (i)))
+  for (int pc = off;; ++pc) {
+    PDinstr I = &P->dcode[pc];
+    const int op = I->op;
+    if (op == MOOG_X_END) break;
+    if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
+    if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
+    if (op == MOOG_X_STORE) {
+      --n;
+      st->mask |= 1u << I->a;
+      st->tags = (st->tags & ~(3u << (2 * I->a))) | ((unsigned)XTAG(n) << (2 * I->a));
+      sv[I->a] = v[n];
+      continue;
+    }
+    if (op == MOOG_X_SELECT) {
+      n -= 2;
+      const bool c = v[n - 1] != 0;
+      const int t = c ? XTAG(n) : XTAG(n + 1);
+      v[n - 1] = c ? v[n] : v[n + 1];
+      XSETTAG(n - 1, t);
+      continue;
+    }
+    if (op >= MOOG_X_NEG && op <= MOOG_X_SIGN) {
+      const double a = v[n - 1];
+      const bool f32 = XTAG(n - 1) == 1;
+      double r = a;
+      switch (op) {
+        case MOOG_X_NEG: r = -a; break;
+        case MOOG_X_ABS: r = fabs(a); break;
+        case MOOG_X_SQRT: r = f32 ? (double)sqrtf((float)a) : sqrt(a); break;
+        case MOOG_X_SIN: r = f32 ? (double)(float)sin(a) : sin(a); break;
+        case MOOG_X_COS: r = f32 ? (double)(float)cos(a) : cos(a); break;
+        case MOOG_X_FLOOR: r = floor(a); break;
+        case MOOG_X_NOT: r = (a != 0) ? 0.0 : 1.0; XSETTAG(n - 1, 0); break;
+        case MOOG_X_SIGN: r = (a > 0) ? 1.0 : ((a < 0) ? -1.0 : a); break;
+        default: break;
+      }
+      v[n - 1] = r;
+      continue;
+    }
+    --n;
+    const double a = v[n - 1], b = v[n];
+    const int ta = XTAG(n - 1), tb = XTAG(n);
+    const bool f32 = (ta == 1 || tb == 1) && ta != 2 && tb != 2;
+    int rt = (ta == 2 || tb == 2) ? 2 : ((ta == 1 || tb == 1) ? 1 : 0);
+    const float af = (float)a, bf = (float)b;
+    double r = 0;
+    switch (op) {
+      case MOOG_X_ADD: r = f32 ? (double)(af + bf) : a + b; break;
+      case MOOG_X_SUB: r = f32 ? (double)(af - bf) : a - b; break;
+      case MOOG_X_MUL: r = f32 ? (double)(af * bf) : a * b; break;
+      case MOOG_X_DIV: r = f32 ? (double)(af / bf) : a / b; break;
+      case MOOG_X_REM: r = f32 ? (double)np_remf(af, bf) : np_rem(a, b); break;
+      case MOOG_X_MIN: r = f32 ? (double)((af < bf || isnan(af)) ? af : bf) : ((a < b || isnan(a)) ? a : b); break;
+      case MOOG_X_MAX: r = f32 ? (double)((af > bf || isnan(af)) ? af : bf) : ((a > b || isnan(a)) ? a : b); break;
+      case MOOG_X_LT: r = f32 ? (af < bf) : (a < b); rt = 0; break;
+      case MOOG_X_LE: r = f32 ? (af <= bf) : (a <= b); rt = 0; break;
+      case MOOG_X_GT: r = f32 ? (af > bf) : (a > b); rt = 0; break;
+      case MOOG_X_GE: r = f32 ? (af >= bf) : (a >= b); rt = 0; break;
+      case MOOG_X_EQ: r = f32 ? (af == bf) : (a == b); rt = 0; break;
+      case MOOG_X_NE: r = f32 ? (af != bf) : (a != b); rt = 0; break;
+      case MOOG_X_AND: r = (a != 0) && (b != 0); rt = 0; break;
+      case MOOG_X_OR: r = (a != 0) || (b != 0); rt = 0; break;
+      default: break;
+    }
+    v[n - 1] = r;
+    XSETTAG(n - 1, rt);
+  }
+  const double top = n > 0 ? v[n - 1] : 0.0;
+  if (out_tag) *out_tag = n > 0 ? XTAG(n - 1) : 0;
+#undef XTAG
+#undef XSETTAG
+  wsync();
+  return top;
+}
+
+// the attribute writes of a modifier (sprite.py setters :540-664)
+__device__ inline void run_modifier(Env& e, int xmod, int s) {
+  XStores st = {0u, 0u};
+  eval_expr(e, xmod, s, s, nullptr, &st);
+  const double* sv = reinterpret_cast<const double*>(e.cand) + MOOG_X_STACK;
+  auto tag = [&](int a) { return (int)((st.tags >> (2 * a)) & 3u); };
+  auto has = [&](int a) { return ((st.mask >> a) & 1u) != 0; };
+  const double vx = sv[MOOG_XA_XVEL], vy = sv[MOOG_XA_YVEL], w = sv[MOOG_XA_ANGVEL];
+  const double m = sv[MOOG_XA_MASS], c0 = sv[MOOG_XA_C0], c1 = sv[MOOG_XA_C1], c2 = sv[MOOG_XA_C2];
+  const double op = sv[MOOG_XA_OPACITY];
+  const double nx = has(MOOG_XA_X) ? sv[MOOG_XA_X] : PX(s), ny = has(MOOG_XA_Y) ? sv[MOOG_XA_Y] : PY(s);
+  wsync();
+  if (has(MOOG_XA_X) || has(MOOG_XA_Y)) set_position(e, s, nx, ny);
+  wsync();
+  if (e.lane == 0) {
+    const bool sf = e.P->sprite_factors != 0;
+    int fl = FLAGS(s);
+    if (has(MOOG_XA_XVEL) || has(MOOG_XA_YVEL)) {   // a fresh ndarray
+      VELX(s) = vx; VELY(s) = vy;
+      fl &= ~MOOG_F_VEL_F32;
+      if (tag(MOOG_XA_XVEL) == 1 && tag(MOOG_XA_YVEL) == 1) fl |= MOOG_F_VEL_F32;
+      vel_unshare(e, s);
+    }
+    if (has(MOOG_XA_ANGVEL)) {
+      ANGV(s) = w;
+      fl &= ~MOOG_F_ANGVEL_F32;
+      if (tag(MOOG_XA_ANGVEL) == 1) fl |= MOOG_F_ANGVEL_F32;
+    }
+    FLAGS(s) = fl;
+    int fm = sf ? FMASK(s) : 0;
+    if (has(MOOG_XA_MASS)) { MASS(s) = m; fm = (fm & ~(1 << MOOG_FAC_MASS)) | ((tag(MOOG_XA_MASS) == 1) << MOOG_FAC_MASS); }
+    if (has(MOOG_XA_C0)) { COL(s, 0) = c0; fm = (fm & ~(1 << MOOG_FAC_C0)) | ((tag(MOOG_XA_C0) == 1) << MOOG_FAC_C0); }
+    if (has(MOOG_XA_C1)) { COL(s, 1) = c1; fm = (fm & ~(1 << MOOG_FAC_C1)) | ((tag(MOOG_XA_C1) == 1) << MOOG_FAC_C1); }
+    if (has(MOOG_XA_C2)) { COL(s, 2) = c2; fm = (fm & ~(1 << MOOG_FAC_C2)) | ((tag(MOOG_XA_C2) == 1) << MOOG_FAC_C2); }
+    if (sf) FMASK(s) = fm;
+    if (has(MOOG_XA_OPACITY)) OPAC(s) = (int32_t)op;
+  }
+  wsync();
+}
+
 // ---- layers that rules append to / pop from (CreateSprites, ChangeLayer): the reference's
 //      Python lists.  Live sprites stay packed at the front of the layer's slots, in list order.
 __device__ inline void move_slot(Env& e, int dst, int src) {
@@ -1300,6 +1472,7 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
     FLAGS(dst) = FLAGS(src); NV(dst) = NV(src); OPAC(dst) = OPAC(src); SHAPEID(dst) = SHAPEID(src);
     TELE(dst) = TELE(src);
     if (e.P->vel_alias) VALIAS(dst) = VALIAS(src);
+    if (e.P->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
     FLAGS(src) = 0; NV(src) = 0;
   }
   wsync();
@@ -1330,9 +1503,12 @@ __device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the
   return P->layer_slot0[l] + n;
 }
 
+__device__ inline bool sprite_filter_x(Env& e, int kind, int xoff, int s) {
+  if (kind == MOOG_FILTER_ALWAYS) return true;
+  return eval_expr(e, xoff, s, s, nullptr, nullptr) != 0;
+}
 __device__ inline bool sprite_filter(Env& e, PRule R, int s) {
-  (void)e; (void)s;
-  return R->filter == MOOG_FILTER_ALWAYS;
+  return sprite_filter_x(e, R->filter, R->xfilter, s);
 }
 
 __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32);
@@ -1348,19 +1524,23 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
   if constexpr (DYN) {
     if (R->kind == MOOG_RULE_VANISH_BY_FILTER) {   // vanish.py:31-39,58-61
       const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
-      wsync();
-      for (int s = a0 + e.lane; s < a1; s += 64)
-        if (ALIVE(s) && sprite_filter(e, R, s)) FLAGS(s) &= ~MOOG_F_ALIVE;
-      wsync();
+      for (int s = a0; s < a1; ++s) {
+        if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
+        wsync();
+        if (e.lane == 0) FLAGS(s) &= ~MOOG_F_ALIVE;
+        wsync();
+      }
       layer_compact(e, R->l0);
       return;
     }
     if (R->kind == MOOG_RULE_CHANGE_LAYER) {       // change_layer.py:36-46
       const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
-      wsync();
-      for (int s = a0 + e.lane; s < a1; s += 64)
-        if (ALIVE(s) && sprite_filter(e, R, s)) FLAGS(s) |= MOOG_F_TMP;
-      wsync();
+      for (int s = a0; s < a1; ++s) {
+        if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
+        wsync();
+        if (e.lane == 0) FLAGS(s) |= MOOG_F_TMP;
+        wsync();
+      }
       for (int s = a0; s < a1; ++s) {
         if (!(FLAGS(s) & MOOG_F_TMP)) continue;
         int dst = layer_append_slot(e, R->l1);
@@ -1371,6 +1551,61 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         move_slot(e, dst, s);
       }
       layer_compact(e, R->l0);
+      return;
+    }
+    if (R->kind == MOOG_RULE_MODIFY_SPRITES) {     // modify_sprites.py:35-52
+      // the sprites passing the filter are marked first (filters see the unmodified state)
+      int n = 0;
+      for (int a = 0; a < R->n_layers; ++a) {
+        const int l = R->layers[a];
+        for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) {
+          if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
+          wsync();
+          if (e.lane == 0) FLAGS(s) |= MOOG_F_TMP;
+          wsync();
+          ++n;
+        }
+      }
+      if (n == 0) return;
+      int pick = -1;
+      if (R->i0 & 1) {   // sample_one: np.random.choice(sprites_to_modify)
+        pick = 0;
+        if (n > 1) { pick = (int)(next_uniform(e) * n); if (pick >= n) pick = n - 1; }
+      }
+      int k = 0;
+      for (int a = 0; a < R->n_layers; ++a) {
+        const int l = R->layers[a];
+        for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) {
+          if (!(FLAGS(s) & MOOG_F_TMP)) continue;
+          wsync();
+          if (e.lane == 0) FLAGS(s) &= ~MOOG_F_TMP;
+          wsync();
+          if (pick < 0 || k == pick) run_modifier(e, R->xmod, s);
+          ++k;
+        }
+      }
+      return;
+    }
+    if (R->kind == MOOG_RULE_MODIFY_ON_CONTACT) {  // contact_rules.py:112-141
+      for (int side = 0; side < 2; ++side) {
+        const int xmod = side ? R->xmod1 : R->xmod;
+        if (xmod < 0) continue;
+        const int na = side ? R->n_layers1 : R->n_layers, nb = side ? R->n_layers : R->n_layers1;
+        for (int a = 0; a < na; ++a) {
+          const int la = side ? R->layers1[a] : R->layers[a];
+          for (int s = P->layer_slot0[la]; s < P->layer_slot0[la] + P->layer_nslots[la]; ++s) {
+            if (!ALIVE(s)) continue;
+            if (!sprite_filter_x(e, side ? R->filter1 : R->filter, side ? R->xfilter1 : R->xfilter, s)) continue;
+            bool any = false;
+            for (int b = 0; b < nb; ++b) {
+              const int lb = side ? R->layers[b] : R->layers1[b];
+              for (int t = P->layer_slot0[lb]; t < P->layer_slot0[lb] + P->layer_nslots[lb]; ++t)
+                if (t != s && ALIVE(t) && overlaps(e, s, t)) any = true;
+            }
+            if (any) run_modifier(e, xmod, s);
+          }
+        }
+      }
       return;
     }
     if (R->kind == MOOG_RULE_CREATE_SPRITES) {     // create_sprites.py:31-37 + sprite_generators.py:77-105
@@ -1594,15 +1829,17 @@ __device__ inline bool task_condition(const Env& e, PTask T) {
   return false;
 }
 
+template <bool DYN>
 __device__ inline double task_reward(Env& e, int step_count, int* should_reset) {
   PProg P = e.P;
   double reward = 0;
+  int reward_t = 0;   // numpy dtype tag of the running sum (composite_task.py:36-40)
   int sr = ((double)step_count >= P->timeout_steps);
   for (int ti = 0; ti < P->n_tasks; ++ti) {
     PTask T = &P->tasks[ti];
     double cnt = e.f[e.L.o_task + ti];
     double r = 0;
-    int tsr = 0;
+    int tsr = 0, rt = 0;
     if (T->kind == MOOG_TASK_CONTACT_REWARD) {
       for (int a = 0; a < T->n0; ++a) {
         int la = T->layers0[a];
@@ -1614,8 +1851,14 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
             int b0 = P->layer_slot0[lb], b1 = b0 + P->layer_nslots[lb];
             for (int s1 = b0; s1 < b1; ++s1) {
               if (!ALIVE(s1)) continue;
+              if constexpr (DYN) {
+                if (T->xcond >= 0 && eval_expr(e, T->xcond, s0, s1, nullptr, nullptr) == 0) continue;
+              }
               if (overlaps(e, s0, s1)) {
-                r = T->p0;
+                r = T->p0; rt = 0;
+                if constexpr (DYN) {
+                  if (T->xreward >= 0) r = eval_expr(e, T->xreward, s0, s1, &rt, nullptr);
+                }
                 if (cnt == DINF) cnt = T->p1;
               }
             }
@@ -1635,7 +1878,9 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
     wsync();
     if (e.lane == 0) e.f[e.L.o_task + ti] = cnt;
     wsync();
-    reward += r;
+    if (reward_t == 2 || rt == 2) { reward = reward + r; reward_t = 2; }
+    else if (reward_t == 1 || rt == 1) { reward = (double)((float)reward + (float)r); reward_t = 1; }
+    else reward = reward + r;
     sr = sr || tsr;
   }
   *should_reset = sr;
@@ -1726,6 +1971,11 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     if (vel_f32) fl |= MOOG_F_VEL_F32;
     if (angvel_f32) fl |= MOOG_F_ANGVEL_F32;
     FLAGS(s) = fl;
+    if (P->sprite_factors) {   // sprite.py:307-316: angle / scale / aspect are float()-ed
+      SCALE(s) = scale; ASPECT(s) = aspect;
+      FMASK(s) = (int32_t)(e.cur_fmask & ((1u << MOOG_FAC_C0) | (1u << MOOG_FAC_C1) | (1u << MOOG_FAC_C2) |
+                                          (1u << MOOG_FAC_MASS)));
+    }
   }
   wsync();
   set_position(e, s, x + sh->centroid[0], y + sh->centroid[1]);
@@ -1758,7 +2008,6 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
 //      Discrete(probs) sampling in the reference's draw order (distributions.py:159-405).
 //      Wave-uniform: every lane runs the same program on the same uniforms; `fac` stays in
 //      registers (static indexing through select chains).
-typedef const MOOG_CONST moog_dinstr_t* PDinstr;
 
 __device__ inline double fac_get(const double* fac, int a) {
   double v = 0;
@@ -1878,13 +2127,16 @@ __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& ve
   vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
   angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
   sample_factors(e, op, fac);
+  unsigned m = 0;
+  for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
+    if (op->factors[k].kind == MOOG_DIST_CONTINUOUS && op->factors[k].f32) m |= 1u << k;
   if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
-    unsigned m = 0;
     run_dist_program(e, op->code_off, fac, m);
     const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
     vel_f32 = (m & vb) == vb;
     angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
   }
+  e.cur_fmask = m;
 }
 
 __device__ inline void run_genop(Env& e, int oi) {

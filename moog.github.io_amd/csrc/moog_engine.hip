@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   if (e.lane == 0) e.q[e.L.o_step_count] = sc;
   wsync();
   int sr = 0;
-  double r = task_reward(e, sc, &sr);
+  double r = task_reward<DYN>(e, sc, &sr);
   wsync();
   if (e.lane == 0) {
     if (sr) e.q[e.L.o_reset_next] = 1;
@@ -310,9 +310,13 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
   for (int r = 0; r < prog->n_rules; ++r) {
     int k = prog->rules[r].kind;
-    if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES)
+    if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES ||
+        k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT)
       e->dynamic_rules = true;
   }
+  for (int t = 0; t < prog->n_tasks; ++t)
+    if (prog->tasks[t].kind == MOOG_TASK_CONTACT_REWARD && (prog->tasks[t].xcond >= 0 || prog->tasks[t].xreward >= 0))
+      e->dynamic_rules = true;
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_reset_kernel),

@@ -12,6 +12,7 @@ import numpy as np
 
 from . import _abi
 from . import _distcode
+from . import _symbolic
 from . import _trace
 from . import action_spaces
 from . import game_rules as rules_lib
@@ -397,6 +398,29 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # ---- game rules ---------------------------------------------------------------
     if len(flat_rules) > _abi.MOOG_MAX_RULES:
         raise ValueError('too many game rules')
+
+    def put_expr(node=None, stores=None):
+        """Appends postfix expression code (plus X_END) to program.dcode; returns its offset."""
+        code = []
+        if node is not None:
+            _symbolic.emit(node, code)
+        for attr, n in (stores or {}).items():
+            _symbolic.emit(n, code)
+            code.append(dict(op=_abi.MOOG_X_STORE, a=_symbolic.ATTRS.index(attr)))
+        if _symbolic.depth(code) > _abi.MOOG_X_STACK:
+            raise NotImplementedError('expression too deep for the device evaluator')
+        if _symbolic.uses_attr(code, ('scale', 'aspect_ratio', 'mass', 'c0', 'c1', 'c2')):
+            P.sprite_factors = 1
+        code.append(dict(op=_abi.MOOG_X_END))
+        base = P.n_dcode
+        if base + len(code) > _abi.MOOG_MAX_DCODE:
+            raise ValueError('expression / distribution code too long')
+        for i, ins in enumerate(code):
+            I = P.dcode[base + i]
+            I.op, I.a, I.b, I.x = ins['op'], ins.get('a', 0), ins.get('b', 0), ins.get('x', 0.0)
+        P.n_dcode = base + len(code)
+        return base
+
     for ri, (r, parent) in enumerate(flat_rules):
         R = P.rules[ri]
         R.parent = parent
@@ -407,11 +431,34 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         elif isinstance(r, rules_lib.VanishByFilter):
             R.kind = _abi.MOOG_RULE_VANISH_BY_FILTER
             R.l0 = layer_index(r._layer)
-            R.filter = rules_lib._classify_filter(r._filter_fn)
+            R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
+            if fnode is not None:
+                R.xfilter = put_expr(fnode)
         elif isinstance(r, rules_lib.ChangeLayer):
             R.kind = _abi.MOOG_RULE_CHANGE_LAYER
             R.l0, R.l1 = layer_index(r._old_layer), layer_index(r._new_layer)
-            R.filter = rules_lib._classify_filter(r._filter_fn)
+            R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
+            if fnode is not None:
+                R.xfilter = put_expr(fnode)
+        elif isinstance(r, rules_lib.ModifyOnContact):
+            R.kind = _abi.MOOG_RULE_MODIFY_ON_CONTACT
+            R.n_layers = _fill_layers(R.layers, list(r._layers_0), layer_index)
+            R.n_layers1 = _fill_layers(R.layers1, list(r._layers_1), layer_index)
+            R.xmod = R.xmod1 = -1
+            R.filter, fnode = rules_lib._classify_filter(r._filter_0)
+            if fnode is not None:
+                R.xfilter = put_expr(fnode)
+            R.filter1, fnode = rules_lib._classify_filter(r._filter_1)
+            if fnode is not None:
+                R.xfilter1 = put_expr(fnode)
+            if r._modifier_0 is not None:
+                mod, vec = _symbolic.trace_modifier(r._modifier_0)
+                R.xmod = put_expr(stores=mod)
+                R.i0 |= 2 if vec else 0
+            if r._modifier_1 is not None:
+                mod, vec = _symbolic.trace_modifier(r._modifier_1)
+                R.xmod1 = put_expr(stores=mod)
+                R.i0 |= 4 if vec else 0
         elif isinstance(r, rules_lib.CreateSprites):
             R.kind = _abi.MOOG_RULE_CREATE_SPRITES
             R.l0 = layer_index(r._layer)
@@ -424,8 +471,13 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.kind = _abi.MOOG_RULE_CONDITIONAL
             R.cond, R.p0 = r.classify()
         elif isinstance(r, rules_lib.ModifySprites):
-            R.kind = r.classify()
+            R.kind, R.filter, fnode, mod, vec = r.classify()
             R.n_layers = _fill_layers(R.layers, r._layers, layer_index)
+            if fnode is not None:
+                R.xfilter = put_expr(fnode)
+            if mod is not None:
+                R.xmod = put_expr(stores=mod)
+                R.i0 = int(bool(r._sample_one)) | (2 if vec else 0)
         elif isinstance(r, rules_lib.Portal):
             R.kind = _abi.MOOG_RULE_PORTAL
             R.l0, R.l1 = layer_index(r._teleporting_layer), layer_index(r._portal_layer)
@@ -452,7 +504,14 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             T.kind = _abi.MOOG_TASK_CONTACT_REWARD
             T.n0 = _fill_layers(T.layers0, t._layers_0, layer_index)
             T.n1 = _fill_layers(T.layers1, t._layers_1, layer_index)
-            T.p0, T.p1 = float(t._reward), float(t._reset_steps_after_contact)
+            T.p1 = float(t._reset_steps_after_contact)
+            T.xcond = T.xreward = -1
+            if callable(t._reward):
+                T.xreward = put_expr(_symbolic.trace_value(t._reward, 2))
+            else:
+                T.p0 = float(t._reward)
+            if t._condition is not None:
+                T.xcond = put_expr(_symbolic.trace_value(t._condition, 2))
         elif isinstance(t, tasks_lib.Reset):
             T.kind = _abi.MOOG_TASK_RESET
             cond, lname, val = t.classify(layer_names)

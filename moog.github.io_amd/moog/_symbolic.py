@@ -1,0 +1,419 @@
+"""Symbolic execution of the small Python callables configs pass around: sprite filters
+(`sprite -> bool`), modifiers (`sprite -> None`, assigning attributes), pair conditions and
+reward functions (`(sprite_0, sprite_1) -> bool / number`).
+
+The reference calls these lambdas on live `Sprite` objects every step (e.g.
+game_rules/modify_sprites.py:41-52, vanish.py:58-61, tasks/contact_reward.py:85-92).  The
+engine instead runs each callable once at build time on *symbolic* sprites whose attributes
+are expression nodes; arithmetic, comparisons and numpy ufuncs build an expression tree,
+and Python control flow (`if`, `and`, `or`, `any(...)`, which call `bool()` on a symbolic
+value) is handled by enumerating the execution paths: every `bool()` on a symbolic value
+is a decision that is explored both ways, and the per-path results are merged into
+`select(cond, a, b)` nodes.  The tree is then emitted as postfix code for the expression VM
+(include/moog_engine.h MOOG_X_*), which the oracle and the HIP engine both interpret.
+
+Scalar dtype semantics follow numpy 2 (NEP 50): Python scalars are weak, float32 samples
+stay float32 through arithmetic with weak scalars; the VM tracks that tag per value.
+"""
+import numpy as np
+
+from . import _abi
+
+MAX_PATHS = 256
+
+# attribute ids (MOOG_XA_*)
+ATTRS = ('x', 'y', 'x_vel', 'y_vel', 'angle', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity',
+         'scale', 'aspect_ratio')
+SETTABLE = ('x', 'y', 'x_vel', 'y_vel', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity')
+
+
+class Unsupported(NotImplementedError):
+    pass
+
+
+# ---- expression nodes ----------------------------------------------------------------------
+class Node(object):
+    """('const', value, strong) | ('attr', sprite, attr) | (op, *children)"""
+
+    def __init__(self, op, *args):
+        self.op, self.args = op, args
+
+    def key(self):
+        return (self.op,) + tuple(a.key() if isinstance(a, Node) else a for a in self.args)
+
+
+def const(v, strong=False):
+    return Node('const', float(v), bool(strong))
+
+
+def lift(v):
+    if isinstance(v, Sym):
+        return v.node
+    if isinstance(v, Node):
+        return v
+    if isinstance(v, (bool, np.bool_)):
+        return const(1.0 if v else 0.0)
+    if isinstance(v, (int, float)):
+        return const(v)
+    if isinstance(v, np.generic):          # numpy scalars are strong-typed
+        return const(float(v), strong=True)
+    if isinstance(v, np.ndarray) and v.ndim == 0:
+        return const(float(v), strong=True)
+    raise Unsupported('cannot use %r in a lowered expression' % (v,))
+
+
+_TRACER = None
+
+
+class Sym(object):
+    """A symbolic scalar."""
+    __array_priority__ = 1000
+
+    def __init__(self, node):
+        self.node = node
+
+    def _bin(self, op, other, swap=False):
+        a, b = self.node, lift(other)
+        if swap:
+            a, b = b, a
+        return Sym(Node(op, a, b))
+
+    __add__ = lambda s, o: s._bin('add', o)
+    __radd__ = lambda s, o: s._bin('add', o, True)
+    __sub__ = lambda s, o: s._bin('sub', o)
+    __rsub__ = lambda s, o: s._bin('sub', o, True)
+    __mul__ = lambda s, o: s._bin('mul', o)
+    __rmul__ = lambda s, o: s._bin('mul', o, True)
+    __truediv__ = lambda s, o: s._bin('div', o)
+    __rtruediv__ = lambda s, o: s._bin('div', o, True)
+    __mod__ = lambda s, o: s._bin('rem', o)
+    __lt__ = lambda s, o: s._bin('lt', o)
+    __le__ = lambda s, o: s._bin('le', o)
+    __gt__ = lambda s, o: s._bin('gt', o)
+    __ge__ = lambda s, o: s._bin('ge', o)
+    __eq__ = lambda s, o: s._bin('eq', o)
+    __ne__ = lambda s, o: s._bin('ne', o)
+    __and__ = lambda s, o: s._bin('and', o)
+    __rand__ = lambda s, o: s._bin('and', o, True)
+    __or__ = lambda s, o: s._bin('or', o)
+    __ror__ = lambda s, o: s._bin('or', o, True)
+    __neg__ = lambda s: Sym(Node('neg', s.node))
+    __abs__ = lambda s: Sym(Node('abs', s.node))
+    __invert__ = lambda s: Sym(Node('not', s.node))
+    __hash__ = None
+
+    def __bool__(self):
+        if self.node.op == 'const':
+            return self.node.args[0] != 0
+        return _TRACER.decide(self.node)
+
+    def __float__(self):
+        raise Unsupported('float() of a symbolic value')
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return _ufunc(ufunc, method, inputs, kwargs)
+
+
+_UFUNCS = {
+    'add': 'add', 'subtract': 'sub', 'multiply': 'mul', 'true_divide': 'div', 'divide': 'div',
+    'remainder': 'rem', 'mod': 'rem', 'minimum': 'min', 'maximum': 'max',
+    'less': 'lt', 'less_equal': 'le', 'greater': 'gt', 'greater_equal': 'ge',
+    'equal': 'eq', 'not_equal': 'ne', 'logical_and': 'and', 'logical_or': 'or',
+    'negative': 'neg', 'absolute': 'abs', 'fabs': 'abs', 'sqrt': 'sqrt', 'sin': 'sin', 'cos': 'cos',
+    'floor': 'floor', 'logical_not': 'not', 'square': 'square', 'sign': 'sign',
+}
+
+
+def _elems(v):
+    """Elements of a scalar-or-vector operand, and its length (None for scalars)."""
+    if isinstance(v, SymVec):
+        return list(v.items), len(v.items)
+    if isinstance(v, (list, tuple)) or (isinstance(v, np.ndarray) and v.ndim == 1):
+        return list(v), len(v)
+    return [v], None
+
+
+def _ufunc(ufunc, method, inputs, kwargs):
+    if method != '__call__' or kwargs.get('out') is not None:
+        raise Unsupported('numpy %s.%s on symbolic values' % (ufunc.__name__, method))
+    name = _UFUNCS.get(ufunc.__name__)
+    if name is None:
+        raise Unsupported('numpy.%s on symbolic values' % ufunc.__name__)
+    parts = [_elems(v) for v in inputs]
+    n = max([ln for _, ln in parts if ln is not None] or [None], key=lambda z: -1 if z is None else z)
+    out = []
+    for i in range(n or 1):
+        args = [lift(p[i] if ln is not None else p[0]) for p, ln in parts]
+        if name == 'square':
+            out.append(Sym(Node('mul', args[0], args[0])))
+        else:
+            out.append(Sym(Node(name, *args)))
+    return SymVec(out) if n else out[0]
+
+
+class SymVec(object):
+    """A symbolic 1-D array (position, velocity, or the result of elementwise ops)."""
+    __array_priority__ = 1000
+
+    def __init__(self, items):
+        self.items = [i if isinstance(i, Sym) else Sym(lift(i)) for i in items]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+    def _bin(self, fn, other):
+        o, ln = _elems(other)
+        if ln is not None and ln != len(self.items):
+            raise Unsupported('shape mismatch in a symbolic expression')
+        return SymVec([fn(a, o[i] if ln is not None else o[0]) for i, a in enumerate(self.items)])
+
+    __add__ = lambda s, o: s._bin(lambda a, b: a + b, o)
+    __radd__ = lambda s, o: s._bin(lambda a, b: b + a, o)
+    __sub__ = lambda s, o: s._bin(lambda a, b: a - b, o)
+    __rsub__ = lambda s, o: s._bin(lambda a, b: b - a, o)
+    __mul__ = lambda s, o: s._bin(lambda a, b: a * b, o)
+    __rmul__ = lambda s, o: s._bin(lambda a, b: b * a, o)
+    __truediv__ = lambda s, o: s._bin(lambda a, b: a / b, o)
+    __rtruediv__ = lambda s, o: s._bin(lambda a, b: b / a, o)
+    __mod__ = lambda s, o: s._bin(lambda a, b: a % b, o)
+    __lt__ = lambda s, o: s._bin(lambda a, b: a < b, o)
+    __le__ = lambda s, o: s._bin(lambda a, b: a <= b, o)
+    __gt__ = lambda s, o: s._bin(lambda a, b: a > b, o)
+    __ge__ = lambda s, o: s._bin(lambda a, b: a >= b, o)
+    __eq__ = lambda s, o: s._bin(lambda a, b: a == b, o)
+    __ne__ = lambda s, o: s._bin(lambda a, b: a != b, o)
+    __and__ = lambda s, o: s._bin(lambda a, b: a & b, o)
+    __or__ = lambda s, o: s._bin(lambda a, b: a | b, o)
+    __neg__ = lambda s: SymVec([-a for a in s.items])
+    __abs__ = lambda s: SymVec([abs(a) for a in s.items])
+    __hash__ = None
+
+    def __bool__(self):
+        raise ValueError('The truth value of an array with more than one element is ambiguous.')
+
+    def any(self):
+        r = self.items[0]
+        for a in self.items[1:]:
+            r = r | a
+        return r
+
+    def all(self):
+        r = self.items[0]
+        for a in self.items[1:]:
+            r = r & a
+        return r
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return _ufunc(ufunc, method, inputs, kwargs)
+
+    def __array_function__(self, func, types, args, kwargs):
+        name = getattr(func, '__name__', '')
+        if name == 'norm' and len(args) == 1 and not kwargs:     # np.linalg.norm: sqrt(dot(x, x))
+            acc = None
+            for a in args[0].items:
+                t = a * a
+                acc = t if acc is None else acc + t
+            return Sym(Node('sqrt', acc.node))
+        if name in ('any', 'all') and len(args) == 1 and not kwargs:
+            return getattr(args[0], name)()
+        if name == 'dot' and len(args) == 2:
+            a, la = _elems(args[0])
+            b, lb = _elems(args[1])
+            if la != lb or la is None:
+                raise Unsupported('np.dot shapes')
+            acc = None
+            for x, y in zip(a, b):
+                t = Sym(lift(x)) * Sym(lift(y))
+                acc = t if acc is None else acc + t
+            return acc
+        if name == 'copy' and len(args) == 1:
+            return SymVec(list(args[0].items))
+        if name == 'clip' and len(args) == 3:
+            return np.minimum(np.maximum(args[0], args[1]), args[2])
+        raise Unsupported('numpy.%s on symbolic values' % name)
+
+
+class SymSprite(object):
+    """A sprite whose factors are symbolic; attribute writes are recorded."""
+
+    def __init__(self, index):
+        object.__setattr__(self, '_index', index)
+        object.__setattr__(self, '_written', {})
+
+    def _get(self, name):
+        w = self._written
+        return w[name] if name in w else Sym(Node('attr', self._index, name))
+
+    def __getattr__(self, name):
+        if name == 'position':
+            return SymVec([self._get('x'), self._get('y')])
+        if name == 'velocity':
+            return SymVec([self._get('x_vel'), self._get('y_vel')])
+        if name == 'color':
+            return (self._get('c0'), self._get('c1'), self._get('c2'))
+        if name in ATTRS:
+            return self._get(name)
+        raise Unsupported('sprite.%s is not available to lowered functions' % name)
+
+    def __setattr__(self, name, value):
+        if name == 'position' or name == 'velocity':
+            v, ln = _elems(value)
+            if ln != 2:
+                raise Unsupported('sprite.%s must be set to a length-2 value' % name)
+            ks = ('x', 'y') if name == 'position' else ('x_vel', 'y_vel')
+            for k, e in zip(ks, v):
+                self._written[k] = Sym(lift(e))
+            self._written['__vec_' + name] = True
+            return
+        if name not in SETTABLE:
+            raise Unsupported('assigning sprite.%s is not lowered' % name)
+        self._written[name] = Sym(lift(value))
+
+
+class _Tracer(object):
+    def __init__(self):
+        self.forced = []
+        self.trail = []
+
+    def decide(self, node):
+        i = len(self.trail)
+        v = self.forced[i] if i < len(self.forced) else True
+        self.trail.append((node, v))
+        return v
+
+
+def _explore(fn, n_sprites):
+    """Runs fn on symbolic sprites along every execution path.  Returns a list of
+    (decisions [(node, bool)], return value, [written dicts])."""
+    global _TRACER
+    paths = []
+    forced = []
+    while True:
+        tr = _Tracer()
+        tr.forced = list(forced)
+        sprites = [SymSprite(i) for i in range(n_sprites)]
+        prev, _TRACER = _TRACER, tr
+        try:
+            ret = fn(*sprites)
+        finally:
+            _TRACER = prev
+        paths.append((list(tr.trail), ret, [dict(s._written) for s in sprites]))
+        if len(paths) > MAX_PATHS:
+            raise Unsupported('too many execution paths in a lowered function')
+        # next path: flip the last decision that was taken as True
+        trail = tr.trail
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            return paths
+        forced = [v for _, v in trail[:k]] + [False]
+
+
+def _merge(paths, leaf):
+    """select-tree over the decision trail; `leaf(path)` gives the node at a path's end."""
+    def build(group, depth):
+        if len(group) == 1 and len(group[0][0]) <= depth:
+            return leaf(group[0])
+        cond = group[0][0][depth][0]
+        t = [p for p in group if p[0][depth][1]]
+        f = [p for p in group if not p[0][depth][1]]
+        if not t or not f:
+            return build(t or f, depth + 1)
+        a, b = build(t, depth + 1), build(f, depth + 1)
+        if a.key() == b.key():
+            return a
+        return Node('select', cond, a, b)
+    return build(paths, 0)
+
+
+def trace_value(fn, n_sprites):
+    """Expression of `fn(*sprites)`'s return value (bool or number)."""
+    paths = _explore(fn, n_sprites)
+
+    def leaf(p):
+        ret = p[1]
+        if isinstance(ret, SymVec):
+            raise Unsupported('lowered function returned an array')
+        if ret is None:
+            raise Unsupported('lowered function returned None')
+        return lift(ret)
+    return _merge(paths, leaf)
+
+
+def trace_modifier(fn):
+    """{attr: expression} of the attribute writes of `fn(sprite)`; and whether the velocity
+    was assigned as a whole (a fresh ndarray in the reference)."""
+    paths = _explore(fn, 1)
+    attrs = []
+    for p in paths:
+        for k in p[2][0]:
+            if k not in attrs and not k.startswith('__'):
+                attrs.append(k)
+    out = {}
+    for a in attrs:
+        out[a] = _merge(paths, lambda p, a=a: p[2][0][a].node if a in p[2][0]
+                        else Node('attr', 0, a))
+    vec_vel = any('__vec_velocity' in p[2][0] for p in paths)
+    return out, vec_vel
+
+
+# ---- emission ---------------------------------------------------------------------------------
+_BIN = {'add': 'ADD', 'sub': 'SUB', 'mul': 'MUL', 'div': 'DIV', 'rem': 'REM', 'min': 'MIN', 'max': 'MAX',
+        'lt': 'LT', 'le': 'LE', 'gt': 'GT', 'ge': 'GE', 'eq': 'EQ', 'ne': 'NE', 'and': 'AND', 'or': 'OR'}
+_UN = {'neg': 'NEG', 'abs': 'ABS', 'sqrt': 'SQRT', 'sin': 'SIN', 'cos': 'COS', 'floor': 'FLOOR',
+       'not': 'NOT', 'sign': 'SIGN'}
+
+
+def emit(node, out):
+    """Postfix code (list of instruction dicts) for an expression tree."""
+    if node.op == 'const':
+        out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
+    elif node.op == 'attr':
+        out.append(dict(op=_abi.MOOG_X_ATTR, a=ATTRS.index(node.args[1]), b=int(node.args[0])))
+    elif node.op == 'select':
+        for a in node.args:
+            emit(a, out)
+        out.append(dict(op=_abi.MOOG_X_SELECT))
+    elif node.op in _BIN:
+        emit(node.args[0], out)
+        emit(node.args[1], out)
+        out.append(dict(op=getattr(_abi, 'MOOG_X_' + _BIN[node.op])))
+    elif node.op in _UN:
+        emit(node.args[0], out)
+        out.append(dict(op=getattr(_abi, 'MOOG_X_' + _UN[node.op])))
+    else:
+        raise Unsupported('expression op %r' % (node.op,))
+    return out
+
+
+def depth(code):
+    """Maximum value-stack depth of a postfix program."""
+    d = m = 0
+    for ins in code:
+        op = ins['op']
+        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR):
+            d += 1
+        elif op == _abi.MOOG_X_SELECT:
+            d -= 2
+        elif op == _abi.MOOG_X_STORE:
+            d -= 1
+        elif op in (_abi.MOOG_X_NEG, _abi.MOOG_X_ABS, _abi.MOOG_X_SQRT, _abi.MOOG_X_SIN, _abi.MOOG_X_COS,
+                    _abi.MOOG_X_FLOOR, _abi.MOOG_X_NOT, _abi.MOOG_X_SIGN):
+            pass
+        else:
+            d -= 1
+        m = max(m, d)
+    return m
+
+
+def uses_attr(code, names):
+    ids = [ATTRS.index(n) for n in names]
+    return any(ins['op'] == _abi.MOOG_X_ATTR and ins['a'] in ids for ins in code) or \
+        any(ins['op'] == _abi.MOOG_X_STORE and ins['a'] in ids for ins in code)

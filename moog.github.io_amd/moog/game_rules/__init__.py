@@ -59,20 +59,41 @@ class ModifySprites(AbstractRule):
         self._filter_fn = filter_fn
 
     def classify(self):
-        """Recognise the modifier by probing it on sample points."""
-        if self._sample_one or self._filter_fn is not None:
-            raise NotImplementedError('ModifySprites(sample_one/filter_fn) is not lowered')
-        pts = [(1.25, -0.25), (0.5, 0.75), (-3.5, 2.0), (0.999, 1e-3)]
-        for p in pts:
-            s = _ProbeSprite(p)
+        """The torus wrap `position = remainder(position, 1)` over whole layers
+        (chase_avoid_torus.py:144-149) keeps its dedicated kernel path; everything else is
+        traced symbolically.  Returns (kind, filter kind, filter node, modifier dict, vec_vel)."""
+        from .. import _symbolic
+        if not self._sample_one and self._filter_fn is None:
             try:
-                self._modifier(s)
-            except Exception as exc:  # pylint: disable=broad-except
-                raise NotImplementedError('ModifySprites modifier not recognised: %r' % (exc,))
-            if not np.array_equal(np.asarray(s.position), np.remainder(np.array(p), 1)):
-                raise NotImplementedError(
-                    'ModifySprites modifier is not the torus wrap position = remainder(position, 1)')
-        return _abi.MOOG_RULE_TORUS_WRAP
+                pts = [(1.25, -0.25), (0.5, 0.75), (-3.5, 2.0), (0.999, 1e-3)]
+                ok = True
+                for p in pts:
+                    s = _ProbeSprite(p)
+                    self._modifier(s)
+                    ok = ok and list(s.__dict__) == ['position'] and np.array_equal(
+                        np.asarray(s.position), np.remainder(np.array(p), 1))
+                if ok:
+                    return _abi.MOOG_RULE_TORUS_WRAP, _abi.MOOG_FILTER_ALWAYS, None, None, False
+            except Exception:  # pylint: disable=broad-except
+                pass
+        fk, fnode = _classify_filter(self._filter_fn)
+        mod, vec_vel = _symbolic.trace_modifier(self._modifier)
+        return _abi.MOOG_RULE_MODIFY_SPRITES, fk, fnode, mod, vec_vel
+
+
+class ModifyOnContact(AbstractRule):
+    """contact_rules.py:58-141: modifier_0 on the sprites of layers_0 that pass filter_0 and
+    touch a sprite of layers_1 (other than themselves); then the same with the roles swapped."""
+
+    def __init__(self, layers_0, layers_1, modifier_0=None, modifier_1=None, filter_0=None,
+                 filter_1=None):
+        if not isinstance(layers_0, (list, tuple)):
+            layers_0 = (layers_0,)
+        if not isinstance(layers_1, (list, tuple)):
+            layers_1 = (layers_1,)
+        self._layers_0, self._layers_1 = tuple(layers_0), tuple(layers_1)
+        self._modifier_0, self._modifier_1 = modifier_0, modifier_1
+        self._filter_0, self._filter_1 = filter_0, filter_1
 
 
 class Portal(AbstractRule):
@@ -93,16 +114,18 @@ class _TouchedSprite(Exception):
 
 
 def _classify_filter(filter_fn):
-    """MOOG_FILTER_* of a `sprite -> bool` function.  None and functions that ignore
-    their argument and return True (e.g. `lambda _: True`) are ALWAYS."""
+    """(MOOG_FILTER_*, expression node or None) of a `sprite -> bool` function.  None and
+    functions that ignore their argument and return True (e.g. `lambda _: True`) are ALWAYS;
+    anything else is traced symbolically (moog/_symbolic.py)."""
     if filter_fn is None:
-        return _abi.MOOG_FILTER_ALWAYS
+        return _abi.MOOG_FILTER_ALWAYS, None
     try:
         if filter_fn(_NoAttributes()) is True:
-            return _abi.MOOG_FILTER_ALWAYS
-    except _TouchedSprite:
+            return _abi.MOOG_FILTER_ALWAYS, None
+    except Exception:  # pylint: disable=broad-except
         pass
-    raise NotImplementedError('sprite filter functions other than "always True" are not lowered')
+    from .. import _symbolic
+    return _abi.MOOG_FILTER_EXPR, _symbolic.trace_value(filter_fn, 1)
 
 
 class VanishByFilter(AbstractRule):

@@ -23,11 +23,12 @@ class CompositeTask(AbstractTask):
 class ContactReward(AbstractTask):
     def __init__(self, reward_fn, layers_0, layers_1, condition=None,
                  reset_steps_after_contact=np.inf):
-        if callable(reward_fn):
-            raise NotImplementedError('ContactReward with a callable reward_fn is not lowered')
-        if condition is not None:
-            raise NotImplementedError('ContactReward(condition=...) is not lowered')
+        # contact_reward.py:44-58: a number or reward_fn(sprite_0, sprite_1); condition takes
+        # (sprite_0, sprite_1) -- the 3-argument form reads meta_state, which lives on the host
         self._reward = reward_fn
+        if condition is not None and len(inspect.signature(condition).parameters) != 2:
+            raise NotImplementedError('ContactReward condition(s0, s1, meta_state) is not lowered')
+        self._condition = condition
         if not isinstance(layers_0, (list, tuple)):
             layers_0 = [layers_0]
         if not isinstance(layers_1, (list, tuple)):

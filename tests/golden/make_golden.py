@@ -75,9 +75,8 @@ def _choice(a, size=None, replace=True, p=None):
         cdf /= cdf[-1]
         idx = int(np.searchsorted(cdf, TAPE.u(), side='right'))
         return idx if isinstance(a, (int, np.integer)) else a[idx]
-    if n == 1:
-        return 0
-    return int(TAPE.u() * n)
+    idx = 0 if n == 1 else int(TAPE.u() * n)
+    return idx if isinstance(a, (int, np.integer)) else a[idx]
 
 
 def _randint(low, high=None, size=None, dtype=int):
@@ -133,6 +132,8 @@ def snapshot(env, layer_names, caps, slot_of):
         inertia=np.full((S, 2), np.nan), maxr=np.full(S, np.nan),
         vel_f32=np.zeros(S, np.uint8), angvel_f32=np.zeros(S, np.uint8),
         sym_circle=np.zeros(S, np.uint8), tele=np.zeros(S, np.uint8),
+        scale=np.full(S, np.nan), aspect=np.full(S, np.nan),
+        fmask=np.zeros(S, np.int32),       # bit i: factor i (Sprite.FACTOR_NAMES order) is a float32 value
         vel_group=np.zeros(S, np.int32))   # 1 + lowest slot among sprites sharing ONE velocity ndarray
     owners = {}
     tele_ids = set()
@@ -161,6 +162,13 @@ def snapshot(env, layer_names, caps, slot_of):
             d['angvel_f32'][k] = getattr(s.angle_vel, 'dtype', None) == np.float32
             d['sym_circle'][k] = bool(s.is_symmetric_circle)
             d['tele'][k] = s.id in tele_ids
+            d['scale'][k] = s.scale
+            d['aspect'][k] = s.aspect_ratio
+            vals = (None, None, None, s.angle, s.scale, s.aspect_ratio, s.color[0], s.color[1], s.color[2],
+                    None, None, None, None, s.mass)
+            for bit, v in enumerate(vals):
+                if getattr(v, 'dtype', None) == np.float32:
+                    d['fmask'][k] |= 1 << bit
             owners.setdefault(id(s.velocity), []).append(k)
     for ks in owners.values():
         if len(ks) > 1:
@@ -480,6 +488,7 @@ def main():
         ('tether_zoo_l3', 45, {}, (0,)),
         ('tether_zoo_l4', 45, {}, (0,)),
         ('distrib_zoo', 60, {}, (0, 1)),
+        ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
     ]

@@ -173,6 +173,10 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
         q[L.o_tele + s] = pm if fx['tele'][t][s] else 0
         if P.vel_alias:
             q[L.o_valias + s] = fx['vel_group'][t][s] if 'vel_group' in fx else 0
+        if P.sprite_factors:
+            f[L.o_scale + s] = nz(fx['scale'][t][s])
+            f[L.o_aspect + s] = nz(fx['aspect'][t][s])
+            q[L.o_fmask + s] = fx['fmask'][t][s]
     q[L.o_step_count] = fx['step_count'][t]
     q[L.o_reset_next] = fx['reset_next'][t]
     return f64, i32
@@ -237,6 +241,15 @@ def state_diff(fx, t, c, f64, i32, env=0):
             ints_ok = False
             detail.append('opacity slot %d' % s)
     err['verts'] = verr
+    if P.sprite_factors and 'scale' in fx:
+        cmp('scale', f[L.o_scale:L.o_scale + S], fx['scale'][t])
+        cmp('aspect', f[L.o_aspect:L.o_aspect + S], fx['aspect'][t])
+        relevant = sum(1 << b for b in (_abi.MOOG_FAC_SCALE, _abi.MOOG_FAC_ASPECT, _abi.MOOG_FAC_C0,
+                                        _abi.MOOG_FAC_C1, _abi.MOOG_FAC_C2, _abi.MOOG_FAC_MASS))
+        for s in range(S):
+            if live[s] and (int(q[L.o_fmask + s]) ^ int(fx['fmask'][t][s])) & relevant:
+                ints_ok = False
+                detail.append('float32 factor mask slot %d: %x vs %x' % (s, q[L.o_fmask + s], fx['fmask'][t][s]))
     if P.vel_alias and 'vel_group' in fx:
         # sprites sharing one velocity ndarray: same partition (the group ids are arbitrary)
         def canon(g):

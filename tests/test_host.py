@@ -77,8 +77,8 @@ def test_program_contents():
 
 def test_unsupported_components_raise():
     from moog import tasks, physics
-    with pytest.raises(NotImplementedError):
-        tasks.ContactReward(lambda a, b: 1., 'a', 'b')
+    with pytest.raises(NotImplementedError):   # meta_state lives on the host
+        tasks.ContactReward(1., 'a', 'b', condition=lambda a, b, meta_state: True)
     with pytest.raises(NotImplementedError):
         physics.DistanceForce(lambda d: d)
     with pytest.raises(NotImplementedError):
@@ -144,3 +144,54 @@ def test_composite_distributions_lower_to_programs():
     assert all((0. <= x < 0.2) or (0.9 <= x < 1.) for x in xs)
     m = distribs.Mixture([distribs.Discrete('k', [1]), distribs.Discrete('k', [2])], probs=[0., 1.])
     assert m.sample()['k'] == 2 and m.contains({'k': 1}) and not m.contains({'k': 3})
+
+
+def test_config_callables_are_traced_symbolically():
+    """Sprite filters / modifiers / pair functions (e.g. cleanup.py:150-216,
+    first_person_predators_prey.py:129-147,193-201) run once on symbolic sprites; Python
+    control flow is covered by enumerating the execution paths."""
+    from moog import _symbolic as sy
+    lo, hi = -1.2, 2.2
+
+    def should_vanish(s):
+        too_small = (s.position < lo) * (s.velocity < 0.)
+        too_large = (s.position > hi) * (s.velocity > 0.)
+        return any(too_small) or any(too_large)
+    code = sy.emit(sy.trace_value(should_vanish, 1), [])
+    assert sy.depth(code) <= _abi.MOOG_X_STACK
+
+    def evaluate(code, attrs):   # reference evaluator of the postfix code, Python floats
+        st = []
+        for ins in code:
+            op = ins['op']
+            if op == _abi.MOOG_X_CONST:
+                st.append(ins['x'])
+            elif op == _abi.MOOG_X_ATTR:
+                st.append(attrs[ins['b']][sy.ATTRS[ins['a']]])
+            elif op == _abi.MOOG_X_SELECT:
+                b, a, c = st.pop(), st.pop(), st.pop()
+                st.append(a if c else b)
+            elif op == _abi.MOOG_X_MUL:
+                b, a = st.pop(), st.pop(); st.append(a * b)
+            elif op == _abi.MOOG_X_LT:
+                b, a = st.pop(), st.pop(); st.append(float(a < b))
+            elif op == _abi.MOOG_X_GT:
+                b, a = st.pop(), st.pop(); st.append(float(a > b))
+            else:
+                raise AssertionError(op)
+        return st[-1]
+
+    class S(object):
+        def __init__(self, x, y, vx, vy):
+            self.position, self.velocity = np.array([x, y]), np.array([vx, vy])
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        x, y = rs.uniform(-2, 3, 2)
+        vx, vy = rs.uniform(-1, 1, 2)
+        want = bool(should_vanish(S(x, y, vx, vy)))
+        got = evaluate(code, [dict(x=x, y=y, x_vel=vx, y_vel=vy)])
+        assert bool(got) == want
+    mod, vec = sy.trace_modifier(lambda s: setattr(s, 'position', np.remainder(s.position, 1)))
+    assert set(mod) == {'x', 'y'} and mod['x'].op == 'rem' and not vec
+    with pytest.raises(sy.Unsupported):
+        sy.trace_value(lambda s: s.metadata['k'], 1)
