@@ -246,6 +246,8 @@ enum {
                                       cond(state) times                           */
   MOOG_RULE_MODIFY_SPRITES,        /* modify_sprites.py:35-52: layers[], filter,
                                       i0 = sample_one, modifier = expression xmod  */
+  MOOG_RULE_KEEP_NEAR_CENTER,      /* re_center.py:48-58: l0 agent layer, layers[] to move,
+                                      p0 / p1 grid cell                            */
   MOOG_RULE_MODIFY_ON_CONTACT      /* contact_rules.py:112-141: layers[] x layers1[];
                                       xmod / filter for side 0, xmod1 / filter1 for
                                       side 1 (xmod < 0: no modifier on that side)  */

@@ -1669,6 +1669,22 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       if constexpr (DYN) layer_compact(e, R->l0);
       break;
     }
+    case MOOG_RULE_KEEP_NEAR_CENTER: {   // re_center.py:48-58
+      int agent = -1;
+      for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0] && agent < 0; ++s)
+        if (ALIVE(s)) agent = s;
+      if (agent < 0) break;
+      const double ax = PX(agent) - 0.5, ay = PY(agent) - 0.5;
+      const double dx = -1. * R->p0 * (double)(ax > R->p0) + R->p0 * (double)(ax < -1. * R->p0);
+      const double dy = -1. * R->p1 * (double)(ay > R->p1) + R->p1 * (double)(ay < -1. * R->p1);
+      if (dx != 0 || dy != 0)
+        for (int a = 0; a < R->n_layers; ++a) {
+          const int l = R->layers[a];
+          for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+            if (ALIVE(s)) set_position(e, s, PX(s) + dx, PY(s) + dy);
+        }
+      break;
+    }
     case MOOG_RULE_TORUS_WRAP: {
       for (int a = 0; a < R->n_layers; ++a) {
         int l = R->layers[a];

@@ -464,6 +464,11 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.l0 = layer_index(r._layer)
             R.op = runtime_op_of_rule[ri]
             R.n_layers = _fill_layers(R.layers, list(r._without_overlapping), layer_index)
+        elif isinstance(r, rules_lib.KeepNearCenter):
+            R.kind = _abi.MOOG_RULE_KEEP_NEAR_CENTER
+            R.l0 = layer_index(r._agent_layer)
+            R.n_layers = _fill_layers(R.layers, r._layers_to_center, layer_index)
+            R.p0, R.p1 = r._grid_cell
         elif isinstance(r, rules_lib.TimedRule):
             R.kind = _abi.MOOG_RULE_TIMED
             R.p0, R.p1 = r._step_interval

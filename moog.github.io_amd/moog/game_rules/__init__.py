@@ -102,6 +102,19 @@ class Portal(AbstractRule):
         self._portal_layer = portal_layer
 
 
+class KeepNearCenter(AbstractRule):
+    """re_center.py:11-58: when the first sprite of agent_layer strays more than a grid cell
+    from (0.5, 0.5), every sprite of layers_to_center (and the agent) is shifted back by one
+    cell."""
+
+    def __init__(self, agent_layer, layers_to_center, grid_x, grid_y=None):
+        self._agent_layer = agent_layer
+        if agent_layer not in set(layers_to_center):
+            layers_to_center = list(layers_to_center) + [agent_layer]
+        self._layers_to_center = list(layers_to_center)
+        self._grid_cell = (float(grid_x), float(grid_x if grid_y is None else grid_y))
+
+
 class _NoAttributes(object):
     """Probe argument: a filter that returns a constant without looking at the sprite."""
 

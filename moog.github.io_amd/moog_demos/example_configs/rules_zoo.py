@@ -3,6 +3,10 @@
 Level 0  timers and layer moves: TimedRule + VanishByFilter (the screen of
          bounce_box_contact_prediction.py:164-166), TemporaryRule, DelayedRule + ChangeLayer
          (timing.py, vanish.py:42-61, change_layer.py).
+Level 2  first-person view: grid_lines background, FirstPersonAgent renderer and
+         KeepNearCenter (re_center.py) snapping everything back by one grid cell, with prey
+         appearing on a boundary Mixture and vanishing by a position / velocity filter
+         (first_person_predators_prey.py:150-209 without its 102-vertex annulus).
 Level 1  sprites appearing and vanishing at run time, as in
          first_person_predators_prey.py:178-209: ConditionalRule(np.random.binomial) around
          CreateSprites (with and without `without_overlapping`), VanishOnContact on a layer
@@ -102,8 +106,70 @@ def _level1():
     return state_initializer, rules, physics, task
 
 
+def _level2():
+    grid_size = 0.25
+    rng = [-0.3, 1.3]
+    boundary = distribs.Mixture([
+        distribs.Product([distribs.Continuous('y', *rng)], x=rng[0]),
+        distribs.Product([distribs.Continuous('y', *rng)], x=rng[1]),
+        distribs.Product([distribs.Continuous('x', *rng)], y=rng[0]),
+        distribs.Product([distribs.Continuous('x', *rng)], y=rng[1]),
+    ])
+    velocity = distribs.SetMinus(
+        distribs.Product([distribs.Continuous('x_vel', -0.04, 0.04),
+                          distribs.Continuous('y_vel', -0.04, 0.04)]),
+        hold_out=distribs.Product([distribs.Continuous('x_vel', -0.02, 0.02),
+                                   distribs.Continuous('y_vel', -0.02, 0.02)]))
+    prey_factors = distribs.Product(
+        [boundary, velocity, distribs.Continuous('scale', 0.07, 0.13)], shape='circle', c0=0.2, c1=1., c2=1.)
+    prey_gen = sprite_generators.generate_sprites(prey_factors, num_sprites=1)
+    grid = shapes.grid_lines(grid_x=grid_size, grid_y=grid_size, buffer_border=0.5, c0=0., c1=0., c2=0.5)
+
+    def state_initializer():
+        agent = sprite.Sprite(x=0.5, y=0.5, shape='circle', scale=0.06, c0=0.33, c1=1., c2=0.66)
+        halo = sprite.Sprite(x=0.5, y=0.5, shape='square', scale=0.2, c0=0.6, c1=1., c2=1., opacity=96)
+        return collections.OrderedDict([
+            ('grid', shapes.grid_lines(grid_x=grid_size, grid_y=grid_size, buffer_border=0.5,
+                                       c0=0., c1=0., c2=0.5)),
+            ('prey', []), ('agent', [agent]), ('halo', [halo])])
+    del grid
+    vanish_range = [-0.5, 1.5]
+
+    def _should_vanish(s):
+        too_small = (s.position < vanish_range[0]) * (s.velocity < 0.)
+        too_large = (s.position > vanish_range[1]) * (s.velocity > 0.)
+        return any(too_small) or any(too_large)
+
+    rules = (
+        game_rules.ConditionalRule(condition=lambda state: np.random.binomial(1, p=0.3),
+                                   rules=game_rules.CreateSprites('prey', prey_gen)),
+        game_rules.VanishByFilter('prey', _should_vanish),
+        game_rules.KeepNearCenter(agent_layer='agent', layers_to_center=['halo', 'prey'],
+                                  grid_x=grid_size),
+        game_rules.VanishOnContact(vanishing_layer='prey', contacting_layer='agent'),
+    )
+    physics = physics_lib.Physics(
+        (physics_lib.Drag(coeff_friction=0.25), ['agent', 'halo']), updates_per_env_step=5)
+    task = tasks.CompositeTask(
+        tasks.ContactReward(lambda _, prey: prey.scale, layers_0='agent', layers_1='prey'),
+        timeout_steps=11)
+    return state_initializer, rules, physics, task
+
+
 def get_config(level=0):
-    state_initializer, rules, physics, task = (_level0, _level1)[level]()
+    state_initializer, rules, physics, task = (_level0, _level1, _level2)[level]()
+    if level == 2:
+        return {
+            'state_initializer': state_initializer,
+            'physics': physics,
+            'task': task,
+            'action_space': action_spaces.Joystick(
+                scaling_factor=0.05, action_layers=('agent', 'halo'), constrained_lr=False),
+            'observers': {'image': observers.PILRenderer(
+                image_size=(64, 64), color_to_rgb='hsv_to_rgb',
+                polygon_modifier=observers.polygon_modifiers.FirstPersonAgent(agent_layer='agent'))},
+            'game_rules': rules,
+        }
     return {
         'state_initializer': state_initializer,
         'physics': physics,

@@ -491,6 +491,7 @@ def main():
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
+        ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
     ]
     only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:
