@@ -381,9 +381,9 @@ __device__ inline void set_position(Env& e, int s, double nx, double ny) {
   double* v = VERT(s);
   int n = NV(s);
   wsync();
-  if (e.lane < n) {
-    v[2 * e.lane] = v[2 * e.lane] + dx;
-    v[2 * e.lane + 1] = v[2 * e.lane + 1] + dy;
+  for (int k = e.lane; k < n; k += 64) {   // > 64 vertices: annuli (shapes.py:170-188)
+    v[2 * k] = v[2 * k] + dx;
+    v[2 * k + 1] = v[2 * k + 1] + dy;
   }
   if (e.lane == 0) {
     PX(s) = nx; PY(s) = ny;
@@ -1958,12 +1958,12 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
   double* v = VERT(s);
   double r = -1.0;
   wsync();
-  if (e.lane < n) {
-    double ux = P->shape_verts[sh->voff + e.lane][0], uy = P->shape_verts[sh->voff + e.lane][1];
+  for (int k = e.lane; k < n; k += 64) {
+    double ux = P->shape_verts[sh->voff + k][0], uy = P->shape_verts[sh->voff + k][1];
     double vx = (m00 * ux + m01 * uy) + x;
     double vy = (m10 * ux + m11 * uy) + y;
-    v[2 * e.lane] = vx; v[2 * e.lane + 1] = vy;
-    r = norm2(vx - x, vy - y);
+    v[2 * k] = vx; v[2 * k + 1] = vy;
+    r = fmax(r, norm2(vx - x, vy - y));
   }
   // np.max over the vertex radii (NaN-free in practice; fmax is order independent)
   for (int o = 32; o > 0; o >>= 1) r = fmax(r, shfl_d(r, e.lane ^ o));

@@ -234,7 +234,7 @@ static int validate(const moog_program_t* p) {
   if (p->n_layers < 0 || p->n_layers > MOOG_MAX_LAYERS) return fail(MOOG_E_INVALID, "n_layers out of range");
   if (p->updates_per_env_step < 1) return fail(MOOG_E_INVALID, "updates_per_env_step < 1");
   for (int s = 0; s < p->n_slots; ++s)
-    if (p->slot_vcap[s] > 64) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 64 vertices");
+    if (p->slot_vcap[s] > 128) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 128 vertices");
   for (int l = 0; l < p->n_layers; ++l)
     if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
   if (p->render.width % 16 != 0 || p->render.width > 128 || p->render.height > 1024 ||

@@ -69,7 +69,7 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   p->o_rowoff = o; o = r_align(o + (items + 1) * 4);
   p->o_rowitems = o; o = r_align(o + (size_t)H * iwords * 4);
   p->o_misc = o; o = r_align(o + 64);
-  p->o_carry = o; o = r_align(o + (size_t)S * 8);     // counts carried over a 64-vertex chunk
+  p->o_carry = o; o = r_align(o + (size_t)S * 16);    // counts of a polygon's earlier 64-vertex chunks
   p->o_queue = o; o = r_align(o + (size_t)cap_rows * 2 + 16);   // rows that need the generic scanline
   p->o_xx = o; o = r_align(o + (size_t)xxcap * R_SLOW * 4);
   // union: the integer vertices are dead once the edge records are packed; the
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       if (s < S) { live = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0; nv = gq[a.L.o_nverts + s]; }
       unsigned long long bal = __ballot(live);
       int rank = n_live + __popcll(bal & ((1ull << tid) - 1ull));
-      if (s < S) { slotinfo[4 * s] = live ? rank : -1; slotinfo[4 * s + 1] = nv; slotinfo[4 * s + 2] = P->slot_voff[s]; carry[2 * s] = 0; carry[2 * s + 1] = 0; }
+      if (s < S) { slotinfo[4 * s] = live ? rank : -1; slotinfo[4 * s + 1] = nv; slotinfo[4 * s + 2] = P->slot_voff[s]; }
       if (live) {
         unsigned r8, g8, b8;
         const double* col = gf + a.L.o_color + 3 * s;
@@ -449,8 +449,9 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   // ---- 2: edges (ImagingDrawPolygon: add_edge + merge of horizontal runs), packed per
   //         polygon: table edges from the front, horizontal heads from the back.  The
   //         in-polygon ranks come from wave ballots (a polygon's vertices are contiguous
-  //         lanes); a polygon straddling a 64-vertex chunk gets the counts of its first
-  //         part through `carry` (it spans at most two chunks: <= 64 vertices).
+  //         lanes); a polygon straddling 64-vertex chunks gets the counts of its earlier
+  //         parts through `carry` (one entry per earlier chunk; it spans at most three
+  //         chunks: <= 128 vertices).
   for (int c = 0; c < ncopy; ++c) {
     for (int base0 = 0; base0 < TOTV; base0 += R_THREADS) {
       const int base = base0 + (tid & ~63);   // this wave's 64-vertex chunk
@@ -485,14 +486,16 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       if (lo_lane < 0) lo_lane = 0;
       unsigned long long below = ((1ull << lane) - 1ull) & ~((1ull << lo_lane) - 1ull);
       int nt = __popcll(m1 & below), nh = __popcll(m2 & below);
-      // the polygon of the chunk's last lane may continue in the next chunk
-      if (lane == 63 && valid && (v0 + nv > base + 64)) {
-        carry[2 * s] = nt + (fl == 1);
-        carry[2 * s + 1] = nh + (fl == 2);
+      // the polygon of the chunk's last lane may continue in the next chunk: publish this
+      // chunk's own counts under the chunk's ordinal within the polygon
+      const int ord = (base >> 6) - (v0 >> 6);
+      if (lane == 63 && valid && (v0 + nv > base + 64) && ord < 2) {
+        carry[4 * s + 2 * ord] = nt + (fl == 1);
+        carry[4 * s + 2 * ord + 1] = nh + (fl == 2);
       }
       __syncthreads();
       if (valid) {
-        if (v0 < base) { nt += carry[2 * s]; nh += carry[2 * s + 1]; }
+        for (int j = 0; j < ord && j < 2; ++j) { nt += carry[4 * s + 2 * j]; nh += carry[4 * s + 2 * j + 1]; }
         REdge* reg = edges + c * TOTV + v0;
         if (fl == 1) {
           REdge E; E.x0 = p0.x; E.y0 = p0.y; E.y1 = p1.y; E.x1 = p1.x; E.pad = 0.0f;

@@ -564,5 +564,47 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     for c in range(3):
         Rn.bg[c] = int(ren._bg_color[c])
 
+    # ---- vertex-count limits of the device kernels ------------------------------------------
+    # Polygons of up to 128 vertices are integrated, moved and rasterised (the annulus of
+    # first_person_predators_prey.py:79-82 has 102); the pairwise geometry (overlap tests,
+    # contact search: lanes = vertices / edges of one wavefront) handles up to 64.
+    if max([P.slot_vcap[sl] for sl in range(S)] or [0]) > 128:
+        raise NotImplementedError('sprites with more than 128 vertices')
+    tested = set()
+    for fi in range(P.n_forces):
+        F = P.forces[fi]
+        if F.kind == _abi.MOOG_FORCE_COLLISION:
+            tested.update(F.layers_a[i] for i in range(F.n_a))
+            tested.update(F.layers_b[i] for i in range(F.n_b))
+    for ri in range(P.n_rules):
+        R = P.rules[ri]
+        if R.kind in (_abi.MOOG_RULE_VANISH_ON_CONTACT, _abi.MOOG_RULE_PORTAL, _abi.MOOG_RULE_BOOSTER):
+            tested.update((R.l0, R.l1))
+        elif R.kind == _abi.MOOG_RULE_MODIFY_ON_CONTACT:
+            tested.update(R.layers[i] for i in range(R.n_layers))
+            tested.update(R.layers1[i] for i in range(R.n_layers1))
+        elif R.kind == _abi.MOOG_RULE_CREATE_SPRITES:
+            tested.update(R.layers[i] for i in range(R.n_layers))
+            if R.n_layers or P.ops[R.op].disjoint:
+                tested.add(R.l0)
+    for ti in range(P.n_tasks):
+        T = P.tasks[ti]
+        if T.kind == _abi.MOOG_TASK_CONTACT_REWARD:
+            tested.update(T.layers0[i] for i in range(T.n0))
+            tested.update(T.layers1[i] for i in range(T.n1))
+    for oi in range(P.n_ops):
+        G = P.ops[oi]
+        if G.runtime or not (G.avoid_ops or G.disjoint):
+            continue
+        tested.add(P.slot_layer[G.slot0])
+        for oj in range(oi):
+            if (G.avoid_ops >> oj) & 1:
+                tested.add(P.slot_layer[P.ops[oj].slot0])
+    for sl in range(S):
+        if P.slot_vcap[sl] > 64 and P.slot_layer[sl] in tested:
+            raise NotImplementedError(
+                'sprites with more than 64 vertices cannot take part in overlap tests '
+                '(layer %r)' % (layer_names[P.slot_layer[sl]],))
+
     layer_slots = {name: (P.layer_slot0[i], P.layer_nslots[i]) for i, name in enumerate(layer_names)}
     return Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P))

@@ -12,7 +12,17 @@ import importlib
 import re
 
 NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
+         'first_person_predators_prey',
          'colliding_predators_32', 'falling_balls_64', 'forces_zoo', 'tether_zoo', 'distrib_zoo', 'rules_zoo', 'lambda_zoo')
+
+
+def capacity(name):
+    """layer_capacity for BatchedEnvironment / compile_config: run-time sprite capacity of the
+    layers a recipe's rules append to (module attribute LAYER_CAPACITY), or None."""
+    m = re.match(r'(.*)_l(\d+)$', name)
+    if m:
+        name = m.group(1)
+    return getattr(importlib.import_module(__name__ + '.' + name), 'LAYER_CAPACITY', None)
 
 
 def load(name, level=0):

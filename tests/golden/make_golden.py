@@ -41,6 +41,7 @@ from matplotlib import path as mpl_path  # noqa: E402
 from PIL import Image, ImageDraw  # noqa: E402
 
 VMAX = 30
+SNAP_VMAX = 104   # first_person_predators_prey's annulus has 102 vertices
 
 
 class Tape(object):
@@ -60,6 +61,7 @@ class Tape(object):
 
 TAPE = None
 DYNAMIC_LAYERS = ()
+STATE_VMAX = VMAX
 
 
 def _uniform(low=0.0, high=1.0, size=None):
@@ -98,7 +100,8 @@ def patch_numpy_random():
     np.random.binomial = _binomial
 
 
-SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls')
+SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
+           'first_person_predators_prey')
 
 
 def load_amd_config(name):
@@ -128,7 +131,7 @@ def snapshot(env, layer_names, caps, slot_of):
         alive=np.zeros(S, np.uint8), pos=np.full((S, 2), np.nan), vel=np.full((S, 2), np.nan),
         angle=np.full(S, np.nan), angvel=np.full(S, np.nan), mass=np.full(S, np.nan),
         color=np.full((S, 3), np.nan), opacity=np.zeros(S, np.int32),
-        nverts=np.zeros(S, np.int32), verts=np.full((S, VMAX, 2), np.nan),
+        nverts=np.zeros(S, np.int32), verts=np.full((S, STATE_VMAX, 2), np.nan),
         inertia=np.full((S, 2), np.nan), maxr=np.full(S, np.nan),
         vel_f32=np.zeros(S, np.uint8), angvel_f32=np.zeros(S, np.uint8),
         sym_circle=np.zeros(S, np.uint8), tele=np.zeros(S, np.uint8),
@@ -197,9 +200,10 @@ def make_slot_map(env, layer_names, caps):
 
 
 def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
-    global TAPE, DYNAMIC_LAYERS
+    global TAPE, DYNAMIC_LAYERS, STATE_VMAX
     caps_by_layer = dict(caps_by_layer)
     DYNAMIC_LAYERS = tuple(caps_by_layer.pop('__dynamic__', ()))
+    STATE_VMAX = caps_by_layer.pop('__vmax__', VMAX)
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -491,6 +495,8 @@ def main():
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
+        ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,
+                                             '__dynamic__': ('prey', 'predators')}, (0,)),
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
     ]
     only = sys.argv[1:]

@@ -102,7 +102,8 @@ class OracleEnv(object):
 
 @functools.lru_cache(maxsize=None)
 def compiled(name):
-    return _compiler.compile_config(**example_configs.load(name))
+    return _compiler.compile_config(layer_capacity=example_configs.capacity(name),
+                                    **example_configs.load(name))
 
 
 @functools.lru_cache(maxsize=None)

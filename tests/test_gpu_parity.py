@@ -15,13 +15,15 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
         ('tether_zoo_l4', 0), ('distrib_zoo', 0), ('distrib_zoo', 1),
         ('rules_zoo_l0', 0), ('rules_zoo_l1', 0), ('rules_zoo_l1', 1),
-        ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0)]
+        ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
+        ('first_person_predators_prey', 0)]
 
 
 def make_env(name, n, seed=0, **kw):
     import torch  # noqa: F401
     from moog import environment
     from moog_demos import example_configs
+    kw.setdefault('layer_capacity', example_configs.capacity(name))
     return environment.BatchedEnvironment(num_envs=n, seed=seed, **example_configs.load(name), **kw)
 
 

@@ -44,14 +44,14 @@ def test_missing_library_fails_loudly(tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
 @pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
-                                  'functional_maze', 'falling_balls'])
+                                  'functional_maze', 'falling_balls', 'first_person_predators_prey'])
 def test_reference_configs_load_unchanged(name):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
     spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    ref = _compiler.compile_config(**m.get_config(0))
+    ref = _compiler.compile_config(layer_capacity=example_configs.capacity(name), **m.get_config(0))
     assert bytes(ref.program) == bytes(helpers.compiled(name).program)
 
 
