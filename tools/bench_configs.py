@@ -7,7 +7,7 @@ from moog_demos import example_configs
 
 def run(name, n, steps=30, observers=True, **kw):
     cfg = example_configs.load(name) if not kw else __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, **kw)
-    env = environment.BatchedEnvironment(num_envs=n, seed=1, **cfg)
+    env = environment.BatchedEnvironment(num_envs=n, seed=1, layer_capacity=example_configs.capacity(name), **cfg)
     env.check_faults = False
     env.reset()
     for _ in range(5):
@@ -30,3 +30,8 @@ run('falling_balls_64', 8192, steps=10)
 run('pong', 4096)
 run('colliding_predators', 4096)
 run('falling_balls', 4096)
+run('first_person_predators_prey', 4096, steps=60)
+run('lambda_zoo', 4096)
+run('rules_zoo_l1', 4096)
+run('tether_zoo_l0', 4096)
+run('distrib_zoo', 4096)
