@@ -117,7 +117,10 @@ def test_reset_sampler_vs_reference(name, seed):
 
 
 @pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
-                                  'functional_maze', 'falling_balls', 'colliding_predators_32'])
+                                  'functional_maze', 'falling_balls', 'colliding_predators_32',
+                                  'forces_zoo', 'tether_zoo_l1', 'tether_zoo_l3', 'tether_zoo_l4',
+                                  'distrib_zoo', 'rules_zoo_l0', 'rules_zoo_l1', 'rules_zoo_l2',
+                                  'lambda_zoo', 'first_person_predators_prey'])
 def test_engine_vs_oracle_own_rng(name):
     """Same Philox streams on both sides, 64 envs, resets included: integer
     records bit-exact, floats <= 1e-9, frames bit-exact from the engine state."""
