@@ -57,6 +57,28 @@ def raster_traffic(workload, n_envs):
     return None
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU
+    quota when the container has one (a 256-thread host with an 8-core quota runs 8)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:           # cgroup v2: "<quota> <period>" or "max ..."
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                quota = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(seconds_target=12.0):
     """Times the CPU oracle (oracle/moog_oracle.c, one OpenMP thread per host core, envs are
     independent) on a bounded sample of the same workload: 64 envs per thread stepped until
@@ -64,7 +86,7 @@ def cpu_baseline(seconds_target=12.0):
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     import numpy as np
     import helpers
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = host_cores()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
     n = 64 * cores
     c = helpers.compiled(WORKLOAD)
