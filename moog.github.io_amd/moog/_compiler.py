@@ -25,7 +25,7 @@ from .observers import polygon_modifiers
 from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
-    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout'])
+    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names'])
 
 
 class _ShapeTable(object):
@@ -100,11 +100,13 @@ def _flatten_rules(rules, parent=-1, depth=0, out=None):
 
 
 def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
-                   meta_state_initializer=None, layer_capacity=None):
+                   meta_state_initializer=None, layer_capacity=None, keep_sprite_factors=False):
     # meta_state lives on the host (environment.py keeps it for `ModifyMetaState`)
     del meta_state_initializer
     P = _abi.Program()
     P.abi_version = _abi.MOOG_ABI_VERSION
+    if keep_sprite_factors:   # scale / aspect_ratio per sprite in the records (LoggingEnvironment)
+        P.sprite_factors = 1
     shapes = _ShapeTable(P)
 
     # ---- trace the state initializer (environment.py:86) -----------------------
@@ -607,4 +609,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 '(layer %r)' % (layer_names[P.slot_layer[sl]],))
 
     layer_slots = {name: (P.layer_slot0[i], P.layer_nslots[i]) for i, name in enumerate(layer_names)}
-    return Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P))
+    c = Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P), [])
+    # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
+    c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
+    return c

@@ -1,6 +1,8 @@
 """Environment wrappers (reference: moog/env_wrappers/__init__.py): the Gym surface
- and the mental-simulation wrapper."""
+(SURVEY 2 row 15), the mental-simulation wrapper and the episode logger."""
 from . import gym_wrapper  # noqa: F401
+from . import logger  # noqa: F401
 from . import simulation  # noqa: F401
 from .gym_wrapper import GymWrapper  # noqa: F401
+from .logger import LoggingEnvironment  # noqa: F401
 from .simulation import SimulationEnvironment  # noqa: F401

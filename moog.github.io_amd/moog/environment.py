@@ -40,7 +40,7 @@ class BatchedEnvironment(object):
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
                  meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0,
-                 layer_capacity=None):
+                 layer_capacity=None, keep_sprite_factors=False):
         import torch
         self._torch = torch
         self._lib = _engine.load_library()  # raises when the HIP extension is missing
@@ -48,7 +48,8 @@ class BatchedEnvironment(object):
             raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
         self.compiled = _compiler.compile_config(
             state_initializer, physics, task, action_space, observers, game_rules,
-            meta_state_initializer, layer_capacity=layer_capacity)
+            meta_state_initializer, layer_capacity=layer_capacity,
+            keep_sprite_factors=keep_sprite_factors)
         self.physics = physics
         self.task = task
         self.action_space = action_space
@@ -300,6 +301,36 @@ class BatchedEnvironment(object):
         if name == 'opacity':
             return q[:, L.o_opacity:L.o_opacity + S]
         raise KeyError(name)
+
+    def sprites(self, env=0):
+        """Host view of one env's state in the reference's shape (environment.py:143-146):
+        OrderedDict layer name -> list of dicts with the Sprite.FACTOR_NAMES attributes
+        (sprite.py:237-253), `vertices` and `slot`, live sprites in list order.  `scale` /
+        `aspect_ratio` need `keep_sprite_factors=True` (else None)."""
+        L, P, S = self.layout, self.compiled.program, self.layout.S
+        f = self.state_f64[env].cpu().numpy()
+        q = self.state_i32[env].cpu().numpy()
+        out = collections.OrderedDict()
+        for li, name in enumerate(self.compiled.layer_names):
+            rows = []
+            for s in range(P.layer_slot0[li], P.layer_slot0[li] + P.layer_nslots[li]):
+                if not q[L.o_flags + s] & _abi.MOOG_F_ALIVE:
+                    continue
+                nv = int(q[L.o_nverts + s])
+                o = L.o_verts + 2 * P.slot_voff[s]
+                rows.append(dict(
+                    x=float(f[L.o_pos + 2 * s]), y=float(f[L.o_pos + 2 * s + 1]),
+                    shape=self.compiled.shape_names[int(q[L.o_shape + s])],
+                    angle=float(f[L.o_angle + s]),
+                    scale=float(f[L.o_scale + s]) if P.sprite_factors else None,
+                    aspect_ratio=float(f[L.o_aspect + s]) if P.sprite_factors else None,
+                    c0=float(f[L.o_color + 3 * s]), c1=float(f[L.o_color + 3 * s + 1]),
+                    c2=float(f[L.o_color + 3 * s + 2]), opacity=int(q[L.o_opacity + s]),
+                    x_vel=float(f[L.o_vel + 2 * s]), y_vel=float(f[L.o_vel + 2 * s + 1]),
+                    angle_vel=float(f[L.o_angvel + s]), mass=float(f[L.o_mass + s]), metadata=None,
+                    vertices=f[o:o + 2 * nv].reshape(nv, 2).copy(), slot=s))
+            out[name] = rows
+        return out
 
     def close(self):
         if self._handle:

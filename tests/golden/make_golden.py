@@ -471,7 +471,44 @@ def make_collision_kat():
     print('collisions_kat: %d scenarios' % len(rows))
 
 
+def make_logger_fixture():
+    """A run of the reference's LoggingEnvironment (env_wrappers/logger.py) on a config without
+    randomness (tether_zoo level 0): the episode files it writes, as one JSON fixture."""
+    import json
+    import shutil
+    import tempfile
+    from moog.env_wrappers import logger as ref_logger
+    cfg = load_amd_config('tether_zoo_l0')
+    tmp = tempfile.mkdtemp()
+    env = ref_logger.LoggingEnvironment(environment.Environment(**cfg), log_dir=tmp)
+    rs = np.random.RandomState(3)
+    actions = rs.uniform(-1., 1., size=(45, 2))
+    env.reset()
+    for a in actions:
+        env.step(a)
+    run_dir = env._log_dir
+    episodes = []
+    for fn in sorted(os.listdir(run_dir)):
+        if fn.isdigit():
+            with open(os.path.join(run_dir, fn)) as f:
+                episodes.append(json.load(f))
+    with open(os.path.join(run_dir, 'attributes.txt')) as f:
+        attributes = json.load(f)
+    with open(os.path.join(run_dir, 'description.txt')) as f:
+        description = f.read()
+    shutil.rmtree(tmp)
+    path = os.path.join(HERE, 'logger_tether_zoo_l0.json')
+    with open(path, 'w') as f:
+        json.dump({'attributes': attributes, 'description': description, 'actions': actions.tolist(),
+                   'episodes': episodes}, f)
+    print('logger fixture: %d episodes, %d steps  %.0f KB' % (
+        len(episodes), sum(len(e) for e in episodes), os.path.getsize(path) / 1024.))
+
+
 def main():
+    if sys.argv[1:] == ['logger']:
+        make_logger_fixture()
+        return
     make_collision_kat()   # before np.random is patched (uses no randomness anyway)
     make_predicates()
     make_raster()

@@ -472,3 +472,60 @@ def test_tether_zipped_layer_mismatch_raises():
     env.step(np.zeros((2, 2)))
     with pytest.raises(ValueError):
         env.raise_faults()
+
+
+def test_logging_wrapper_writes_the_reference_format(tmp_path):
+    """LoggingEnvironment (env_wrappers/logger.py:33-224): same files, same step structure
+    and the same logged values as the reference's logger on the same action script (fixture:
+    tests/golden/logger_tether_zoo_l0.json, a config without randomness)."""
+    import json
+    import os
+    from moog import environment
+    from moog.env_wrappers import logger
+    from moog_demos import example_configs
+    with open(os.path.join(helpers.GOLDEN, 'logger_tether_zoo_l0.json')) as f:
+        ref = json.load(f)
+    env = logger.LoggingEnvironment(
+        environment.Environment(keep_sprite_factors=True, **example_configs.load('tether_zoo_l0')),
+        log_dir=str(tmp_path))
+    env.reset()
+    for a in ref['actions']:
+        env.step(np.array(a))
+    files = sorted(fn for fn in os.listdir(env.log_dir) if fn.isdigit())
+    assert files == ['%05d' % i for i in range(len(ref['episodes']))]
+    with open(os.path.join(env.log_dir, 'attributes.txt')) as f:
+        assert json.load(f) == ref['attributes']
+    with open(os.path.join(env.log_dir, 'description.txt')) as f:
+        assert f.read() == ref['description']
+    id_col = ref['attributes'].index('id')
+    for fn, ref_ep in zip(files, ref['episodes']):
+        with open(os.path.join(env.log_dir, fn)) as f:
+            ep = json.load(f)
+        assert len(ep) == len(ref_ep)
+        ids, ref_ids = {}, {}
+        for step, ref_step in zip(ep, ref_ep):
+            assert [k for k, _ in step[:5]] == [k for k, _ in ref_step[:5]] == [
+                'time', 'reward', 'step_type', 'action', 'meta_state']
+            assert step[1][1] == ref_step[1][1] and step[2][1] == ref_step[2][1]
+            assert np.allclose(step[3][1], ref_step[3][1]) and step[4][1] == ref_step[4][1]
+            assert [l[0] for l in step[5]] == [l[0] for l in ref_step[5]]
+            for (_, sprites), (_, ref_sprites) in zip(step[5], ref_step[5]):
+                assert len(sprites) == len(ref_sprites)
+                for s, r in zip(sprites, ref_sprites):
+                    assert len(s) == len(r), 'vertices are logged on the same steps'
+                    for j, (a, b) in enumerate(zip(s, r)):
+                        if j == id_col:      # ids differ, identity over time must not
+                            continue
+                        if isinstance(b, (int, float)) and not isinstance(b, bool):
+                            assert abs(a - b) <= 1e-9, (ref['attributes'][j], a, b)
+                        elif isinstance(b, list):
+                            assert np.allclose(a, b, atol=1e-9)
+                        else:
+                            assert a == b, (ref['attributes'][j], a, b)
+            # the same sprite keeps the same id from step to step in both logs
+            cur = [s[id_col] for _, sprites in step[5] for s in sprites]
+            ref_cur = [s[id_col] for _, sprites in ref_step[5] for s in sprites]
+            same = [c in ids for c in cur]
+            ref_same = [c in ref_ids for c in ref_cur]
+            assert same == ref_same
+            ids, ref_ids = set(cur), set(ref_cur)
