@@ -91,6 +91,7 @@ class BatchedEnvironment(object):
         self._out.step_type = ctypes.cast(self.step_type.data_ptr(), ctypes.POINTER(ctypes.c_int32))
         self._out.image = ctypes.cast(self.image.data_ptr(), ctypes.POINTER(ctypes.c_uint8))
         self._is_grid = P.action.kind == _abi.MOOG_ACTION_GRID
+        self._dynamic_layers = any(P.layer_dynamic[i] for i in range(P.n_layers))
         self.check_faults = True
         self._cost = self._perm = None
 
@@ -185,7 +186,9 @@ class BatchedEnvironment(object):
                 self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,
                 ctypes.byref(self._out), self._stream()))
         self._last_action = a
-        if self.check_faults and injected_uniforms is not None:
+        # Programs whose rules append to layers can overflow a layer's capacity at any step:
+        # surface that (one host sync per step; set check_faults = False to opt out).
+        if self.check_faults and (injected_uniforms is not None or self._dynamic_layers):
             self.raise_faults()
         del keep
         return self._timestep()

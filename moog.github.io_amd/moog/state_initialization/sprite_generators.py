@@ -35,3 +35,25 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
         return sprites
 
     return _generate
+
+
+def chain_generators(*sprite_generators):
+    """Concatenates the sprites of several generators (sprite_generators.py:110-128); each
+    component stays its own generation op, run in order."""
+    def _generate(*args, **kwargs):
+        out = []
+        for g in sprite_generators:
+            out.extend(g(*args, **kwargs))
+        return out
+    return _generate
+
+
+def sample_generator(sprite_generators, p=None):
+    """sprite_generators.py:131-154 picks one generator at random per call; the device sampler
+    has no conditional generation ops yet."""
+    raise NotImplementedError('sample_generator is not lowered to the device sampler')
+
+
+def shuffle(sprite_generator):
+    """sprite_generators.py:157-183 permutes the generated sprites; not lowered yet."""
+    raise NotImplementedError('shuffle is not lowered to the device sampler')

@@ -529,3 +529,17 @@ def test_logging_wrapper_writes_the_reference_format(tmp_path):
             ref_same = [c in ref_ids for c in ref_cur]
             assert same == ref_same
             ids, ref_ids = set(cur), set(ref_cur)
+
+
+def test_dynamic_layer_overflow_is_reported():
+    """The reference's layers are unbounded Python lists; the engine's have a capacity
+    (`layer_capacity`).  Appending to a full layer sets a fault that surfaces as RuntimeError."""
+    from moog import environment
+    from moog_demos import example_configs
+    env = environment.BatchedEnvironment(num_envs=64, seed=2, layer_capacity={'predators': 1, 'prey': 1},
+                                         **example_configs.load('rules_zoo_l1'))
+    env.reset()
+    with pytest.raises(RuntimeError):
+        for _ in range(12):
+            env.step(np.zeros((64, 2)))
+    assert bool((env.field('alive')[:, env.compiled.layer_slots['predators'][0]]).any())

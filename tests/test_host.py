@@ -195,3 +195,24 @@ def test_config_callables_are_traced_symbolically():
     assert set(mod) == {'x', 'y'} and mod['x'].op == 'rem' and not vec
     with pytest.raises(sy.Unsupported):
         sy.trace_value(lambda s: s.metadata['k'], 1)
+
+
+def test_chain_generators_is_a_sequence_of_ops():
+    """chain_generators (sprite_generators.py:110-128): the chained generators stay separate
+    generation ops in call order."""
+    import collections
+    from moog import action_spaces, observers, physics as physics_lib, tasks
+    from moog.state_initialization import distributions as distribs, sprite_generators as sg
+    fa = distribs.Product([distribs.Continuous('x', 0., 1.)], y=0.2, shape='square', scale=0.05)
+    fb = distribs.Product([distribs.Continuous('y', 0., 1.)], x=0.8, shape='circle', scale=0.05)
+    gen = sg.chain_generators(sg.generate_sprites(fa, num_sprites=2), sg.generate_sprites(fb, num_sprites=3))
+    c = _compiler.compile_config(
+        state_initializer=lambda: collections.OrderedDict([('things', gen())]),
+        physics=physics_lib.Physics(), task=tasks.CompositeTask(timeout_steps=5),
+        action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='things'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))})
+    P = c.program
+    assert P.n_ops == 2 and (P.ops[0].slot0, P.ops[0].count_max) == (0, 2)
+    assert (P.ops[1].slot0, P.ops[1].count_max) == (2, 3)
+    with pytest.raises(NotImplementedError):
+        sg.shuffle(gen)
