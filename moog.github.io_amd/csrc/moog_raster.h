@@ -267,18 +267,23 @@ __device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ym
 // partner's entry, whose value equals this edge's crossing x, i.e. "remove one x,
 // insert vv".  More than N crossings or a second fix-up on the same row (the
 // partner's entry might already be modified) report `overflow`.
-template <int N>
-__device__ inline RMask scanline_regs(const RPoly& p, int y, int poly_ymax, int W, bool* overflow) {
+// BITS: `bits` has bit i set for every table edge i whose row range contains y (built once per
+// frame by the edge threads, phase 3b), so the loop visits only the edges that cross the row
+// instead of the whole table (a 30-gon has 28 table edges, a row crosses ~6 of them).
+template <int N, bool BITS>
+__device__ inline RMask scanline_regs(const RPoly& p, int y, int poly_ymax, int W, bool* overflow,
+                                      unsigned long long bits) {
   const float INF = __builtin_inff();
   float r[N];
 #pragma unroll
   for (int q = 0; q < N; ++q) r[q] = INF;
   int j = 0, nfix = 0;
-  for (int i = 0; i < p.nt; ++i) {
+  for (int i = 0; BITS ? (bits != 0ull) : (i < p.nt); ++i) {
+    if (BITS) { i = __ffsll((long long)bits) - 1; bits &= bits - 1ull; }
     REdge E = p.e[i];
     int y0 = E.y0, y1 = E.y1;
     int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
-    bool active = (y >= emin) && (y <= emax);
+    bool active = BITS || ((y >= emin) && (y <= emax));
     float x = (float)(y - y0) * E.dx + (float)E.x0;
     bool dup = active && (y == emax) && (y < poly_ymax);
     j += (active ? 1 : 0) + (dup ? 1 : 0);
@@ -335,10 +340,19 @@ __device__ inline RMask scanline_regs(const RPoly& p, int y, int poly_ymax, int 
 
 // 8 sorted registers cover ~99 % of the rows; rows with 9..16 crossings (spoked
 // shapes) re-run with 16; anything beyond is queued for the generic LDS routine.
-__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int W, bool* need_generic) {
+template <bool BITS>
+__device__ inline RMask scanline_mask(const RPoly& p, int y, int poly_ymax, int W, bool* need_generic,
+                                      unsigned long long bits) {
   bool over = false;
-  RMask m = scanline_regs<8>(p, y, poly_ymax, W, &over);
-  if (over) m = scanline_regs<16>(p, y, poly_ymax, W, &over);
+  RMask m;
+  // A wave whose rows include one with many crossings (the top / bottom rows of a small
+  // circle hold a dozen sub-pixel edges) would run the 8-register pass for nothing.
+  if (BITS && __any(__popcll(bits) > 6)) {
+    m = scanline_regs<16, BITS>(p, y, poly_ymax, W, &over, bits);
+  } else {
+    m = scanline_regs<8, BITS>(p, y, poly_ymax, W, &over, bits);
+    if (over) m = scanline_regs<16, BITS>(p, y, poly_ymax, W, &over, bits);
+  }
   *need_generic = over;
   return m;
 }
@@ -446,6 +460,29 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   }
   __syncthreads();
   if (a.debug_stop == 2) return;
+  // ---- 3 (ahead of 2, whose barriers publish it): exclusive scan of the clamped row counts
+  //         of all items (wave 0)
+  if (tid < 64) {
+    int run = 0;
+    for (int i0 = 0; i0 < total_items; i0 += 64) {
+      int it = i0 + tid;
+      int cnt = 0;
+      if (it < total_items) {
+        int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
+        if (y0 < 0) y0 = 0;
+        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
+        cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
+      }
+      int inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (tid >= o) inc += t;
+      }
+      if (it < total_items) rowoff[it] = run + inc - cnt;
+      run += __shfl(inc, 63);
+    }
+    if (tid == 0) rowoff[total_items] = run;
+  }
   // ---- 2: edges (ImagingDrawPolygon: add_edge + merge of horizontal runs), packed per
   //         polygon: table edges from the front, horizontal heads from the back.  The
   //         in-polygon ranks come from wave ballots (a polygon's vertices are contiguous
@@ -557,30 +594,37 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   }
   if (a.debug_stop == 3) return;
 
-  // ---- 3: exclusive scan of the clamped row counts of all items (wave 0) ----------------
-  if (tid < 64) {
-    int run = 0;
-    for (int i0 = 0; i0 < total_items; i0 += 64) {
-      int it = i0 + tid;
-      int cnt = 0;
-      if (it < total_items) {
-        int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
-        if (y0 < 0) y0 = 0;
-        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
-        cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
-      }
-      int inc = cnt;
-      for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (tid >= o) inc += t;
-      }
-      if (it < total_items) rowoff[it] = run + inc - cnt;
-      run += __shfl(inc, 63);
-    }
-    if (tid == 0) rowoff[total_items] = run;
-  }
   __syncthreads();   // also: the integer vertices are dead from here on (masks alias them)
   if (a.debug_stop == 4) return;
+
+  // ---- 3b: per (item, row) the set of table edges whose row range contains the row, as a
+  //          64-bit mask kept where the row's coverage mask goes later (each row's thread
+  //          reads it before it writes the mask).  One thread per table edge ORs its bit
+  //          into the rows it spans.  Used when all rows fit in one pass and no polygon has
+  //          more than 64 edges; the scanline then visits only those edges.
+  const bool use_bits = (rowoff[total_items] <= cap_rows) && (a.xxcap <= 128);
+  if (use_bits) {
+    const int nrows = rowoff[total_items];
+    for (int i = tid; i < nrows; i += R_THREADS) masks[(size_t)i * words] = 0ull;
+    __syncthreads();
+    for (int c = 0; c < ncopy; ++c) {
+      for (int idx = tid; idx < TOTV; idx += R_THREADS) {
+        int s = a.vslot[idx];
+        int rank = slotinfo[4 * s];
+        if (rank < 0) continue;
+        int g = rank * ncopy + c;
+        int k = idx - slotinfo[4 * s + 2];
+        if (k >= (item_cnt[g] & 0xffff)) continue;
+        REdge E = edges[c * TOTV + idx];
+        int emin = E.y0 < E.y1 ? E.y0 : E.y1, emax = E.y0 < E.y1 ? E.y1 : E.y0;
+        int ymin = item_y[2 * g];
+        int wbase = rowoff[g] - (ymin < 0 ? 0 : ymin);
+        int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
+        const unsigned long long bit = 1ull << k;
+        for (int y = ya; y <= yb; ++y) atomicOr(&masks[(size_t)(wbase + y) * words], bit);
+      }
+    }
+  }
 
   const int segs = (H * W) / 16;   // 16-pixel row segments
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
@@ -619,7 +663,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       int cnt = item_cnt[g];
       RPoly poly = {edges + c * TOTV + slotinfo[4 * s + 2], slotinfo[4 * s + 1], cnt & 0xffff, cnt >> 16};
       bool generic = false;
-      RMask m = scanline_mask(poly, y, pymax, W, &generic);
+      RMask m = use_bits ? scanline_mask<true>(poly, y, pymax, W, &generic, masks[(size_t)w * words])
+                         : scanline_mask<false>(poly, y, pymax, W, &generic, 0ull);
       if (generic) {
         queue[atomicAdd(&misc[1], 1)] = (unsigned short)w;
       } else {
