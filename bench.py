@@ -168,7 +168,11 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    env.set_timing(True)
+    # the roofline kernel (raster) is timed live, with HIP events around every one of its
+    # launches in the timed region; the other kernels' averages come from a short extra run
+    # afterwards so that their event pairs do not sit in the timed stream (each pair costs
+    # stream time: ~9 us around the 6 us reset kernel)
+    env.set_timing(True, kernels=[_abi.MOOG_K_RASTER])
     for k in range(_abi.MOOG_K_COUNT):
         env.kernel_time(k)   # clear
     barrier()
@@ -181,8 +185,18 @@ def main():
     # MAX over ranks, off the timed path (RCCL needs the tensor on the GPU, gloo on the host)
     dt_max = sharding.max_over_ranks(dt, device=dev if backend == 'nccl' else None)
 
-    k_ms = {name: env.kernel_time(kid) for name, kid in
-            (('step', _abi.MOOG_K_STEP), ('raster', _abi.MOOG_K_RASTER), ('reset', _abi.MOOG_K_RESET))}
+    k_ms = {'raster': env.kernel_time(_abi.MOOG_K_RASTER)}
+    # all kernels, outside the timed region; as many steps again, because the workload is
+    # periodic (episodes time out together every 200 steps: sparse right after a reset,
+    # clustered contacts later), so a shorter window would not be representative
+    env.set_timing(True)
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize(dev)
+    env.set_timing(False)
+    env.kernel_time(_abi.MOOG_K_RASTER)
+    k_ms['step'] = env.kernel_time(_abi.MOOG_K_STEP)
+    k_ms['reset'] = env.kernel_time(_abi.MOOG_K_RESET)
     faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
     if rank == 0:
         total_steps = n * world * args.steps

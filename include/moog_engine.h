@@ -522,8 +522,9 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
  * cost so that the expensive envs (clustered contacts) start first.  NULLs disable. */
 int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* cost_dev);
 
-/* Per-kernel device timing: when enabled every launch is bracketed by HIP
- * events on the launch stream; totals are read back (synchronising) here. */
+/* Per-kernel device timing: `enabled` is a bit mask over MOOG_K_* (bit k set: every launch
+ * of kernel k is bracketed by HIP events on the launch stream; 0 disables); totals are read
+ * back (synchronising) by moog_engine_kernel_time. */
 int moog_engine_set_timing(moog_engine_t* e, int32_t enabled);
 int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_ms,
                             int64_t* launches);

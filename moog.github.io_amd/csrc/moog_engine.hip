@@ -215,7 +215,7 @@ struct moog_engine {
   size_t step_lds = 0, raster_lds = 0;
   bool dynamic_rules = false;
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
-  bool timing = false;
+  int timing = 0;   // bit k: launches of kernel k are bracketed by HIP events
   const int32_t* perm = nullptr;
   float* cost = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
@@ -369,10 +369,10 @@ int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view) {
 struct Bracket {
   moog_engine* e; int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
   Bracket(moog_engine* e_, int id_, hipStream_t s_) : e(e_), id(id_), s(s_) {
-    if (e->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    if ((e->timing >> id) & 1) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
   }
   ~Bracket() {
-    if (e->timing) { hipEventRecord(b, s); e->timed[id].pending.emplace_back(a, b); }
+    if (a) { hipEventRecord(b, s); e->timed[id].pending.emplace_back(a, b); }
   }
 };
 
@@ -487,7 +487,7 @@ int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* c
 
 int moog_engine_set_timing(moog_engine_t* e, int32_t enabled) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
-  e->timing = enabled != 0;
+  e->timing = enabled;
   return MOOG_OK;
 }
 

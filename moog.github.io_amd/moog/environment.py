@@ -261,8 +261,15 @@ class BatchedEnvironment(object):
         return self.state_i32[:, self.layout.o_step_count]
 
     # -- kernel timing -------------------------------------------------------------------
-    def set_timing(self, enabled):
-        _engine.check(self._lib, self._lib.moog_engine_set_timing(self._handle, int(bool(enabled))))
+    def set_timing(self, enabled, kernels=None):
+        """Brackets kernel launches with HIP events: all kernels, or only the MOOG_K_* ids in
+        `kernels` (every event pair costs a few microseconds of stream time)."""
+        mask = 0
+        if enabled:
+            ids = range(_abi.MOOG_K_COUNT) if kernels is None else kernels
+            for k in ids:
+                mask |= 1 << int(k)
+        _engine.check(self._lib, self._lib.moog_engine_set_timing(self._handle, mask))
 
     def kernel_time(self, kernel_id):
         ms, cnt = ctypes.c_double(), ctypes.c_int64()
