@@ -42,10 +42,14 @@ __device__ __forceinline__ PProg as_const_prog(const moog_program_t* p) {
 #define DINF (__builtin_inf())
 
 struct Env {
-  double* f;               // LDS f64 record
-  int32_t* q;              // LDS i32 record
+  double* f;               // LDS f64 record (hot fields only, see HotLayout)
+  int32_t* q;              // LDS i32 record (hot fields only)
   PProg P;                 // lowered config (constant address space)
-  moog_layout_t L;
+  moog_layout_t L;         // layout of the LDS records
+  double* gcol;            // this env's colours / opacity / shape ids in HBM: fields the step
+  int32_t* gopa;           //   path never reads are not staged in LDS (LDS per env sets how many
+  int32_t* gshape;         //   envs a CU holds, and the kernels scale with resident waves)
+  int32_t* gtele;          // Portal bookkeeping bits, likewise
   const double* inj;
   int inj_n;
   uint64_t seed;
@@ -54,7 +58,6 @@ struct Env {
   float* bb;               // LDS scratch [S][8]: conservative 8-DOP (lo x, y, x+y, x-y; hi x, y, x+y, x-y)
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
-  uint8_t* vsl;            // LDS copy of vslot [TOTV]
   unsigned cur_fmask;      // float32 factors of the sprite being created
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
@@ -70,14 +73,14 @@ struct Env {
 #define ANG(s) (e.f[e.L.o_angle + (s)])
 #define ANGV(s) (e.f[e.L.o_angvel + (s)])
 #define MASS(s) (e.f[e.L.o_mass + (s)])
-#define COL(s, c) (e.f[e.L.o_color + 3 * (s) + (c)])
+#define COL(s, c) (e.gcol[3 * (s) + (c)])
 #define INER(s, c) (e.f[e.L.o_inertia + 2 * (s) + (c)])
 #define MAXR(s) (e.f[e.L.o_maxr + (s)])
 #define FLAGS(s) (e.q[e.L.o_flags + (s)])
 #define NV(s) (e.q[e.L.o_nverts + (s)])
-#define OPAC(s) (e.q[e.L.o_opacity + (s)])
-#define SHAPEID(s) (e.q[e.L.o_shape + (s)])
-#define TELE(s) (e.q[e.L.o_tele + (s)])
+#define OPAC(s) (e.gopa[(s)])
+#define SHAPEID(s) (e.gshape[(s)])
+#define TELE(s) (e.gtele[(s)])
 #define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
 #define VALIAS(s) (e.q[e.L.o_valias + (s)])
@@ -460,7 +463,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
   for (int base = 0; base < TOTV; base += 64) {
     int idx = base + e.lane;
     bool in = idx < TOTV;
-    int s = in ? (int)e.vsl[idx] : 0;
+    int s = in ? (int)e.vslot[idx] : 0;   // vertex -> slot table (shared by all envs, cache resident)
     double x0, x1, x2, x3, x4, x5, mode;
     if (in_regs) {
       x0 = shfl_d(r0, s); x1 = shfl_d(r1, s); x2 = shfl_d(r2, s); x3 = shfl_d(r3, s);
@@ -1448,6 +1451,7 @@ __device__ inline void run_modifier(Env& e, int xmod, int s) {
     if (sf) FMASK(s) = fm;
     if (has(MOOG_XA_OPACITY)) OPAC(s) = (int32_t)op;
   }
+  __threadfence();   // colours / opacity live in HBM: later rules of this launch may read them
   wsync();
 }
 
@@ -1475,6 +1479,7 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
     if (e.P->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
     FLAGS(src) = 0; NV(src) = 0;
   }
+  __threadfence();
   wsync();
 }
 
@@ -1644,6 +1649,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (e.lane == 0) FLAGS(s) |= MOOG_F_ALIVE;
         wsync();
       }
+      __threadfence();   // the new sprites' colours / opacity / shape ids are in HBM
       return;
     }
   }
@@ -1718,6 +1724,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (entry < 0) {
           wsync();
           if (e.lane == 0) TELE(s) = tele & ~(1 << ri);
+          __threadfence();   // the Portal bits live in HBM
           wsync();
           continue;
         }
@@ -1732,6 +1739,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         }
         set_position(e, s, PX(exs), PY(exs));
         if (e.lane == 0) TELE(s) = tele | (1 << ri);
+        __threadfence();
         wsync();
       }
       break;
@@ -1752,6 +1760,8 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             double c2 = 1. - (1. - COL(agent, 2)) * R->p1;
             wsync();
             if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+          __threadfence();
+            __threadfence();
             cnt = R->p2;
           }
         } else if (cnt <= 0) {
@@ -1759,6 +1769,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           double c2 = 1. - (1. - COL(agent, 2)) / R->p1;
           wsync();
           if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+          __threadfence();
           cnt = DINF;
         }
       }
@@ -1777,6 +1788,7 @@ __device__ inline void rule_reset(Env& e, int ri) {
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
+  __threadfence();
   if (e.lane == 0) e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 : DINF;   // timing.py:47
   wsync();
 }
@@ -2204,9 +2216,11 @@ __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
   for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; vel_unshare(e, s); }
+  __threadfence();
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();
   for (int oi = 0; oi < P->n_ops; ++oi) run_genop(e, oi);
+  __threadfence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {
     for (int t = 0; t < P->n_tasks; ++t) e.f[e.L.o_task + t] = DINF;

@@ -22,31 +22,89 @@
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
 // =====================================================================================
-__device__ inline void load_record(const Env& e, const double* gf, const int32_t* gq) {
+// Hot layout: the records as staged in LDS.  The colour triples (f64) and the opacity / shape-id
+// words (i32) are read by the rasteriser only, so the step / reset kernels leave them in HBM
+// (Env::gcol / gopa / gshape): the staged records are the HBM records with those two ranges,
+// shrunk inward to 16-byte boundaries, cut out.
+struct HotLayout {
+  moog_layout_t L;            // offsets inside the LDS records
+  int32_t f_cut0, f_cut1;     // removed range of the f64 record (doubles, multiples of 2)
+  int32_t i_cut0, i_cut1;     // removed range of the i32 record (ints, multiples of 4)
+};
+
+__host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
+  HotLayout h;
+  h.L = G;
+  const int S = G.S;
+  // A range is cut only when it is 16-byte aligned as a whole (S even): a partially staged
+  // field would be written back over the values the kernels write to HBM directly.
+  const bool f_ok = (G.o_color % 2 == 0) && ((3 * S) % 2 == 0);
+  h.f_cut0 = G.o_color;
+  h.f_cut1 = f_ok ? G.o_color + 3 * S : G.o_color;
+  const int fc = h.f_cut1 - h.f_cut0;
+  // fields behind the colours (moog_layout(): inertia, maxr, action, task, rule, scale, aspect, verts)
+  h.L.o_inertia -= fc; h.L.o_maxr -= fc; h.L.o_action -= fc; h.L.o_task -= fc; h.L.o_rule -= fc;
+  if (G.o_scale >= 0) { h.L.o_scale -= fc; h.L.o_aspect -= fc; }
+  h.L.o_verts -= fc; h.L.f64_per_env -= fc;
+  // opacity, shape ids and the Portal bits are adjacent ([S] each)
+  const bool i_ok = (G.o_opacity % 4 == 0) && ((3 * S) % 4 == 0) && (G.o_shape == G.o_opacity + S) &&
+                    (G.o_tele == G.o_shape + S);
+  h.i_cut0 = G.o_opacity;
+  h.i_cut1 = i_ok ? G.o_opacity + 3 * S : G.o_opacity;
+  const int ic = h.i_cut1 - h.i_cut0;
+  if (G.o_valias >= 0) h.L.o_valias -= ic;
+  if (G.o_fmask >= 0) h.L.o_fmask -= ic;
+  h.L.o_step_count -= ic; h.L.o_reset_next -= ic; h.L.o_fault -= ic; h.L.o_rng -= ic;
+  h.L.i32_per_env -= ic;
+  return h;   // o_color / o_opacity / o_shape keep their values: valid in LDS when nothing was cut
+}
+
+// =====================================================================================
+// record staging: HBM <-> LDS, 16 bytes per lane, coalesced
+// =====================================================================================
+__device__ inline void load_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
+                                   const double* gf, const int32_t* gq) {
   const double2* src = reinterpret_cast<const double2*>(gf);
   double2* dst = reinterpret_cast<double2*>(e.f);
-  for (int i = e.lane; i < e.L.f64_per_env / 2; i += 64) dst[i] = src[i];
+  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
+  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
+    if (i < fa) dst[i] = src[i];
+    else if (i >= fb) dst[i - (fb - fa)] = src[i];
+  }
   const int4* srci = reinterpret_cast<const int4*>(gq);
   int4* dsti = reinterpret_cast<int4*>(e.q);
-  for (int i = e.lane; i < e.L.i32_per_env / 4; i += 64) dsti[i] = srci[i];
+  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
+  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
+    if (i < ia) dsti[i] = srci[i];
+    else if (i >= ib) dsti[i - (ib - ia)] = srci[i];
+  }
   for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
-  for (int i = e.lane; i < e.L.TOTV; i += 64) e.vsl[i] = (uint8_t)e.vslot[i];
   wsync();
 }
 
-__device__ inline void store_record(const Env& e, double* gf, int32_t* gq) {
+__device__ inline void store_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
+                                    double* gf, int32_t* gq) {
   wsync();
   double2* dst = reinterpret_cast<double2*>(gf);
   const double2* src = reinterpret_cast<const double2*>(e.f);
-  for (int i = e.lane; i < e.L.f64_per_env / 2; i += 64) dst[i] = src[i];
+  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
+  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
+    if (i < fa) dst[i] = src[i];
+    else if (i >= fb) dst[i] = src[i - (fb - fa)];
+  }
   int4* dsti = reinterpret_cast<int4*>(gq);
   const int4* srci = reinterpret_cast<const int4*>(e.q);
-  for (int i = e.lane; i < e.L.i32_per_env / 4; i += 64) dsti[i] = srci[i];
+  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
+  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
+    if (i < ia) dsti[i] = srci[i];
+    else if (i >= ib) dsti[i] = srci[i - (ib - ia)];
+  }
 }
 
 struct KArgs {
   const moog_program_t* P;
-  moog_layout_t L;
+  moog_layout_t L;       // layout of the records in HBM (the ABI's)
+  HotLayout H;           // layout of the records staged in LDS
   double* f64;
   int32_t* i32;
   const void* actions;
@@ -72,16 +130,27 @@ extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
 __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.P = as_const_prog(a.P);
-  e.L = a.L;
+  e.L = a.H.L;
+  const moog_layout_t& H = a.H.L;
   e.f = reinterpret_cast<double*>(moog_lds);
-  e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)a.L.f64_per_env * 8);
-  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)a.L.f64_per_env * 8 + (size_t)a.L.i32_per_env * 4);
-  e.xf = reinterpret_cast<double*>(e.bb + 8 * a.L.S);       // [S][8] only when S > 64
-  double* after_xf = (a.L.S > 64) ? e.xf + 8 * a.L.S : e.xf;
+  e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)H.f64_per_env * 8);
+  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
+  e.xf = reinterpret_cast<double*>(e.bb + 8 * H.S);       // [S][8] only when S > 64
+  double* after_xf = (H.S > 64) ? e.xf + 8 * H.S : e.xf;
   e.voff = reinterpret_cast<int32_t*>(after_xf);
-  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((a.L.S + 3) & ~3));
+  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
-  e.vsl = e.lst + 128;
+  if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
+  else e.gcol = e.f + H.o_color;
+  if (a.H.i_cut1 > a.H.i_cut0) {
+    e.gopa = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_opacity;
+    e.gshape = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_shape;
+    e.gtele = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_tele;
+  } else {
+    e.gopa = e.q + H.o_opacity;
+    e.gshape = e.q + H.o_shape;
+    e.gtele = e.q + H.o_tele;
+  }
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0;
@@ -105,7 +174,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   Env e;
   bind_env(e, a, env);
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  load_record(e, gf, gq);
+  load_record(e, a.H, a.L, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
   env_reset(e);
@@ -116,7 +185,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
     if (a.discount) a.discount[env] = __builtin_nan("");
     if (a.step_type) a.step_type[env] = 0;
   }
-  store_record(e, gf, gq);
+  store_record(e, a.H, a.L, gf, gq);
 }
 
 // DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
@@ -137,7 +206,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   bind_env(e, a, env);
   const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  load_record(e, gf, gq);
+  load_record(e, a.H, a.L, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
   bbox_build_all(e);
@@ -145,7 +214,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
     for (int k = 0; k < K; ++k) apply_physics(e);
-    store_record(e, gf, gq);
+    store_record(e, a.H, a.L, gf, gq);
     return;
   }
   // environment.py:98-126
@@ -174,7 +243,7 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
     if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
-  store_record(e, gf, gq);
+  store_record(e, a.H, a.L, gf, gq);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);
@@ -270,9 +339,10 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       err = hipMemcpy(e->d_vslot, vs.data(), vs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
-  e->step_lds = (size_t)e->L.f64_per_env * 8 + (size_t)e->L.i32_per_env * 4 +
+  const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
+  e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
                 (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
-                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + (size_t)((e->L.TOTV + 15) & ~15) + 16;
+                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 16;
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     hipFree(e->d_prog); delete e;
@@ -379,7 +449,7 @@ struct Bracket {
 static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t* inj,
                        const moog_step_out_t* out, int mode, const uint8_t* mask) {
   KArgs a;
-  a.P = e->d_prog; a.L = e->L; a.f64 = e->view.f64; a.i32 = e->view.i32;
+  a.P = e->d_prog; a.L = e->L; a.H = hot_layout(e->L); a.f64 = e->view.f64; a.i32 = e->view.i32;
   a.actions = actions;
   a.inj = (inj && inj->uniforms) ? inj->uniforms : nullptr;
   a.inj_n = (inj && inj->uniforms) ? inj->per_env : 0;
