@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 9
+#define MOOG_ABI_VERSION 10
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -515,12 +515,14 @@ int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject,
 /* env.observation() only (environment.py:128-131, runtime_benchmark.py:113-130). */
 int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
 
-/* Optional launch-order schedule for the step kernel (pure performance hint, results
- * do not depend on it).  `cost_dev` (float[n_envs], borrowed) receives every env's
- * shader-clock cycles of the last step; `perm_dev` (int32[n_envs], borrowed) is the order
- * in which workgroups pick envs -- the host typically keeps it sorted by descending
- * cost so that the expensive envs (clustered contacts) start first.  NULLs disable. */
-int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* cost_dev);
+/* Optional launch-order schedule for the step kernel (pure performance hint, results do
+ * not depend on it).  `cost_dev` (float[n_envs], borrowed) receives every env's shader-clock
+ * cycles of the last step; `perm_dev` (int32[n_envs], borrowed, initialised by the caller to a
+ * permutation, e.g. the identity) is the order in which workgroups pick envs.  After every
+ * step the engine re-sorts it by descending cost (counting sort on a side stream, overlapped
+ * with the rasteriser) so that the expensive envs (clustered contacts) start first instead of
+ * landing in the under-filled tail of the launch.  NULLs disable. */
+int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_dev);
 
 /* Per-kernel device timing: `enabled` is a bit mask over MOOG_K_* (bit k set: every launch
  * of kernel k is bracketed by HIP events on the launch stream; 0 disables); totals are read

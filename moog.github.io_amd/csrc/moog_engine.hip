@@ -188,6 +188,51 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   store_record(e, a.H, a.L, gf, gq);
 }
 
+// Launch order for the next step: envs in (approximately) descending order of the cycles they
+// took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
+// counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
+// The order inside a bin is arbitrary -- the schedule never changes a result.
+#define SCHED_BINS 1024
+__global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int32_t* perm, int n) {
+  __shared__ int hist[SCHED_BINS];
+  __shared__ float red[16];
+  const int t = threadIdx.x;
+  float m = 0.f;
+  for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  hist[t] = 0;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  const float scale = m > 0.f ? (float)(SCHED_BINS - 1) / m : 0.f;
+  // bin 0 = most expensive
+  for (int i = t; i < n; i += 1024) {
+    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
+    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the 1024 bins (one bin per thread, Hillis-Steele in LDS)
+  int v = hist[t];
+  __syncthreads();
+  for (int o = 1; o < SCHED_BINS; o <<= 1) {
+    int add = (t >= o) ? hist[t - o] : 0;
+    __syncthreads();
+    hist[t] += add;
+    __syncthreads();
+  }
+  const int start = hist[t] - v;
+  __syncthreads();
+  hist[t] = start;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
+    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
+    perm[atomicAdd(&hist[b], 1)] = i;
+  }
+}
+
 // DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
 // ChangeLayer, VanishByFilter): that variant carries the reset path's sampler; the plain one
 // is what the benchmark configs run.
@@ -285,7 +330,10 @@ struct moog_engine {
   bool dynamic_rules = false;
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
   int timing = 0;   // bit k: launches of kernel k are bracketed by HIP events
-  const int32_t* perm = nullptr;
+  int32_t* perm = nullptr;
+  hipStream_t sched_stream = nullptr;   // the launch-order sort runs beside the rasteriser
+  hipEvent_t ev_step_done = nullptr, ev_sched_done = nullptr;
+  bool sched_pending = false;
   float* cost = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
 };
@@ -416,6 +464,11 @@ static void drain(TimedKernel& t) {
 int moog_engine_destroy(moog_engine_t* e) {
   if (!e) return MOOG_OK;
   for (int k = 0; k < MOOG_K_COUNT; ++k) drain(e->timed[k]);
+  if (e->sched_stream) {
+    hipStreamSynchronize(e->sched_stream);
+    hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
+    hipStreamDestroy(e->sched_stream);
+  }
   if (e->d_prog) hipFree(e->d_prog);
   if (e->d_vslot) hipFree(e->d_vslot);
   delete e;
@@ -517,12 +570,23 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   a.mode = MODE_STEP;
   a.perm = e->perm;
   a.cost = e->cost;
+  if (e->sched_pending) {   // the order computed from the previous step's costs
+    HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
+    e->sched_pending = false;
+  }
   {
     Bracket br(e, MOOG_K_STEP, s);
     if (e->dynamic_rules) hipLaunchKernelGGL(moog_step_kernel<true>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
     else hipLaunchKernelGGL(moog_step_kernel<false>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
+  if (e->perm && e->cost) {
+    HIPCHK(hipEventRecord(e->ev_step_done, s));
+    HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
+    hipLaunchKernelGGL(moog_sched_kernel, dim3(1), dim3(1024), 0, e->sched_stream, e->cost, e->perm, e->n_envs);
+    HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
+    e->sched_pending = true;
+  }
   if (out && out->image) return launch_raster(e, out->image, s);
   return MOOG_OK;
 }
@@ -548,10 +612,17 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream) {
   return launch_raster(e, image_dev, (hipStream_t)hip_stream);
 }
 
-int moog_engine_set_schedule(moog_engine_t* e, const int32_t* perm_dev, float* cost_dev) {
+int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_dev) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
+  if (e->sched_pending) { hipEventSynchronize(e->ev_sched_done); e->sched_pending = false; }
   e->perm = perm_dev;
   e->cost = cost_dev;
+  if (perm_dev && cost_dev && !e->sched_stream) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamCreateWithFlags(&e->sched_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_step_done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_sched_done, hipEventDisableTiming));
+  }
   return MOOG_OK;
 }
 

@@ -98,8 +98,9 @@ class BatchedEnvironment(object):
     def enable_cost_schedule(self, enabled=True):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
         previous step (longest-processing-time first): the envs with clustered contacts
-        start first instead of landing in the under-filled tail of the launch.  A pure
-        scheduling hint -- results are identical."""
+        start first instead of landing in the under-filled tail of the launch.  The engine
+        re-sorts the order after every step on a side stream.  A pure scheduling hint --
+        results are identical."""
         torch = self._torch
         if enabled:
             self._cost = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
@@ -177,10 +178,6 @@ class BatchedEnvironment(object):
                 for r in self._host_rules:
                     r.step(None, self._meta_state)
         inj, keep = self._inject(injected_uniforms)
-        if self._perm is not None:   # refresh the launch order from the last per-env cycle counts
-            self._sched_tick = getattr(self, '_sched_tick', 0) + 1
-            if self._sched_tick % 4 == 1:   # per-env cost changes slowly: re-sort every 4th step
-                self._perm.copy_(torch.argsort(self._cost, descending=True))
         with torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_step(
                 self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,
