@@ -153,12 +153,16 @@ def main():
     env.reset()
     is_grid = env._is_grid
 
+    # random actions drawn on the device, one kernel per step, into a reused buffer
+    act = torch.zeros((n,), dtype=torch.int32, device=dev) if is_grid else \
+        torch.zeros((n, 2), dtype=torch.float64, device=dev)
+
     def one_step():
         if is_grid:
-            a = torch.randint(0, 5, (n,), dtype=torch.int32, device=dev)
+            act.random_(0, 5)
         else:
-            a = torch.rand((n, 2), dtype=torch.float64, device=dev) * 2 - 1
-        env.step(a)
+            act.uniform_(-1.0, 1.0)
+        env.step(act)
 
     def barrier():
         torch.cuda.synchronize(dev)
