@@ -37,6 +37,13 @@ __device__ __forceinline__ PProg as_const_prog(const moog_program_t* p) {
 }
 
 #define EPS_INTERP 1e-8  // sprite.py:35
+#ifdef MOOG_PROFILE
+#define PROF_T0 const long long prof_t0_ = clock64()
+#define PROF_ADD(e_, k) const_cast<Env&>(e_).prof[k] += clock64() - prof_t0_
+#else
+#define PROF_T0
+#define PROF_ADD(e_, k)
+#endif
 #define EPS_COLL 1e-2    // collisions.py:46
 #define MOOG_F_TMP 0x100 // scratch flag bit (vanish marks)
 #define DINF (__builtin_inf())
@@ -63,6 +70,9 @@ struct Env {
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
   int n_path, n_resp;      // profiling counters (path tests, contact searches)
+#ifdef MOOG_PROFILE
+  long long prof[8];       // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
+#endif
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
 };
 
@@ -364,7 +374,10 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
   }
   if (e.dbg & 8) return false;
   if (e.dbg & 128) const_cast<Env&>(e).n_path++;
-  return paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
+  PROF_T0;
+  const bool hit = paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
+  PROF_ADD(e, 0);
+  return hit;
 }
 
 // sprite.py:442-460 (one point, one lane)
@@ -952,14 +965,14 @@ __device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K) {
     if (e.dbg & 128) e.n_resp++;
     double dt = 1. / K;
     CVec c;
-    get_collision_vectors(e, s0, s1, dt, c);
+    { PROF_T0; get_collision_vectors(e, s0, s1, dt, c); PROF_ADD(e, 1); }
     if (c.status == CV_NONE) {
-      make_disjoint(e, s0, s1, symmetric);
+      PROF_T0; make_disjoint(e, s0, s1, symmetric); PROF_ADD(e, 2);
       moved = true;
     } else if (c.status == CV_FUTURE) {
       return moved;
     } else {
-      resolve_contact(e, F, s0, s1, c, symmetric, upd);
+      PROF_T0; resolve_contact(e, F, s0, s1, c, symmetric, upd); PROF_ADD(e, 3);
       moved = true;
     }
   }
@@ -1209,6 +1222,7 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
     // ---- build: candidates with flattened index >= start --------------------------------
     int count = 0, scanned = start;
     wsync();
+    PROF_T0;
     while (scanned < total && count <= CAND_CAP - 64) {
       int idx = scanned + e.lane;
       bool cand = false;
@@ -1224,6 +1238,7 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
       scanned += 64;
     }
     wsync();
+    PROF_ADD(e, 4);
     if (scanned > total) scanned = total;
     // ---- consume ----------------------------------------------------------------------------
     bool rebuilt = false;
@@ -1276,7 +1291,7 @@ __device__ inline void apply_physics(Env& e) {
     if (P->corrective[c].kind == MOOG_CORR_CONSTANT_SPEED) constant_speed(e, &P->corrective[c]);
     else tether(e, &P->corrective[c], c);
   }
-  if (!(e.dbg & 2)) integrate_all(e, 1. / K);
+  { PROF_T0; if (!(e.dbg & 2)) integrate_all(e, 1. / K); PROF_ADD(e, 5); }
 }
 
 // ---- game rules ------------------------------------------------------------------------

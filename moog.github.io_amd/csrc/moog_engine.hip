@@ -154,6 +154,9 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0;
+#ifdef MOOG_PROFILE
+  for (int k = 0; k < 8; ++k) e.prof[k] = 0;
+#endif
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
   e.seed = a.seed;
@@ -293,6 +296,9 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);
     if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp);
+#ifdef MOOG_PROFILE
+    if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 15) - 1];
+#endif
   }
 }
 
