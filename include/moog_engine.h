@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 10
+#define MOOG_ABI_VERSION 11
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -255,7 +255,13 @@ enum {
 /* sprite filters: ALWAYS, or the expression at rule.xfilter */
 enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };
 /* conditions of CONDITIONAL */
-enum { MOOG_RCOND_BERNOULLI = 1 /* np.random.binomial(1, p0): one uniform u, value u < p0 */ };
+enum {
+  MOOG_RCOND_BERNOULLI = 1,     /* np.random.binomial(1, p0): one uniform u, value u < p0 */
+  MOOG_RCOND_CONTACT_COUNT,     /* contact_rules.get_contact_counter(l0, l1): overlapping pairs */
+  MOOG_RCOND_ALL_EXPR,          /* as MOOG_COND_ALL_EXPR .. FIRST_EXPR: layer l0, expression   */
+  MOOG_RCOND_ANY_EXPR,          /*   xfilter; FIRST_EXPR's value is the repeat count           */
+  MOOG_RCOND_FIRST_EXPR
+};
 
 /* Rules form a forest in pre-order: `parent` is the index of the enclosing TIMED /
  * CONDITIONAL rule or -1; the children of rule r are the later entries whose parent
@@ -286,9 +292,14 @@ enum {
   MOOG_TASK_RESET,              /* reset.py:48-61 cond, p0 reward, p1 steps_after_condition */
   MOOG_TASK_STAY_ALIVE          /* stay_alive.py:22-32 i0 period, p0 value    */
 };
+/* state conditions of RESET tasks (cond, cond_layer, cond_value / xcond); 3-5 are traced
+ * symbolically (moog/_symbolic.py trace_state_condition): xcond is a one-sprite expression */
 enum {
   MOOG_COND_LAYER_EMPTY = 1,    /* lambda state: len(state[L]) == 0           */
-  MOOG_COND_ALL_Y_LT            /* lambda state: all(s.y < c for s in state[L]) */
+  MOOG_COND_ALL_Y_LT,           /* lambda state: all(s.y < c for s in state[L]) */
+  MOOG_COND_ALL_EXPR,           /* all(pred(s) for s in state[L])             */
+  MOOG_COND_ANY_EXPR,           /* any(pred(s) for s in state[L])             */
+  MOOG_COND_FIRST_EXPR          /* expr(state[L][0])                          */
 };
 
 typedef struct {

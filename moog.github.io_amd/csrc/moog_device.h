@@ -1816,6 +1816,25 @@ __device__ inline void rule_reset_tree(Env& e, int ri) {
   for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) rule_reset(e, c);
 }
 
+// all(pred(s) ...) / any(pred(s) ...) over a layer, or expr(layer[0]) (conditions traced by
+// moog/_symbolic.py trace_state_condition; MOOG_COND_* and MOOG_RCOND_* share the numbering)
+__device__ inline double layer_condition(Env& e, int kind, int layer, int xoff) {
+  PProg P = e.P;
+  const int a0 = P->layer_slot0[layer], a1 = a0 + P->layer_nslots[layer];
+  if (kind == MOOG_COND_FIRST_EXPR) {
+    for (int s = a0; s < a1; ++s)
+      if (ALIVE(s)) return eval_expr(e, xoff, s, s, nullptr, nullptr);
+    return 0;
+  }
+  bool all = true, any = false;
+  for (int s = a0; s < a1; ++s) {
+    if (!ALIVE(s)) continue;
+    const bool v = eval_expr(e, xoff, s, s, nullptr, nullptr) != 0;
+    all = all && v; any = any || v;
+  }
+  return (kind == MOOG_COND_ALL_EXPR) ? (all ? 1 : 0) : (any ? 1 : 0);
+}
+
 // Combinator gate of rule ri for this call: how many times its children run
 // (timing.py:51-59, conditional.py:60-63).  Steps the TimedRule countdown.
 __device__ inline int rule_gate(Env& e, int ri) {
@@ -1829,6 +1848,16 @@ __device__ inline int rule_gate(Env& e, int ri) {
     return n;
   }
   if (R->cond == MOOG_RCOND_BERNOULLI) return next_uniform(e) < R->p0 ? 1 : 0;
+  if (R->cond == MOOG_RCOND_CONTACT_COUNT) {   // contact_rules.py:28-56
+    PProg P = e.P;
+    int n = 0;
+    for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0]; ++s)
+      for (int t = P->layer_slot0[R->l1]; t < P->layer_slot0[R->l1] + P->layer_nslots[R->l1]; ++t)
+        if (ALIVE(s) && ALIVE(t) && overlaps(e, s, t)) ++n;
+    return n;
+  }
+  if (R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR)
+    return (int)layer_condition(e, R->cond, R->l0, R->xfilter);
   return 0;
 }
 
@@ -1871,6 +1900,12 @@ __device__ inline bool task_condition(const Env& e, PTask T) {
   }
   return false;
 }
+// conditions that run the expression evaluator (DYN kernels only)
+__device__ inline bool task_condition_x(Env& e, PTask T) {
+  if (T->cond >= MOOG_COND_ALL_EXPR && T->cond <= MOOG_COND_FIRST_EXPR)
+    return layer_condition(e, T->cond, T->cond_layer, T->xcond) != 0;
+  return task_condition(e, T);
+}
 
 template <bool DYN>
 __device__ inline double task_reward(Env& e, int step_count, int* should_reset) {
@@ -1911,7 +1946,11 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
       cnt -= 1;
       tsr = (cnt < 0);
     } else if (T->kind == MOOG_TASK_RESET) {
-      if (cnt == DINF && task_condition(e, T)) { r = T->p0; cnt = T->p1; }
+      bool hit = false;
+      if (cnt == DINF) {
+        if constexpr (DYN) hit = task_condition_x(e, T); else hit = task_condition(e, T);
+      }
+      if (hit) { r = T->p0; cnt = T->p1; }
       else r = 0.;
       cnt -= 1;
       tsr = (cnt < 0);

@@ -438,9 +438,15 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT)
       e->dynamic_rules = true;
   }
-  for (int t = 0; t < prog->n_tasks; ++t)
+  for (int t = 0; t < prog->n_tasks; ++t) {
     if (prog->tasks[t].kind == MOOG_TASK_CONTACT_REWARD && (prog->tasks[t].xcond >= 0 || prog->tasks[t].xreward >= 0))
       e->dynamic_rules = true;
+    if (prog->tasks[t].kind == MOOG_TASK_RESET && prog->tasks[t].cond >= MOOG_COND_ALL_EXPR)
+      e->dynamic_rules = true;
+  }
+  for (int r = 0; r < prog->n_rules; ++r)
+    if (prog->rules[r].kind == MOOG_RULE_CONDITIONAL && prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
+      e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_reset_kernel),

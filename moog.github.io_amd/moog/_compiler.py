@@ -476,7 +476,11 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.p0, R.p1 = r._step_interval
         elif isinstance(r, rules_lib.ConditionalRule):
             R.kind = _abi.MOOG_RULE_CONDITIONAL
-            R.cond, R.p0 = r.classify()
+            R.cond, R.p0, lay, node = r.classify()
+            if lay is not None:
+                R.l0, R.l1 = layer_index(lay[0]), layer_index(lay[1])
+            if node is not None:
+                R.xfilter = put_expr(node)
         elif isinstance(r, rules_lib.ModifySprites):
             R.kind, R.filter, fnode, mod, vec = r.classify()
             R.n_layers = _fill_layers(R.layers, r._layers, layer_index)
@@ -522,7 +526,11 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         elif isinstance(t, tasks_lib.Reset):
             T.kind = _abi.MOOG_TASK_RESET
             cond, lname, val = t.classify(layer_names)
-            T.cond, T.cond_layer, T.cond_value = cond, layer_index(lname), val
+            T.cond, T.cond_layer = cond, layer_index(lname)
+            if isinstance(val, _symbolic.Node):
+                T.xcond = put_expr(val)
+            else:
+                T.cond_value = val
             T.p0, T.p1 = float(t.reward_value()), float(t._steps_after_condition)
         elif isinstance(t, tasks_lib.StayAlive):
             T.kind = _abi.MOOG_TASK_STAY_ALIVE

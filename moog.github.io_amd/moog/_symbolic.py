@@ -364,6 +364,121 @@ def trace_modifier(fn):
     return out, vec_vel
 
 
+# ---- state-level conditions ---------------------------------------------------------------------
+class _SymLayer(object):
+    """`state[layer]` inside a traced condition.  Iteration yields two representative sprites
+    (enough to tell `all(...)` from `any(...)` in the explored paths); `[0]` is the layer's
+    first sprite; `len()` is not symbolic (Python requires an int)."""
+
+    def __init__(self, owner, name):
+        self._owner, self._name = owner, name
+
+    def __iter__(self):
+        self._owner.note('quant', self._name)
+        return iter([SymSprite(0), SymSprite(1)])
+
+    def __getitem__(self, i):
+        if i != 0:
+            raise Unsupported('only state[layer][0] is lowered')
+        self._owner.note('first', self._name)
+        return SymSprite(0)
+
+    def __len__(self):
+        raise Unsupported('len(state[layer]) is not symbolic')
+
+
+class _SymState(object):
+    def __init__(self):
+        self.uses = []
+
+    def note(self, kind, layer):
+        if (kind, layer) not in self.uses:
+            self.uses.append((kind, layer))
+
+    def __getitem__(self, name):
+        return _SymLayer(self, name)
+
+
+def _substitute(node, old, new):
+    if node.op == 'attr':
+        return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
+    if node.op == 'const':
+        return node
+    return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
+
+
+def _sprites_of(node, acc):
+    if node.op == 'attr':
+        acc.add(node.args[0])
+    elif node.op != 'const':
+        for a in node.args:
+            if isinstance(a, Node):
+                _sprites_of(a, acc)
+    return acc
+
+
+def trace_state_condition(fn):
+    """Lowers `condition(state)` of the forms
+        all(pred(s) for s in state[L])  /  any(...)      -> ('all' | 'any', L, pred expression)
+        expr(state[L][0])                                 -> ('first', L, expression)
+    where pred / expr only read sprite attributes."""
+    global _TRACER
+    paths = []
+    forced = []
+    uses = None
+    while True:
+        tr = _Tracer()
+        tr.forced = list(forced)
+        st = _SymState()
+        prev, _TRACER = _TRACER, tr
+        try:
+            ret = fn(st)
+        finally:
+            _TRACER = prev
+        uses = st.uses if uses is None else uses
+        if st.uses != uses:
+            raise Unsupported('condition touches different layers on different paths')
+        paths.append((list(tr.trail), ret, []))
+        if len(paths) > MAX_PATHS:
+            raise Unsupported('too many execution paths in a lowered condition')
+        trail = tr.trail
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            break
+        forced = [v for _, v in trail[:k]] + [False]
+    if len(uses) != 1:
+        raise Unsupported('condition must look at exactly one layer')
+    kind, layer = uses[0]
+    if kind == 'first':
+        return 'first', layer, _merge(paths, lambda p: lift(p[1]))
+    # quantifier: every decision must be the same predicate on one of the two representatives
+    preds = {}
+    for trail, ret, _ in paths:
+        if isinstance(ret, Sym):
+            raise Unsupported('quantified condition must return a bool')
+        for node, _v in trail:
+            who = _sprites_of(node, set())
+            if len(who) != 1:
+                raise Unsupported('predicate must read one sprite')
+            preds.setdefault(next(iter(who)), node)
+    if set(preds) != {0, 1} or _substitute(preds[1], 1, 0).key() != preds[0].key():
+        raise Unsupported('condition is not all(...) / any(...) of one predicate over the layer')
+    table = {}
+    for trail, ret, _ in paths:
+        val = {next(iter(_sprites_of(n, set()))): v for n, v in trail}
+        for a in (True, False):
+            for b in (True, False):
+                if val.get(0, a) == a and val.get(1, b) == b:
+                    table[(a, b)] = bool(ret)
+    if table == {(True, True): True, (True, False): False, (False, True): False, (False, False): False}:
+        return 'all', layer, preds[0]
+    if table == {(True, True): True, (True, False): True, (False, True): True, (False, False): False}:
+        return 'any', layer, preds[0]
+    raise Unsupported('condition is neither all(...) nor any(...) over the layer')
+
+
 # ---- emission ---------------------------------------------------------------------------------
 _BIN = {'add': 'ADD', 'sub': 'SUB', 'mul': 'MUL', 'div': 'DIV', 'rem': 'REM', 'min': 'MIN', 'max': 'MAX',
         'lt': 'LT', 'le': 'LE', 'gt': 'GT', 'ge': 'GE', 'eq': 'EQ', 'ne': 'NE', 'and': 'AND', 'or': 'OR'}

@@ -201,6 +201,21 @@ class TemporaryRule(TimedRule):
         super(TemporaryRule, self).__init__((0, steps_until_stop), rules)
 
 
+class _ContactCounter(object):
+    """contact_rules.get_contact_counter / get_contact_indices (:15-56): a `state -> int`
+    condition for ConditionalRule, evaluated on the device (number of overlapping pairs)."""
+
+    def __init__(self, layer_0, layer_1):
+        self.layer_0, self.layer_1 = layer_0, layer_1
+
+    def __call__(self, state):
+        raise RuntimeError('contact counters are evaluated by the engine, not on the host')
+
+
+def get_contact_counter(layer_0, layer_1):
+    return _ContactCounter(layer_0, layer_1)
+
+
 class _BinomialProbe(object):
     def __init__(self, n, p):
         self.n, self.p = n, p
@@ -219,18 +234,30 @@ class ConditionalRule(AbstractRule):
         self._rules = tuple(rules)
 
     def classify(self):
+        """Returns (MOOG_RCOND_*, p0, layers (l0, l1) or None, expression node or None)."""
         import inspect
+        from .. import _symbolic
+        if isinstance(self._condition, _ContactCounter):
+            return (_abi.MOOG_RCOND_CONTACT_COUNT, 0.,
+                    (self._condition.layer_0, self._condition.layer_1), None)
         real = np.random.binomial
         np.random.binomial = lambda n, p, size=None: _BinomialProbe(n, p)
+        nargs = len(inspect.signature(self._condition).parameters)
         try:
-            nargs = len(inspect.signature(self._condition).parameters)
             out = self._condition(*([None] * nargs))
-        except Exception as exc:  # pylint: disable=broad-except
-            raise NotImplementedError('ConditionalRule condition not recognised: %r' % (exc,))
+        except Exception:  # pylint: disable=broad-except
+            out = None
         finally:
             np.random.binomial = real
+        if out is None:   # reads the state: all / any over a layer, or the layer's first sprite
+            if nargs != 1:
+                raise NotImplementedError('ConditionalRule condition(state, meta_state) is not lowered')
+            kind, layer, node = _symbolic.trace_state_condition(self._condition)
+            code = {'all': _abi.MOOG_RCOND_ALL_EXPR, 'any': _abi.MOOG_RCOND_ANY_EXPR,
+                    'first': _abi.MOOG_RCOND_FIRST_EXPR}[kind]
+            return code, 0., (layer, layer), node
         if isinstance(out, _BinomialProbe) and out.n == 1:
-            return _abi.MOOG_RCOND_BERNOULLI, float(out.p)
+            return _abi.MOOG_RCOND_BERNOULLI, float(out.p), None, None
         raise NotImplementedError('ConditionalRule condition is not np.random.binomial(1, p)')
 
 

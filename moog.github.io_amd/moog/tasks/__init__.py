@@ -59,6 +59,16 @@ class Reset(AbstractTask):
         (pong.py:87).  Returns (cond_kind, layer_name, value).
         """
         cond = self._condition
+        try:   # all(...) / any(...) over one layer, or a test of its first sprite
+            from .. import _symbolic
+            kind, layer, node = _symbolic.trace_state_condition(cond)
+            code = {'all': _abi.MOOG_COND_ALL_EXPR, 'any': _abi.MOOG_COND_ANY_EXPR,
+                    'first': _abi.MOOG_COND_FIRST_EXPR}[kind]
+            if not (kind == 'all' and node.op == 'lt' and node.args[0].key() == ('attr', 0, 'y')
+                    and node.args[1].op == 'const'):
+                return code, layer, node
+        except NotImplementedError:
+            pass
 
         def state_with(empty=(), y=None):
             return {l: ([] if l in empty else [_Probe(y=(0.5 if y is None else y), x=0.5)])

@@ -530,6 +530,7 @@ def main():
         ('tether_zoo_l4', 45, {}, (0,)),
         ('distrib_zoo', 60, {}, (0, 1)),
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
+        ('cond_zoo', 120, {'extras': 8, '__dynamic__': ('extras',)}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,
