@@ -556,7 +556,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # ---- observer -----------------------------------------------------------------------
     obs_items = list(observers.items()) if observers else []
     renderers = [(k, o) for k, o in obs_items if isinstance(o, observers_lib.PILRenderer)]
-    if len(renderers) != 1 or len(obs_items) != 1:
+    others = [o for _, o in obs_items if not isinstance(o, (observers_lib.PILRenderer, observers_lib.RawState))]
+    if len(renderers) != 1 or others:
         raise NotImplementedError('exactly one PILRenderer observer is supported')
     obs_key, ren = renderers[0]
     Rn = P.render

@@ -127,8 +127,18 @@ class BatchedEnvironment(object):
         return inj, t
 
     def _timestep(self):
-        obs = {self.compiled.observer_key: self.image}
-        return dm_env.TimeStep(self.step_type, self.reward, self.discount, obs)
+        return dm_env.TimeStep(self.step_type, self.reward, self.discount, self._observation())
+
+    def _observation(self):
+        from .observers import raw_state
+        obs = {}
+        for key, o in self.observers.items():   # the reference's dict order
+            if isinstance(o, raw_state.RawState):
+                obs[key] = raw_state.StateView(self)
+            else:
+                obs[key] = self.image
+        return obs
+
 
     def raise_faults(self):
         """Re-raises device-side per-env faults with the reference's exception types."""
@@ -235,10 +245,12 @@ class BatchedEnvironment(object):
         with self._torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_render(
                 self._handle, ctypes.c_void_p(self.image.data_ptr()), self._stream()))
-        return {self.compiled.observer_key: self.image}
+        return self._observation()
 
     def observation_spec(self):
-        return {k: o.observation_spec() for k, o in self.observers.items()}
+        from .observers import raw_state
+        return {k: o.observation_spec() for k, o in self.observers.items()
+                if not isinstance(o, raw_state.RawState)}
 
     def action_spec(self):
         return self.action_space.action_spec()
@@ -369,7 +381,7 @@ class Environment(object):
 
     def _unbatch(self, ts):
         st = dm_env.StepType(int(ts.step_type[0].item()))
-        obs = {k: v[0].cpu().numpy() for k, v in ts.observation.items()}
+        obs = self._host_obs(ts.observation)
         self.step_count = int(self._batched.step_count[0].item())
         if st == dm_env.StepType.FIRST:
             return dm_env.TimeStep(st, None, None, obs)
@@ -386,8 +398,15 @@ class Environment(object):
             a = a.reshape(1, 2).astype(np.float64)
         return self._unbatch(self._batched.step(a))
 
+    @staticmethod
+    def _host_obs(observation):
+        """numpy frame; a RawState entry becomes the env's OrderedDict of sprite dicts
+        (observers/raw_state.py:17-19 passes the state itself)."""
+        return {k: (v.sprites(0) if hasattr(v, 'sprites') else v[0].cpu().numpy())
+                for k, v in observation.items()}
+
     def observation(self):
-        return {k: v[0].cpu().numpy() for k, v in self._batched.observation().items()}
+        return self._host_obs(self._batched.observation())
 
     def observation_spec(self):
         return self._batched.observation_spec()

@@ -2,3 +2,4 @@
 from . import color_maps
 from . import polygon_modifiers
 from .pil_renderer import PILRenderer
+from .raw_state import RawState

@@ -543,3 +543,29 @@ def test_dynamic_layer_overflow_is_reported():
         for _ in range(12):
             env.step(np.zeros((64, 2)))
     assert bool((env.field('alive')[:, env.compiled.layer_slots['predators'][0]]).any())
+
+
+def test_raw_state_observer():
+    """observers.RawState (raw_state.py:6-22) next to the renderer: the facade returns the
+    state as an OrderedDict of sprite dicts, the batched engine a lazy view of the records."""
+    import collections
+    from moog import action_spaces, environment, observers, physics as physics_lib, sprite, tasks
+    cfg = dict(
+        state_initializer=lambda: collections.OrderedDict([
+            ('walls', []), ('agent', [sprite.Sprite(x=0.25, y=0.75, shape='triangle', scale=0.1, c0=255)])]),
+        physics=physics_lib.Physics((physics_lib.Drag(coeff_friction=0.25), 'agent'), updates_per_env_step=2),
+        task=tasks.CompositeTask(timeout_steps=5),
+        action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64)), 'state': observers.RawState()})
+    env = environment.Environment(**cfg)
+    ts = env.reset()
+    assert list(ts.observation) == ['image', 'state'] and ts.observation['image'].shape == (64, 64, 3)
+    state = ts.observation['state']
+    assert list(state) == ['walls', 'agent'] and state['walls'] == []
+    agent = state['agent'][0]
+    assert abs(agent['x'] - 0.25) < 1e-12 and abs(agent['y'] - 0.75) < 1e-12   # centroid shift, sprite.py:406
+    assert (agent['shape'], agent['c0']) == ('triangle', 255.0)
+    assert agent['vertices'].shape == (3, 2)
+    ts = env.step(np.array([1.0, 0.0]))
+    assert ts.observation['state']['agent'][0]['x'] > 0.25
+    assert 'state' not in env.observation_spec()
