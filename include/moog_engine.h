@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 11
+#define MOOG_ABI_VERSION 12
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -68,6 +68,8 @@ extern "C" {
 /* CreateSprites / ChangeLayer appended to a layer whose slot capacity is used up (the
  * reference's lists are unbounded; the engine's layers have a fixed capacity)      */
 #define MOOG_FAULT_LAYER_FULL 64
+/* PhaseSequence stepped past its last phase (task_phases.py:136-139 raises IndexError) */
+#define MOOG_FAULT_PHASE_END 128
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -135,7 +137,8 @@ enum {
   MOOG_X_CONST = 32, MOOG_X_ATTR, MOOG_X_ADD, MOOG_X_SUB, MOOG_X_MUL, MOOG_X_DIV, MOOG_X_REM,
   MOOG_X_MIN, MOOG_X_MAX, MOOG_X_LT, MOOG_X_LE, MOOG_X_GT, MOOG_X_GE, MOOG_X_EQ, MOOG_X_NE,
   MOOG_X_AND, MOOG_X_OR, MOOG_X_NEG, MOOG_X_ABS, MOOG_X_SQRT, MOOG_X_SIN, MOOG_X_COS,
-  MOOG_X_FLOOR, MOOG_X_NOT, MOOG_X_SIGN, MOOG_X_SELECT, MOOG_X_STORE, MOOG_X_END
+  MOOG_X_FLOOR, MOOG_X_NOT, MOOG_X_SIGN, MOOG_X_SELECT, MOOG_X_STORE, MOOG_X_END,
+  MOOG_X_RULE_STATE   /* push the state scalar of rule a (e.g. a PhaseSequence's current phase index) */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -246,6 +249,13 @@ enum {
                                       cond(state) times                           */
   MOOG_RULE_MODIFY_SPRITES,        /* modify_sprites.py:35-52: layers[], filter,
                                       i0 = sample_one, modifier = expression xmod  */
+  MOOG_RULE_PHASE,                 /* task_phases.py:17-98: children = i0 one-time rules
+                                      (stepped on the phase's first step) followed by the
+                                      continual rules; ends after p0 steps or when cond
+                                      (MOOG_RCOND_*, 0 = never) holds; state = step count,
+                                      -1 once ended                                 */
+  MOOG_RULE_PHASE_SEQUENCE,        /* task_phases.py:101-141: children = PHASE rules, one
+                                      current at a time; state = index of the current one */
   MOOG_RULE_KEEP_NEAR_CENTER,      /* re_center.py:48-58: l0 agent layer, layers[] to move,
                                       p0 / p1 grid cell                            */
   MOOG_RULE_MODIFY_ON_CONTACT      /* contact_rules.py:112-141: layers[] x layers1[];

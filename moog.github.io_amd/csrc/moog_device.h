@@ -1360,6 +1360,7 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     if (op == MOOG_X_END) break;
     if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_STORE) {
       --n;
       st->mask |= 1u << I->a;
@@ -1804,7 +1805,9 @@ __device__ inline void rule_reset(Env& e, int ri) {
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
   __threadfence();
-  if (e.lane == 0) e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 : DINF;   // timing.py:47
+  if (e.lane == 0)
+    e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
+        ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE) ? 0.0 : DINF);
   wsync();
 }
 
@@ -1835,19 +1838,11 @@ __device__ inline double layer_condition(Env& e, int kind, int layer, int xoff) 
   return (kind == MOOG_COND_ALL_EXPR) ? (all ? 1 : 0) : (any ? 1 : 0);
 }
 
-// Combinator gate of rule ri for this call: how many times its children run
-// (timing.py:51-59, conditional.py:60-63).  Steps the TimedRule countdown.
-__device__ inline int rule_gate(Env& e, int ri) {
-  PRule R = &e.P->rules[ri];
-  if (R->kind == MOOG_RULE_TIMED) {
-    const double start = e.f[e.L.o_rule + ri];
-    const int n = (start <= 0 && start + (R->p1 - R->p0) > 0) ? 1 : 0;
-    wsync();
-    if (e.lane == 0) e.f[e.L.o_rule + ri] = start - 1;
-    wsync();
-    return n;
-  }
-  if (R->cond == MOOG_RCOND_BERNOULLI) return next_uniform(e) < R->p0 ? 1 : 0;
+// value of a rule's state condition (ConditionalRule repeat count, Phase end condition)
+template <bool DYN>
+__device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
+  if (R->cond == MOOG_RCOND_BERNOULLI) return next_uniform(e) < p_bernoulli ? 1 : 0;
+  if constexpr (!DYN) return 0;   // the other conditions make the host pick the DYN kernel
   if (R->cond == MOOG_RCOND_CONTACT_COUNT) {   // contact_rules.py:28-56
     PProg P = e.P;
     int n = 0;
@@ -1861,28 +1856,120 @@ __device__ inline int rule_gate(Env& e, int ri) {
   return 0;
 }
 
+__device__ __forceinline__ bool is_combinator(int k) {
+  return k == MOOG_RULE_TIMED || k == MOOG_RULE_CONDITIONAL || k == MOOG_RULE_PHASE ||
+         k == MOOG_RULE_PHASE_SEQUENCE;
+}
+
+// What a combinator does with its children in this call (timing.py:51-59, conditional.py:60-63,
+// task_phases.py:68-82,129-141): run them n times; a Phase runs its first i0 children (the
+// one-time rules) only on its first step; a PhaseSequence runs only child number `only`.
+struct RuleGate { int n, only, i0; bool first; };
+
+__device__ inline int n_children(Env& e, int ri) {
+  PProg P = e.P;
+  int n = 0;
+  for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) n += (P->rules[c].parent == ri) ? 1 : 0;
+  return n;
+}
+
+template <bool DYN>
+__device__ inline RuleGate rule_open(Env& e, int ri) {
+  PRule R = &e.P->rules[ri];
+  RuleGate g = {0, -1, 0, true};
+  const double st = e.f[e.L.o_rule + ri];
+  if (R->kind == MOOG_RULE_TIMED) {
+    g.n = (st <= 0 && st + (R->p1 - R->p0) > 0) ? 1 : 0;
+    // the countdown happens after the children in the reference; they never read it
+    wsync();
+    if (e.lane == 0) e.f[e.L.o_rule + ri] = st - 1;
+    wsync();
+  } else if (R->kind == MOOG_RULE_CONDITIONAL) {
+    g.n = rule_condition<DYN>(e, R, R->p0);
+  } else if (R->kind == MOOG_RULE_PHASE) {
+    g.n = (st < 0) ? 0 : 1;   // should_end
+    g.i0 = R->i0;
+    g.first = (st == 0);
+  } else {   // PHASE_SEQUENCE
+    g.only = (int)st;
+    g.n = 1;
+    if (g.only >= n_children(e, ri)) {
+      g.n = 0;
+      wsync();
+      if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_PHASE_END;
+      wsync();
+    }
+  }
+  return g;
+}
+
+template <bool DYN>
+__device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
+  PProg P = e.P;
+  PRule R = &P->rules[ri];
+  if (g.n == 0) return;
+  if (R->kind == MOOG_RULE_PHASE) {
+    double st = e.f[e.L.o_rule + ri] + 1;
+    if (st >= R->p0 || (R->cond && rule_condition<DYN>(e, R, R->p1) != 0)) st = -1;
+    wsync();
+    if (e.lane == 0) e.f[e.L.o_rule + ri] = st;
+    wsync();
+  } else if (R->kind == MOOG_RULE_PHASE_SEQUENCE) {
+    int k = 0, cur = -1;
+    for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) {
+      if (P->rules[c].parent != ri) continue;
+      if (k == g.only) cur = c;
+      ++k;
+    }
+    if (cur >= 0 && e.f[e.L.o_rule + cur] < 0) {   // the current phase ended: move on
+      wsync();
+      if (e.lane == 0) {
+        e.f[e.L.o_rule + ri] = (double)(g.only + 1);
+        if (g.only + 1 >= k) e.q[e.L.o_fault] |= MOOG_FAULT_PHASE_END;   // self._phases[ind]: IndexError
+      }
+      wsync();
+    }
+  }
+}
+
+__device__ __forceinline__ bool child_selected(const RuleGate& g, int parent_kind, int k) {
+  if (g.only >= 0) return k == g.only;
+  if (parent_kind == MOOG_RULE_PHASE) return k >= g.i0 || g.first;
+  return true;
+}
+
 // rule.step() of a top-level rule.  Nesting is at most two combinators deep, so the walk is
-// three explicit levels (no device recursion).  A TimedRule counts down AFTER its children ran.
+// three explicit levels (no device recursion).
 template <bool DYN>
 __device__ inline void rule_step(Env& e, int ri) {
   PProg P = e.P;
   const int k0 = P->rules[ri].kind;
-  if (k0 != MOOG_RULE_TIMED && k0 != MOOG_RULE_CONDITIONAL) { rule_leaf_step<DYN>(e, ri); return; }
+  if (!is_combinator(k0)) { rule_leaf_step<DYN>(e, ri); return; }
   const int nr = P->n_rules;
-  // the countdown of a TimedRule happens after its children in the reference; children never
-  // read the parent's counter, so taking the gate first is equivalent
-  const int n0 = rule_gate(e, ri);
-  for (int i0 = 0; i0 < n0; ++i0) {
+  const RuleGate g0 = rule_open<DYN>(e, ri);
+  for (int i0 = 0; i0 < g0.n; ++i0) {
+    int kc = 0;
     for (int c = ri + 1; c < nr && P->rules[c].parent >= ri; ++c) {
       if (P->rules[c].parent != ri) continue;
+      const bool sel = child_selected(g0, k0, kc);
+      ++kc;
+      if (!sel) continue;
       const int k1 = P->rules[c].kind;
-      if (k1 != MOOG_RULE_TIMED && k1 != MOOG_RULE_CONDITIONAL) { rule_leaf_step<DYN>(e, c); continue; }
-      const int n1 = rule_gate(e, c);
-      for (int i1 = 0; i1 < n1; ++i1)
-        for (int d = c + 1; d < nr && P->rules[d].parent >= c; ++d)
-          if (P->rules[d].parent == c) rule_leaf_step<DYN>(e, d);
+      if (!is_combinator(k1)) { rule_leaf_step<DYN>(e, c); continue; }
+      const RuleGate g1 = rule_open<DYN>(e, c);
+      for (int i1 = 0; i1 < g1.n; ++i1) {
+        int kd = 0;
+        for (int d = c + 1; d < nr && P->rules[d].parent >= c; ++d) {
+          if (P->rules[d].parent != c) continue;
+          const bool sel1 = child_selected(g1, k1, kd);
+          ++kd;
+          if (sel1) rule_leaf_step<DYN>(e, d);
+        }
+      }
+      rule_close<DYN>(e, c, g1);
     }
   }
+  rule_close<DYN>(e, ri, g0);
 }
 
 // ---- tasks ---------------------------------------------------------------------------------

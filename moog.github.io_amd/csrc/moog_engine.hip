@@ -445,7 +445,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       e->dynamic_rules = true;
   }
   for (int r = 0; r < prog->n_rules; ++r)
-    if (prog->rules[r].kind == MOOG_RULE_CONDITIONAL && prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
+    if ((prog->rules[r].kind == MOOG_RULE_CONDITIONAL || prog->rules[r].kind == MOOG_RULE_PHASE) &&
+        prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   if (err == hipSuccess)

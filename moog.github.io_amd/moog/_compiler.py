@@ -92,7 +92,8 @@ def _flatten_rules(rules, parent=-1, depth=0, out=None):
         if getattr(r, 'host_side', False):
             continue
         out.append((r, parent))
-        if isinstance(r, (rules_lib.TimedRule, rules_lib.ConditionalRule)):
+        if isinstance(r, (rules_lib.TimedRule, rules_lib.ConditionalRule, rules_lib.Phase,
+                          rules_lib.PhaseSequence)):
             if depth >= 2:
                 raise NotImplementedError('rule combinators nested deeper than 2')
             _flatten_rules(r._rules, len(out) - 1, depth + 1, out)
@@ -401,13 +402,27 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     if len(flat_rules) > _abi.MOOG_MAX_RULES:
         raise ValueError('too many game rules')
 
+    # meta_state[key] == 'phase name' tests refer to the PhaseSequence that publishes under key
+    phase_keys = {}
+    for ri, (r, _parent) in enumerate(flat_rules):
+        if isinstance(r, rules_lib.PhaseSequence) and r._meta_state_key is not None:
+            phase_keys[r._meta_state_key] = (ri, [ph.name for ph in r._phases])
+
+    def resolve_phase(key, name):
+        if key not in phase_keys:
+            raise NotImplementedError('meta_state[%r] is not published by a PhaseSequence' % (key,))
+        ri, names = phase_keys[key]
+        if name not in names:
+            raise ValueError('no phase named %r' % (name,))
+        return ri, names.index(name)
+
     def put_expr(node=None, stores=None):
         """Appends postfix expression code (plus X_END) to program.dcode; returns its offset."""
         code = []
         if node is not None:
-            _symbolic.emit(node, code)
+            _symbolic.emit(node, code, resolve_phase)
         for attr, n in (stores or {}).items():
-            _symbolic.emit(n, code)
+            _symbolic.emit(n, code, resolve_phase)
             code.append(dict(op=_abi.MOOG_X_STORE, a=_symbolic.ATTRS.index(attr)))
         if _symbolic.depth(code) > _abi.MOOG_X_STACK:
             raise NotImplementedError('expression too deep for the device evaluator')
@@ -471,6 +486,20 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.l0 = layer_index(r._agent_layer)
             R.n_layers = _fill_layers(R.layers, r._layers_to_center, layer_index)
             R.p0, R.p1 = r._grid_cell
+        elif isinstance(r, rules_lib.Phase):
+            R.kind = _abi.MOOG_RULE_PHASE
+            R.i0 = len(r._one_time_rules)
+            R.p0 = r._duration
+            if r._end_condition is not None:
+                R.cond, _p, lay, node = rules_lib.classify_condition(r._end_condition)
+                if lay is not None:
+                    R.l0, R.l1 = layer_index(lay[0]), layer_index(lay[1])
+                if node is not None:
+                    R.xfilter = put_expr(node)
+                if R.cond == _abi.MOOG_RCOND_BERNOULLI:
+                    R.p1 = _p
+        elif isinstance(r, rules_lib.PhaseSequence):
+            R.kind = _abi.MOOG_RULE_PHASE_SEQUENCE
         elif isinstance(r, rules_lib.TimedRule):
             R.kind = _abi.MOOG_RULE_TIMED
             R.p0, R.p1 = r._step_interval

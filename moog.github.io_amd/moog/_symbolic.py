@@ -399,10 +399,33 @@ class _SymState(object):
         return _SymLayer(self, name)
 
 
+class _SymMetaValue(object):
+    """`meta_state[key]` inside a traced condition: only `== 'phase name'` / `!=` are lowered
+    (the value a PhaseSequence publishes, task_phases.py:126-127,140-141)."""
+
+    def __init__(self, key):
+        self._key = key
+
+    def __eq__(self, other):
+        if not isinstance(other, str):
+            raise Unsupported('meta_state values can only be compared with a phase name')
+        return Sym(Node('phase_is', self._key, other))
+
+    def __ne__(self, other):
+        return Sym(Node('not', self.__eq__(other).node))
+
+    __hash__ = None
+
+
+class _SymMeta(object):
+    def __getitem__(self, key):
+        return _SymMetaValue(key)
+
+
 def _substitute(node, old, new):
     if node.op == 'attr':
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
-    if node.op == 'const':
+    if node.op in ('const', 'phase_is'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -410,15 +433,15 @@ def _substitute(node, old, new):
 def _sprites_of(node, acc):
     if node.op == 'attr':
         acc.add(node.args[0])
-    elif node.op != 'const':
+    elif node.op not in ('const', 'phase_is'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
     return acc
 
 
-def trace_state_condition(fn):
-    """Lowers `condition(state)` of the forms
+def trace_state_condition(fn, with_meta=False):
+    """Lowers `condition(state)` / `condition(state, meta_state)` of the forms
         all(pred(s) for s in state[L])  /  any(...)      -> ('all' | 'any', L, pred expression)
         expr(state[L][0])                                 -> ('first', L, expression)
     where pred / expr only read sprite attributes."""
@@ -432,7 +455,7 @@ def trace_state_condition(fn):
         st = _SymState()
         prev, _TRACER = _TRACER, tr
         try:
-            ret = fn(st)
+            ret = fn(st, _SymMeta()) if with_meta else fn(st)
         finally:
             _TRACER = prev
         uses = st.uses if uses is None else uses
@@ -448,6 +471,8 @@ def trace_state_condition(fn):
         if k < 0:
             break
         forced = [v for _, v in trail[:k]] + [False]
+    if not uses:   # reads only the meta-state (e.g. the current phase)
+        return 'plain', None, _merge(paths, lambda p: lift(p[1]))
     if len(uses) != 1:
         raise Unsupported('condition must look at exactly one layer')
     kind, layer = uses[0]
@@ -486,22 +511,31 @@ _UN = {'neg': 'NEG', 'abs': 'ABS', 'sqrt': 'SQRT', 'sin': 'SIN', 'cos': 'COS', '
        'not': 'NOT', 'sign': 'SIGN'}
 
 
-def emit(node, out):
-    """Postfix code (list of instruction dicts) for an expression tree."""
+def emit(node, out, resolver=None):
+    """Postfix code (list of instruction dicts) for an expression tree.  `resolver(key, name)`
+    maps a meta-state phase test to (rule index, phase index)."""
+    if node.op == 'phase_is':
+        if resolver is None:
+            raise Unsupported('meta_state phase test outside a config with a PhaseSequence')
+        rule, idx = resolver(node.args[0], node.args[1])
+        out.append(dict(op=_abi.MOOG_X_RULE_STATE, a=rule))
+        out.append(dict(op=_abi.MOOG_X_CONST, x=float(idx), b=0))
+        out.append(dict(op=_abi.MOOG_X_EQ))
+        return out
     if node.op == 'const':
         out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
     elif node.op == 'attr':
         out.append(dict(op=_abi.MOOG_X_ATTR, a=ATTRS.index(node.args[1]), b=int(node.args[0])))
     elif node.op == 'select':
         for a in node.args:
-            emit(a, out)
+            emit(a, out, resolver)
         out.append(dict(op=_abi.MOOG_X_SELECT))
     elif node.op in _BIN:
-        emit(node.args[0], out)
-        emit(node.args[1], out)
+        emit(node.args[0], out, resolver)
+        emit(node.args[1], out, resolver)
         out.append(dict(op=getattr(_abi, 'MOOG_X_' + _BIN[node.op])))
     elif node.op in _UN:
-        emit(node.args[0], out)
+        emit(node.args[0], out, resolver)
         out.append(dict(op=getattr(_abi, 'MOOG_X_' + _UN[node.op])))
     else:
         raise Unsupported('expression op %r' % (node.op,))
@@ -513,7 +547,7 @@ def depth(code):
     d = m = 0
     for ins in code:
         op = ins['op']
-        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR):
+        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE):
             d += 1
         elif op == _abi.MOOG_X_SELECT:
             d -= 2

@@ -28,6 +28,7 @@ _FAULT_EXC = (
     (_abi.MOOG_FAULT_INJECT_UNDERRUN, RuntimeError, 'injected uniform buffer exhausted.'),
     (_abi.MOOG_FAULT_DIST_EXHAUSTED, ValueError,
      'Maximum number of tried exceeded when trying to sample from a distribution.'),
+    (_abi.MOOG_FAULT_PHASE_END, IndexError, 'tuple index out of range (PhaseSequence ran past its last phase).'),
     (_abi.MOOG_FAULT_LAYER_FULL, RuntimeError,
      'a rule appended to a layer whose slot capacity is used up (raise layer_capacity).'),
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
@@ -61,8 +62,8 @@ class BatchedEnvironment(object):
         # available for a batch of one.
         self._host_rules = [r for r in game_rules if getattr(r, 'host_side', False)]
         self._meta_state_initializer = meta_state_initializer
-        if (self._host_rules or meta_state_initializer is not None) and self.num_envs != 1:
-            raise NotImplementedError('meta_state / ModifyMetaState need num_envs == 1')
+        if self._host_rules and self.num_envs != 1:
+            raise NotImplementedError('ModifyMetaState rules need num_envs == 1')
         self._meta_state = None
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)

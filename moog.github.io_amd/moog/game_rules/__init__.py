@@ -201,6 +201,50 @@ class TemporaryRule(TimedRule):
         super(TemporaryRule, self).__init__((0, steps_until_stop), rules)
 
 
+class Phase(AbstractRule):
+    """task_phases.py:17-98: one-time rules on the phase's first step, continual rules every
+    step, until `duration` steps have passed or end_condition(state[, meta_state]) holds."""
+
+    def __init__(self, one_time_rules=(), continual_rules=(), end_condition=None, duration=np.inf,
+                 name=''):
+        if not isinstance(one_time_rules, (list, tuple)):
+            one_time_rules = (one_time_rules,)
+        if not isinstance(continual_rules, (list, tuple)):
+            continual_rules = (continual_rules,)
+        if callable(duration):
+            raise NotImplementedError('Phase with a callable duration is not lowered')
+        self._one_time_rules, self._continual_rules = tuple(one_time_rules), tuple(continual_rules)
+        self._end_condition = end_condition
+        self._duration = float(duration)
+        self._name = name
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def _rules(self):   # children in the order the device walks them
+        return self._one_time_rules + self._continual_rules
+
+
+class PhaseSequence(AbstractRule):
+    """task_phases.py:101-141: the phases one after the other.  With
+    meta_state_phase_name_key the reference publishes the current phase's name in the
+    meta-state; conditions that test it (`meta_state[key] == 'name'`) are lowered to a test of
+    this rule's phase index."""
+
+    def __init__(self, *single_phases, meta_state_phase_name_key=None):
+        for ph in single_phases:
+            if not isinstance(ph, Phase):
+                raise TypeError('PhaseSequence takes Phase instances')
+        self._phases = tuple(single_phases)
+        self._meta_state_key = meta_state_phase_name_key
+
+    @property
+    def _rules(self):
+        return self._phases
+
+
 class _ContactCounter(object):
     """contact_rules.get_contact_counter / get_contact_indices (:15-56): a `state -> int`
     condition for ConditionalRule, evaluated on the device (number of overlapping pairs)."""
@@ -234,31 +278,34 @@ class ConditionalRule(AbstractRule):
         self._rules = tuple(rules)
 
     def classify(self):
-        """Returns (MOOG_RCOND_*, p0, layers (l0, l1) or None, expression node or None)."""
-        import inspect
-        from .. import _symbolic
-        if isinstance(self._condition, _ContactCounter):
-            return (_abi.MOOG_RCOND_CONTACT_COUNT, 0.,
-                    (self._condition.layer_0, self._condition.layer_1), None)
-        real = np.random.binomial
-        np.random.binomial = lambda n, p, size=None: _BinomialProbe(n, p)
-        nargs = len(inspect.signature(self._condition).parameters)
-        try:
-            out = self._condition(*([None] * nargs))
-        except Exception:  # pylint: disable=broad-except
-            out = None
-        finally:
-            np.random.binomial = real
-        if out is None:   # reads the state: all / any over a layer, or the layer's first sprite
-            if nargs != 1:
-                raise NotImplementedError('ConditionalRule condition(state, meta_state) is not lowered')
-            kind, layer, node = _symbolic.trace_state_condition(self._condition)
-            code = {'all': _abi.MOOG_RCOND_ALL_EXPR, 'any': _abi.MOOG_RCOND_ANY_EXPR,
-                    'first': _abi.MOOG_RCOND_FIRST_EXPR}[kind]
-            return code, 0., (layer, layer), node
-        if isinstance(out, _BinomialProbe) and out.n == 1:
+        return classify_condition(self._condition)
+
+
+def classify_condition(condition):
+    """Lowers a `state[, meta_state] -> bool / int` condition (ConditionalRule, Phase end
+    conditions).  Returns (MOOG_RCOND_*, p0, layers (l0, l1) or None, expression node or None)."""
+    import inspect
+    from .. import _symbolic
+    if isinstance(condition, _ContactCounter):
+        return _abi.MOOG_RCOND_CONTACT_COUNT, 0., (condition.layer_0, condition.layer_1), None
+    nargs = len(inspect.signature(condition).parameters)
+    real = np.random.binomial
+    np.random.binomial = lambda n, p, size=None: _BinomialProbe(n, p)
+    try:
+        out = condition(*([None] * nargs))
+    except Exception:  # pylint: disable=broad-except
+        out = None
+    finally:
+        np.random.binomial = real
+    if isinstance(out, _BinomialProbe):
+        if out.n == 1:
             return _abi.MOOG_RCOND_BERNOULLI, float(out.p), None, None
-        raise NotImplementedError('ConditionalRule condition is not np.random.binomial(1, p)')
+        raise NotImplementedError('condition is np.random.binomial(n, p) with n != 1')
+    # reads the state: all / any over a layer, the layer's first sprite, or the current phase
+    kind, layer, node = _symbolic.trace_state_condition(condition, with_meta=(nargs == 2))
+    code = {'all': _abi.MOOG_RCOND_ALL_EXPR, 'any': _abi.MOOG_RCOND_ANY_EXPR,
+            'first': _abi.MOOG_RCOND_FIRST_EXPR, 'plain': _abi.MOOG_RCOND_FIRST_EXPR}[kind]
+    return code, 0., ((layer, layer) if layer is not None else None), node
 
 
 # ---- lowering registry for config-local rule classes --------------------------

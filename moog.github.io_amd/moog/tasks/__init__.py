@@ -45,8 +45,7 @@ class _Probe(object):
 
 class Reset(AbstractTask):
     def __init__(self, condition, reward_fn=None, steps_after_condition=np.inf):
-        if len(inspect.signature(condition).parameters.values()) != 1:
-            raise NotImplementedError('Reset(condition(state, meta_state)) is not lowered')
+        self._with_meta = len(inspect.signature(condition).parameters.values()) == 2
         self._condition = condition
         self._steps_after_condition = steps_after_condition
         self._reward_fn = reward_fn
@@ -61,14 +60,17 @@ class Reset(AbstractTask):
         cond = self._condition
         try:   # all(...) / any(...) over one layer, or a test of its first sprite
             from .. import _symbolic
-            kind, layer, node = _symbolic.trace_state_condition(cond)
+            kind, layer, node = _symbolic.trace_state_condition(cond, with_meta=self._with_meta)
             code = {'all': _abi.MOOG_COND_ALL_EXPR, 'any': _abi.MOOG_COND_ANY_EXPR,
-                    'first': _abi.MOOG_COND_FIRST_EXPR}[kind]
+                    'first': _abi.MOOG_COND_FIRST_EXPR, 'plain': _abi.MOOG_COND_FIRST_EXPR}[kind]
+            if layer is None:
+                layer = layer_names[0]
             if not (kind == 'all' and node.op == 'lt' and node.args[0].key() == ('attr', 0, 'y')
                     and node.args[1].op == 'const'):
                 return code, layer, node
         except NotImplementedError:
-            pass
+            if self._with_meta:
+                raise
 
         def state_with(empty=(), y=None):
             return {l: ([] if l in empty else [_Probe(y=(0.5 if y is None else y), x=0.5)])

@@ -184,9 +184,30 @@ def bookkeeping(env):
     tc = [float(getattr(t, '_steps_until_reset', np.nan)) for t in subtasks]
     rc = [float(getattr(r, '_steps_until_expire', getattr(r, '_steps_until_start', np.nan)))
           for r in env.game_rules]
+
+    def state_of(r):   # the scalar the engine keeps per rule (include/moog_engine.h moog_rule_t)
+        if hasattr(r, '_current_phase_ind'):
+            return float(r._current_phase_ind)
+        if hasattr(r, '_should_end'):
+            return -1.0 if r._should_end else float(r._step_count)
+        return float(getattr(r, '_steps_until_expire', getattr(r, '_steps_until_start', np.nan)))
+
+    def walk(rules, out):   # pre-order over the rule forest, children in stepping order
+        for r in rules:
+            out.append(state_of(r))
+            kids = getattr(r, '_phases', None)
+            if kids is None and hasattr(r, '_one_time_rules'):
+                kids = list(r._one_time_rules) + list(r._continual_rules)
+            if kids is None:
+                kids = getattr(r, '_rules', None)
+            if kids is not None:
+                walk(list(kids), out)
+        return out
+    rc_flat = walk(list(env.game_rules), [])
     return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
                 action_mem=np.array(env.action_space._action, dtype=float),
-                task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float))
+                task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
+                rule_counters_flat=np.array(rc_flat, dtype=float))
 
 
 def make_slot_map(env, layer_names, caps):
@@ -531,6 +552,7 @@ def main():
         ('distrib_zoo', 60, {}, (0, 1)),
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('cond_zoo', 120, {'extras': 8, '__dynamic__': ('extras',)}, (0, 1)),
+        ('phase_zoo', 120, {}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,

@@ -153,6 +153,11 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
     for k, r in enumerate(tops):
         if k < len(rc) and not np.isnan(rc[k]):
             f[L.o_rule + r] = rc[k]
+    if 'rule_counters_flat' in fx:   # newer fixtures: every rule of the pre-order forest
+        flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
+        for r in range(min(P.n_rules, len(flat))):
+            if not np.isnan(flat[r]):
+                f[L.o_rule + r] = flat[r]
     pm = portal_rule_mask(P)
     for s in range(S):
         nv = int(fx['nverts'][t][s])
@@ -278,6 +283,12 @@ def state_diff(fx, t, c, f64, i32, env=0):
         if not np.isnan(rc[k]) and f[L.o_rule + r] != rc[k]:
             ints_ok = False
             detail.append('rule counter %d: %r vs %r' % (k, f[L.o_rule + r], rc[k]))
+    if 'rule_counters_flat' in fx:
+        flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
+        for r in range(min(P.n_rules, len(flat))):
+            if not np.isnan(flat[r]) and f[L.o_rule + r] != flat[r]:
+                ints_ok = False
+                detail.append('rule state %d: %r vs %r' % (r, f[L.o_rule + r], flat[r]))
     return dict(float=max(err.values()), err=err, ints_ok=ints_ok, detail='; '.join(detail))
 
 
