@@ -68,8 +68,24 @@ def tracing():
         t.randint_calls.append((int(low), int(high)))
         return int(high) - 1
     np.random.randint = fake_randint
+    # Any other draw from numpy's global generator inside the initializer would be taken
+    # once, at build time, and frozen into every episode: refuse it instead.
+    blocked = {}
+
+    def refuse(name):
+        def _raise(*args, **kwargs):
+            raise NotImplementedError(
+                'np.random.%s inside a state_initializer is not lowered to the device sampler '
+                '(sample through moog.state_initialization.distributions)' % name)
+        return _raise
+    for name in ('uniform', 'rand', 'randn', 'normal', 'random', 'random_sample', 'choice', 'shuffle',
+                 'permutation', 'binomial'):
+        blocked[name] = getattr(np.random, name)
+        setattr(np.random, name, refuse(name))
     try:
         yield t
     finally:
         np.random.randint = real_randint
+        for name, fn in blocked.items():
+            setattr(np.random, name, fn)
         _ACTIVE = prev

@@ -216,3 +216,22 @@ def test_chain_generators_is_a_sequence_of_ops():
     assert (P.ops[1].slot0, P.ops[1].count_max) == (2, 3)
     with pytest.raises(NotImplementedError):
         sg.shuffle(gen)
+
+
+def test_host_randomness_in_initializer_is_refused():
+    """A state_initializer that draws from np.random directly (e.g.
+    bounce_box_contact_prediction.py:77-79) would be sampled once at build time; the lowering
+    refuses it instead of freezing the draw into every episode."""
+    import collections
+    from moog import action_spaces, observers, physics as physics_lib, sprite, tasks
+
+    def state_initializer():
+        return collections.OrderedDict(
+            [('agent', [sprite.Sprite(x=np.random.uniform(0.2, 0.8), y=0.5, scale=0.1)])])
+    with pytest.raises(NotImplementedError):
+        _compiler.compile_config(
+            state_initializer=state_initializer, physics=physics_lib.Physics(),
+            task=tasks.CompositeTask(timeout_steps=5),
+            action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
+            observers={'image': observers.PILRenderer(image_size=(64, 64))})
+    assert 0.0 <= np.random.uniform(0., 1.) < 1.0   # the generator is restored afterwards
