@@ -45,6 +45,15 @@ class Sprite(object):
     def is_symbolic(self):
         return bool(self.sample_order)
 
+    def __setattr__(self, name, value):
+        # `sprite.mass = ...` after construction (e.g. predators_arena.py:88-89 inside its
+        # state_initializer) is host logic the recipe cannot carry: refuse instead of ignoring it
+        if name in FACTOR_NAMES and 'factors' in self.__dict__:
+            raise NotImplementedError(
+                'assigning sprite.%s after construction is not lowered; pass it to Sprite(...) or '
+                'through the factor distribution' % name)
+        object.__setattr__(self, name, value)
+
     def __getattr__(self, name):
         f = self.__dict__.get('factors')
         if f is not None and name in f:
