@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 12
+#define MOOG_ABI_VERSION 13
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -42,6 +42,8 @@ extern "C" {
 #define MOOG_MAX_DCODE 512
 #define MOOG_X_STACK 16
 #define MOOG_MAX_SLOTS 128
+#define MOOG_MAX_ACTIONS 4
+#define MOOG_MAX_MORE_ACTIONS 3 /* MOOG_MAX_ACTIONS - 1 */
 #define MOOG_NUM_FACTORS 14
 
 /* ---- error codes --------------------------------------------------------- */
@@ -328,8 +330,10 @@ typedef struct {
 } moog_task_t;
 
 /* ---- action space ---------------------------------------------------------- */
-enum { MOOG_ACTION_JOYSTICK = 1, /* joystick.py:45-70 */
-       MOOG_ACTION_GRID = 2 };   /* grid.py:15-21,52-75 */
+enum { MOOG_ACTION_JOYSTICK = 1,      /* joystick.py:45-70 */
+       MOOG_ACTION_GRID = 2,          /* grid.py:15-21,52-75 */
+       MOOG_ACTION_SET_POSITION = 3 };/* set_position.py:41-58: position = inertia * position
+                                         + (1 - inertia) * action; `momentum` holds inertia */
 
 typedef struct {
   int32_t kind;
@@ -389,7 +393,14 @@ typedef struct {
   moog_corrective_t corrective[MOOG_MAX_CORRECTIVE];
   moog_rule_t rules[MOOG_MAX_RULES];
   moog_task_t tasks[MOOG_MAX_TASKS];
-  moog_action_t action;
+  moog_action_t action;            /* the action space, or the first of a Composite      */
+  int32_t n_actions;               /* sub-spaces of a Composite (composite.py:38-49), in
+                                    * keyword order; 0 / 1: `action` alone.  With more than
+                                    * one the action buffer is f64 [n_envs][n_actions][2]
+                                    * (a Grid move in component 0) and o_action holds
+                                    * 2 words per sub-space                              */
+  int32_t pad_actions_;
+  moog_action_t more_actions[MOOG_MAX_MORE_ACTIONS];
   moog_render_t render;
   moog_genop_t ops[MOOG_MAX_OPS];
   moog_shape_t shapes[MOOG_MAX_SHAPES];
@@ -417,7 +428,7 @@ typedef struct {
   int32_t o_color;    /* [S][3]   c0,c1,c2                                     */
   int32_t o_inertia;  /* [S][2]   _x_y_rotational_inertia                      */
   int32_t o_maxr;     /* [S]      _max_radius                                  */
-  int32_t o_action;   /* [2]      action-space memory (_action)                */
+  int32_t o_action;   /* [2 * max(1, n_actions)] action-space memory (_action)    */
   int32_t o_task;     /* [T]      per-task _steps_until_reset (inf sentinel)   */
   int32_t o_rule;     /* [R]      per-rule scalar (Booster countdown)          */
   int32_t o_scale;    /* [S] sprite.scale, [S] sprite.aspect_ratio at o_aspect; -1 when
@@ -455,7 +466,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_color = o; o += 3 * S;
   L->o_inertia = o; o += 2 * S;
   L->o_maxr = o; o += S;
-  L->o_action = o; o += 2;
+  L->o_action = o; o += 2 * (p->n_actions > 1 ? p->n_actions : 1);
   L->o_task = o; o += p->n_tasks;
   L->o_rule = o; o += p->n_rules;
   if (p->sprite_factors) { L->o_scale = o; o += S; L->o_aspect = o; o += S; }
@@ -524,7 +535,8 @@ int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view);
 int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev,
                       const moog_inject_t* inject, const moog_step_out_t* out,
                       void* hip_stream);
-/* Replaces Environment.step (environment.py:98-126).  actions: f64 [n_envs][2]
+/* Replaces Environment.step (environment.py:98-126).  actions: f64 [n_envs][n_actions][2] for
+ * a Composite action space, else f64 [n_envs][2]
  * (Joystick) or i32 [n_envs] (Grid).  Envs with reset_next set are reset
  * instead (auto-reset, :100-101). */
 int moog_engine_step(moog_engine_t* e, const void* actions_dev,

@@ -2057,10 +2057,21 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
 }
 
 // ---- action spaces ---------------------------------------------------------------------------
-__device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_action) {
+__device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, int grid_action) {
   PProg P = e.P;
-  PAction A = &P->action;
-  double m0 = e.f[e.L.o_action], m1 = e.f[e.L.o_action + 1];
+  PAction A = (k == 0) ? &P->action : &P->more_actions[k - 1];
+  const int om = e.L.o_action + 2 * k;
+  if (A->kind == MOOG_ACTION_SET_POSITION) {   // set_position.py:48-58 (`momentum` = inertia)
+    for (int a = 0; a < A->n_layers; ++a) {
+      const int l = A->layers[a];
+      for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+        if (ALIVE(s))
+          set_position(e, s, A->momentum * PX(s) + (1 - A->momentum) * ax_in,
+                       A->momentum * PY(s) + (1 - A->momentum) * ay_in);
+    }
+    return;
+  }
+  double m0 = e.f[om], m1 = e.f[om + 1];
   if (A->kind == MOOG_ACTION_JOYSTICK) {
     double ax = ax_in, ay = A->constrained_lr ? 0. : ay_in;
     m0 *= A->momentum; m1 *= A->momentum;
@@ -2077,7 +2088,7 @@ __device__ inline void action_step(Env& e, double ax_in, double ay_in, int grid_
   if (m1 < -sc) m1 = -sc;
   if (m1 > sc) m1 = sc;
   wsync();
-  if (e.lane == 0) { e.f[e.L.o_action] = m0; e.f[e.L.o_action + 1] = m1; }
+  if (e.lane == 0) { e.f[om] = m0; e.f[om + 1] = m1; }
   wsync();
   for (int a = 0; a < A->n_layers; ++a) {
     int l = A->layers[a];
@@ -2365,7 +2376,7 @@ __device__ inline void env_reset(Env& e) {
   wsync();
   if (e.lane == 0) {
     for (int t = 0; t < P->n_tasks; ++t) e.f[e.L.o_task + t] = DINF;
-    e.f[e.L.o_action] = 0; e.f[e.L.o_action + 1] = 0;
+    for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) e.f[e.L.o_action + k] = 0;
   }
   wsync();
   for (int r = 0; r < P->n_rules; ++r)

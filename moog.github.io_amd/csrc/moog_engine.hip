@@ -269,14 +269,20 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
   const int n_rules = uni(P->n_rules);
   for (int r = 0; r < n_rules; ++r)
     if (P->rules[r].parent < 0) rule_step<DYN>(e, r);
-  double ax = 0, ay = 0;
-  int ga = 4;
-  if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
-  else {
-    ax = reinterpret_cast<const double*>(a.actions)[2 * env];
-    ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
+  if (uni(P->n_actions) > 1) {   // composite.py:61-62: every sub-space, in keyword order
+    const int na = uni(P->n_actions);
+    const double* act = reinterpret_cast<const double*>(a.actions) + (size_t)2 * na * env;
+    for (int k = 0; k < na; ++k) action_step(e, k, act[2 * k], act[2 * k + 1], (int)act[2 * k]);
+  } else {
+    double ax = 0, ay = 0;
+    int ga = 4;
+    if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
+    else {
+      ax = reinterpret_cast<const double*>(a.actions)[2 * env];
+      ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
+    }
+    action_step(e, 0, ax, ay, ga);
   }
-  action_step(e, ax, ay, ga);
   for (int k = 0; k < K; ++k) apply_physics(e);
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();

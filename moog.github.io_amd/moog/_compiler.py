@@ -569,18 +569,34 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     P.n_tasks = len(subtasks)
 
     # ---- action space -----------------------------------------------------------------
-    A = P.action
-    if isinstance(action_space, action_spaces.Joystick):
-        A.kind = _abi.MOOG_ACTION_JOYSTICK
-        A.constrained_lr = int(action_space._constrained_lr)
-    elif isinstance(action_space, action_spaces.Grid):
-        A.kind = _abi.MOOG_ACTION_GRID
+    def lower_action(A, space):
+        if isinstance(space, action_spaces.Joystick):
+            A.kind = _abi.MOOG_ACTION_JOYSTICK
+            A.constrained_lr = int(space._constrained_lr)
+        elif isinstance(space, action_spaces.Grid):
+            A.kind = _abi.MOOG_ACTION_GRID
+        elif isinstance(space, action_spaces.SetPosition):
+            A.kind = _abi.MOOG_ACTION_SET_POSITION
+            A.n_layers = _fill_layers(A.layers, space._action_layers, layer_index)
+            A.momentum = float(space._inertia)
+            return
+        else:
+            raise NotImplementedError('action space %r is not lowered' % (type(space).__name__,))
+        A.n_layers = _fill_layers(A.layers, space._action_layers, layer_index)
+        A.control_velocity = int(space._control_velocity)
+        A.scaling_factor = float(space._scaling_factor)
+        A.momentum = float(space._momentum)
+
+    if isinstance(action_space, action_spaces.Composite):
+        subs = list(action_space.action_spaces.values())
+        if not 1 <= len(subs) <= _abi.MOOG_MAX_ACTIONS:
+            raise ValueError('Composite takes 1..%d action spaces' % _abi.MOOG_MAX_ACTIONS)
+        P.n_actions = len(subs)
+        for k, sub in enumerate(subs):
+            lower_action(P.action if k == 0 else P.more_actions[k - 1], sub)
     else:
-        raise NotImplementedError('action space %r is not lowered' % (type(action_space).__name__,))
-    A.n_layers = _fill_layers(A.layers, action_space._action_layers, layer_index)
-    A.control_velocity = int(action_space._control_velocity)
-    A.scaling_factor = float(action_space._scaling_factor)
-    A.momentum = float(action_space._momentum)
+        P.n_actions = 1
+        lower_action(P.action, action_space)
 
     # ---- observer -----------------------------------------------------------------------
     obs_items = list(observers.items()) if observers else []

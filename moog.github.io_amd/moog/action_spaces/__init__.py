@@ -1,6 +1,9 @@
 """Action spaces (reference: moog/action_spaces/__init__.py:3-7): Joystick
-(joystick.py:10-77) and Grid (grid.py:8-82).  Parameter records + specs.
+(joystick.py:10-77), Grid (grid.py:8-82), SetPosition (set_position.py:13-67) and Composite
+(composite.py:11-79).  Parameter records + specs.
 """
+import collections
+
 import numpy as np
 
 from .. import _dm_env as dm_env
@@ -49,3 +52,43 @@ class Grid(AbstractActionSpace):
 
     def action_spec(self):
         return self._action_spec
+
+
+class SetPosition(AbstractActionSpace):
+    """set_position.py:13-67: the action in [0, 1]^2 is where the sprites of action_layers go
+    (blended with their position by `inertia`)."""
+
+    def __init__(self, action_layers='agent', inertia=0.):
+        if not isinstance(action_layers, (list, tuple)):
+            action_layers = (action_layers,)
+        self._action_layers = action_layers
+        self._inertia = inertia
+        self._action_spec = dm_env.specs.BoundedArray(
+            shape=(2,), dtype=np.float32, minimum=0, maximum=1)
+
+    def random_action(self):
+        return np.random.uniform(0., 1., size=(2,))
+
+    def action_spec(self):
+        return self._action_spec
+
+
+class Composite(AbstractActionSpace):
+    """composite.py:11-79: several action spaces side by side (multi-agent tasks, eye + hand);
+    an action is a dict with the same keys, applied in keyword order.  Batched actions are a
+    dict of tensors (or one f64 tensor [N, n_spaces, 2]; a Grid move goes in component 0)."""
+
+    def __init__(self, **action_spaces):
+        self.action_spaces = collections.OrderedDict(action_spaces)
+        self._action_keys = list(self.action_spaces.keys())
+        self._action_spec = {k: v.action_spec() for k, v in self.action_spaces.items()}
+
+    def random_action(self):
+        return {k: v.random_action() for k, v in self.action_spaces.items()}
+
+    def action_spec(self):
+        return self._action_spec
+
+    @property
+    def action_keys(self):
+        return list(self._action_keys)

@@ -91,7 +91,9 @@ class BatchedEnvironment(object):
         self._out.discount = ctypes.cast(self.discount.data_ptr(), ctypes.POINTER(ctypes.c_double))
         self._out.step_type = ctypes.cast(self.step_type.data_ptr(), ctypes.POINTER(ctypes.c_int32))
         self._out.image = ctypes.cast(self.image.data_ptr(), ctypes.POINTER(ctypes.c_uint8))
-        self._is_grid = P.action.kind == _abi.MOOG_ACTION_GRID
+        self._composite = hasattr(action_space, 'action_spaces')
+        self._n_actions = max(1, int(P.n_actions))
+        self._is_grid = (not self._composite) and P.action.kind == _abi.MOOG_ACTION_GRID
         self._dynamic_layers = any(P.layer_dynamic[i] for i in range(P.n_layers))
         self.check_faults = True
         self._cost = self._perm = None
@@ -174,7 +176,9 @@ class BatchedEnvironment(object):
 
     def step(self, action, injected_uniforms=None):
         torch = self._torch
-        if self._is_grid:
+        if self._composite:
+            a = self._pack_composite(action)
+        elif self._is_grid:
             a = torch.as_tensor(action, device=self.device).to(torch.int32).contiguous()
             assert a.shape == (self.num_envs,)
         else:
@@ -200,6 +204,33 @@ class BatchedEnvironment(object):
             self.raise_faults()
         del keep
         return self._timestep()
+
+    def _pack_composite(self, action):
+        """Composite actions (composite.py:51-62): a dict {key: tensor [N, 2] or, for a Grid
+        sub-space, [N] move indices}, or the packed f64 tensor [N, n_spaces, 2] itself."""
+        torch = self._torch
+        n, k = self.num_envs, self._n_actions
+        if isinstance(action, dict):
+            keys = self.action_space.action_keys
+            if set(action) != set(keys):
+                raise KeyError('composite action keys %s, expected %s' % (sorted(action), keys))
+            a = torch.zeros((n, len(keys), 2), dtype=torch.float64, device=self.device)
+            for i, key in enumerate(keys):
+                v = torch.as_tensor(action[key], device=self.device).to(torch.float64)
+                if v.dim() == 1 and v.shape[0] == n:      # Grid move indices
+                    a[:, i, 0] = v
+                else:
+                    a[:, i, :] = v.reshape(n, 2)
+        else:
+            a = torch.as_tensor(action, device=self.device).to(torch.float64)
+        a = a.reshape(n, -1)
+        if self._n_actions == 1:   # a Composite of one space is that space's own buffer
+            a = a[:, :2]
+            if self.compiled.program.action.kind == _abi.MOOG_ACTION_GRID:
+                return a[:, 0].to(torch.int32).contiguous()
+            return a.contiguous()
+        assert a.shape == (n, 2 * k), a.shape
+        return a.contiguous()
 
     def _host_reset(self):
         if self._meta_state_initializer is not None:
@@ -258,6 +289,17 @@ class BatchedEnvironment(object):
 
     def random_action(self):
         torch = self._torch
+        if self._composite:
+            out = {}
+            for key, sub in self.action_space.action_spaces.items():
+                kind = type(sub).__name__
+                if kind == 'Grid':
+                    out[key] = torch.randint(0, 5, (self.num_envs,), dtype=torch.int32, device=self.device)
+                elif kind == 'SetPosition':
+                    out[key] = torch.rand((self.num_envs, 2), dtype=torch.float64, device=self.device)
+                else:
+                    out[key] = torch.rand((self.num_envs, 2), dtype=torch.float64, device=self.device) * 2 - 1
+            return out
         if self._is_grid:
             return torch.randint(0, 5, (self.num_envs,), dtype=torch.int32, device=self.device)
         return torch.rand((self.num_envs, 2), dtype=torch.float64, device=self.device) * 2 - 1
@@ -392,6 +434,13 @@ class Environment(object):
         return self._unbatch(self._batched.reset())
 
     def step(self, action):
+        if isinstance(action, dict):   # Composite: {key: sub-action}
+            keys = self._batched.action_space.action_keys
+            packed = np.zeros((1, len(keys), 2))
+            for i, key in enumerate(keys):
+                v = np.asarray(action[key], dtype=np.float64).reshape(-1)
+                packed[0, i, :len(v)] = v
+            return self._unbatch(self._batched.step(packed))
         a = np.asarray(action)
         if self._batched._is_grid:
             a = a.reshape(1)

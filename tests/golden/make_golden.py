@@ -179,6 +179,14 @@ def snapshot(env, layer_names, caps, slot_of):
     return d
 
 
+def action_memory(space):
+    """_action of the space; for a Composite the sub-spaces' memories in keyword order
+    (zeros for spaces without memory, e.g. SetPosition)."""
+    subs = list(space.action_spaces.values()) if hasattr(space, 'action_spaces') else [space]
+    return np.concatenate([np.array(getattr(sp, '_action', np.zeros(2)), dtype=float).reshape(2)
+                           for sp in subs])
+
+
 def bookkeeping(env):
     subtasks = getattr(env.task, '_tasks', (env.task,))
     tc = [float(getattr(t, '_steps_until_reset', np.nan)) for t in subtasks]
@@ -205,7 +213,7 @@ def bookkeeping(env):
         return out
     rc_flat = walk(list(env.game_rules), [])
     return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
-                action_mem=np.array(env.action_space._action, dtype=float),
+                action_mem=action_memory(env.action_space),
                 task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
                 rule_counters_flat=np.array(rc_flat, dtype=float))
 
@@ -231,6 +239,17 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     if not hasattr(env, 'game_rules') or env.game_rules is None:
         env.game_rules = ()
     is_grid = type(env.action_space).__name__ == 'Grid'
+    space_kind = type(env.action_space).__name__
+
+    def draw_action(space):
+        """(the action handed to the reference, its packed [2] record)"""
+        kind = type(space).__name__
+        if kind == 'Grid':
+            a = int(act_rs.randint(5))
+            return a, np.array([float(a), 0.])
+        lo = 0. if kind == 'SetPosition' else -1.
+        a = act_rs.uniform(lo, 1., size=2)
+        return a, a.copy()
     K = env.physics.updates_per_env_step
 
     sub_log = []
@@ -283,13 +302,23 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         rows.append(row)
 
     zero_action = 4 if is_grid else np.zeros(2)
+    if space_kind == 'Composite':
+        zero_action = np.zeros((len(env.action_space.action_spaces), 2))
     push(ts, zero_action, TAPE.take())
     for t in range(1, n_calls + 1):
-        action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
+        if space_kind == 'Composite':      # dict action, recorded as [n_spaces, 2]
+            drawn = [(k, draw_action(sp)) for k, sp in env.action_space.action_spaces.items()]
+            ref_action = {k: d[0] for k, d in drawn}
+            action = np.stack([d[1] for _, d in drawn])
+        elif space_kind == 'SetPosition':
+            ref_action, action = draw_action(env.action_space)
+        else:
+            action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
+            ref_action = action if is_grid else np.array(action)
         will_reset = env.reset_next_step
         if t <= n_sub_steps and not will_reset:
             state_box['log'] = []
-        ts = env.step(np.array(action) if not is_grid else action)
+        ts = env.step(ref_action)
         if will_reset:
             slot_of = init_box['slot_of']
             state_box['slot_of'] = slot_of
@@ -553,6 +582,8 @@ def main():
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('cond_zoo', 120, {'extras': 8, '__dynamic__': ('extras',)}, (0, 1)),
         ('phase_zoo', 120, {}, (0, 1)),
+        ('actions_zoo', 60, {}, (0, 1)),
+        ('actions_zoo_l1', 40, {}, (0,)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,

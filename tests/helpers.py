@@ -76,7 +76,10 @@ class OracleEnv(object):
 
     def step(self, actions, uniforms=None, render=True):
         u, nu = self._inj(uniforms)
-        if self.P.action.kind == _abi.MOOG_ACTION_GRID:
+        if self.P.n_actions > 1:   # Composite: [n, n_actions, 2] (a Grid move in component 0)
+            a = np.ascontiguousarray(actions, np.float64).reshape(self.n, 2 * self.P.n_actions)
+            af, ai = a, None
+        elif self.P.action.kind == _abi.MOOG_ACTION_GRID:
             a = np.ascontiguousarray(actions, np.int32).reshape(self.n)
             af, ai = None, a
         else:
@@ -141,7 +144,8 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
     f[L.o_color:L.o_color + 3 * S] = nz(fx['color'][t]).ravel()
     f[L.o_inertia:L.o_inertia + 2 * S] = nz(fx['inertia'][t]).ravel()
     f[L.o_maxr:L.o_maxr + S] = nz(fx['maxr'][t])
-    f[L.o_action:L.o_action + 2] = fx['action_mem'][t]
+    am = np.asarray(fx['action_mem'][t], np.float64).reshape(-1)
+    f[L.o_action:L.o_action + len(am)] = am
     tc = np.asarray(fx['task_counters'][t], np.float64).reshape(-1)
     for k in range(P.n_tasks):
         f[L.o_task + k] = tc[k] if k < len(tc) and not np.isnan(tc[k]) else np.inf
@@ -270,7 +274,8 @@ def state_diff(fx, t, c, f64, i32, env=0):
         ints_ok = False
         detail.append('step_count/reset_next %d/%d vs %d/%d' % (
             q[L.o_step_count], q[L.o_reset_next], fx['step_count'][t], fx['reset_next'][t]))
-    am = float(np.max(np.abs(f[L.o_action:L.o_action + 2] - fx['action_mem'][t])))
+    ref_am = np.asarray(fx['action_mem'][t], np.float64).reshape(-1)
+    am = float(np.max(np.abs(f[L.o_action:L.o_action + len(ref_am)] - ref_am)))
     err['action_mem'] = am
     tc = np.asarray(fx['task_counters'][t], np.float64).reshape(-1)
     for k in range(min(P.n_tasks, len(tc))):

@@ -16,7 +16,8 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('tether_zoo_l4', 0), ('distrib_zoo', 0), ('distrib_zoo', 1),
         ('rules_zoo_l0', 0), ('rules_zoo_l1', 0), ('rules_zoo_l1', 1),
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
-        ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1)]
+        ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1),
+        ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0)]
 
 
 def make_env(name, n, seed=0, **kw):
@@ -92,8 +93,9 @@ def test_free_running_vs_reference(name, seed):
     upload(env, f64, i32)
     env.check_faults = False
     for t in range(1, T):
-        out = env.step(np.asarray(fx['action'][t]).reshape((1, 2) if not fx['is_grid'] else (1,)),
-                       injected_uniforms=padded_uniforms(fx, [t]))
+        a = np.asarray(fx['action'][t])
+        a = a.reshape((1,) + a.shape) if a.ndim == 2 else a.reshape((1, 2) if not fx['is_grid'] else (1,))
+        out = env.step(a, injected_uniforms=padded_uniforms(fx, [t]))
         f, q = download(env)
         d = state_diff(fx, t, c, f, q)
         assert d['ints_ok'], (t, d)
@@ -569,3 +571,37 @@ def test_raw_state_observer():
     ts = env.step(np.array([1.0, 0.0]))
     assert ts.observation['state']['agent'][0]['x'] > 0.25
     assert 'state' not in env.observation_spec()
+
+
+def test_composite_action_dict_api():
+    """Composite (composite.py:51-62): dict actions keyed like the sub-spaces, through the
+    batched engine (dict of tensors) and the single-env facade (dict of arrays); both equal
+    the packed-tensor form."""
+    import torch
+    from moog import environment
+    from moog_demos import example_configs
+    cfg = example_configs.load('actions_zoo')
+    env = environment.BatchedEnvironment(num_envs=32, seed=3, **cfg)
+    env2 = environment.BatchedEnvironment(num_envs=32, seed=3, **example_configs.load('actions_zoo'))
+    env.reset(); env2.reset()
+    assert set(env.action_spec()) == {'agent_0', 'agent_1', 'eye'}
+    g = torch.Generator().manual_seed(0)
+    for _ in range(6):
+        joy = torch.rand((32, 2), generator=g, dtype=torch.float64) * 2 - 1
+        move = torch.randint(0, 5, (32,), generator=g)
+        eye = torch.rand((32, 2), generator=g, dtype=torch.float64)
+        env.step({'agent_0': joy, 'agent_1': move, 'eye': eye})
+        packed = torch.zeros((32, 3, 2), dtype=torch.float64)
+        packed[:, 0], packed[:, 1, 0], packed[:, 2] = joy, move.double(), eye
+        env2.step(packed)
+    f, q = download(env)
+    f2, q2 = download(env2)
+    assert np.array_equal(f, f2, equal_nan=True) and np.array_equal(q, q2)
+    with pytest.raises(KeyError):
+        env.step({'agent_0': joy})
+    single = environment.Environment(**example_configs.load('actions_zoo'))
+    single.reset()
+    ts = single.step({'agent_0': np.array([0.5, -0.5]), 'agent_1': 3, 'eye': np.array([0.2, 0.9])})
+    assert ts.observation['image'].shape == (64, 64, 3)
+    ra = env.random_action()
+    assert set(ra) == {'agent_0', 'agent_1', 'eye'} and ra['agent_1'].shape == (32,)
