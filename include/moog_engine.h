@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 13
+#define MOOG_ABI_VERSION 14
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -140,7 +140,8 @@ enum {
   MOOG_X_MIN, MOOG_X_MAX, MOOG_X_LT, MOOG_X_LE, MOOG_X_GT, MOOG_X_GE, MOOG_X_EQ, MOOG_X_NE,
   MOOG_X_AND, MOOG_X_OR, MOOG_X_NEG, MOOG_X_ABS, MOOG_X_SQRT, MOOG_X_SIN, MOOG_X_COS,
   MOOG_X_FLOOR, MOOG_X_NOT, MOOG_X_SIGN, MOOG_X_SELECT, MOOG_X_STORE, MOOG_X_END,
-  MOOG_X_RULE_STATE   /* push the state scalar of rule a (e.g. a PhaseSequence's current phase index) */
+  MOOG_X_RULE_STATE,  /* push the state scalar of rule a (e.g. a PhaseSequence's current phase index) */
+  MOOG_X_OVERLAPS_FIRST /* push sprite b .overlaps_sprite(first live sprite of layer a) (0 when the layer is empty) */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -272,7 +273,9 @@ enum {
   MOOG_RCOND_CONTACT_COUNT,     /* contact_rules.get_contact_counter(l0, l1): overlapping pairs */
   MOOG_RCOND_ALL_EXPR,          /* as MOOG_COND_ALL_EXPR .. FIRST_EXPR: layer l0, expression   */
   MOOG_RCOND_ANY_EXPR,          /*   xfilter; FIRST_EXPR's value is the repeat count           */
-  MOOG_RCOND_FIRST_EXPR
+  MOOG_RCOND_FIRST_EXPR,
+  MOOG_RCOND_COUNT_EXPR         /* sum of expression xfilter over the sprites of layer l0 (a loop that
+                                   accumulates per-sprite terms, cleanup.py:181-190)                 */
 };
 
 /* Rules form a forest in pre-order: `parent` is the index of the enclosing TIMED /

@@ -1361,6 +1361,15 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
     if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_OVERLAPS_FIRST) {   // sprite.overlaps_sprite(state[L][0])
+      const int sp = I->b ? s1 : s0;
+      int first = -1;
+      for (int q = P->layer_slot0[I->a]; q < P->layer_slot0[I->a] + P->layer_nslots[I->a] && first < 0; ++q)
+        if (ALIVE(q)) first = q;
+      const bool ov = first >= 0 && overlaps(e, sp, first);
+      v[n] = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
+      continue;
+    }
     if (op == MOOG_X_STORE) {
       --n;
       st->mask |= 1u << I->a;
@@ -1853,6 +1862,13 @@ __device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
   }
   if (R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR)
     return (int)layer_condition(e, R->cond, R->l0, R->xfilter);
+  if (R->cond == MOOG_RCOND_COUNT_EXPR) {   // accumulated per-sprite terms
+    PProg P = e.P;
+    double acc = 0;
+    for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0]; ++s)
+      if (ALIVE(s)) acc += eval_expr(e, R->xfilter, s, s, nullptr, nullptr);
+    return (int)acc;
+  }
   return 0;
 }
 

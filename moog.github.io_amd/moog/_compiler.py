@@ -409,6 +409,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             phase_keys[r._meta_state_key] = (ri, [ph.name for ph in r._phases])
 
     def resolve_phase(key, name):
+        if key is None:   # an overlap test against state[name][0]
+            return layer_index(name)
         if key not in phase_keys:
             raise NotImplementedError('meta_state[%r] is not published by a PhaseSequence' % (key,))
         ri, names = phase_keys[key]

@@ -242,9 +242,22 @@ class SymVec(object):
 class SymSprite(object):
     """A sprite whose factors are symbolic; attribute writes are recorded."""
 
-    def __init__(self, index):
+    def __init__(self, index, first_of=None):
         object.__setattr__(self, '_index', index)
         object.__setattr__(self, '_written', {})
+        object.__setattr__(self, '_first_of', first_of)   # layer name when this is state[L][0]
+
+    def overlaps_sprite(self, other):
+        """sprite.py:462-484 as a symbolic test (lowered to the engine's overlap routine):
+        only a representative of a quantified layer against the first sprite of a layer."""
+        if not isinstance(other, SymSprite):
+            raise Unsupported('overlaps_sprite with a concrete sprite')
+        a, b = self, other
+        if a._first_of is not None and b._first_of is None:
+            a, b = b, a          # overlap is symmetric (intersects_path both ways, filled)
+        if a._first_of is not None or b._first_of is None:
+            raise Unsupported('overlaps_sprite is lowered for (layer sprite, state[L][0]) only')
+        return Sym(Node('overlaps', a._index, b._first_of))
 
     def _get(self, name):
         w = self._written
@@ -375,21 +388,22 @@ class _SymLayer(object):
 
     def __iter__(self):
         self._owner.note('quant', self._name)
-        return iter([SymSprite(0), SymSprite(1)])
+        return iter([SymSprite(i) for i in range(self._owner.reps)])
 
     def __getitem__(self, i):
         if i != 0:
             raise Unsupported('only state[layer][0] is lowered')
         self._owner.note('first', self._name)
-        return SymSprite(0)
+        return SymSprite(0, first_of=self._name)
 
     def __len__(self):
         raise Unsupported('len(state[layer]) is not symbolic')
 
 
 class _SymState(object):
-    def __init__(self):
+    def __init__(self, reps=2):
         self.uses = []
+        self.reps = reps
 
     def note(self, kind, layer):
         if (kind, layer) not in self.uses:
@@ -425,13 +439,15 @@ class _SymMeta(object):
 def _substitute(node, old, new):
     if node.op == 'attr':
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
+    if node.op == 'overlaps':
+        return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op in ('const', 'phase_is'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
 
 def _sprites_of(node, acc):
-    if node.op == 'attr':
+    if node.op in ('attr', 'overlaps'):
         acc.add(node.args[0])
     elif node.op not in ('const', 'phase_is'):
         for a in node.args:
@@ -440,42 +456,98 @@ def _sprites_of(node, acc):
     return acc
 
 
+class _RandomLeaves(object):
+    """Random values for the leaves of an expression (consistent within one assignment)."""
+
+    def __init__(self, rs):
+        self.rs, self.vals = rs, {}
+
+    def get(self, key, boolean):
+        if key not in self.vals:
+            self.vals[key] = float(self.rs.randint(2)) if boolean else float(self.rs.choice(
+                [0., 0.3, 0.5, 0.6, 1., -1., 2.5]))
+        return self.vals[key]
+
+
+def _evaluate(node, env):
+    """Python-float value of an expression tree (used to check algebraic properties)."""
+    op, a = node.op, node.args
+    if op == 'const':
+        return a[0]
+    if op == 'attr':
+        return env.get(node.key(), False)
+    if op in ('overlaps', 'phase_is'):
+        return env.get(node.key(), True)
+    v = [_evaluate(x, env) for x in a]
+    if op == 'select':
+        return v[1] if v[0] != 0 else v[2]
+    table = {
+        'add': lambda: v[0] + v[1], 'sub': lambda: v[0] - v[1], 'mul': lambda: v[0] * v[1],
+        'div': lambda: v[0] / v[1] if v[1] else float('inf'), 'rem': lambda: np.remainder(v[0], v[1]),
+        'min': lambda: min(v), 'max': lambda: max(v), 'lt': lambda: float(v[0] < v[1]),
+        'le': lambda: float(v[0] <= v[1]), 'gt': lambda: float(v[0] > v[1]), 'ge': lambda: float(v[0] >= v[1]),
+        'eq': lambda: float(v[0] == v[1]), 'ne': lambda: float(v[0] != v[1]),
+        'and': lambda: float(v[0] != 0 and v[1] != 0), 'or': lambda: float(v[0] != 0 or v[1] != 0),
+        'neg': lambda: -v[0], 'abs': lambda: abs(v[0]), 'sqrt': lambda: abs(v[0]) ** 0.5,
+        'sin': lambda: np.sin(v[0]), 'cos': lambda: np.cos(v[0]), 'floor': lambda: np.floor(v[0]),
+        'not': lambda: float(v[0] == 0), 'sign': lambda: np.sign(v[0]),
+    }
+    return float(table[op]())
+
+
 def trace_state_condition(fn, with_meta=False):
     """Lowers `condition(state)` / `condition(state, meta_state)` of the forms
         all(pred(s) for s in state[L])  /  any(...)      -> ('all' | 'any', L, pred expression)
         expr(state[L][0])                                 -> ('first', L, expression)
     where pred / expr only read sprite attributes."""
-    global _TRACER
-    paths = []
-    forced = []
-    uses = None
-    while True:
-        tr = _Tracer()
-        tr.forced = list(forced)
-        st = _SymState()
-        prev, _TRACER = _TRACER, tr
-        try:
-            ret = fn(st, _SymMeta()) if with_meta else fn(st)
-        finally:
-            _TRACER = prev
-        uses = st.uses if uses is None else uses
-        if st.uses != uses:
-            raise Unsupported('condition touches different layers on different paths')
-        paths.append((list(tr.trail), ret, []))
-        if len(paths) > MAX_PATHS:
-            raise Unsupported('too many execution paths in a lowered condition')
-        trail = tr.trail
-        k = len(trail) - 1
-        while k >= 0 and trail[k][1] is False:
-            k -= 1
-        if k < 0:
-            break
-        forced = [v for _, v in trail[:k]] + [False]
+    def explore(reps):
+        global _TRACER
+        paths, forced, uses = [], [], []
+        while True:
+            tr = _Tracer()
+            tr.forced = list(forced)
+            st = _SymState(reps)
+            prev, _TRACER = _TRACER, tr
+            try:
+                ret = fn(st, _SymMeta()) if with_meta else fn(st)
+            finally:
+                _TRACER = prev
+            for u in st.uses:
+                if u not in uses:
+                    uses.append(u)
+            paths.append((list(tr.trail), ret, []))
+            if len(paths) > MAX_PATHS:
+                raise Unsupported('too many execution paths in a lowered condition')
+            trail = tr.trail
+            k = len(trail) - 1
+            while k >= 0 and trail[k][1] is False:
+                k -= 1
+            if k < 0:
+                return paths, uses
+            forced = [v for _, v in trail[:k]] + [False]
+
+    paths, uses = explore(2)
     if not uses:   # reads only the meta-state (e.g. the current phase)
         return 'plain', None, _merge(paths, lambda p: lift(p[1]))
-    if len(uses) != 1:
-        raise Unsupported('condition must look at exactly one layer')
-    kind, layer = uses[0]
+    quant = [l for k, l in uses if k == 'quant']
+    if len(quant) > 1 or (not quant and len(uses) != 1):
+        raise Unsupported('condition must iterate over at most one layer')
+    if quant and not all(isinstance(p[1], (bool, np.bool_)) for p in paths):
+        # an accumulated number, e.g. `n += s.overlaps_sprite(agent)` in a loop (cleanup.py:181-190):
+        # the per-sprite term comes from a one-sprite layer; that the two-sprite result is the sum
+        # of the two terms is checked on random assignments of the attribute / overlap values
+        one, _ = explore(1)
+        g = _merge(one, lambda p: lift(p[1]))
+        h = _merge(paths, lambda p: lift(p[1]))
+        rs = np.random.RandomState(0)
+        for _ in range(256):
+            env = _RandomLeaves(rs)
+            if abs(_evaluate(h, env) - (_evaluate(g, env) + _evaluate(_substitute(g, 0, 1), env))) > 1e-12:
+                raise Unsupported('condition is not a sum of per-sprite terms over the layer')
+        return 'count', quant[0], g
+    kind, layer = ('quant', quant[0]) if quant else uses[0]
+    if quant and len(uses) > 1:
+        raise Unsupported('all / any conditions may read one layer only')
     if kind == 'first':
         return 'first', layer, _merge(paths, lambda p: lift(p[1]))
     # quantifier: every decision must be the same predicate on one of the two representatives
@@ -522,6 +594,11 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_CONST, x=float(idx), b=0))
         out.append(dict(op=_abi.MOOG_X_EQ))
         return out
+    if node.op == 'overlaps':   # (layer sprite, state[L][0]); resolver(None, L) gives L's index
+        if resolver is None:
+            raise Unsupported('overlap test outside a state condition')
+        out.append(dict(op=_abi.MOOG_X_OVERLAPS_FIRST, a=resolver(None, node.args[1]), b=int(node.args[0])))
+        return out
     if node.op == 'const':
         out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
     elif node.op == 'attr':
@@ -547,7 +624,7 @@ def depth(code):
     d = m = 0
     for ins in code:
         op = ins['op']
-        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE):
+        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE, _abi.MOOG_X_OVERLAPS_FIRST):
             d += 1
         elif op == _abi.MOOG_X_SELECT:
             d -= 2

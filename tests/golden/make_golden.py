@@ -101,7 +101,7 @@ def patch_numpy_random():
 
 
 SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
-           'first_person_predators_prey')
+           'first_person_predators_prey', 'cleanup')
 
 
 def load_amd_config(name):
@@ -233,6 +233,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     caps_by_layer = dict(caps_by_layer)
     DYNAMIC_LAYERS = tuple(caps_by_layer.pop('__dynamic__', ()))
     STATE_VMAX = caps_by_layer.pop('__vmax__', VMAX)
+    action_bias = caps_by_layer.pop('__bias__', None)   # [n_spaces][2] drift of the random actions
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -308,6 +309,9 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     for t in range(1, n_calls + 1):
         if space_kind == 'Composite':      # dict action, recorded as [n_spaces, 2]
             drawn = [(k, draw_action(sp)) for k, sp in env.action_space.action_spaces.items()]
+            if action_bias is not None:   # steer the agents so that the rules have something to do
+                drawn = [(k, (np.clip(d[0] + b, -1., 1.), np.clip(d[1] + b, -1., 1.)))
+                         for (k, d), b in zip(drawn, np.asarray(action_bias, dtype=float))]
             ref_action = {k: d[0] for k, d in drawn}
             action = np.stack([d[1] for _, d in drawn])
         elif space_kind == 'SetPosition':
@@ -584,6 +588,7 @@ def main():
         ('phase_zoo', 120, {}, (0, 1)),
         ('actions_zoo', 60, {}, (0, 1)),
         ('actions_zoo_l1', 40, {}, (0,)),
+        ('cleanup', 150, {'__bias__': [[0., -0.7], [0., 0.7], [0.3, -0.5]]}, (0, 1)),
         ('rules_zoo_l0', 40, {'bin': 8, '__dynamic__': ('bin',)}, (0,)),
         ('rules_zoo_l1', 80, {'prey': 8, 'predators': 8, '__dynamic__': ('prey', 'predators')}, (0, 1)),
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,

@@ -35,3 +35,4 @@ run('lambda_zoo', 4096)
 run('rules_zoo_l1', 4096)
 run('tether_zoo_l0', 4096)
 run('distrib_zoo', 4096)
+run('cleanup', 4096, steps=60)
