@@ -432,6 +432,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     }
     e->raster_chunk = chunk;
     e->raster_lds = pl.total;
+    { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
   err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
