@@ -333,6 +333,7 @@ struct moog_engine {
   moog_layout_t L;
   moog_program_t* d_prog = nullptr;
   int16_t* d_vslot = nullptr;
+  uint32_t* d_vinfo = nullptr;   // rasteriser: vertex slot -> sprite slot | index within the sprite << 8
   int32_t n_envs = 0;
   int device = 0;
   uint64_t seed = 0;
@@ -340,7 +341,8 @@ struct moog_engine {
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
   bool dynamic_rules = false;
-  int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_items = 0, raster_xxcap = 4;
+  RPlan raster_plan_{};
+  int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_hwords = 1, raster_xxcap = 4;
   int timing = 0;   // bit k: launches of kernel k are bracketed by HIP events
   int32_t* perm = nullptr;
   hipStream_t sched_stream = nullptr;   // the launch-order sort runs beside the rasteriser
@@ -398,6 +400,13 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err == hipSuccess)
       err = hipMemcpy(e->d_vslot, vs.data(), vs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
     if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
+    std::vector<uint32_t> vi(vs.size(), 0u);
+    for (int sl = 0; sl < prog->n_slots; ++sl)
+      for (int k = 0; k < prog->slot_vcap[sl]; ++k) vi[prog->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
+    err = hipMalloc(&e->d_vinfo, vi.size() * sizeof(uint32_t));
+    if (err == hipSuccess)
+      err = hipMemcpy(e->d_vinfo, vi.data(), vi.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { hipFree(e->d_prog); hipFree(e->d_vslot); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
@@ -408,29 +417,32 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
   }
-  // raster LDS plan (moog_raster.h): masks for `chunk` items per pass
+  // raster LDS plan (moog_raster.h): row records for `chunk` rows per pass
   {
     int W = prog->render.width, H = prog->render.height;
     int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
+    int items = prog->n_slots * ncopy;
+    if (items < 1) items = 1;
     e->raster_words = (W + 63) / 64;
-    e->raster_items = prog->n_slots * ncopy;
-    if (e->raster_items < 1) e->raster_items = 1;
-    e->raster_iwords = (e->raster_items + 31) / 32;
+    e->raster_iwords = (items + 31) / 32;
     int maxv = 2;
     for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
     e->raster_xxcap = 2 * maxv;
+    e->raster_hwords = (maxv + 31) / 32;
     RPlan pl;
-    // coverage-mask buffer: at most 512 rows per pass (>= H so any item fits)
-    int cap = e->raster_items * H;
-    if (cap > 512) cap = 512;
+    // at most 376 rows per pass (>= H so that any item fits; sized so that six workgroups of the
+    // 4096 x 32-sprite workload share a CU); frames with more rows take several passes
+    int cap = items * H;
+    if (cap > 376) cap = 376;
     if (cap < H) cap = H;
-    int chunk = cap;
-    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_words, e->raster_iwords, e->raster_xxcap, &pl);
-    if (pl.total > 160 * 1024) {
-      hipFree(e->d_prog); hipFree(e->d_vslot); delete e;
+    { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= H) cap = atoi(rc); }   // tuning / tests of the multi-pass path
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_iwords, e->raster_hwords, e->raster_xxcap, &pl);
+    if (pl.total > 160 * 1024 || (size_t)e->L.TOTV * ncopy >= (1u << 20)) {
+      hipFree(e->d_prog); hipFree(e->d_vslot); hipFree(e->d_vinfo); delete e;
       return fail(MOOG_E_UNSUPPORTED, "raster working set does not fit in LDS");
     }
-    e->raster_chunk = chunk;
+    e->raster_chunk = cap;
+    e->raster_plan_ = pl;
     e->raster_lds = pl.total;
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
@@ -460,8 +472,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_reset_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
   if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->raster_lds);
+    err = (hipError_t)moog_raster_configure(e->raster_lds);
   if (err != hipSuccess) {
     hipFree(e->d_prog); delete e;
     return fail(MOOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(err));
@@ -491,6 +502,7 @@ int moog_engine_destroy(moog_engine_t* e) {
   }
   if (e->d_prog) hipFree(e->d_prog);
   if (e->d_vslot) hipFree(e->d_vslot);
+  if (e->d_vinfo) hipFree(e->d_vinfo);
   delete e;
   return MOOG_OK;
 }
@@ -542,13 +554,13 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
 static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   RArgs r;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
-  r.vslot = e->d_vslot;
+  r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
-  r.iwords = e->raster_iwords; r.max_items = e->raster_items; r.xxcap = e->raster_xxcap;
+  r.iwords = e->raster_iwords; r.hwords = e->raster_hwords; r.xxcap = e->raster_xxcap;
   { const char* ds = getenv("MOOG_RASTER_STOP"); r.debug_stop = ds ? atoi(ds) : 0; }
   {
     Bracket br(e, MOOG_K_RASTER, s);
-    hipLaunchKernelGGL(moog_raster_kernel, dim3(e->n_envs), dim3(R_THREADS), e->raster_lds, s, r);
+    moog_raster_launch(r, e->raster_lds, s);
   }
   HIPCHK(hipGetLastError());
   return MOOG_OK;

@@ -153,6 +153,31 @@ def test_engine_vs_oracle_own_rng(name):
     assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,rows', [('colliding_predators_32', None), ('colliding_predators_32', 64),
+                                       ('chase_avoid_torus', None), ('chase_avoid_torus', 64),
+                                       ('functional_maze', 64), ('falling_balls_64', None),
+                                       ('first_person_predators_prey', 128)])
+def test_frames_many_states(name, rows, monkeypatch):
+    """Frames of 256 envs over 12 steps against the oracle renderer, every step; with `rows` the
+    rasteriser's row records are capped (MOOG_RASTER_ROWS) so that a frame takes several passes."""
+    if rows is not None:
+        monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
+    n = 256
+    env = make_env(name, n, seed=21, env_index0=300)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=21, env_index0=300)
+    env.reset()
+    rs = np.random.RandomState(8)
+    for k in range(12):
+        a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.f64[:], o.i32[:] = download(env)
+        img = out.observation['image'].cpu().numpy()
+        ref = o.render()
+        bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+        assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist(), int(bad.size))
+
+
 def test_philox_bit_exact():
     """The device RNG stream equals the oracle's: a reset driven by it gives the
     same integer records (shape ids, counts, rng counters)."""

@@ -9,7 +9,7 @@ env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.lo
 env.reset()
 for _ in range(3):
     env.step(env.random_action())
-for stop in (4, 5, 0):
+for stop in [int(x) for x in os.environ.get('MOOG_RASTER_STOPS', '1,2,3,4,5,0').split(',')]:
     os.environ['MOOG_RASTER_STOP'] = str(stop)
     for _ in range(3):
         env.observation()
