@@ -430,11 +430,26 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_xxcap = 2 * maxv;
     e->raster_hwords = (maxv + 31) / 32;
     RPlan pl;
-    // at most 376 rows per pass (>= H so that any item fits; sized so that six workgroups of the
-    // 4096 x 32-sprite workload share a CU); frames with more rows take several passes
+    // Row records per pass: 376 (>= H so that any item fits; sized so that six workgroups of the
+    // 4096 x 32-sprite workload share a CU), then as many more as fit without costing a resident
+    // workgroup (frames with more rows than records take several passes).
     int cap = items * H;
     if (cap > 376) cap = 376;
     if (cap < H) cap = H;
+    raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_iwords, e->raster_hwords, e->raster_xxcap, &pl);
+    {
+      const unsigned lds_cu = 160 * 1024;
+      unsigned wgs = pl.total ? lds_cu / pl.total : 0;
+      if (wgs > 6) wgs = 6;   // registers hold six workgroups per CU at most
+      const int want = items * H < 4096 ? items * H : 4096;
+      while (wgs && cap < want) {
+        RPlan p2;
+        int c2 = cap + 32 < want ? cap + 32 : want;
+        raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, c2, e->raster_iwords, e->raster_hwords, e->raster_xxcap, &p2);
+        if (lds_cu / p2.total < wgs) break;
+        cap = c2; pl = p2;
+      }
+    }
     { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= H) cap = atoi(rc); }   // tuning / tests of the multi-pass path
     raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_iwords, e->raster_hwords, e->raster_xxcap, &pl);
     if (pl.total > 160 * 1024 || (size_t)e->L.TOTV * ncopy >= (1u << 20)) {

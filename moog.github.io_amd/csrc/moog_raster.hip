@@ -77,6 +77,7 @@ struct RPoly {
   int n;
   const unsigned* head;      // bit k: record k is a horizontal head
   int hwords;
+  unsigned rowbits;          // heads on the row being drawn, bit (k mod 32) (~0u: not known)
 };
 
 __device__ __forceinline__ bool r_is_table(const REdge& E) { return E.y0 != E.y1; }
@@ -84,7 +85,7 @@ __device__ __forceinline__ bool r_is_table(const REdge& E) { return E.y0 != E.y1
 // Draw.c draw_horizontal_lines (heads visited in edge order)
 __device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask& m, int W) {
   for (int hw = 0; hw < p.hwords; ++hw) {
-    unsigned bits = p.head[hw];
+    unsigned bits = p.head[hw] & p.rowbits;
     while (bits) {
       int k = hw * 32 + __ffs((int)bits) - 1;
       bits &= bits - 1u;
@@ -388,6 +389,7 @@ __device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt,
   int x_pos = (cnt == 0) ? -1 : 0;
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
+    if (q >= 1 && !__any(2 * q + 1 < cnt)) break;   // no row of the wave has another pair
     if (2 * q + 1 < cnt) {
       int x_end = key_down(k[2 * q + 1]);
       if (x_end >= x_pos) {
@@ -415,7 +417,7 @@ __device__ __forceinline__ unsigned blend8(unsigned bg, unsigned fg, unsigned al
 }
 
 template <int WORDS>
-__global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
+__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   const int env = blockIdx.x;
   if (env >= a.n_envs) return;
   PProg P = as_const_prog(a.P);
@@ -429,7 +431,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   const int tid = threadIdx.x, lane = tid & 63;
-  const long long T0 = clock64();
+  const bool clk = (a.debug_stop == 11);   // profiling aid: phase clocks instead of a frame
+  const long long T0 = clk ? clock64() : 0;
   long long T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, TA = 0, TB = 0;
 
   const RPlan& pl = a.plan;
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
   }
   __syncthreads();
   if (a.debug_stop == 3) return;
-  T1 = clock64();
+  if (clk) T1 = clock64();
 
   const int nlist = misc[0];
   const int nvtot = TOTV * ncopy;
@@ -628,9 +631,10 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
           RRow* r = rows + (rb + y);
           unsigned old = atomicOr(&r->hbits, 1u << (k & 31));
           atomicOr(&r->cnt, (unsigned)(g + 1) << R_ITEM_SHIFT);
-          if (old != 0u && (old & (old - 1u)) == 0u)   // the row's second head: queue it once
+          // the row's second head queues it (once); with more than 32 edges per polygon a bit
+          // stands for several edges, so the first head does
+          if (hwords > 1 ? old == 0u : (old != 0u && (old & (old - 1u)) == 0u))
             queue[2 * cap_rows - 1 - atomicAdd(&misc[3], 1)] = (unsigned short)(rb + y);
-          if (k >= 32) make_generic(r, rb + y, queue, misc);
         }
         continue;
       }
@@ -638,13 +642,13 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       const int pymax = iymax > H ? H : iymax;    // polygon_generic clamps ymax to ysize
       const int emin = E.y0 < E.y1 ? E.y0 : E.y1, emax = E.y0 < E.y1 ? E.y1 : E.y0;
       short vtop = E.vtop, vbot = E.vbot;
-      if (a.debug_stop == 11) TA = clock64();
+      if (clk) TA = clock64();
       if (base == 0) {   // every edge of the frame comes by in the first pass; later passes reuse the record
         tip_replacements(edges + c * TOTV + (idx - k), reinterpret_cast<const unsigned*>(ivert + c * TOTV + (idx - k)),
                          k, E, emin >= 0 && emin < H, emax < H && emax >= pymax, &vtop, &vbot);
         edges[c * TOTV + idx].vtop = vtop; edges[c * TOTV + idx].vbot = vbot;
       }
-      if (a.debug_stop == 11) TB = clock64();
+      if (clk) TB = clock64();
       if (g < base || g >= end) continue;
       const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
 #pragma unroll
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         else longlist[atomicAdd(&misc[1], 1)] = entry;
       }
     }
-    T2 = clock64();
+    if (clk) T2 = clock64();
     __syncthreads();
     // ---- 3b: the remaining rows of long edges: eight lanes per edge with up to 12 rows, a
     //          whole wave per longer edge (walls)
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
     }
     __syncthreads();
     if (a.debug_stop == 4) return;
-    T3 = clock64();
+    if (clk) T3 = clock64();
 
     // ---- 4: coverage masks, one thread per (item, row) ------------------------------------
     for (int w0 = 0; w0 < total_rows; w0 += R_THREADS) {
@@ -708,8 +712,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         g = (int)(cw >> R_ITEM_SHIFT) - 1;
         cnt = cw & R_CNT_MASK;
         slow = (cw & R_GENERIC) != 0u;
-        head = !slow && hbits != 0u && (hbits & (hbits - 1u)) == 0u;
-        multi = !slow && (hbits & (hbits - 1u)) != 0u;
+        head = !slow && hwords == 1 && hbits != 0u && (hbits & (hbits - 1u)) == 0u;
+        multi = !slow && hbits != 0u && !head;
       } else {
 #pragma unroll
         for (int q = 0; q < R_CAP; ++q) k[q] = 0xffffu;
@@ -749,13 +753,14 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
       }
     }
     // The rare rows, beside the main loop's tail (no barrier in between: their queues were
-    // complete before phase 4): rows with several horizontal heads on the last wave (same keys,
-    // heads through the row's head bits), rows for the generic scanline on the wave before it.
+    // complete before phase 4): rows with several horizontal heads, handed out from the last
+    // wave backwards (same keys, heads through the row's head bits); rows for the generic
+    // scanline on the third wave.
     if (a.debug_stop == 6) { __syncthreads(); return; }
-    T4 = clock64();
-    if (tid >= R_THREADS - 64) {
-      const int nmulti = (a.debug_stop == 8) ? 0 : ((a.debug_stop == 9) ? (misc[3] > 1 ? 1 : misc[3]) : misc[3]);
-      for (int qi = lane; qi < nmulti; qi += 64) {
+    if (clk) T4 = clock64();
+    {
+      const int nmulti = misc[3];
+      for (int qi = R_THREADS - 1 - tid; qi < nmulti; qi += R_THREADS) {   // the last wave first: it is free soonest
         const int w = queue[2 * cap_rows - 1 - qi];
         const uint4* rr = reinterpret_cast<const uint4*>(rows + w);
         uint4 q0 = rr[0], q1 = rr[1];
@@ -771,7 +776,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         const int y = w + r0 - rowbase[g];
         const unsigned hbits = q1.z;   // the heads on this row (the polygon has <= 32 edges)
         const REdge* pe = edges + c * TOTV + pbase[s];
-        RPoly poly = {pe, 32, &hbits, 1};
+        const unsigned all = ~0u;
+        RPoly poly = {pe, 32, hwords > 1 ? headmask + g * hwords : &all, hwords, hbits};
         sort_network<16>(k);
         RMask m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
         unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
@@ -783,7 +789,8 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
             atomicOr(&segitems[(y * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
         }
       }
-    } else if (tid >= R_THREADS - 128 && a.debug_stop != 7) {
+    }
+    if (tid >= R_THREADS - 128 && tid < R_THREADS - 64 && a.debug_stop != 7) {
       {
         const int qn = misc[2], t = lane < R_SLOW ? lane : qn;
         for (int qi = t; qi < qn; qi += R_SLOW) {
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
           int y = w + r0 - rowbase[g];
           int iymax = item_y[2 * g + 1];
           int pymax = iymax > H ? H : iymax;
-          RPoly poly = {edges + c * TOTV + pbase[s], gq[a.L.o_nverts + s], headmask + g * hwords, hwords};
+          RPoly poly = {edges + c * TOTV + pbase[s], gq[a.L.o_nverts + s], headmask + g * hwords, hwords, ~0u};
           RMask m = scanline_mask_generic(poly, y, pymax, xxs + t, W, a.xxcap);
           unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
           mp[0] = m.w0;
@@ -806,11 +813,11 @@ __global__ __launch_bounds__(R_THREADS) void moog_raster_kernel(RArgs a) {
         }
       }
     }
-    T5 = clock64();
+    if (clk) T5 = clock64();
     __syncthreads();
-    T6 = clock64();
+    if (clk) T6 = clock64();
     if (a.debug_stop == 5) return;
-    if (a.debug_stop == 11) {   // phase clocks of waves 0 and 3 instead of a frame
+    if (clk) {   // phase clocks of waves 0 and 3 instead of a frame
       if (lane == 0 && (tid == 0 || tid == 192)) {
         unsigned* o32 = reinterpret_cast<unsigned*>(out) + (tid ? 8 : 0);
         o32[0] = (unsigned)(T1 - T0); o32[1] = (unsigned)(T2 - T1); o32[2] = (unsigned)(T3 - T2); o32[3] = (unsigned)(T4 - T3);

@@ -4,8 +4,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import torch
 from moog import environment
 from moog_demos import example_configs
-name = sys.argv[1] if len(sys.argv) > 1 else 'colliding_predators_32'
-env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.load(name))
+name = sys.argv[1] if len(sys.argv) > 1 else "colliding_predators_32"
+kw = dict(image_size=(int(sys.argv[2]),) * 2) if len(sys.argv) > 2 else {}
+env = environment.BatchedEnvironment(num_envs=4096, seed=1, **(__import__("moog_demos.example_configs." + name, fromlist=["x"]).get_config(0, **kw) if kw else example_configs.load(name)))
 env.reset()
 for _ in range(3):
     env.step(env.random_action())
