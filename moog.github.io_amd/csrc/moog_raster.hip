@@ -75,7 +75,7 @@ __device__ inline void mask_fill(RMask& m, int W, int x0, int x1) {
 struct RPoly {
   const REdge* e;            // n records, one per vertex
   int n;
-  const unsigned* head;      // bit k: record k is a horizontal head
+  const unsigned* head;      // bit k: record k is a horizontal head (null: one word, all ones)
   int hwords;
   unsigned rowbits;          // heads on the row being drawn, bit (k mod 32) (~0u: not known)
 };
@@ -85,7 +85,7 @@ __device__ __forceinline__ bool r_is_table(const REdge& E) { return E.y0 != E.y1
 // Draw.c draw_horizontal_lines (heads visited in edge order)
 __device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask& m, int W) {
   for (int hw = 0; hw < p.hwords; ++hw) {
-    unsigned bits = p.head[hw] & p.rowbits;
+    unsigned bits = (p.head ? p.head[hw] : ~0u) & p.rowbits;
     while (bits) {
       int k = hw * 32 + __ffs((int)bits) - 1;
       bits &= bits - 1u;
@@ -431,9 +431,14 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool clk = (a.debug_stop == 11);   // profiling aid: phase clocks instead of a frame
+#ifdef MOOG_RASTER_PROFILE   // tools/raster_profile.sh: phase clocks / work counters instead of a frame
+  const bool clk = (a.debug_stop == 11);
   const long long T0 = clk ? clock64() : 0;
   long long T1 = 0, T2 = 0, T3 = 0, T4 = 0, T5 = 0, T6 = 0, TA = 0, TB = 0;
+#define R_CLK(t) if (clk) t = clock64()
+#else
+#define R_CLK(t)
+#endif
 
   const RPlan& pl = a.plan;
   REdge* edges = reinterpret_cast<REdge*>(moog_lds + pl.o_edge);
@@ -452,6 +457,16 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   unsigned short* queue = reinterpret_cast<unsigned short*>(moog_lds + pl.o_queue);
   int* misc = reinterpret_cast<int*>(moog_lds + pl.o_misc);   // [0] list length, [1] long list, [2] generic queue, [3] multi-head queue, [4] very long edges
 
+  // phase 1's first loads go out before the tables are cleared (HBM latency under the clearing)
+  unsigned vi_next = 0u;
+  double2 v_next = make_double2(0.0, 0.0);
+  int fl_next = 0, nv_next = 0;
+  if (tid < TOTV) {
+    vi_next = a.vinfo[tid];
+    v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * tid);
+    fl_next = gq[a.L.o_flags + (vi_next & 0xffu)];
+    nv_next = gq[a.L.o_nverts + (vi_next & 0xffu)];
+  }
   // ---- 0: clear the per-item tables and the row records ---------------------------------
   for (int i = tid; i < items; i += R_THREADS) { item_y[2 * i] = 0x7fffffff; item_y[2 * i + 1] = -0x7fffffff; }
   for (int i = tid; i < items * hwords; i += R_THREADS) headmask[i] = 0u;
@@ -492,10 +507,17 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
-    unsigned vi = a.vinfo[idx];
+    const unsigned vi = vi_next;
+    const double2 v = v_next;
+    const int fl = fl_next, nv = nv_next;
+    if (idx + R_THREADS < TOTV) {   // the next round's loads
+      vi_next = a.vinfo[idx + R_THREADS];
+      v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (idx + R_THREADS));
+      fl_next = gq[a.L.o_flags + (vi_next & 0xffu)];
+      nv_next = gq[a.L.o_nverts + (vi_next & 0xffu)];
+    }
     int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
-    double2 v = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * idx);
-    if (!(gq[a.L.o_flags + s] & MOOG_F_ALIVE) || k >= gq[a.L.o_nverts + s]) continue;
+    if (!(fl & MOOG_F_ALIVE) || k >= nv) continue;
     for (int c = 0; c < ncopy; ++c) {
       double vx = v.x, vy = v.y;
       if (torus) { vx = vx + (double)(c / 3 - 1); vy = vy + (double)(c % 3 - 1); }
@@ -587,20 +609,19 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         if (lane == 0) pos0 = atomicAdd(&misc[0], __popcll(m));
         pos0 = __shfl(pos0, 0);
         if (kind) list[pos0 + __popcll(m & ((1ull << lane) - 1ull))] =
-            (unsigned)idx | ((unsigned)c << 20) | (kind == 2 ? 0x80000000u : 0u);
+            (a.vinfo[idx] & 0xffffu) | ((unsigned)c << 16) | (kind == 2 ? 0x80000000u : 0u);
       }
     }
   }
   __syncthreads();
   if (a.debug_stop == 3) return;
-  if (clk) T1 = clock64();
+  R_CLK(T1);
 
   const int nlist = misc[0];
   const int nvtot = TOTV * ncopy;
   const int segs = H * nseg;   // 16-pixel row segments
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
                        (((unsigned)P->render.bg[2] & 255u) << 16);
-  uint8_t* out = a.image + (size_t)env * H * W * 3;
 
   // passes: as many whole items as fit in the row records (cap_rows >= H); with more
   // than one pass the partially composed frame round-trips through `out` (L2)
@@ -617,10 +638,9 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 
     // ---- 3a: fix-up partners, then every listed edge pushes its first rows ---------------
     for (int ei = tid; ei < nlist; ei += R_THREADS) {
-      unsigned entry = list[ei];
-      int idx = entry & 0xfffffu, c = (entry >> 20) & 0xfu;
-      unsigned vi = a.vinfo[idx];
-      int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
+      unsigned entry = list[ei];   // slot | index within the sprite << 8 | copy << 16 | head << 31
+      const int s = entry & 0xffu, k = (entry >> 8) & 0xffu, c = (entry >> 16) & 0xfu;
+      const int idx = pbase[s] + k;
       int g = s * ncopy + c;
       REdge E = edges[c * TOTV + idx];
       const int rb = rowbase[g] - r0;
@@ -642,13 +662,13 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       const int pymax = iymax > H ? H : iymax;    // polygon_generic clamps ymax to ysize
       const int emin = E.y0 < E.y1 ? E.y0 : E.y1, emax = E.y0 < E.y1 ? E.y1 : E.y0;
       short vtop = E.vtop, vbot = E.vbot;
-      if (clk) TA = clock64();
+      R_CLK(TA);
       if (base == 0) {   // every edge of the frame comes by in the first pass; later passes reuse the record
         tip_replacements(edges + c * TOTV + (idx - k), reinterpret_cast<const unsigned*>(ivert + c * TOTV + (idx - k)),
                          k, E, emin >= 0 && emin < H, emax < H && emax >= pymax, &vtop, &vbot);
         edges[c * TOTV + idx].vtop = vtop; edges[c * TOTV + idx].vbot = vbot;
       }
-      if (clk) TB = clock64();
+      R_CLK(TB);
       if (g < base || g >= end) continue;
       const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
 #pragma unroll
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         else longlist[atomicAdd(&misc[1], 1)] = entry;
       }
     }
-    if (clk) T2 = clock64();
+    R_CLK(T2);
     __syncthreads();
     // ---- 3b: the remaining rows of long edges: eight lanes per edge with up to 12 rows, a
     //          whole wave per longer edge (walls)
@@ -672,9 +692,8 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int li = vl ? u - ngroups : u * 8 + (lane >> 3);
         if (!vl && li >= nlong) continue;
         unsigned entry = vl ? longlist[nvtot - 1 - li] : longlist[li];
-        int idx = entry & 0xfffffu, c = (entry >> 20) & 0xfu;
-        unsigned vi = a.vinfo[idx];
-        int s = vi & 0xffu;
+        const int s = entry & 0xffu, c = (entry >> 16) & 0xfu;
+        const int idx = pbase[s] + ((entry >> 8) & 0xffu);
         int g = s * ncopy + c;
         REdge E = edges[c * TOTV + idx];
         const int rb = rowbase[g] - r0;
@@ -692,7 +711,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     }
     __syncthreads();
     if (a.debug_stop == 4) return;
-    if (clk) T3 = clock64();
+    R_CLK(T3);
 
     // ---- 4: coverage masks, one thread per (item, row) ------------------------------------
     for (int w0 = 0; w0 < total_rows; w0 += R_THREADS) {
@@ -757,7 +776,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     // wave backwards (same keys, heads through the row's head bits); rows for the generic
     // scanline on the third wave.
     if (a.debug_stop == 6) { __syncthreads(); return; }
-    if (clk) T4 = clock64();
+    R_CLK(T4);
     {
       const int nmulti = misc[3];
       for (int qi = R_THREADS - 1 - tid; qi < nmulti; qi += R_THREADS) {   // the last wave first: it is free soonest
@@ -776,8 +795,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int y = w + r0 - rowbase[g];
         const unsigned hbits = q1.z;   // the heads on this row (the polygon has <= 32 edges)
         const REdge* pe = edges + c * TOTV + pbase[s];
-        const unsigned all = ~0u;
-        RPoly poly = {pe, 32, hwords > 1 ? headmask + g * hwords : &all, hwords, hbits};
+        RPoly poly = {pe, 32, hwords > 1 ? headmask + g * hwords : nullptr, hwords, hbits};
         sort_network<16>(k);
         RMask m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
         unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
@@ -813,21 +831,24 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         }
       }
     }
-    if (clk) T5 = clock64();
+    R_CLK(T5);
     __syncthreads();
-    if (clk) T6 = clock64();
+    R_CLK(T6);
     if (a.debug_stop == 5) return;
+#ifdef MOOG_RASTER_PROFILE
     if (clk) {   // phase clocks of waves 0 and 3 instead of a frame
       if (lane == 0 && (tid == 0 || tid == 192)) {
-        unsigned* o32 = reinterpret_cast<unsigned*>(out) + (tid ? 8 : 0);
+        unsigned* o32 = reinterpret_cast<unsigned*>(a.image + (size_t)env * H * W * 3) + (tid ? 8 : 0);
         o32[0] = (unsigned)(T1 - T0); o32[1] = (unsigned)(T2 - T1); o32[2] = (unsigned)(T3 - T2); o32[3] = (unsigned)(T4 - T3);
         o32[4] = (unsigned)(T5 - T4); o32[5] = (unsigned)(T6 - T5); o32[6] = (unsigned)(clock64() - T0); o32[7] = (unsigned)(TB - TA);
       }
       return;
     }
-    if (a.debug_stop == 10) { if (tid < 8) out[tid] = (uint8_t)(tid == 5 ? (rowoff[items] >> 2) : misc[tid]); return; }   // counters instead of a frame
+    if (a.debug_stop == 10) { uint8_t* out = a.image + (size_t)env * H * W * 3; if (tid < 8) out[tid] = (uint8_t)(tid == 5 ? (rowoff[items] >> 2) : misc[tid]); return; }   // counters instead of a frame
+#endif
 
     // ---- 5: compose (painter's order = item order), pack RGB, store flipped ------------------
+    uint8_t* out = a.image + (size_t)env * H * W * 3;
     for (int seg = tid; seg < segs; seg += R_THREADS) {
       int y = seg / nseg, sg = seg - y * nseg, x0 = sg * 16;
       uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(H - 1 - y) * W + x0) * 3);
