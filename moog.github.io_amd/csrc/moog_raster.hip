@@ -382,6 +382,48 @@ __device__ __forceinline__ RMask span_loop(const unsigned (&k)[N], int cnt, bool
   return m;
 }
 
+// draw_horizontal_lines for a row whose heads are bits of `hb` (polygons of <= 32 edges).  x_pos
+// only grows, so a head that is not "after the current position" is finished after this call
+// whether it was drawn or not: its bit is cleared and later calls do not visit it again.
+template <int WORDS>
+__device__ __forceinline__ void draw_pending_heads(const REdge* pe, unsigned& hb, int& x_pos, RMask& m, int W) {
+  unsigned bits = hb;
+  while (bits) {
+    const int k = __ffs((int)bits) - 1;
+    bits &= bits - 1u;
+    const unsigned xb = (unsigned)__float_as_int(pe[k].dx);
+    const int xmin = (short)(xb & 0xffffu), xmax = (short)(xb >> 16);
+    if (x_pos != -1 && x_pos < xmin) continue;   // after the current position: stays pending
+    hb &= ~(1u << k);
+    const int hs = x_pos > xmin ? x_pos : xmin;
+    const bool draw = !(x_pos > xmin && xmax < hs);
+    mask_or_range<WORDS>(m, W, hs, xmax, draw);
+    x_pos = draw ? xmax + 1 : x_pos;
+  }
+}
+
+template <int NP, int N, int WORDS>
+__device__ __forceinline__ RMask span_loop_pending(const unsigned (&k)[N], int cnt, const REdge* pe, unsigned hb, int W) {
+  RMask m = {0ull, 0ull};
+  int x_pos = (cnt == 0) ? -1 : 0;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    if (q >= 1 && !__any(2 * q + 1 < cnt)) break;
+    const int x_end = key_down(k[2 * q + 1]);
+    bool act = (2 * q + 1 < cnt) && (x_end >= x_pos);
+    if (act) draw_pending_heads<WORDS>(pe, hb, x_pos, m, W);
+    act = act && (x_end >= x_pos);
+    const int x_start = key_up(k[2 * q]);
+    const bool gt = x_pos > x_start;
+    const int xs = gt ? x_pos : x_start;
+    act = act && !(gt && x_end < xs);
+    mask_or_range<WORDS>(m, W, xs, x_end, act);
+    x_pos = act ? x_end + 1 : x_pos;
+  }
+  draw_pending_heads<WORDS>(pe, hb, x_pos, m, W);
+  return m;
+}
+
 // The same with any number of heads in the row, visited through the polygon's head list
 template <int NP, int N>
 __device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt, const RPoly& p, int y, int W) {
@@ -714,7 +756,11 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     R_CLK(T3);
 
     // ---- 4: coverage masks, one thread per (item, row) ------------------------------------
-    for (int w0 = 0; w0 < total_rows; w0 += R_THREADS) {
+    // A handful of multi-head rows (below) is one long dependent chain on a single wave: then the
+    // last wave does only those, beside the other three waves' main loop.
+    const bool spare_wave = misc[3] > 0 && misc[3] <= 64;
+    const int main_threads = spare_wave ? R_THREADS - 64 : R_THREADS;
+    for (int w0 = (tid < main_threads) ? 0 : total_rows; w0 < total_rows; w0 += main_threads) {
       const int w = w0 + tid;
       unsigned k[16];
       int cnt = 0, g = -1, hxmin = 0, hxmax = 0;
@@ -795,9 +841,14 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int y = w + r0 - rowbase[g];
         const unsigned hbits = q1.z;   // the heads on this row (the polygon has <= 32 edges)
         const REdge* pe = edges + c * TOTV + pbase[s];
-        RPoly poly = {pe, 32, hwords > 1 ? headmask + g * hwords : nullptr, hwords, hbits};
         sort_network<16>(k);
-        RMask m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
+        RMask m;
+        if (hwords > 1) {
+          RPoly poly = {pe, 32, headmask + g * hwords, hwords, hbits};
+          m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
+        } else {
+          m = span_loop_pending<R_CAP / 2, 16, WORDS>(k, cnt, pe, hbits, W);
+        }
         unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
         mp[0] = m.w0;
         if (words > 1) mp[1] = m.w1;
