@@ -212,32 +212,52 @@ __device__ __forceinline__ void make_generic(RRow* r, int w, unsigned short* que
   if (!(old & R_GENERIC)) queue[atomicAdd(&misc[2], 1)] = (unsigned short)w;
 }
 
-// One crossing of table edge E with row y, pushed into the row's record.
-__device__ __forceinline__ void push_crossing(RRow* rows, int rb, const REdge& E, int emin, int emax,
-                                              int pymax, short vtop, short vbot, int g, int y,
-                                              unsigned short* queue, int* misc) {
+// One crossing of table edge E with row y, in two halves so that a thread with several rows has
+// all its slot requests (LDS atomics with return) in flight before it needs the first answer.
+struct RPush { unsigned key, n; RRow* r; bool on, fix, far; unsigned pos; };
+
+__device__ __forceinline__ RPush push_prepare(RRow* rows, int rb, const REdge& E, int emin, int emax, int pymax,
+                                              short vtop, short vbot, int y, bool on) {
+  RPush p;
   float x = (float)(y - (int)E.y0) * E.dx + (float)E.x0;
   const bool bot = (y == emax);
   const bool dup = bot && (y < pymax);      // polygon_generic: an edge's last row counts twice
   const short vv = (y == emin) ? vtop : ((bot && !dup) ? vbot : R_NONE);
-  const unsigned n = dup ? 2u : 1u;
+  p.n = dup ? 2u : 1u;
+  p.fix = on && (vv != R_NONE);
   if (vv != R_NONE) x = (float)vv;
-  const bool far = !(fabsf(x) <= R_XLIM);
-  unsigned key = (unsigned)(pil_round_up(x) + pil_round_down(x) + R_KEY_BIAS);
-  RRow* r = rows + (rb + y);
-  unsigned pos = atomicAdd(&r->cnt, n) & R_CNT_MASK;
-  if (pos < R_CAP) r->key[pos] = (unsigned short)key;
-  if (dup && pos + 1 < R_CAP) r->key[pos + 1] = (unsigned short)key;
-  atomicOr(&r->cnt, (unsigned)(g + 1) << R_ITEM_SHIFT);
-  bool gen = far || (pos <= R_CAP && pos + n > R_CAP);
-  if (vv != R_NONE) {
+  p.far = !(fabsf(x) <= R_XLIM);
+  p.key = (unsigned)(pil_round_up(x) + pil_round_down(x) + R_KEY_BIAS);
+  p.r = rows + (rb + y);
+  p.on = on;
+  p.pos = 0u;
+  return p;
+}
+
+__device__ __forceinline__ void push_commit(const RPush& p, const REdge& E, int rb, int y, int g,
+                                            unsigned short* queue, int* misc) {
+  if (!p.on) return;
+  const unsigned pos = p.pos & R_CNT_MASK;
+  if (pos < R_CAP) p.r->key[pos] = (unsigned short)p.key;
+  if (p.n == 2u && pos + 1 < R_CAP) p.r->key[pos + 1] = (unsigned short)p.key;
+  if (pos == 0u) atomicOr(&p.r->cnt, (unsigned)(g + 1) << R_ITEM_SHIFT);   // the first arrival names the item
+  bool gen = p.far || (pos <= R_CAP && pos + p.n > R_CAP);
+  if (p.fix) {
     // Two fix-ups on one row are independent unless they belong to the same tip point (then
     // the reference overwrites one partner entry twice): remember the tip columns mod 8.
     const int tipx = (y == E.y0) ? E.x0 : E.x1;
     const unsigned bit = R_FIX_ONE << (tipx & 7);
-    gen = gen || (atomicOr(&r->cnt, bit) & bit);
+    gen = gen || (atomicOr(&p.r->cnt, bit) & bit);
   }
-  if (gen) make_generic(r, rb + y, queue, misc);
+  if (gen) make_generic(p.r, rb + y, queue, misc);
+}
+
+__device__ __forceinline__ void push_crossing(RRow* rows, int rb, const REdge& E, int emin, int emax,
+                                              int pymax, short vtop, short vbot, int g, int y,
+                                              unsigned short* queue, int* misc) {
+  RPush p = push_prepare(rows, rb, E, emin, emax, pymax, vtop, vbot, y, true);
+  p.pos = atomicAdd(&p.r->cnt, p.n);
+  push_commit(p, E, rb, y, g, queue, misc);
 }
 
 // Generic scanline (any number of crossings, several fix-ups): crossing list in LDS.
@@ -456,6 +476,17 @@ __device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt,
 __device__ __forceinline__ unsigned blend8(unsigned bg, unsigned fg, unsigned al) {
   unsigned t = bg * (255u - al) + fg * al + 128u;
   return ((t >> 8) + t) >> 8;
+}
+
+// Later passes of a frame with more rows than records start from clean row records (rare; kept
+// out of line so that its address arithmetic is not hoisted into the common path's registers).
+__device__ __noinline__ void r_next_pass(RRow* rows, int cap_rows, int* misc, int tid) {
+  for (int i = tid; i < cap_rows; i += R_THREADS) {
+    uint4* r = reinterpret_cast<uint4*>(rows + i);
+    r[0] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    r[1] = make_uint4(~0u, ~0u, 0u, 0u);
+  }
+  if (tid == 0) { misc[1] = 0; misc[2] = 0; misc[3] = 0; misc[4] = 0; }
 }
 
 template <int WORDS>
@@ -704,18 +735,23 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       const int pymax = iymax > H ? H : iymax;    // polygon_generic clamps ymax to ysize
       const int emin = E.y0 < E.y1 ? E.y0 : E.y1, emax = E.y0 < E.y1 ? E.y1 : E.y0;
       short vtop = E.vtop, vbot = E.vbot;
-      R_CLK(TA);
       if (base == 0) {   // every edge of the frame comes by in the first pass; later passes reuse the record
         tip_replacements(edges + c * TOTV + (idx - k), reinterpret_cast<const unsigned*>(ivert + c * TOTV + (idx - k)),
                          k, E, emin >= 0 && emin < H, emax < H && emax >= pymax, &vtop, &vbot);
         edges[c * TOTV + idx].vtop = vtop; edges[c * TOTV + idx].vbot = vbot;
       }
-      R_CLK(TB);
       if (g < base || g >= end) continue;
+      R_CLK(TA);
       const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
+      RPush pp[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (ya + j <= yb) push_crossing(rows, rb, E, emin, emax, pymax, vtop, vbot, g, ya + j, queue, misc);
+      for (int j = 0; j < 4; ++j) pp[j] = push_prepare(rows, rb, E, emin, emax, pymax, vtop, vbot, ya + j, ya + j <= yb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)   // (rows the edge does not have add 0 to a spare word: no branch, one wait for all four)
+        pp[j].pos = atomicAdd(pp[j].on ? &pp[j].r->cnt : reinterpret_cast<unsigned*>(misc + 7), pp[j].on ? pp[j].n : 0u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) push_commit(pp[j], E, rb, ya + j, g, queue, misc);
+      R_CLK(TB);
       if (yb - ya >= 4) {
         if (yb - ya >= 12) longlist[nvtot - 1 - atomicAdd(&misc[4], 1)] = entry;   // very long: from the back
         else longlist[atomicAdd(&misc[1], 1)] = entry;
@@ -959,13 +995,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     if (end >= items) break;
     base = end;
     __syncthreads();
-    // later passes start from clean row records
-    for (int i = tid; i < cap_rows; i += R_THREADS) {
-      uint4* r = reinterpret_cast<uint4*>(rows + i);
-      r[0] = make_uint4(~0u, ~0u, ~0u, ~0u);
-      r[1] = make_uint4(~0u, ~0u, 0u, 0u);
-    }
-    if (tid >= 1 && tid <= 4) misc[tid] = 0;
+    r_next_pass(rows, cap_rows, misc, tid);
     __syncthreads();
   }
 }
