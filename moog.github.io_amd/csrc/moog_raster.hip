@@ -533,12 +533,9 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   // phase 1's first loads go out before the tables are cleared (HBM latency under the clearing)
   unsigned vi_next = 0u;
   double2 v_next = make_double2(0.0, 0.0);
-  int fl_next = 0, nv_next = 0;
   if (tid < TOTV) {
     vi_next = a.vinfo[tid];
     v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * tid);
-    fl_next = gq[a.L.o_flags + (vi_next & 0xffu)];
-    nv_next = gq[a.L.o_nverts + (vi_next & 0xffu)];
   }
   // ---- 0: clear the per-item tables and the row records ---------------------------------
   for (int i = tid; i < items; i += R_THREADS) { item_y[2 * i] = 0x7fffffff; item_y[2 * i + 1] = -0x7fffffff; }
@@ -552,7 +549,11 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   // per-sprite colour (the last wave: it has the fewest vertices to convert)
   for (int s = tid - (R_THREADS - 64); s >= 0 && s < S; s += 64) {
     unsigned rgba = 0u;
-    if (gq[a.L.o_flags + s] & MOOG_F_ALIVE) {
+    const bool alive = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0;
+    // first edge record of the slot | live vertex count << 20 (0 for a dead sprite): the later
+    // phases take both from LDS instead of chasing the record's flag words through HBM
+    pbase[s] = P->slot_voff[s] | ((alive ? gq[a.L.o_nverts + s] : 0) << 20);
+    if (alive) {
       unsigned r8, g8, b8;
       const double* col = gf + a.L.o_color + 3 * s;
       if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
@@ -561,7 +562,6 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
     }
     for (int c = 0; c < ncopy; ++c) item_rgba[s * ncopy + c] = rgba;
-    pbase[s] = P->slot_voff[s];
   }
   // FirstPersonAgent (polygon_modifiers.py:41-64): every polygon is translated so that the
   // agent layer's first sprite sits at (0.5, 0.5)
@@ -582,15 +582,12 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     const unsigned vi = vi_next;
     const double2 v = v_next;
-    const int fl = fl_next, nv = nv_next;
     if (idx + R_THREADS < TOTV) {   // the next round's loads
       vi_next = a.vinfo[idx + R_THREADS];
       v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (idx + R_THREADS));
-      fl_next = gq[a.L.o_flags + (vi_next & 0xffu)];
-      nv_next = gq[a.L.o_nverts + (vi_next & 0xffu)];
     }
     int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
-    if (!(fl & MOOG_F_ALIVE) || k >= nv) continue;
+    if (k >= (pbase[s] >> 20)) continue;
     for (int c = 0; c < ncopy; ++c) {
       double vx = v.x, vy = v.y;
       if (torus) { vx = vx + (double)(c / 3 - 1); vy = vy + (double)(c % 3 - 1); }
@@ -638,8 +635,8 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       if (idx < TOTV) {
         unsigned vi = a.vinfo[idx];
         int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
-        int nv = gq[a.L.o_nverts + s];
-        if ((gq[a.L.o_flags + s] & MOOG_F_ALIVE) && k < nv) {
+        int nv = pbase[s] >> 20;
+        if (k < nv) {
           const short2* pv = ivert + c * TOTV + (idx - k);
           int k2 = (k + 1 == nv) ? 0 : k + 1;
           short2 p0 = pv[k], p1 = pv[k2];
@@ -713,7 +710,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     for (int ei = tid; ei < nlist; ei += R_THREADS) {
       unsigned entry = list[ei];   // slot | index within the sprite << 8 | copy << 16 | head << 31
       const int s = entry & 0xffu, k = (entry >> 8) & 0xffu, c = (entry >> 16) & 0xfu;
-      const int idx = pbase[s] + k;
+      const int idx = (pbase[s] & 0xfffff) + k;
       int g = s * ncopy + c;
       REdge E = edges[c * TOTV + idx];
       const int rb = rowbase[g] - r0;
@@ -771,7 +768,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         if (!vl && li >= nlong) continue;
         unsigned entry = vl ? longlist[nvtot - 1 - li] : longlist[li];
         const int s = entry & 0xffu, c = (entry >> 16) & 0xfu;
-        const int idx = pbase[s] + ((entry >> 8) & 0xffu);
+        const int idx = (pbase[s] & 0xfffff) + ((entry >> 8) & 0xffu);
         int g = s * ncopy + c;
         REdge E = edges[c * TOTV + idx];
         const int rb = rowbase[g] - r0;
@@ -826,7 +823,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       const int y = live ? w + r0 - rowbase[g] : 0;
       if (head) {   // the row's one head: its record
         const int s = torus ? g / 9 : g, c = g - s * ncopy;
-        unsigned xb = (unsigned)__float_as_int(edges[c * TOTV + pbase[s] + __ffs((int)hbits) - 1].dx);
+        unsigned xb = (unsigned)__float_as_int(edges[c * TOTV + (pbase[s] & 0xfffff) + __ffs((int)hbits) - 1].dx);
         hxmin = (short)(xb & 0xffffu); hxmax = (short)(xb >> 16);
       }
       RMask m;
@@ -876,7 +873,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int s = torus ? g / 9 : g, c = g - s * ncopy;
         const int y = w + r0 - rowbase[g];
         const unsigned hbits = q1.z;   // the heads on this row (the polygon has <= 32 edges)
-        const REdge* pe = edges + c * TOTV + pbase[s];
+        const REdge* pe = edges + c * TOTV + (pbase[s] & 0xfffff);
         sort_network<16>(k);
         RMask m;
         if (hwords > 1) {
@@ -905,7 +902,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
           int y = w + r0 - rowbase[g];
           int iymax = item_y[2 * g + 1];
           int pymax = iymax > H ? H : iymax;
-          RPoly poly = {edges + c * TOTV + pbase[s], gq[a.L.o_nverts + s], headmask + g * hwords, hwords, ~0u};
+          RPoly poly = {edges + c * TOTV + (pbase[s] & 0xfffff), pbase[s] >> 20, headmask + g * hwords, hwords, ~0u};
           RMask m = scanline_mask_generic(poly, y, pymax, xxs + t, W, a.xxcap);
           unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
           mp[0] = m.w0;
