@@ -630,3 +630,68 @@ def test_composite_action_dict_api():
     assert ts.observation['image'].shape == (64, 64, 3)
     ra = env.random_action()
     assert set(ra) == {'agent_0', 'agent_1', 'eye'} and ra['agent_1'].shape == (32,)
+
+
+def _poly_env(W, n_envs, n_sprites, opacities):
+    import collections
+    from moog import environment, action_spaces, observers, physics as physics_lib, sprite, tasks
+    cfg = dict(
+        state_initializer=lambda: collections.OrderedDict(
+            [('a', [sprite.Sprite(shape='circle', c0=40 + 60 * i, c1=200 - 50 * i, c2=30 + 70 * i,
+                                  opacity=opacities[i % len(opacities)]) for i in range(n_sprites)]),
+             ('agent', [])]),
+        physics=physics_lib.Physics(updates_per_env_step=1),
+        task=tasks.CompositeTask(),
+        action_space=action_spaces.Grid(action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(W, W), bg_color=(10, 20, 30))})
+    return environment.BatchedEnvironment(num_envs=n_envs, **cfg)
+
+
+@pytest.mark.parametrize('W', [64, 128])
+def test_raster_degenerate_polygon_fuzz(W):
+    """Differential fuzz of the rasteriser's rare paths against the oracle renderer (itself
+    validated against Pillow): polygons on a coarse integer lattice (coinciding vertices,
+    zero-width spikes, runs of horizontal edges, several fix-ups per row), combs with more
+    than 12 crossings per row, vertices far off the canvas, all-horizontal polygons, four
+    overlapping sprites per frame with mixed opacity."""
+    n, ns = 2048, 4
+    env = _poly_env(W, n, ns, (255, 128, 255, 77))
+    env.reset()
+    f, q = download(env)
+    L, P = env.layout, env.compiled.program
+    import os
+    rs = np.random.RandomState(1234 + W + 1000 * int(os.environ.get('MOOG_FUZZ_SEED', '0')))
+    for e in range(n):
+        kind = e % 8
+        for s in range(ns):
+            nv = int(rs.randint(3, 31))
+            if kind <= 2:      # coarse lattice: heavy degeneracy
+                step = (2, 3, 5)[kind]
+                ox, oy = rs.randint(-4, W - 8, size=2)
+                xy = np.stack([ox + step * rs.randint(0, 5, size=nv), oy + step * rs.randint(0, 5, size=nv)], 1)
+            elif kind == 3:    # comb: many crossings per row
+                t = np.arange(nv)
+                xy = np.stack([rs.randint(0, W // 2) + 2 * t, np.where(t % 2 == 0, rs.randint(0, W // 2), rs.randint(W // 2, W)) + rs.randint(-2, 3, size=nv)], 1)
+            elif kind == 4:    # far off-canvas vertices mixed with near ones
+                xy = rs.randint(-10, W + 10, size=(nv, 2))
+                far = rs.rand(nv) < 0.3
+                xy[far] = rs.choice([-30000, -17000, 17000, 30000], size=(int(far.sum()), 2))   # (the engine clamps at +-32000)
+            elif kind == 5:    # all vertices on one or two rows
+                xy = np.stack([rs.randint(-5, W + 5, size=nv), rs.randint(0, W) + rs.randint(0, 2, size=nv)], 1)
+            elif kind == 6:    # small random polygon straddling a canvas border
+                c = rs.choice([-2, 0, W - 3, W])
+                xy = np.stack([c + rs.randint(-6, 7, size=nv), rs.choice([-2, 0, W - 3, W]) + rs.randint(-6, 7, size=nv)], 1)
+            else:              # plain random
+                xy = rs.randint(-8, W + 8, size=(nv, 2))
+            xy = xy.astype(np.float64)
+            v = (xy + np.where(xy >= 0, 0.5, -0.5)) / W   # (int)(W * v) == xy exactly
+            v0 = P.slot_voff[s]
+            q[e, L.o_nverts + s] = nv
+            f[e, L.o_verts + 2 * v0:L.o_verts + 2 * (v0 + nv)] = v.ravel()
+    upload(env, f, q)
+    img = env.observation()['image'].cpu().numpy()
+    o = helpers.OracleEnv(env.compiled, n_envs=n)
+    o.f64[:], o.i32[:] = f, q
+    ref = o.render()
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', [(int(b), int(b) % 8) for b in bad[:10]], int(bad.size))

@@ -236,3 +236,57 @@ def test_host_randomness_in_initializer_is_refused():
             action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
             observers={'image': observers.PILRenderer(image_size=(64, 64))})
     assert 0.0 <= np.random.uniform(0., 1.) < 1.0   # the generator is restored afterwards
+
+
+def test_raster_sort_key_and_network():
+    """Host-side checks of two devices the HIP rasteriser relies on (csrc/moog_raster.hip):
+    the 16-bit crossing key ROUND_UP(x) + ROUND_DOWN(x) is monotone in x and gives both roundings
+    back, and the Batcher compare-exchange schedule sorts (0-1 principle)."""
+    f = np.float32
+
+    def round_up(x):    # Draw.c ROUND_UP, float arithmetic
+        return int(np.copysign(np.floor(np.abs(x) + f(0.5)), x))
+
+    def round_down(x):  # Draw.c ROUND_DOWN
+        return int(np.copysign(np.ceil(np.abs(x) - f(0.5)), x))
+
+    def key_up(s):
+        return (s + 1) >> 1 if s >= 0 else s >> 1
+
+    def key_down(s):
+        return s >> 1 if s >= 0 else (s + 1) >> 1
+
+    xs = []
+    for n in range(-40, 41):
+        for d in (-0.5, -0.25, 0.0, 0.25, 0.5):
+            c = f(n + d)
+            xs += [np.nextafter(c, f(-1e9)), c, np.nextafter(c, f(1e9))]
+    xs = np.array(sorted(set(float(v) for v in xs)), dtype=np.float32)
+    prev = None
+    for x in xs:
+        up, dn = round_up(x), round_down(x)
+        s = up + dn
+        assert key_up(s) == up and key_down(s) == dn, (x, up, dn)
+        assert prev is None or s >= prev, x
+        prev = s
+
+    def network(n):
+        ces, p = [], 1
+        while p < n:
+            q = p
+            while q >= 1:
+                for j in range(q % p, n - q, 2 * q):
+                    for i in range(q):
+                        if i + j + q <= n - 1 and (i + j) // (2 * p) == (i + j + q) // (2 * p):
+                            ces.append((i + j, i + j + q))
+                q //= 2
+            p *= 2
+        return ces
+
+    for n in (8, 16):
+        ces = network(n)
+        v = (np.arange(1 << n)[:, None] >> np.arange(n)) & 1      # every 0-1 input
+        for a, b in ces:
+            lo, hi = np.minimum(v[:, a], v[:, b]), np.maximum(v[:, a], v[:, b])
+            v[:, a], v[:, b] = lo, hi
+        assert (np.diff(v, axis=1) >= 0).all(), n
