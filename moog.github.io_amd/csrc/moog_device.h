@@ -380,6 +380,77 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
   return hit;
 }
 
+// Narrow phase of up to four broad-phase candidates at once, sixteen lanes each.  About nine
+// candidates in ten do not overlap, and a lone Path.intersects_path keeps ~10 lanes busy, so the
+// ordered pair loop first asks how many of its next candidates are decided "no overlap" by the very
+// tests of paths_intersect_filled (same culls, same segment arithmetic); those are skipped together.
+// The first candidate that hits, or that needs what sixteen lanes cannot do (a polygon of more than
+// 16 vertices, more than 16 surviving edge pairs, a containment test), ends the prefix and takes the
+// ordinary path (without repeating the test when its edges were seen to cross).  The state cannot
+// change in between: only a hit moves sprites.
+__device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
+  const int grp = e.lane >> 4, gl = e.lane & 15;
+  const bool active = grp < n;
+  const int pr = active ? (int)e.cand[c + grp] : 0;
+  const int s0 = pr >> 8, t = pr & 255;
+  const int na = active ? NV(s0) : 0, nb = active ? NV(t) : 0;
+  const double* va = VERT(s0);
+  const double* vb = VERT(t);
+  const float* da = &BB(s0, 0);
+  const float* db = &BB(t, 0);
+  bool slow = na > 16 || nb > 16;
+  // the "all vertices of one inside the other" tests would run (box within box): not here
+  slow = slow || (na + 1 >= 3 && nb > 0 &&
+                  !(db[0] < da[0] - BB_MARGIN || db[1] < da[1] - BB_MARGIN || db[4] > da[4] + BB_MARGIN ||
+                    db[5] > da[5] + BB_MARGIN));
+  slow = slow || (nb + 1 >= 3 && na > 0 &&
+                  !(da[0] < db[0] - BB_MARGIN || da[1] < db[1] - BB_MARGIN || da[4] > db[4] + BB_MARGIN ||
+                    da[5] > db[5] + BB_MARGIN));
+  slow = slow && active;
+  bool ka = false, kb = false;
+  if (active && !slow) {
+    if (gl < na) {
+      int i2 = (gl + 1 == na) ? 0 : gl + 1;
+      ka = !seg_outside_dop(va[2 * gl], va[2 * gl + 1], va[2 * i2], va[2 * i2 + 1], db);
+    }
+    if (gl < nb) {
+      int j2 = (gl + 1 == nb) ? 0 : gl + 1;
+      kb = !seg_outside_dop(vb[2 * gl], vb[2 * gl + 1], vb[2 * j2], vb[2 * j2 + 1], da);
+    }
+  }
+  const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
+  const unsigned ga = (unsigned)(ma >> (16 * grp)) & 0xffffu, gb = (unsigned)(mb >> (16 * grp)) & 0xffffu;
+  const int ca = __popc(ga), cb = __popc(gb), total = ca * cb;
+  slow = slow || total > 16;
+  const unsigned below = (1u << gl) - 1u;
+  if (ka) e.lst[16 * grp + __popc(ga & below)] = (uint8_t)gl;
+  if (kb) e.lst[64 + 16 * grp + __popc(gb & below)] = (uint8_t)gl;
+  wsync();
+  bool hit = false;
+  if (active && !slow && gl < total) {
+    // gl / cb for gl < 16, 1 <= cb <= 16 (the quotient of a half-integer is never near an integer)
+    const int ia = (int)(((float)gl + 0.5f) / (float)cb), ib = gl - ia * cb;
+    const int i = e.lst[16 * grp + ia], j = e.lst[64 + 16 * grp + ib];
+    const int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
+    double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
+    double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
+    bool apart = fmin(x11, x12) > fmax(x21, x22) + BB_MARGIN || fmin(x21, x22) > fmax(x11, x12) + BB_MARGIN ||
+                 fmin(y11, y12) > fmax(y21, y22) + BB_MARGIN || fmin(y21, y22) > fmax(y11, y12) + BB_MARGIN;
+    if (!apart) {
+      bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
+      bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
+      if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
+    }
+  }
+  const unsigned long long stop = __ballot(hit || slow), slows = __ballot(slow);
+  wsync();
+  int r = 0;
+  while (r < n && ((stop >> (16 * r)) & 0xffffull) == 0ull) ++r;
+  // bit 8: the candidate that ended the prefix is a proven overlap (its edges cross)
+  if (r < n && ((slows >> (16 * r)) & 0xffffull) == 0ull) r |= 256;
+  return r;
+}
+
 // sprite.py:442-460 (one point, one lane)
 __device__ inline bool contains_points1(const Env& e, int s, double x, double y) {
   if (FLAGS(s) & MOOG_F_SYM_CIRCLE) return norm2(x - PX(s), y - PY(s)) <= MAXR(s);
@@ -954,13 +1025,14 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
 // collisions.py:494-584.  Returns true when a sprite position changed (the broad
 // phase must then be redone for the following pairs); velocity-only outcomes and
 // "future contact" no-ops return false.
-__device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K) {
+// `known_hit`: the caller has already seen the two paths intersect on the current state
+__device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K, bool known_hit = false) {
   const int symmetric = uni(F->symmetric), upd = uni(F->i0), maxdepth = uni(F->i1);
   s0 = uni(s0); s1 = uni(s1);
   bool moved = false;
   for (int depth = 0; depth <= maxdepth; ++depth) {
     if (s0 == s1) return moved;
-    if (!overlaps(e, s0, s1, depth == 0)) return moved;
+    if (!(known_hit && depth == 0) && !overlaps(e, s0, s1, depth == 0)) return moved;
     if (e.dbg & 16) return moved;
     if (e.dbg & 128) e.n_resp++;
     double dt = 1. / K;
@@ -1243,9 +1315,19 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
     // ---- consume ----------------------------------------------------------------------------
     bool rebuilt = false;
     for (int c = 0; c < count; ++c) {
+      bool known_hit = false;
+      if (count - c >= 2 && !(e.dbg & (4 | 32))) {   // skip the leading candidates that do not overlap
+        PROF_T0;
+        const int n = count - c < 4 ? count - c : 4;
+        const int rr = uni(narrow_reject_prefix(e, c, n)), r = rr & 255;
+        PROF_ADD(e, 0);
+        known_hit = (rr & 256) != 0;
+        c += r;
+        if (r == n) { --c; continue; }   // all of them: on to the next batch
+      }
       int pr = uni((int)e.cand[c]);
       int s0 = pr >> 8, t = pr & 255;
-      if (!(e.dbg & 4) && collision_step(e, F, s0, t, K)) {
+      if (!(e.dbg & 4) && collision_step(e, F, s0, t, K, known_hit)) {
         start = (s0 - a0) * nB + (t - b0) + 1;
         rebuilt = true;
         break;
