@@ -1059,24 +1059,23 @@ __device__ inline void newton_apply(Env& e, int s, double fx, double fy, int K) 
   vel_iadd(e, s, fx / den, fy / den);
 }
 
-__device__ inline void force_single(Env& e, PForce F, int s, int K) {
+// New velocity of sprite s under a single-sprite force other than RandomForce (which draws from the
+// env's RNG stream in sprite order); false: the velocity is left alone (infinite mass).  One lane's work.
+__device__ inline bool force_single_newvel(const Env& e, PForce F, int s, int K, double* ovx, double* ovy) {
+  double fx, fy;
+  const double m = MASS(s);
   switch (F->kind) {
     case MOOG_FORCE_DRAG: {
-      double m = MASS(s);
       if (FLAGS(s) & MOOG_F_VEL_F32) {
-        if (!isfinite(m)) return;
+        if (!isfinite(m)) return false;
         float c = (float)(-1 * F->p0), mf = (float)m, den = (float)(m * (double)K);
-        float fx = (c * (float)VELX(s)) * mf, fy = (c * (float)VELY(s)) * mf;
-        double vx = (double)((float)VELX(s) + fx / den);
-        double vy = (double)((float)VELY(s) + fy / den);
-        wsync();
-        if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
-        wsync();
-        vel_share(e, s);
-      } else {
-        double c = -1 * F->p0;
-        newton_apply(e, s, (c * VELX(s)) * m, (c * VELY(s)) * m, K);
+        float ffx = (c * (float)VELX(s)) * mf, ffy = (c * (float)VELY(s)) * mf;
+        *ovx = (double)((float)VELX(s) + ffx / den);
+        *ovy = (double)((float)VELY(s) + ffy / den);
+        return true;
       }
+      double c = -1 * F->p0;
+      fx = (c * VELX(s)) * m; fy = (c * VELY(s)) * m;
       break;
     }
     case MOOG_FORCE_KINETIC_FRICTION: {
@@ -1084,22 +1083,52 @@ __device__ inline void force_single(Env& e, PForce F, int s, int K) {
       double nx = 0, ny = 0;
       if (vn != 0) { nx = VELX(s) / vn; ny = VELY(s) / vn; }
       double c = -1 * F->p0;
-      newton_apply(e, s, (c * nx) * MASS(s), (c * ny) * MASS(s), K);
+      fx = (c * nx) * MASS(s); fy = (c * ny) * MASS(s);
       break;
     }
     case MOOG_FORCE_DOWN_GRAVITY: {
       double gm = F->p0 * MASS(s);
-      newton_apply(e, s, gm * 0, gm * 1, K);
+      fx = gm * 0; fy = gm * 1;
       break;
     }
-    case MOOG_FORCE_RANDOM: {
-      double r = 0 + (F->p0 - 0) * next_uniform(e);
-      double th = 0 + (2 * 3.14159265358979323846 - 0) * next_uniform(e);
-      newton_apply(e, s, r * cos(th), r * sin(th), K);
-      break;
-    }
-    default: break;
+    default: return false;
   }
+  // newton_apply + vel_iadd
+  if (!isfinite(m)) return false;
+  const double den = m * (double)K;
+  const double dx = fx / den, dy = fy / den;
+  double vx = VELX(s), vy = VELY(s);
+  if (FLAGS(s) & MOOG_F_VEL_F32) { vx = f32r(vx + dx); vy = f32r(vy + dy); }
+  else { vx = vx + dx; vy = vy + dy; }
+  *ovx = vx; *ovy = vy;
+  return true;
+}
+
+__device__ inline void force_single(Env& e, PForce F, int s, int K) {
+  if (F->kind == MOOG_FORCE_RANDOM) {
+    double r = 0 + (F->p0 - 0) * next_uniform(e);
+    double th = 0 + (2 * 3.14159265358979323846 - 0) * next_uniform(e);
+    newton_apply(e, s, r * cos(th), r * sin(th), K);
+    return;
+  }
+  double vx = 0, vy = 0;
+  const bool ch = force_single_newvel(e, F, s, K, &vx, &vy);
+  if (!ch) return;   // (wave uniform: every lane evaluates the same sprite)
+  wsync();
+  if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; }
+  wsync();
+  vel_share(e, s);
+}
+
+// The same for every live sprite of slots [a0, a1) at once, lanes = sprites: without shared velocity
+// arrays (program.vel_alias) the sprites of a layer are independent under these forces.
+__device__ inline void force_single_layer(Env& e, PForce F, int a0, int a1, int K) {
+  wsync();
+  for (int s = a0 + e.lane; s < a1; s += 64) {
+    double vx = 0, vy = 0;
+    if (ALIVE(s) && force_single_newvel(e, F, s, K, &vx, &vy)) { VELX(s) = vx; VELY(s) = vy; }
+  }
+  wsync();
 }
 
 __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K) {
@@ -1349,14 +1378,18 @@ __device__ inline void apply_physics(Env& e) {
       int la = uni(F->layers_a[a]);
       int a0 = uni(P->layer_slot0[la]), a1 = a0 + uni(P->layer_nslots[la]);
       if (n_b == 0) {
-        for (int s = a0; s < a1; ++s)
-          if (ALIVE(s)) force_single(e, F, s, K);
+        if (kind != MOOG_FORCE_RANDOM && !uni(P->vel_alias)) {
+          force_single_layer(e, F, a0, a1, K);
+        } else {
+          for (int s = a0; s < a1; ++s)
+            if (ALIVE(s)) force_single(e, F, s, K);
+        }
       } else {
         for (int b = 0; b < n_b; ++b) {
           int lb = uni(F->layers_b[b]);
           int b0 = uni(P->layer_slot0[lb]), b1 = b0 + uni(P->layer_nslots[lb]);
           if (kind == MOOG_FORCE_COLLISION) {
-            if (!(e.dbg & 1)) collision_layer_pair(e, F, a0, a1, b0, b1, K);
+            if (!(e.dbg & 1)) { PROF_T0; collision_layer_pair(e, F, a0, a1, b0, b1, K); PROF_ADD(e, 7); }
           } else {
             for (int s0 = a0; s0 < a1; ++s0) {
               if (!ALIVE(s0)) continue;

@@ -283,13 +283,14 @@ __global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
     }
     action_step(e, 0, ax, ay, ga);
   }
-  for (int k = 0; k < K; ++k) apply_physics(e);
+  { PROF_T0; for (int k = 0; k < K; ++k) apply_physics(e); PROF_ADD(e, 6); }
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();
   if (e.lane == 0) e.q[e.L.o_step_count] = sc;
   wsync();
   int sr = 0;
-  double r = task_reward<DYN>(e, sc, &sr);
+  double r;
+  r = task_reward<DYN>(e, sc, &sr);
   wsync();
   if (e.lane == 0) {
     if (sr) e.q[e.L.o_reset_next] = 1;

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import numpy as np, torch
 from moog import environment
 from moog_demos import example_configs
-NAMES = ['path tests', 'contact search', 'make_disjoint', 'resolve', 'broad-phase scan', 'integrate']
+NAMES = ['path tests', 'contact search', 'make_disjoint', 'resolve', 'broad-phase scan', 'integrate', 'apply_physics (all)', 'collision loops (all)']
 res = {}
 for sel in range(len(NAMES) + 1):
     os.environ['MOOG_STEP_DEBUG'] = str(128 | (sel << 8))
@@ -28,7 +28,10 @@ for sel, name in enumerate(NAMES, 1):
     v = res[sel][1]
     print('  %-18s mean %9.0f (%4.1f%%)   heaviest-40 %9.0f (%4.1f%%)' % (
         name, v.mean(), 100 * v.mean() / tot.mean(), v[heavy].mean(), 100 * v[heavy].mean() / tot[heavy].mean()))
-    acc_all += v.mean(); acc_heavy += v[heavy].mean()
-print('  %-18s mean %9.0f (%4.1f%%)   heaviest-40 %9.0f (%4.1f%%)' % (
-    'everything else', tot.mean() - acc_all, 100 - 100 * acc_all / tot.mean(),
-    tot[heavy].mean() - acc_heavy, 100 - 100 * acc_heavy / tot[heavy].mean()))
+phys, coll = res[7][1], res[8][1]
+integ = res[6][1]
+for name, v in (('collision loop overhead', coll - sum(res[k][1] for k in range(1, 6))),
+                ('forces + scaffolding', phys - coll - integ),
+                ('outside apply_physics', tot - phys)):
+    print('  %-18s mean %9.0f (%4.1f%%)   heaviest-40 %9.0f (%4.1f%%)' % (
+        name, v.mean(), 100 * v.mean() / tot.mean(), v[heavy].mean(), 100 * v[heavy].mean() / tot[heavy].mean()))
