@@ -407,6 +407,7 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
                   !(da[0] < db[0] - BB_MARGIN || da[1] < db[1] - BB_MARGIN || da[4] > db[4] + BB_MARGIN ||
                     da[5] > db[5] + BB_MARGIN));
   slow = slow && active;
+  if (__ballot(slow) & 0xffffull) return 0;   // the first candidate takes the ordinary path anyway
   bool ka = false, kb = false;
   if (active && !slow) {
     if (gl < na) {
