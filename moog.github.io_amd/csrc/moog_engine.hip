@@ -239,8 +239,11 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
 // DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
 // ChangeLayer, VanishByFilter): that variant carries the reset path's sampler; the plain one
 // is what the benchmark configs run.
-template <bool DYN>
-__global__ __launch_bounds__(64, 4) void moog_step_kernel(KArgs a) {
+// WPS = waves per SIMD the register allocation is sized for: 4 (128 VGPRs, some scratch) keeps sixteen
+// envs per CU in flight, which is what programs with small state records want; 3 (168 VGPRs, no
+// scratch in the hot loops) is faster once LDS holds fewer than fifteen records per CU anyway.
+template <bool DYN, int WPS>
+__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
   if (a.perm) env = a.perm[env];
@@ -341,6 +344,7 @@ struct moog_engine {
   int64_t env_index0 = 0;
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
+  int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
   bool dynamic_rules = false;
   RPlan raster_plan_{};
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_hwords = 1, raster_xxcap = 4;
@@ -462,11 +466,16 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_lds = pl.total;
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
-  err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_step_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+  {
+    const void* variants[4] = {reinterpret_cast<const void*>(moog_step_kernel<false, 3>),
+                               reinterpret_cast<const void*>(moog_step_kernel<false, 4>),
+                               reinterpret_cast<const void*>(moog_step_kernel<true, 3>),
+                               reinterpret_cast<const void*>(moog_step_kernel<true, 4>)};
+    for (int v = 0; v < 4 && err == hipSuccess; ++v)
+      err = hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+    e->step_wps = (160 * 1024 / (e->step_lds ? e->step_lds : 1)) <= 14 ? 3 : 4;
+    { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) e->step_wps = atoi(w); }   // experiments
+  }
   for (int r = 0; r < prog->n_rules; ++r) {
     int k = prog->rules[r].kind;
     if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES ||
@@ -567,6 +576,17 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   return a;
 }
 
+static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
+  const dim3 g(e->n_envs), b(64);
+  if (e->dynamic_rules) {
+    if (e->step_wps == 3) hipLaunchKernelGGL((moog_step_kernel<true, 3>), g, b, e->step_lds, s, a);
+    else hipLaunchKernelGGL((moog_step_kernel<true, 4>), g, b, e->step_lds, s, a);
+  } else {
+    if (e->step_wps == 3) hipLaunchKernelGGL((moog_step_kernel<false, 3>), g, b, e->step_lds, s, a);
+    else hipLaunchKernelGGL((moog_step_kernel<false, 4>), g, b, e->step_lds, s, a);
+  }
+}
+
 static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   RArgs r;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
@@ -624,8 +644,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   }
   {
     Bracket br(e, MOOG_K_STEP, s);
-    if (e->dynamic_rules) hipLaunchKernelGGL(moog_step_kernel<true>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
-    else hipLaunchKernelGGL(moog_step_kernel<false>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    launch_step(e, s, a);
   }
   HIPCHK(hipGetLastError());
   if (e->perm && e->cost) {
@@ -646,8 +665,7 @@ int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject, void
   KArgs a = make_args(e, nullptr, inject, nullptr, MODE_PHYSICS, nullptr);
   {
     Bracket br(e, MOOG_K_STEP, s);
-    if (e->dynamic_rules) hipLaunchKernelGGL(moog_step_kernel<true>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
-    else hipLaunchKernelGGL(moog_step_kernel<false>, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    launch_step(e, s, a);
   }
   HIPCHK(hipGetLastError());
   return MOOG_OK;
