@@ -771,11 +771,132 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
   out.status = CV_OK;
 }
 
+// Both directed searches of get_collision_vectors at once, 32 lanes each (polygons of <= 32
+// vertices): lanes 0-31 run directed(s1, s0), lanes 32-63 directed(s0, s1), with the very
+// arithmetic of directed_collision_vectors; the two dependent chains overlap instead of adding up.
+__device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int sb, double dt, CVec& ra, CVec& rb) {
+  const int h = e.lane >> 5, j = e.lane & 31, hb = h << 5;
+  const int s0 = h ? sa : sb, s1 = h ? sb : sa;
+  const double* v0 = VERT(s0);
+  const double* v1 = VERT(s1);
+  const int n0 = NV(s0), n1 = NV(s1);
+  double e1x = 0, e1y = 0, e2x = 0, e2y = 0;
+  if (j < n1) {
+    int j2 = (j + 1 == n1) ? 0 : j + 1;
+    e1x = v1[2 * j]; e1y = v1[2 * j + 1]; e2x = v1[2 * j2]; e2y = v1[2 * j2 + 1];
+  }
+  double cx = 0, cy = 0;
+  bool contained = false, maybe = false;
+  const bool disc = (FLAGS(s1) & MOOG_F_SYM_CIRCLE) != 0;
+  if (j < n0) {
+    cx = v0[2 * j]; cy = v0[2 * j + 1];
+    if (disc) contained = norm2(cx - PX(s1), cy - PY(s1)) <= MAXR(s1);
+    else maybe = isfinite(cx) && isfinite(cy) && !seg_outside_dop(cx, cy, cx, cy, &BB(s1, 0));
+  }
+  unsigned mbh = (unsigned)(__ballot(maybe) >> hb);
+  while (__any(mbh != 0u)) {
+    const bool on = mbh != 0u;
+    const int l = on ? __ffs((int)mbh) - 1 : 0;
+    if (on) mbh &= mbh - 1u;
+    double tx = shfl_d(cx, hb + l), ty = shfl_d(cy, hb + l);
+    bool toggle = false;
+    if (on && j < n1) {
+      bool f0 = (e1y >= ty), f1 = (e2y >= ty);
+      if (f0 != f1) toggle = (((e2y - ty) * (e1x - e2x) >= (e2x - tx) * (e1y - e2y)) == f1);
+    }
+    const int par = __popc((unsigned)(__ballot(toggle) >> hb)) & 1;
+    if (on && j == l) contained = (par != 0);
+  }
+  const unsigned long long call = __ballot(contained);
+  const unsigned cmh = (unsigned)(call >> hb);
+  ra.status = CV_NONE; rb.status = CV_NONE;
+  if (call == 0ull) return;
+  double m[6];
+  relative_motion_matrix(e, s0, s1, dt, m);
+  const double ds1x = e2x - e1x, ds1y = e2y - e1y;
+  bool anycross = false;
+  int ci = -1, e1 = 0;
+  double bv = 0, ca = 0, bpx = 0, bpy = 0, bsx = 0, bsy = 0;
+  bool cnan = false;
+  unsigned mm = cmh;
+  const unsigned inrow = (n1 >= 32) ? ~0u : ((1u << n1) - 1u);
+  while (__any(mm != 0u)) {
+    const bool on = mm != 0u;
+    const int l = on ? __ffs((int)mm) - 1 : 0;
+    if (on) mm &= mm - 1u;
+    double rcx = shfl_d(cx, hb + l), rcy = shfl_d(cy, hb + l);
+    double pvx = (m[0] * rcx + m[1] * rcy) + m[2];
+    double pvy = (m[3] * rcx + m[4] * rcy) + m[5];
+    double ds0x = rcx - pvx, ds0y = rcy - pvy;
+    bool crossing = false;
+    double cav = -DINF;
+    if (on && j < n1) {
+      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
+      double mx = e1x - pvx, my = e1y - pvy;
+      double B = (mx * ds0y - my * ds0x) / den;
+      crossing = (B >= 0) && (B <= 1);
+      if (crossing) cav = (mx * ds1y - my * ds1x) / den;
+    }
+    double ab = fabs(1. - cav);
+    const unsigned crossm = (unsigned)(__ballot(crossing) >> hb);
+    if (on) anycross = anycross || (crossm != 0u);
+    const unsigned nanm = (unsigned)(__ballot(isnan(ab)) >> hb) & inrow;
+    double v = (j < n1) ? ab : DINF, mn = v;
+    for (int o = 16; o > 0; o >>= 1) mn = fmin(mn, shfl_d(mn, e.lane ^ o));
+    const unsigned eq = (unsigned)(__ballot(v == mn) >> hb) & inrow;
+    int best = nanm ? __ffs((int)nanm) - 1 : __ffs((int)eq) - 1;
+    if (!on || best < 0) best = 0;
+    double bca = shfl_d(cav, hb + best);
+    double cpx = pvx + bca * (rcx - pvx), cpy = pvy + bca * (rcy - pvy);
+    double dfx = rcx - cpx, dfy = rcy - cpy;
+    double dist = norm2(dfx, dfy);
+    if (dist == DINF) dist = 0;
+    if (on) {
+      bool take;
+      if (ci < 0) { take = true; cnan = isnan(dist); }
+      else if (cnan) take = false;
+      else if (isnan(dist)) { take = true; cnan = true; }
+      else take = dist > bv;
+      if (take) { ci = l; bv = dist; e1 = best; ca = bca; bpx = cpx; bpy = cpy; bsx = dfx; bsy = dfy; }
+    }
+  }
+  // this half's result (uniform within the half), then one lane of each half speaks for it
+  int st = CV_NONE;
+  double nx = 0, ny = 0, qx = 0, qy = 0;
+  if (cmh != 0u && anycross) {
+    if (ca > 1) st = CV_FUTURE;
+    else {
+      int e2 = (e1 + 1 == n1) ? 0 : e1 + 1;
+      double dvx = v1[2 * e2] - v1[2 * e1], dvy = v1[2 * e2 + 1] - v1[2 * e1 + 1];
+      double tnx = dvy, tny = -1 * dvx;
+      double nn = sqrt(tnx * tnx + tny * tny);
+      nx = tnx / nn; ny = tny / nn;
+      double sc = (bsx * dvx + bsy * dvy) / (dvx * dvx + dvy * dvy);
+      qx = bsx - dvx * sc;
+      qy = bsy - dvy * sc;
+      st = CV_OK;
+    }
+  }
+  ra.status = __shfl(st, 0); rb.status = __shfl(st, 32);
+  ra.px = shfl_d(bpx, 0); rb.px = shfl_d(bpx, 32);
+  ra.py = shfl_d(bpy, 0); rb.py = shfl_d(bpy, 32);
+  ra.sx = shfl_d(bsx, 0); rb.sx = shfl_d(bsx, 32);
+  ra.sy = shfl_d(bsy, 0); rb.sy = shfl_d(bsy, 32);
+  ra.nx = shfl_d(nx, 0); rb.nx = shfl_d(nx, 32);
+  ra.ny = shfl_d(ny, 0); rb.ny = shfl_d(ny, 32);
+  ra.qx = shfl_d(qx, 0); rb.qx = shfl_d(qx, 32);
+  ra.qy = shfl_d(qy, 0); rb.qy = shfl_d(qy, 32);
+}
+
 // collisions.py:235-289
 __device__ inline void get_collision_vectors(const Env& e, int s0, int s1, double dt, CVec& out) {
   CVec r0, r1;
-  directed_collision_vectors(e, s1, s0, dt, r0);
-  directed_collision_vectors(e, s0, s1, dt, r1);
+  if (NV(s0) <= 32 && NV(s1) <= 32 && !(e.dbg & 64)) {
+    directed_collision_vectors_pair(e, s0, s1, dt, r0, r1);
+  } else {
+    directed_collision_vectors(e, s1, s0, dt, r0);
+    directed_collision_vectors(e, s0, s1, dt, r1);
+  }
   double a0x = 0, a0y = 0, a1x = 0, a1y = 0;
   if (r0.status != CV_NONE) {
     r0.nx = -1. * r0.nx; r0.ny = -1. * r0.ny;
