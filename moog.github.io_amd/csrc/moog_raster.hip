@@ -651,6 +651,10 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
             if (k >= 1 && !closing) {
               short2 pp = pv[k - 1];
               if (pp.y == p0.y) absorbed = (p1.x > p0.x && p0.x > pp.x) || (p1.x < p0.x && p0.x < pp.x);
+              // Three equal vertices in a row (tiny circles): this zero-length head repeats the one
+              // before it, which is visited immediately before it with the same result either way
+              // (drawn: x_pos has passed it; not drawn: same x_pos, same decision) -- drop it.
+              if (pp.x == p0.x && pp.y == p0.y && p1.x == p0.x) absorbed = true;
             }
             if (!absorbed) {
               // extend over the following absorbed edges (never the closing edge)
