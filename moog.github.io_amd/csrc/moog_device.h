@@ -137,6 +137,22 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// min over each row of 16 lanes, in every lane of the row, by DPP exchanges (xor 1, xor 2 inside
+// the quads, then the two mirrors): VALU moves instead of four round trips through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_min(double v) {
+  v = fmin(v, dpp_d<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmin(v, dpp_d<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmin(v, dpp_d<0x141>(v));   // row_half_mirror
+  v = fmin(v, dpp_d<0x140>(v));   // row_mirror
+  return v;
+}
+
 // ---- RNG: Philox4x32-10, bit-identical to oracle/moog_oracle.c ---------------
 __device__ inline void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -738,7 +754,9 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
     if (nanm) best = __ffsll((long long)nanm) - 1;
     else {
       double v = (j < n1) ? ab : DINF, mn = v;
-      for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, shfl_d(mn, e.lane ^ o));
+      mn = row16_min(mn);
+      mn = fmin(mn, shfl_d(mn, e.lane ^ 16));
+      mn = fmin(mn, shfl_d(mn, e.lane ^ 32));
       uint64_t eq = __ballot(v == mn) & inrow;
       best = __ffsll((long long)eq) - 1;
     }
@@ -842,7 +860,8 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
     if (on) anycross = anycross || (crossm != 0u);
     const unsigned nanm = (unsigned)(__ballot(isnan(ab)) >> hb) & inrow;
     double v = (j < n1) ? ab : DINF, mn = v;
-    for (int o = 16; o > 0; o >>= 1) mn = fmin(mn, shfl_d(mn, e.lane ^ o));
+    mn = row16_min(mn);
+    mn = fmin(mn, shfl_d(mn, e.lane ^ 16));
     const unsigned eq = (unsigned)(__ballot(v == mn) >> hb) & inrow;
     int best = nanm ? __ffs((int)nanm) - 1 : __ffs((int)eq) - 1;
     if (!on || best < 0) best = 0;
