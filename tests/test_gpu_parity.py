@@ -695,3 +695,26 @@ def test_raster_degenerate_polygon_fuzz(W):
     ref = o.render()
     bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
     assert bad.size == 0, ('frames differ', [(int(b), int(b) % 8) for b in bad[:10]], int(bad.size))
+
+
+@pytest.mark.parametrize('name', ['colliding_predators_32', 'chase_avoid_torus', 'lambda_zoo'])
+def test_step_register_variants_agree(name, monkeypatch):
+    """The step kernel exists in two register allocations (3 / 4 waves per SIMD, chosen per program);
+    both give bit-identical records, rewards and frames."""
+    import torch
+    n = 128
+    envs = []
+    for wps in ('3', '4'):
+        monkeypatch.setenv('MOOG_STEP_WPS', wps)
+        envs.append(make_env(name, n, seed=5, env_index0=40))
+    rs = np.random.RandomState(2)
+    for env in envs:
+        env.reset()
+    for k in range(20):
+        a = rs.randint(0, 5, size=n) if envs[0]._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        outs = [env.step(a) for env in envs]
+        (f0, q0), (f1, q1) = download(envs[0]), download(envs[1])
+        assert np.array_equal(q0, q1), k
+        assert np.array_equal(f0.view(np.int64), f1.view(np.int64)), k
+        assert np.array_equal(outs[0].observation['image'].cpu().numpy(), outs[1].observation['image'].cpu().numpy()), k
+        assert helpers.same_or_nan(outs[0].reward.cpu().numpy(), outs[1].reward.cpu().numpy())
