@@ -258,6 +258,47 @@ def test_full_size_properties():
     assert np.array_equal(q2, q[128:192]) and np.array_equal(f2, f[128:192], equal_nan=True)
 
 
+@pytest.mark.parametrize('name,n,steps,size', [('chase_avoid_torus', 4096, 8, None),
+                                               ('colliding_predators_32', 4096, 8, None),
+                                               ('functional_maze', 8192, 6, 128),
+                                               ('falling_balls_64', 8192, 2, None)])
+def test_full_size_vs_oracle(name, n, steps, size):
+    """BASELINE.json's configs at their full per-GPU sizes against the oracle itself (OpenMP over envs
+    makes it affordable): reset + a few steps in lock step -- integer records bit-exact, floats <= 1e-9,
+    rewards / step types exact, and every one of the final frames bit-exact."""
+    import torch  # noqa: F401
+    from moog import environment
+    from moog_demos import example_configs
+    if size is None:
+        env = make_env(name, n, seed=17, env_index0=0)
+    else:
+        cfg = __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, image_size=(size, size))
+        env = environment.BatchedEnvironment(num_envs=n, seed=17, env_index0=0,
+                                             layer_capacity=example_configs.capacity(name), **cfg)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=17, env_index0=0)
+    env.reset()
+    o.reset(render=False)
+    rs = np.random.RandomState(9)
+    for k in range(steps):
+        a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.step(a, render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.abs(f - o.f64)
+        err = np.where(np.isnan(f) & np.isnan(o.f64), 0, err)
+        err = np.where(f == o.f64, 0, err)
+        assert float(np.max(err)) <= 1e-9, (k, float(np.max(err)))
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+        o.f64[:], o.i32[:] = f, q   # lock step (removes 1-ulp libm / ocml drift)
+    img = out.observation['image'].cpu().numpy()
+    ref = o.render()
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
+
+
 def test_gym_wrapper_contract():
     """The Gym surface pinned by the reference's tests/moog/env_wrappers/test_gym_wrapper.py:49-131:
     spaces, uint8 image observations, `done` exactly at the timeout step and False on
