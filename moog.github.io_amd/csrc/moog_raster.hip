@@ -878,13 +878,18 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int y = w + r0 - rowbase[g];
         const unsigned hbits = q1.z;   // the heads on this row (the polygon has <= 32 edges)
         const REdge* pe = edges + c * TOTV + (pbase[s] & 0xfffff);
-        sort_network<16>(k);
         RMask m;
         if (hwords > 1) {
+          sort_network<16>(k);
           RPoly poly = {pe, 32, headmask + g * hwords, hwords, hbits};
           m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
-        } else {
+        } else if (__any(cnt > 8)) {
+          sort_network<16>(k);
           m = span_loop_pending<R_CAP / 2, 16, WORDS>(k, cnt, pe, hbits, W);
+        } else {   // this is one wave's dependent chain: the short network when it suffices
+          unsigned k8[8] = {k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]};
+          sort_network<8>(k8);
+          m = span_loop_pending<4, 8, WORDS>(k8, cnt, pe, hbits, W);
         }
         unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
         mp[0] = m.w0;
