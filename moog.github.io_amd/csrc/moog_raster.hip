@@ -548,18 +548,20 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   if (tid < 8) misc[tid] = 0;
   // per-sprite colour (the last wave: it has the fewest vertices to convert)
   for (int s = tid - (R_THREADS - 64); s >= 0 && s < S; s += 64) {
-    unsigned rgba = 0u;
-    const bool alive = (gq[a.L.o_flags + s] & MOOG_F_ALIVE) != 0;
+    // (every load of the slot goes out at once: one trip to HBM, not one per dependent step)
+    const int flags = gq[a.L.o_flags + s], nvs = gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
+    const double* col = gf + a.L.o_color + 3 * s;
+    const double c0 = col[0], c1 = col[1], c2 = col[2];
+    const bool alive = (flags & MOOG_F_ALIVE) != 0;
     // first edge record of the slot | live vertex count << 20 (0 for a dead sprite): the later
     // phases take both from LDS instead of chasing the record's flag words through HBM
-    pbase[s] = P->slot_voff[s] | ((alive ? gq[a.L.o_nverts + s] : 0) << 20);
+    pbase[s] = P->slot_voff[s] | ((alive ? nvs : 0) << 20);
+    unsigned rgba = 0u;
     if (alive) {
       unsigned r8, g8, b8;
-      const double* col = gf + a.L.o_color + 3 * s;
-      if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(col[0], col[1], col[2], r8, g8, b8);
-      else { r8 = (unsigned)(int)col[0] & 255u; g8 = (unsigned)(int)col[1] & 255u; b8 = (unsigned)(int)col[2] & 255u; }
-      unsigned a8 = (unsigned)gq[a.L.o_opacity + s] & 255u;
-      rgba = r8 | (g8 << 8) | (b8 << 16) | (a8 << 24);
+      if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(c0, c1, c2, r8, g8, b8);
+      else { r8 = (unsigned)(int)c0 & 255u; g8 = (unsigned)(int)c1 & 255u; b8 = (unsigned)(int)c2 & 255u; }
+      rgba = r8 | (g8 << 8) | (b8 << 16) | (((unsigned)opa & 255u) << 24);
     }
     for (int c = 0; c < ncopy; ++c) item_rgba[s * ncopy + c] = rgba;
   }
@@ -579,9 +581,11 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   if (a.debug_stop == 1) return;
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
+  unsigned vi_keep0 = 0u, vi_keep1 = 0u;   // the first two rounds' table entries, reused by phase 2
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     const unsigned vi = vi_next;
     const double2 v = v_next;
+    if (idx == tid) vi_keep0 = vi; else if (idx == tid + R_THREADS) vi_keep1 = vi;
     if (idx + R_THREADS < TOTV) {   // the next round's loads
       vi_next = a.vinfo[idx + R_THREADS];
       v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (idx + R_THREADS));
@@ -603,29 +607,6 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   __syncthreads();
   if (a.debug_stop == 2) return;
 
-  // ---- 2a: exclusive scan of the clamped row counts of all items (wave 0) --------------
-  if (tid < 64) {
-    int run = 0;
-    for (int i0 = 0; i0 < items; i0 += 64) {
-      int it = i0 + tid;
-      int cnt = 0, ystart = 0;
-      if (it < items) {
-        int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
-        if (y0 < 0) y0 = 0;
-        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
-        cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
-        ystart = y0;
-      }
-      int inc = cnt;
-      for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(inc, o);
-        if (tid >= o) inc += t;
-      }
-      if (it < items) { rowoff[it] = run + inc - cnt; rowbase[it] = run + inc - cnt - ystart; }
-      run += __shfl(inc, 63);
-    }
-    if (tid == 0) rowoff[items] = run;
-  }
   // ---- 2b: the edge leaving every vertex (ImagingDrawPolygon: add_edge + merge of
   //          horizontal runs); table edges and horizontal heads join the compact list
   for (int c = 0; c < ncopy; ++c) {
@@ -633,7 +614,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       const int idx = base0 + tid;
       int kind = 0;   // 1 table edge, 2 horizontal head
       if (idx < TOTV) {
-        unsigned vi = a.vinfo[idx];
+        const unsigned vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx]);
         int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
         int nv = pbase[s] >> 20;
         if (k < nv) {
@@ -683,9 +664,35 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         if (lane == 0) pos0 = atomicAdd(&misc[0], __popcll(m));
         pos0 = __shfl(pos0, 0);
         if (kind) list[pos0 + __popcll(m & ((1ull << lane) - 1ull))] =
-            (a.vinfo[idx] & 0xffffu) | ((unsigned)c << 16) | (kind == 2 ? 0x80000000u : 0u);
+            ((base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx])) & 0xffffu) | ((unsigned)c << 16) |
+            (kind == 2 ? 0x80000000u : 0u);
       }
     }
+  }
+  // ---- 2a: exclusive scan of the clamped row counts of all items (the last wave, whose second
+  //          round of edges is nearly empty; needed after the barrier only) ----------------------
+  if (tid >= R_THREADS - 64) {
+    const int tid = lane;
+    int run = 0;
+    for (int i0 = 0; i0 < items; i0 += 64) {
+      int it = i0 + tid;
+      int cnt = 0, ystart = 0;
+      if (it < items) {
+        int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
+        if (y0 < 0) y0 = 0;
+        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
+        cnt = (y1 >= y0) ? (y1 - y0 + 1) : 0;
+        ystart = y0;
+      }
+      int inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (tid >= o) inc += t;
+      }
+      if (it < items) { rowoff[it] = run + inc - cnt; rowbase[it] = run + inc - cnt - ystart; }
+      run += __shfl(inc, 63);
+    }
+    if (tid == 0) rowoff[items] = run;
   }
   __syncthreads();
   if (a.debug_stop == 3) return;
