@@ -2,14 +2,29 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" = one `BatchedEnvironment.step(actions)` over the whole batch: auto-reset
-kernel + step kernel (rules -> action -> K physics substeps -> task) + raster
-kernel writing the uint8 frame batch, with random actions generated on device.
+A "step" = one `BatchedEnvironment.step(actions)` over the whole batch: step
+kernel (auto-reset of the envs whose episode ended, else rules -> action -> K
+physics substeps -> task) + raster kernel writing the uint8 frame batch, with
+random actions generated on device.
 Workload (BASELINE.json configs[2], the one the metric is quoted on):
 colliding_predators scaled to 32 sprites, 4096 envs per GPU, 64x64 observations.
-For N > 1 the driver launches one rank per GPU (torch.distributed.run); envs are
-independent, so ranks shard the env axis with no data-path collective (weak
-scaling: 4096 envs per GPU, global env index = rank * 4096 + local).
+`--workload falling_balls_64 --envs-per-gpu 8192` is BASELINE.json configs[4]
+(the 8-GPU weak-scaling stress).
+
+N > 1: one process per GPU.  Launched under torch.distributed.run (the driver's
+form, WORLD_SIZE set) the script is one rank; launched plainly with `--gpus N`
+it starts the N ranks itself (before anything touches a GPU) and relays rank
+0's JSON line.  Envs are independent, so ranks shard the env axis with no
+data-path collective (weak scaling: global env index = rank * envs_per_gpu +
+local); one MAX all-reduce of the wall time is the only communication.
+
+Stationary load: every episode of the headline workload lasts exactly
+`timeout_steps` calls, so a batch that was reset together would time out
+together and the cost of a step would depend on where in the episode the timed
+window falls.  The benchmark therefore de-synchronises the episodes before
+timing (each env starts at a different `step_count`) and burns in one episode
+length; after that the same fraction of the batch is resetting in every call,
+as in any long-running job.  `--lockstep` keeps the synchronous episodes.
 
 The JSON line also carries
   roofline     achieved algorithmic GB/s of the raster kernel (HIP events around
@@ -20,6 +35,8 @@ The JSON line also carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,13 +62,14 @@ def raster_bytes_per_env(env):
 
 
 def raster_traffic(workload, n_envs):
-    """HBM bytes per raster launch from the committed rocprofv3 PMC passes
-    (profiles/raster_traffic.json; collected with tools/prof.sh), or None."""
+    """HBM bytes per raster launch as profiled offline (rocprofv3 PMC passes of this
+    workload, tools/prof.sh -> profiles/raster_traffic.json; the record names the
+    profile file and commit it came from), or None.  Not a measurement of this run."""
     try:
         with open(os.path.join(REPO, 'profiles', 'raster_traffic.json')) as f:
             rec = json.load(f).get(workload)
         if rec and rec.get('n_envs') == n_envs:
-            return rec['traffic_bytes']
+            return rec
     except (OSError, ValueError):
         pass
     return None
@@ -79,31 +97,92 @@ def host_cores():
     return n
 
 
-def cpu_baseline(seconds_target=12.0):
-    """Times the CPU oracle (oracle/moog_oracle.c, one OpenMP thread per host core, envs are
-    independent) on a bounded sample of the same workload: 64 envs per thread stepped until
-    ~seconds_target."""
-    sys.path.insert(0, os.path.join(REPO, 'tests'))
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _time_oracle(workload, n, threads, seconds_target, max_steps):
+    import ctypes
     import numpy as np
     import helpers
-    cores = host_cores()
-    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
-    n = 64 * cores
-    c = helpers.compiled(WORKLOAD)
+    try:   # the oracle is OpenMP over envs: pin the team size for this sample
+        ctypes.CDLL('libgomp.so.1').omp_set_num_threads(int(threads))
+    except OSError:
+        pass
+    c = helpers.compiled(workload)
     o = helpers.OracleEnv(c, n_envs=n, seed=1)
     o.reset()
     rs = np.random.RandomState(0)
+    grid = bool(c.program.action.kind == 2 and c.program.n_actions <= 1)
+    act = (lambda: rs.randint(0, 5, size=n)) if grid else (lambda: rs.uniform(-1, 1, size=(n, 2)))
     for _ in range(2):
-        o.step(rs.uniform(-1, 1, size=(n, 2)))
+        o.step(act())
     t0 = time.perf_counter()
     steps = 0
-    while time.perf_counter() - t0 < seconds_target and steps < 400:
-        o.step(rs.uniform(-1, 1, size=(n, 2)))
+    while time.perf_counter() - t0 < seconds_target and steps < max_steps:
+        o.step(act())
         steps += 1
     dt = time.perf_counter() - t0
-    return {'value': n * steps / dt, 'unit': 'env steps/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%s, %d envs x %d steps (physics + 64x64 raster), %d OpenMP threads, %.1f s'
-                      % (WORKLOAD, n, steps, cores, dt)}
+    return n * steps / dt, steps, dt
+
+
+def cpu_baseline(workload, seconds_target=10.0):
+    """Times the CPU oracle (oracle/moog_oracle.c, a C restatement of the reference
+    algorithm) on a bounded sample of the same workload: first one thread (the
+    reference's own single-threaded design), then one OpenMP thread per host core over
+    disjoint env shards (envs are independent)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    cores = host_cores()
+    os.environ.setdefault('OMP_NUM_THREADS', str(cores))
+    v1, s1, d1 = _time_oracle(workload, 32, 1, seconds_target * 0.5, 200)
+    vn, sn, dn = _time_oracle(workload, 64 * cores, cores, seconds_target, 400)
+    return {'value': vn, 'unit': 'env steps/sec', 'cores': cores, 'kind': 'port',
+            'cpu_model': cpu_model(),
+            'single_thread': {'value': v1, 'unit': 'env steps/sec', 'cores': 1,
+                              'sample': '%s, 32 envs x %d steps, 1 thread, %.1f s' % (workload, s1, d1)},
+            'sample': '%s, %d envs x %d steps (physics + raster), %d OpenMP threads, %.1f s'
+                      % (workload, 64 * cores, sn, cores, dn)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with
+    torch.distributed.run as child processes.  This process never initialises a GPU
+    (device_count() does not), so nothing is re-executed over a live HIP context."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible\n' % (args.gpus, have))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
+def stagger_episodes(env, timeout, index0):
+    """De-synchronises the episodes: env i starts its first episode at step_count
+    (i * 7919) mod timeout (7919 is prime: a contiguous shard of the env axis covers all
+    episode phases evenly)."""
+    import torch
+    n = env.num_envs
+    idx = torch.arange(n, dtype=torch.int64, device=env.device) + int(index0)
+    env.state_i32[:, env.layout.o_step_count] = ((idx * 7919) % int(timeout)).to(torch.int32)
 
 
 def main():
@@ -115,14 +194,22 @@ def main():
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
+    ap.add_argument('--lockstep', action='store_true', help='keep the episodes of the batch synchronous')
+    ap.add_argument('--no-extras', action='store_true', help='skip the strict-fault-check comparison window')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     from moog import _abi, environment, sharding
     from moog_demos import example_configs
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # Test hooks for 1-GPU boxes (tools/bench_ranks.sh): MOOG_BENCH_ONE_DEVICE=1 puts every
@@ -131,6 +218,9 @@ def main():
     backend = os.environ.get('MOOG_BENCH_BACKEND', 'nccl')
     if os.environ.get('MOOG_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        sys.stderr.write('bench.py: rank %d has no GPU (%d visible)\n' % (rank, torch.cuda.device_count()))
+        sys.exit(2)
     use_dist = world > 1 or os.environ.get('MOOG_BENCH_FORCE_DIST') == '1'
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -143,15 +233,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     n = args.envs_per_gpu
+    index0 = sharding.shard_range(n * world, rank, world)[0]
 
     env = environment.BatchedEnvironment(
-        num_envs=n, device=dev, seed=2024, env_index0=sharding.shard_range(n * world, rank, world)[0],
+        num_envs=n, device=dev, seed=2024, env_index0=index0,
+        layer_capacity=example_configs.capacity(args.workload),
         **example_configs.load(args.workload))
-    env.check_faults = False
     if not args.no_schedule:
         env.enable_cost_schedule()
     env.reset()
     is_grid = env._is_grid
+    P = env.compiled.program
+    timeout = P.timeout_steps
+    staggered = (not args.lockstep) and timeout == timeout and 1 < timeout < 1e6
 
     # random actions drawn on the device, one kernel per step, into a reused buffer
     act = torch.zeros((n,), dtype=torch.int32, device=dev) if is_grid else \
@@ -170,13 +264,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    burn_in = 0
+    if staggered:   # setup, not part of the W warm-up steps: reach the stationary mix of episode phases
+        stagger_episodes(env, timeout, index0)
+        burn_in = int(timeout) + 1
+        for _ in range(burn_in):
+            one_step()
     for _ in range(args.warmup):
         one_step()
-    # the roofline kernel (raster) is timed live, with HIP events around every one of its
-    # launches in the timed region; the other kernels' averages come from a short extra run
-    # afterwards so that their event pairs do not sit in the timed stream (each pair costs
-    # stream time: ~9 us around the 6 us reset kernel)
-    env.set_timing(True, kernels=[_abi.MOOG_K_RASTER])
+    # Every kernel of the timed region is bracketed by HIP events on the launch stream, so the
+    # per-kernel averages (and the roofline figure of the raster kernel) are measurements of the
+    # timed steps themselves; the event pairs cost the timed region about 1 % of stream time.
+    env.set_timing(True)
     for k in range(_abi.MOOG_K_COUNT):
         env.kernel_time(k)   # clear
     barrier()
@@ -188,19 +287,23 @@ def main():
     env.set_timing(False)
     # MAX over ranks, off the timed path (RCCL needs the tensor on the GPU, gloo on the host)
     dt_max = sharding.max_over_ranks(dt, device=dev if backend == 'nccl' else None)
+    env.raise_faults()   # faults of the timed steps (deferred surfacing: none were skipped silently)
 
-    k_ms = {'raster': env.kernel_time(_abi.MOOG_K_RASTER)}
-    # all kernels, outside the timed region; as many steps again, because the workload is
-    # periodic (episodes time out together every 200 steps: sparse right after a reset,
-    # clustered contacts later), so a shorter window would not be representative
-    env.set_timing(True)
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize(dev)
-    env.set_timing(False)
-    env.kernel_time(_abi.MOOG_K_RASTER)
-    k_ms['step'] = env.kernel_time(_abi.MOOG_K_STEP)
-    k_ms['reset'] = env.kernel_time(_abi.MOOG_K_RESET)
+    k_ms = {'raster': env.kernel_time(_abi.MOOG_K_RASTER), 'step': env.kernel_time(_abi.MOOG_K_STEP),
+            'reset': env.kernel_time(_abi.MOOG_K_RESET)}
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the same steps with a host synchronisation + fault check after every call
+        # (check_faults = 'sync': exceptions surface in the call that caused them)
+        env.check_faults = 'sync'
+        m = max(20, args.steps // 4)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(m):
+            one_step()
+        torch.cuda.synchronize(dev)
+        extras['value_sync_fault_check'] = n * m / (time.perf_counter() - t1)
+        env.check_faults = True
     faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
     if rank == 0:
         total_steps = n * world * args.steps
@@ -208,7 +311,7 @@ def main():
         r_ms, r_n = k_ms['raster']
         r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
         achieved = (n * rb / r_avg_s) / 1e9 if r_avg_s > 0 else 0.0
-        P = env.compiled.program
+        tr = raster_traffic(args.workload, n)
         line = {
             'metric': 'env steps/sec (whole node), 4096 envs x 32 sprites, 64x64 obs',
             'value': total_steps / dt_max,
@@ -227,19 +330,25 @@ def main():
                                        args.workload, n, P.n_slots, P.updates_per_env_step,
                                        P.render.height, P.render.width),
                        'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
-                       'parallelism': 'env-sharded x%d, no collective' % world},
+                       'parallelism': 'env-sharded x%d, no collective' % world,
+                       'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)
+                                   if staggered else 'lockstep'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBPS, 'traffic': raster_traffic(args.workload, n),
-                         'traffic_unit': 'bytes per launch (rocprofv3 PMC, profiles/r01_current.txt)',
+                         'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': tr['traffic_bytes'] if tr else None,
+                         'traffic_source': (tr.get('source', 'profiles/raster_traffic.json') + ' (offline rocprofv3 PMC passes, '
+                                            'not this run)') if tr else None,
                          'algorithmic_bytes_per_launch': n * rb,
                          'kernel': 'moog_raster_kernel', 'avg_kernel_us': r_avg_s * 1e6,
                          'algorithmic_bytes_per_env': rb},
-            'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items()},
+            'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items() if v[1] > 0},
             'faulted_envs': faults,
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(args.workload)
         print(json.dumps(line))
+        sys.stdout.flush()
     if use_dist:
         dist.destroy_process_group()
 

@@ -567,6 +567,19 @@ int moog_engine_set_timing(moog_engine_t* e, int32_t enabled);
 int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_ms,
                             int64_t* launches);
 
+/* The rasteriser's static prefix: the leading sprite slots that every reset creates identically and
+ * at rest (border walls) are rendered once at create; frames whose prefix equals that reference
+ * bit for bit are composed on top of the cached picture (pil_renderer.py:104-111 draws them first,
+ * so the result is the same).  Returns the number of slots in the prefix (0: feature unused) and,
+ * when `image_dev` is not NULL, copies the cached picture [height][width][3] there. */
+int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image_dev, void* hip_stream);
+
+/* Profiling aids, both 0 in production (they make results wrong: timing only).  `step_debug`: bit
+ * mask that switches parts of the step kernel off / writes cycle counters instead of outputs;
+ * `raster_stop` = k truncates the raster kernel after phase k.  The initial values come from the
+ * environment variables MOOG_STEP_DEBUG / MOOG_RASTER_STOP, read once by moog_engine_create. */
+int moog_engine_set_debug(moog_engine_t* e, int32_t step_debug, int32_t raster_stop);
+
 #ifdef __cplusplus
 }
 #endif

@@ -355,7 +355,47 @@ struct moog_engine {
   bool sched_pending = false;
   float* cost = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
+  int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
+  // static prefix of the rasteriser (moog_raster.h): a scratch env record that holds the reference
+  // sprites (what a reset makes of the constant generation ops) and their picture
+  int n_static = 0, nsv = 0;
+  double* s_f64 = nullptr;
+  int32_t* s_i32 = nullptr;
+  uint8_t* s_bg = nullptr;
 };
+
+static void free_engine(moog_engine* e) {
+  if (e->d_prog) hipFree(e->d_prog);
+  if (e->d_vslot) hipFree(e->d_vslot);
+  if (e->d_vinfo) hipFree(e->d_vinfo);
+  if (e->s_f64) hipFree(e->s_f64);
+  if (e->s_i32) hipFree(e->s_i32);
+  if (e->s_bg) hipFree(e->s_bg);
+  delete e;
+}
+
+// Leading sprite slots that every reset creates identically and at rest: slots filled by generation
+// ops without a random factor, zero velocity.  Whether a frame's prefix really equals the reference
+// is checked by the raster kernel per frame, so this only has to be a good guess.
+static int static_prefix_slots(const moog_program_t* p, int* nsv) {
+  *nsv = 0;
+  if (p->render.polymod != MOOG_POLYMOD_NONE) return 0;
+  std::vector<char> ok((size_t)(p->n_slots > 0 ? p->n_slots : 1), 0);
+  for (int oi = 0; oi < p->n_ops; ++oi) {
+    const moog_genop_t& op = p->ops[oi];
+    if (op.runtime || op.n_sampled != 0 || op.code_off >= 0 || op.count_min != op.count_max) continue;
+    bool c = true;
+    for (int k = 0; k < MOOG_NUM_FACTORS; ++k) c = c && op.factors[k].kind == MOOG_DIST_CONST;
+    c = c && op.factors[MOOG_FAC_XVEL].a == 0 && op.factors[MOOG_FAC_YVEL].a == 0 && op.factors[MOOG_FAC_ANGVEL].a == 0;
+    if (!c) continue;
+    for (int sl = op.slot0; sl < op.slot0 + op.count_max && sl < p->n_slots; ++sl)
+      if (sl >= 0 && !p->layer_dynamic[p->slot_layer[sl]]) ok[sl] = 1;
+  }
+  int ns = 0, nv = 0;
+  while (ns < p->n_slots && ns < 32 && ok[ns] && p->slot_voff[ns] == nv) { nv += p->slot_vcap[ns]; ++ns; }
+  *nsv = nv;
+  return ns;
+}
 
 extern "C" {
 
@@ -379,6 +419,39 @@ static int validate(const moog_program_t* p) {
   return MOOG_OK;
 }
 
+static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t* inj,
+                       const moog_step_out_t* out, int mode, const uint8_t* mask);
+static RArgs raster_args(moog_engine* e, uint8_t* image);
+
+// Resets one scratch env (the constant generation ops do not depend on the random stream) and renders
+// its static prefix on top of the background colour: the reference record and picture of moog_raster.h.
+static int build_static_prefix(moog_engine* e) {
+  int nsv = 0;
+  const int ns = getenv("MOOG_RASTER_NO_STATIC") ? 0 : static_prefix_slots(&e->prog, &nsv);
+  if (ns == 0) return MOOG_OK;
+  const size_t fb = (size_t)e->L.f64_per_env * 8, ib = (size_t)e->L.i32_per_env * 4;
+  const size_t pb = (size_t)e->prog.render.width * e->prog.render.height * 3;
+  if (hipMalloc(&e->s_f64, fb) != hipSuccess || hipMalloc(&e->s_i32, ib) != hipSuccess ||
+      hipMalloc(&e->s_bg, pb) != hipSuccess)
+    return fail(MOOG_E_NOMEM, "hipMalloc(static prefix) failed");
+  HIPCHK(hipMemset(e->s_f64, 0, fb));
+  HIPCHK(hipMemset(e->s_i32, 0, ib));
+  const moog_state_view_t keep = e->view;
+  const int32_t keep_n = e->n_envs;
+  e->view.f64 = e->s_f64; e->view.i32 = e->s_i32; e->n_envs = 1;
+  KArgs a = make_args(e, nullptr, nullptr, nullptr, MODE_RESET_MASK, nullptr);
+  a.dbg = 0;
+  hipLaunchKernelGGL(moog_reset_kernel, dim3(1), dim3(64), e->step_lds, 0, a);
+  RArgs r = raster_args(e, e->s_bg);
+  r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
+  moog_raster_launch(r, e->raster_lds, 0);
+  e->view = keep; e->n_envs = keep_n;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(0));
+  e->n_static = ns; e->nsv = nsv;
+  return MOOG_OK;
+}
+
 int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t device_id, uint64_t seed,
                        int64_t env_index0, moog_engine_t** out) {
   if (!out) return fail(MOOG_E_INVALID, "null out");
@@ -394,9 +467,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   e->seed = seed;
   e->env_index0 = env_index0;
   hipError_t err = hipMalloc(&e->d_prog, sizeof(moog_program_t));
-  if (err != hipSuccess) { delete e; return fail(MOOG_E_NOMEM, "hipMalloc(program) failed"); }
+  if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "hipMalloc(program) failed"); }
   err = hipMemcpy(e->d_prog, prog, sizeof(moog_program_t), hipMemcpyHostToDevice);
-  if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_HIP, "hipMemcpy(program) failed"); }
+  if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_HIP, "hipMemcpy(program) failed"); }
   {
     std::vector<int16_t> vs((size_t)(prog->n_total_verts > 0 ? prog->n_total_verts : 1), 0);
     for (int sl = 0; sl < prog->n_slots; ++sl)
@@ -404,14 +477,14 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     err = hipMalloc(&e->d_vslot, vs.size() * sizeof(int16_t));
     if (err == hipSuccess)
       err = hipMemcpy(e->d_vslot, vs.data(), vs.size() * sizeof(int16_t), hipMemcpyHostToDevice);
-    if (err != hipSuccess) { hipFree(e->d_prog); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
+    if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "vertex table"); }
     std::vector<uint32_t> vi(vs.size(), 0u);
     for (int sl = 0; sl < prog->n_slots; ++sl)
       for (int k = 0; k < prog->slot_vcap[sl]; ++k) vi[prog->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
     err = hipMalloc(&e->d_vinfo, vi.size() * sizeof(uint32_t));
     if (err == hipSuccess)
       err = hipMemcpy(e->d_vinfo, vi.data(), vi.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (err != hipSuccess) { hipFree(e->d_prog); hipFree(e->d_vslot); delete e; return fail(MOOG_E_NOMEM, "vertex table"); }
+    if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "vertex table"); }
   }
   const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
@@ -419,7 +492,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
                 (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 16;
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
-    hipFree(e->d_prog); delete e;
+    free_engine(e);
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
   }
   // raster LDS plan (moog_raster.h): row records for `chunk` rows per pass
@@ -458,7 +531,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= H) cap = atoi(rc); }   // tuning / tests of the multi-pass path
     raster_plan(prog->n_slots, e->L.TOTV, ncopy, W, H, cap, e->raster_iwords, e->raster_hwords, e->raster_xxcap, &pl);
     if (pl.total > 160 * 1024 || (size_t)e->L.TOTV * ncopy >= (1u << 20)) {
-      hipFree(e->d_prog); hipFree(e->d_vslot); hipFree(e->d_vinfo); delete e;
+      free_engine(e);
       return fail(MOOG_E_UNSUPPORTED, "raster working set does not fit in LDS");
     }
     e->raster_chunk = cap;
@@ -499,9 +572,13 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
   if (err != hipSuccess) {
-    hipFree(e->d_prog); delete e;
+    free_engine(e);
     return fail(MOOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(err));
   }
+  { const char* ds = getenv("MOOG_STEP_DEBUG"); e->step_dbg = ds ? atoi(ds) : 0; }
+  { const char* ds = getenv("MOOG_RASTER_STOP"); e->raster_stop = ds ? atoi(ds) : 0; }
+  int rc2 = build_static_prefix(e);
+  if (rc2) { free_engine(e); return rc2; }
   *out = e;
   return MOOG_OK;
 }
@@ -525,10 +602,7 @@ int moog_engine_destroy(moog_engine_t* e) {
     hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
     hipStreamDestroy(e->sched_stream);
   }
-  if (e->d_prog) hipFree(e->d_prog);
-  if (e->d_vslot) hipFree(e->d_vslot);
-  if (e->d_vinfo) hipFree(e->d_vinfo);
-  delete e;
+  free_engine(e);
   return MOOG_OK;
 }
 
@@ -572,7 +646,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.vslot = e->d_vslot;
   a.perm = (mode == MODE_STEP) ? e->perm : nullptr;
   a.cost = (mode == MODE_STEP) ? e->cost : nullptr;
-  { const char* ds = getenv("MOOG_STEP_DEBUG"); a.dbg = ds ? atoi(ds) : 0; }
+  a.dbg = e->step_dbg;
   return a;
 }
 
@@ -587,13 +661,25 @@ static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   }
 }
 
-static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
+static RArgs raster_args(moog_engine* e, uint8_t* image) {
   RArgs r;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
   r.iwords = e->raster_iwords; r.hwords = e->raster_hwords; r.xxcap = e->raster_xxcap;
-  { const char* ds = getenv("MOOG_RASTER_STOP"); r.debug_stop = ds ? atoi(ds) : 0; }
+  r.debug_stop = e->raster_stop;
+  r.n_static = e->n_static; r.nsv = e->nsv; r.build = 0;
+  r.sref_v = e->s_f64 ? e->s_f64 + e->L.o_verts : nullptr;
+  r.sref_col = e->s_f64 ? e->s_f64 + e->L.o_color : nullptr;
+  r.sref_flags = e->s_i32 ? e->s_i32 + e->L.o_flags : nullptr;
+  r.sref_nv = e->s_i32 ? e->s_i32 + e->L.o_nverts : nullptr;
+  r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
+  r.sbg = e->s_bg;
+  return r;
+}
+
+static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
+  RArgs r = raster_args(e, image);
   {
     Bracket br(e, MOOG_K_RASTER, s);
     moog_raster_launch(r, e->raster_lds, s);
@@ -689,6 +775,24 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
     HIPCHK(hipEventCreateWithFlags(&e->ev_step_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_sched_done, hipEventDisableTiming));
   }
+  return MOOG_OK;
+}
+
+int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image_dev, void* hip_stream) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  if (n_slots) *n_slots = e->n_static;
+  if (image_dev && e->n_static > 0) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(image_dev, e->s_bg, (size_t)e->prog.render.width * e->prog.render.height * 3,
+                          hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+  }
+  return MOOG_OK;
+}
+
+int moog_engine_set_debug(moog_engine_t* e, int32_t step_debug, int32_t raster_stop) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  e->step_dbg = step_debug;
+  e->raster_stop = raster_stop;
   return MOOG_OK;
 }
 

@@ -61,6 +61,20 @@ struct RArgs {
   int32_t debug_stop;  // >0: return after that phase (profiling aid)
   RPlan plan;
   int32_t xxcap;       // crossing-list capacity of the generic scanline = 2 * max vertices per sprite
+  // Static prefix: sprites that a reset always creates the same way and that nothing moves (the
+  // border walls of most configs) come first in painter's order.  The engine renders them once,
+  // on top of the background colour, into `sbg`; the kernel compares every frame's prefix with
+  // the reference record bit for bit (vertices, colours, flags) and, when equal, skips those
+  // sprites and composes on top of `sbg`.  A frame whose prefix differs takes the ordinary path.
+  int32_t n_static;    // slots in the prefix (0: none)
+  int32_t nsv;         // vertex slots of the prefix (they are the first nsv of the record)
+  int32_t build;       // 1: render ONLY the prefix of env 0 (the launch that fills `sbg`)
+  const double* sref_v;     // reference world vertices [nsv][2]
+  const double* sref_col;   // reference colours [n_static][3]
+  const int32_t* sref_flags; // reference flags / vertex counts / opacities [n_static] each
+  const int32_t* sref_nv;
+  const int32_t* sref_opa;
+  const uint8_t* sbg;       // background + prefix, [H][W][3] in output (flipped) order
 };
 
 // Edge record, 16 bytes, one per vertex slot (the edge from vertex k to k + 1).

@@ -79,9 +79,11 @@ class BatchedEnvironment(object):
             self.image = torch.zeros((n, P.render.height, P.render.width, 3), dtype=torch.uint8,
                                      device=self.device)
         self._handle = ctypes.c_void_p()
-        _engine.check(self._lib, self._lib.moog_engine_create(
-            ctypes.byref(P), n, self.device.index or 0, int(seed), int(env_index0),
-            ctypes.byref(self._handle)))
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(self.device):   # (the engine calls hipSetDevice: keep torch's current device)
+            _engine.check(self._lib, self._lib.moog_engine_create(
+                ctypes.byref(P), n, dev_index, int(seed), int(env_index0),
+                ctypes.byref(self._handle)))
         view = _abi.StateView()
         view.f64 = ctypes.cast(self.state_f64.data_ptr(), ctypes.POINTER(ctypes.c_double))
         view.i32 = ctypes.cast(self.state_i32.data_ptr(), ctypes.POINTER(ctypes.c_int32))
@@ -108,9 +110,10 @@ class BatchedEnvironment(object):
         if enabled:
             self._cost = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
             self._perm = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
-            _engine.check(self._lib, self._lib.moog_engine_set_schedule(
-                self._handle, ctypes.c_void_p(self._perm.data_ptr()),
-                ctypes.c_void_p(self._cost.data_ptr())))
+            with torch.cuda.device(self.device):
+                _engine.check(self._lib, self._lib.moog_engine_set_schedule(
+                    self._handle, ctypes.c_void_p(self._perm.data_ptr()),
+                    ctypes.c_void_p(self._cost.data_ptr())))
         else:
             self._cost = self._perm = None
             _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
@@ -311,6 +314,23 @@ class BatchedEnvironment(object):
     @property
     def step_count(self):
         return self.state_i32[:, self.layout.o_step_count]
+
+    def static_prefix(self):
+        """(number of leading sprite slots the rasteriser keeps as a cached picture, that
+        picture uint8[H, W, 3] or None) -- include/moog_engine.h moog_engine_static_prefix."""
+        n = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_static_prefix(self._handle, ctypes.byref(n), None, None))
+        if n.value == 0:
+            return 0, None
+        img = self._torch.zeros_like(self.image[0])
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_static_prefix(
+                self._handle, ctypes.byref(n), ctypes.c_void_p(img.data_ptr()), self._stream()))
+        return n.value, img
+
+    def set_debug(self, step_debug=0, raster_stop=0):
+        """Profiling aids of the kernels (include/moog_engine.h moog_engine_set_debug)."""
+        _engine.check(self._lib, self._lib.moog_engine_set_debug(self._handle, int(step_debug), int(raster_stop)))
 
     # -- kernel timing -------------------------------------------------------------------
     def set_timing(self, enabled, kernels=None):

@@ -178,6 +178,50 @@ def test_frames_many_states(name, rows, monkeypatch):
         assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist(), int(bad.size))
 
 
+@pytest.mark.parametrize('name', ['colliding_predators_32', 'pong', 'functional_maze'])
+def test_static_prefix_cache_and_fallback(name, monkeypatch):
+    """The rasteriser composes on top of a cached picture of the leading constant sprites (the walls)
+    when a frame's prefix equals the reference record bit for bit.  Frames whose prefix was changed
+    (a wall moved by one ulp / by pixels, recoloured, made translucent or removed) must take the
+    ordinary path, next to untouched frames that use the cache: all compared with the oracle
+    renderer, and the whole batch with the cache disabled gives the same pictures."""
+    n = 96
+    env = make_env(name, n, seed=5, env_index0=40)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=5, env_index0=40)
+    env.reset()
+    rs = np.random.RandomState(3)
+    for _ in range(3):
+        env.step(rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2)))
+    f, q = download(env)
+    L, P = env.layout, env.compiled.program
+    for i in range(0, n, 2):   # every other env keeps its prefix
+        kind = (i // 2) % 6
+        s = (i // 12) % 4      # which of the leading sprites
+        v0 = L.o_verts + 2 * P.slot_voff[s]
+        if kind == 0:
+            f[i, v0] = np.nextafter(f[i, v0], 2.0)
+        elif kind == 1:
+            f[i, v0:v0 + 2 * int(q[i, L.o_nverts + s]):2] += 0.11
+        elif kind == 2:
+            f[i, L.o_color + 3 * s + 2] = 0.9 if P.render.cmap else 200
+        elif kind == 3:
+            q[i, L.o_opacity + s] = 100
+        elif kind == 4:
+            q[i, L.o_flags + s] &= ~1
+        else:
+            q[i, L.o_nverts + s] -= 1
+    upload(env, f, q)
+    o.f64[:], o.i32[:] = f, q
+    img = env.observation()['image'].cpu().numpy()
+    ref = o.render()
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
+    monkeypatch.setenv('MOOG_RASTER_NO_STATIC', '1')
+    env2 = make_env(name, n, seed=5, env_index0=40)
+    upload(env2, f, q)
+    assert np.array_equal(env2.observation()['image'].cpu().numpy(), img)
+
+
 def test_philox_bit_exact():
     """The device RNG stream equals the oracle's: a reset driven by it gives the
     same integer records (shape ids, counts, rng counters)."""

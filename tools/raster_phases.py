@@ -11,7 +11,7 @@ env.reset()
 for _ in range(3):
     env.step(env.random_action())
 for stop in [int(x) for x in os.environ.get('MOOG_RASTER_STOPS', '1,2,3,4,5,0').split(',')]:
-    os.environ['MOOG_RASTER_STOP'] = str(stop)
+    env.set_debug(0, stop)
     for _ in range(3):
         env.observation()
     env.set_timing(True); env.kernel_time(_abi.MOOG_K_RASTER)

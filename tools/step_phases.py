@@ -12,7 +12,7 @@ for _ in range(10):
     env.step(env.random_action())
 snap = (env.state_f64.clone(), env.state_i32.clone())
 for dbg in (0, 1, 2, 3, 4, 8, 16):
-    os.environ['MOOG_STEP_DEBUG'] = str(dbg)
+    env.set_debug(dbg, 0)
     env.state_f64.copy_(snap[0]); env.state_i32.copy_(snap[1])
     for _ in range(2):
         env.physics_step()
