@@ -203,7 +203,7 @@ class BatchedEnvironment(object):
         self._last_action = a
         # Programs whose rules append to layers can overflow a layer's capacity at any step:
         # surface that (one host sync per step; set check_faults = False to opt out).
-        if self.check_faults and (injected_uniforms is not None or self._dynamic_layers):
+        if self.check_faults == 'sync' or (self.check_faults and (injected_uniforms is not None or self._dynamic_layers)):
             self.raise_faults()
         del keep
         return self._timestep()
