@@ -567,6 +567,14 @@ int moog_engine_set_timing(moog_engine_t* e, int32_t enabled);
 int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_ms,
                             int64_t* launches);
 
+/* Deferred fault surfacing.  Device-side per-env faults (MOOG_FAULT_* bits in the i32 record, the
+ * engine's counterpart of the reference's synchronous exceptions: sprite_generators.py:92-98 RecursionError,
+ * portal.py:51-54 / collisions.py:322-326 ValueError, ...) are also OR-ed by the kernels into one
+ * host-visible word.  This call reads that word WITHOUT synchronising the stream (it reports what has
+ * arrived so far) and optionally clears the bits it returns; a binding polls it at the start of every
+ * call and, when non-zero, synchronises and raises from the per-env fault words. */
+int moog_engine_poll_faults(moog_engine_t* e, int32_t clear, int32_t* bits);
+
 /* The rasteriser's static prefix: the leading sprite slots that every reset creates identically and
  * at rest (border walls) are rendered once at create; frames whose prefix equals that reference
  * bit for bit are composed on top of the cached picture (pil_renderer.py:104-111 draws them first,

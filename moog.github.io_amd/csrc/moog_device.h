@@ -69,7 +69,7 @@ struct Env {
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
-  int n_path, n_resp;      // profiling counters (path tests, contact searches)
+  int n_path, n_resp, n_disj;   // profiling counters (path tests, contact searches, make_disjoint calls)
 #ifdef MOOG_PROFILE
   long long prof[8];       // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
 #endif
@@ -1180,6 +1180,7 @@ __device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K, b
     CVec c;
     { PROF_T0; get_collision_vectors(e, s0, s1, dt, c); PROF_ADD(e, 1); }
     if (c.status == CV_NONE) {
+      if (e.dbg & 128) e.n_disj++;
       PROF_T0; make_disjoint(e, s0, s1, symmetric); PROF_ADD(e, 2);
       moved = true;
     } else if (c.status == CV_FUTURE) {

@@ -17,300 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "moog_device.h"
-
-// =====================================================================================
-// record staging: HBM <-> LDS, 16 bytes per lane, coalesced
-// =====================================================================================
-// Hot layout: the records as staged in LDS.  The colour triples (f64) and the opacity / shape-id
-// words (i32) are read by the rasteriser only, so the step / reset kernels leave them in HBM
-// (Env::gcol / gopa / gshape): the staged records are the HBM records with those two ranges,
-// shrunk inward to 16-byte boundaries, cut out.
-struct HotLayout {
-  moog_layout_t L;            // offsets inside the LDS records
-  int32_t f_cut0, f_cut1;     // removed range of the f64 record (doubles, multiples of 2)
-  int32_t i_cut0, i_cut1;     // removed range of the i32 record (ints, multiples of 4)
-};
-
-__host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
-  HotLayout h;
-  h.L = G;
-  const int S = G.S;
-  // A range is cut only when it is 16-byte aligned as a whole (S even): a partially staged
-  // field would be written back over the values the kernels write to HBM directly.
-  const bool f_ok = (G.o_color % 2 == 0) && ((3 * S) % 2 == 0);
-  h.f_cut0 = G.o_color;
-  h.f_cut1 = f_ok ? G.o_color + 3 * S : G.o_color;
-  const int fc = h.f_cut1 - h.f_cut0;
-  // fields behind the colours (moog_layout(): inertia, maxr, action, task, rule, scale, aspect, verts)
-  h.L.o_inertia -= fc; h.L.o_maxr -= fc; h.L.o_action -= fc; h.L.o_task -= fc; h.L.o_rule -= fc;
-  if (G.o_scale >= 0) { h.L.o_scale -= fc; h.L.o_aspect -= fc; }
-  h.L.o_verts -= fc; h.L.f64_per_env -= fc;
-  // opacity, shape ids and the Portal bits are adjacent ([S] each)
-  const bool i_ok = (G.o_opacity % 4 == 0) && ((3 * S) % 4 == 0) && (G.o_shape == G.o_opacity + S) &&
-                    (G.o_tele == G.o_shape + S);
-  h.i_cut0 = G.o_opacity;
-  h.i_cut1 = i_ok ? G.o_opacity + 3 * S : G.o_opacity;
-  const int ic = h.i_cut1 - h.i_cut0;
-  if (G.o_valias >= 0) h.L.o_valias -= ic;
-  if (G.o_fmask >= 0) h.L.o_fmask -= ic;
-  h.L.o_step_count -= ic; h.L.o_reset_next -= ic; h.L.o_fault -= ic; h.L.o_rng -= ic;
-  h.L.i32_per_env -= ic;
-  return h;   // o_color / o_opacity / o_shape keep their values: valid in LDS when nothing was cut
-}
-
-// =====================================================================================
-// record staging: HBM <-> LDS, 16 bytes per lane, coalesced
-// =====================================================================================
-__device__ inline void load_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
-                                   const double* gf, const int32_t* gq) {
-  const double2* src = reinterpret_cast<const double2*>(gf);
-  double2* dst = reinterpret_cast<double2*>(e.f);
-  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
-  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
-    if (i < fa) dst[i] = src[i];
-    else if (i >= fb) dst[i - (fb - fa)] = src[i];
-  }
-  const int4* srci = reinterpret_cast<const int4*>(gq);
-  int4* dsti = reinterpret_cast<int4*>(e.q);
-  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
-  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
-    if (i < ia) dsti[i] = srci[i];
-    else if (i >= ib) dsti[i - (ib - ia)] = srci[i];
-  }
-  for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
-  wsync();
-}
-
-__device__ inline void store_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
-                                    double* gf, int32_t* gq) {
-  wsync();
-  double2* dst = reinterpret_cast<double2*>(gf);
-  const double2* src = reinterpret_cast<const double2*>(e.f);
-  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
-  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
-    if (i < fa) dst[i] = src[i];
-    else if (i >= fb) dst[i] = src[i - (fb - fa)];
-  }
-  int4* dsti = reinterpret_cast<int4*>(gq);
-  const int4* srci = reinterpret_cast<const int4*>(e.q);
-  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
-  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
-    if (i < ia) dsti[i] = srci[i];
-    else if (i >= ib) dsti[i] = srci[i - (ib - ia)];
-  }
-}
-
-struct KArgs {
-  const moog_program_t* P;
-  moog_layout_t L;       // layout of the records in HBM (the ABI's)
-  HotLayout H;           // layout of the records staged in LDS
-  double* f64;
-  int32_t* i32;
-  const void* actions;
-  const double* inj;
-  int32_t inj_n;
-  int32_t n_envs;
-  uint64_t seed;
-  int64_t env_index0;
-  const uint8_t* mask;
-  double* reward;
-  double* discount;
-  int32_t* step_type;
-  int32_t mode;
-  const int16_t* vslot;
-  int32_t dbg;
-  const int32_t* perm;   // launch order (or null)
-  float* cost;           // per-env cycles of this step (or null)
-};
-
-enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_RESET_AUTO = 3 };
-
-extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
-
-__device__ inline void bind_env(Env& e, const KArgs& a, int env) {
-  e.P = as_const_prog(a.P);
-  e.L = a.H.L;
-  const moog_layout_t& H = a.H.L;
-  e.f = reinterpret_cast<double*>(moog_lds);
-  e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)H.f64_per_env * 8);
-  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
-  e.xf = reinterpret_cast<double*>(e.bb + 8 * H.S);       // [S][8] only when S > 64
-  double* after_xf = (H.S > 64) ? e.xf + 8 * H.S : e.xf;
-  e.voff = reinterpret_cast<int32_t*>(after_xf);
-  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
-  e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
-  if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
-  else e.gcol = e.f + H.o_color;
-  if (a.H.i_cut1 > a.H.i_cut0) {
-    e.gopa = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_opacity;
-    e.gshape = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_shape;
-    e.gtele = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_tele;
-  } else {
-    e.gopa = e.q + H.o_opacity;
-    e.gshape = e.q + H.o_shape;
-    e.gtele = e.q + H.o_tele;
-  }
-  e.vslot = a.vslot;
-  e.dbg = a.dbg;
-  e.n_path = 0; e.n_resp = 0;
-#ifdef MOOG_PROFILE
-  for (int k = 0; k < 8; ++k) e.prof[k] = 0;
-#endif
-  e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
-  e.inj_n = a.inj_n;
-  e.seed = a.seed;
-  e.env_index = a.env_index0 + env;
-  e.lane = threadIdx.x;
-}
-
-// reset_next word: 0 = running, 1 = reset on the next call (environment.py:100-101),
-// 2 = was reset earlier in THIS call (the step kernel skips it and clears the mark).
-__global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
-  int env = blockIdx.x;
-  if (env >= a.n_envs) return;
-  int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  bool want;
-  if (a.mode == MODE_RESET_MASK) want = (a.mask == nullptr) || (a.mask[env] != 0);
-  else want = (gq[a.L.o_reset_next] == 1);
-  if (!want) return;
-  Env e;
-  bind_env(e, a, env);
-  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  load_record(e, a.H, a.L, gf, gq);
-  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
-  wsync();
-  env_reset(e);
-  wsync();
-  if (e.lane == 0) {
-    e.q[e.L.o_reset_next] = (a.mode == MODE_RESET_AUTO) ? 2 : 0;
-    if (a.reward) a.reward[env] = __builtin_nan("");
-    if (a.discount) a.discount[env] = __builtin_nan("");
-    if (a.step_type) a.step_type[env] = 0;
-  }
-  store_record(e, a.H, a.L, gf, gq);
-}
-
-// Launch order for the next step: envs in (approximately) descending order of the cycles they
-// took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
-// counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
-// The order inside a bin is arbitrary -- the schedule never changes a result.
-#define SCHED_BINS 1024
-__global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int32_t* perm, int n) {
-  __shared__ int hist[SCHED_BINS];
-  __shared__ float red[16];
-  const int t = threadIdx.x;
-  float m = 0.f;
-  for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((t & 63) == 0) red[t >> 6] = m;
-  hist[t] = 0;
-  __syncthreads();
-  m = red[0];
-  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
-  const float scale = m > 0.f ? (float)(SCHED_BINS - 1) / m : 0.f;
-  // bin 0 = most expensive
-  for (int i = t; i < n; i += 1024) {
-    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
-    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
-    atomicAdd(&hist[b], 1);
-  }
-  __syncthreads();
-  // exclusive prefix sum over the 1024 bins (one bin per thread, Hillis-Steele in LDS)
-  int v = hist[t];
-  __syncthreads();
-  for (int o = 1; o < SCHED_BINS; o <<= 1) {
-    int add = (t >= o) ? hist[t - o] : 0;
-    __syncthreads();
-    hist[t] += add;
-    __syncthreads();
-  }
-  const int start = hist[t] - v;
-  __syncthreads();
-  hist[t] = start;
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
-    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
-    perm[atomicAdd(&hist[b], 1)] = i;
-  }
-}
-
-// DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
-// ChangeLayer, VanishByFilter): that variant carries the reset path's sampler; the plain one
-// is what the benchmark configs run.
-// WPS = waves per SIMD the register allocation is sized for: 4 (128 VGPRs, some scratch) keeps sixteen
-// envs per CU in flight, which is what programs with small state records want; 3 (168 VGPRs, no
-// scratch in the hot loops) is faster once LDS holds fewer than fifteen records per CU anyway.
-template <bool DYN, int WPS>
-__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
-  int env = blockIdx.x;
-  if (env >= a.n_envs) return;
-  if (a.perm) env = a.perm[env];
-  const long long t_sched = a.cost ? clock64() : 0;
-  int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  if (a.mode == MODE_STEP && gq[a.L.o_reset_next] == 2) {  // reset earlier in this call
-    if (threadIdx.x == 0) gq[a.L.o_reset_next] = 0;
-    return;
-  }
-  Env e;
-  bind_env(e, a, env);
-  const long long t_begin = (a.dbg & 128) ? clock64() : 0;
-  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  load_record(e, a.H, a.L, gf, gq);
-  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
-  wsync();
-  bbox_build_all(e);
-  PProg P = as_const_prog(a.P);
-  const int K = uni(P->updates_per_env_step);
-  if (a.mode == MODE_PHYSICS) {
-    for (int k = 0; k < K; ++k) apply_physics(e);
-    store_record(e, a.H, a.L, gf, gq);
-    return;
-  }
-  // environment.py:98-126
-  const int n_rules = uni(P->n_rules);
-  for (int r = 0; r < n_rules; ++r)
-    if (P->rules[r].parent < 0) rule_step<DYN>(e, r);
-  if (uni(P->n_actions) > 1) {   // composite.py:61-62: every sub-space, in keyword order
-    const int na = uni(P->n_actions);
-    const double* act = reinterpret_cast<const double*>(a.actions) + (size_t)2 * na * env;
-    for (int k = 0; k < na; ++k) action_step(e, k, act[2 * k], act[2 * k + 1], (int)act[2 * k]);
-  } else {
-    double ax = 0, ay = 0;
-    int ga = 4;
-    if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
-    else {
-      ax = reinterpret_cast<const double*>(a.actions)[2 * env];
-      ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
-    }
-    action_step(e, 0, ax, ay, ga);
-  }
-  { PROF_T0; for (int k = 0; k < K; ++k) apply_physics(e); PROF_ADD(e, 6); }
-  int sc = e.q[e.L.o_step_count] + 1;
-  wsync();
-  if (e.lane == 0) e.q[e.L.o_step_count] = sc;
-  wsync();
-  int sr = 0;
-  double r;
-  r = task_reward<DYN>(e, sc, &sr);
-  wsync();
-  if (e.lane == 0) {
-    if (sr) e.q[e.L.o_reset_next] = 1;
-    if (a.reward) a.reward[env] = r;
-    if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
-    if (a.step_type) a.step_type[env] = sr ? 2 : 1;
-  }
-  store_record(e, a.H, a.L, gf, gq);
-  if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
-  if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
-    a.discount[env] = (double)(clock64() - t_begin);
-    if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp);
-#ifdef MOOG_PROFILE
-    if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 15) - 1];
-#endif
-  }
-}
+#include "moog_kernels.h"
 
 #include "moog_raster.h"
 
@@ -355,6 +62,7 @@ struct moog_engine {
   bool sched_pending = false;
   float* cost = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
+  int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
   int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
   // static prefix of the rasteriser (moog_raster.h): a scratch env record that holds the reference
   // sprites (what a reset makes of the constant generation ops) and their picture
@@ -371,6 +79,7 @@ static void free_engine(moog_engine* e) {
   if (e->s_f64) hipFree(e->s_f64);
   if (e->s_i32) hipFree(e->s_i32);
   if (e->s_bg) hipFree(e->s_bg);
+  if (e->fault_flag) hipHostFree(e->fault_flag);
   delete e;
 }
 
@@ -441,7 +150,8 @@ static int build_static_prefix(moog_engine* e) {
   e->view.f64 = e->s_f64; e->view.i32 = e->s_i32; e->n_envs = 1;
   KArgs a = make_args(e, nullptr, nullptr, nullptr, MODE_RESET_MASK, nullptr);
   a.dbg = 0;
-  hipLaunchKernelGGL(moog_reset_kernel, dim3(1), dim3(64), e->step_lds, 0, a);
+  a.fault_flag = nullptr;   // (faults of the scratch env are nobody's business)
+  moog_launch_reset(1, e->step_lds, 0, a);
   RArgs r = raster_args(e, e->s_bg);
   r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
   moog_raster_launch(r, e->raster_lds, 0);
@@ -540,12 +250,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
   {
-    const void* variants[4] = {reinterpret_cast<const void*>(moog_step_kernel<false, 3>),
-                               reinterpret_cast<const void*>(moog_step_kernel<false, 4>),
-                               reinterpret_cast<const void*>(moog_step_kernel<true, 3>),
-                               reinterpret_cast<const void*>(moog_step_kernel<true, 4>)};
-    for (int v = 0; v < 4 && err == hipSuccess; ++v)
-      err = hipFuncSetAttribute(variants[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+    int (*const configure[4])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
+                                         moog_configure_step_t4};
+    for (int v = 0; v < 4 && err == hipSuccess; ++v) err = (hipError_t)configure[v](e->step_lds);
     e->step_wps = (160 * 1024 / (e->step_lds ? e->step_lds : 1)) <= 14 ? 3 : 4;
     { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) e->step_wps = atoi(w); }   // experiments
   }
@@ -567,8 +274,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_reset_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->step_lds);
+    err = (hipError_t)moog_configure_reset(e->step_lds);
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
   if (err != hipSuccess) {
@@ -577,6 +283,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   }
   { const char* ds = getenv("MOOG_STEP_DEBUG"); e->step_dbg = ds ? atoi(ds) : 0; }
   { const char* ds = getenv("MOOG_RASTER_STOP"); e->raster_stop = ds ? atoi(ds) : 0; }
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->fault_flag), sizeof(int32_t), hipHostMallocMapped) != hipSuccess) {
+    free_engine(e);
+    return fail(MOOG_E_NOMEM, "hipHostMalloc(fault flag) failed");
+  }
+  *e->fault_flag = 0;
   int rc2 = build_static_prefix(e);
   if (rc2) { free_engine(e); return rc2; }
   *out = e;
@@ -647,18 +358,14 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.perm = (mode == MODE_STEP) ? e->perm : nullptr;
   a.cost = (mode == MODE_STEP) ? e->cost : nullptr;
   a.dbg = e->step_dbg;
+  a.fault_flag = e->fault_flag;
   return a;
 }
 
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
-  const dim3 g(e->n_envs), b(64);
-  if (e->dynamic_rules) {
-    if (e->step_wps == 3) hipLaunchKernelGGL((moog_step_kernel<true, 3>), g, b, e->step_lds, s, a);
-    else hipLaunchKernelGGL((moog_step_kernel<true, 4>), g, b, e->step_lds, s, a);
-  } else {
-    if (e->step_wps == 3) hipLaunchKernelGGL((moog_step_kernel<false, 3>), g, b, e->step_lds, s, a);
-    else hipLaunchKernelGGL((moog_step_kernel<false, 4>), g, b, e->step_lds, s, a);
-  }
+  static const moog_step_launch_fn launch[4] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
+                                                moog_launch_step_t4};
+  launch[(e->dynamic_rules ? 2 : 0) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
 }
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
@@ -703,7 +410,7 @@ int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev, const moog_
   KArgs a = make_args(e, nullptr, inject, out, MODE_RESET_MASK, env_mask_dev);
   {
     Bracket br(e, MOOG_K_RESET, s);
-    hipLaunchKernelGGL(moog_reset_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
+    moog_launch_reset(e->n_envs, e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
   if (out && out->image) return launch_raster(e, out->image, s);
@@ -716,14 +423,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   if (rc) return rc;
   if (!actions_dev) return fail(MOOG_E_INVALID, "null actions");
   hipStream_t s = (hipStream_t)hip_stream;
-  KArgs a = make_args(e, actions_dev, inject, out, MODE_RESET_AUTO, nullptr);
-  {
-    Bracket br(e, MOOG_K_RESET, s);
-    hipLaunchKernelGGL(moog_reset_kernel, dim3(e->n_envs), dim3(64), e->step_lds, s, a);
-  }
-  a.mode = MODE_STEP;
-  a.perm = e->perm;
-  a.cost = e->cost;
+  // (envs whose episode ended in the previous call are reset inside the step kernel, environment.py:100-101)
+  KArgs a = make_args(e, actions_dev, inject, out, MODE_STEP, nullptr);
   if (e->sched_pending) {   // the order computed from the previous step's costs
     HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
     e->sched_pending = false;
@@ -736,7 +437,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   if (e->perm && e->cost) {
     HIPCHK(hipEventRecord(e->ev_step_done, s));
     HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
-    hipLaunchKernelGGL(moog_sched_kernel, dim3(1), dim3(1024), 0, e->sched_stream, e->cost, e->perm, e->n_envs);
+    moog_launch_sched(e->sched_stream, e->cost, e->perm, e->n_envs, e->view.i32 + e->L.o_reset_next, e->L.i32_per_env);
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
   }
@@ -786,6 +487,13 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
     HIPCHK(hipMemcpyAsync(image_dev, e->s_bg, (size_t)e->prog.render.width * e->prog.render.height * 3,
                           hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   }
+  return MOOG_OK;
+}
+
+int moog_engine_poll_faults(moog_engine_t* e, int32_t clear, int32_t* bits) {
+  if (!e || !bits) return fail(MOOG_E_INVALID, "null argument");
+  *bits = __atomic_load_n(e->fault_flag, __ATOMIC_RELAXED);   // no stream synchronisation: what has arrived so far
+  if (clear && *bits) __atomic_and_fetch(e->fault_flag, ~*bits, __ATOMIC_RELAXED);
   return MOOG_OK;
 }
 

@@ -1,0 +1,333 @@
+// moog_kernels.h -- the step / reset kernels of the engine (templates and launch arguments), shared by
+// the translation units that instantiate them (moog_step_inst.hip, four times; moog_reset.hip) and by
+// the host side (moog_engine.hip), which only sees the launch functions declared at the bottom.
+#pragma once
+#include "moog_device.h"
+
+// =====================================================================================
+// record staging: HBM <-> LDS, 16 bytes per lane, coalesced
+// =====================================================================================
+// Hot layout: the records as staged in LDS.  The colour triples (f64) and the opacity / shape-id
+// words (i32) are read by the rasteriser only, so the step / reset kernels leave them in HBM
+// (Env::gcol / gopa / gshape): the staged records are the HBM records with those two ranges,
+// shrunk inward to 16-byte boundaries, cut out.
+struct HotLayout {
+  moog_layout_t L;            // offsets inside the LDS records
+  int32_t f_cut0, f_cut1;     // removed range of the f64 record (doubles, multiples of 2)
+  int32_t i_cut0, i_cut1;     // removed range of the i32 record (ints, multiples of 4)
+};
+
+__host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
+  HotLayout h;
+  h.L = G;
+  const int S = G.S;
+  // A range is cut only when it is 16-byte aligned as a whole (S even): a partially staged
+  // field would be written back over the values the kernels write to HBM directly.
+  const bool f_ok = (G.o_color % 2 == 0) && ((3 * S) % 2 == 0);
+  h.f_cut0 = G.o_color;
+  h.f_cut1 = f_ok ? G.o_color + 3 * S : G.o_color;
+  const int fc = h.f_cut1 - h.f_cut0;
+  // fields behind the colours (moog_layout(): inertia, maxr, action, task, rule, scale, aspect, verts)
+  h.L.o_inertia -= fc; h.L.o_maxr -= fc; h.L.o_action -= fc; h.L.o_task -= fc; h.L.o_rule -= fc;
+  if (G.o_scale >= 0) { h.L.o_scale -= fc; h.L.o_aspect -= fc; }
+  h.L.o_verts -= fc; h.L.f64_per_env -= fc;
+  // opacity, shape ids and the Portal bits are adjacent ([S] each)
+  const bool i_ok = (G.o_opacity % 4 == 0) && ((3 * S) % 4 == 0) && (G.o_shape == G.o_opacity + S) &&
+                    (G.o_tele == G.o_shape + S);
+  h.i_cut0 = G.o_opacity;
+  h.i_cut1 = i_ok ? G.o_opacity + 3 * S : G.o_opacity;
+  const int ic = h.i_cut1 - h.i_cut0;
+  if (G.o_valias >= 0) h.L.o_valias -= ic;
+  if (G.o_fmask >= 0) h.L.o_fmask -= ic;
+  h.L.o_step_count -= ic; h.L.o_reset_next -= ic; h.L.o_fault -= ic; h.L.o_rng -= ic;
+  h.L.i32_per_env -= ic;
+  return h;   // o_color / o_opacity / o_shape keep their values: valid in LDS when nothing was cut
+}
+
+// =====================================================================================
+// record staging: HBM <-> LDS, 16 bytes per lane, coalesced
+// =====================================================================================
+__device__ inline void load_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
+                                   const double* gf, const int32_t* gq) {
+  const double2* src = reinterpret_cast<const double2*>(gf);
+  double2* dst = reinterpret_cast<double2*>(e.f);
+  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
+  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
+    if (i < fa) dst[i] = src[i];
+    else if (i >= fb) dst[i - (fb - fa)] = src[i];
+  }
+  const int4* srci = reinterpret_cast<const int4*>(gq);
+  int4* dsti = reinterpret_cast<int4*>(e.q);
+  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
+  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
+    if (i < ia) dsti[i] = srci[i];
+    else if (i >= ib) dsti[i - (ib - ia)] = srci[i];
+  }
+  for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
+  wsync();
+}
+
+__device__ inline void store_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
+                                    double* gf, int32_t* gq, int32_t* fault_flag = nullptr) {
+  wsync();
+  if (fault_flag && e.lane == 0) {   // rare: tell the host without waiting for it to look at every record
+    const int32_t fw = e.q[e.L.o_fault];
+    if (fw) __hip_atomic_fetch_or(fault_flag, fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  double2* dst = reinterpret_cast<double2*>(gf);
+  const double2* src = reinterpret_cast<const double2*>(e.f);
+  const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
+  for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
+    if (i < fa) dst[i] = src[i];
+    else if (i >= fb) dst[i] = src[i - (fb - fa)];
+  }
+  int4* dsti = reinterpret_cast<int4*>(gq);
+  const int4* srci = reinterpret_cast<const int4*>(e.q);
+  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
+  for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
+    if (i < ia) dsti[i] = srci[i];
+    else if (i >= ib) dsti[i] = srci[i - (ib - ia)];
+  }
+}
+
+struct KArgs {
+  const moog_program_t* P;
+  moog_layout_t L;       // layout of the records in HBM (the ABI's)
+  HotLayout H;           // layout of the records staged in LDS
+  double* f64;
+  int32_t* i32;
+  const void* actions;
+  const double* inj;
+  int32_t inj_n;
+  int32_t n_envs;
+  uint64_t seed;
+  int64_t env_index0;
+  const uint8_t* mask;
+  double* reward;
+  double* discount;
+  int32_t* step_type;
+  int32_t mode;
+  const int16_t* vslot;
+  int32_t dbg;
+  const int32_t* perm;   // launch order (or null)
+  float* cost;           // per-env cycles of this step (or null)
+  int32_t* fault_flag;   // host-visible word: OR of every fault bit raised by any env (deferred fault surfacing)
+};
+
+enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
+
+extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
+
+__device__ inline void bind_env(Env& e, const KArgs& a, int env) {
+  e.P = as_const_prog(a.P);
+  e.L = a.H.L;
+  const moog_layout_t& H = a.H.L;
+  e.f = reinterpret_cast<double*>(moog_lds);
+  e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)H.f64_per_env * 8);
+  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
+  e.xf = reinterpret_cast<double*>(e.bb + 8 * H.S);       // [S][8] only when S > 64
+  double* after_xf = (H.S > 64) ? e.xf + 8 * H.S : e.xf;
+  e.voff = reinterpret_cast<int32_t*>(after_xf);
+  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
+  e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
+  if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
+  else e.gcol = e.f + H.o_color;
+  if (a.H.i_cut1 > a.H.i_cut0) {
+    e.gopa = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_opacity;
+    e.gshape = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_shape;
+    e.gtele = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_tele;
+  } else {
+    e.gopa = e.q + H.o_opacity;
+    e.gshape = e.q + H.o_shape;
+    e.gtele = e.q + H.o_tele;
+  }
+  e.vslot = a.vslot;
+  e.dbg = a.dbg;
+  e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
+#ifdef MOOG_PROFILE
+  for (int k = 0; k < 8; ++k) e.prof[k] = 0;
+#endif
+  e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
+  e.inj_n = a.inj_n;
+  e.seed = a.seed;
+  e.env_index = a.env_index0 + env;
+  e.lane = threadIdx.x;
+}
+
+// reset_next word: 0 = running, 1 = reset on the next call (environment.py:100-101): the step kernel
+// resets such an env instead of stepping it (its action is ignored, the timestep is FIRST).
+#ifdef MOOG_DEFINE_RESET_KERNELS
+__global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
+  int env = blockIdx.x;
+  if (env >= a.n_envs) return;
+  int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
+  if (a.mask != nullptr && a.mask[env] == 0) return;
+  Env e;
+  bind_env(e, a, env);
+  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
+  load_record(e, a.H, a.L, gf, gq);
+  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
+  wsync();
+  env_reset(e);
+  wsync();
+  if (e.lane == 0) {
+    e.q[e.L.o_reset_next] = 0;
+    if (a.reward) a.reward[env] = __builtin_nan("");
+    if (a.discount) a.discount[env] = __builtin_nan("");
+    if (a.step_type) a.step_type[env] = 0;
+  }
+  store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+}
+
+// Launch order for the next step: envs in (approximately) descending order of the cycles they
+// took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
+// counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
+// The order inside a bin is arbitrary -- the schedule never changes a result.
+#define SCHED_BINS 1024
+__global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int32_t* perm, int n,
+                                                           const int32_t* reset_next, int stride) {
+  __shared__ int hist[SCHED_BINS];
+  __shared__ float red[16];
+  const int t = threadIdx.x;
+  float m = 0.f;
+  for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((t & 63) == 0) red[t >> 6] = m;
+  hist[t] = 0;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  const float scale = m > 0.f ? (float)(SCHED_BINS - 1) / m : 0.f;
+  // bin 0 = most expensive
+  // (an env whose episode just ended is reset inside the next step kernel: the sampler's rejection loop is
+  //  as long as the heaviest step, so it starts first)
+  for (int i = t; i < n; i += 1024) {
+    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
+    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
+    if (reset_next[(size_t)i * stride] == 1) b = 0;
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the 1024 bins (one bin per thread, Hillis-Steele in LDS)
+  int v = hist[t];
+  __syncthreads();
+  for (int o = 1; o < SCHED_BINS; o <<= 1) {
+    int add = (t >= o) ? hist[t - o] : 0;
+    __syncthreads();
+    hist[t] += add;
+    __syncthreads();
+  }
+  const int start = hist[t] - v;
+  __syncthreads();
+  hist[t] = start;
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) {
+    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
+    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
+    if (reset_next[(size_t)i * stride] == 1) b = 0;
+    perm[atomicAdd(&hist[b], 1)] = i;
+  }
+}
+
+#endif  // MOOG_DEFINE_RESET_KERNELS
+
+// DYN = the program has rules that create / move / filter sprites at run time (CreateSprites,
+// ChangeLayer, VanishByFilter): that variant carries the reset path's sampler; the plain one
+// is what the benchmark configs run.
+// WPS = waves per SIMD the register allocation is sized for: 4 (128 VGPRs, some scratch) keeps sixteen
+// envs per CU in flight, which is what programs with small state records want; 3 (168 VGPRs, no
+// scratch in the hot loops) is faster once LDS holds fewer than fifteen records per CU anyway.
+template <bool DYN, int WPS>
+__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
+  int env = blockIdx.x;
+  if (env >= a.n_envs) return;
+  if (a.perm) env = a.perm[env];
+  const long long t_sched = a.cost ? clock64() : 0;
+  int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
+  Env e;
+  bind_env(e, a, env);
+  const long long t_begin = (a.dbg & 128) ? clock64() : 0;
+  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
+  load_record(e, a.H, a.L, gf, gq);
+  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
+  wsync();
+  if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
+    env_reset(e);
+    wsync();
+    if (e.lane == 0) {
+      e.q[e.L.o_reset_next] = 0;
+      if (a.reward) a.reward[env] = __builtin_nan("");
+      if (a.discount) a.discount[env] = __builtin_nan("");
+      if (a.step_type) a.step_type[env] = 0;
+    }
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+    if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
+    return;
+  }
+  bbox_build_all(e);
+  PProg P = as_const_prog(a.P);
+  const int K = uni(P->updates_per_env_step);
+  if (a.mode == MODE_PHYSICS) {
+    for (int k = 0; k < K; ++k) apply_physics(e);
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+    return;
+  }
+  // environment.py:98-126
+  const int n_rules = uni(P->n_rules);
+  for (int r = 0; r < n_rules; ++r)
+    if (P->rules[r].parent < 0) rule_step<DYN>(e, r);
+  if (uni(P->n_actions) > 1) {   // composite.py:61-62: every sub-space, in keyword order
+    const int na = uni(P->n_actions);
+    const double* act = reinterpret_cast<const double*>(a.actions) + (size_t)2 * na * env;
+    for (int k = 0; k < na; ++k) action_step(e, k, act[2 * k], act[2 * k + 1], (int)act[2 * k]);
+  } else {
+    double ax = 0, ay = 0;
+    int ga = 4;
+    if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
+    else {
+      ax = reinterpret_cast<const double*>(a.actions)[2 * env];
+      ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
+    }
+    action_step(e, 0, ax, ay, ga);
+  }
+  { PROF_T0; for (int k = 0; k < K; ++k) apply_physics(e); PROF_ADD(e, 6); }
+  int sc = e.q[e.L.o_step_count] + 1;
+  wsync();
+  if (e.lane == 0) e.q[e.L.o_step_count] = sc;
+  wsync();
+  int sr = 0;
+  double r;
+  r = task_reward<DYN>(e, sc, &sr);
+  wsync();
+  if (e.lane == 0) {
+    if (sr) e.q[e.L.o_reset_next] = 1;
+    if (a.reward) a.reward[env] = r;
+    if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
+    if (a.step_type) a.step_type[env] = sr ? 2 : 1;
+  }
+  store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+  if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
+  if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
+    a.discount[env] = (double)(clock64() - t_begin);
+    if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp) + 1e10 * (double)e.n_disj;
+#ifdef MOOG_PROFILE
+    if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 15) - 1];
+#endif
+  }
+}
+
+
+// ---- launch functions (one translation unit each, so that they compile in parallel) ------------------
+// variant = (dynamic rules ? 2 : 0) + (waves per SIMD == 4 ? 1 : 0)
+typedef void (*moog_step_launch_fn)(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_f3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_f4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_t3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_t4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+int moog_configure_step_f3(size_t lds);
+int moog_configure_step_f4(size_t lds);
+int moog_configure_step_t3(size_t lds);
+int moog_configure_step_t4(size_t lds);
+void moog_launch_reset(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+int moog_configure_reset(size_t lds);
+void moog_launch_sched(hipStream_t s, const float* cost, int32_t* perm, int n, const int32_t* reset_next, int stride);

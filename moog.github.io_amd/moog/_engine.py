@@ -16,7 +16,7 @@ SYMBOLS = (
     'moog_engine_destroy', 'moog_engine_layout', 'moog_engine_load_state', 'moog_engine_reset',
     'moog_engine_step', 'moog_engine_physics_only', 'moog_engine_render',
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
-    'moog_engine_set_debug', 'moog_engine_static_prefix',
+    'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
 )
 
 _LIB = None
@@ -61,6 +61,7 @@ def load_library(path=None):
     lib.moog_engine_set_timing.argtypes = [vp, i32]
     lib.moog_engine_set_debug.argtypes = [vp, i32, i32]
     lib.moog_engine_static_prefix.argtypes = [vp, ctypes.POINTER(i32), vp, vp]
+    lib.moog_engine_poll_faults.argtypes = [vp, i32, ctypes.POINTER(i32)]
     lib.moog_engine_kernel_time.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(i64)]
     for name in SYMBOLS:

