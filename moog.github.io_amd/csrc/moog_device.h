@@ -71,7 +71,7 @@ struct Env {
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
   int n_path, n_resp, n_disj;   // profiling counters (path tests, contact searches, make_disjoint calls)
 #ifdef MOOG_PROFILE
-  long long prof[8];       // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
+  long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
 #endif
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
 };
@@ -256,6 +256,16 @@ __device__ __forceinline__ bool seg_outside_dop(double x1, double y1, double x2,
          fmin(m1, m2) > (double)d[7] + BB_MARGIN || fmax(m1, m2) < (double)d[3] - BB_MARGIN;
 }
 
+// the same with the 8-DOP already in registers (lo = x, y, x+y, x-y minima; hi = the maxima)
+__device__ __forceinline__ bool seg_outside_dop_r(double x1, double y1, double x2, double y2, const float4& lo,
+                                                  const float4& hi) {
+  double p1 = x1 + y1, p2 = x2 + y2, m1 = x1 - y1, m2 = x2 - y2;
+  return fmin(x1, x2) > (double)hi.x + BB_MARGIN || fmax(x1, x2) < (double)lo.x - BB_MARGIN ||
+         fmin(y1, y2) > (double)hi.y + BB_MARGIN || fmax(y1, y2) < (double)lo.y - BB_MARGIN ||
+         fmin(p1, p2) > (double)hi.z + BB_MARGIN || fmax(p1, p2) < (double)lo.z - BB_MARGIN ||
+         fmin(m1, m2) > (double)hi.w + BB_MARGIN || fmax(m1, m2) < (double)lo.w - BB_MARGIN;
+}
+
 __device__ inline bool paths_intersect_filled(const Env& e, const double* va, int na,
                                               const double* vb, int nb, const float* da,
                                               const float* db) {
@@ -404,53 +414,68 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
 // 16 vertices, more than 16 surviving edge pairs, a containment test), ends the prefix and takes the
 // ordinary path (without repeating the test when its edges were seen to cross).  The state cannot
 // change in between: only a hit moves sprites.
+// k-th set bit (k = 0 first) of a 16-bit mask, k < popcount: a binary descent on popcounts, in registers
+__device__ __forceinline__ int nth_set_bit16(unsigned m, int k) {
+  int pos = 0;
+  int c = __popc(m & 0xffu);
+  if (k >= c) { k -= c; pos = 8; m >>= 8; }
+  c = __popc(m & 0xfu);
+  if (k >= c) { k -= c; pos += 4; m >>= 4; }
+  c = __popc(m & 0x3u);
+  if (k >= c) { k -= c; pos += 2; m >>= 2; }
+  if (k >= (int)(m & 1u)) pos += 1;
+  return pos;
+}
+
 __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   const int grp = e.lane >> 4, gl = e.lane & 15;
   const bool active = grp < n;
   const int pr = active ? (int)e.cand[c + grp] : 0;
   const int s0 = pr >> 8, t = pr & 255;
-  const int na = active ? NV(s0) : 0, nb = active ? NV(t) : 0;
+  // (all the loads that depend only on the pair go out together: this routine is a chain of LDS round
+  //  trips on the critical path of a contact-heavy env)
+  const int na_ = NV(s0), nb_ = NV(t);
   const double* va = VERT(s0);
   const double* vb = VERT(t);
   const float* da = &BB(s0, 0);
   const float* db = &BB(t, 0);
+  const float4 al = *reinterpret_cast<const float4*>(da), ah = *reinterpret_cast<const float4*>(da + 4);
+  const float4 bl = *reinterpret_cast<const float4*>(db), bh = *reinterpret_cast<const float4*>(db + 4);
+  const int na = active ? na_ : 0, nb = active ? nb_ : 0;
+  // this lane's own edge of either polygon (vertex gl and the next one)
+  const int ga1 = (gl < na) ? gl : 0, ga2 = (gl + 1 >= na) ? 0 : gl + 1;
+  const int gb1 = (gl < nb) ? gl : 0, gb2 = (gl + 1 >= nb) ? 0 : gl + 1;
+  const double2 a1 = *reinterpret_cast<const double2*>(va + 2 * ga1), a2 = *reinterpret_cast<const double2*>(va + 2 * ga2);
+  const double2 b1 = *reinterpret_cast<const double2*>(vb + 2 * gb1), b2 = *reinterpret_cast<const double2*>(vb + 2 * gb2);
   bool slow = na > 16 || nb > 16;
   // the "all vertices of one inside the other" tests would run (box within box): not here
   slow = slow || (na + 1 >= 3 && nb > 0 &&
-                  !(db[0] < da[0] - BB_MARGIN || db[1] < da[1] - BB_MARGIN || db[4] > da[4] + BB_MARGIN ||
-                    db[5] > da[5] + BB_MARGIN));
+                  !(bl.x < al.x - BB_MARGIN || bl.y < al.y - BB_MARGIN || bh.x > ah.x + BB_MARGIN ||
+                    bh.y > ah.y + BB_MARGIN));
   slow = slow || (nb + 1 >= 3 && na > 0 &&
-                  !(da[0] < db[0] - BB_MARGIN || da[1] < db[1] - BB_MARGIN || da[4] > db[4] + BB_MARGIN ||
-                    da[5] > db[5] + BB_MARGIN));
+                  !(al.x < bl.x - BB_MARGIN || al.y < bl.y - BB_MARGIN || ah.x > bh.x + BB_MARGIN ||
+                    ah.y > bh.y + BB_MARGIN));
   slow = slow && active;
   if (__ballot(slow) & 0xffffull) return 0;   // the first candidate takes the ordinary path anyway
   bool ka = false, kb = false;
   if (active && !slow) {
-    if (gl < na) {
-      int i2 = (gl + 1 == na) ? 0 : gl + 1;
-      ka = !seg_outside_dop(va[2 * gl], va[2 * gl + 1], va[2 * i2], va[2 * i2 + 1], db);
-    }
-    if (gl < nb) {
-      int j2 = (gl + 1 == nb) ? 0 : gl + 1;
-      kb = !seg_outside_dop(vb[2 * gl], vb[2 * gl + 1], vb[2 * j2], vb[2 * j2 + 1], da);
-    }
+    if (gl < na) ka = !seg_outside_dop_r(a1.x, a1.y, a2.x, a2.y, bl, bh);
+    if (gl < nb) kb = !seg_outside_dop_r(b1.x, b1.y, b2.x, b2.y, al, ah);
   }
   const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
   const unsigned ga = (unsigned)(ma >> (16 * grp)) & 0xffffu, gb = (unsigned)(mb >> (16 * grp)) & 0xffffu;
   const int ca = __popc(ga), cb = __popc(gb), total = ca * cb;
   slow = slow || total > 16;
-  const unsigned below = (1u << gl) - 1u;
-  if (ka) e.lst[16 * grp + __popc(ga & below)] = (uint8_t)gl;
-  if (kb) e.lst[64 + 16 * grp + __popc(gb & below)] = (uint8_t)gl;
-  wsync();
   bool hit = false;
   if (active && !slow && gl < total) {
     // gl / cb for gl < 16, 1 <= cb <= 16 (the quotient of a half-integer is never near an integer)
     const int ia = (int)(((float)gl + 0.5f) / (float)cb), ib = gl - ia * cb;
-    const int i = e.lst[16 * grp + ia], j = e.lst[64 + 16 * grp + ib];
+    const int i = nth_set_bit16(ga, ia), j = nth_set_bit16(gb, ib);   // the surviving edges, in order
     const int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
-    double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
-    double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
+    const double2 p11 = *reinterpret_cast<const double2*>(va + 2 * i), p12 = *reinterpret_cast<const double2*>(va + 2 * i2);
+    const double2 p21 = *reinterpret_cast<const double2*>(vb + 2 * j), p22 = *reinterpret_cast<const double2*>(vb + 2 * j2);
+    const double x11 = p11.x, y11 = p11.y, x12 = p12.x, y12 = p12.y;
+    const double x21 = p21.x, y21 = p21.y, x22 = p22.x, y22 = p22.y;
     bool apart = fmin(x11, x12) > fmax(x21, x22) + BB_MARGIN || fmin(x21, x22) > fmax(x11, x12) + BB_MARGIN ||
                  fmin(y11, y12) > fmax(y21, y22) + BB_MARGIN || fmin(y21, y22) > fmax(y11, y12) + BB_MARGIN;
     if (!apart) {
@@ -460,7 +485,6 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
     }
   }
   const unsigned long long stop = __ballot(hit || slow), slows = __ballot(slow);
-  wsync();
   int r = 0;
   while (r < n && ((stop >> (16 * r)) & 0xffffull) == 0ull) ++r;
   // bit 8: the candidate that ended the prefix is a proven overlap (its edges cross)
@@ -1468,13 +1492,31 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
     wsync();
     PROF_T0;
     while (scanned < total && count <= CAND_CAP - 64) {
-      int idx = scanned + e.lane;
-      bool cand = false;
-      int s0 = 0, t = 0;
-      if (idx < total) {
-        int i = (total <= 4096 && nB <= 128) ? div_small(idx, nB) : idx / nB;
-        s0 = a0 + i; t = b0 + (idx - i * nB);
-        if (s0 != t && ALIVE(s0) && ALIVE(t)) cand = !bbox_apart(e, s0, t) && !circles_apart(e, s0, t);
+      // Every load of the round goes out before anything is tested (a lane's pair is known from its index
+      // alone), so a round costs one LDS round trip instead of a chain of dependent ones: this loop is
+      // the largest single piece of an env's critical path.
+      const int idx = scanned + e.lane;
+      const bool in = idx < total;
+      const int idc = in ? idx : 0;
+      const int i = (total <= 4096 && nB <= 128) ? div_small(idc, nB) : idc / nB;
+      const int s0 = a0 + i, t = b0 + (idc - i * nB);
+      const int fl0 = FLAGS(s0), fl1 = FLAGS(t);
+      const float4 al = *reinterpret_cast<const float4*>(&BB(s0, 0)), ah = *reinterpret_cast<const float4*>(&BB(s0, 4));
+      const float4 bl = *reinterpret_cast<const float4*>(&BB(t, 0)), bh = *reinterpret_cast<const float4*>(&BB(t, 4));
+      const double2 p0 = *reinterpret_cast<const double2*>(&PX(s0)), p1 = *reinterpret_cast<const double2*>(&PX(t));
+      const double r0 = MAXR(s0), r1 = MAXR(t);
+      const float M = (float)BB_MARGIN;
+      const bool apart = al.x > bh.x + M || bl.x > ah.x + M || al.y > bh.y + M || bl.y > ah.y + M ||
+                         al.z > bh.z + M || bl.z > ah.z + M || al.w > bh.w + M || bl.w > ah.w + M;
+      bool cand = in && s0 != t && (fl0 & fl1 & MOOG_F_ALIVE) && !apart;
+      if (cand) {   // circles_apart (sprite.py:464-466), on the values already loaded
+        const double dx = p0.x - p1.x, dy = p0.y - p1.y;
+        const double d2 = dx * dx + dy * dy, r = r0 + r1, r2 = r * r;
+        bool ca;
+        if (d2 > r2 * (1.0 + 1e-9) && r >= 0) ca = true;
+        else if (d2 < r2 * (1.0 - 1e-9)) ca = false;
+        else ca = sqrt(d2) > r;
+        cand = !ca;
       }
       uint64_t m = __ballot(cand);
       if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (uint16_t)((s0 << 8) | t);
@@ -1492,7 +1534,7 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
         PROF_T0;
         const int n = count - c < 4 ? count - c : 4;
         const int rr = uni(narrow_reject_prefix(e, c, n)), r = rr & 255;
-        PROF_ADD(e, 0);
+        PROF_ADD(e, 8);
         known_hit = (rr & 256) != 0;
         c += r;
         if (r == n) { --c; continue; }   // all of them: on to the next batch

@@ -145,7 +145,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
 #ifdef MOOG_PROFILE
-  for (int k = 0; k < 8; ++k) e.prof[k] = 0;
+  for (int k = 0; k < 16; ++k) e.prof[k] = 0;
 #endif
   e.inj = a.inj ? a.inj + (size_t)env * a.inj_n : nullptr;
   e.inj_n = a.inj_n;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   bind_env(e, a, env);
   const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  load_record(e, a.H, a.L, gf, gq);
+  { PROF_T0; load_record(e, a.H, a.L, gf, gq); PROF_ADD(e, 9); }
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
   if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
     return;
   }
-  bbox_build_all(e);
+  { PROF_T0; bbox_build_all(e); PROF_ADD(e, 9); }
   PProg P = as_const_prog(a.P);
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     return;
   }
+  {
+  PROF_T0;
   // environment.py:98-126
   const int n_rules = uni(P->n_rules);
   for (int r = 0; r < n_rules; ++r)
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     }
     action_step(e, 0, ax, ay, ga);
   }
+  PROF_ADD(e, 10);
+  }
   { PROF_T0; for (int k = 0; k < K; ++k) apply_physics(e); PROF_ADD(e, 6); }
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   wsync();
   int sr = 0;
   double r;
-  r = task_reward<DYN>(e, sc, &sr);
+  { PROF_T0; r = task_reward<DYN>(e, sc, &sr); PROF_ADD(e, 11); }
   wsync();
   if (e.lane == 0) {
     if (sr) e.q[e.L.o_reset_next] = 1;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     a.discount[env] = (double)(clock64() - t_begin);
     if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp) + 1e10 * (double)e.n_disj;
 #ifdef MOOG_PROFILE
-    if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 15) - 1];
+    if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 31) - 1];
 #endif
   }
 }
