@@ -197,6 +197,34 @@ __device__ inline double next_uniform(Env& e) {
   return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) / 9007199254740992.0;
 }
 
+// The next n <= 64 draws at once: lane i returns draw i (the same values, in the same order, that n calls
+// of next_uniform would give); the counter advances by n.  One Philox latency instead of n.
+__device__ inline double next_uniforms_lanes(Env& e, int n) {
+  int32_t* r = &e.q[e.L.o_rng];
+  if (e.inj) {
+    const int cur = r[2];
+    const int have = e.inj_n - cur < n ? (e.inj_n - cur < 0 ? 0 : e.inj_n - cur) : n;
+    const double out = (e.lane < have) ? e.inj[cur + e.lane] : 0.0;
+    wsync();
+    if (e.lane == 0) {
+      r[2] = cur + have;
+      if (have < n) e.q[e.L.o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+    }
+    wsync();
+    return out;
+  }
+  const uint64_t base = (uint32_t)r[0] | ((uint64_t)(uint32_t)r[1] << 32);
+  const uint64_t ctr = base + (uint64_t)e.lane;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)e.env_index,
+                   (uint32_t)((uint64_t)e.env_index >> 32)};
+  philox4x32(c, (uint32_t)e.seed, (uint32_t)(e.seed >> 32));
+  const uint64_t next = base + (uint64_t)n;
+  wsync();
+  if (e.lane == 0) { r[0] = (int32_t)(uint32_t)next; r[1] = (int32_t)(uint32_t)(next >> 32); }
+  wsync();
+  return ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) / 9007199254740992.0;
+}
+
 // ---- matplotlib _path restatements (see oracle for the citations) ------------
 __device__ __forceinline__ bool mpl_isclose(double a, double b) {
   return fabs(a - b) <= fmax(1e-10 * fmax(fabs(a), fabs(b)), 1e-13);
@@ -404,6 +432,24 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
   const bool hit = paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
   PROF_ADD(e, 0);
   return hit;
+}
+
+// Does sprite s overlap any live sprite of slots [t0, t1)?  Lanes = the other sprites for the bounding
+// circle / box rejects (the rejection sampler's inner loop: dozens of earlier sprites per try), then the
+// few survivors take the path test one at a time.  Same predicate as a loop over overlaps().
+__device__ inline bool overlaps_any(const Env& e, int s, int t0, int t1) {
+  for (int base = t0; base < t1; base += 64) {
+    const int t = base + e.lane;
+    bool cand = false;
+    if (t < t1 && t != s && ALIVE(t)) cand = !circles_apart(e, s, t) && !bbox_apart(e, s, t);
+    unsigned long long m = __ballot(cand);
+    while (m) {
+      const int tt = base + __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      if (overlaps(e, s, tt, true)) return true;
+    }
+  }
+  return false;
 }
 
 // Narrow phase of up to four broad-phase candidates at once, sixteen lanes each.  About nine
@@ -1955,12 +2001,9 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           bool ov = false;
           for (int a = 0; a < R->n_layers && !ov; ++a) {
             int l = R->layers[a];
-            for (int t = P->layer_slot0[l]; t < P->layer_slot0[l] + P->layer_nslots[l] && !ov; ++t)
-              if (t != s && ALIVE(t) && overlaps(e, s, t)) ov = true;
+            ov = overlaps_any(e, s, P->layer_slot0[l], P->layer_slot0[l] + P->layer_nslots[l]);
           }
-          if (op->disjoint)
-            for (int t = first; t < s && !ov; ++t)
-              if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+          if (op->disjoint && !ov) ov = overlaps_any(e, s, first, s);
           if (!ov) break;
           if (count > op->max_tries) {
             wsync();
@@ -2480,16 +2523,24 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
 
 __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
+  // every sampled factor of a flat Product takes exactly one draw, in sample order: all of them at once
+  int ndraw = 0;
+  for (int k = 0; k < op->n_sampled; ++k) {
+    const int kind = op->factors[op->sample_order[k]].kind;
+    ndraw += (kind == MOOG_DIST_CONTINUOUS || kind == MOOG_DIST_DISCRETE) ? 1 : 0;
+  }
+  const double draws = ndraw > 0 ? next_uniforms_lanes(e, ndraw) : 0.0;
+  int kd = 0;
   for (int k = 0; k < op->n_sampled; ++k) {
     int fi = op->sample_order[k];
     PFactor F = &op->factors[fi];
     double val = F->a;
     if (F->kind == MOOG_DIST_CONTINUOUS) {
-      double u = next_uniform(e);
+      double u = shfl_d(draws, kd++);
       val = F->a + (F->b - F->a) * u;
       if (F->f32) val = f32r(val);
     } else if (F->kind == MOOG_DIST_DISCRETE) {
-      double u = next_uniform(e);
+      double u = shfl_d(draws, kd++);
       int idx = (int)(u * F->n_cand);
       if (idx >= F->n_cand) idx = F->n_cand - 1;
       val = e.P->cand[F->cand_off + idx];
@@ -2658,12 +2709,9 @@ __device__ inline void run_genop(Env& e, int oi) {
       for (int oj = 0; oj < oi && !ov; ++oj) {
         if (!((op->avoid_ops >> oj) & 1)) continue;
         PGenop o2 = &P->ops[oj];
-        for (int t = o2->slot0; t < o2->slot0 + o2->count_max && !ov; ++t)
-          if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+        ov = overlaps_any(e, s, o2->slot0, o2->slot0 + o2->count_max);
       }
-      if (op->disjoint)
-        for (int t = op->slot0; t < s && !ov; ++t)
-          if (ALIVE(t) && overlaps(e, s, t)) ov = true;
+      if (op->disjoint && !ov) ov = overlaps_any(e, s, op->slot0, s);
       if (!ov) break;
       if (count > op->max_tries) {
         wsync();
