@@ -69,6 +69,7 @@ struct Env {
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
+  unsigned long long* rowm; // LDS scratch [64]: candidate bit matrix of a layer against itself
   int n_path, n_resp, n_disj;   // profiling counters (path tests, contact searches, make_disjoint calls)
 #ifdef MOOG_PROFILE
   long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
@@ -1518,6 +1519,30 @@ __device__ inline void constant_speed(Env& e, PCorr C) {
   }
 }
 
+// Broad phase of one ordered pair: both sprites alive, bounding circles (sprite.py:464-466) and conservative
+// 8-DOPs not apart.  Symmetric in (s0, t).  Every load goes out before anything is tested.
+__device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in) {
+  const int fl0 = FLAGS(s0), fl1 = FLAGS(t);
+  const float4 al = *reinterpret_cast<const float4*>(&BB(s0, 0)), ah = *reinterpret_cast<const float4*>(&BB(s0, 4));
+  const float4 bl = *reinterpret_cast<const float4*>(&BB(t, 0)), bh = *reinterpret_cast<const float4*>(&BB(t, 4));
+  const double2 p0 = *reinterpret_cast<const double2*>(&PX(s0)), p1 = *reinterpret_cast<const double2*>(&PX(t));
+  const double r0 = MAXR(s0), r1 = MAXR(t);
+  const float M = (float)BB_MARGIN;
+  const bool apart = al.x > bh.x + M || bl.x > ah.x + M || al.y > bh.y + M || bl.y > ah.y + M ||
+                     al.z > bh.z + M || bl.z > ah.z + M || al.w > bh.w + M || bl.w > ah.w + M;
+  bool cand = in && s0 != t && (fl0 & fl1 & MOOG_F_ALIVE) && !apart;
+  if (cand) {   // circles_apart, on the values already loaded
+    const double dx = p0.x - p1.x, dy = p0.y - p1.y;
+    const double d2 = dx * dx + dy * dy, r = r0 + r1, r2 = r * r;
+    bool ca;
+    if (d2 > r2 * (1.0 + 1e-9) && r >= 0) ca = true;
+    else if (d2 < r2 * (1.0 - 1e-9)) ca = false;
+    else ca = sqrt(d2) > r;
+    cand = !ca;
+  }
+  return cand;
+}
+
 // Collision force over (layer la) x (layer lb): the reference visits ordered pairs
 // (s0, s1), s0 outer, sequentially (physics.py:103-108) and every resolved contact
 // moves sprites, so later pairs must see the new state.  Broad phase: the flattened
@@ -1546,24 +1571,7 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
       const int idc = in ? idx : 0;
       const int i = (total <= 4096 && nB <= 128) ? div_small(idc, nB) : idc / nB;
       const int s0 = a0 + i, t = b0 + (idc - i * nB);
-      const int fl0 = FLAGS(s0), fl1 = FLAGS(t);
-      const float4 al = *reinterpret_cast<const float4*>(&BB(s0, 0)), ah = *reinterpret_cast<const float4*>(&BB(s0, 4));
-      const float4 bl = *reinterpret_cast<const float4*>(&BB(t, 0)), bh = *reinterpret_cast<const float4*>(&BB(t, 4));
-      const double2 p0 = *reinterpret_cast<const double2*>(&PX(s0)), p1 = *reinterpret_cast<const double2*>(&PX(t));
-      const double r0 = MAXR(s0), r1 = MAXR(t);
-      const float M = (float)BB_MARGIN;
-      const bool apart = al.x > bh.x + M || bl.x > ah.x + M || al.y > bh.y + M || bl.y > ah.y + M ||
-                         al.z > bh.z + M || bl.z > ah.z + M || al.w > bh.w + M || bl.w > ah.w + M;
-      bool cand = in && s0 != t && (fl0 & fl1 & MOOG_F_ALIVE) && !apart;
-      if (cand) {   // circles_apart (sprite.py:464-466), on the values already loaded
-        const double dx = p0.x - p1.x, dy = p0.y - p1.y;
-        const double d2 = dx * dx + dy * dy, r = r0 + r1, r2 = r * r;
-        bool ca;
-        if (d2 > r2 * (1.0 + 1e-9) && r >= 0) ca = true;
-        else if (d2 < r2 * (1.0 - 1e-9)) ca = false;
-        else ca = sqrt(d2) > r;
-        cand = !ca;
-      }
+      const bool cand = broad_pair(e, s0, t, in);
       uint64_t m = __ballot(cand);
       if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (uint16_t)((s0 << 8) | t);
       count += __popcll(m);
@@ -1597,6 +1605,114 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
   }
 }
 
+// The same for a layer against itself (n <= 64 sprites), where the broad-phase test is symmetric: the
+// candidate pairs live in a bit matrix (row i = partners of sprite a0 + i), filled from the n (n - 1) / 2
+// unordered pairs (half the rounds of the ordered scan), and after a contact only the rows / columns of
+// the sprites it moved are re-tested (one round) instead of re-scanning every later pair.  The ordered
+// candidate list the narrow phase consumes is written from the matrix, rows in order, bits in order:
+// exactly the list the ordered scan would build.
+__device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, int K) {
+  const int n = a1 - a0, total = n * n;
+  const int symmetric = uni(F->symmetric);
+  unsigned long long* rowm = e.rowm;
+  wsync();
+  PROF_T0;
+  if (e.lane < n) rowm[e.lane] = 0ull;
+  wsync();
+  {   // unordered pairs by rounds of a round-robin: row r pairs column c with c + r + 1 (mod n)
+    const int h = (n - 1) >> 1;                        // full rows
+    const int npairs = h * n + ((n & 1) ? 0 : n >> 1);   // (an even n has a last half row)
+    for (int base = 0; base < npairs; base += 64) {
+      const int idx = base + e.lane;
+      const bool in = idx < npairs;
+      const int idc = in ? idx : 0;
+      const int r = div_small(idc, n), c = idc - r * n;
+      int j = c + r + 1;
+      if (j >= n) j -= n;
+      const bool cand = broad_pair(e, a0 + c, a0 + j, in);
+      if (cand) { atomicOr(&rowm[c], 1ull << j); atomicOr(&rowm[j], 1ull << c); }
+    }
+  }
+  wsync();
+  PROF_ADD(e, 4);
+  int start = 0;
+  while (start < total) {
+    // ---- the ordered list of candidates with flattened index >= start, as many whole rows as fit --------
+    PROF_T0;
+    const int srow = div_small(start, n), scol = start - srow * n;
+    unsigned long long bits = 0ull;
+    if (e.lane < n && e.lane >= srow) {
+      bits = rowm[e.lane];
+      if (e.lane == srow) bits &= ~((1ull << scol) - 1ull);
+    }
+    const int cnt = __popcll(bits);
+    int inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int tt = __shfl_up(inc, o);
+      if (e.lane >= o) inc += tt;
+    }
+    const unsigned long long over = __ballot(inc > CAND_CAP);
+    const int rows_end = over ? (__ffsll((long long)over) - 1) : 64;   // rows >= rows_end do not fit: next pass
+    int count = 0;
+    {
+      const int last = rows_end - 1 < 63 ? rows_end - 1 : 63;
+      count = rows_end > 0 ? __shfl(inc, last) : 0;
+      if (rows_end <= srow) {   // (a single row with more than CAND_CAP partners cannot happen: n <= 64 < CAND_CAP)
+        count = 0;
+      }
+    }
+    if (e.lane < rows_end) {
+      int pos = inc - cnt;
+      unsigned long long b = bits;
+      while (b) {
+        const int j = __ffsll((long long)b) - 1;
+        b &= b - 1ull;
+        e.cand[pos++] = (uint16_t)(((a0 + e.lane) << 8) | (a0 + j));
+      }
+    }
+    const int scanned = rows_end >= n ? total : rows_end * n;
+    wsync();
+    PROF_ADD(e, 4);
+    // ---- consume ----------------------------------------------------------------------------
+    bool rebuilt = false;
+    for (int c = 0; c < count; ++c) {
+      bool known_hit = false;
+      if (count - c >= 2 && !(e.dbg & (4 | 32))) {   // skip the leading candidates that do not overlap
+        PROF_T0;
+        const int nn = count - c < 4 ? count - c : 4;
+        const int rr = uni(narrow_reject_prefix(e, c, nn)), r = rr & 255;
+        PROF_ADD(e, 8);
+        known_hit = (rr & 256) != 0;
+        c += r;
+        if (r == nn) { --c; continue; }   // all of them: on to the next batch
+      }
+      const int pr = uni((int)e.cand[c]);
+      const int s0 = pr >> 8, t = pr & 255;
+      if (!(e.dbg & 4) && collision_step(e, F, s0, t, K, known_hit)) {
+        start = (s0 - a0) * n + (t - a0) + 1;
+        // re-test the pairs of the sprites the contact moved (s0; t as well when symmetric)
+        PROF_T0;
+        for (int w = 0; w < (symmetric ? 2 : 1); ++w) {
+          const int m = (w ? t : s0) - a0;
+          wsync();
+          const bool cand = broad_pair(e, a0 + m, a0 + (e.lane < n ? e.lane : 0), e.lane < n);
+          const unsigned long long cm = __ballot(cand);
+          if (e.lane < n) {
+            unsigned long long rw = rowm[e.lane] & ~(1ull << m);
+            if (cand) rw |= 1ull << m;
+            rowm[e.lane] = (e.lane == m) ? cm : rw;
+          }
+          wsync();
+        }
+        PROF_ADD(e, 4);
+        rebuilt = true;
+        break;
+      }
+    }
+    if (!rebuilt) start = scanned;
+  }
+}
+
 // physics.py:88-117 (one substep)
 __device__ inline void apply_physics(Env& e) {
   PProg P = e.P;
@@ -1620,7 +1736,12 @@ __device__ inline void apply_physics(Env& e) {
           int lb = uni(F->layers_b[b]);
           int b0 = uni(P->layer_slot0[lb]), b1 = b0 + uni(P->layer_nslots[lb]);
           if (kind == MOOG_FORCE_COLLISION) {
-            if (!(e.dbg & 1)) { PROF_T0; collision_layer_pair(e, F, a0, a1, b0, b1, K); PROF_ADD(e, 7); }
+            if (!(e.dbg & 1)) {
+              PROF_T0;
+              if (a0 == b0 && a1 == b1 && a1 - a0 <= 64 && a1 - a0 >= 2) collision_same_layer(e, F, a0, a1, K);
+              else collision_layer_pair(e, F, a0, a1, b0, b1, K);
+              PROF_ADD(e, 7);
+            }
           } else {
             for (int s0 = a0; s0 < a1; ++s0) {
               if (!ALIVE(s0)) continue;

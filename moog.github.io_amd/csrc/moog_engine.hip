@@ -199,7 +199,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
                 (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
-                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 16;
+                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     free_engine(e);

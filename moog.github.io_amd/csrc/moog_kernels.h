@@ -130,6 +130,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.voff = reinterpret_cast<int32_t*>(after_xf);
   e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
+  e.rowm = reinterpret_cast<unsigned long long*>(e.lst + 128);
   if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
   else e.gcol = e.f + H.o_color;
   if (a.H.i_cut1 > a.H.i_cut0) {
