@@ -54,6 +54,7 @@ struct moog_engine {
   int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
   bool dynamic_rules = false;
   RPlan raster_plan_{};
+  int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_hwords = 1, raster_xxcap = 4;
   int timing = 0;   // bit k: launches of kernel k are bracketed by HIP events
   int32_t* perm = nullptr;
@@ -122,9 +123,9 @@ static int validate(const moog_program_t* p) {
     if (p->slot_vcap[s] > 128) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 128 vertices");
   for (int l = 0; l < p->n_layers; ++l)
     if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
-  if (p->render.width % 16 != 0 || p->render.width > 128 || p->render.height > 1024 ||
-      p->render.height > 1024)
-    return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, width <= 128)");
+  if (p->render.width % 16 != 0 || p->render.width < 16 || p->render.width > 4096 || p->render.height < 1 ||
+      p->render.height > 4096)
+    return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, 16 <= width <= 4096, height <= 4096)");
   return MOOG_OK;
 }
 
@@ -207,7 +208,15 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   }
   // raster LDS plan (moog_raster.h): row records for `chunk` rows per pass
   {
-    int W = prog->render.width, H = prog->render.height;
+    // Tiles: the row masks of the kernel are 128 bits, so a wider canvas is cut into columns of the widest
+    // multiple of 16 <= 128 that divides the width, and a taller one into bands of 64 rows.
+    int tw = prog->render.width <= 128 ? prog->render.width : 128;
+    while (prog->render.width % tw != 0) tw -= 16;
+    e->raster_tile_w = tw;
+    e->raster_tiles_x = prog->render.width / tw;
+    e->raster_band_h = prog->render.height <= 128 ? prog->render.height : 64;
+    e->raster_bands = (prog->render.height + e->raster_band_h - 1) / e->raster_band_h;
+    int W = e->raster_tile_w, H = e->raster_band_h;   // (the LDS plan is per tile)
     int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
     int items = prog->n_slots * ncopy;
     if (items < 1) items = 1;
@@ -373,6 +382,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
+  r.tile_w = e->raster_tile_w; r.band_h = e->raster_band_h; r.tiles_x = e->raster_tiles_x; r.bands = e->raster_bands;
   r.iwords = e->raster_iwords; r.hwords = e->raster_hwords; r.xxcap = e->raster_xxcap;
   r.debug_stop = e->raster_stop;
   r.n_static = e->n_static; r.nsv = e->nsv; r.build = 0;

@@ -55,7 +55,11 @@ struct RArgs {
   const uint32_t* vinfo;  // per vertex slot: sprite slot | index within the sprite << 8
   int32_t n_envs;
   int32_t chunk;       // row records per pass
-  int32_t words;       // 64-bit words per row mask
+  int32_t words;       // 64-bit words per row mask (of a tile)
+  int32_t tile_w;      // columns per workgroup tile (<= 128, a multiple of 16 that divides the width)
+  int32_t band_h;      // rows per workgroup tile
+  int32_t tiles_x;     // tiles per canvas row
+  int32_t bands;       // tile rows per canvas
   int32_t iwords;      // 32-bit words of a segment's item bitmask
   int32_t hwords;      // 32-bit words of an item's head bitmask
   int32_t debug_stop;  // >0: return after that phase (profiling aid)

@@ -56,7 +56,9 @@ __device__ inline short clamp16(int v) { return (short)(v < -32000 ? -32000 : (v
 
 struct RMask { unsigned long long w0, w1; };
 
-__device__ inline void mask_fill(RMask& m, int W, int x0, int x1) {
+// (W = width of the tile the workgroup renders, xoff = its first canvas column: bit i of the mask is column xoff + i)
+__device__ inline void mask_fill(RMask& m, int W, int xoff, int x0, int x1) {
+  x0 -= xoff; x1 -= xoff;
   if (x0 < 0) x0 = 0; else if (x0 >= W) return;
   if (x1 < 0) return; else if (x1 >= W) x1 = W - 1;
   if (x0 > x1) return;
@@ -83,7 +85,7 @@ struct RPoly {
 __device__ __forceinline__ bool r_is_table(const REdge& E) { return E.y0 != E.y1; }
 
 // Draw.c draw_horizontal_lines (heads visited in edge order)
-__device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask& m, int W) {
+__device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask& m, int W, int xoff) {
   for (int hw = 0; hw < p.hwords; ++hw) {
     unsigned bits = (p.head ? p.head[hw] : ~0u) & p.rowbits;
     while (bits) {
@@ -98,7 +100,7 @@ __device__ inline void draw_horizontal(const RPoly& p, int y, int* x_pos, RMask&
         xmin = *x_pos;
         if (xmax < xmin) continue;
       }
-      mask_fill(m, W, xmin, xmax);
+      mask_fill(m, W, xoff, xmin, xmax);
       *x_pos = xmax + 1;
     }
   }
@@ -262,7 +264,7 @@ __device__ __forceinline__ void push_crossing(RRow* rows, int rb, const REdge& E
 
 // Generic scanline (any number of crossings, several fix-ups): crossing list in LDS.
 // xx: this thread's crossing list, element j at xx[j * R_SLOW].
-__device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ymax, float* xx, int W,
+__device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ymax, float* xx, int W, int xoff,
                                               const int R_XX) {
   RMask m = {0ull, 0ull};
   int j = 0;
@@ -312,17 +314,17 @@ __device__ inline RMask scanline_mask_generic(const RPoly& p, int y, int poly_ym
   for (int i = 1; i < j; i += 2) {
     int x_end = pil_round_down(xx[i * R_SLOW]);
     if (x_end < x_pos) continue;
-    draw_horizontal(p, y, &x_pos, m, W);
+    draw_horizontal(p, y, &x_pos, m, W, xoff);
     if (x_end < x_pos) continue;
     int x_start = pil_round_up(xx[(i - 1) * R_SLOW]);
     if (x_pos > x_start) {
       x_start = x_pos;
       if (x_end < x_start) continue;
     }
-    mask_fill(m, W, x_start, x_end);
+    mask_fill(m, W, xoff, x_start, x_end);
     x_pos = x_end + 1;
   }
-  draw_horizontal(p, y, &x_pos, m, W);
+  draw_horizontal(p, y, &x_pos, m, W, xoff);
   return m;
 }
 
@@ -350,7 +352,8 @@ __device__ __forceinline__ void sort_network(unsigned (&k)[N]) {
 
 // bits [xs, xe] of the row mask, clipped to the canvas; nothing when xs > xe or !pred.  Branch free.
 template <int WORDS>
-__device__ __forceinline__ void mask_or_range(RMask& m, int W, int xs, int xe, bool pred) {
+__device__ __forceinline__ void mask_or_range(RMask& m, int W, int xoff, int xs, int xe, bool pred) {
+  xs -= xoff; xe -= xoff;
   const int a = xs < 0 ? 0 : xs, b = xe > W - 1 ? W - 1 : xe;
   pred = pred && (a <= b);
   {
@@ -367,18 +370,18 @@ __device__ __forceinline__ void mask_or_range(RMask& m, int W, int xs, int xe, b
 
 // draw_horizontal_lines for a row with exactly one head [hxmin, hxmax]; `act`: the call happens
 template <int WORDS>
-__device__ __forceinline__ void draw_one_head(bool act, int hxmin, int hxmax, int& x_pos, RMask& m, int W) {
+__device__ __forceinline__ void draw_one_head(bool act, int hxmin, int hxmax, int& x_pos, RMask& m, int W, int xoff) {
   bool hv = act && (x_pos == -1 || x_pos >= hxmin);
   const int hs = x_pos > hxmin ? x_pos : hxmin;
   hv = hv && !(x_pos > hxmin && hxmax < hs);
-  if (__any(hv)) mask_or_range<WORDS>(m, W, hs, hxmax, hv);
+  if (__any(hv)) mask_or_range<WORDS>(m, W, xoff, hs, hxmax, hv);
   x_pos = hv ? hxmax + 1 : x_pos;
 }
 
 // Pillow's span loop on NP sorted pairs (polygon_generic after qsort), predicated instead of
 // branching: lanes of a wave work on rows of different polygons.
 template <int NP, int N, int WORDS>
-__device__ __forceinline__ RMask span_loop(const unsigned (&k)[N], int cnt, bool head, int hxmin, int hxmax, int W) {
+__device__ __forceinline__ RMask span_loop(const unsigned (&k)[N], int cnt, bool head, int hxmin, int hxmax, int W, int xoff) {
   RMask m = {0ull, 0ull};
   int x_pos = (cnt == 0) ? -1 : 0;
   const bool anyhead = __any(head);
@@ -388,17 +391,17 @@ __device__ __forceinline__ RMask span_loop(const unsigned (&k)[N], int cnt, bool
     const int x_end = key_down(k[2 * q + 1]);
     bool act = (2 * q + 1 < cnt) && (x_end >= x_pos);
     if (anyhead) {
-      draw_one_head<WORDS>(act && head, hxmin, hxmax, x_pos, m, W);
+      draw_one_head<WORDS>(act && head, hxmin, hxmax, x_pos, m, W, xoff);
       act = act && (x_end >= x_pos);
     }
     const int x_start = key_up(k[2 * q]);
     const bool gt = x_pos > x_start;
     const int xs = gt ? x_pos : x_start;
     act = act && !(gt && x_end < xs);
-    mask_or_range<WORDS>(m, W, xs, x_end, act);   // empty when x_start > x_end, x_pos still moves
+    mask_or_range<WORDS>(m, W, xoff, xs, x_end, act);   // empty when x_start > x_end, x_pos still moves
     x_pos = act ? x_end + 1 : x_pos;
   }
-  if (anyhead) draw_one_head<WORDS>(head, hxmin, hxmax, x_pos, m, W);
+  if (anyhead) draw_one_head<WORDS>(head, hxmin, hxmax, x_pos, m, W, xoff);
   return m;
 }
 
@@ -406,7 +409,7 @@ __device__ __forceinline__ RMask span_loop(const unsigned (&k)[N], int cnt, bool
 // only grows, so a head that is not "after the current position" is finished after this call
 // whether it was drawn or not: its bit is cleared and later calls do not visit it again.
 template <int WORDS>
-__device__ __forceinline__ void draw_pending_heads(const REdge* pe, unsigned& hb, int& x_pos, RMask& m, int W) {
+__device__ __forceinline__ void draw_pending_heads(const REdge* pe, unsigned& hb, int& x_pos, RMask& m, int W, int xoff) {
   unsigned bits = hb;
   while (bits) {
     const int k = __ffs((int)bits) - 1;
@@ -417,13 +420,13 @@ __device__ __forceinline__ void draw_pending_heads(const REdge* pe, unsigned& hb
     hb &= ~(1u << k);
     const int hs = x_pos > xmin ? x_pos : xmin;
     const bool draw = !(x_pos > xmin && xmax < hs);
-    mask_or_range<WORDS>(m, W, hs, xmax, draw);
+    mask_or_range<WORDS>(m, W, xoff, hs, xmax, draw);
     x_pos = draw ? xmax + 1 : x_pos;
   }
 }
 
 template <int NP, int N, int WORDS>
-__device__ __forceinline__ RMask span_loop_pending(const unsigned (&k)[N], int cnt, const REdge* pe, unsigned hb, int W) {
+__device__ __forceinline__ RMask span_loop_pending(const unsigned (&k)[N], int cnt, const REdge* pe, unsigned hb, int W, int xoff) {
   RMask m = {0ull, 0ull};
   int x_pos = (cnt == 0) ? -1 : 0;
 #pragma unroll
@@ -431,22 +434,22 @@ __device__ __forceinline__ RMask span_loop_pending(const unsigned (&k)[N], int c
     if (q >= 1 && !__any(2 * q + 1 < cnt)) break;
     const int x_end = key_down(k[2 * q + 1]);
     bool act = (2 * q + 1 < cnt) && (x_end >= x_pos);
-    if (act) draw_pending_heads<WORDS>(pe, hb, x_pos, m, W);
+    if (act) draw_pending_heads<WORDS>(pe, hb, x_pos, m, W, xoff);
     act = act && (x_end >= x_pos);
     const int x_start = key_up(k[2 * q]);
     const bool gt = x_pos > x_start;
     const int xs = gt ? x_pos : x_start;
     act = act && !(gt && x_end < xs);
-    mask_or_range<WORDS>(m, W, xs, x_end, act);
+    mask_or_range<WORDS>(m, W, xoff, xs, x_end, act);
     x_pos = act ? x_end + 1 : x_pos;
   }
-  draw_pending_heads<WORDS>(pe, hb, x_pos, m, W);
+  draw_pending_heads<WORDS>(pe, hb, x_pos, m, W, xoff);
   return m;
 }
 
 // The same with any number of heads in the row, visited through the polygon's head list
 template <int NP, int N>
-__device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt, const RPoly& p, int y, int W) {
+__device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt, const RPoly& p, int y, int W, int xoff) {
   RMask m = {0ull, 0ull};
   int x_pos = (cnt == 0) ? -1 : 0;
 #pragma unroll
@@ -455,20 +458,20 @@ __device__ __forceinline__ RMask span_loop_poly(const unsigned (&k)[N], int cnt,
     if (2 * q + 1 < cnt) {
       int x_end = key_down(k[2 * q + 1]);
       if (x_end >= x_pos) {
-        draw_horizontal(p, y, &x_pos, m, W);
+        draw_horizontal(p, y, &x_pos, m, W, xoff);
         if (x_end >= x_pos) {
           int x_start = key_up(k[2 * q]);
           bool skip = false;
           if (x_pos > x_start) { x_start = x_pos; skip = (x_end < x_start); }
           if (!skip) {
-            mask_fill(m, W, x_start, x_end);
+            mask_fill(m, W, xoff, x_start, x_end);
             x_pos = x_end + 1;
           }
         }
       }
     }
   }
-  draw_horizontal(p, y, &x_pos, m, W);
+  draw_horizontal(p, y, &x_pos, m, W, xoff);
   return m;
 }
 
@@ -491,10 +494,17 @@ __device__ __noinline__ void r_next_pass(RRow* rows, int cap_rows, int* misc, in
 
 template <int WORDS>
 __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
-  const int env = blockIdx.x;
+  // one workgroup = one tile (<= 128 columns x band_h rows) of one env's frame; frames up to 128 x 128 are one tile
+  const int tiles = a.tiles_x * a.bands;
+  const int env = a.tiles_x * a.bands == 1 ? (int)blockIdx.x : (int)blockIdx.x / tiles;
   if (env >= a.n_envs) return;
+  const int tile_id = (int)blockIdx.x - env * tiles;
+  const int band = tile_id / a.tiles_x;
   PProg P = as_const_prog(a.P);
-  const int W = P->render.width, H = P->render.height;
+  const int WF = P->render.width, H = P->render.height;   // the whole canvas
+  const int W = a.tile_w;                                  // this tile: columns [xoff, xoff + W), rows [yb0, yb1)
+  const int xoff = (tile_id - band * a.tiles_x) * a.tile_w;
+  const int yb0 = band * a.band_h, yb1 = (yb0 + a.band_h < H) ? yb0 + a.band_h : H;
   const int S = P->n_slots, TOTV = a.L.TOTV;
   const bool torus = (P->render.polymod == MOOG_POLYMOD_TORUS);
   const int ncopy = torus ? 9 : 1;
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       double vx = v.x, vy = v.y;
       if (torus) { vx = vx + (double)(c / 3 - 1); vy = vy + (double)(c % 3 - 1); }
       if (first_person) { vx = vx + fpx; vy = vy + fpy; }
-      int ix = pil_int((double)W * vx), iy = pil_int((double)H * vy);
+      int ix = pil_int((double)WF * vx), iy = pil_int((double)H * vy);
       short2 o; o.x = clamp16(ix); o.y = clamp16(iy);
       ivert[c * TOTV + idx] = o;
       int it = s * ncopy + c;
@@ -697,8 +707,8 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       int cnt = 0, ystart = 0;
       if (it < items) {
         int y0 = item_y[2 * it], y1 = item_y[2 * it + 1];
-        if (y0 < 0) y0 = 0;
-        if (y1 > H - 1) y1 = H - 1;   // rows >= H draw nothing (hline clips)
+        if (y0 < yb0) y0 = yb0;
+        if (y1 > yb1 - 1) y1 = yb1 - 1;   // rows >= H draw nothing (hline clips); other bands have their own workgroups
         cnt = (y1 >= y0 && it >= s_lo * ncopy) ? (y1 - y0 + 1) : 0;
         ystart = y0;
       }
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 
   const int nlist = misc[0];
   const int nvtot = TOTV * ncopy;
-  const int segs = H * nseg;   // 16-pixel row segments
+  const int segs = (yb1 - yb0) * nseg;   // 16-pixel row segments of this tile
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
                        (((unsigned)P->render.bg[2] & 255u) << 16);
 
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       if (entry >> 31) {
         if (g < base || g >= end) continue;
         int y = E.y0;
-        if (y >= 0 && y < H) {
+        if (y >= yb0 && y < yb1) {
           RRow* r = rows + (rb + y);
           unsigned old = atomicOr(&r->hbits, 1u << (k & 31));
           atomicOr(&r->cnt, (unsigned)(g + 1) << R_ITEM_SHIFT);
@@ -768,7 +778,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       }
       if (g < base || g >= end) continue;
       R_CLK(TA);
-      const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
+      const int ya = emin < yb0 ? yb0 : emin, yb = emax > yb1 - 1 ? yb1 - 1 : emax;
       RPush pp[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) pp[j] = push_prepare(rows, rb, E, emin, emax, pymax, vtop, vbot, ya + j, ya + j <= yb);
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     __syncthreads();
     // ---- 3b: the remaining rows of long edges: eight lanes per edge with up to 12 rows, a
     //          whole wave per longer edge (walls)
-    for (int i = tid; i < H * nseg * iwords; i += R_THREADS) segitems[i] = 0u;   // (aliases the integer vertices)
+    for (int i = tid; i < segs * iwords; i += R_THREADS) segitems[i] = 0u;   // (aliases the integer vertices)
     {
       const int nlong = misc[1], nvlong = misc[4], sub = tid & 7;
       const int ngroups = (nlong + 7) >> 3;   // waves' worth of 8-lane groups come first, then whole-wave edges
@@ -804,7 +814,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         const int iymax = item_y[2 * g + 1];
         const int pymax = iymax > H ? H : iymax;
         const int emin = E.y0 < E.y1 ? E.y0 : E.y1, emax = E.y0 < E.y1 ? E.y1 : E.y0;
-        const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
+        const int ya = emin < yb0 ? yb0 : emin, yb = emax > yb1 - 1 ? yb1 - 1 : emax;
         if (vl) {
           for (int y = ya + 4 + lane; y <= yb; y += 64)
             push_crossing(rows, rb, E, emin, emax, pymax, E.vtop, E.vbot, g, y, queue, misc);
@@ -858,11 +868,11 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
       RMask m;
       if (__any(cnt > 8)) {
         sort_network<16>(k);
-        m = span_loop<R_CAP / 2, 16, WORDS>(k, cnt, head, hxmin, hxmax, W);
+        m = span_loop<R_CAP / 2, 16, WORDS>(k, cnt, head, hxmin, hxmax, W, xoff);
       } else {
         unsigned k8[8] = {k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]};
         sort_network<8>(k8);
-        m = span_loop<4, 8, WORDS>(k8, cnt, head, hxmin, hxmax, W);
+        m = span_loop<4, 8, WORDS>(k8, cnt, head, hxmin, hxmax, W, xoff);
       }
       if (w < total_rows) {
         if (!slow && !multi) {   // (those rows were queued by the push phase)
@@ -873,7 +883,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
             for (int sg = 0; sg < nseg; ++sg) {
               unsigned long long mw = (sg < 4) ? m.w0 : m.w1;
               if ((mw >> ((sg & 3) * 16)) & 0xffffull)
-                atomicOr(&segitems[(y * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
+                atomicOr(&segitems[((y - yb0) * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
             }
           }
         }
@@ -907,14 +917,14 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         if (hwords > 1) {
           sort_network<16>(k);
           RPoly poly = {pe, 32, headmask + g * hwords, hwords, hbits};
-          m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W);
+          m = span_loop_poly<R_CAP / 2, 16>(k, cnt, poly, y, W, xoff);
         } else if (__any(cnt > 8)) {
           sort_network<16>(k);
-          m = span_loop_pending<R_CAP / 2, 16, WORDS>(k, cnt, pe, hbits, W);
+          m = span_loop_pending<R_CAP / 2, 16, WORDS>(k, cnt, pe, hbits, W, xoff);
         } else {   // this is one wave's dependent chain: the short network when it suffices
           unsigned k8[8] = {k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7]};
           sort_network<8>(k8);
-          m = span_loop_pending<4, 8, WORDS>(k8, cnt, pe, hbits, W);
+          m = span_loop_pending<4, 8, WORDS>(k8, cnt, pe, hbits, W, xoff);
         }
         unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
         mp[0] = m.w0;
@@ -922,7 +932,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
         for (int sg = 0; sg < nseg; ++sg) {
           unsigned long long mw = (sg < 4) ? m.w0 : m.w1;
           if ((mw >> ((sg & 3) * 16)) & 0xffffull)
-            atomicOr(&segitems[(y * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
+            atomicOr(&segitems[((y - yb0) * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
         }
       }
     }
@@ -937,14 +947,14 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
           int iymax = item_y[2 * g + 1];
           int pymax = iymax > H ? H : iymax;
           RPoly poly = {edges + c * TOTV + (pbase[s] & 0xfffff), pbase[s] >> 20, headmask + g * hwords, hwords, ~0u};
-          RMask m = scanline_mask_generic(poly, y, pymax, xxs + t, W, a.xxcap);
+          RMask m = scanline_mask_generic(poly, y, pymax, xxs + t, W, xoff, a.xxcap);
           unsigned long long* mp = reinterpret_cast<unsigned long long*>(rows + w);
           mp[0] = m.w0;
           if (words > 1) mp[1] = m.w1;
           for (int sg = 0; sg < nseg; ++sg) {
             unsigned long long mw = (sg < 4) ? m.w0 : m.w1;
             if ((mw >> ((sg & 3) * 16)) & 0xffffull)
-              atomicOr(&segitems[(y * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
+              atomicOr(&segitems[((y - yb0) * nseg + sg) * iwords + (g >> 5)], 1u << (g & 31));
           }
         }
       }
@@ -956,26 +966,26 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 #ifdef MOOG_RASTER_PROFILE
     if (clk) {   // phase clocks of waves 0 and 3 instead of a frame
       if (lane == 0 && (tid == 0 || tid == 192)) {
-        unsigned* o32 = reinterpret_cast<unsigned*>(a.image + (size_t)env * H * W * 3) + (tid ? 8 : 0);
+        unsigned* o32 = reinterpret_cast<unsigned*>(a.image + (size_t)env * H * WF * 3) + (tid ? 8 : 0);
         o32[0] = (unsigned)(T1 - T0); o32[1] = (unsigned)(T2 - T1); o32[2] = (unsigned)(T3 - T2); o32[3] = (unsigned)(T4 - T3);
         o32[4] = (unsigned)(T5 - T4); o32[5] = (unsigned)(T6 - T5); o32[6] = (unsigned)(clock64() - T0); o32[7] = (unsigned)(TB - TA);
       }
       return;
     }
-    if (a.debug_stop == 10) { uint8_t* out = a.image + (size_t)env * H * W * 3; if (tid < 8) out[tid] = (uint8_t)(tid == 5 ? (rowoff[items] >> 2) : misc[tid]); return; }   // counters instead of a frame
+    if (a.debug_stop == 10) { uint8_t* out = a.image + (size_t)env * H * WF * 3; if (tid < 8) out[tid] = (uint8_t)(tid == 5 ? (rowoff[items] >> 2) : misc[tid]); return; }   // counters instead of a frame
 #endif
 
     // ---- 5: compose (painter's order = item order), pack RGB, store flipped ------------------
-    uint8_t* out = a.image + (size_t)env * H * W * 3;
+    uint8_t* out = a.image + (size_t)env * H * WF * 3;
     const bool from_cache = (base == 0 && s_lo > 0);
     for (int seg = tid; seg < segs; seg += R_THREADS) {
-      int y = seg / nseg, sg = seg - y * nseg, x0 = sg * 16;
-      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(H - 1 - y) * W + x0) * 3);
+      const int yr = seg / nseg, sg = seg - yr * nseg, x0 = sg * 16, y = yb0 + yr;
+      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3);
       if (from_cache) {   // a segment no sprite touches is a copy of the cached picture
         bool any = false;
         for (int iw = 0; iw < iwords; ++iw) any = any || segitems[seg * iwords + iw] != 0u;
         if (!any) {
-          const uint4* src = reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * W + x0) * 3);
+          const uint4* src = reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3);
           const uint4 c0 = src[0], c1 = src[1], c2 = src[2];
           dst[0] = c0; dst[1] = c1; dst[2] = c2;
           continue;
@@ -986,7 +996,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) px[i] = bgx;
       } else {  // continue from the previous pass, or from the cached picture of the static prefix
-        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * W + x0) * 3) : dst;
+        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3) : dst;
         uint4 q0 = src[0], q1 = src[1], q2 = src[2];
         unsigned d[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
@@ -1053,6 +1063,7 @@ int moog_raster_configure(size_t lds_bytes) {
 }
 
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
-  if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, dim3(a.n_envs), dim3(R_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(moog_raster_kernel<1>, dim3(a.n_envs), dim3(R_THREADS), lds_bytes, stream, a);
+  const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
+  if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, grid, dim3(R_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(moog_raster_kernel<1>, grid, dim3(R_THREADS), lds_bytes, stream, a);
 }

@@ -1028,3 +1028,31 @@ def test_deferred_fault_surfaces_on_the_next_call():
     env.check_faults = 'sync'
     with pytest.raises(ValueError):
         env.step(np.zeros(8, np.int32))
+
+
+@pytest.mark.parametrize('name,size,n', [('colliding_predators_32', (256, 256), 64), ('functional_maze', (512, 256), 48),
+                                         ('chase_avoid_torus', (192, 320), 48), ('first_person_predators_prey', (1024, 1024), 6),
+                                         ('falling_balls_64', (320, 144), 32)])
+def test_frames_larger_than_one_tile(name, size, n):
+    """Canvases wider / taller than the 128 x 128 tile a workgroup renders (the reference's benchmark renders
+    256, 512 and 1024 pixels, tests/runtime_benchmark.py:31-38; pacman renders 256): every tile of every frame
+    against the oracle renderer over a few steps.  (image_size = (width, height) as in pil_renderer.py:64-66.)"""
+    from moog import environment, observers
+    from moog_demos import example_configs
+    cfg = example_configs.load(name)
+    old = cfg['observers']['image']
+    cfg['observers'] = {'image': observers.PILRenderer(image_size=size, bg_color=old._bg_color, color_to_rgb=old.color_to_rgb,
+                                                       polygon_modifier=old.polygon_modifier)}
+    env = environment.BatchedEnvironment(num_envs=n, seed=3, env_index0=11, layer_capacity=example_configs.capacity(name), **cfg)
+    assert tuple(env.image.shape[1:3]) == (size[1], size[0])
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=3, env_index0=11)
+    env.reset()
+    rs = np.random.RandomState(8)
+    for k in range(4):
+        a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.f64[:], o.i32[:] = download(env)
+        img = out.observation['image'].cpu().numpy()
+        ref = o.render()
+        bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+        assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist(), int(bad.size))
