@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 14
+#define MOOG_ABI_VERSION 15
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -354,11 +354,14 @@ enum { MOOG_POLYMOD_NONE = 0, MOOG_POLYMOD_TORUS = 1,   /* polygon_modifiers.py:
        MOOG_POLYMOD_FIRST_PERSON = 2 };                  /* polygon_modifiers.py:41-64 */
 
 typedef struct {
-  int32_t width, height; /* PIL canvas (image_size[0], image_size[1])          */
+  int32_t width, height; /* the observation: image_size[0], image_size[1]      */
   int32_t cmap;
   int32_t polymod;
   int32_t bg[3];
   int32_t polymod_layer; /* FIRST_PERSON: agent layer (its first sprite is drawn at (0.5, 0.5)) */
+  int32_t aa;            /* anti_aliasing: the canvas is aa * width x aa * height and is
+                          * down-sampled with Pillow's LANCZOS filter (pil_renderer.py:64-66,112); 0 / 1: none */
+  int32_t pad_;
 } moog_render_t;
 
 /* ---- the lowered config ----------------------------------------------------- */

@@ -55,6 +55,12 @@ struct moog_engine {
   bool dynamic_rules = false;
   RPlan raster_plan_{};
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
+  // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
+  int aa = 1, canvas_w = 0, canvas_h = 0, aa_chunk = 0;
+  uint8_t* aa_canvas = nullptr;   // [aa_chunk][canvas_h][canvas_w][3]
+  uint8_t* aa_tmp = nullptr;      // [aa_chunk][canvas_h][width][3]
+  int32_t* aa_tables = nullptr;   // bounds + coefficients of both axes
+  RResize aa_resize{};
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_hwords = 1, raster_xxcap = 4;
   int timing = 0;   // bit k: launches of kernel k are bracketed by HIP events
   int32_t* perm = nullptr;
@@ -80,6 +86,9 @@ static void free_engine(moog_engine* e) {
   if (e->s_f64) hipFree(e->s_f64);
   if (e->s_i32) hipFree(e->s_i32);
   if (e->s_bg) hipFree(e->s_bg);
+  if (e->aa_canvas) hipFree(e->aa_canvas);
+  if (e->aa_tmp) hipFree(e->aa_tmp);
+  if (e->aa_tables) hipFree(e->aa_tables);
   if (e->fault_flag) hipHostFree(e->fault_flag);
   delete e;
 }
@@ -123,15 +132,81 @@ static int validate(const moog_program_t* p) {
     if (p->slot_vcap[s] > 128) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 128 vertices");
   for (int l = 0; l < p->n_layers; ++l)
     if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
-  if (p->render.width % 16 != 0 || p->render.width < 16 || p->render.width > 4096 || p->render.height < 1 ||
-      p->render.height > 4096)
-    return fail(MOOG_E_UNSUPPORTED, "render size unsupported (width % 16 == 0, 16 <= width <= 4096, height <= 4096)");
+  {
+    const int aa = p->render.aa > 1 ? p->render.aa : 1;
+    const long long cw = (long long)aa * p->render.width, ch = (long long)aa * p->render.height;
+    if (cw % 16 != 0 || cw < 16 || cw > 8192 || ch < 1 || ch > 8192 || aa > 16)
+      return fail(MOOG_E_UNSUPPORTED, "render size unsupported (canvas width % 16 == 0, 16 <= canvas width <= 8192, canvas height <= 8192)");
+  }
   return MOOG_OK;
 }
 
 static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t* inj,
                        const moog_step_out_t* out, int mode, const uint8_t* mask);
 static RArgs raster_args(moog_engine* e, uint8_t* image);
+
+// Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS filter (support 3): the window of
+// output sample xx is centred on (xx + 0.5) * scale, weights are normalised in double and rounded to fixed
+// point with 22 fractional bits.  Returns the taps per output sample.
+static int resize_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& kk) {
+  const double scale = (double)in_size / out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 3.0 * filterscale;
+  const int ksize = (int)std::ceil(support) * 2 + 1;
+  auto sinc = [](double x) { return x == 0.0 ? 1.0 : std::sin(x * M_PI) / (x * M_PI); };
+  auto lanczos = [&](double x) { return (-3.0 <= x && x < 3.0) ? sinc(x) * sinc(x / 3) : 0.0; };
+  bounds.assign(2 * (size_t)out_size, 0);
+  kk.assign((size_t)out_size * ksize, 0);
+  std::vector<double> pre((size_t)ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    const double center = 0 + (xx + 0.5) * scale, ss = 1.0 / filterscale;
+    double ww = 0.0;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    int x;
+    for (x = 0; x < xmax; ++x) {
+      const double w = lanczos((x + xmin - center + 0.5) * ss);
+      pre[x] = w;
+      ww += w;
+    }
+    for (x = 0; x < xmax; ++x)
+      if (ww != 0.0) pre[x] /= ww;
+    for (; x < ksize; ++x) pre[x] = 0;
+    for (x = 0; x < ksize; ++x)
+      kk[(size_t)xx * ksize + x] = pre[x] < 0 ? (int)(-0.5 + pre[x] * (1 << 22)) : (int)(0.5 + pre[x] * (1 << 22));
+    bounds[2 * xx] = xmin;
+    bounds[2 * xx + 1] = xmax;
+  }
+  return ksize;
+}
+
+static int setup_anti_aliasing(moog_engine* e) {
+  if (e->aa <= 1) return MOOG_OK;
+  const int ow = e->prog.render.width, oh = e->prog.render.height;
+  std::vector<int32_t> bh, bv, ch, cv;
+  const int kh = resize_coeffs(e->canvas_w, ow, bh, ch), kv = resize_coeffs(e->canvas_h, oh, bv, cv);
+  const size_t words = bh.size() + bv.size() + ch.size() + cv.size();
+  if (hipMalloc(&e->aa_tables, words * sizeof(int32_t)) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(resize tables) failed");
+  int32_t* d = e->aa_tables;
+  HIPCHK(hipMemcpy(d, bh.data(), bh.size() * 4, hipMemcpyHostToDevice)); const int32_t* dbh = d; d += bh.size();
+  HIPCHK(hipMemcpy(d, bv.data(), bv.size() * 4, hipMemcpyHostToDevice)); const int32_t* dbv = d; d += bv.size();
+  HIPCHK(hipMemcpy(d, ch.data(), ch.size() * 4, hipMemcpyHostToDevice)); const int32_t* dch = d; d += ch.size();
+  HIPCHK(hipMemcpy(d, cv.data(), cv.size() * 4, hipMemcpyHostToDevice)); const int32_t* dcv = d;
+  e->aa_resize = RResize{e->canvas_w, e->canvas_h, ow, oh, kh, kv, dbh, dbv, dch, dcv};
+  // canvases of a chunk of envs at a time: at most 1 GiB of scratch
+  const size_t canvas = (size_t)e->canvas_w * e->canvas_h * 3;
+  size_t chunk = ((size_t)1 << 30) / canvas;
+  if (chunk < 1) chunk = 1;
+  if (chunk > (size_t)e->n_envs) chunk = (size_t)e->n_envs;
+  e->aa_chunk = (int)chunk;
+  if (hipMalloc(&e->aa_canvas, chunk * canvas) != hipSuccess ||
+      hipMalloc(&e->aa_tmp, chunk * (size_t)e->canvas_h * ow * 3) != hipSuccess)
+    return fail(MOOG_E_NOMEM, "hipMalloc(anti-aliasing canvas) failed");
+  return MOOG_OK;
+}
 
 // Resets one scratch env (the constant generation ops do not depend on the random stream) and renders
 // its static prefix on top of the background colour: the reference record and picture of moog_raster.h.
@@ -140,7 +215,7 @@ static int build_static_prefix(moog_engine* e) {
   const int ns = getenv("MOOG_RASTER_NO_STATIC") ? 0 : static_prefix_slots(&e->prog, &nsv);
   if (ns == 0) return MOOG_OK;
   const size_t fb = (size_t)e->L.f64_per_env * 8, ib = (size_t)e->L.i32_per_env * 4;
-  const size_t pb = (size_t)e->prog.render.width * e->prog.render.height * 3;
+  const size_t pb = (size_t)e->canvas_w * e->canvas_h * 3;
   if (hipMalloc(&e->s_f64, fb) != hipSuccess || hipMalloc(&e->s_i32, ib) != hipSuccess ||
       hipMalloc(&e->s_bg, pb) != hipSuccess)
     return fail(MOOG_E_NOMEM, "hipMalloc(static prefix) failed");
@@ -210,12 +285,15 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   {
     // Tiles: the row masks of the kernel are 128 bits, so a wider canvas is cut into columns of the widest
     // multiple of 16 <= 128 that divides the width, and a taller one into bands of 64 rows.
-    int tw = prog->render.width <= 128 ? prog->render.width : 128;
-    while (prog->render.width % tw != 0) tw -= 16;
+    e->aa = prog->render.aa > 1 ? prog->render.aa : 1;
+    e->canvas_w = e->aa * prog->render.width;
+    e->canvas_h = e->aa * prog->render.height;
+    int tw = e->canvas_w <= 128 ? e->canvas_w : 128;
+    while (e->canvas_w % tw != 0) tw -= 16;
     e->raster_tile_w = tw;
-    e->raster_tiles_x = prog->render.width / tw;
-    e->raster_band_h = prog->render.height <= 128 ? prog->render.height : 64;
-    e->raster_bands = (prog->render.height + e->raster_band_h - 1) / e->raster_band_h;
+    e->raster_tiles_x = e->canvas_w / tw;
+    e->raster_band_h = e->canvas_h <= 128 ? e->canvas_h : 64;
+    e->raster_bands = (e->canvas_h + e->raster_band_h - 1) / e->raster_band_h;
     int W = e->raster_tile_w, H = e->raster_band_h;   // (the LDS plan is per tile)
     int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
     int items = prog->n_slots * ncopy;
@@ -298,6 +376,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   }
   *e->fault_flag = 0;
   int rc2 = build_static_prefix(e);
+  if (rc2 == MOOG_OK) rc2 = setup_anti_aliasing(e);
   if (rc2) { free_engine(e); return rc2; }
   *out = e;
   return MOOG_OK;
@@ -383,6 +462,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
   r.tile_w = e->raster_tile_w; r.band_h = e->raster_band_h; r.tiles_x = e->raster_tiles_x; r.bands = e->raster_bands;
+  r.canvas_w = e->canvas_w; r.canvas_h = e->canvas_h; r.flip = e->aa > 1 ? 0 : 1;
   r.iwords = e->raster_iwords; r.hwords = e->raster_hwords; r.xxcap = e->raster_xxcap;
   r.debug_stop = e->raster_stop;
   r.n_static = e->n_static; r.nsv = e->nsv; r.build = 0;
@@ -397,9 +477,21 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
 
 static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
   RArgs r = raster_args(e, image);
-  {
-    Bracket br(e, MOOG_K_RASTER, s);
+  Bracket br(e, MOOG_K_RASTER, s);
+  if (e->aa <= 1) {
     moog_raster_launch(r, e->raster_lds, s);
+  } else {   // pil_renderer.py:111-112: draw on the large canvas, then Image.resize(LANCZOS); a chunk of envs at a time
+    const size_t frame = (size_t)e->prog.render.width * e->prog.render.height * 3;
+    for (int e0 = 0; e0 < e->n_envs; e0 += e->aa_chunk) {
+      const int n = e->n_envs - e0 < e->aa_chunk ? e->n_envs - e0 : e->aa_chunk;
+      RArgs c = r;
+      c.f64 = r.f64 + (size_t)e0 * e->L.f64_per_env;
+      c.i32 = r.i32 + (size_t)e0 * e->L.i32_per_env;
+      c.image = e->aa_canvas;
+      c.n_envs = n;
+      moog_raster_launch(c, e->raster_lds, s);
+      moog_resize_launch(e->aa_resize, e->aa_canvas, e->aa_tmp, image + (size_t)e0 * frame, n, s);
+    }
   }
   HIPCHK(hipGetLastError());
   return MOOG_OK;
@@ -494,6 +586,7 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
   if (n_slots) *n_slots = e->n_static;
   if (image_dev && e->n_static > 0) {
     HIPCHK(hipSetDevice(e->device));
+    if (e->aa > 1) return fail(MOOG_E_UNSUPPORTED, "the cached picture of an anti-aliased renderer is canvas sized");
     HIPCHK(hipMemcpyAsync(image_dev, e->s_bg, (size_t)e->prog.render.width * e->prog.render.height * 3,
                           hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   }

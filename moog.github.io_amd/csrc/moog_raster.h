@@ -60,6 +60,8 @@ struct RArgs {
   int32_t band_h;      // rows per workgroup tile
   int32_t tiles_x;     // tiles per canvas row
   int32_t bands;       // tile rows per canvas
+  int32_t canvas_w, canvas_h;   // the canvas: anti_aliasing x the observation size (pil_renderer.py:65-66)
+  int32_t flip;        // 1: rows are written bottom-up (np.flipud, pil_renderer.py:118); 0 for a canvas that is down-sampled next
   int32_t iwords;      // 32-bit words of a segment's item bitmask
   int32_t hwords;      // 32-bit words of an item's head bitmask
   int32_t debug_stop;  // >0: return after that phase (profiling aid)
@@ -119,5 +121,8 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
 }
 
 // moog_raster.hip: the kernel's own translation unit
+// Image.resize(LANCZOS) of a batch of canvases [n][ch][cw][3] -> observations [n][oh][ow][3], flipped; tmp: [n][ch][ow][3]
+struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_t* bv; const int32_t* ch_coef; const int32_t* cv_coef; };
+void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream);
 int moog_raster_configure(size_t lds_bytes);   // hipFuncSetAttribute(max dynamic LDS); returns a hipError_t
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream);

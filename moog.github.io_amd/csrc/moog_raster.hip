@@ -501,7 +501,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
   const int tile_id = (int)blockIdx.x - env * tiles;
   const int band = tile_id / a.tiles_x;
   PProg P = as_const_prog(a.P);
-  const int WF = P->render.width, H = P->render.height;   // the whole canvas
+  const int WF = a.canvas_w, H = a.canvas_h;   // the whole canvas (anti_aliasing x the observation)
   const int W = a.tile_w;                                  // this tile: columns [xoff, xoff + W), rows [yb0, yb1)
   const int xoff = (tile_id - band * a.tiles_x) * a.tile_w;
   const int yb0 = band * a.band_h, yb1 = (yb0 + a.band_h < H) ? yb0 + a.band_h : H;
@@ -980,12 +980,12 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     const bool from_cache = (base == 0 && s_lo > 0);
     for (int seg = tid; seg < segs; seg += R_THREADS) {
       const int yr = seg / nseg, sg = seg - yr * nseg, x0 = sg * 16, y = yb0 + yr;
-      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3);
+      uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3);
       if (from_cache) {   // a segment no sprite touches is a copy of the cached picture
         bool any = false;
         for (int iw = 0; iw < iwords; ++iw) any = any || segitems[seg * iwords + iw] != 0u;
         if (!any) {
-          const uint4* src = reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3);
+          const uint4* src = reinterpret_cast<const uint4*>(a.sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3);
           const uint4 c0 = src[0], c1 = src[1], c2 = src[2];
           dst[0] = c0; dst[1] = c1; dst[2] = c2;
           continue;
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) px[i] = bgx;
       } else {  // continue from the previous pass, or from the cached picture of the static prefix
-        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(a.sbg + ((size_t)(H - 1 - y) * WF + xoff + x0) * 3) : dst;
+        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(a.sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3) : dst;
         uint4 q0 = src[0], q1 = src[1], q2 = src[2];
         unsigned d[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
@@ -1066,4 +1066,55 @@ void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
   if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, grid, dim3(R_THREADS), lds_bytes, stream, a);
   else hipLaunchKernelGGL(moog_raster_kernel<1>, grid, dim3(R_THREADS), lds_bytes, stream, a);
+}
+
+// ---- Image.resize(size, resample=LANCZOS) (pil_renderer.py:112; Pillow Resample.c, 8 bits per channel): a horizontal
+// pass, then a vertical pass, each rounding to uint8 (clip8); the fixed-point coefficient tables come from the host
+// (moog_engine.hip resize_coeffs, the oracle's oracle_resize_coeffs restated).  One thread per output pixel.
+#define R_PRECISION_BITS (32 - 8 - 2)
+__device__ __forceinline__ unsigned r_clip8(int v) {
+  v >>= R_PRECISION_BITS;
+  return (unsigned)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void moog_resize_h_kernel(RResize r, const uint8_t* in, uint8_t* tmp, int n) {
+  const long long total = (long long)n * r.ch * r.ow;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xx = (int)(i % r.ow);
+  const long long row = i / r.ow;   // env * ch + y
+  const int xmin = r.bh[2 * xx], xmax = r.bh[2 * xx + 1];
+  const int32_t* k = r.ch_coef + (size_t)xx * r.kh;
+  const uint8_t* p = in + ((size_t)row * r.cw + xmin) * 3;
+  int s0 = 1 << (R_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+  for (int x = 0; x < xmax; ++x) { const int kk = k[x]; s0 += p[3 * x] * kk; s1 += p[3 * x + 1] * kk; s2 += p[3 * x + 2] * kk; }
+  uint8_t* o = tmp + ((size_t)row * r.ow + xx) * 3;
+  o[0] = (uint8_t)r_clip8(s0); o[1] = (uint8_t)r_clip8(s1); o[2] = (uint8_t)r_clip8(s2);
+}
+
+__global__ __launch_bounds__(256) void moog_resize_v_kernel(RResize r, const uint8_t* tmp, uint8_t* out, int n) {
+  const long long total = (long long)n * r.oh * r.ow;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % r.ow);
+  const long long t = i / r.ow;
+  const int yy = (int)(t % r.oh);
+  const long long env = t / r.oh;
+  const int ymin = r.bv[2 * yy], ymax = r.bv[2 * yy + 1];
+  const int32_t* k = r.cv_coef + (size_t)yy * r.kv;
+  const uint8_t* p = tmp + (((size_t)env * r.ch + ymin) * r.ow + x) * 3;
+  int s0 = 1 << (R_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+  for (int y = 0; y < ymax; ++y) {
+    const int kk = k[y];
+    const uint8_t* q = p + (size_t)y * r.ow * 3;
+    s0 += q[0] * kk; s1 += q[1] * kk; s2 += q[2] * kk;
+  }
+  uint8_t* o = out + (((size_t)env * r.oh + (r.oh - 1 - yy)) * r.ow + x) * 3;   // np.flipud (pil_renderer.py:118)
+  o[0] = (uint8_t)r_clip8(s0); o[1] = (uint8_t)r_clip8(s1); o[2] = (uint8_t)r_clip8(s2);
+}
+
+void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream) {
+  const long long th = (long long)n * r.ch * r.ow, tv = (long long)n * r.oh * r.ow;
+  hipLaunchKernelGGL(moog_resize_h_kernel, dim3((unsigned)((th + 255) / 256)), dim3(256), 0, stream, r, canvas, tmp, n);
+  hipLaunchKernelGGL(moog_resize_v_kernel, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, stream, r, tmp, out, n);
 }

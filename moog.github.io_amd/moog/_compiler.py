@@ -608,7 +608,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         raise NotImplementedError('exactly one PILRenderer observer is supported')
     obs_key, ren = renderers[0]
     Rn = P.render
-    Rn.width, Rn.height = int(ren._canvas_size[0]), int(ren._canvas_size[1])
+    Rn.width, Rn.height = int(ren._image_size[0]), int(ren._image_size[1])
+    Rn.aa = int(ren._anti_aliasing)   # the canvas is aa x the observation (pil_renderer.py:64-66)
     Rn.cmap = _abi.MOOG_CMAP_HSV if ren._cmap == 'hsv' else _abi.MOOG_CMAP_IDENTITY
     if isinstance(ren._polygon_modifier, polygon_modifiers.TorusGeometry):
         Rn.polymod = _abi.MOOG_POLYMOD_TORUS

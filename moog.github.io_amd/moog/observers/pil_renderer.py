@@ -13,9 +13,9 @@ from . import polygon_modifiers
 class PILRenderer(object):
     def __init__(self, image_size=(64, 64), anti_aliasing=1, bg_color=None, color_to_rgb=None,
                  polygon_modifier=None):
-        if anti_aliasing != 1:
-            raise NotImplementedError(
-                'anti_aliasing != 1 (LANCZOS down-sampling, pil_renderer.py:112) is not supported')
+        if int(anti_aliasing) != anti_aliasing or not 1 <= anti_aliasing <= 16:
+            raise NotImplementedError('anti_aliasing must be an integer in 1 .. 16')
+        anti_aliasing = int(anti_aliasing)
         self._image_size = tuple(image_size)
         self._anti_aliasing = anti_aliasing
         self._canvas_size = (anti_aliasing * image_size[0], anti_aliasing * image_size[1])

@@ -361,6 +361,38 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         name, seed, n_calls, n_first, sum(caps), umax, os.path.getsize(path) / 1024.))
 
 
+def make_resize(seed=13):
+    """Image.resize(size, resample=Image.LANCZOS) as PILRenderer uses it (pil_renderer.py:112) on canvases that
+    look like rendered frames (flat background, opaque and translucent polygons) and on noise."""
+    rs = np.random.RandomState(seed)
+    cases = [((128, 128), 2), ((64, 64), 2), ((96, 48), 2), ((64, 64), 3), ((48, 80), 4), ((256, 256), 2), ((32, 32), 5)]
+    out = {'n_cases': np.int32(len(cases))}
+    for ci, ((ow, oh), aa) in enumerate(cases):
+        cw, ch = aa * ow, aa * oh
+        ins, outs = [], []
+        for rep in range(4):
+            if rep == 3:
+                arr = rs.randint(0, 256, size=(ch, cw, 3)).astype(np.uint8)
+                img = Image.fromarray(arr, 'RGB')
+            else:
+                img = Image.new('RGB', (cw, ch), tuple(int(v) for v in rs.randint(0, 256, size=3)))
+                draw = ImageDraw.Draw(img, 'RGBA')
+                for _ in range(12):
+                    n = rs.randint(3, 9)
+                    c = rs.uniform(0, 1, size=2) * [cw, ch]
+                    r = rs.uniform(0.02, 0.3) * cw
+                    ang = np.sort(rs.uniform(0, 2 * np.pi, size=n))
+                    pts = [(float(c[0] + r * np.cos(a)), float(c[1] + r * np.sin(a))) for a in ang]
+                    draw.polygon(pts, fill=tuple(int(v) for v in rs.randint(0, 256, size=3)) + (int(rs.choice([255, 255, 128, 60])),))
+            ins.append(np.asarray(img).copy())
+            outs.append(np.asarray(img.resize((ow, oh), resample=Image.LANCZOS)).copy())
+        out['in_%d' % ci] = np.stack(ins)
+        out['out_%d' % ci] = np.stack(outs)
+    path = os.path.join(HERE, 'resize.npz')
+    np.savez_compressed(path, **out)
+    print('resize corpus: %d cases x 4 images  %.0f KB' % (len(cases), os.path.getsize(path) / 1024.))
+
+
 # ---- predicate corpora --------------------------------------------------------------
 def random_sprite(rs, shapes_pool):
     shape = shapes_pool[rs.randint(len(shapes_pool))]
@@ -572,7 +604,11 @@ def main():
         make_logger_fixture()
         return
     only = sys.argv[1:]   # config names, or name:seed; the corpora are made by a run without arguments
+    if only == ['resize']:
+        make_resize()
+        return
     if not only:
+        make_resize()
         make_collision_kat()   # before np.random is patched (uses no randomness anyway)
         make_predicates()
         make_raster()
@@ -605,6 +641,9 @@ def main():
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,
                                              '__dynamic__': ('prey', 'predators')}, (0,)),
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
+        ('aa_zoo', 30, {}, (0,)),
+        ('aa_zoo_l1', 30, {}, (0,)),
+        ('aa_zoo_l2', 12, {}, (0,)),
     ]
     for name, n_calls, caps, seeds in plan:
         for seed in seeds:

@@ -19,7 +19,8 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('rules_zoo_l0', 0), ('rules_zoo_l1', 0), ('rules_zoo_l1', 1),
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
         ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1),
-        ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1)]
+        ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
+        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0)]
 TOL = 1e-5   # BASELINE.json: float sprite state within 1e-5 abs
 
 
@@ -362,3 +363,19 @@ def test_tether_known_answers(level):
                  f[L.o_angvel + s]) for s in range(s0, s0 + 3)]
     check_tether_kat(level, sprite_state, o.physics)
     del S
+
+
+def test_pillow_lanczos_resize():
+    """Image.resize(size, resample=LANCZOS) (pil_renderer.py:112) vs Pillow 12.2.0: 28 canvases (rendered-looking
+    and noise, anti_aliasing 2..5, square and not) through the oracle's restatement of Resample.c, bit for bit."""
+    z = dict(np.load(helpers.GOLDEN + '/resize.npz'))
+    lib = helpers.oracle()
+    bp = ctypes.POINTER(ctypes.c_uint8)
+    for ci in range(int(z['n_cases'])):
+        ins, outs = z['in_%d' % ci], z['out_%d' % ci]
+        for k in range(len(ins)):
+            src = np.ascontiguousarray(ins[k])
+            got = np.zeros_like(outs[k])
+            lib.oracle_resize_lanczos(src.ctypes.data_as(bp), src.shape[1], src.shape[0],
+                                      got.ctypes.data_as(bp), got.shape[1], got.shape[0])
+            assert np.array_equal(got, outs[k]), (ci, k, int((got != outs[k]).sum()))
