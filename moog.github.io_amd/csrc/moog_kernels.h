@@ -252,6 +252,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   { PROF_T0; load_record(e, a.H, a.L, gf, gq); PROF_ADD(e, 9); }
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
+#ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
   if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
     env_reset(e);
     wsync();
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
     return;
   }
+#endif
   { PROF_T0; bbox_build_all(e); PROF_ADD(e, 9); }
   PProg P = as_const_prog(a.P);
   const int K = uni(P->updates_per_env_step);
