@@ -8,7 +8,10 @@ engine's kernels plus wall clock):
   4. rendering only                     (:113-130, env.observation())
   5. full step with rendering           (:136-157)
 
-    python -m moog_demos.runtime_benchmark --config colliding_predators_32 --num_envs 4096
+followed by the reference's six renderer settings (image size, anti_aliasing), runtime_benchmark.py:31-38
+and :113-130 (`env.observation()` with a renderer of that size), with --render_sizes.
+
+    python -m moog_demos.runtime_benchmark --config colliding_predators_32 --num_envs 4096 --render_sizes
 """
 import argparse
 import time
@@ -34,6 +37,8 @@ def main():
     ap.add_argument('--level', type=int, default=0)
     ap.add_argument('--num_envs', type=int, default=4096)
     ap.add_argument('--reps', type=int, default=50)
+    ap.add_argument('--render_sizes', action='store_true', help='time the six (size, anti_aliasing) renderer settings')
+    ap.add_argument('--render_envs', type=int, default=256, help='batch of the renderer-size sweep')
     args = ap.parse_args()
     env = environment.BatchedEnvironment(
         num_envs=args.num_envs, **example_configs.load(args.config, args.level))
@@ -63,6 +68,25 @@ def main():
                                                      P.render.width))
     for name, ms in rows:
         print('  %-16s %9.3f ms / batch   %12.0f env-calls/s' % (name, ms, n / ms * 1e3))
+    if args.render_sizes:   # _IMAGE_SIZE_ANTI_ALIASING of the reference's benchmark
+        from moog import observers
+        env.close()
+        m = args.render_envs
+        for size, aa in ((64, 1), (128, 1), (256, 1), (512, 1), (512, 2), (1024, 1)):
+            cfg = example_configs.load(args.config, args.level)
+            old = cfg['observers']['image']
+            cfg['observers'] = {'image': observers.PILRenderer(
+                image_size=(size, size), anti_aliasing=aa, bg_color=old._bg_color, color_to_rgb=old.color_to_rgb,
+                polygon_modifier=old.polygon_modifier)}
+            e2 = environment.BatchedEnvironment(num_envs=m, layer_capacity=example_configs.capacity(args.config), **cfg)
+            e2.check_faults = False
+            e2.reset()
+            for _ in range(3):
+                e2.step(e2.random_action())
+            ms = _timed(e2.observation, max(args.reps // 5, 3), sync)
+            print('  render only, %4d x %-4d anti_aliasing %d: %9.3f ms / batch of %d   %10.0f frames/s' % (
+                size, size, aa, ms, m, m / ms * 1e3))
+            e2.close()
 
 
 if __name__ == '__main__':
