@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 15
+#define MOOG_ABI_VERSION 16
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -35,9 +35,9 @@ extern "C" {
 #define MOOG_MAX_CORRECTIVE 4
 #define MOOG_MAX_RULES 16
 #define MOOG_MAX_TASKS 8
-#define MOOG_MAX_OPS 64
-#define MOOG_MAX_SHAPES 32
-#define MOOG_MAX_SHAPE_VERTS 512
+#define MOOG_MAX_OPS 256
+#define MOOG_MAX_SHAPES 256
+#define MOOG_MAX_SHAPE_VERTS 2048
 #define MOOG_MAX_CAND 128
 #define MOOG_MAX_DCODE 512
 #define MOOG_X_STACK 16
@@ -72,6 +72,9 @@ extern "C" {
 #define MOOG_FAULT_LAYER_FULL 64
 /* PhaseSequence stepped past its last phase (task_phases.py:136-139 raises IndexError) */
 #define MOOG_FAULT_PHASE_END 128
+/* MazePhysics: an avatar is on no grid line of the maze (maze_physics.py:87-97 raises ValueError) */
+#define MOOG_FAULT_OFF_GRID 256
+#define MOOG_MAX_MAZE 32
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -203,9 +206,12 @@ enum {
                                    p1 = slope, i0 = apply_distant, i1 = apply_nearby */
   MOOG_FORCE_DISTANCE_SPRING,   /* distance_fn_force.py:77-89 p0 = k, p1 = equilibrium */
   MOOG_FORCE_RANDOM,            /* random_force.py:22-26 p0 = max magnitude   */
-  MOOG_FORCE_COLLISION          /* collisions.py:457-584 p0 = elasticity,
+  MOOG_FORCE_COLLISION,         /* collisions.py:457-584 p0 = elasticity,
                                    symmetric, i0 = update_angle_vel,
                                    i1 = max_recursion_depth                   */
+  MOOG_FORCE_MAZE_WALK          /* maze_walk.py:96-193 RandomMazeWalk: p0 = speed, i0 bit 0 prevent_backtracking,
+                                   bit 1 allow_wall_backtracking, bit 2 only_turn_at_wall; the maze is
+                                   program.maze (Maze.from_state of the wall layer, maze.py:39-84)      */
 };
 
 typedef struct {
@@ -221,7 +227,9 @@ typedef struct {
 /* corrective physics (physics.py:110-111), applied after the forces of a substep:
  * ConstantSpeed (constant_speed.py:34-46), Tether and TetherZippedLayers
  * (tether_physics.py:43-201) */
-enum { MOOG_CORR_CONSTANT_SPEED = 0, MOOG_CORR_TETHER = 1, MOOG_CORR_TETHER_ZIPPED = 2 };
+enum { MOOG_CORR_CONSTANT_SPEED = 0, MOOG_CORR_TETHER = 1, MOOG_CORR_TETHER_ZIPPED = 2,
+       MOOG_CORR_MAZE = 3 /* maze_physics.py:18-211 MazePhysics: layers = avatar layers, speed = constant_speed
+                           * (NaN: None), anchor[0] = max_speed (NaN: None)                            */ };
 
 typedef struct {
   int32_t kind;              /* MOOG_CORR_*                                      */
@@ -364,6 +372,14 @@ typedef struct {
   int32_t pad_;
 } moog_render_t;
 
+/* ---- maze (maze_lib/maze.py:20-36): the binary matrix MazePhysics / the maze walks infer from the wall
+ *      sprites when they are reset (Maze.from_state, maze.py:39-84) ------------------------------------- */
+typedef struct {
+  int32_t size;                    /* N: the maze is N x N cells (0: the program has no maze)      */
+  int32_t pad_;
+  uint32_t rows[MOOG_MAX_MAZE];    /* rows[j] bit i = Maze.maze[j, i] (1 = wall)                    */
+} moog_maze_t;
+
 /* ---- the lowered config ----------------------------------------------------- */
 typedef struct {
   int32_t abi_version;
@@ -408,6 +424,7 @@ typedef struct {
   int32_t pad_actions_;
   moog_action_t more_actions[MOOG_MAX_MORE_ACTIONS];
   moog_render_t render;
+  moog_maze_t maze;
   moog_genop_t ops[MOOG_MAX_OPS];
   moog_shape_t shapes[MOOG_MAX_SHAPES];
   double shape_verts[MOOG_MAX_SHAPE_VERTS][2]; /* centred, CCW, unit shapes    */

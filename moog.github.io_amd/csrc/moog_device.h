@@ -1317,6 +1317,8 @@ __device__ inline bool force_single_newvel(const Env& e, PForce F, int s, int K,
   return true;
 }
 
+__device__ inline void maze_walk_step(Env& e, PForce F, int s, int K);
+
 __device__ inline void force_single(Env& e, PForce F, int s, int K) {
   if (F->kind == MOOG_FORCE_RANDOM) {
     double r = 0 + (F->p0 - 0) * next_uniform(e);
@@ -1543,6 +1545,227 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
   return cand;
 }
 
+// ---- mazes: maze_lib/maze.py Maze, physics/maze_walk.py RandomMazeWalk, physics/maze_physics.py MazePhysics.
+//      Scalar logic per sprite: every lane evaluates it redundantly (wave uniform), lane 0 commits; the one
+//      vector step is the rotation of a sprite that turned (lanes = vertices).
+#define MAZE_EPS 1e-5   // maze_physics.py:15, maze_walk.py:14
+
+// maze.py:107-112 open_vertex(i, j): inside the matrix and not a wall (maze[j, i])
+__device__ __forceinline__ int maze_open(PProg P, long i, long j) {
+  const int n = P->maze.size;
+  if (i < 0 || j < 0 || i >= n || j >= n) return 0;
+  return !((P->maze.rows[j] >> i) & 1u);
+}
+// maze.py:114-120 valid_directions: [[open(i-1, j), open(i+1, j)], [open(i, j-1), open(i, j+1)]]
+__device__ inline void maze_valid_directions(PProg P, long i, long j, double v[2][2]) {
+  v[0][0] = maze_open(P, i - 1, j); v[0][1] = maze_open(P, i + 1, j);
+  v[1][0] = maze_open(P, i, j - 1); v[1][1] = maze_open(P, i, j + 1);
+}
+// numpy floor_divide on doubles (npy_divmod)
+__device__ inline double np_floor_divide(double a, double b) {
+  if (b == 0) return a / b;
+  double mod = fmod(a, b), div = (a - mod) / b;
+  if (mod != 0) { if ((b < 0) != (mod < 0)) div -= 1.0; }
+  double fl;
+  if (div != 0) { fl = floor(div); if (div - fl > 0.5) fl += 1.0; }
+  else fl = copysign(0.0, a / b);
+  return fl;
+}
+__device__ __forceinline__ double np_sign(double x) { return isnan(x) ? x : (x > 0 ? 1. : (x < 0 ? -1. : 0.)); }
+__device__ __forceinline__ long np_rint_l(double x) { return (long)rint(x); }
+__device__ __forceinline__ int argmax_abs2(const double v[2]) {   // np.argmax(np.abs(v)): NaN wins, first on ties
+  if (isnan(v[0])) return 0;
+  if (isnan(v[1])) return 1;
+  return fabs(v[1]) > fabs(v[0]) ? 1 : 0;
+}
+
+// velocity := (vx, vy) as a fresh float64 array
+__device__ inline void maze_set_velocity(Env& e, int s, double vx, double vy) {
+  wsync();
+  if (e.lane == 0) { VELX(s) = vx; VELY(s) = vy; FLAGS(s) &= ~MOOG_F_VEL_F32; vel_unshare(e, s); }
+  wsync();
+}
+
+// maze_walk.py:149-193 RandomMazeWalk._step_sprite (with :52-79 _get_pos_vel and :81-93 _get_nearest_point)
+__device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
+  PProg P = e.P;
+  if (isinf(MASS(s))) return;
+  const double speed = F->p0, gs = 1. / P->maze.size, half = 0.5 * gs;
+  const double px = PX(s), py = PY(s);
+  double vel[2] = {speed * np_sign(VELX(s)), speed * np_sign(VELY(s))};
+  const double nx = px + vel[0] / K, ny = py + vel[1] / K;
+  const long n0 = np_rint_l(px / gs - 0.5), n1 = np_rint_l(py / gs - 0.5);
+  const double ix = gs * n0 + half, iy = gs * n1 + half;
+  const double d_next_cur = (0 + fabs(nx - px)) + fabs(ny - py);
+  const double d_int_next = (0 + fabs(nx - ix)) + fabs(ny - iy);
+  const double d_int_cur = (0 + fabs(nx - ix)) + fabs(ny - iy);   // (the reference measures from next_position here too)
+  const bool entering = d_next_cur > d_int_cur && d_next_cur > d_int_next;
+  double valid[2][2];
+  if (entering) {
+    maze_valid_directions(P, n0, n1, valid);
+    if (F->i0 & 1) {   // :121-147 _update_valid_directions
+      const int axis = argmax_abs2(vel);
+      const double direction = np_sign(vel[axis]);
+      if (direction != 0) {
+        const int fwd = (int)(0.5 * (1 + direction)), back = (int)(0.5 * (1 - direction));
+        const bool can_continue = valid[axis][fwd] != 0;
+        if (!can_continue && (F->i0 & 2)) { /* every open direction stays valid */ }
+        else if (can_continue && (F->i0 & 4)) {
+          valid[0][0] = valid[0][1] = valid[1][0] = valid[1][1] = 0;
+          valid[axis][fwd] = 1;
+        } else valid[axis][back] = 0;
+      }
+    }
+  } else if (vel[0] == 0. && vel[1] == 0.) {
+    const double rx = half + n0 * gs, ry = half + n1 * gs;
+    const bool on0 = fabs(rx - px) < MAZE_EPS, on1 = fabs(ry - py) < MAZE_EPS;
+    if (on0 && on1) maze_valid_directions(P, n0, n1, valid);
+    else {
+      valid[0][0] = valid[0][1] = valid[1][0] = valid[1][1] = 0;
+      const int row = 1 - (on0 ? 0 : (on1 ? 1 : 0));   // 1 - np.argmax(on_grid)
+      valid[row][0] = valid[row][1] = 1;
+    }
+  } else {
+    maze_set_velocity(e, s, vel[0], vel[1]);
+    return;
+  }
+  // :183-192: sample = valid_directions * np.random.rand(2, 2); argmax of the flattened sample (first maximum, NaN wins)
+  double sample[4];
+  for (int k = 0; k < 4; ++k) sample[k] = valid[k >> 1][k & 1] * next_uniform(e);
+  int ind = 0;
+  for (int k = 1; k < 4; ++k)
+    if (!isnan(sample[ind]) && (isnan(sample[k]) || sample[k] > sample[ind])) ind = k;
+  const double nv = (1 + MAZE_EPS) * speed * (2 * (ind & 1) - 1);
+  if (ind >> 1) vel[1] = nv; else vel[0] = nv;
+  maze_set_velocity(e, s, vel[0], vel[1]);
+}
+
+// maze_physics.py:48-109 _get_position_affordances (the position itself is returned unchanged)
+__device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[2][2]) {
+  PProg P = e.P;
+  const double gs = 1. / P->maze.size, half = 0.5 * gs;
+  long nearest[2], inds[2];
+  bool on[2];
+  for (int a = 0; a < 2; ++a) {
+    nearest[a] = np_rint_l(pos[a] / gs - 0.5);
+    const double rounded = half + nearest[a] * gs;
+    on[a] = fabs(rounded - pos[a]) < MAZE_EPS;
+    inds[a] = (long)np_floor_divide(pos[a] - half, gs);
+    if (on[a]) inds[a] = nearest[a];
+  }
+  aff[0][0] = aff[0][1] = aff[1][0] = aff[1][1] = 0;
+  if (!on[0] && !on[1]) {
+    wsync();
+    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_OFF_GRID;
+    wsync();
+    return false;
+  }
+  if (on[0] && on[1]) {
+    double v[2][2];
+    maze_valid_directions(P, inds[0], inds[1], v);
+    for (int a = 0; a < 2; ++a) { aff[a][0] = v[a][0] * gs * -1.; aff[a][1] = v[a][1] * gs * 1.; }
+  } else {
+    const int i = 1 - (on[0] ? 0 : 1);
+    aff[i][0] = inds[i] * gs + half - pos[i];
+    aff[i][1] = (inds[i] + 1) * gs + half - pos[i];
+  }
+  return true;
+}
+
+// maze_physics.py:111-163 _get_new_velocity: recursive in the reference (through a vertex the remainder of the step
+// is solved from the vertex's affordances); D bounds the depth (a step crosses at most a few vertices)
+template <int D>
+__device__ inline bool maze_new_velocity(Env& e, double pos[2], double v[2], double aff[2][2], int axis, double out[2]) {
+  if constexpr (D == 0) {
+    wsync();
+    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_OFF_GRID;
+    wsync();
+    out[0] = out[1] = 0;
+    return false;
+  } else {
+    if (axis < 0) axis = argmax_abs2(v);
+    if (aff[axis][0] <= v[axis] && v[axis] <= aff[axis][1]) {
+      v[1 - axis] = 0;
+      out[0] = v[0]; out[1] = v[1];
+      return true;
+    }
+    int direction = (int)(0.5 + 0.5 * np_sign(v[axis]));
+    if (aff[axis][direction] == 0) {
+      axis = 1 - axis;
+      direction = (int)(0.5 + 0.5 * np_sign(v[axis]));
+      if (aff[axis][direction] == 0 || v[axis] == 0) { out[0] = out[1] = 0; return true; }
+      return maze_new_velocity<D - 1>(e, pos, v, aff, axis, out);
+    }
+    pos[axis] += aff[axis][direction];
+    double vaff[2][2];
+    if (!maze_affordances(e, pos, vaff)) { out[0] = out[1] = 0; return false; }
+    const double scaling = aff[axis][direction] / v[axis];
+    double rem[2] = {(1. - scaling) * v[0], (1. - scaling) * v[1]};
+    double post[2];
+    if (!maze_new_velocity<D - 1>(e, pos, rem, vaff, -1, post)) { out[0] = out[1] = 0; return false; }
+    v[0] *= scaling; v[1] *= scaling;
+    v[1 - axis] = 0;
+    v[0] += post[0]; v[1] += post[1];
+    out[0] = v[0]; out[1] = v[1];
+    return true;
+  }
+}
+
+// sprite.py:531-540 angle setter: the cached path is rotated about the position (lanes = vertices)
+__device__ inline void rotate_path(Env& e, int s, double d_theta) {
+  const double a = cos(d_theta), b = sin(d_theta);
+  const double x = PX(s), y = PY(s);
+  const double tx = (a * (-x) - b * (-y)) + x;
+  const double ty = (b * (-x) + a * (-y)) + y;
+  double* v = VERT(s);
+  const int n = NV(s);
+  wsync();
+  for (int k = e.lane; k < n; k += 64) {
+    const double vx = v[2 * k], vy = v[2 * k + 1];
+    v[2 * k] = (a * vx + (-b) * vy) + tx;
+    v[2 * k + 1] = (b * vx + a * vy) + ty;
+  }
+  wsync();
+  bbox_exact_wave(e, s);
+}
+
+// maze_physics.py:186-203 _update_sprite_in_maze + :165-184 _update_sprite_angle
+__device__ inline void maze_update_sprite(Env& e, PCorr C, int s) {
+  double v[2] = {VELX(s), VELY(s)};
+  if ((v[0] == 0 && v[1] == 0) || isnan(v[0]) || isnan(v[1])) return;
+  const double max_speed = C->anchor[0], cspeed = C->speed;
+  if (!isnan(max_speed))
+    for (int a = 0; a < 2; ++a) v[a] = v[a] < -max_speed ? -max_speed : (v[a] > max_speed ? max_speed : v[a]);
+  if (!isnan(cspeed))
+    for (int a = 0; a < 2; ++a) { v[a] += np_sign(v[a]); v[a] *= cspeed; }
+  double pos[2] = {PX(s), PY(s)}, aff[2][2], nv[2];
+  if (!maze_affordances(e, pos, aff)) return;
+  set_position(e, s, pos[0], pos[1]);   // sprite.position = np.copy(position): a translation by zero
+  if (!maze_new_velocity<6>(e, pos, v, aff, -1, nv)) return;
+  double new_angle;
+  if (nv[0] == 0 && nv[1] == 0) new_angle = __builtin_nan("");
+  else if (nv[1] == 0) new_angle = -0.5 * np_sign(nv[0]) * 3.14159265358979323846;
+  else if (np_sign(nv[1]) > 0) new_angle = atan(-nv[0] / nv[1]);
+  else new_angle = 3.14159265358979323846 + atan(-nv[0] / nv[1]);
+  const double old_angle = ANG(s);
+  if (!isnan(new_angle) && fabs(new_angle - old_angle) > MAZE_EPS) {
+    rotate_path(e, s, new_angle - old_angle);
+    if (e.lane == 0) ANG(s) = new_angle;
+    wsync();
+  }
+  maze_set_velocity(e, s, nv[0], nv[1]);
+}
+
+// maze_physics.py:205-211 MazePhysics.apply_physics
+__device__ inline void maze_physics(Env& e, PCorr C) {
+  PProg P = e.P;
+  for (int a = 0; a < C->n_layers; ++a) {
+    const int l = C->layers[a];
+    for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
+      if (ALIVE(s)) maze_update_sprite(e, C, s);
+  }
+}
+
 // Collision force over (layer la) x (layer lb): the reference visits ordered pairs
 // (s0, s1), s0 outer, sequentially (physics.py:103-108) and every resolved contact
 // moves sprites, so later pairs must see the new state.  Broad phase: the flattened
@@ -1713,7 +1936,9 @@ __device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, in
   }
 }
 
-// physics.py:88-117 (one substep)
+// physics.py:88-117 (one substep).  DYN: the kernel variant that carries the rarely used components (here the maze
+// walk / MazePhysics, whose scratch frame must not weigh on the plain step kernel).
+template <bool DYN>
 __device__ inline void apply_physics(Env& e) {
   PProg P = e.P;
   const int K = uni(P->updates_per_env_step);
@@ -1725,11 +1950,14 @@ __device__ inline void apply_physics(Env& e) {
       int la = uni(F->layers_a[a]);
       int a0 = uni(P->layer_slot0[la]), a1 = a0 + uni(P->layer_nslots[la]);
       if (n_b == 0) {
-        if (kind != MOOG_FORCE_RANDOM && !uni(P->vel_alias)) {
+        if (kind != MOOG_FORCE_RANDOM && kind != MOOG_FORCE_MAZE_WALK && !uni(P->vel_alias)) {
           force_single_layer(e, F, a0, a1, K);
         } else {
           for (int s = a0; s < a1; ++s)
-            if (ALIVE(s)) force_single(e, F, s, K);
+            if (ALIVE(s)) {
+              if constexpr (DYN) { if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; } }
+              force_single(e, F, s, K);
+            }
         }
       } else {
         for (int b = 0; b < n_b; ++b) {
@@ -1756,6 +1984,7 @@ __device__ inline void apply_physics(Env& e) {
   const int n_corr = uni(P->n_corrective);
   for (int c = 0; c < n_corr; ++c) {
     if (P->corrective[c].kind == MOOG_CORR_CONSTANT_SPEED) constant_speed(e, &P->corrective[c]);
+    else if (P->corrective[c].kind == MOOG_CORR_MAZE) { if constexpr (DYN) maze_physics(e, &P->corrective[c]); }
     else tether(e, &P->corrective[c], c);
   }
   { PROF_T0; if (!(e.dbg & 2)) integrate_all(e, 1. / K); PROF_ADD(e, 5); }
@@ -2827,7 +3056,7 @@ __device__ inline void run_genop(Env& e, int oi) {
       sample_op_factors(e, op, fac, vel_f32, angvel_f32);
       create_sprite(e, s, fac, vel_f32, angvel_f32);
       bool ov = false;
-      for (int oj = 0; oj < oi && !ov; ++oj) {
+      for (int oj = 0; oj < oi && oj < 64 && !ov; ++oj) {
         if (!((op->avoid_ops >> oj) & 1)) continue;
         PGenop o2 = &P->ops[oj];
         ov = overlaps_any(e, s, o2->slot0, o2->slot0 + o2->count_max);

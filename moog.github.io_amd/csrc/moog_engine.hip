@@ -360,6 +360,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
+  for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->dynamic_rules = true;
+  for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->dynamic_rules = true;
   if (err == hipSuccess)
     err = (hipError_t)moog_configure_reset(e->step_lds);
   if (err == hipSuccess)

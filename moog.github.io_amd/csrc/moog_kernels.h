@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   PProg P = as_const_prog(a.P);
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
-    for (int k = 0; k < K; ++k) apply_physics(e);
+    for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     return;
   }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   }
   PROF_ADD(e, 10);
   }
-  { PROF_T0; for (int k = 0; k < K; ++k) apply_physics(e); PROF_ADD(e, 6); }
+  { PROF_T0; for (int k = 0; k < K; ++k) apply_physics<DYN>(e); PROF_ADD(e, 6); }
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();
   if (e.lane == 0) e.q[e.L.o_step_count] = sc;

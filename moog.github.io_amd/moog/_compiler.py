@@ -100,6 +100,20 @@ def _flatten_rules(rules, parent=-1, depth=0, out=None):
     return out
 
 
+def _reject_f32_velocity(state, layers, what):
+    """The maze components restate numpy's float64 arithmetic only: velocities sampled by Continuous are float32
+    arrays in the reference (distributions.py:81,99)."""
+    from .state_initialization import distributions as distribs
+    if not isinstance(layers, (list, tuple)):
+        layers = [layers]
+    for name in layers:
+        for sp in state[name]:
+            for k in ('x_vel', 'y_vel'):
+                f = sp.factors[k]
+                if isinstance(f, sprite_lib.SymbolicFactor) and isinstance(f.dist, distribs.Continuous):
+                    raise NotImplementedError('%s over sprites whose velocity is sampled by Continuous' % what)
+
+
 def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
                    meta_state_initializer=None, layer_capacity=None, keep_sprite_factors=False):
     # meta_state lives on the host (environment.py keeps it for `ModifyMetaState`)
@@ -231,6 +245,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 aj = op_index_of_sprite[id(a)]
                 if aj >= oi:
                     raise ValueError('without_overlapping refers to a later generator')
+                if aj >= 64:
+                    raise NotImplementedError('without_overlapping over more than the first 64 generation ops')
                 avoid |= (1 << aj)
         G.avoid_ops = avoid
         proto = sprites[0]
@@ -328,6 +344,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     P.updates_per_env_step = int(physics.updates_per_env_step)
     if len(physics._forces) > _abi.MOOG_MAX_FORCES:
         raise ValueError('too many forces')
+    maze_layers = set()   # wall layers the maze walks / MazePhysics infer their maze from
     for fi, entry in enumerate(physics._forces):
         force, args = entry[0], entry[1:]
         F = P.forces[fi]
@@ -357,6 +374,12 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             else:
                 F.kind = _abi.MOOG_FORCE_DISTANCE_SPRING
                 F.p0, F.p1 = fn.params['spring_constant'], fn.params['equilibrium']
+        elif isinstance(force, physics_lib.RandomMazeWalk):
+            F.kind, F.p0 = _abi.MOOG_FORCE_MAZE_WALK, force._speed
+            F.i0 = (int(bool(force._prevent_backtracking)) | (int(bool(force._allow_wall_backtracking)) << 1) |
+                    (int(bool(force._only_turn_at_wall)) << 2))
+            maze_layers.add(force._maze_layer)
+            _reject_f32_velocity(state, args[0], 'RandomMazeWalk')
         elif isinstance(force, physics_lib.Collision):
             pair = True
             F.kind = _abi.MOOG_FORCE_COLLISION
@@ -394,9 +417,30 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     if isinstance(m, sprite_lib.SymbolicFactor) or not isinstance(m, (int, float)):
                         raise NotImplementedError(
                             'tethered sprites must have constant Python-number masses')
+        elif isinstance(c, physics_lib.MazePhysics):
+            C.kind = _abi.MOOG_CORR_MAZE
+            C.n_layers = _fill_layers(C.layers, c._avatar_layers, layer_index)
+            C.speed = float('nan') if c._constant_speed is None else float(c._constant_speed)
+            C.anchor[0] = float('nan') if c._max_speed is None else float(c._max_speed)
+            maze_layers.add(c._maze_layer)
+            if physics.updates_per_env_step != 1:
+                raise ValueError('Must have updates_per_env_step be 1 for maze.')   # maze_physics.py:207-208
+            _reject_f32_velocity(state, c._avatar_layers, 'MazePhysics')
         else:
             raise NotImplementedError('corrective physics %r is not lowered' % (type(c).__name__,))
     P.n_corrective = len(physics._corrective_physics)
+    if maze_layers:
+        # Maze.from_state (maze.py:39-84) runs when the physics is reset; the wall layer is constant, so the
+        # matrix is inferred once, here
+        if len(maze_layers) != 1:
+            raise NotImplementedError('one maze layer per environment')
+        from . import maze_lib
+        mz = maze_lib.Maze.from_state(state, maze_layer=next(iter(maze_layers)))
+        if mz.maze_size > _abi.MOOG_MAX_MAZE:
+            raise NotImplementedError('mazes beyond %d x %d cells' % (_abi.MOOG_MAX_MAZE, _abi.MOOG_MAX_MAZE))
+        P.maze.size = int(mz.maze_size)
+        for j in range(mz.maze_size):
+            P.maze.rows[j] = int(sum(int(bool(mz.maze[j, i])) << i for i in range(mz.maze_size)))
 
     # ---- game rules ---------------------------------------------------------------
     if len(flat_rules) > _abi.MOOG_MAX_RULES:

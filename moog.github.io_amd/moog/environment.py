@@ -33,6 +33,7 @@ _FAULT_EXC = (
      'a rule appended to a layer whose slot capacity is used up (raise layer_capacity).'),
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
+    (_abi.MOOG_FAULT_OFF_GRID, ValueError, 'Object is not on the maze grid.'),
 )
 
 

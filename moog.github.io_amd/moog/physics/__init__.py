@@ -139,6 +139,40 @@ class TetherZippedLayers(Tether):
     layers must hold the same number of sprites (ValueError otherwise)."""
 
 
+class MazePhysics(AbstractPhysics):
+    """Constrains the sprites of `avatar_layers` to the corridors of the maze drawn by the wall sprites of
+    `maze_layer` (maze_physics.py:18-211); used as the last corrective physics of a Physics."""
+
+    def __init__(self, maze_layer='walls', avatar_layers=(), constant_speed=None, max_speed=None):
+        super(MazePhysics, self).__init__(updates_per_env_step=1)
+        self._maze_layer = maze_layer
+        if not isinstance(avatar_layers, (list, tuple)):
+            avatar_layers = [avatar_layers]
+        self._avatar_layers = list(avatar_layers)
+        self._constant_speed = constant_speed
+        self._max_speed = max_speed
+
+
+class AbstractMazeWalk(AbstractForce):
+    """maze_walk.py:17-93"""
+
+    def __init__(self, speed, maze_layer='walls'):
+        self._speed = speed
+        self._maze_layer = maze_layer
+
+
+class RandomMazeWalk(AbstractMazeWalk):
+    """Sprites walk the maze at constant speed and turn at random at corners and intersections
+    (maze_walk.py:96-193)."""
+
+    def __init__(self, speed, maze_layer='walls', prevent_backtracking=True, allow_wall_backtracking=False,
+                 only_turn_at_wall=False):
+        super(RandomMazeWalk, self).__init__(speed, maze_layer=maze_layer)
+        self._prevent_backtracking = prevent_backtracking
+        self._allow_wall_backtracking = allow_wall_backtracking
+        self._only_turn_at_wall = only_turn_at_wall
+
+
 class Physics(AbstractPhysics):
     def __init__(self, *forces, updates_per_env_step=1, corrective_physics=()):
         super(Physics, self).__init__(updates_per_env_step=updates_per_env_step)

@@ -93,8 +93,16 @@ def _binomial(n, p, size=None):
     return int(TAPE.u() < p)
 
 
+def _rand(*shape):
+    """np.random.rand(d0, d1, ...): one tape uniform per element, row-major."""
+    if not shape:
+        return TAPE.u()
+    return np.array([TAPE.u() for _ in range(int(np.prod(shape)))]).reshape(shape)
+
+
 def patch_numpy_random():
     np.random.uniform = _uniform
+    np.random.rand = _rand
     np.random.choice = _choice
     np.random.randint = _randint
     np.random.binomial = _binomial
@@ -641,6 +649,8 @@ def main():
         ('first_person_predators_prey', 70, {'prey': 16, 'predators': 40, '__vmax__': SNAP_VMAX,
                                              '__dynamic__': ('prey', 'predators')}, (0,)),
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
+        ('maze_zoo', 120, {}, (0, 1)),
+        ('maze_zoo_l1', 120, {}, (0,)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),
