@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 16
+#define MOOG_ABI_VERSION 17
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -38,10 +38,10 @@ extern "C" {
 #define MOOG_MAX_OPS 256
 #define MOOG_MAX_SHAPES 256
 #define MOOG_MAX_SHAPE_VERTS 2048
-#define MOOG_MAX_CAND 128
+#define MOOG_MAX_CAND 256
 #define MOOG_MAX_DCODE 512
 #define MOOG_X_STACK 16
-#define MOOG_MAX_SLOTS 128
+#define MOOG_MAX_SLOTS 256
 #define MOOG_MAX_ACTIONS 4
 #define MOOG_MAX_MORE_ACTIONS 3 /* MOOG_MAX_ACTIONS - 1 */
 #define MOOG_NUM_FACTORS 14
@@ -75,6 +75,8 @@ extern "C" {
 /* MazePhysics: an avatar is on no grid line of the maze (maze_physics.py:87-97 raises ValueError) */
 #define MOOG_FAULT_OFF_GRID 256
 #define MOOG_MAX_MAZE 32
+#define MOOG_MAX_MAZE_POINTS 8 /* cells of one sample_distinct_open_points() call */
+#define MOOG_MAX_MAZE_GEN 16   /* size of a maze drawn on the device (its frontier list holds size^2 one-byte cells) */
 
 /* ---- sprite flag bits (i32 record, o_flags[slot]) ------------------------ */
 #define MOOG_F_ALIVE 1
@@ -92,7 +94,22 @@ enum {
 
 /* factor distribution kinds (state_initialization/distributions.py).  TREE: the
  * factor is written by the op's distribution program (moog_dinstr_t below). */
-enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2, MOOG_DIST_TREE = 3 };
+enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2, MOOG_DIST_TREE = 3,
+       /* factors of a sprite placed on a cell (i, j) of the per-episode random maze (pacman.py:40-65), see
+        * moog_genop_t.cell_sel.  MAZE_COORD: cand[cand_off + (n_cand ? j : i)] -- the config's arithmetic on the
+        * cell index (`grid_side * (0.5 + index)`), tabulated on the host for every index.  MAZE_SHAPE: shape id
+        * a + j * N + i, the wall square of cell (row i, column j) (maze.py:98-111)                          */
+       MOOG_DIST_MAZE_COORD = 4, MOOG_DIST_MAZE_SHAPE = 5 };
+/* moog_genop_t.cell_sel: which maze cell (row i, column j of Maze.maze) a one-sprite op is placed on.  The op's
+ * slot stays dead when the maze has fewer such cells.  GENERATE / SAMPLE are ops without sprites.           */
+enum {
+  MOOG_CELL_NONE = 0,
+  MOOG_CELL_GENERATE,   /* maze_generators.py:96-171 generate_random_maze_matrix -> the record's maze rows */
+  MOOG_CELL_SAMPLE,     /* maze.py:200-214 sample_distinct_open_points(cell_arg) -> the record's point words */
+  MOOG_CELL_SAMPLED,    /* the cell_arg-th point of that sample                                            */
+  MOOG_CELL_OPEN_RANK,  /* the cell_arg-th open cell in np.argwhere order (rows outer; pacman.py:62-65)     */
+  MOOG_CELL_WALL_RANK   /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
+};
 
 /* Distribution programs.  A factor distribution that is not a flat Product of
  * Continuous / Discrete / constants (distributions.py:159-420: Mixture, Intersection,
@@ -183,6 +200,8 @@ typedef struct {
   int32_t code_off;     /* distribution program in program.dcode, or -1       */
   int32_t runtime;      /* 1: run by a CREATE_SPRITES rule, not at reset; slot0
                          * is unused (sprites are appended to the rule's layer) */
+  int32_t cell_sel;     /* MOOG_CELL_*                                        */
+  int32_t cell_arg;
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;
 
@@ -376,7 +395,11 @@ typedef struct {
  *      sprites when they are reset (Maze.from_state, maze.py:39-84) ------------------------------------- */
 typedef struct {
   int32_t size;                    /* N: the maze is N x N cells (0: the program has no maze)      */
-  int32_t pad_;
+  int32_t random;                  /* 1: the matrix is drawn at every reset (a MOOG_CELL_GENERATE op) and lives in
+                                    * the env's record (o_maze); `rows` is unused                  */
+  int32_t gen_size;                /* random: `size` argument of generate_random_maze_matrix, centred in the
+                                    * N x N ambient matrix of walls (maze_generators.py:160-167)   */
+  int32_t flip;                    /* random: np.flip(matrix, axis=0) before use (pacman.py:42)     */
   uint32_t rows[MOOG_MAX_MAZE];    /* rows[j] bit i = Maze.maze[j, i] (1 = wall)                    */
 } moog_maze_t;
 
@@ -474,6 +497,8 @@ typedef struct {
   int32_t o_reset_next;
   int32_t o_fault;
   int32_t o_rng;      /* [4] rng draw counter lo/hi, injected cursor, spare    */
+  int32_t o_maze;     /* [MOOG_MAX_MAZE] rows of the episode's maze as in moog_maze_t.rows, then
+                       * [MOOG_MAX_MAZE_POINTS] sampled cells (i << 8 | j); -1 unless maze.random */
 } moog_layout_t;
 
 static inline int32_t moog_align_(int32_t x, int32_t a) { return (x + a - 1) / a * a; }
@@ -509,6 +534,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_reset_next = o; o += 1;
   L->o_fault = o; o += 1;
   L->o_rng = o; o += 4;
+  if (p->maze.random) { L->o_maze = o; o += MOOG_MAX_MAZE + MOOG_MAX_MAZE_POINTS; } else L->o_maze = -1;
   L->i32_per_env = moog_align_(o, 4);          /* 16-byte multiple */
 }
 

@@ -66,6 +66,7 @@ struct Env {
   double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   unsigned cur_fmask;      // float32 factors of the sprite being created
+  int cell_i, cell_j;      // maze cell (row, column) of the sprite being created (MOOG_CELL_* ops)
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -1551,15 +1552,19 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
 #define MAZE_EPS 1e-5   // maze_physics.py:15, maze_walk.py:14
 
 // maze.py:107-112 open_vertex(i, j): inside the matrix and not a wall (maze[j, i])
-__device__ __forceinline__ int maze_open(PProg P, long i, long j) {
-  const int n = P->maze.size;
+// row j of the maze: a program constant, or (a maze drawn per reset) part of the env's record
+__device__ __forceinline__ uint32_t maze_row(const Env& e, int j) {
+  return e.P->maze.random ? (uint32_t)e.q[e.L.o_maze + j] : e.P->maze.rows[j];
+}
+__device__ __forceinline__ int maze_open(const Env& e, long i, long j) {
+  const int n = e.P->maze.size;
   if (i < 0 || j < 0 || i >= n || j >= n) return 0;
-  return !((P->maze.rows[j] >> i) & 1u);
+  return !((maze_row(e, (int)j) >> i) & 1u);
 }
 // maze.py:114-120 valid_directions: [[open(i-1, j), open(i+1, j)], [open(i, j-1), open(i, j+1)]]
-__device__ inline void maze_valid_directions(PProg P, long i, long j, double v[2][2]) {
-  v[0][0] = maze_open(P, i - 1, j); v[0][1] = maze_open(P, i + 1, j);
-  v[1][0] = maze_open(P, i, j - 1); v[1][1] = maze_open(P, i, j + 1);
+__device__ inline void maze_valid_directions(const Env& e, long i, long j, double v[2][2]) {
+  v[0][0] = maze_open(e, i - 1, j); v[0][1] = maze_open(e, i + 1, j);
+  v[1][0] = maze_open(e, i, j - 1); v[1][1] = maze_open(e, i, j + 1);
 }
 // numpy floor_divide on doubles (npy_divmod)
 __device__ inline double np_floor_divide(double a, double b) {
@@ -1602,7 +1607,7 @@ __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
   const bool entering = d_next_cur > d_int_cur && d_next_cur > d_int_next;
   double valid[2][2];
   if (entering) {
-    maze_valid_directions(P, n0, n1, valid);
+    maze_valid_directions(e, n0, n1, valid);
     if (F->i0 & 1) {   // :121-147 _update_valid_directions
       const int axis = argmax_abs2(vel);
       const double direction = np_sign(vel[axis]);
@@ -1619,7 +1624,7 @@ __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
   } else if (vel[0] == 0. && vel[1] == 0.) {
     const double rx = half + n0 * gs, ry = half + n1 * gs;
     const bool on0 = fabs(rx - px) < MAZE_EPS, on1 = fabs(ry - py) < MAZE_EPS;
-    if (on0 && on1) maze_valid_directions(P, n0, n1, valid);
+    if (on0 && on1) maze_valid_directions(e, n0, n1, valid);
     else {
       valid[0][0] = valid[0][1] = valid[1][0] = valid[1][1] = 0;
       const int row = 1 - (on0 ? 0 : (on1 ? 1 : 0));   // 1 - np.argmax(on_grid)
@@ -1662,7 +1667,7 @@ __device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[
   }
   if (on[0] && on[1]) {
     double v[2][2];
-    maze_valid_directions(P, inds[0], inds[1], v);
+    maze_valid_directions(e, inds[0], inds[1], v);
     for (int a = 0; a < 2; ++a) { aff[a][0] = v[a][0] * gs * -1.; aff[a][1] = v[a][1] * gs * 1.; }
   } else {
     const int i = 1 - (on[0] ? 0 : 1);
@@ -2873,6 +2878,14 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
 
 __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
+  if (op->cell_sel != MOOG_CELL_NONE) {   // factors read off the maze cell the sprite sits on (pacman.py:47-65, maze.py:98-111)
+#pragma unroll
+    for (int k = 0; k < MOOG_NUM_FACTORS; ++k) {
+      PFactor F = &op->factors[k];
+      if (F->kind == MOOG_DIST_MAZE_COORD) fac[k] = e.P->cand[F->cand_off + (F->n_cand ? e.cell_j : e.cell_i)];
+      else if (F->kind == MOOG_DIST_MAZE_SHAPE) fac[k] = F->a + (double)(e.cell_j * e.P->maze.size + e.cell_i);
+    }
+  }
   // every sampled factor of a flat Product takes exactly one draw, in sample order: all of them at once
   int ndraw = 0;
   for (int k = 0; k < op->n_sampled; ++k) {
@@ -3036,11 +3049,185 @@ __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& ve
   e.cur_fmask = m;
 }
 
+// ---- the per-episode random maze of pacman.py:39-65 (see the oracle for the line-by-line citations) --------
+// Wave-uniform scalar code: every lane runs it redundantly on the same LDS scratch (the bit-matrix words of the
+// same-layer collision scan, free during a reset); a wave's LDS operations complete in order, so plain stores
+// followed by loads need no barrier.  Draws are fetched up to 64 at a time (one Philox latency per batch).
+// maze_generators.py:96-171 generate_random_maze_matrix + np.flip(axis=0) -> rows in the record.
+__device__ inline void maze_generate(Env& e) {
+  PProg P = e.P;
+  const int n = P->maze.gen_size, N = P->maze.size;
+  uint32_t* m = reinterpret_cast<uint32_t*>(e.rowm);   // [16] row masks of the size x size matrix (bit b of row a = wall)
+  uint32_t* inl = m + MOOG_MAX_MAZE_GEN;               // [16] "is in closed_neighbors"
+  uint8_t* list = reinterpret_cast<uint8_t*>(inl + MOOG_MAX_MAZE_GEN);   // [256] closed_neighbors as a << 4 | b
+  const uint32_t full = (n >= 32) ? 0xffffffffu : ((1u << n) - 1u);
+  for (;;) {   // a maze without open cells is drawn again (:154-156)
+    int nlist = 0;
+    for (int a = 0; a < MOOG_MAX_MAZE_GEN; ++a) { m[a] = full; inl[a] = 0u; }
+    const double d2 = next_uniforms_lanes(e, 2);   // randint(0, size, size=(2,)) (:143)
+    int pi = (int)(shfl_d(d2, 0) * n), pj = (int)(shfl_d(d2, 1) * n);
+    if (pi >= n) pi = n - 1;
+    if (pj >= n) pj = n - 1;
+    for (;;) {
+      // _open_point (:118-123): closed neighbours join the list once (order: up, down, left, right), then the point opens
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int a = pi + (d == 0 ? -1 : (d == 1 ? 1 : 0)), b = pj + (d == 2 ? -1 : (d == 3 ? 1 : 0));
+        if (a < 0 || b < 0 || a >= n || b >= n) continue;
+        if (((m[a] >> b) & 1u) && !((inl[a] >> b) & 1u)) { inl[a] |= 1u << b; list[nlist++] = (uint8_t)(a << 4 | b); }
+      }
+      m[pi] &= ~(1u << pj);
+      // _find_and_open_new_point (:125-140): np.random.shuffle(list) = for i = n - 1 .. 1: j = int(u * (i + 1)); swap
+      for (int hi = nlist - 1; hi > 0; hi -= 64) {
+        const int cnt = hi < 64 ? hi : 64;
+        const double draws = next_uniforms_lanes(e, cnt);
+        for (int t = 0; t < cnt; ++t) {
+          const int i = hi - t;
+          int j = (int)(shfl_d(draws, t) * (i + 1));
+          if (j > i) j = i;
+          const uint8_t vi = list[i], vj = list[j];
+          list[i] = vj; list[j] = vi;
+        }
+      }
+      bool found = false;
+      for (int k = 0; k < nlist && !found; ++k) {
+        const int a = list[k] >> 4, b = list[k] & 15;
+        if (!((m[a] >> b) & 1u)) continue;
+        // would opening (a, b) complete an open 2 x 2 block?  rows a-1, a, a+1 around columns b-1 .. b+1 (:45-57)
+        const uint32_t up = a > 0 ? m[a - 1] : full, mid = m[a], dn = a + 1 < n ? m[a + 1] : full;
+        bool will = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ba = a - 1 + (q >> 1), bb = b - 1 + (q & 1);
+          if (ba < 0 || bb < 0 || ba + 1 >= n || bb + 1 >= n) continue;
+          const uint32_t r0 = (q >> 1) ? mid : up, r1 = (q >> 1) ? dn : mid;
+          const int sum = (int)((r0 >> bb) & 1u) + (int)((r0 >> (bb + 1)) & 1u) + (int)((r1 >> bb) & 1u) +
+                          (int)((r1 >> (bb + 1)) & 1u);
+          will = will || sum <= 1;
+        }
+        if (!will) { pi = a; pj = b; found = true; }
+      }
+      if (!found) break;
+    }
+    // _remove_dead_ends (:62-93): close the first open cell (row-major) with fewer than two open neighbours, repeat
+    for (bool again = true; again;) {
+      again = false;
+      for (int a = 0; a < n && !again; ++a) {
+        const uint32_t up = a > 0 ? m[a - 1] : full, mid = m[a], dn = a + 1 < n ? m[a + 1] : full;
+        for (int b = 0; b < n && !again; ++b) {
+          if ((mid >> b) & 1u) continue;
+          int open = (int)(!((up >> b) & 1u)) + (int)(!((dn >> b) & 1u));
+          if (b > 0) open += (int)(!((mid >> (b - 1)) & 1u));
+          if (b + 1 < n) open += (int)(!((mid >> (b + 1)) & 1u));
+          if (open < 2) { m[a] = mid | (1u << b); again = true; }
+        }
+      }
+    }
+    uint32_t any_open = 0u;
+    for (int a = 0; a < n; ++a) any_open |= ~m[a] & full;
+    if (any_open) break;
+  }
+  // wall border (:159-167), flip, rows to the record
+  const int start = N > n ? (N - n) / 2 : 0;
+  const uint32_t fullN = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+  for (int r = 0; r < N; ++r) {
+    const int a = (P->maze.flip ? N - 1 - r : r) - start;
+    uint32_t bits = fullN;
+    if (a >= 0 && a < n) bits = (fullN & ~(full << start)) | ((m[a] & full) << start);
+    if (e.lane == 0) e.q[e.L.o_maze + r] = (int32_t)bits;
+  }
+  wsync();
+}
+
+// k-th (0-based) open cell of the maze in np.argwhere order (rows outer); -1 when there are fewer
+__device__ inline int maze_open_cell(const Env& e, int k) {
+  const int N = e.P->maze.size;
+  const uint32_t fullN = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+  for (int i = 0; i < N; ++i) {
+    uint32_t open = ~maze_row(e, i) & fullN;
+    const int c = __popc(open);
+    if (k < c) {
+      for (; k > 0; --k) open &= open - 1u;
+      return i << 8 | (__ffs((int)open) - 1);
+    }
+    k -= c;
+  }
+  return -1;
+}
+
+// maze.py:200-214 sample_distinct_open_points(k): the first k steps of a forward Fisher-Yates shuffle of the open
+// cells' ranks (make_golden.py _choice): the permutation is tracked as the few displaced entries only
+__device__ inline void maze_sample_points(Env& e, int k) {
+  const int N = e.P->maze.size;
+  const uint32_t fullN = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
+  int n = 0;
+  for (int i = 0; i < N; ++i) n += __popc(~maze_row(e, i) & fullN);
+  const int kk = k < MOOG_MAX_MAZE_POINTS ? k : MOOG_MAX_MAZE_POINTS;
+  const int nd = kk < n ? kk : n;
+  const double draws = nd > 0 ? next_uniforms_lanes(e, nd) : 0.0;
+  int moved_pos[MOOG_MAX_MAZE_POINTS], moved_val[MOOG_MAX_MAZE_POINTS];   // perm[pos] = val where it differs from pos
+#pragma unroll
+  for (int t = 0; t < MOOG_MAX_MAZE_POINTS; ++t) {
+    if (t >= kk) break;
+    int point = -1;
+    if (t < n) {
+      int j = t + (int)(shfl_d(draws, t) * (n - t));
+      if (j >= n) j = n - 1;
+      // value at j (after the earlier swaps), value at t
+      int vj = j, vt = t;
+#pragma unroll
+      for (int q = 0; q < MOOG_MAX_MAZE_POINTS; ++q)
+        if (q < t) { if (moved_pos[q] == j) vj = moved_val[q]; if (moved_pos[q] == t) vt = moved_val[q]; }
+      // perm[t] <-> perm[j]: position t is never read again; position j now holds vt
+      bool upd = false;
+#pragma unroll
+      for (int q = 0; q < MOOG_MAX_MAZE_POINTS; ++q)
+        if (q < t && moved_pos[q] == j) { moved_val[q] = vt; upd = true; }
+      moved_pos[t] = upd ? -1 : j; moved_val[t] = vt;
+      point = maze_open_cell(e, vj);
+    } else { moved_pos[t] = -1; moved_val[t] = 0; }
+    if (e.lane == 0) e.q[e.L.o_maze + MOOG_MAX_MAZE + t] = point;
+  }
+  wsync();
+}
+
+// the cell a one-sprite op sits on; false when the maze has no such cell (the slot stays dead)
+__device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
+  int p = -1;
+  if (sel == MOOG_CELL_SAMPLED) p = e.q[e.L.o_maze + MOOG_MAX_MAZE + arg];
+  else if (sel == MOOG_CELL_OPEN_RANK) p = maze_open_cell(e, arg);   // np.argwhere(maze.maze == 0), pacman.py:62
+  else {   // Maze.to_sprites: x (column) outer, y (row) inner, maze.py:101-103
+    const int N = e.P->maze.size;
+    int seen = 0;
+    for (int j = 0; j < N && p < 0; ++j) {
+      uint32_t col = 0u;
+      for (int i = 0; i < N; ++i) col |= ((maze_row(e, i) >> j) & 1u) << i;
+      const int c = __popc(col);
+      if (arg - seen < c) {
+        for (int k = arg - seen; k > 0; --k) col &= col - 1u;
+        p = (__ffs((int)col) - 1) << 8 | j;
+      }
+      seen += c;
+    }
+  }
+  if (p < 0) return false;
+  e.cell_i = p >> 8; e.cell_j = p & 255;
+  return true;
+}
+
+template <bool DYN>
 __device__ inline void run_genop(Env& e, int oi) {
   PProg P = e.P;
   PGenop op = &P->ops[oi];
   if (op->runtime) return;   // CreateSprites generators run at rule time
-  const int n = genop_count(e, op);
+  if constexpr (DYN) {
+    if (op->cell_sel == MOOG_CELL_GENERATE) { maze_generate(e); return; }
+    if (op->cell_sel == MOOG_CELL_SAMPLE) { maze_sample_points(e, op->cell_arg); return; }
+  }
+  int n = genop_count(e, op);
+  if constexpr (DYN) {
+    if (op->cell_sel != MOOG_CELL_NONE && !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
+  }
   for (int k = 0; k < op->count_max; ++k) {
     int s = op->slot0 + k;
     if (k >= n) {
@@ -3078,6 +3265,7 @@ __device__ inline void run_genop(Env& e, int oi) {
 }
 
 // environment.py:82-96
+template <bool DYN>
 __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
@@ -3085,7 +3273,7 @@ __device__ inline void env_reset(Env& e) {
   __threadfence();
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();
-  for (int oi = 0; oi < P->n_ops; ++oi) run_genop(e, oi);
+  for (int oi = 0; oi < P->n_ops; ++oi) run_genop<DYN>(e, oi);
   __threadfence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {

@@ -130,8 +130,18 @@ static int validate(const moog_program_t* p) {
   if (p->updates_per_env_step < 1) return fail(MOOG_E_INVALID, "updates_per_env_step < 1");
   for (int s = 0; s < p->n_slots; ++s)
     if (p->slot_vcap[s] > 128) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 128 vertices");
-  for (int l = 0; l < p->n_layers; ++l)
-    if (p->layer_nslots[l] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer too large");
+  // the pairwise forces (collisions, gravity, springs) scan a layer pair's candidates 64 / 128 at a time
+  for (int f = 0; f < p->n_forces; ++f) {
+    const moog_force_t* F = &p->forces[f];
+    if (F->n_b <= 0) continue;
+    for (int k = 0; k < F->n_a; ++k)
+      if (p->layer_nslots[F->layers_a[k]] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer of a pairwise force too large");
+    for (int k = 0; k < F->n_b; ++k)
+      if (p->layer_nslots[F->layers_b[k]] > 64 * 2) return fail(MOOG_E_UNSUPPORTED, "layer of a pairwise force too large");
+  }
+  if (p->maze.random && (p->maze.gen_size < 1 || p->maze.gen_size > MOOG_MAX_MAZE_GEN || p->maze.size < p->maze.gen_size ||
+                         p->maze.size > MOOG_MAX_MAZE))
+    return fail(MOOG_E_UNSUPPORTED, "random maze size unsupported");
   {
     const int aa = p->render.aa > 1 ? p->render.aa : 1;
     const long long cw = (long long)aa * p->render.width, ch = (long long)aa * p->render.height;
@@ -362,6 +372,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
   for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->dynamic_rules = true;
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->dynamic_rules = true;
+  if (prog->maze.random) e->dynamic_rules = true;   // the maze generator is compiled into the rare-components variants only
   if (err == hipSuccess)
     err = (hipError_t)moog_configure_reset(e->step_lds);
   if (err == hipSuccess)

@@ -40,6 +40,7 @@ __host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
   if (G.o_valias >= 0) h.L.o_valias -= ic;
   if (G.o_fmask >= 0) h.L.o_fmask -= ic;
   h.L.o_step_count -= ic; h.L.o_reset_next -= ic; h.L.o_fault -= ic; h.L.o_rng -= ic;
+  if (G.o_maze >= 0) h.L.o_maze -= ic;
   h.L.i32_per_env -= ic;
   return h;   // o_color / o_opacity / o_shape keep their values: valid in LDS when nothing was cut
 }
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   load_record(e, a.H, a.L, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
-  env_reset(e);
+  env_reset<true>(e);
   wsync();
   if (e.lane == 0) {
     e.q[e.L.o_reset_next] = 0;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   wsync();
 #ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
   if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
-    env_reset(e);
+    env_reset<DYN>(e);
     wsync();
     if (e.lane == 0) {
       e.q[e.L.o_reset_next] = 0;

@@ -217,10 +217,40 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     cand_n = 0
     vcap = [0] * S
     op_max_nv = {}
+    # the per-reset random maze (maze_lib/_traced.py): its matrix lives in the env records
+    from .maze_lib import _traced as traced_maze
+    wall_shape0 = None
+    coord_tables = {}   # tuple(table) -> offset in program.cand
+    if tr.maze is not None:
+        if tr.maze['flip'] is None:
+            raise NotImplementedError('a random maze matrix that no Maze(...) wraps')
+        P.maze.size, P.maze.random = tr.maze['ambient'], 1
+        P.maze.gen_size, P.maze.flip = tr.maze['gen_size'], int(tr.maze['flip'])
+        if 'walls' in tr.maze:   # the wall squares of all cells, column-major like Maze.to_sprites (maze.py:98-111)
+            n = P.maze.size
+            v = np.linspace(0., 1., n + 1)
+            for x in range(n):
+                for y in range(n):
+                    sid = shapes.intern(np.array([[v[x], v[y]], [v[x], v[y + 1]], [v[x + 1], v[y + 1]],
+                                                  [v[x + 1], v[y]]]))
+                    if wall_shape0 is None:
+                        wall_shape0 = sid
+                    if sid != wall_shape0 + x * n + y:
+                        raise NotImplementedError('maze wall squares that coincide with other shapes of the config')
     for oi, (op, sprites) in enumerate(ops):
         G = P.ops[oi]
         runtime = oi >= n_reset_ops
         G.runtime = int(runtime)
+        if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE: randomness, no sprite
+            G.cell_sel, G.cell_arg = op.cell
+            G.code_off = -1
+            op_max_nv[oi] = 0
+            continue
+        cell = traced_maze.cell_of(sprites[0])
+        if cell is not None:
+            if len(sprites) != 1 or runtime:
+                raise NotImplementedError('generators over maze cells')
+            G.cell_sel, G.cell_arg = cell
         if runtime:
             slots = []
             if op.avoid:
@@ -250,7 +280,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 avoid |= (1 << aj)
         G.avoid_ops = avoid
         proto = sprites[0]
-        order = list(proto.sample_order)
+        order = [k for k in proto.sample_order   # factors read off a maze cell take no draw
+                 if not isinstance(proto.factors[k], (traced_maze.CellShape, traced_maze.CellIndex))]
         G.n_sampled = len(order)
         max_nv = 0
         G.code_off = -1
@@ -276,7 +307,24 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             if fname in tree_keys:
                 F.kind = _abi.MOOG_DIST_TREE
                 continue
-            if isinstance(val, sprite_lib.SymbolicFactor):
+            if isinstance(val, traced_maze.CellShape):
+                if fname != 'shape':
+                    raise NotImplementedError('a maze wall square as factor %r' % (fname,))
+                F.kind, F.a = _abi.MOOG_DIST_MAZE_SHAPE, float(wall_shape0)
+                max_nv = max(max_nv, 4)
+            elif isinstance(val, traced_maze.CellIndex):
+                if fname in ('shape', 'opacity'):
+                    raise NotImplementedError('a maze cell index as factor %r' % (fname,))
+                table = tuple(val.table(P.maze.size))
+                if table not in coord_tables:
+                    if cand_n + len(table) > _abi.MOOG_MAX_CAND:
+                        raise ValueError('too many Discrete candidates')
+                    coord_tables[table] = cand_n
+                    for c in table:
+                        P.cand[cand_n] = c
+                        cand_n += 1
+                F.kind, F.n_cand, F.cand_off = _abi.MOOG_DIST_MAZE_COORD, int(val.axis), coord_tables[table]
+            elif isinstance(val, sprite_lib.SymbolicFactor):
                 d = val.dist
                 if isinstance(d, distribs.Continuous):
                     F.kind = _abi.MOOG_DIST_CONTINUOUS
@@ -435,12 +483,20 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if len(maze_layers) != 1:
             raise NotImplementedError('one maze layer per environment')
         from . import maze_lib
-        mz = maze_lib.Maze.from_state(state, maze_layer=next(iter(maze_layers)))
-        if mz.maze_size > _abi.MOOG_MAX_MAZE:
-            raise NotImplementedError('mazes beyond %d x %d cells' % (_abi.MOOG_MAX_MAZE, _abi.MOOG_MAX_MAZE))
-        P.maze.size = int(mz.maze_size)
-        for j in range(mz.maze_size):
-            P.maze.rows[j] = int(sum(int(bool(mz.maze[j, i])) << i for i in range(mz.maze_size)))
+        wall_layer = next(iter(maze_layers))
+        if tr.maze is not None:
+            # the walls are the traced maze's own squares, so Maze.from_state would give its matrix back: the
+            # smallest N with every wall vertex on the 1 / N lattice is the ambient size (a wall square has a
+            # corner at an odd multiple of 1 / N), and a cell centre lies in a wall iff the cell is a wall
+            if [id(sp) for sp in state[wall_layer]] != [id(sp) for sp in tr.maze.get('walls', ())]:
+                raise NotImplementedError('a maze layer that is not Maze(random matrix).to_sprites()')
+        else:
+            mz = maze_lib.Maze.from_state(state, maze_layer=wall_layer)
+            if mz.maze_size > _abi.MOOG_MAX_MAZE:
+                raise NotImplementedError('mazes beyond %d x %d cells' % (_abi.MOOG_MAX_MAZE, _abi.MOOG_MAX_MAZE))
+            P.maze.size = int(mz.maze_size)
+            for j in range(mz.maze_size):
+                P.maze.rows[j] = int(sum(int(bool(mz.maze[j, i])) << i for i in range(mz.maze_size)))
 
     # ---- game rules ---------------------------------------------------------------
     if len(flat_rules) > _abi.MOOG_MAX_RULES:

@@ -31,6 +31,7 @@ class Tracer(object):
         self.ops = []               # GenOp, in randomness-consumption order
         self.op_of = {}             # id(sprite) -> (op, k)
         self.randint_calls = []
+        self.maze = None            # the per-reset random maze of the initializer (maze_lib/_traced.py)
 
     def add_op(self, op):
         self.ops.append(op)

@@ -2,6 +2,7 @@
 import numpy as np
 
 from .. import sprite as sprite_lib
+from . import _traced
 
 _EPSILON = 1e-4       # maze.py:12: tolerance when testing wall vertices against multiples of 1 / N
 _MAX_MAZE_SIZE = 100  # maze.py:16
@@ -44,6 +45,8 @@ class Maze(object):
         self.grid_side = 1. / self.maze_size
         self.half_grid_side = 0.5 * self.grid_side
         self.side_vertices = np.linspace(self.half_grid_side, 1. - self.half_grid_side, self.maze_size)
+        if isinstance(maze, _traced.TracedMatrix):   # a maze drawn per reset on the device (pacman.py:40-42)
+            _traced.bind(self)
 
     @classmethod
     def from_state(cls, state, maze_layer='walls'):
@@ -68,6 +71,8 @@ class Maze(object):
 
     def to_sprites(self, **color):
         """One square sprite per wall cell, columns outer, rows inner (maze.py:86-105)."""
+        if isinstance(self.maze, _traced.TracedMatrix):
+            return _traced.wall_sprites(self, color)
         n = self.maze_size
         v = np.linspace(0., 1., n + 1)
         out = []
@@ -126,6 +131,8 @@ class Maze(object):
 
     def sample_distinct_open_points(self, num_points):
         """`num_points` different open cells (maze.py:194-208)."""
+        if isinstance(self.maze, _traced.TracedMatrix):
+            return _traced.sample_points(self, num_points)
         if np.sum(1 - self.maze) < num_points:
             raise ValueError('Maze has no open point.')
         cells = np.argwhere(self.maze == 0)

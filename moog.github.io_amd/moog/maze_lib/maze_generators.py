@@ -45,7 +45,12 @@ def _fill_dead_ends(maze):
 
 def generate_random_maze_matrix(size, ambient_size=None):
     """A connected maze of `size` x `size` cells grown from a random cell (maze_generators.py:96-162), embedded in
-    an `ambient_size` matrix of walls when that is larger."""
+    an `ambient_size` matrix of walls when that is larger.  Inside a traced state_initializer the matrix is drawn on
+    the device at every reset and a symbolic stand-in is returned (maze_lib/_traced.py)."""
+    from .. import _trace
+    if _trace.active() is not None:
+        from . import _traced
+        return _traced.generate(size, ambient_size)
     maze = np.ones((size, size))
     frontier = []   # walls next to open cells
 

@@ -20,7 +20,9 @@ Randomness: the reference draws from numpy's global MT19937.  To
 make runs reproducible by an engine with a different generator, np.random.uniform
 / choice / randint are replaced by equivalents that consume one recorded uniform
 u in [0,1) each: uniform = low + (high-low)*u (numpy's own formula),
-binomial(1, p) = int(u < p), choice(n) = int(u*n), choice(n, p) = searchsorted(cumsum(p)/sum(p), u, 'right') (numpy's
+binomial(1, p) = int(u < p), rand(shape) = one u per element, shuffle(list) = numpy's backward Fisher-Yates with j = int(u*(i+1)),
+choice(n, size=k, replace=False) = the first k steps of a forward Fisher-Yates of range(n), randint(a, b, size) = one u per element,
+choice(n) = int(u*n), choice(n, p) = searchsorted(cumsum(p)/sum(p), u, 'right') (numpy's
 own formula), randint(a,b) = a + int(u*(b-a)).
 """
 import importlib.util
@@ -70,8 +72,16 @@ def _uniform(low=0.0, high=1.0, size=None):
 
 
 def _choice(a, size=None, replace=True, p=None):
-    assert size is None
     n = a if isinstance(a, (int, np.integer)) else len(a)
+    if size is not None:
+        # k distinct indices (maze.py:212 sample_distinct_open_points): the first k steps of a forward
+        # Fisher-Yates shuffle of range(n), one tape uniform per step
+        assert not replace and p is None and isinstance(a, (int, np.integer))
+        perm = list(range(n))
+        for t in range(int(size)):
+            j = t + int(TAPE.u() * (n - t))
+            perm[t], perm[j] = perm[j], perm[t]
+        return np.array(perm[:int(size)])
     if p is not None:   # numpy's own algorithm (legacy RandomState.choice with p)
         cdf = np.cumsum(np.asarray(p, dtype=np.float64))
         cdf /= cdf[-1]
@@ -82,10 +92,19 @@ def _choice(a, size=None, replace=True, p=None):
 
 
 def _randint(low, high=None, size=None, dtype=int):
-    assert size is None
     if high is None:
         low, high = 0, low
+    if size is not None:   # one tape uniform per element, row-major (maze_generators.py:143)
+        return np.array([low + int(TAPE.u() * (high - low)) for _ in range(int(np.prod(size)))]).reshape(size)
     return low + int(TAPE.u() * (high - low))
+
+
+def _shuffle(x):
+    """np.random.shuffle of a list (maze_generators.py:131): numpy's backward Fisher-Yates order, one tape
+    uniform per swap: for i = n - 1 .. 1: j = int(u * (i + 1)); swap(x[i], x[j])."""
+    for i in range(len(x) - 1, 0, -1):
+        j = int(TAPE.u() * (i + 1))
+        x[i], x[j] = x[j], x[i]
 
 
 def _binomial(n, p, size=None):
@@ -106,10 +125,11 @@ def patch_numpy_random():
     np.random.choice = _choice
     np.random.randint = _randint
     np.random.binomial = _binomial
+    np.random.shuffle = _shuffle
 
 
 SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
-           'first_person_predators_prey', 'cleanup')
+           'first_person_predators_prey', 'cleanup', 'pacman')
 
 
 def load_amd_config(name):
@@ -651,6 +671,7 @@ def main():
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
         ('maze_zoo', 120, {}, (0, 1)),
         ('maze_zoo_l1', 120, {}, (0,)),
+        ('pacman', 150, {'walls': 136, 'prey': 48}, (0, 1)),   # the per-episode random maze: walls + prey = 144 cells
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),

@@ -189,7 +189,27 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
             q[L.o_fmask + s] = fx['fmask'][t][s]
     q[L.o_step_count] = fx['step_count'][t]
     q[L.o_reset_next] = fx['reset_next'][t]
+    if P.maze.random:   # the episode's maze: what Maze.from_state reads off the recorded wall squares
+        rows = maze_rows_from_fixture(fx, t, c)
+        q[L.o_maze:L.o_maze + len(rows)] = rows
     return f64, i32
+
+
+def maze_rows_from_fixture(fx, t, c):
+    """Row bit masks (bit column = wall) of the maze whose wall squares call t of a recording holds."""
+    P = c.program
+    n = P.maze.size
+    rows = np.zeros(_abi.MOOG_MAX_MAZE, np.int64)
+    for oi in range(P.n_ops):
+        if P.ops[oi].cell_sel != _abi.MOOG_CELL_WALL_RANK:
+            continue
+        s = P.ops[oi].slot0
+        if not fx['alive'][t][s]:
+            continue
+        v = fx['verts'][t][s, :4]
+        j, i = int(round(v[:, 0].min() * n)), int(round(v[:, 1].min() * n))
+        rows[i] |= 1 << j
+    return rows.astype(np.int32)
 
 
 def state_diff(fx, t, c, f64, i32, env=0):
@@ -274,6 +294,11 @@ def state_diff(fx, t, c, f64, i32, env=0):
         ints_ok = False
         detail.append('step_count/reset_next %d/%d vs %d/%d' % (
             q[L.o_step_count], q[L.o_reset_next], fx['step_count'][t], fx['reset_next'][t]))
+    if P.maze.random:
+        rows = maze_rows_from_fixture(fx, t, c)
+        if not np.array_equal(q[L.o_maze:L.o_maze + len(rows)], rows):
+            ints_ok = False
+            detail.append('maze rows %s vs %s' % (list(q[L.o_maze:L.o_maze + P.maze.size]), list(rows[:P.maze.size])))
     ref_am = np.asarray(fx['action_mem'][t], np.float64).reshape(-1)
     am = float(np.max(np.abs(f[L.o_action:L.o_action + len(ref_am)] - ref_am)))
     err['action_mem'] = am

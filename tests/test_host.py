@@ -45,7 +45,7 @@ def test_missing_library_fails_loudly(tmp_path):
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
 @pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
                                   'functional_maze', 'falling_balls', 'first_person_predators_prey',
-                                  'cleanup'])
+                                  'cleanup', 'pacman'])
 def test_reference_configs_load_unchanged(name):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
