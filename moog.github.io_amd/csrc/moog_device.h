@@ -1549,6 +1549,9 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
 // ---- mazes: maze_lib/maze.py Maze, physics/maze_walk.py RandomMazeWalk, physics/maze_physics.py MazePhysics.
 //      Scalar logic per sprite: every lane evaluates it redundantly (wave uniform), lane 0 commits; the one
 //      vector step is the rotation of a sprite that turned (lanes = vertices).
+#ifndef MOOG_WITH_MAZE   // 0: a translation unit whose kernel leaves the maze components out (their local arrays
+#define MOOG_WITH_MAZE 1  //    enlarge the scratch frame of every program that shares the kernel)
+#endif
 #define MAZE_EPS 1e-5   // maze_physics.py:15, maze_walk.py:14
 
 // maze.py:107-112 open_vertex(i, j): inside the matrix and not a wall (maze[j, i])
@@ -1960,7 +1963,7 @@ __device__ inline void apply_physics(Env& e) {
         } else {
           for (int s = a0; s < a1; ++s)
             if (ALIVE(s)) {
-              if constexpr (DYN) { if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; } }
+              if constexpr (DYN && MOOG_WITH_MAZE) { if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; } }
               force_single(e, F, s, K);
             }
         }
@@ -1989,7 +1992,7 @@ __device__ inline void apply_physics(Env& e) {
   const int n_corr = uni(P->n_corrective);
   for (int c = 0; c < n_corr; ++c) {
     if (P->corrective[c].kind == MOOG_CORR_CONSTANT_SPEED) constant_speed(e, &P->corrective[c]);
-    else if (P->corrective[c].kind == MOOG_CORR_MAZE) { if constexpr (DYN) maze_physics(e, &P->corrective[c]); }
+    else if (P->corrective[c].kind == MOOG_CORR_MAZE) { if constexpr (DYN && MOOG_WITH_MAZE) maze_physics(e, &P->corrective[c]); }
     else tether(e, &P->corrective[c], c);
   }
   { PROF_T0; if (!(e.dbg & 2)) integrate_all(e, 1. / K); PROF_ADD(e, 5); }
@@ -3220,12 +3223,12 @@ __device__ inline void run_genop(Env& e, int oi) {
   PProg P = e.P;
   PGenop op = &P->ops[oi];
   if (op->runtime) return;   // CreateSprites generators run at rule time
-  if constexpr (DYN) {
+  if constexpr (DYN && MOOG_WITH_MAZE) {
     if (op->cell_sel == MOOG_CELL_GENERATE) { maze_generate(e); return; }
     if (op->cell_sel == MOOG_CELL_SAMPLE) { maze_sample_points(e, op->cell_arg); return; }
   }
   int n = genop_count(e, op);
-  if constexpr (DYN) {
+  if constexpr (DYN && MOOG_WITH_MAZE) {
     if (op->cell_sel != MOOG_CELL_NONE && !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
   }
   for (int k = 0; k < op->count_max; ++k) {

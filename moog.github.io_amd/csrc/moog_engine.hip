@@ -53,6 +53,7 @@ struct moog_engine {
   size_t step_lds = 0, raster_lds = 0;
   int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
   bool dynamic_rules = false;
+  bool maze_kernel = false;   // the program uses MazePhysics / a maze walk / a per-reset maze
   RPlan raster_plan_{};
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
@@ -347,9 +348,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
   {
-    int (*const configure[4])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
-                                         moog_configure_step_t4};
-    for (int v = 0; v < 4 && err == hipSuccess; ++v) err = (hipError_t)configure[v](e->step_lds);
+    int (*const configure[6])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
+                                         moog_configure_step_t4, moog_configure_step_m3, moog_configure_step_m4};
+    for (int v = 0; v < 6 && err == hipSuccess; ++v) err = (hipError_t)configure[v](e->step_lds);
     e->step_wps = (160 * 1024 / (e->step_lds ? e->step_lds : 1)) <= 14 ? 3 : 4;
     { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) e->step_wps = atoi(w); }   // experiments
   }
@@ -370,9 +371,10 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
-  for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->dynamic_rules = true;
-  for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->dynamic_rules = true;
-  if (prog->maze.random) e->dynamic_rules = true;   // the maze generator is compiled into the rare-components variants only
+  // the maze components live in a kernel variant of their own (m3 / m4): their code would only enlarge the others
+  for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->maze_kernel = true;
+  for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
+  if (prog->maze.random) e->maze_kernel = true;
   if (err == hipSuccess)
     err = (hipError_t)moog_configure_reset(e->step_lds);
   if (err == hipSuccess)
@@ -464,9 +466,9 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
 }
 
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
-  static const moog_step_launch_fn launch[4] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
-                                                moog_launch_step_t4};
-  launch[(e->dynamic_rules ? 2 : 0) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
+  static const moog_step_launch_fn launch[6] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
+                                                moog_launch_step_t4, moog_launch_step_m3, moog_launch_step_m4};
+  launch[(e->maze_kernel ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
 }
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
 // WPS = waves per SIMD the register allocation is sized for: 4 (128 VGPRs, some scratch) keeps sixteen
 // envs per CU in flight, which is what programs with small state records want; 3 (168 VGPRs, no
 // scratch in the hot loops) is faster once LDS holds fewer than fifteen records per CU anyway.
-template <bool DYN, int WPS>
+template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
 __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
@@ -332,10 +332,14 @@ void moog_launch_step_f3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_f4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_t3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_t4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_m3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_m4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 int moog_configure_step_f3(size_t lds);
 int moog_configure_step_f4(size_t lds);
 int moog_configure_step_t3(size_t lds);
 int moog_configure_step_t4(size_t lds);
+int moog_configure_step_m3(size_t lds);
+int moog_configure_step_m4(size_t lds);
 void moog_launch_reset(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 int moog_configure_reset(size_t lds);
 void moog_launch_sched(hipStream_t s, const float* cost, int32_t* perm, int n, const int32_t* reset_next, int stride);

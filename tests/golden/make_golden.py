@@ -137,6 +137,8 @@ def load_amd_config(name):
     variants from this repo's recipes, run against the reference package."""
     if name in SHIPPED:
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
+    if name == 'pacman_l1':   # level 1: three ghosts, 10 x 10 maze
+        return importlib.import_module('moog_demos.example_configs.pacman').get_config(1)
     if name == 'chase_avoid_torus_l1':   # level 1: 1-2 prey and 1-2 predators (randint counts)
         return importlib.import_module('moog_demos.example_configs.chase_avoid_torus').get_config(1)
     level = 0
@@ -672,6 +674,7 @@ def main():
         ('maze_zoo', 120, {}, (0, 1)),
         ('maze_zoo_l1', 120, {}, (0,)),
         ('pacman', 150, {'walls': 136, 'prey': 48}, (0, 1)),   # the per-episode random maze: walls + prey = 144 cells
+        ('pacman_l1', 100, {'walls': 136, 'prey': 75}, (0,)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),

@@ -36,3 +36,6 @@ run('rules_zoo_l1', 4096)
 run('tether_zoo_l0', 4096)
 run('distrib_zoo', 4096)
 run('cleanup', 4096, steps=60)
+run('maze_zoo', 4096, steps=60)
+run('pacman', 1024, steps=60)
+run('pacman', 4096, steps=60)
