@@ -202,6 +202,10 @@ typedef struct {
                          * is unused (sprites are appended to the rule's layer) */
   int32_t cell_sel;     /* MOOG_CELL_*                                        */
   int32_t cell_arg;
+  int32_t fail_gracefully; /* sprite_generators.py:93-95: when max_tries is exceeded the call returns the
+                            * sprites made so far (this and the op's remaining slots stay dead) instead of
+                            * raising RecursionError (MOOG_FAULT_SAMPLER_EXHAUSTED)                         */
+  int32_t pad_;
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;
 

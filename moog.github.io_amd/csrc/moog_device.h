@@ -2346,6 +2346,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       PGenop op = &P->ops[R->op];
       const int n = genop_count(e, op);
       int first = -1;
+      bool gave_up = false;
       for (int k = 0; k < n; ++k) {
         const int s = layer_append_slot(e, R->l0);
         if (s < 0) break;
@@ -2359,18 +2360,24 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           bool ov = false;
           for (int a = 0; a < R->n_layers && !ov; ++a) {
             int l = R->layers[a];
-            ov = overlaps_any(e, s, P->layer_slot0[l], P->layer_slot0[l] + P->layer_nslots[l]);
+            // (the sprites this call has made so far join the layer only afterwards, create_sprites.py:34-37)
+            ov = overlaps_any(e, s, P->layer_slot0[l], l == R->l0 ? first : P->layer_slot0[l] + P->layer_nslots[l]);
           }
           if (op->disjoint && !ov) ov = overlaps_any(e, s, first, s);
           if (!ov) break;
           if (count > op->max_tries) {
             wsync();
-            if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+            if (e.lane == 0) {
+              if (op->fail_gracefully) { FLAGS(s) = 0; NV(s) = 0; }   // the generator returns what it has (:93-95)
+              else e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+            }
             wsync();
+            gave_up = op->fail_gracefully != 0;
             break;
           }
           ++count;
         }
+        if (gave_up) break;
         wsync();
         if (e.lane == 0) FLAGS(s) |= MOOG_F_ALIVE;
         wsync();
@@ -3255,6 +3262,11 @@ __device__ inline void run_genop(Env& e, int oi) {
       if (!ov) break;
       if (count > op->max_tries) {
         wsync();
+        if (op->fail_gracefully) {   // `return sprites` (sprite_generators.py:93-95): this sprite and the rest of the call are dropped
+          for (int t = k + e.lane; t < op->count_max; t += 64) { FLAGS(op->slot0 + t) = 0; NV(op->slot0 + t) = 0; }
+          wsync();
+          return;
+        }
         if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
         wsync();
         break;

@@ -267,6 +267,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         G.count_min = len(sprites) if op is None else op.count_min
         G.disjoint = 0 if op is None else int(op.disjoint)
         G.max_tries = 0 if op is None else int(op.max_tries)
+        G.fail_gracefully = int(bool(getattr(op, 'fail_gracefully', False)))
         avoid = 0
         if op is not None and not runtime:
             for a in op.avoid:

@@ -16,8 +16,6 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             raise RuntimeError(
                 'sprite generators only run inside an environment (the state_initializer is '
                 'lowered to the device-side sampler; there is no host sampling path)')
-        if fail_gracefully:
-            raise NotImplementedError('fail_gracefully=True is not supported by the device sampler')
         n_calls = len(t.randint_calls)
         n = num_sprites() if callable(num_sprites) else num_sprites
         if len(t.randint_calls) > n_calls:
@@ -30,8 +28,10 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             sprites = [sprite_lib.Sprite(**factor_dist.sample()) for _ in range(count_max)]
         finally:
             t.suspend = False
-        t.add_op(_trace.GenOp(factor_dist, count_min, count_max, bool(disjoint),
-                              list(without_overlapping), int(max_recursion_depth), sprites))
+        op = _trace.GenOp(factor_dist, count_min, count_max, bool(disjoint),
+                          list(without_overlapping), int(max_recursion_depth), sprites)
+        op.fail_gracefully = bool(fail_gracefully)   # (:93-95) return the sprites made so far instead of raising
+        t.add_op(op)
         return sprites
 
     return _generate

@@ -675,6 +675,8 @@ def main():
         ('maze_zoo_l1', 120, {}, (0,)),
         ('pacman', 150, {'walls': 136, 'prey': 48}, (0, 1)),   # the per-episode random maze: walls + prey = 144 cells
         ('pacman_l1', 100, {'walls': 136, 'prey': 75}, (0,)),
+        ('sampler_zoo', 60, {'blocks': 8}, (0, 1)),
+        ('sampler_zoo_l1', 70, {'blocks': 8, '__dynamic__': ('blocks',)}, (0,)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),
