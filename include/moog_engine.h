@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 17
+#define MOOG_ABI_VERSION 18
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -39,12 +39,14 @@ extern "C" {
 #define MOOG_MAX_SHAPES 256
 #define MOOG_MAX_SHAPE_VERTS 2048
 #define MOOG_MAX_CAND 256
-#define MOOG_MAX_DCODE 512
+#define MOOG_MAX_DCODE 2048
 #define MOOG_X_STACK 16
 #define MOOG_MAX_SLOTS 256
 #define MOOG_MAX_ACTIONS 4
 #define MOOG_MAX_MORE_ACTIONS 3 /* MOOG_MAX_ACTIONS - 1 */
 #define MOOG_NUM_FACTORS 14
+#define MOOG_MAX_HDRAWS 32   /* draws a state_initializer takes from np.random directly (per reset) */
+#define MOOG_MAX_OP_DRAWS 24 /* draws of one generation op: its sampled factors + the direct draws made between them */
 
 /* ---- error codes --------------------------------------------------------- */
 #define MOOG_OK 0
@@ -99,7 +101,12 @@ enum { MOOG_DIST_CONST = 0, MOOG_DIST_CONTINUOUS = 1, MOOG_DIST_DISCRETE = 2, MO
         * moog_genop_t.cell_sel.  MAZE_COORD: cand[cand_off + (n_cand ? j : i)] -- the config's arithmetic on the
         * cell index (`grid_side * (0.5 + index)`), tabulated on the host for every index.  MAZE_SHAPE: shape id
         * a + j * N + i, the wall square of cell (row i, column j) (maze.py:98-111)                          */
-       MOOG_DIST_MAZE_COORD = 4, MOOG_DIST_MAZE_SHAPE = 5 };
+       MOOG_DIST_MAZE_COORD = 4, MOOG_DIST_MAZE_SHAPE = 5,
+       /* EXPR: the value of the postfix expression at dcode[cand_off] (leaves: constants, MOOG_X_HDRAW, MOOG_X_SLOT_ATTR).
+        * EXPR_SHAPE (factor `shape` only): a raw polygon of n_cand vertices whose coordinates the code at
+        * dcode[cand_off] stores with MOOG_X_STORE_VERT; centroid, inertia and the centred path are then derived on
+        * the device as Sprite.__init__ derives them (sprite.py:360-401)                                          */
+       MOOG_DIST_EXPR = 6, MOOG_DIST_EXPR_SHAPE = 7 };
 /* moog_genop_t.cell_sel: which maze cell (row i, column j of Maze.maze) a one-sprite op is placed on.  The op's
  * slot stays dead when the maze has fewer such cells.  GENERATE / SAMPLE are ops without sprites.           */
 enum {
@@ -108,7 +115,8 @@ enum {
   MOOG_CELL_SAMPLE,     /* maze.py:200-214 sample_distinct_open_points(cell_arg) -> the record's point words */
   MOOG_CELL_SAMPLED,    /* the cell_arg-th point of that sample                                            */
   MOOG_CELL_OPEN_RANK,  /* the cell_arg-th open cell in np.argwhere order (rows outer; pacman.py:62-65)     */
-  MOOG_CELL_WALL_RANK   /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
+  MOOG_CELL_WALL_RANK,  /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
+  MOOG_CELL_HDRAW       /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW) */
 };
 
 /* Distribution programs.  A factor distribution that is not a flat Product of
@@ -161,7 +169,12 @@ enum {
   MOOG_X_AND, MOOG_X_OR, MOOG_X_NEG, MOOG_X_ABS, MOOG_X_SQRT, MOOG_X_SIN, MOOG_X_COS,
   MOOG_X_FLOOR, MOOG_X_NOT, MOOG_X_SIGN, MOOG_X_SELECT, MOOG_X_STORE, MOOG_X_END,
   MOOG_X_RULE_STATE,  /* push the state scalar of rule a (e.g. a PhaseSequence's current phase index) */
-  MOOG_X_OVERLAPS_FIRST /* push sprite b .overlaps_sprite(first live sprite of layer a) (0 when the layer is empty) */
+  MOOG_X_OVERLAPS_FIRST, /* push sprite b .overlaps_sprite(first live sprite of layer a) (0 when the layer is empty) */
+  /* reset-time expressions (factor values computed by the state_initializer's own arithmetic on np.random draws,
+   * e.g. parallelogram_catch.py:34-68, multi_tracking_with_feature.py:41-46,136): */
+  MOOG_X_HDRAW,      /* push uniform a of this reset (the a-th direct np.random call of the initializer)        */
+  MOOG_X_SLOT_ATTR,  /* push attribute a (MOOG_XA_*) of sprite slot b (a factor copied from an earlier sprite)  */
+  MOOG_X_STORE_VERT  /* pop -> component a of the raw shape being built (vertex a / 2, x or y)                   */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -195,7 +208,7 @@ typedef struct {
   int32_t disjoint;     /* _generate(disjoint=True)                           */
   int32_t max_tries;    /* max_recursion_depth (default 1e4)                  */
   int32_t n_sampled;    /* number of random factors                           */
-  int32_t sample_order[MOOG_NUM_FACTORS]; /* factor ids in draw order         */
+  int32_t sample_order[MOOG_MAX_OP_DRAWS]; /* factor ids in draw order; MOOG_NUM_FACTORS + k: direct draw k */
   uint64_t avoid_ops;   /* without_overlapping: bitmask of earlier ops        */
   int32_t code_off;     /* distribution program in program.dcode, or -1       */
   int32_t runtime;      /* 1: run by a CREATE_SPRITES rule, not at reset; slot0
@@ -436,6 +449,8 @@ typedef struct {
   int32_t n_ops;
   int32_t n_shapes;
   int32_t n_cand;
+  int32_t n_hdraws;                /* direct np.random draws per reset (o_hdraw) */
+  int32_t pad_hdraws_;
   double timeout_steps;            /* CompositeTask timeout (inf allowed)      */
 
   moog_force_t forces[MOOG_MAX_FORCES];
@@ -481,6 +496,7 @@ typedef struct {
   int32_t o_action;   /* [2 * max(1, n_actions)] action-space memory (_action)    */
   int32_t o_task;     /* [T]      per-task _steps_until_reset (inf sentinel)   */
   int32_t o_rule;     /* [R]      per-rule scalar (Booster countdown)          */
+  int32_t o_hdraw;    /* [n_hdraws] the uniforms of this episode's direct draws; -1 when there are none */
   int32_t o_scale;    /* [S] sprite.scale, [S] sprite.aspect_ratio at o_aspect; -1 when
                        *     program.sprite_factors == 0                              */
   int32_t o_aspect;
@@ -521,6 +537,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_action = o; o += 2 * (p->n_actions > 1 ? p->n_actions : 1);
   L->o_task = o; o += p->n_tasks;
   L->o_rule = o; o += p->n_rules;
+  if (p->n_hdraws > 0) { L->o_hdraw = o; o += p->n_hdraws; } else L->o_hdraw = -1;
   if (p->sprite_factors) { L->o_scale = o; o += S; L->o_aspect = o; o += S; }
   else { L->o_scale = -1; L->o_aspect = -1; }
   o = moog_align_(o, 2);

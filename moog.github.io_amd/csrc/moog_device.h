@@ -67,6 +67,9 @@ struct Env {
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   unsigned cur_fmask;      // float32 factors of the sprite being created
   int cell_i, cell_j;      // maze cell (row, column) of the sprite being created (MOOG_CELL_* ops)
+  int cur_slot;            // slot of the sprite being created (a computed shape is staged in its vertex area)
+  double xs_centroid[2], xs_inertia[2];   // centroid / inertia per unit area of a computed shape (MOOG_DIST_EXPR_SHAPE)
+  int xs_n;
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -2065,6 +2068,15 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
     if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if constexpr (MOOG_WITH_MAZE != 0) {   // reset-time expressions: only in the kernels that carry every component
+      if (op == MOOG_X_HDRAW) { v[n] = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
+      if (op == MOOG_X_SLOT_ATTR) { int t; v[n] = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
+      if (op == MOOG_X_STORE_VERT) {   // raw shape coordinate -> the vertex area of the slot being created
+        --n;
+        if (e.lane == 0) VERT(e.cur_slot)[I->a] = v[n];
+        continue;
+      }
+    }
     if (op == MOOG_X_OVERLAPS_FIRST) {   // sprite.overlaps_sprite(state[L][0])
       const int sp = I->b ? s1 : s0;
       int first = -1;
@@ -2245,7 +2257,9 @@ __device__ inline bool sprite_filter(Env& e, PRule R, int s) {
   return sprite_filter_x(e, R->filter, R->xfilter, s);
 }
 
+template <bool X>
 __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32);
+template <bool X>
 __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& vel_f32, int& angvel_f32);
 __device__ inline int genop_count(Env& e, PGenop op);
 
@@ -2355,8 +2369,9 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         for (;;) {
           double fac[MOOG_NUM_FACTORS];
           int vel_f32, angvel_f32;
-          sample_op_factors(e, op, fac, vel_f32, angvel_f32);
-          create_sprite(e, s, fac, vel_f32, angvel_f32);
+          e.cur_slot = s;
+          sample_op_factors<MOOG_WITH_MAZE != 0>(e, op, fac, vel_f32, angvel_f32);
+          create_sprite<MOOG_WITH_MAZE != 0>(e, s, fac, vel_f32, angvel_f32);
           bool ov = false;
           for (int a = 0; a < R->n_layers && !ov; ++a) {
             int l = R->layers[a];
@@ -2832,22 +2847,28 @@ __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, in
 }
 
 // ---- reset path (sprite.py:261-424, distributions.py, sprite_generators.py:77-105) ----------
+template <bool X>   // X: computed shapes possible (rare-components kernels only)
 __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32) {
   PProg P = e.P;
-  int sid = (int)fac[MOOG_FAC_SHAPE];
-  PShape sh = &P->shapes[sid];
+  const int sid = (int)fac[MOOG_FAC_SHAPE];
+  const bool computed = X && sid < 0;   // MOOG_DIST_EXPR_SHAPE: the centred path is staged in the slot's vertex area
+  PShape sh = &P->shapes[computed ? 0 : sid];
   double x = fac[MOOG_FAC_X], y = fac[MOOG_FAC_Y];
   double angle = fac[MOOG_FAC_ANGLE], scale = fac[MOOG_FAC_SCALE], aspect = fac[MOOG_FAC_ASPECT];
   double sx = scale, sy = scale * aspect;
   double c = cos(angle), sn = sin(angle);
   double m00 = c * sx, m01 = (-sn) * sy, m10 = sn * sx, m11 = c * sy;
-  int n = sh->nverts;
+  int n = computed ? e.xs_n : sh->nverts;
   if (n > P->slot_vcap[s]) n = P->slot_vcap[s];
   double* v = VERT(s);
   double r = -1.0;
+  const double cen0 = computed ? e.xs_centroid[0] : sh->centroid[0], cen1 = computed ? e.xs_centroid[1] : sh->centroid[1];
+  const double ine0 = computed ? e.xs_inertia[0] : sh->inertia[0], ine1 = computed ? e.xs_inertia[1] : sh->inertia[1];
   wsync();
   for (int k = e.lane; k < n; k += 64) {
-    double ux = P->shape_verts[sh->voff + k][0], uy = P->shape_verts[sh->voff + k][1];
+    double ux, uy;
+    if (computed) { ux = v[2 * k]; uy = v[2 * k + 1]; }   // (n <= 64: every lane reads its own vertex before writing it)
+    else { ux = P->shape_verts[sh->voff + k][0]; uy = P->shape_verts[sh->voff + k][1]; }
     double vx = (m00 * ux + m01 * uy) + x;
     double vy = (m10 * ux + m11 * uy) + y;
     v[2 * k] = vx; v[2 * k + 1] = vy;
@@ -2859,8 +2880,8 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     NV(s) = n;
     SHAPEID(s) = sid;
     MAXR(s) = r;
-    INER(s, 0) = sh->inertia[0] * (sx * sx);
-    INER(s, 1) = sh->inertia[1] * (sy * sy);
+    INER(s, 0) = ine0 * (sx * sx);
+    INER(s, 1) = ine1 * (sy * sy);
     PX(s) = x; PY(s) = y;
     ANG(s) = angle;
     VELX(s) = fac[MOOG_FAC_XVEL]; VELY(s) = fac[MOOG_FAC_YVEL];
@@ -2871,7 +2892,7 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     TELE(s) = 0;
     vel_unshare(e, s);
     int fl = 0;
-    if (sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
+    if (!computed && sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
     if (vel_f32) fl |= MOOG_F_VEL_F32;
     if (angvel_f32) fl |= MOOG_F_ANGVEL_F32;
     FLAGS(s) = fl;
@@ -2882,10 +2903,48 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     }
   }
   wsync();
-  set_position(e, s, x + sh->centroid[0], y + sh->centroid[1]);
+  set_position(e, s, x + cen0, y + cen1);
   bbox_exact_wave(e, s);
 }
 
+// sprite.py:360-401 for a polygon computed per episode: signed area, centroid and inertia by the triangle fan from
+// the origin (sequential sums, every lane redundantly: the order is part of the result); a clockwise polygon is
+// reversed; the path is centred on the centroid (1 * x + 0 * y + t); inertia about the centroid, per unit area.
+// In: raw vertices in the slot's vertex area.  Out: the centred path there, e.xs_* for create_sprite.
+__device__ inline void shape_record(Env& e, int s, int n) {
+  double* raw = VERT(s);
+  wsync();
+  double in0 = 0, in1 = 0, area = 0, c0 = 0, c1 = 0;
+  for (int i = 0; i < n; ++i) {
+    const int j = (i + 1 == n) ? 0 : i + 1;
+    const double ax = raw[2 * i], ay = raw[2 * i + 1], bx = raw[2 * j], by = raw[2 * j + 1];
+    const double cr = ax * by - ay * bx;
+    const double w = (1. / 12.) * cr;
+    in0 += w * ((ax * ax + bx * bx) + ax * bx);
+    in1 += w * ((ay * ay + by * by) + ay * by);
+    const double tri = cr / 2.;
+    area += tri;
+    c0 += ((ax + bx) / 3.) * tri;
+    c1 += ((ay + by) / 3.) * tri;
+  }
+  c0 /= area; c1 /= area;
+  const bool rev = area < 0;
+  if (rev) { in0 *= -1.; in1 *= -1.; area *= -1.; }
+  const double n0 = -1 * c0, n1 = -1 * c1;
+  double px = 0, py = 0;
+  if (e.lane < n) { const int src = rev ? n - 1 - e.lane : e.lane; px = raw[2 * src]; py = raw[2 * src + 1]; }
+  wsync();
+  if (e.lane < n) { raw[2 * e.lane] = (1.0 * px + 0.0 * py) + n0; raw[2 * e.lane + 1] = (0.0 * px + 1.0 * py) + n1; }
+  wsync();
+  in0 -= area * (c0 * c0); in1 -= area * (c1 * c1);
+  e.xs_n = n;
+  e.xs_centroid[0] = c0; e.xs_centroid[1] = c1;
+  e.xs_inertia[0] = in0 / area; e.xs_inertia[1] = in1 / area;
+}
+
+// X: the program may carry reset-time expressions (direct np.random draws of the initializer and factors / shapes
+// computed from them); only the rare-components kernels compile that in.
+template <bool X>
 __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
   if (op->cell_sel != MOOG_CELL_NONE) {   // factors read off the maze cell the sprite sits on (pacman.py:47-65, maze.py:98-111)
@@ -2899,13 +2958,22 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   // every sampled factor of a flat Product takes exactly one draw, in sample order: all of them at once
   int ndraw = 0;
   for (int k = 0; k < op->n_sampled; ++k) {
-    const int kind = op->factors[op->sample_order[k]].kind;
+    const int fi = op->sample_order[k];
+    if (X && fi >= MOOG_NUM_FACTORS) { ++ndraw; continue; }
+    const int kind = op->factors[fi].kind;
     ndraw += (kind == MOOG_DIST_CONTINUOUS || kind == MOOG_DIST_DISCRETE) ? 1 : 0;
   }
   const double draws = ndraw > 0 ? next_uniforms_lanes(e, ndraw) : 0.0;
   int kd = 0;
   for (int k = 0; k < op->n_sampled; ++k) {
     int fi = op->sample_order[k];
+    if (X && fi >= MOOG_NUM_FACTORS) {   // a direct np.random draw of the initializer, taken between the factor draws
+      const double u = shfl_d(draws, kd++);
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_hdraw + fi - MOOG_NUM_FACTORS] = u;
+      wsync();
+      continue;
+    }
     PFactor F = &op->factors[fi];
     double val = F->a;
     if (F->kind == MOOG_DIST_CONTINUOUS) {
@@ -2921,6 +2989,18 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
     // static indexing keeps `fac` in registers
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == fi) fac[q] = val;
+  }
+  if constexpr (X) {   // factors the initializer computed from its draws (after all draws of the op are in)
+#pragma unroll
+    for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
+      PFactor F = &op->factors[q];
+      if (F->kind == MOOG_DIST_EXPR) fac[q] = eval_expr(e, F->cand_off, 0, 0, nullptr, nullptr);
+      else if (F->kind == MOOG_DIST_EXPR_SHAPE) {
+        eval_expr(e, F->cand_off, 0, 0, nullptr, nullptr);   // raw vertices -> VERT(cur_slot)
+        shape_record(e, e.cur_slot, F->n_cand);
+        fac[q] = -1.0;
+      }
+    }
   }
 }
 
@@ -3040,13 +3120,14 @@ __device__ inline int genop_count(Env& e, PGenop op) {
 }
 
 // one `factor_dist.sample()`: the factors and which of them are float32 samples
+template <bool X>
 __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& vel_f32, int& angvel_f32) {
   PFactor FX = &op->factors[MOOG_FAC_XVEL];
   PFactor FY = &op->factors[MOOG_FAC_YVEL];
   PFactor FW = &op->factors[MOOG_FAC_ANGVEL];
   vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
   angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
-  sample_factors(e, op, fac);
+  sample_factors<X>(e, op, fac);
   unsigned m = 0;
   for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
     if (op->factors[k].kind == MOOG_DIST_CONTINUOUS && op->factors[k].f32) m |= 1u << k;
@@ -3230,13 +3311,24 @@ __device__ inline void run_genop(Env& e, int oi) {
   PProg P = e.P;
   PGenop op = &P->ops[oi];
   if (op->runtime) return;   // CreateSprites generators run at rule time
-  if constexpr (DYN && MOOG_WITH_MAZE) {
+  constexpr bool FULL = DYN && (MOOG_WITH_MAZE != 0);   // maze ops and reset-time expressions: the m3 / m4 kernels only
+  if constexpr (FULL) {
     if (op->cell_sel == MOOG_CELL_GENERATE) { maze_generate(e); return; }
     if (op->cell_sel == MOOG_CELL_SAMPLE) { maze_sample_points(e, op->cell_arg); return; }
   }
+  if constexpr (FULL) {
+    if (op->cell_sel == MOOG_CELL_HDRAW) {   // a direct np.random draw of the initializer
+      const double u = next_uniform(e);
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = u;
+      wsync();
+      return;
+    }
+  }
   int n = genop_count(e, op);
-  if constexpr (DYN && MOOG_WITH_MAZE) {
-    if (op->cell_sel != MOOG_CELL_NONE && !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
+  if constexpr (FULL) {
+    if (op->cell_sel != MOOG_CELL_NONE && op->cell_sel != MOOG_CELL_HDRAW &&
+        !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
   }
   for (int k = 0; k < op->count_max; ++k) {
     int s = op->slot0 + k;
@@ -3250,8 +3342,9 @@ __device__ inline void run_genop(Env& e, int oi) {
     for (;;) {
       double fac[MOOG_NUM_FACTORS];
       int vel_f32, angvel_f32;
-      sample_op_factors(e, op, fac, vel_f32, angvel_f32);
-      create_sprite(e, s, fac, vel_f32, angvel_f32);
+      if constexpr (FULL) e.cur_slot = s;
+      sample_op_factors<FULL>(e, op, fac, vel_f32, angvel_f32);
+      create_sprite<FULL>(e, s, fac, vel_f32, angvel_f32);
       bool ov = false;
       for (int oj = 0; oj < oi && oj < 64 && !ov; ++oj) {
         if (!((op->avoid_ops >> oj) & 1)) continue;
@@ -3297,5 +3390,5 @@ __device__ inline void env_reset(Env& e) {
   }
   wsync();
   for (int r = 0; r < P->n_rules; ++r)
-    if (P->rules[r].parent < 0) { rule_reset_tree(e, r); rule_step<true>(e, r); }
+    if (P->rules[r].parent < 0) { rule_reset_tree(e, r); rule_step<DYN>(e, r); }
 }

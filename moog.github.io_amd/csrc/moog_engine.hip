@@ -128,6 +128,7 @@ static int validate(const moog_program_t* p) {
   if (p->abi_version != MOOG_ABI_VERSION) return fail(MOOG_E_INVALID, "program abi_version mismatch");
   if (p->n_slots < 0 || p->n_slots > MOOG_MAX_SLOTS) return fail(MOOG_E_INVALID, "n_slots out of range");
   if (p->n_layers < 0 || p->n_layers > MOOG_MAX_LAYERS) return fail(MOOG_E_INVALID, "n_layers out of range");
+  if (p->n_hdraws < 0 || p->n_hdraws > MOOG_MAX_HDRAWS) return fail(MOOG_E_INVALID, "n_hdraws out of range");
   if (p->updates_per_env_step < 1) return fail(MOOG_E_INVALID, "updates_per_env_step < 1");
   for (int s = 0; s < p->n_slots; ++s)
     if (p->slot_vcap[s] > 128) return fail(MOOG_E_UNSUPPORTED, "sprites with more than 128 vertices");
@@ -371,6 +372,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
+  if (prog->n_hdraws > 0) e->maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
+  for (int o = 0; o < prog->n_ops; ++o)
+    for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
+      if (prog->ops[o].factors[k].kind == MOOG_DIST_EXPR || prog->ops[o].factors[k].kind == MOOG_DIST_EXPR_SHAPE)
+        e->maze_kernel = true;
   // the maze components live in a kernel variant of their own (m3 / m4): their code would only enlarge the others
   for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->maze_kernel = true;
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;

@@ -217,6 +217,26 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     cand_n = 0
     vcap = [0] * S
     op_max_nv = {}
+
+    def put_code(code):
+        """Appends postfix expression code (plus X_END) to program.dcode; returns its offset."""
+        if _symbolic.depth(code) > _abi.MOOG_X_STACK:
+            raise NotImplementedError('expression too deep for the device evaluator')
+        if _symbolic.uses_attr(code, ('scale', 'aspect_ratio', 'mass', 'c0', 'c1', 'c2')):
+            P.sprite_factors = 1
+        code = list(code) + [dict(op=_abi.MOOG_X_END)]
+        base = P.n_dcode
+        if base + len(code) > _abi.MOOG_MAX_DCODE:
+            raise ValueError('expression / distribution code too long')
+        for i, ins in enumerate(code):
+            I = P.dcode[base + i]
+            I.op, I.a, I.b, I.x = ins['op'], ins.get('a', 0), ins.get('b', 0), ins.get('x', 0.0)
+        P.n_dcode = base + len(code)
+        return base
+
+    # reset-time expressions: factors the initializer computed from its own np.random draws (_trace.Tracer.hdraw)
+    P.n_hdraws = tr.n_hdraws
+    shape_code = {}   # id(ExprShape rows source) -> code offset (one shape object shared by several sprites)
     # the per-reset random maze (maze_lib/_traced.py): its matrix lives in the env records
     from .maze_lib import _traced as traced_maze
     wall_shape0 = None
@@ -284,6 +304,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         order = [k for k in proto.sample_order   # factors read off a maze cell take no draw
                  if not isinstance(proto.factors[k], (traced_maze.CellShape, traced_maze.CellIndex))]
         G.n_sampled = len(order)
+        draw_seq = getattr(op, 'draw_seq', None)   # factor samples interleaved with direct draws (_trace.note_sprite)
         max_nv = 0
         G.code_off = -1
         tree_keys = set()
@@ -308,7 +329,34 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             if fname in tree_keys:
                 F.kind = _abi.MOOG_DIST_TREE
                 continue
-            if isinstance(val, traced_maze.CellShape):
+            if isinstance(val, sprite_lib.ExprFactor):
+                if fname in ('shape', 'opacity'):
+                    raise NotImplementedError('a computed value as factor %r' % (fname,))
+
+                def slot_resolver(key, ref, _oi=oi):
+                    if key != 'slot' or id(ref) not in slot_of:
+                        raise NotImplementedError('a factor copied from a sprite that is not in the state')
+                    if op_index_of_sprite[id(ref)] >= _oi:
+                        raise NotImplementedError('a factor copied from a sprite that is created later')
+                    return slot_of[id(ref)]
+                F.kind, F.cand_off = _abi.MOOG_DIST_EXPR, put_code(_symbolic.emit(val.node, [], slot_resolver))
+            elif isinstance(val, sprite_lib.ExprShape):
+                if fname != 'shape':
+                    raise NotImplementedError('a computed polygon as factor %r' % (fname,))
+                nv = len(val.rows)
+                if nv < 3 or nv > 64 or any(len(r) != 2 for r in val.rows):
+                    raise NotImplementedError('computed shapes need 3 .. 64 vertices of two coordinates')
+                key = tuple(n.key() for r in val.rows for n in r)
+                if key not in shape_code:
+                    code = []
+                    for vi, row in enumerate(val.rows):
+                        for ci, node in enumerate(row):
+                            _symbolic.emit(node, code, None)
+                            code.append(dict(op=_abi.MOOG_X_STORE_VERT, a=2 * vi + ci))
+                    shape_code[key] = put_code(code)
+                F.kind, F.n_cand, F.cand_off = _abi.MOOG_DIST_EXPR_SHAPE, nv, shape_code[key]
+                max_nv = max(max_nv, nv)
+            elif isinstance(val, traced_maze.CellShape):
                 if fname != 'shape':
                     raise NotImplementedError('a maze wall square as factor %r' % (fname,))
                 F.kind, F.a = _abi.MOOG_DIST_MAZE_SHAPE, float(wall_shape0)
@@ -359,8 +407,16 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     F.a = float(sid)
                 else:
                     F.a = float(val)
-        for k, fname in enumerate(order):
-            G.sample_order[k] = _abi.FACTOR_NAMES.index(fname)
+        if draw_seq is not None and order:
+            entries = [(_abi.FACTOR_NAMES.index(v) if kind == 'factor' else _abi.MOOG_NUM_FACTORS + v)
+                       for kind, v in draw_seq if kind == 'hdraw' or v in order]
+        else:
+            entries = [_abi.FACTOR_NAMES.index(fname) for fname in order]
+        if len(entries) > _abi.MOOG_MAX_OP_DRAWS:
+            raise NotImplementedError('more than %d draws in one sprite' % _abi.MOOG_MAX_OP_DRAWS)
+        G.n_sampled = len(entries)
+        for k, ent in enumerate(entries):
+            G.sample_order[k] = ent
         for sl in slots:
             vcap[sl] = max_nv
         op_max_nv[oi] = max_nv
@@ -527,19 +583,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         for attr, n in (stores or {}).items():
             _symbolic.emit(n, code, resolve_phase)
             code.append(dict(op=_abi.MOOG_X_STORE, a=_symbolic.ATTRS.index(attr)))
-        if _symbolic.depth(code) > _abi.MOOG_X_STACK:
-            raise NotImplementedError('expression too deep for the device evaluator')
-        if _symbolic.uses_attr(code, ('scale', 'aspect_ratio', 'mass', 'c0', 'c1', 'c2')):
-            P.sprite_factors = 1
-        code.append(dict(op=_abi.MOOG_X_END))
-        base = P.n_dcode
-        if base + len(code) > _abi.MOOG_MAX_DCODE:
-            raise ValueError('expression / distribution code too long')
-        for i, ins in enumerate(code):
-            I = P.dcode[base + i]
-            I.op, I.a, I.b, I.x = ins['op'], ins.get('a', 0), ins.get('b', 0), ins.get('x', 0.0)
-        P.n_dcode = base + len(code)
-        return base
+        return put_code(code)
 
     for ri, (r, parent) in enumerate(flat_rules):
         R = P.rules[ri]

@@ -232,11 +232,98 @@ class SymVec(object):
                 t = Sym(lift(x)) * Sym(lift(y))
                 acc = t if acc is None else acc + t
             return acc
+        if name == 'stack' and len(args) == 1 and kwargs.get('axis', 0) in (0, 1):
+            cols = [_elems(a)[0] for a in args[0]]
+            if len(set(len(c) for c in cols)) != 1:
+                raise Unsupported('np.stack of symbolic vectors of different lengths')
+            if kwargs.get('axis', 0) == 0:
+                return SymMat([list(c) for c in cols])
+            return SymMat([[c[i] for c in cols] for i in range(len(cols[0]))])
         if name == 'copy' and len(args) == 1:
             return SymVec(list(args[0].items))
         if name == 'clip' and len(args) == 3:
             return np.minimum(np.maximum(args[0], args[1]), args[2])
         raise Unsupported('numpy.%s on symbolic values' % name)
+
+
+class SymMat(object):
+    """A symbolic 2-D array (rows of symbolic scalars): the vertex arrays a state_initializer computes from its
+    draws (parallelogram_catch.py:34-68).  Elementwise arithmetic with scalars, [n, 1] / [n, m] arrays and
+    length-m rows, in place or not; rows index and iterate as SymVec."""
+    __array_priority__ = 1000
+
+    def __init__(self, rows):
+        self.rows = [[i if isinstance(i, Sym) else Sym(lift(i)) for i in r] for r in rows]
+
+    @property
+    def shape(self):
+        return (len(self.rows), len(self.rows[0]))
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __iter__(self):
+        return iter(SymVec(r) for r in self.rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, tuple) and len(i) == 2 and all(isinstance(k, (int, np.integer)) for k in i):
+            return self.rows[i[0]][i[1]]
+        if isinstance(i, (int, np.integer)):
+            return SymVec(self.rows[i])
+        raise Unsupported('indexing a symbolic matrix with %r' % (i,))
+
+    def _other(self, o, r, c):
+        if isinstance(o, SymMat):
+            rr, cc = o.shape
+            return o.rows[r if rr > 1 else 0][c if cc > 1 else 0]
+        if isinstance(o, SymVec):
+            return o.items[c if len(o.items) > 1 else 0]
+        if isinstance(o, np.ndarray):
+            if o.ndim == 0:
+                return o[()]
+            if o.ndim == 1:
+                return o[c if o.shape[0] > 1 else 0]
+            if o.ndim == 2:
+                return o[r if o.shape[0] > 1 else 0, c if o.shape[1] > 1 else 0]
+            raise Unsupported('broadcasting a symbolic matrix with a %d-d array' % o.ndim)
+        return o
+
+    def _bin(self, fn, other):
+        return SymMat([[fn(a, self._other(other, r, c)) for c, a in enumerate(row)]
+                       for r, row in enumerate(self.rows)])
+
+    def _ibin(self, fn, other):
+        self.rows = self._bin(fn, other).rows
+        return self
+
+    __add__ = lambda s, o: s._bin(lambda a, b: a + b, o)
+    __radd__ = lambda s, o: s._bin(lambda a, b: b + a, o)
+    __sub__ = lambda s, o: s._bin(lambda a, b: a - b, o)
+    __rsub__ = lambda s, o: s._bin(lambda a, b: b - a, o)
+    __mul__ = lambda s, o: s._bin(lambda a, b: a * b, o)
+    __rmul__ = lambda s, o: s._bin(lambda a, b: b * a, o)
+    __truediv__ = lambda s, o: s._bin(lambda a, b: a / b, o)
+    __iadd__ = lambda s, o: s._ibin(lambda a, b: a + b, o)
+    __isub__ = lambda s, o: s._ibin(lambda a, b: a - b, o)
+    __imul__ = lambda s, o: s._ibin(lambda a, b: a * b, o)
+    __itruediv__ = lambda s, o: s._ibin(lambda a, b: a / b, o)
+    __neg__ = lambda s: SymMat([[-a for a in r] for r in s.rows])
+    __hash__ = None
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        name = _UFUNCS.get(ufunc.__name__)
+        if method != '__call__' or kwargs.get('out') is not None or name is None:
+            raise Unsupported('numpy %s.%s on a symbolic matrix' % (ufunc.__name__, method))
+        mats = [m for m in inputs if isinstance(m, SymMat)]
+        nr, nc = mats[0].shape
+        rows = []
+        for r in range(nr):
+            row = []
+            for c in range(nc):
+                args = [lift(m.rows[r][c] if isinstance(m, SymMat) else mats[0]._other(m, r, c)) for m in inputs]
+                row.append(Sym(Node('mul', args[0], args[0])) if name == 'square' else Sym(Node(name, *args)))
+            rows.append(row)
+        return SymMat(rows)
 
 
 class SymSprite(object):
@@ -603,6 +690,12 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
     elif node.op == 'attr':
         out.append(dict(op=_abi.MOOG_X_ATTR, a=ATTRS.index(node.args[1]), b=int(node.args[0])))
+    elif node.op == 'hdraw':      # a direct np.random draw of the state_initializer (reset-time expressions)
+        out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(node.args[0])))
+    elif node.op == 'slotattr':   # a factor of an earlier sprite; resolver('slot', sprite) gives its slot
+        if resolver is None:
+            raise Unsupported('sprite factor reference outside a state_initializer')
+        out.append(dict(op=_abi.MOOG_X_SLOT_ATTR, a=ATTRS.index(node.args[1]), b=int(resolver('slot', node.args[0]))))
     elif node.op == 'select':
         for a in node.args:
             emit(a, out, resolver)
@@ -624,11 +717,12 @@ def depth(code):
     d = m = 0
     for ins in code:
         op = ins['op']
-        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE, _abi.MOOG_X_OVERLAPS_FIRST):
+        if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE, _abi.MOOG_X_OVERLAPS_FIRST,
+                  _abi.MOOG_X_HDRAW, _abi.MOOG_X_SLOT_ATTR):
             d += 1
         elif op == _abi.MOOG_X_SELECT:
             d -= 2
-        elif op == _abi.MOOG_X_STORE:
+        elif op in (_abi.MOOG_X_STORE, _abi.MOOG_X_STORE_VERT):
             d -= 1
         elif op in (_abi.MOOG_X_NEG, _abi.MOOG_X_ABS, _abi.MOOG_X_SQRT, _abi.MOOG_X_SIN, _abi.MOOG_X_COS,
                     _abi.MOOG_X_FLOOR, _abi.MOOG_X_NOT, _abi.MOOG_X_SIGN):

@@ -26,12 +26,41 @@ class GenOp(object):
         self.sprites = sprites      # placeholder Sprite objects, one per reserved slot
 
 
+class HDrawOp(GenOp):
+    """One direct np.random call of the initializer (np.random.uniform / binomial outside a distribution): an op
+    without sprites that takes draw `index` of the reset; expressions refer to it as Node('hdraw', index)."""
+
+    def __init__(self, index, seq):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.index, self.seq = index, seq
+        from . import _abi
+        self.cell = (_abi.MOOG_CELL_HDRAW, index)
+
+
 class Tracer(object):
     def __init__(self):
         self.ops = []               # GenOp, in randomness-consumption order
         self.op_of = {}             # id(sprite) -> (op, k)
         self.randint_calls = []
+        self.n_hdraws = 0
         self.maze = None            # the per-reset random maze of the initializer (maze_lib/_traced.py)
+        self.seq = 0                # order of sampling events (deferred factor samples and direct draws)
+
+    def next_seq(self):
+        self.seq += 1
+        return self.seq
+
+    def hdraw(self):
+        """A new direct draw: a symbolic uniform in [0, 1)."""
+        from . import _abi, _symbolic
+        if getattr(self, 'suspend', False):
+            raise NotImplementedError('np.random calls inside a distribution sampled by generate_sprites')
+        if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+            raise NotImplementedError('more than %d direct np.random draws per reset' % _abi.MOOG_MAX_HDRAWS)
+        k = self.n_hdraws
+        self.n_hdraws += 1
+        self.add_op(HDrawOp(k, self.next_seq()))
+        return _symbolic.Sym(_symbolic.Node('hdraw', k))
 
     def add_op(self, op):
         self.ops.append(op)
@@ -50,7 +79,18 @@ def note_sprite(s):
     if t is None or getattr(t, 'suspend', False):
         return
     if s.is_symbolic:
-        t.add_op(GenOp(None, 1, 1, False, [], 0, [s]))
+        op = GenOp(None, 1, 1, False, [], 0, [s])
+        # The sprite's own factor samples were taken (in the reference) when `dist.sample()` ran; direct draws made
+        # after the first of them belong between / after them, not before the whole op.
+        own = sorted((s.factors[k].seq, k) for k in s.sample_order)
+        if own:
+            late = [o for o in t.ops if isinstance(o, HDrawOp) and o.seq > own[0][0]]
+            if late:
+                for o in late:
+                    t.ops.remove(o)
+                merged = sorted([(q, ('factor', k)) for q, k in own] + [(o.seq, ('hdraw', o.index)) for o in late])
+                op.draw_seq = [item for _, item in merged]
+        t.add_op(op)
 
 
 @contextlib.contextmanager
@@ -69,6 +109,24 @@ def tracing():
         t.randint_calls.append((int(low), int(high)))
         return int(high) - 1
     np.random.randint = fake_randint
+
+    # direct draws of the initializer become symbolic values the device re-draws at every reset (numpy's own
+    # formulas over one uniform each, as tests/golden/make_golden.py defines them)
+    def fake_uniform(low=0.0, high=1.0, size=None):
+        if size is not None:
+            raise NotImplementedError('np.random.uniform(size=...) inside a traced state_initializer')
+        return low + (high - low) * t.hdraw()
+
+    def fake_binomial(n, p, size=None):
+        if n != 1:
+            raise NotImplementedError('np.random.binomial(n != 1) inside a traced state_initializer')
+        from . import _symbolic
+        if size is None:
+            return t.hdraw() < p
+        count = int(np.prod(size))
+        if np.ndim(size) > 1 or (np.ndim(size) == 1 and len(size) != 1):
+            raise NotImplementedError('np.random.binomial with a multi-dimensional size')
+        return _symbolic.SymVec([t.hdraw() < p for _ in range(count)])
     # Any other draw from numpy's global generator inside the initializer would be taken
     # once, at build time, and frozen into every episode: refuse it instead.
     blocked = {}
@@ -83,6 +141,8 @@ def tracing():
                  'permutation', 'binomial'):
         blocked[name] = getattr(np.random, name)
         setattr(np.random, name, refuse(name))
+    np.random.uniform = fake_uniform
+    np.random.binomial = fake_binomial
     try:
         yield t
     finally:

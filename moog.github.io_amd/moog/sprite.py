@@ -20,6 +20,27 @@ class SymbolicFactor(object):
 
     def __init__(self, dist):
         self.dist = dist  # distributions.Continuous / Discrete
+        from . import _trace
+        t = _trace.active()
+        self.seq = t.next_seq() if t is not None else 0   # when the reference would have drawn it
+        self.owner = None                                  # (sprite, factor name) that carries the draw
+
+
+class ExprFactor(SymbolicFactor):
+    """A factor value the initializer computed from its own np.random draws / from other sprites' factors: an
+    expression tree (moog/_symbolic.py) evaluated on the device at every reset; takes no draw itself."""
+
+    def __init__(self, node):
+        SymbolicFactor.__init__(self, None)
+        self.node = node
+
+
+class ExprShape(SymbolicFactor):
+    """A raw shape whose vertex coordinates are expressions (parallelogram_catch.py:34-43)."""
+
+    def __init__(self, rows):
+        SymbolicFactor.__init__(self, None)
+        self.rows = rows   # [[node_x, node_y], ...]
 
 
 class Sprite(object):
@@ -36,14 +57,35 @@ class Sprite(object):
         if unknown:
             raise TypeError('unknown sprite factors: %s' % sorted(unknown))
         self.factors = dict(_DEFAULTS)
-        self.factors.update(factors)
-        self.sample_order = [k for k in factors if isinstance(factors[k], SymbolicFactor)]
+        self.factors.update(self._adopt(factors))
+        self.sample_order = [k for k in factors if isinstance(self.factors[k], SymbolicFactor) and
+                             not isinstance(self.factors[k], (ExprFactor, ExprShape))]
         from . import _trace
         _trace.note_sprite(self)
 
+    def _adopt(self, factors):
+        """Symbolic values as factor records: expressions become ExprFactor / ExprShape; a sampled factor that
+        another sprite already carries (`Sprite(x=other.x)`, multi_tracking_with_feature.py:137-141) becomes a
+        reference to that sprite's value instead of a second draw."""
+        from . import _symbolic
+        out = {}
+        for k, v in factors.items():
+            if isinstance(v, _symbolic.Sym):
+                v = ExprFactor(v.node)
+            elif k == 'shape' and isinstance(v, _symbolic.SymMat):
+                v = ExprShape([[_symbolic.lift(c) for c in row] for row in v.rows])
+            elif isinstance(v, SymbolicFactor) and not isinstance(v, (ExprFactor, ExprShape)) \
+                    and getattr(v, 'cell', None) is None:
+                if v.owner is None:
+                    v.owner = (self, k)
+                elif v.owner[0] is not self:
+                    v = ExprFactor(_symbolic.Node('slotattr', v.owner[0], v.owner[1]))
+            out[k] = v
+        return out
+
     @property
     def is_symbolic(self):
-        return bool(self.sample_order)
+        return any(isinstance(v, SymbolicFactor) for v in self.factors.values())
 
     def __setattr__(self, name, value):
         # `sprite.mass = ...` after construction (e.g. predators_arena.py:88-89 inside its

@@ -129,7 +129,7 @@ def patch_numpy_random():
 
 
 SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
-           'first_person_predators_prey', 'cleanup', 'pacman')
+           'first_person_predators_prey', 'cleanup', 'pacman', 'parallelogram_catch')
 
 
 def load_amd_config(name):
@@ -137,6 +137,8 @@ def load_amd_config(name):
     variants from this repo's recipes, run against the reference package."""
     if name in SHIPPED:
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
+    if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
+        return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
     if name == 'pacman_l1':   # level 1: three ghosts, 10 x 10 maze
         return importlib.import_module('moog_demos.example_configs.pacman').get_config(1)
     if name == 'chase_avoid_torus_l1':   # level 1: 1-2 prey and 1-2 predators (randint counts)
@@ -677,6 +679,9 @@ def main():
         ('pacman_l1', 100, {'walls': 136, 'prey': 75}, (0,)),
         ('sampler_zoo', 60, {'blocks': 8}, (0, 1)),
         ('sampler_zoo_l1', 70, {'blocks': 8, '__dynamic__': ('blocks',)}, (0,)),
+        ('parallelogram_catch', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
+        ('parallelogram_catch_l1', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
+        ('parallelogram_catch_l2', 60, {'__vmax__': SNAP_VMAX}, (0,)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),

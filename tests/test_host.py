@@ -45,7 +45,7 @@ def test_missing_library_fails_loudly(tmp_path):
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
 @pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
                                   'functional_maze', 'falling_balls', 'first_person_predators_prey',
-                                  'cleanup', 'pacman'])
+                                  'cleanup', 'pacman', 'parallelogram_catch'])
 def test_reference_configs_load_unchanged(name):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
@@ -219,22 +219,30 @@ def test_chain_generators_is_a_sequence_of_ops():
         sg.shuffle(gen)
 
 
-def test_host_randomness_in_initializer_is_refused():
-    """A state_initializer that draws from np.random directly (e.g.
-    bounce_box_contact_prediction.py:77-79) would be sampled once at build time; the lowering
-    refuses it instead of freezing the draw into every episode."""
+def test_host_randomness_in_initializer():
+    """A state_initializer that draws from np.random directly (parallelogram_catch.py:36-38,64-65) must not be
+    sampled once at build time and frozen into every episode: uniform / binomial draws become per-reset draws on the
+    device (an op per draw, factors as expressions of them); generators the lowering has no device form for are refused."""
     import collections
     from moog import action_spaces, observers, physics as physics_lib, sprite, tasks
 
-    def state_initializer():
-        return collections.OrderedDict(
-            [('agent', [sprite.Sprite(x=np.random.uniform(0.2, 0.8), y=0.5, scale=0.1)])])
+    def config(draw):
+        def state_initializer():
+            return collections.OrderedDict([('agent', [sprite.Sprite(x=draw(), y=0.5, scale=0.1)])])
+        return dict(state_initializer=state_initializer, physics=physics_lib.Physics(),
+                    task=tasks.CompositeTask(timeout_steps=5),
+                    action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
+                    observers={'image': observers.PILRenderer(image_size=(64, 64))})
+    c = _compiler.compile_config(**config(lambda: 0.5 * np.random.uniform(0.2, 0.8)))
+    P = c.program
+    assert P.n_hdraws == 1 and c.layout.o_hdraw >= 0
+    ops = [P.ops[i] for i in range(P.n_ops)]
+    assert [o.cell_sel for o in ops] == [_abi.MOOG_CELL_HDRAW, _abi.MOOG_CELL_NONE]
+    assert ops[1].factors[_abi.MOOG_FAC_X].kind == _abi.MOOG_DIST_EXPR
+    code = [P.dcode[ops[1].factors[_abi.MOOG_FAC_X].cand_off + k].op for k in range(8)]
+    assert _abi.MOOG_X_HDRAW in code and code[-1] == _abi.MOOG_X_END   # 0.5 * (0.2 + 0.6 * u)
     with pytest.raises(NotImplementedError):
-        _compiler.compile_config(
-            state_initializer=state_initializer, physics=physics_lib.Physics(),
-            task=tasks.CompositeTask(timeout_steps=5),
-            action_space=action_spaces.Joystick(scaling_factor=0.01, action_layers='agent'),
-            observers={'image': observers.PILRenderer(image_size=(64, 64))})
+        _compiler.compile_config(**config(lambda: np.random.normal(0.5, 0.1)))
     assert 0.0 <= np.random.uniform(0., 1.) < 1.0   # the generator is restored afterwards
 
 

@@ -22,7 +22,9 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
         ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
-        ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0)]
+        ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
+        ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
+        ('parallelogram_catch_l2', 0)]
 TOL = 1e-5   # BASELINE.json: float sprite state within 1e-5 abs
 
 
