@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 18
+#define MOOG_ABI_VERSION 19
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -300,14 +300,20 @@ enum {
                                       (stepped on the phase's first step) followed by the
                                       continual rules; ends after p0 steps or when cond
                                       (MOOG_RCOND_*, 0 = never) holds; state = step count,
-                                      -1 once ended                                 */
+                                      -1 once ended.  op = 1: the duration is drawn when the
+                                      phase is reset, np.random.randint(p0, p2) (task_phases.py:72),
+                                      and kept in o_rule2                           */
   MOOG_RULE_PHASE_SEQUENCE,        /* task_phases.py:101-141: children = PHASE rules, one
                                       current at a time; state = index of the current one */
   MOOG_RULE_KEEP_NEAR_CENTER,      /* re_center.py:48-58: l0 agent layer, layers[] to move,
                                       p0 / p1 grid cell                            */
-  MOOG_RULE_MODIFY_ON_CONTACT      /* contact_rules.py:112-141: layers[] x layers1[];
+  MOOG_RULE_MODIFY_ON_CONTACT,     /* contact_rules.py:112-141: layers[] x layers1[];
                                       xmod / filter for side 0, xmod1 / filter1 for
                                       side 1 (xmod < 0: no modifier on that side)  */
+  MOOG_RULE_FIXATION               /* fixation.py:17-58: state = consecutive steps during which the first sprite
+                                      of l0 has been within p0 of the first sprite of l1 (the number the
+                                      reference keeps in meta_state[key]); conditions read it through
+                                      MOOG_X_RULE_STATE                                                   */
 };
 /* sprite filters: ALWAYS, or the expression at rule.xfilter */
 enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };
@@ -339,7 +345,8 @@ typedef struct {
   int32_t xmod;        /* MODIFY_*: modifier code (X_STORE ...), or -1            */
   int32_t filter1, xfilter1, xmod1;   /* MODIFY_ON_CONTACT, side 1                */
   int32_t i0;          /* MODIFY_SPRITES: sample_one; velocity assigned as a whole
-                        * by xmod (bit 1) / xmod1 (bit 2)                          */
+                        * by xmod (bit 1) / xmod1 (bit 2); bit 3: only the layer's first
+                        * sprite is modified (a rule written as `s = state[L][0]; s.attr = ...`) */
   int32_t n_layers1;
   int32_t layers1[MOOG_MAX_LAYERS];
   double p0, p1, p2;
@@ -450,7 +457,7 @@ typedef struct {
   int32_t n_shapes;
   int32_t n_cand;
   int32_t n_hdraws;                /* direct np.random draws per reset (o_hdraw) */
-  int32_t pad_hdraws_;
+  int32_t rule_state2;             /* some rule keeps a second scalar (o_rule2) */
   double timeout_steps;            /* CompositeTask timeout (inf allowed)      */
 
   moog_force_t forces[MOOG_MAX_FORCES];
@@ -497,6 +504,7 @@ typedef struct {
   int32_t o_task;     /* [T]      per-task _steps_until_reset (inf sentinel)   */
   int32_t o_rule;     /* [R]      per-rule scalar (Booster countdown)          */
   int32_t o_hdraw;    /* [n_hdraws] the uniforms of this episode's direct draws; -1 when there are none */
+  int32_t o_rule2;    /* [R] second per-rule scalar (the drawn duration of a PHASE); -1 unless program.rule_state2 */
   int32_t o_scale;    /* [S] sprite.scale, [S] sprite.aspect_ratio at o_aspect; -1 when
                        *     program.sprite_factors == 0                              */
   int32_t o_aspect;
@@ -538,6 +546,7 @@ static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   L->o_task = o; o += p->n_tasks;
   L->o_rule = o; o += p->n_rules;
   if (p->n_hdraws > 0) { L->o_hdraw = o; o += p->n_hdraws; } else L->o_hdraw = -1;
+  if (p->rule_state2) { L->o_rule2 = o; o += p->n_rules; } else L->o_rule2 = -1;
   if (p->sprite_factors) { L->o_scale = o; o += S; L->o_aspect = o; o += S; }
   else { L->o_scale = -1; L->o_aspect = -1; }
   o = moog_align_(o, 2);

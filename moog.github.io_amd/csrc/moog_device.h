@@ -2169,6 +2169,14 @@ __device__ inline void run_modifier(Env& e, int xmod, int s) {
   wsync();
   if (has(MOOG_XA_X) || has(MOOG_XA_Y)) set_position(e, s, nx, ny);
   wsync();
+  if constexpr (MOOG_WITH_MAZE != 0) {   // sprite.py:531-540 (in the kernels that carry every component)
+    if (has(MOOG_XA_ANGLE)) {
+      const double na = sv[MOOG_XA_ANGLE];
+      rotate_path(e, s, na - ANG(s));
+      if (e.lane == 0) ANG(s) = na;
+      wsync();
+    }
+  }
   if (e.lane == 0) {
     const bool sf = e.P->sprite_factors != 0;
     int fl = FLAGS(s);
@@ -2315,7 +2323,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         }
       }
       if (n == 0) return;
-      int pick = -1;
+      int pick = (R->i0 & 8) ? 0 : -1;   // bit 3: a config-local rule on `state[L][0]`
       if (R->i0 & 1) {   // sample_one: np.random.choice(sprites_to_modify)
         pick = 0;
         if (n > 1) { pick = (int)(next_uniform(e) * n); if (pick >= n) pick = n - 1; }
@@ -2421,6 +2429,21 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (FLAGS(s) & MOOG_F_TMP) FLAGS(s) &= ~(MOOG_F_TMP | MOOG_F_ALIVE);
       wsync();
       if constexpr (DYN) layer_compact(e, R->l0);
+      break;
+    }
+    case MOOG_RULE_FIXATION: {   // fixation.py:48-58
+      int a = -1, t = -1;
+      for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0] && a < 0; ++s)
+        if (ALIVE(s)) a = s;
+      for (int s = P->layer_slot0[R->l1]; s < P->layer_slot0[R->l1] + P->layer_nslots[R->l1] && t < 0; ++s)
+        if (ALIVE(s)) t = s;
+      if (a < 0 || t < 0) break;   // (state[layer][0] of an empty layer raises IndexError in the reference)
+      const double dx = PX(a) - PX(t), dy = PY(a) - PY(t);
+      const double dist = sqrt(dx * dx + dy * dy);   // np.linalg.norm
+      const double cnt = e.f[e.L.o_rule + ri];
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
+      wsync();
       break;
     }
     case MOOG_RULE_KEEP_NEAR_CENTER: {   // re_center.py:48-58
@@ -2539,8 +2562,16 @@ __device__ inline void rule_reset(Env& e, int ri) {
   __threadfence();
   if (e.lane == 0)
     e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
-        ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE) ? 0.0 : DINF);
+        ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
+  if (R->kind == MOOG_RULE_PHASE && R->op == 1) {   // task_phases.py:72: the duration is drawn when the phase is reset
+    const int lo = (int)R->p0, hi = (int)R->p2;
+    int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
+    if (k >= hi - lo) k = hi - lo - 1;
+    wsync();
+    if (e.lane == 0) e.f[e.L.o_rule2 + ri] = (double)(lo + k);
+    wsync();
+  }
 }
 
 // TimedRule.reset / ConditionalRule.reset (timing.py:46-49, conditional.py:56-58): the whole
@@ -2649,7 +2680,8 @@ __device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
   if (g.n == 0) return;
   if (R->kind == MOOG_RULE_PHASE) {
     double st = e.f[e.L.o_rule + ri] + 1;
-    if (st >= R->p0 || (R->cond && rule_condition<DYN>(e, R, R->p1) != 0)) st = -1;
+    const double duration = (R->op == 1) ? e.f[e.L.o_rule2 + ri] : R->p0;
+    if (st >= duration || (R->cond && rule_condition<DYN>(e, R, R->p1) != 0)) st = -1;
     wsync();
     if (e.lane == 0) e.f[e.L.o_rule + ri] = st;
     wsync();

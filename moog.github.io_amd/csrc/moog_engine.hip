@@ -372,6 +372,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
+  for (int r = 0; r < prog->n_rules; ++r)
+    if (prog->rules[r].kind == MOOG_RULE_FIXATION || (prog->rules[r].kind == MOOG_RULE_PHASE && prog->rules[r].op == 1))
+      e->dynamic_rules = true;
+  for (int k = 0; k < prog->n_dcode; ++k)   // assigning sprite.angle turns the path: in the kernels that carry every component
+    if (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE) e->maze_kernel = true;
   if (prog->n_hdraws > 0) e->maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
   for (int o = 0; o < prog->n_ops; ++o)
     for (int k = 0; k < MOOG_NUM_FACTORS; ++k)

@@ -30,6 +30,7 @@ __host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
   // fields behind the colours (moog_layout(): inertia, maxr, action, task, rule, scale, aspect, verts)
   h.L.o_inertia -= fc; h.L.o_maxr -= fc; h.L.o_action -= fc; h.L.o_task -= fc; h.L.o_rule -= fc;
   if (G.o_hdraw >= 0) h.L.o_hdraw -= fc;
+  if (G.o_rule2 >= 0) h.L.o_rule2 -= fc;
   if (G.o_scale >= 0) { h.L.o_scale -= fc; h.L.o_aspect -= fc; }
   h.L.o_verts -= fc; h.L.f64_per_env -= fc;
   // opacity, shape ids and the Portal bits are adjacent ([S] each)

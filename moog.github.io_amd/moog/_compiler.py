@@ -565,9 +565,20 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if isinstance(r, rules_lib.PhaseSequence) and r._meta_state_key is not None:
             phase_keys[r._meta_state_key] = (ri, [ph.name for ph in r._phases])
 
+    fixation_keys = {}   # meta-state key -> index of the Fixation rule that counts under it
+    for ri, (r, _parent) in enumerate(flat_rules):
+        if isinstance(r, rules_lib.Fixation):
+            if r._meta_state_fixation_key in fixation_keys or r._meta_state_fixation_key in phase_keys:
+                raise NotImplementedError('two rules publish meta_state[%r]' % (r._meta_state_fixation_key,))
+            fixation_keys[r._meta_state_fixation_key] = ri
+
     def resolve_phase(key, name):
         if key is None:   # an overlap test against state[name][0]
             return layer_index(name)
+        if name is None:  # the number a Fixation rule keeps under this key
+            if key not in fixation_keys:
+                raise NotImplementedError('meta_state[%r] is not kept by a Fixation rule' % (key,))
+            return fixation_keys[key]
         if key not in phase_keys:
             raise NotImplementedError('meta_state[%r] is not published by a PhaseSequence' % (key,))
         ri, names = phase_keys[key]
@@ -633,10 +644,17 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.l0 = layer_index(r._agent_layer)
             R.n_layers = _fill_layers(R.layers, r._layers_to_center, layer_index)
             R.p0, R.p1 = r._grid_cell
+        elif isinstance(r, rules_lib.Fixation):
+            R.kind = _abi.MOOG_RULE_FIXATION
+            R.l0, R.l1 = layer_index(r._agent_layer), layer_index(r._fixation_layer)
+            R.p0 = float(r._fixation_threshold)
         elif isinstance(r, rules_lib.Phase):
             R.kind = _abi.MOOG_RULE_PHASE
             R.i0 = len(r._one_time_rules)
             R.p0 = r._duration
+            if r._random_duration is not None:   # np.random.randint(lo, hi), drawn whenever the phase is reset
+                R.op, R.p0, R.p2 = 1, float(r._random_duration[0]), float(r._random_duration[1])
+                P.rule_state2 = 1
             if r._end_condition is not None:
                 R.cond, _p, lay, node = rules_lib.classify_condition(r._end_condition)
                 if lay is not None:
@@ -673,9 +691,17 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.kind, R.l0, R.l1 = d['kind'], d.get('l0', 0), d.get('l1', 0)
             R.p0, R.p1, R.p2 = d.get('p0', 0.), d.get('p1', 0.), d.get('p2', 0.)
         else:
-            raise NotImplementedError(
-                'game rule %r has no device lowering (see game_rules.register_lowering)'
-                % (type(r).__name__,))
+            # a config-local rule class: its step() is traced once on a symbolic state
+            try:
+                lname, mod, vec = _symbolic.trace_rule_step(r.step)
+            except (NotImplementedError, AttributeError, TypeError) as exc:
+                raise NotImplementedError(
+                    'game rule %r has no device lowering (see game_rules.register_lowering): %s'
+                    % (type(r).__name__, exc))
+            R.kind, R.filter = _abi.MOOG_RULE_MODIFY_SPRITES, _abi.MOOG_FILTER_ALWAYS
+            R.n_layers = _fill_layers(R.layers, [lname], layer_index)
+            R.xmod = put_expr(stores=mod)
+            R.i0 = 8 | (2 if vec else 0)   # only the layer's first sprite
     P.n_rules = len(flat_rules)
 
     # ---- task -----------------------------------------------------------------------

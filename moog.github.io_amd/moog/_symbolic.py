@@ -24,7 +24,7 @@ MAX_PATHS = 256
 # attribute ids (MOOG_XA_*)
 ATTRS = ('x', 'y', 'x_vel', 'y_vel', 'angle', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity',
          'scale', 'aspect_ratio')
-SETTABLE = ('x', 'y', 'x_vel', 'y_vel', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity')
+SETTABLE = ('x', 'y', 'x_vel', 'y_vel', 'angle', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity')
 
 
 class Unsupported(NotImplementedError):
@@ -464,6 +464,40 @@ def trace_modifier(fn):
     return out, vec_vel
 
 
+def trace_rule_step(step_fn):
+    """Lowers the `step(state, meta_state)` of a config-local rule class that modifies the first sprite of one layer
+    (`s = state[L][0]; s.attr = expr(s)`, e.g. multi_tracking_with_feature.py:66-74).  Returns (layer name,
+    {attr: expression}, velocity assigned as a whole)."""
+    global _TRACER
+    st = _SymState(1)
+    made = []
+    real_first = _SymLayer.__getitem__
+
+    def first(self, i):
+        sp = real_first(self, i)
+        made.append((self._name, sp))
+        return sp
+    _SymLayer.__getitem__ = first
+    tr = _Tracer()
+    prev, _TRACER = _TRACER, tr
+    try:
+        step_fn(st, _SymMeta())
+    finally:
+        _TRACER = prev
+        _SymLayer.__getitem__ = real_first
+    if tr.trail:
+        raise Unsupported('a config-local rule that branches on the state')
+    written = [(l, sp) for l, sp in made if sp._written]
+    if len(written) != 1 or any(k == 'quant' for k, _ in st.uses):
+        raise Unsupported('a config-local rule must modify the first sprite of exactly one layer')
+    layer, sp = written[0]
+    for node in [v.node for k, v in sp._written.items() if not k.startswith('__')]:
+        if _sprites_of(node, set()) - {0}:
+            raise Unsupported('a config-local rule that reads other sprites')
+    mod = {k: v.node for k, v in sp._written.items() if not k.startswith('__')}
+    return layer, mod, '__vec_velocity' in sp._written
+
+
 # ---- state-level conditions ---------------------------------------------------------------------
 class _SymLayer(object):
     """`state[layer]` inside a traced condition.  Iteration yields two representative sprites
@@ -501,20 +535,34 @@ class _SymState(object):
 
 
 class _SymMetaValue(object):
-    """`meta_state[key]` inside a traced condition: only `== 'phase name'` / `!=` are lowered
-    (the value a PhaseSequence publishes, task_phases.py:126-127,140-141)."""
+    """`meta_state[key]` inside a traced condition: `== 'phase name'` / `!=` test the value a PhaseSequence
+    publishes (task_phases.py:126-127,140-141); in arithmetic and numeric comparisons it is the count a Fixation
+    rule publishes under that key (fixation.py:47-58), i.e. that rule's state scalar."""
 
     def __init__(self, key):
         self._key = key
 
+    def _num(self):
+        return Sym(Node('meta_num', self._key))
+
     def __eq__(self, other):
-        if not isinstance(other, str):
-            raise Unsupported('meta_state values can only be compared with a phase name')
-        return Sym(Node('phase_is', self._key, other))
+        if isinstance(other, str):
+            return Sym(Node('phase_is', self._key, other))
+        return self._num() == other
 
     def __ne__(self, other):
         return Sym(Node('not', self.__eq__(other).node))
 
+    __lt__ = lambda s, o: s._num() < o
+    __le__ = lambda s, o: s._num() <= o
+    __gt__ = lambda s, o: s._num() > o
+    __ge__ = lambda s, o: s._num() >= o
+    __add__ = lambda s, o: s._num() + o
+    __radd__ = lambda s, o: o + s._num()
+    __sub__ = lambda s, o: s._num() - o
+    __rsub__ = lambda s, o: o - s._num()
+    __mul__ = lambda s, o: s._num() * o
+    __rmul__ = lambda s, o: o * s._num()
     __hash__ = None
 
 
@@ -528,7 +576,7 @@ def _substitute(node, old, new):
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
-    if node.op in ('const', 'phase_is'):
+    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -536,7 +584,7 @@ def _substitute(node, old, new):
 def _sprites_of(node, acc):
     if node.op in ('attr', 'overlaps'):
         acc.add(node.args[0])
-    elif node.op not in ('const', 'phase_is'):
+    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -565,6 +613,8 @@ def _evaluate(node, env):
         return env.get(node.key(), False)
     if op in ('overlaps', 'phase_is'):
         return env.get(node.key(), True)
+    if op == 'meta_num':
+        return env.get(node.key(), False)
     v = [_evaluate(x, env) for x in a]
     if op == 'select':
         return v[1] if v[0] != 0 else v[2]
@@ -680,6 +730,11 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_RULE_STATE, a=rule))
         out.append(dict(op=_abi.MOOG_X_CONST, x=float(idx), b=0))
         out.append(dict(op=_abi.MOOG_X_EQ))
+        return out
+    if node.op == 'meta_num':   # the count a Fixation rule publishes under this meta-state key
+        if resolver is None:
+            raise Unsupported('meta_state value outside a config with a Fixation rule')
+        out.append(dict(op=_abi.MOOG_X_RULE_STATE, a=resolver(node.args[0], None)))
         return out
     if node.op == 'overlaps':   # (layer sprite, state[L][0]); resolver(None, L) gives L's index
         if resolver is None:

@@ -58,13 +58,12 @@ class BatchedEnvironment(object):
         self.observers = observers
         self.game_rules = game_rules
         self.num_envs = int(num_envs)
-        # meta_state (environment.py:60-63,87): a host-side Python object shared by the
-        # `ModifyMetaState` rules.  It is per environment in the reference, so it is only
-        # available for a batch of one.
+        # meta_state (environment.py:60-63,87): a host-side Python object per environment, touched only by
+        # `ModifyMetaState` rules (arbitrary Python, never sprites): one object for a batch of one, a list of
+        # num_envs objects otherwise.  Those rules run in a host loop over the envs, and every step then reads the
+        # auto-reset flags back (one device-to-host copy per step): convenient, not fast.
         self._host_rules = [r for r in game_rules if getattr(r, 'host_side', False)]
         self._meta_state_initializer = meta_state_initializer
-        if self._host_rules and self.num_envs != 1:
-            raise NotImplementedError('ModifyMetaState rules need num_envs == 1')
         self._meta_state = None
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
             else torch.device(device)
@@ -214,11 +213,21 @@ class BatchedEnvironment(object):
         if self._host_rules or self._meta_state_initializer is not None:
             # environment.py:100-104: an auto-reset re-initialises the meta-state; either way
             # every rule steps once per call
-            if bool(self.reset_next_step[0].item()):
-                self._host_reset()
+            flags = self.reset_next_step.cpu().numpy()
+            if self.num_envs == 1:
+                if flags[0]:
+                    self._host_reset()
+                else:
+                    for r in self._host_rules:
+                        r.step(None, self._meta_state)
             else:
-                for r in self._host_rules:
-                    r.step(None, self._meta_state)
+                if self._meta_state is None:   # stepped from a loaded state without a reset()
+                    self._meta_state = [self._new_meta_state() for _ in range(self.num_envs)]
+                for i in range(self.num_envs):
+                    if flags[i]:
+                        self._meta_state[i] = self._new_meta_state()
+                    for r in self._host_rules:
+                        r.step(None, self._meta_state[i])
         inj, keep = self._inject(injected_uniforms)
         with torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_step(
@@ -259,13 +268,19 @@ class BatchedEnvironment(object):
         assert a.shape == (n, 2 * k), a.shape
         return a.contiguous()
 
+    def _new_meta_state(self):
+        return self._meta_state_initializer() if self._meta_state_initializer is not None else None
+
     def _host_reset(self):
-        if self._meta_state_initializer is not None:
-            self._meta_state = self._meta_state_initializer()
-        elif self._host_rules:
-            self._meta_state = None
-        for r in self._host_rules:
-            r.step(None, self._meta_state)
+        if self.num_envs == 1:
+            self._meta_state = self._new_meta_state()
+            for r in self._host_rules:
+                r.step(None, self._meta_state)
+            return
+        self._meta_state = [self._new_meta_state() for _ in range(self.num_envs)]
+        for m in self._meta_state:
+            for r in self._host_rules:
+                r.step(None, m)
 
     @property
     def meta_state(self):

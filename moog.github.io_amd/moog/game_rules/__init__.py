@@ -211,10 +211,28 @@ class Phase(AbstractRule):
             one_time_rules = (one_time_rules,)
         if not isinstance(continual_rules, (list, tuple)):
             continual_rules = (continual_rules,)
-        if callable(duration):
-            raise NotImplementedError('Phase with a callable duration is not lowered')
         self._one_time_rules, self._continual_rules = tuple(one_time_rules), tuple(continual_rules)
         self._end_condition = end_condition
+        self._random_duration = None
+        if callable(duration):
+            # task_phases.py:72 draws `duration()` whenever the phase is reset; the one form the configs use,
+            # `lambda: np.random.randint(lo, hi)` (multi_tracking_with_feature.py:233), is drawn on the device
+            real, seen = np.random.randint, []
+
+            def probe(low, high=None, size=None, dtype=int):
+                if high is None:
+                    low, high = 0, low
+                seen.append((int(low), int(high), size))
+                return int(low)
+            np.random.randint = probe
+            try:
+                value = duration()
+            finally:
+                np.random.randint = real
+            if len(seen) != 1 or seen[0][2] is not None or value != seen[0][0]:
+                raise NotImplementedError('a callable Phase duration other than np.random.randint(lo, hi)')
+            self._random_duration = seen[0][:2]
+            duration = seen[0][0]
         self._duration = float(duration)
         self._name = name
 
@@ -243,6 +261,20 @@ class PhaseSequence(AbstractRule):
     @property
     def _rules(self):
         return self._phases
+
+
+class Fixation(AbstractRule):
+    """fixation.py:17-58: counts the consecutive steps during which the first sprite of `agent_layer` stays within
+    `fixation_threshold` of the first sprite of `fixation_layer`.  The reference keeps the count in
+    meta_state[meta_state_fixation_key]; here it is the rule's state scalar on the device, and traced conditions that
+    read `meta_state[key]` (e.g. `>= 15`, multi_tracking_with_feature.py:205-206) read that scalar."""
+
+    def __init__(self, agent_layer, fixation_layer, fixation_threshold=0.1,
+                 meta_state_fixation_key='fixation_duration'):
+        self._agent_layer = agent_layer
+        self._fixation_layer = fixation_layer
+        self._fixation_threshold = fixation_threshold
+        self._meta_state_fixation_key = meta_state_fixation_key
 
 
 class _ContactCounter(object):

@@ -108,7 +108,9 @@ def _shuffle(x):
 
 
 def _binomial(n, p, size=None):
-    assert n == 1 and size is None
+    assert n == 1
+    if size is not None:   # one tape uniform per element (multi_tracking_with_feature.py:136)
+        return np.array([int(TAPE.u() < p) for _ in range(int(np.prod(size)))]).reshape(size)
     return int(TAPE.u() < p)
 
 
@@ -117,6 +119,19 @@ def _rand(*shape):
     if not shape:
         return TAPE.u()
     return np.array([TAPE.u() for _ in range(int(np.prod(shape)))]).reshape(shape)
+
+
+def track_and_fixate(env, t, rs):
+    """Policy for multi_tracking_with_feature: hold the gaze on the fixation cross (with a lapse now and then, so that
+    the fixation counter restarts), then on the first target once its bar has turned."""
+    phase = env.meta_state.get('phase', '')
+    if phase == 'change':
+        goal = np.array(env.state['targets'][0].position, dtype=float)
+    else:
+        goal = np.array([0.5, 0.5])
+    if t % 41 == 5 and phase in ('fixation', 'change'):
+        return rs.uniform(0., 1., size=2)      # a lapse
+    return np.clip(goal + rs.uniform(-0.03, 0.03, size=2), 0., 1.)
 
 
 def patch_numpy_random():
@@ -130,6 +145,7 @@ def patch_numpy_random():
 
 SHIPPED = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
            'first_person_predators_prey', 'cleanup', 'pacman', 'parallelogram_catch')
+# (multi_tracking_with_feature takes its number of targets where the others take a level)
 
 
 def load_amd_config(name):
@@ -139,6 +155,8 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
         return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
+    if name in ('multi_tracking_with_feature_l1', 'multi_tracking_with_feature_l3'):
+        return importlib.import_module('moog_demos.example_configs.multi_tracking_with_feature').get_config(int(name[-1]))
     if name == 'pacman_l1':   # level 1: three ghosts, 10 x 10 maze
         return importlib.import_module('moog_demos.example_configs.pacman').get_config(1)
     if name == 'chase_avoid_torus_l1':   # level 1: 1-2 prey and 1-2 predators (randint counts)
@@ -226,6 +244,8 @@ def bookkeeping(env):
           for r in env.game_rules]
 
     def state_of(r):   # the scalar the engine keeps per rule (include/moog_engine.h moog_rule_t)
+        if hasattr(r, '_meta_state_fixation_key'):   # Fixation keeps its count in the meta-state (fixation.py:44-58)
+            return float(env.meta_state[r._meta_state_fixation_key])
         if hasattr(r, '_current_phase_ind'):
             return float(r._current_phase_ind)
         if hasattr(r, '_should_end'):
@@ -244,10 +264,24 @@ def bookkeeping(env):
                 walk(list(kids), out)
         return out
     rc_flat = walk(list(env.game_rules), [])
+
+    def walk2(rules, out):   # second scalar per rule: the duration a Phase drew when it was reset (task_phases.py:72)
+        for r in rules:
+            out.append(float(getattr(r, '_current_duration', np.nan)))
+            kids = getattr(r, '_phases', None)
+            if kids is None and hasattr(r, '_one_time_rules'):
+                kids = list(r._one_time_rules) + list(r._continual_rules)
+            if kids is None:
+                kids = getattr(r, '_rules', None)
+            if kids is not None:
+                walk2(list(kids), out)
+        return out
+    rc2_flat = walk2(list(env.game_rules), [])
     return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
                 action_mem=action_memory(env.action_space),
                 task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
-                rule_counters_flat=np.array(rc_flat, dtype=float))
+                rule_counters_flat=np.array(rc_flat, dtype=float),
+                rule_counters2_flat=np.array(rc2_flat, dtype=float))
 
 
 def make_slot_map(env, layer_names, caps):
@@ -268,6 +302,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     action_bias = caps_by_layer.pop('__bias__', None)   # [n_spaces][2] drift of the random actions
     skip = caps_by_layer.pop('__skip__', 0)   # un-recorded steps after the reset: the recording starts from a later state
     sub_calls = tuple(caps_by_layer.pop('__sub_calls__', ()))   # further calls whose sub-step states are recorded
+    script = caps_by_layer.pop('__script__', None)   # (env, call, RandomState) -> action: a policy instead of random actions
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -354,6 +389,9 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
             action = np.stack([d[1] for _, d in drawn])
         elif space_kind == 'SetPosition':
             ref_action, action = draw_action(env.action_space)
+            if script is not None:
+                ref_action = np.asarray(script(env, t, act_rs), dtype=float)
+                action = ref_action.copy()
         else:
             action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
             ref_action = action if is_grid else np.array(action)
@@ -682,6 +720,8 @@ def main():
         ('parallelogram_catch', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l1', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l2', 60, {'__vmax__': SNAP_VMAX}, (0,)),
+        ('multi_tracking_with_feature_l3', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0, 1)),
+        ('multi_tracking_with_feature_l1', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0,)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),

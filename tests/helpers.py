@@ -162,6 +162,10 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
         for r in range(min(P.n_rules, len(flat))):
             if not np.isnan(flat[r]):
                 f[L.o_rule + r] = flat[r]
+    if P.rule_state2:   # the duration a Phase drew when it was reset
+        flat2 = np.asarray(fx['rule_counters2_flat'][t], np.float64).reshape(-1)
+        for r in range(min(P.n_rules, len(flat2))):
+            f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[r]) else flat2[r]
     pm = portal_rule_mask(P)
     for s in range(S):
         nv = int(fx['nverts'][t][s])
@@ -294,6 +298,18 @@ def state_diff(fx, t, c, f64, i32, env=0):
         ints_ok = False
         detail.append('step_count/reset_next %d/%d vs %d/%d' % (
             q[L.o_step_count], q[L.o_reset_next], fx['step_count'][t], fx['reset_next'][t]))
+    if 'rule_counters_flat' in fx:   # every rule of the pre-order forest (NaN: the reference rule keeps no number)
+        flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
+        for r in range(min(P.n_rules, len(flat))):
+            if not np.isnan(flat[r]) and f[L.o_rule + r] != flat[r]:
+                ints_ok = False
+                detail.append('rule %d state: %r vs %r' % (r, f[L.o_rule + r], flat[r]))
+    if P.rule_state2:
+        flat2 = np.asarray(fx['rule_counters2_flat'][t], np.float64).reshape(-1)
+        for r in range(min(P.n_rules, len(flat2))):
+            if P.rules[r].op == 1 and P.rules[r].kind == _abi.MOOG_RULE_PHASE and f[L.o_rule2 + r] != flat2[r]:
+                ints_ok = False
+                detail.append('phase %d duration: %r vs %r' % (r, f[L.o_rule2 + r], flat2[r]))
     if P.maze.random:
         rows = maze_rows_from_fixture(fx, t, c)
         if not np.array_equal(q[L.o_maze:L.o_maze + len(rows)], rows):

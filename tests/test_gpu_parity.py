@@ -22,7 +22,8 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
         ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
-        ('parallelogram_catch_l2', 0)]
+        ('parallelogram_catch_l2', 0), ('multi_tracking_with_feature_l3', 0), ('multi_tracking_with_feature_l3', 1),
+        ('multi_tracking_with_feature_l1', 0)]
 
 
 def make_env(name, n, seed=0, **kw):
@@ -1062,3 +1063,35 @@ def test_frames_larger_than_one_tile(name, size, n):
         ref = o.render()
         bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
         assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist(), int(bad.size))
+
+
+@pytest.mark.gpu
+def test_batched_meta_state():
+    """ModifyMetaState (modify_meta_state.py:8-50) over a batch: every env owns a meta-state object, the rule runs
+    once per env and call, and an env's object is re-initialised when that env auto-resets (environment.py:100-104)."""
+    import collections
+    from moog import action_spaces, environment, game_rules, observers, physics as physics_lib, sprite, tasks
+    n = 6
+    bump = game_rules.ModifyMetaState(lambda m: m.__setitem__('calls', m['calls'] + 1))
+    cfg = dict(
+        state_initializer=lambda: collections.OrderedDict(
+            [('target', [sprite.Sprite(x=0.8, y=0.5, shape='square', scale=0.1, c0=64)]),
+             ('agent', [sprite.Sprite(x=0.2, y=0.5, shape='circle', scale=0.1, c0=255)])]),
+        physics=physics_lib.Physics(updates_per_env_step=1),
+        task=tasks.CompositeTask(tasks.ContactReward(1., 'agent', 'target', reset_steps_after_contact=0),
+                                 timeout_steps=50),
+        action_space=action_spaces.SetPosition(action_layers='agent'),
+        observers={'image': observers.PILRenderer(image_size=(64, 64))},
+        game_rules=(bump,), meta_state_initializer=lambda: {'calls': 0})
+    env = environment.BatchedEnvironment(num_envs=n, **cfg)
+    env.reset()
+    assert [m['calls'] for m in env.meta_state] == [1] * n      # rules step once inside reset (environment.py:92-94)
+    far, hit = [0.2, 0.5], [0.8, 0.5]
+    env.step(np.array([far] * n))
+    assert [m['calls'] for m in env.meta_state] == [2] * n
+    ts = env.step(np.array([hit if i % 2 else far for i in range(n)]))   # odd envs touch the target: episode over
+    assert list(ts.step_type.cpu().numpy()) == [2 if i % 2 else 1 for i in range(n)]
+    assert [m['calls'] for m in env.meta_state] == [3] * n
+    env.step(np.array([far] * n))                                 # odd envs auto-reset: fresh object, one rule step
+    assert [m['calls'] for m in env.meta_state] == [1 if i % 2 else 4 for i in range(n)]
+    env.close()

@@ -43,17 +43,20 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
-@pytest.mark.parametrize('name', ['pong', 'chase_avoid_torus', 'colliding_predators',
-                                  'functional_maze', 'falling_balls', 'first_person_predators_prey',
-                                  'cleanup', 'pacman', 'parallelogram_catch'])
-def test_reference_configs_load_unchanged(name):
+@pytest.mark.parametrize('name,level', [('pong', 0), ('chase_avoid_torus', 0), ('colliding_predators', 0),
+                                        ('functional_maze', 0), ('falling_balls', 0),
+                                        ('first_person_predators_prey', 0), ('cleanup', 0), ('pacman', 0),
+                                        ('pacman', 1), ('parallelogram_catch', 0), ('parallelogram_catch', 2),
+                                        ('multi_tracking_with_feature', 3)])
+def test_reference_configs_load_unchanged(name, level):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
     spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    ref = _compiler.compile_config(layer_capacity=example_configs.capacity(name), **m.get_config(0))
-    assert bytes(ref.program) == bytes(helpers.compiled(name).program)
+    ref = _compiler.compile_config(layer_capacity=example_configs.capacity(name), **m.get_config(level))
+    mine = helpers.compiled(name if level == 0 else '%s_l%d' % (name, level))
+    assert bytes(ref.program) == bytes(mine.program)
 
 
 def test_program_contents():
