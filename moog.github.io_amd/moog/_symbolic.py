@@ -270,6 +270,8 @@ class SymMat(object):
             return self.rows[i[0]][i[1]]
         if isinstance(i, (int, np.integer)):
             return SymVec(self.rows[i])
+        if isinstance(i, slice):
+            return SymMat(self.rows[i])
         raise Unsupported('indexing a symbolic matrix with %r' % (i,))
 
     def _other(self, o, r, c):

@@ -99,7 +99,16 @@ class Sprite(object):
     def __getattr__(self, name):
         f = self.__dict__.get('factors')
         if f is not None and name in f:
-            return f[name]
+            v = f[name]
+            # a symbolic factor read back by the initializer (`Sprite(x=other.x)`, `1. - other.y`) is a value to
+            # compute with: the expression itself, or a reference to this sprite's sampled value
+            if isinstance(v, ExprFactor):
+                from . import _symbolic
+                return _symbolic.Sym(v.node)
+            if isinstance(v, SymbolicFactor) and not isinstance(v, ExprShape) and getattr(v, 'cell', None) is None:
+                from . import _symbolic
+                return _symbolic.Sym(_symbolic.Node('slotattr', self, name))
+            return v
         raise AttributeError(name)
 
 

@@ -33,7 +33,13 @@ def random_config(seed):
         return distribs.Product(parts, c0=color, c1=1., c2=float(rs.uniform(0.4, 1.0)),
                                 mass=float(rs.choice([1., 2., 0.5])))
     n_a, n_b = int(rs.randint(2, 6)), int(rs.randint(1, 5))
-    gen_a = sprite_generators.generate_sprites(factors(0.15, 0.85, True, 0.05), num_sprites=n_a)
+    rs2 = np.random.RandomState(7000 + seed)   # (later additions draw from their own stream: the older choices stay put)
+    give_up = bool(rs2.rand() < 0.4)           # generators that give up after a few rejections and return what they have
+    host_draws = bool(rs2.rand() < 0.5)        # sprites computed by the initializer from its own np.random draws
+    n_extra, corners = int(rs2.randint(1, 4)), int(rs2.randint(3, 7))
+    gen_a = sprite_generators.generate_sprites(factors(0.15, 0.85, True, 0.05), num_sprites=n_a,
+                                               **(dict(max_recursion_depth=int(rs2.randint(1, 4)), fail_gracefully=True)
+                                                  if give_up else {}))
     gen_b = sprite_generators.generate_sprites(factors(0.2, 0.8, bool(rs.rand() < 0.5), 0.6), num_sprites=n_b)
     gen_new = sprite_generators.generate_sprites(factors(0.2, 0.8, True, 0.8), num_sprites=1)
     gen_agent = sprite_generators.generate_sprites(
@@ -47,7 +53,22 @@ def random_config(seed):
         agent = gen_agent(without_overlapping=walls)
         a = gen_a(disjoint=disjoint, without_overlapping=walls + agent)
         b = gen_b(without_overlapping=walls)
-        return collections.OrderedDict([('walls', walls), ('a', a), ('b', b), ('spawn', []), ('agent', agent)])
+        extra = []
+        if host_draws:   # as parallelogram_catch.py:34-68 / multi_tracking_with_feature.py:136-141 do
+            from moog import sprite
+            turn = np.random.uniform(0, 2)
+            angles = np.pi * (2. * np.arange(corners) / corners + turn)
+            outline = np.stack((np.sin(angles), np.cos(angles)), axis=1)
+            outline *= np.array([[1.] if k % 2 else [np.random.uniform(0.5, 1.)] for k in range(corners)])
+            centres = 0.3 * outline[:n_extra] + np.array([0.5, 0.5])
+            flips = 0.5 * np.pi * np.random.binomial(1, 0.5, (n_extra))
+            for c, f in zip(centres, flips):
+                extra.append(sprite.Sprite(x=c[0], y=c[1], shape=0.06 * outline, angle=f, c0=0.45, c1=1., c2=0.9,
+                                           x_vel=np.random.uniform(-0.02, 0.02), y_vel=0.01 * np.cos(f)))
+            extra.append(sprite.Sprite(x=extra[0].x, y=1. - extra[0].y, shape='triangle', scale=0.05, c0=0.5, c1=1.,
+                                       c2=0.5, x_vel=-1 * extra[0].x_vel))
+        return collections.OrderedDict([('walls', walls), ('a', a), ('b', b), ('spawn', []), ('extra', extra),
+                                        ('agent', agent)])
 
     forces = [(physics_lib.Drag(coeff_friction=float(rs.choice([0.05, 0.25]))), 'agent')]
     pairs = [('a', 'walls'), ('agent', 'walls'), ('a', 'a'), ('a', 'b'), ('agent', 'b'), ('b', 'walls'),
