@@ -346,7 +346,8 @@ typedef struct {
   int32_t filter1, xfilter1, xmod1;   /* MODIFY_ON_CONTACT, side 1                */
   int32_t i0;          /* MODIFY_SPRITES: sample_one; velocity assigned as a whole
                         * by xmod (bit 1) / xmod1 (bit 2); bit 3: only the layer's first
-                        * sprite is modified (a rule written as `s = state[L][0]; s.attr = ...`) */
+                        * sprite is modified (a rule written as `s = state[L][0]; s.attr = ...`); bit 4 (a hint):
+                        * the stored values are constants and none of them moves vertices */
   int32_t n_layers1;
   int32_t layers1[MOOG_MAX_LAYERS];
   double p0, p1, p2;

@@ -2156,6 +2156,34 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
 }
 
 // the attribute writes of a modifier (sprite.py setters :540-664)
+// the stores of a modifier that do not move vertices (velocities, mass, colours, opacity), by one lane for sprite s
+__device__ __forceinline__ void apply_light_stores(Env& e, int s, const XStores& st, double vx, double vy, double w, double m,
+                                                   double c0, double c1, double c2, double op) {
+  auto tag = [&](int a) { return (int)((st.tags >> (2 * a)) & 3u); };
+  auto has = [&](int a) { return ((st.mask >> a) & 1u) != 0; };
+  const bool sf = e.P->sprite_factors != 0;
+  int fl = FLAGS(s);
+  if (has(MOOG_XA_XVEL) || has(MOOG_XA_YVEL)) {   // a fresh ndarray
+    VELX(s) = vx; VELY(s) = vy;
+    fl &= ~MOOG_F_VEL_F32;
+    if (tag(MOOG_XA_XVEL) == 1 && tag(MOOG_XA_YVEL) == 1) fl |= MOOG_F_VEL_F32;
+    vel_unshare(e, s);
+  }
+  if (has(MOOG_XA_ANGVEL)) {
+    ANGV(s) = w;
+    fl &= ~MOOG_F_ANGVEL_F32;
+    if (tag(MOOG_XA_ANGVEL) == 1) fl |= MOOG_F_ANGVEL_F32;
+  }
+  FLAGS(s) = fl;
+  int fm = sf ? FMASK(s) : 0;
+  if (has(MOOG_XA_MASS)) { MASS(s) = m; fm = (fm & ~(1 << MOOG_FAC_MASS)) | ((tag(MOOG_XA_MASS) == 1) << MOOG_FAC_MASS); }
+  if (has(MOOG_XA_C0)) { COL(s, 0) = c0; fm = (fm & ~(1 << MOOG_FAC_C0)) | ((tag(MOOG_XA_C0) == 1) << MOOG_FAC_C0); }
+  if (has(MOOG_XA_C1)) { COL(s, 1) = c1; fm = (fm & ~(1 << MOOG_FAC_C1)) | ((tag(MOOG_XA_C1) == 1) << MOOG_FAC_C1); }
+  if (has(MOOG_XA_C2)) { COL(s, 2) = c2; fm = (fm & ~(1 << MOOG_FAC_C2)) | ((tag(MOOG_XA_C2) == 1) << MOOG_FAC_C2); }
+  if (sf) FMASK(s) = fm;
+  if (has(MOOG_XA_OPACITY)) OPAC(s) = (int32_t)op;
+}
+
 __device__ inline void run_modifier(Env& e, int xmod, int s) {
   XStores st = {0u, 0u};
   eval_expr(e, xmod, s, s, nullptr, &st);
@@ -2177,29 +2205,7 @@ __device__ inline void run_modifier(Env& e, int xmod, int s) {
       wsync();
     }
   }
-  if (e.lane == 0) {
-    const bool sf = e.P->sprite_factors != 0;
-    int fl = FLAGS(s);
-    if (has(MOOG_XA_XVEL) || has(MOOG_XA_YVEL)) {   // a fresh ndarray
-      VELX(s) = vx; VELY(s) = vy;
-      fl &= ~MOOG_F_VEL_F32;
-      if (tag(MOOG_XA_XVEL) == 1 && tag(MOOG_XA_YVEL) == 1) fl |= MOOG_F_VEL_F32;
-      vel_unshare(e, s);
-    }
-    if (has(MOOG_XA_ANGVEL)) {
-      ANGV(s) = w;
-      fl &= ~MOOG_F_ANGVEL_F32;
-      if (tag(MOOG_XA_ANGVEL) == 1) fl |= MOOG_F_ANGVEL_F32;
-    }
-    FLAGS(s) = fl;
-    int fm = sf ? FMASK(s) : 0;
-    if (has(MOOG_XA_MASS)) { MASS(s) = m; fm = (fm & ~(1 << MOOG_FAC_MASS)) | ((tag(MOOG_XA_MASS) == 1) << MOOG_FAC_MASS); }
-    if (has(MOOG_XA_C0)) { COL(s, 0) = c0; fm = (fm & ~(1 << MOOG_FAC_C0)) | ((tag(MOOG_XA_C0) == 1) << MOOG_FAC_C0); }
-    if (has(MOOG_XA_C1)) { COL(s, 1) = c1; fm = (fm & ~(1 << MOOG_FAC_C1)) | ((tag(MOOG_XA_C1) == 1) << MOOG_FAC_C1); }
-    if (has(MOOG_XA_C2)) { COL(s, 2) = c2; fm = (fm & ~(1 << MOOG_FAC_C2)) | ((tag(MOOG_XA_C2) == 1) << MOOG_FAC_C2); }
-    if (sf) FMASK(s) = fm;
-    if (has(MOOG_XA_OPACITY)) OPAC(s) = (int32_t)op;
-  }
+  if (e.lane == 0) apply_light_stores(e, s, st, vx, vy, w, m, c0, c1, c2, op);
   __threadfence();   // colours / opacity live in HBM: later rules of this launch may read them
   wsync();
 }
@@ -2307,6 +2313,31 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         move_slot(e, dst, s);
       }
       layer_compact(e, R->l0);
+      return;
+    }
+    if (MOOG_WITH_MAZE != 0 && R->kind == MOOG_RULE_MODIFY_SPRITES && (R->i0 & 16)) {   // (in the kernels that carry every component)
+      // every live sprite of the layers gets the same constants (mass, colours, opacity, velocities): one
+      // evaluation, then lanes = sprites (pacman's `unglue` rule touches ~50 sprites every step)
+      int first = -1;
+      for (int a = 0; a < R->n_layers && first < 0; ++a) {
+        const int l = R->layers[a];
+        for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l] && first < 0; ++s)
+          if (ALIVE(s)) first = s;
+      }
+      if (first < 0) return;
+      XStores st = {0u, 0u};
+      eval_expr(e, R->xmod, first, first, nullptr, &st);
+      const double* sv = reinterpret_cast<const double*>(e.cand) + MOOG_X_STACK;
+      const double vx = sv[MOOG_XA_XVEL], vy = sv[MOOG_XA_YVEL], w = sv[MOOG_XA_ANGVEL], m = sv[MOOG_XA_MASS];
+      const double c0 = sv[MOOG_XA_C0], c1 = sv[MOOG_XA_C1], c2 = sv[MOOG_XA_C2], op = sv[MOOG_XA_OPACITY];
+      wsync();
+      for (int a = 0; a < R->n_layers; ++a) {
+        const int l = R->layers[a];
+        for (int s = P->layer_slot0[l] + e.lane; s < P->layer_slot0[l] + P->layer_nslots[l]; s += 64)
+          if (ALIVE(s)) apply_light_stores(e, s, st, vx, vy, w, m, c0, c1, c2, op);
+      }
+      __threadfence();
+      wsync();
       return;
     }
     if (R->kind == MOOG_RULE_MODIFY_SPRITES) {     // modify_sprites.py:35-52

@@ -683,6 +683,12 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             if mod is not None:
                 R.xmod = put_expr(stores=mod)
                 R.i0 = int(bool(r._sample_one)) | (2 if vec else 0)
+                # every sprite gets the same constants (e.g. `s.mass = 1.`, pacman.py:124-125) and none of the
+                # stores moves vertices: the device evaluates once and stores lane-parallel
+                const_only = all(_symbolic.is_constant(n) for n in mod.values())
+                light = set(mod) <= {'x_vel', 'y_vel', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity'}
+                if const_only and light and fnode is None and not r._sample_one and R.filter == _abi.MOOG_FILTER_ALWAYS:
+                    R.i0 |= 16
         elif isinstance(r, rules_lib.Portal):
             R.kind = _abi.MOOG_RULE_PORTAL
             R.l0, R.l1 = layer_index(r._teleporting_layer), layer_index(r._portal_layer)

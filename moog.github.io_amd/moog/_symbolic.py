@@ -462,6 +462,9 @@ def trace_modifier(fn):
     for a in attrs:
         out[a] = _merge(paths, lambda p, a=a: p[2][0][a].node if a in p[2][0]
                         else Node('attr', 0, a))
+    for a, b in (('x_vel', 'y_vel'), ('y_vel', 'x_vel'), ('x', 'y'), ('y', 'x')):
+        if a in out and b not in out:   # the device stores a pair as a whole: the other component keeps its value
+            out[b] = Node('attr', 0, b)
     vec_vel = any('__vec_velocity' in p[2][0] for p in paths)
     return out, vec_vel
 
@@ -788,6 +791,15 @@ def depth(code):
             d -= 1
         m = max(m, d)
     return m
+
+
+def is_constant(node):
+    """The expression reads nothing (constants and arithmetic on them only)."""
+    if node.op == 'const':
+        return True
+    if node.op in ('attr', 'overlaps', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
+        return False
+    return all(is_constant(a) for a in node.args if isinstance(a, Node))
 
 
 def uses_attr(code, names):

@@ -10,7 +10,7 @@ SECTIONS = [(1, 'single path tests'), (9, 'candidate batches (4 x 16 lanes)'), (
             (5, 'broad-phase scan'), (6, 'integrate'), (10, 'record load + boxes'), (11, 'rules + action'), (12, 'task reward')]
 res = {}
 for sel in [0, 7, 8] + [s for s, _ in SECTIONS]:
-    env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.load(name))
+    env = environment.BatchedEnvironment(num_envs=int(os.environ.get('MOOG_PROFILE_ENVS', 4096)), seed=1, **example_configs.load(name))
     env.check_faults = False
     env.reset()
     env.set_debug(128 | (sel << 8), 0)
