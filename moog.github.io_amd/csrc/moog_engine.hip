@@ -239,7 +239,7 @@ static int build_static_prefix(moog_engine* e) {
   KArgs a = make_args(e, nullptr, nullptr, nullptr, MODE_RESET_MASK, nullptr);
   a.dbg = 0;
   a.fault_flag = nullptr;   // (faults of the scratch env are nobody's business)
-  moog_launch_reset(1, e->step_lds, 0, a);
+  (e->maze_kernel ? moog_launch_reset_full : moog_launch_reset_plain)(1, e->step_lds, 0, a);
   RArgs r = raster_args(e, e->s_bg);
   r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
   moog_raster_launch(r, e->raster_lds, 0);
@@ -387,7 +387,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
   if (prog->maze.random) e->maze_kernel = true;
   if (err == hipSuccess)
-    err = (hipError_t)moog_configure_reset(e->step_lds);
+    err = (hipError_t)moog_configure_reset_plain(e->step_lds);
+    if (err == hipSuccess) err = (hipError_t)moog_configure_reset_full(e->step_lds);
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
   if (err != hipSuccess) {
@@ -538,7 +539,7 @@ int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev, const moog_
   KArgs a = make_args(e, nullptr, inject, out, MODE_RESET_MASK, env_mask_dev);
   {
     Bracket br(e, MOOG_K_RESET, s);
-    moog_launch_reset(e->n_envs, e->step_lds, s, a);
+    (e->maze_kernel ? moog_launch_reset_full : moog_launch_reset_plain)(e->n_envs, e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
   if (out && out->image) return launch_raster(e, out->image, s);

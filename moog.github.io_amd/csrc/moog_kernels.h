@@ -161,6 +161,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
 // reset_next word: 0 = running, 1 = reset on the next call (environment.py:100-101): the step kernel
 // resets such an env instead of stepping it (its action is ignored, the timestep is FIRST).
 #ifdef MOOG_DEFINE_RESET_KERNELS
+template <int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
 __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
 }
 
+#if !MOOG_RESET_FULL   // (the sort kernel lives in the first of the two reset translation units)
 // Launch order for the next step: envs in (approximately) descending order of the cycles they
 // took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
 // counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
     perm[atomicAdd(&hist[b], 1)] = i;
   }
 }
+#endif
 
 #endif  // MOOG_DEFINE_RESET_KERNELS
 
@@ -342,6 +345,8 @@ int moog_configure_step_t3(size_t lds);
 int moog_configure_step_t4(size_t lds);
 int moog_configure_step_m3(size_t lds);
 int moog_configure_step_m4(size_t lds);
-void moog_launch_reset(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
-int moog_configure_reset(size_t lds);
+void moog_launch_reset_plain(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_reset_full(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+int moog_configure_reset_plain(size_t lds);
+int moog_configure_reset_full(size_t lds);
 void moog_launch_sched(hipStream_t s, const float* cost, int32_t* perm, int n, const int32_t* reset_next, int stride);
