@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 19
+#define MOOG_ABI_VERSION 20
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -116,7 +116,10 @@ enum {
   MOOG_CELL_SAMPLED,    /* the cell_arg-th point of that sample                                            */
   MOOG_CELL_OPEN_RANK,  /* the cell_arg-th open cell in np.argwhere order (rows outer; pacman.py:62-65)     */
   MOOG_CELL_WALL_RANK,  /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
-  MOOG_CELL_HDRAW       /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW) */
+  MOOG_CELL_HDRAW,      /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW) */
+  MOOG_CELL_SHUFFLE     /* not a cell: sprite_generators.shuffle (sprite_generators.py:157-183): the live sprites in
+                         * slots slot0 .. slot0 + cell_arg - 1 (a packed prefix) are permuted as np.random.shuffle
+                         * permutes their list; slot slot0 + cell_arg is a spare used while swapping              */
 };
 
 /* Distribution programs.  A factor distribution that is not a flat Product of
@@ -174,7 +177,9 @@ enum {
    * e.g. parallelogram_catch.py:34-68, multi_tracking_with_feature.py:41-46,136): */
   MOOG_X_HDRAW,      /* push uniform a of this reset (the a-th direct np.random call of the initializer)        */
   MOOG_X_SLOT_ATTR,  /* push attribute a (MOOG_XA_*) of sprite slot b (a factor copied from an earlier sprite)  */
-  MOOG_X_STORE_VERT  /* pop -> component a of the raw shape being built (vertex a / 2, x or y)                   */
+  MOOG_X_STORE_VERT, /* pop -> component a of the raw shape being built (vertex a / 2, x or y)                   */
+  MOOG_X_FACTOR      /* push factor a (MOOG_FAC_*) of the sprite being created, as just sampled: the argument of a
+                      * DependentDistribution's dependent_fn (distributions.py:420-475)                           */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {

@@ -70,6 +70,7 @@ struct Env {
   int cur_slot;            // slot of the sprite being created (a computed shape is staged in its vertex area)
   double xs_centroid[2], xs_inertia[2];   // centroid / inertia per unit area of a computed shape (MOOG_DIST_EXPR_SHAPE)
   int xs_n;
+  unsigned fac_f32, expr_f32;   // float32 samples among the staged factors (MOOG_X_FACTOR); computed factors that came out float32
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -2076,6 +2077,12 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
         if (e.lane == 0) VERT(e.cur_slot)[I->a] = v[n];
         continue;
       }
+      if (op == MOOG_X_FACTOR) {   // a factor of the sprite being created, staged by sample_factors
+        v[n] = reinterpret_cast<const double*>(e.lst)[I->a];
+        XSETTAG(n, ((e.fac_f32 >> I->a) & 1u) ? 1 : 0);
+        ++n;
+        continue;
+      }
     }
     if (op == MOOG_X_OVERLAPS_FIRST) {   // sprite.overlaps_sprite(state[L][0])
       const int sp = I->b ? s1 : s0;
@@ -3054,16 +3061,32 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == fi) fac[q] = val;
   }
   if constexpr (X) {   // factors the initializer computed from its draws (after all draws of the op are in)
+    // a DependentDistribution's function reads the sampled factors themselves: staged in LDS for MOOG_X_FACTOR
+    unsigned f32m = 0u;
+    wsync();
+#pragma unroll
+    for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
+      if (e.lane == 0) reinterpret_cast<double*>(e.lst)[q] = fac[q];
+      if (op->factors[q].kind == MOOG_DIST_CONTINUOUS && op->factors[q].f32) f32m |= 1u << q;
+    }
+    wsync();
+    e.fac_f32 = f32m; e.expr_f32 = 0u;
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
       PFactor F = &op->factors[q];
-      if (F->kind == MOOG_DIST_EXPR) fac[q] = eval_expr(e, F->cand_off, 0, 0, nullptr, nullptr);
+      if (F->kind == MOOG_DIST_EXPR) {
+        int tag = 0;
+        fac[q] = eval_expr(e, F->cand_off, 0, 0, &tag, nullptr);
+        if (tag == 1) e.expr_f32 |= 1u << q;
+      }
       else if (F->kind == MOOG_DIST_EXPR_SHAPE) {
         eval_expr(e, F->cand_off, 0, 0, nullptr, nullptr);   // raw vertices -> VERT(cur_slot)
         shape_record(e, e.cur_slot, F->n_cand);
         fac[q] = -1.0;
       }
     }
+  } else {
+    e.expr_f32 = 0u;
   }
 }
 
@@ -3196,6 +3219,12 @@ __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& ve
     if (op->factors[k].kind == MOOG_DIST_CONTINUOUS && op->factors[k].f32) m |= 1u << k;
   if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
     run_dist_program(e, op->code_off, fac, m);
+    const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
+    vel_f32 = (m & vb) == vb;
+    angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
+  }
+  if (X && e.expr_f32) {   // computed factors that came out float32 (a float32 sample under weak scalars)
+    m |= e.expr_f32;
     const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
     vel_f32 = (m & vb) == vb;
     angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
@@ -3385,6 +3414,22 @@ __device__ inline void run_genop(Env& e, int oi) {
       wsync();
       if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = u;
       wsync();
+      return;
+    }
+  }
+  if constexpr (FULL) {
+    if (op->cell_sel == MOOG_CELL_SHUFFLE) {   // np.random.shuffle(order) + reindexing = the same swaps on the list itself
+      int n = 0;
+      while (n < op->cell_arg && ALIVE(op->slot0 + n)) ++n;
+      const int tmp = op->slot0 + op->cell_arg;
+      for (int i = n - 1; i > 0; --i) {
+        int j = (int)(next_uniform(e) * (i + 1));
+        if (j > i) j = i;
+        if (j == i) continue;
+        move_slot(e, tmp, op->slot0 + i);
+        move_slot(e, op->slot0 + i, op->slot0 + j);
+        move_slot(e, op->slot0 + j, tmp);
+      }
       return;
     }
   }

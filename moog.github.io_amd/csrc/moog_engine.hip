@@ -377,6 +377,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       e->dynamic_rules = true;
   for (int k = 0; k < prog->n_dcode; ++k)   // assigning sprite.angle turns the path: in the kernels that carry every component
     if (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE) e->maze_kernel = true;
+  for (int o = 0; o < prog->n_ops; ++o) if (prog->ops[o].cell_sel != MOOG_CELL_NONE) e->maze_kernel = true;   // maze / draw / shuffle ops
   if (prog->n_hdraws > 0) e->maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
   for (int o = 0; o < prog->n_ops; ++o)
     for (int k = 0; k < MOOG_NUM_FACTORS; ++k)

@@ -152,6 +152,14 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     for name in layer_capacity:
         layer_index(name)
 
+    # sprite_generators.shuffle swaps its sprites through a spare slot behind them
+    shuffle_ops = [op for op in tr.ops if isinstance(op, _trace.ShuffleOp)]
+    for op in shuffle_ops:
+        owners = [n for n in layer_names if state[n] and state[n][-1] is op.members[-1]]
+        if len(owners) != 1 or [id(x) for x in state[owners[0]][-len(op.members):]] != [id(x) for x in op.members]:
+            raise NotImplementedError('shuffled sprites must be the last sprites of one layer, in generation order')
+        layer_capacity[owners[0]] = max(int(layer_capacity.get(owners[0], 0)), len(state[owners[0]]) + 1)
+
     # slots: layer order, list order
     slot_of = {}
     slot_sprite = []
@@ -261,6 +269,12 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         G = P.ops[oi]
         runtime = oi >= n_reset_ops
         G.runtime = int(runtime)
+        if isinstance(op, _trace.ShuffleOp):
+            G.cell_sel, G.cell_arg = _abi.MOOG_CELL_SHUFFLE, len(op.members)
+            G.slot0 = slot_of[id(op.members[0])]
+            G.code_off = -1
+            op_max_nv[oi] = 0
+            continue
         if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE: randomness, no sprite
             G.cell_sel, G.cell_arg = op.cell
             G.code_off = -1
@@ -436,6 +450,12 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if P.layer_dynamic[li]:
             for sl in range(P.layer_slot0[li], P.layer_slot0[li] + P.layer_nslots[li]):
                 vcap[sl] = layer_nv[li]
+    for op in shuffle_ops:   # any of the shuffled sprites can end up in any of their slots (and in the spare)
+        s0 = slot_of[id(op.members[0])]
+        rng_ = range(s0, s0 + len(op.members) + 1)
+        top = max(vcap[sl] for sl in rng_)
+        for sl in rng_:
+            vcap[sl] = top
     voff = 0
     for sl in range(S):
         P.slot_voff[sl] = voff

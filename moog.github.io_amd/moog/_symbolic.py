@@ -581,7 +581,7 @@ def _substitute(node, old, new):
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
-    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
+    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -589,7 +589,7 @@ def _substitute(node, old, new):
 def _sprites_of(node, acc):
     if node.op in ('attr', 'overlaps'):
         acc.add(node.args[0])
-    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
+    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -750,6 +750,8 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
     elif node.op == 'attr':
         out.append(dict(op=_abi.MOOG_X_ATTR, a=ATTRS.index(node.args[1]), b=int(node.args[0])))
+    elif node.op == 'selffac':    # a factor of the sprite being created, as just sampled (DependentDistribution)
+        out.append(dict(op=_abi.MOOG_X_FACTOR, a=_abi.FACTOR_NAMES.index(node.args[0])))
     elif node.op == 'hdraw':      # a direct np.random draw of the state_initializer (reset-time expressions)
         out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(node.args[0])))
     elif node.op == 'slotattr':   # a factor of an earlier sprite; resolver('slot', sprite) gives its slot
@@ -778,7 +780,7 @@ def depth(code):
     for ins in code:
         op = ins['op']
         if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE, _abi.MOOG_X_OVERLAPS_FIRST,
-                  _abi.MOOG_X_HDRAW, _abi.MOOG_X_SLOT_ATTR):
+                  _abi.MOOG_X_HDRAW, _abi.MOOG_X_SLOT_ATTR, _abi.MOOG_X_FACTOR):
             d += 1
         elif op == _abi.MOOG_X_SELECT:
             d -= 2
@@ -797,7 +799,7 @@ def is_constant(node):
     """The expression reads nothing (constants and arithmetic on them only)."""
     if node.op == 'const':
         return True
-    if node.op in ('attr', 'overlaps', 'phase_is', 'meta_num', 'hdraw', 'slotattr'):
+    if node.op in ('attr', 'overlaps', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac'):
         return False
     return all(is_constant(a) for a in node.args if isinstance(a, Node))
 

@@ -37,6 +37,14 @@ class HDrawOp(GenOp):
         self.cell = (_abi.MOOG_CELL_HDRAW, index)
 
 
+class ShuffleOp(GenOp):
+    """sprite_generators.shuffle: permutes the slots of `members` (generated just before) at every reset."""
+
+    def __init__(self, members):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.members = members
+
+
 class Tracer(object):
     def __init__(self):
         self.ops = []               # GenOp, in randomness-consumption order

@@ -211,6 +211,57 @@ class Selection(_Composite):
         return self._keys
 
 
+class DependentDistribution(AbstractDistribution):
+    """Some factors are a deterministic function of others (distributions.py:420-475):
+    `dependent_fn(sample of independent_distrib) -> {key: value}`.  Inside a traced initializer / generator the
+    function runs once on symbolic values ("this sprite's own factor k"); its results become expressions the device
+    evaluates after the independent factors are drawn (MOOG_X_FACTOR), with numpy's float32 promotion."""
+
+    def __init__(self, independent_distrib, dependent_fn, dependent_fn_keys):
+        self._independent_distrib = independent_distrib
+        self._dependent_fn = dependent_fn
+        self._dependent_fn_keys = list(dependent_fn_keys)
+        if not set(independent_distrib.keys).isdisjoint(set(dependent_fn_keys)):
+            raise ValueError('independent_distrib keys {} and dependent_fn keys {} are not disjoint.'.format(
+                independent_distrib.keys, dependent_fn_keys))
+
+    def sample(self, rng=None):
+        rng = self._get_rng(rng)
+        sample = self._independent_distrib.sample(rng=rng)
+        if _trace.active() is None:
+            sample.update(self._dependent_fn(sample))
+            return sample
+        from .. import _symbolic
+        from ..sprite import ExprFactor, ExprShape
+        view = {}
+        for k, v in sample.items():
+            if isinstance(v, ExprFactor):
+                view[k] = _symbolic.Sym(v.node)
+            elif isinstance(v, SymbolicFactor) and not isinstance(v, ExprShape):
+                if k == 'shape':
+                    raise NotImplementedError('a dependent_fn over a sampled shape')
+                view[k] = _symbolic.Sym(_symbolic.Node('selffac', k))
+            else:
+                view[k] = v
+        sample.update(self._dependent_fn(view))
+        return sample
+
+    def contains(self, spec):
+        ok = self._independent_distrib.contains(spec)
+        dep = self._dependent_fn({k: spec[k] for k in self._independent_distrib.keys})
+        for k in self._dependent_fn_keys:
+            ok &= spec[k] == dep[k]
+        return ok
+
+    @property
+    def keys(self):
+        return set(self._independent_distrib.keys).union(self._dependent_fn_keys)
+
+    def to_str(self, indent):
+        return indent * '  ' + '<DependentDistribution: independent_distrib={}, dependent_fn={}>'.format(
+            self._independent_distrib, self._dependent_fn)
+
+
 def is_flat(dist):
     """True when the flat per-factor sampler (moog_factor_t) covers `dist`."""
     if isinstance(dist, Continuous):
@@ -219,4 +270,6 @@ def is_flat(dist):
         return dist.probs is None
     if isinstance(dist, Product):
         return all(is_flat(c) for c in dist.components)
+    if isinstance(dist, DependentDistribution):   # its dependent factors are expressions of the op's own draws
+        return is_flat(dist._independent_distrib)
     return False

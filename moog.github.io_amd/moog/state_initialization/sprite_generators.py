@@ -55,5 +55,16 @@ def sample_generator(sprite_generators, p=None):
 
 
 def shuffle(sprite_generator):
-    """sprite_generators.py:157-183 permutes the generated sprites; not lowered yet."""
-    raise NotImplementedError('shuffle is not lowered to the device sampler')
+    """sprite_generators.py:157-183: the generated sprites in a random order (`np.random.shuffle` of their indices).
+    On the device the sprites are generated into their slots first and then swapped as numpy's shuffle swaps the list;
+    the placeholders keep their positions, so the shuffled sprites must be the last of their layer (the next slot is
+    the spare the swaps go through)."""
+    def _generate(*args, **kwargs):
+        t = _trace.active()
+        if t is None:
+            raise RuntimeError('sprite generators only run inside an environment')
+        sprites = sprite_generator(*args, **kwargs)
+        if len(sprites) > 1:
+            t.add_op(_trace.ShuffleOp(list(sprites)))
+        return sprites
+    return _generate

@@ -4,7 +4,9 @@ after `max_recursion_depth` rejections returns the sprites it has made so far in
 bounce_box_contact_prediction.py).  Pinned by golden vectors captured from the reference (tests/golden/sampler_zoo_*.npz).
 
 level 0: six disjoint large squares are asked for at every reset where three to five fit;
-level 1: the same generator behind a CreateSprites rule that keeps appending to a crowded layer.
+level 1: the same generator behind a CreateSprites rule that keeps appending to a crowded layer;
+level 2: `shuffle(chain_generators(...))` (sprite_generators.py:108-183): two squares and two circles in a random
+         z-order (they overlap, so the order shows in the frames), behind a fixed sprite of the same layer.
 """
 import collections
 
@@ -25,9 +27,19 @@ def get_config(level):
     one_more = sprite_generators.generate_sprites(block_factors, num_sprites=2, max_recursion_depth=3,
                                                   fail_gracefully=True)
 
+    def small(shape, hue):
+        return sprite_generators.generate_sprites(distribs.Product(
+            [distribs.Continuous('x', 0.35, 0.65), distribs.Continuous('y', 0.4, 0.7)],
+            shape=shape, scale=0.22, c0=hue, c1=0.9, c2=0.9), num_sprites=2)
+    stacked = sprite_generators.shuffle(sprite_generators.chain_generators(small('square', 0.1), small('circle', 0.7)))
+
     def state_initializer():
         walls = shapes.border_walls(visible_thickness=0.05, c0=0., c1=0., c2=0.5)
-        blocks = crowd(disjoint=True, without_overlapping=walls) if level == 0 else one_more(without_overlapping=walls)
+        if level == 2:
+            base = sprite.Sprite(x=0.5, y=0.55, shape='hexagon', scale=0.3, c0=0.3, c1=0.5, c2=0.6)
+            blocks = [base] + stacked(without_overlapping=walls)
+        else:
+            blocks = crowd(disjoint=True, without_overlapping=walls) if level == 0 else one_more(without_overlapping=walls)
         agent = sprite.Sprite(x=0.5, y=0.12, shape='circle', scale=0.06, c0=0.33, c1=1., c2=0.7)
         return collections.OrderedDict([('walls', walls), ('blocks', blocks), ('agent', [agent])])
 
@@ -37,7 +49,8 @@ def get_config(level):
             game_rules.CreateSprites('blocks', one_more, without_overlapping=('walls', 'blocks', 'agent')),)),)
     physics = physics_lib.Physics(
         (physics_lib.Drag(coeff_friction=0.25), 'agent'),
-        (physics_lib.Collision(elasticity=0.8, symmetric=False, update_angle_vel=False), 'agent', ['walls', 'blocks']),
+        (physics_lib.Collision(elasticity=0.8, symmetric=False, update_angle_vel=False), 'agent',
+         ['walls', 'blocks'] if level != 2 else ['walls']),
         updates_per_env_step=4)
     return {
         'state_initializer': state_initializer,

@@ -717,11 +717,13 @@ def main():
         ('pacman_l1', 100, {'walls': 136, 'prey': 75}, (0,)),
         ('sampler_zoo', 60, {'blocks': 8}, (0, 1)),
         ('sampler_zoo_l1', 70, {'blocks': 8, '__dynamic__': ('blocks',)}, (0,)),
+        ('sampler_zoo_l2', 50, {'blocks': 8}, (0, 1)),
         ('parallelogram_catch', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l1', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l2', 60, {'__vmax__': SNAP_VMAX}, (0,)),
         ('multi_tracking_with_feature_l3', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0, 1)),
         ('multi_tracking_with_feature_l1', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0,)),
+        ('dependent_zoo', 50, {}, (0, 1)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),

@@ -218,8 +218,14 @@ def test_chain_generators_is_a_sequence_of_ops():
     P = c.program
     assert P.n_ops == 2 and (P.ops[0].slot0, P.ops[0].count_max) == (0, 2)
     assert (P.ops[1].slot0, P.ops[1].count_max) == (2, 3)
-    with pytest.raises(NotImplementedError):
-        sg.shuffle(gen)
+    with pytest.raises(NotImplementedError):   # (one generator picked at random per call: no device form yet)
+        sg.sample_generator([gen, gen])
+    c2 = helpers.compiled('sampler_zoo_l2')      # shuffle(chain_generators(...)): a permutation op behind the generators
+    ops = [c2.program.ops[i] for i in range(c2.program.n_ops)]
+    shuffles = [o for o in ops if o.cell_sel == _abi.MOOG_CELL_SHUFFLE]
+    assert len(shuffles) == 1 and shuffles[0].cell_arg == 4
+    s0 = shuffles[0].slot0
+    assert len({c2.program.slot_vcap[s] for s in range(s0, s0 + 5)}) == 1   # the four sprites and the spare slot
 
 
 def test_host_randomness_in_initializer():
