@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 20
+#define MOOG_ABI_VERSION 21
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -117,6 +117,10 @@ enum {
   MOOG_CELL_OPEN_RANK,  /* the cell_arg-th open cell in np.argwhere order (rows outer; pacman.py:62-65)     */
   MOOG_CELL_WALL_RANK,  /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
   MOOG_CELL_HDRAW,      /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW) */
+  MOOG_CELL_CHOICE,     /* not a cell: np.random.choice(count_max alternatives, p) of a sample_generator: the picked index
+                         * goes to o_hdraw[cell_arg]; factors[0].cand_off >= 0: the normalised cumulative
+                         * probabilities in program.cand (searchsorted(cdf, u, 'right')), else int(u * n) (no draw
+                         * for n == 1)                                                                            */
   MOOG_CELL_SHUFFLE     /* not a cell: sprite_generators.shuffle (sprite_generators.py:157-183): the live sprites in
                          * slots slot0 .. slot0 + cell_arg - 1 (a packed prefix) are permuted as np.random.shuffle
                          * permutes their list; slot slot0 + cell_arg is a spare used while swapping              */
@@ -223,6 +227,10 @@ typedef struct {
   int32_t fail_gracefully; /* sprite_generators.py:93-95: when max_tries is exceeded the call returns the
                             * sprites made so far (this and the op's remaining slots stay dead) instead of
                             * raising RecursionError (MOOG_FAULT_SAMPLER_EXHAUSTED)                         */
+  int32_t cond_hdraw;      /* 1 + k: the op belongs to one alternative of a sample_generator (sprite_generators.py:
+                            * 131-154) and runs only when the MOOG_CELL_CHOICE op that drew into o_hdraw[k] picked
+                            * alternative cond_value; 0: unconditional.  The alternatives share their slots.      */
+  int32_t cond_value;
   int32_t pad_;
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;

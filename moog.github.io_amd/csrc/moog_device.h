@@ -3405,6 +3405,24 @@ __device__ inline void run_genop(Env& e, int oi) {
   if (op->runtime) return;   // CreateSprites generators run at rule time
   constexpr bool FULL = DYN && (MOOG_WITH_MAZE != 0);   // maze ops and reset-time expressions: the m3 / m4 kernels only
   if constexpr (FULL) {
+    // an alternative of a sample_generator runs only when it was the one picked (sprite_generators.py:131-154)
+    if (op->cond_hdraw > 0 && (int)e.f[e.L.o_hdraw + op->cond_hdraw - 1] != op->cond_value) return;
+    if (op->cell_sel == MOOG_CELL_CHOICE) {   // np.random.choice(generators, p=p)
+      const int n = op->count_max, off = op->factors[0].cand_off;
+      int idx = 0;
+      if (off >= 0) {   // cdf = cumsum(p) / sum(p); searchsorted(cdf, u, side='right')
+        const double u = next_uniform(e);
+        while (idx < n && P->cand[off + idx] <= u) ++idx;
+        if (idx >= n) idx = n - 1;
+      } else if (n > 1) {
+        idx = (int)(next_uniform(e) * n);
+        if (idx >= n) idx = n - 1;
+      }
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = (double)idx;
+      wsync();
+      return;
+    }
     if (op->cell_sel == MOOG_CELL_GENERATE) { maze_generate(e); return; }
     if (op->cell_sel == MOOG_CELL_SAMPLE) { maze_sample_points(e, op->cell_arg); return; }
   }

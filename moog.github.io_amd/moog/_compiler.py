@@ -185,6 +185,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             P.slot_layer[len(slot_sprite)] = li
             slot_sprite.append(None)
         P.layer_nslots[li] = len(slot_sprite) - P.layer_slot0[li]
+    for alias_id, target in tr.alias.items():   # later alternatives of a sample_generator share the first one's slots
+        if id(target) in slot_of:
+            slot_of[alias_id] = slot_of[id(target)]
     S = len(slot_sprite)
     if S > _abi.MOOG_MAX_SLOTS:
         raise ValueError('too many sprites (max %d)' % _abi.MOOG_MAX_SLOTS)
@@ -269,6 +272,23 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         G = P.ops[oi]
         runtime = oi >= n_reset_ops
         G.runtime = int(runtime)
+        if getattr(op, 'cond', None) is not None:
+            G.cond_hdraw, G.cond_value = 1 + op.cond[0], op.cond[1]
+        if isinstance(op, _trace.ChoiceOp):
+            G.cell_sel, G.cell_arg, G.count_max = _abi.MOOG_CELL_CHOICE, op.index, op.n
+            G.code_off = -1
+            G.factors[0].cand_off = -1
+            if op.p is not None:
+                if len(op.p) != op.n or cand_n + op.n > _abi.MOOG_MAX_CAND:
+                    raise ValueError('sample_generator probabilities')
+                cdf = np.cumsum(np.asarray(op.p, dtype=np.float64))
+                cdf /= cdf[-1]
+                G.factors[0].cand_off = cand_n
+                for v in cdf:
+                    P.cand[cand_n] = float(v)
+                    cand_n += 1
+            op_max_nv[oi] = 0
+            continue
         if isinstance(op, _trace.ShuffleOp):
             G.cell_sel, G.cell_arg = _abi.MOOG_CELL_SHUFFLE, len(op.members)
             G.slot0 = slot_of[id(op.members[0])]
@@ -432,7 +452,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         for k, ent in enumerate(entries):
             G.sample_order[k] = ent
         for sl in slots:
-            vcap[sl] = max_nv
+            vcap[sl] = max(vcap[sl], max_nv)   # (sample_generator alternatives share slots)
         op_max_nv[oi] = max_nv
     P.n_cand = cand_n
     # every slot of a dynamic layer can hold any sprite that may end up in that layer

@@ -45,12 +45,22 @@ class ShuffleOp(GenOp):
         self.members = members
 
 
+class ChoiceOp(GenOp):
+    """np.random.choice over the alternatives of a sample_generator: the picked index goes to direct-draw slot `index`."""
+
+    def __init__(self, index, n, p):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.index, self.n, self.p = index, n, p
+
+
 class Tracer(object):
     def __init__(self):
         self.ops = []               # GenOp, in randomness-consumption order
         self.op_of = {}             # id(sprite) -> (op, k)
         self.randint_calls = []
         self.n_hdraws = 0
+        self.alias = {}             # id(placeholder of a later sample_generator alternative) -> the first alternative's
+        self.alias_keep = []        # (keeps those placeholders alive: ids must stay unique)
         self.maze = None            # the per-reset random maze of the initializer (maze_lib/_traced.py)
         self.seq = 0                # order of sampling events (deferred factor samples and direct draws)
 
@@ -69,6 +79,32 @@ class Tracer(object):
         self.n_hdraws += 1
         self.add_op(HDrawOp(k, self.next_seq()))
         return _symbolic.Sym(_symbolic.Node('hdraw', k))
+
+    def choose(self, generators, p, args, kwargs):
+        """sample_generator: runs every alternative; their ops become conditional on the drawn index."""
+        from . import _abi
+        if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+            raise NotImplementedError('more than %d direct np.random draws per reset' % _abi.MOOG_MAX_HDRAWS)
+        k = self.n_hdraws
+        self.n_hdraws += 1
+        self.add_op(ChoiceOp(k, len(generators), None if p is None else [float(x) for x in p]))
+        first = None
+        for j, g in enumerate(generators):
+            mark = len(self.ops)
+            sprites = g(*args, **kwargs)
+            for op in self.ops[mark:]:
+                if getattr(op, 'cond', None) is not None:
+                    raise NotImplementedError('a sample_generator inside a sample_generator')
+                op.cond = (k, j)
+            if first is None:
+                first = sprites
+            else:
+                if len(sprites) != len(first):
+                    raise NotImplementedError('sample_generator alternatives that return different numbers of sprites')
+                for a, b in zip(sprites, first):
+                    self.alias[id(a)] = b   # the alternatives fill the same slots
+                    self.alias_keep.append(a)
+        return first
 
     def add_op(self, op):
         self.ops.append(op)

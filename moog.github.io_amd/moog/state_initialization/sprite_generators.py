@@ -49,9 +49,18 @@ def chain_generators(*sprite_generators):
 
 
 def sample_generator(sprite_generators, p=None):
-    """sprite_generators.py:131-154 picks one generator at random per call; the device sampler
-    has no conditional generation ops yet."""
-    raise NotImplementedError('sample_generator is not lowered to the device sampler')
+    """sprite_generators.py:131-154: one of the generators, picked at random per call (`np.random.choice(generators,
+    p=p)`), makes the sprites.  While tracing every alternative is run once; the device draws the index at each reset
+    and runs only the ops of the picked alternative, all alternatives filling the same slots (so they must return the
+    same number of sprites)."""
+    sprite_generators = list(sprite_generators)
+
+    def _generate(*args, **kwargs):
+        t = _trace.active()
+        if t is None:
+            raise RuntimeError('sprite generators only run inside an environment')
+        return t.choose(sprite_generators, p, args, kwargs)
+    return _generate
 
 
 def shuffle(sprite_generator):

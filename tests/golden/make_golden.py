@@ -718,6 +718,7 @@ def main():
         ('sampler_zoo', 60, {'blocks': 8}, (0, 1)),
         ('sampler_zoo_l1', 70, {'blocks': 8, '__dynamic__': ('blocks',)}, (0,)),
         ('sampler_zoo_l2', 50, {'blocks': 8}, (0, 1)),
+        ('sampler_zoo_l3', 60, {'blocks': 8}, (0, 1)),
         ('parallelogram_catch', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l1', 60, {'__vmax__': SNAP_VMAX}, (0, 1)),
         ('parallelogram_catch_l2', 60, {'__vmax__': SNAP_VMAX}, (0,)),

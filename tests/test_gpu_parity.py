@@ -24,7 +24,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
         ('parallelogram_catch_l2', 0), ('multi_tracking_with_feature_l3', 0), ('multi_tracking_with_feature_l3', 1),
         ('multi_tracking_with_feature_l1', 0), ('dependent_zoo', 0), ('dependent_zoo', 1),
-        ('sampler_zoo_l2', 0), ('sampler_zoo_l2', 1)]
+        ('sampler_zoo_l2', 0), ('sampler_zoo_l2', 1), ('sampler_zoo_l3', 0), ('sampler_zoo_l3', 1)]
 
 
 def make_env(name, n, seed=0, **kw):

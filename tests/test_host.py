@@ -218,8 +218,12 @@ def test_chain_generators_is_a_sequence_of_ops():
     P = c.program
     assert P.n_ops == 2 and (P.ops[0].slot0, P.ops[0].count_max) == (0, 2)
     assert (P.ops[1].slot0, P.ops[1].count_max) == (2, 3)
-    with pytest.raises(NotImplementedError):   # (one generator picked at random per call: no device form yet)
-        sg.sample_generator([gen, gen])
+    c3 = helpers.compiled('sampler_zoo_l3')      # sample_generator: a choice op, then both alternatives on the same slots
+    ops = [c3.program.ops[i] for i in range(c3.program.n_ops)]
+    choices = [o for o in ops if o.cell_sel == _abi.MOOG_CELL_CHOICE]
+    assert [o.count_max for o in choices] == [2, 2] and choices[0].factors[0].cand_off >= 0 and choices[1].factors[0].cand_off < 0
+    alts = [o for o in ops if o.cond_hdraw == 1 + choices[0].cell_arg]
+    assert [o.cond_value for o in alts] == [0, 1] and alts[0].slot0 == alts[1].slot0 and alts[0].count_max == 2
     c2 = helpers.compiled('sampler_zoo_l2')      # shuffle(chain_generators(...)): a permutation op behind the generators
     ops = [c2.program.ops[i] for i in range(c2.program.n_ops)]
     shuffles = [o for o in ops if o.cell_sel == _abi.MOOG_CELL_SHUFFLE]
