@@ -1096,3 +1096,38 @@ def test_batched_meta_state():
     env.step(np.array([far] * n))                                 # odd envs auto-reset: fresh object, one rule step
     assert [m['calls'] for m in env.meta_state] == [1 if i % 2 else 4 for i in range(n)]
     env.close()
+
+
+@pytest.mark.gpu
+def test_multi_agent_wrapper():
+    """MultiAgentEnvironment (env_wrappers/multi_agent.py:12-52): the caller drives one key of the Composite action
+    space, agent objects fill in the rest from the observation; same trajectory as stepping with the full dict."""
+    import torch
+    from moog import env_wrappers, environment
+    from moog_demos import example_configs
+
+    class Drift(object):
+        def __init__(self, value):
+            self.value, self.seen = value, 0
+
+        def step(self, observation):
+            assert 'image' in observation
+            self.seen += 1
+            return self.value
+    n = 8
+    joy = torch.full((n, 2), 0.25, dtype=torch.float64)
+    move = torch.full((n,), 3, dtype=torch.int64)
+    eye = torch.full((n, 2), 0.6, dtype=torch.float64)
+    base = environment.BatchedEnvironment(num_envs=n, seed=4, **example_configs.load('actions_zoo'))
+    other = environment.BatchedEnvironment(num_envs=n, seed=4, **example_configs.load('actions_zoo'))
+    a1, a2 = Drift(move), Drift(eye)
+    wrapped = env_wrappers.MultiAgentEnvironment(base, 'agent_0', agent_1=a1, eye=a2)
+    wrapped.reset(); other.reset()
+    for _ in range(5):
+        ts = wrapped.step(joy)
+        other.step({'agent_0': joy, 'agent_1': move, 'eye': eye})
+    assert (a1.seen, a2.seen) == (5, 5) and ts.observation['image'].shape == (n, 64, 64, 3)
+    f, q = download(base)
+    f2, q2 = download(other)
+    assert np.array_equal(f, f2, equal_nan=True) and np.array_equal(q, q2)
+    assert wrapped.action_spec().keys() == base.action_spec().keys() and wrapped.step_count is not None
