@@ -535,3 +535,6 @@ class Environment(object):
     @property
     def batched(self):
         return self._batched
+
+    def close(self):
+        self._batched.close()

@@ -1131,3 +1131,35 @@ def test_multi_agent_wrapper():
     f2, q2 = download(other)
     assert np.array_equal(f, f2, equal_nan=True) and np.array_equal(q, q2)
     assert wrapped.action_spec().keys() == base.action_spec().keys() and wrapped.step_count is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,levels', [
+    ('chase_avoid_torus', [0, 1]), ('colliding_predators', [0]), ('falling_balls', [0]),
+    ('first_person_predators_prey', [0]), ('functional_maze', [0]), ('multi_tracking_with_feature', [2, 3, 4]),
+    ('pacman', [0, 1]), ('parallelogram_catch', [0, 1, 2]), ('pong', [0]), ('cleanup', [0])])
+def test_example_configs_run(name, levels):
+    """The reference's own smoke test of its example configs (tests/moog_demos/example_configs/test_examples.py:
+    52-64): every level, two episodes of 200 random actions through the single-environment facade.  (The four
+    configs that do not lower -- match_to_sample, predators_arena, red_green, bounce_box_contact_prediction --
+    are listed in DESIGN.md.)"""
+    import importlib
+    from moog import environment
+    from moog_demos import example_configs
+    module = importlib.import_module('moog_demos.example_configs.' + name)
+    for level in levels:
+        # (layers that rules append to have a fixed capacity on the engine; the reference's lists are unbounded)
+        capacity, steps = example_configs.capacity(name), 200
+        if name == 'first_person_predators_prey':
+            # a predator appears every other step and a prey every fifth (:178-190) and they leave slowly: the
+            # reference's lists just grow, the engine's layers are sized up front (and the rasteriser keeps a
+            # frame's edges in LDS), so this config runs shorter episodes with room for every arrival
+            capacity, steps = {'prey': 30, 'predators': 70}, 120
+        env = environment.Environment(layer_capacity=capacity, **module.get_config(level))
+        for _ in range(2):
+            ts = env.reset()
+            assert ts.first()
+            for _ in range(steps):
+                ts = env.step(action=env.action_space.random_action())
+                assert ts.observation['image'].dtype == np.uint8
+        env.close()
