@@ -575,7 +575,17 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) {
     }
     // first edge record of the slot | live vertex count << 20 (0 for a dead sprite): the later
     // phases take both from LDS instead of chasing the record's flag words through HBM
-    pbase[s] = P->slot_voff[s] | ((alive ? nvs : 0) << 20);
+    // A canvas cut into tiles: a sprite whose bounding circle (position, _max_radius: the bound overlaps_sprite
+    // itself relies on) misses this tile by more than two pixels has no pixel in it and is left out of the
+    // tile's vertex, edge and row work.  (NaN coordinates fail every comparison and stay in.)
+    bool in_tile = true;
+    if (tiles > 1 && alive && !torus && P->render.polymod != MOOG_POLYMOD_FIRST_PERSON) {
+      const double px = gf[a.L.o_pos + 2 * s], py = gf[a.L.o_pos + 2 * s + 1], rad = gf[a.L.o_maxr + s];
+      const double x0 = (px - rad) * (double)WF - 2.0, x1 = (px + rad) * (double)WF + 2.0;
+      const double y0 = (py - rad) * (double)H - 2.0, y1 = (py + rad) * (double)H + 2.0;
+      if (x1 < (double)xoff || x0 > (double)(xoff + W) || y1 < (double)yb0 || y0 > (double)yb1) in_tile = false;
+    }
+    pbase[s] = P->slot_voff[s] | (((alive && in_tile) ? nvs : 0) << 20);
     unsigned rgba = 0u;
     if (alive) {
       unsigned r8, g8, b8;
