@@ -207,7 +207,14 @@ static int setup_anti_aliasing(moog_engine* e) {
   HIPCHK(hipMemcpy(d, bv.data(), bv.size() * 4, hipMemcpyHostToDevice)); const int32_t* dbv = d; d += bv.size();
   HIPCHK(hipMemcpy(d, ch.data(), ch.size() * 4, hipMemcpyHostToDevice)); const int32_t* dch = d; d += ch.size();
   HIPCHK(hipMemcpy(d, cv.data(), cv.size() * 4, hipMemcpyHostToDevice)); const int32_t* dcv = d;
-  e->aa_resize = RResize{e->canvas_w, e->canvas_h, ow, oh, kh, kv, dbh, dbv, dch, dcv};
+  int hspan = 0;   // the horizontal pass stages the bytes a block of 256 output columns reads in LDS
+  for (int x0 = 0; x0 < ow; x0 += 256) {
+    const int xl = (x0 + 255 < ow ? x0 + 255 : ow - 1);
+    const int b0 = 3 * bh[2 * x0] & ~3, b1 = 3 * (bh[2 * xl] + bh[2 * xl + 1]);
+    if (b1 - b0 > hspan) hspan = b1 - b0;
+  }
+  hspan = (hspan + 7) & ~3;
+  e->aa_resize = RResize{e->canvas_w, e->canvas_h, ow, oh, kh, kv, dbh, dbv, dch, dcv, hspan};
   // canvases of a chunk of envs at a time: at most 1 GiB of scratch
   const size_t canvas = (size_t)e->canvas_w * e->canvas_h * 3;
   size_t chunk = ((size_t)1 << 30) / canvas;

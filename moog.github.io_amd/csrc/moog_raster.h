@@ -122,7 +122,8 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
 
 // moog_raster.hip: the kernel's own translation unit
 // Image.resize(LANCZOS) of a batch of canvases [n][ch][cw][3] -> observations [n][oh][ow][3], flipped; tmp: [n][ch][ow][3]
-struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_t* bv; const int32_t* ch_coef; const int32_t* cv_coef; };
+struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_t* bv; const int32_t* ch_coef; const int32_t* cv_coef;
+                 int32_t hspan; /* bytes of a canvas row that 256 consecutive output columns read, at most (+ alignment slack) */ };
 void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream);
 int moog_raster_configure(size_t lds_bytes);   // hipFuncSetAttribute(max dynamic LDS); returns a hipError_t
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream);

@@ -1163,3 +1163,30 @@ def test_example_configs_run(name, levels):
                 ts = env.step(action=env.action_space.random_action())
                 assert ts.observation['image'].dtype == np.uint8
         env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size,aa', [((64, 64), 2), ((64, 48), 3), ((32, 32), 4), ((48, 64), 5), ((16, 16), 8),
+                                     ((32, 16), 16), ((512, 256), 2), ((272, 272), 3), ((1024, 64), 2)])
+def test_anti_aliasing_sweep(size, aa):
+    """PILRenderer(anti_aliasing=aa) (pil_renderer.py:64-66,111-112) over scale factors 2..16 and frame shapes whose
+    rows span one and several blocks of the resize kernels: canvas + both LANCZOS passes against the oracle's
+    restatement of Pillow's resample (itself pinned by tests/golden/resize.npz)."""
+    from moog import environment, observers
+    from moog_demos import example_configs
+    cfg = example_configs.load('colliding_predators_32')
+    old = cfg['observers']['image']
+    cfg['observers'] = {'image': observers.PILRenderer(image_size=size, anti_aliasing=aa, bg_color=old._bg_color,
+                                                       color_to_rgb=old.color_to_rgb)}
+    n = 6
+    env = environment.BatchedEnvironment(num_envs=n, seed=5, **cfg)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=5)
+    env.reset()
+    rs = np.random.RandomState(2)
+    for k in range(2):
+        out = env.step(rs.uniform(-1, 1, size=(n, 2)))
+        o.f64[:], o.i32[:] = download(env)
+        img = out.observation['image'].cpu().numpy()
+        assert img.shape == (n, size[1], size[0], 3)
+        assert np.array_equal(img, o.render()), 'frames differ at step %d' % k
+    env.close()
