@@ -68,6 +68,7 @@ struct Env {
   unsigned cur_fmask;      // float32 factors of the sprite being created
   int cell_i, cell_j;      // maze cell (row, column) of the sprite being created (MOOG_CELL_* ops)
   int cur_slot;            // slot of the sprite being created (a computed shape is staged in its vertex area)
+  int cell_tab_n, cell_nw; // rank -> cell table of the episode's maze in LDS (cells; wall cells), 0: none
   double xs_centroid[2], xs_inertia[2];   // centroid / inertia per unit area of a computed shape (MOOG_DIST_EXPR_SHAPE)
   int xs_n;
   unsigned fac_f32, expr_f32;   // float32 samples among the staged factors (MOOG_X_FACTOR); computed factors that came out float32
@@ -3060,7 +3061,14 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == fi) fac[q] = val;
   }
-  if constexpr (X) {   // factors the initializer computed from its draws (after all draws of the op are in)
+  bool any_expr = false;
+  if constexpr (X) {
+#pragma unroll
+    for (int q = 0; q < MOOG_NUM_FACTORS; ++q)
+      any_expr = any_expr || op->factors[q].kind == MOOG_DIST_EXPR || op->factors[q].kind == MOOG_DIST_EXPR_SHAPE;
+    e.expr_f32 = 0u;
+  }
+  if (X && any_expr) {   // factors the initializer computed from its draws (after all draws of the op are in)
     // a DependentDistribution's function reads the sampled factors themselves: staged in LDS for MOOG_X_FACTOR
     unsigned f32m = 0u;
     wsync();
@@ -3320,6 +3328,33 @@ __device__ inline void maze_generate(Env& e) {
     if (e.lane == 0) e.q[e.L.o_maze + r] = (int32_t)bits;
   }
   wsync();
+  // rank -> cell tables for the one-sprite ops that follow (each used to re-scan the matrix: a quarter of a pacman
+  // reset): wall cells in Maze.to_sprites order (columns outer) from the front, open cells in np.argwhere order (rows
+  // outer) behind them, as i << 8 | j, in the scratch the generator no longer needs.  Lanes = cells.
+  e.cell_tab_n = 0;
+  if (N * N <= 256) {
+    unsigned short* tab = reinterpret_cast<unsigned short*>(e.rowm);
+    int nw = 0;
+    for (int c0 = 0; c0 < N * N; c0 += 64) {
+      const int c = c0 + e.lane;
+      const int j = c / N, i = c - j * N;   // column-major
+      const bool wall = c < N * N && ((maze_row(e, i) >> j) & 1u);
+      const unsigned long long m = __ballot(wall);
+      if (wall) tab[nw + __popcll(m & ((1ull << e.lane) - 1ull))] = (unsigned short)(i << 8 | j);
+      nw += __popcll(m);
+    }
+    int no = 0;
+    for (int c0 = 0; c0 < N * N; c0 += 64) {
+      const int c = c0 + e.lane;
+      const int i = c / N, j = c - i * N;   // row-major
+      const bool open = c < N * N && !((maze_row(e, i) >> j) & 1u);
+      const unsigned long long m = __ballot(open);
+      if (open) tab[nw + no + __popcll(m & ((1ull << e.lane) - 1ull))] = (unsigned short)(i << 8 | j);
+      no += __popcll(m);
+    }
+    wsync();
+    e.cell_tab_n = N * N; e.cell_nw = nw;
+  }
 }
 
 // k-th (0-based) open cell of the maze in np.argwhere order (rows outer); -1 when there are fewer
@@ -3378,6 +3413,11 @@ __device__ inline void maze_sample_points(Env& e, int k) {
 __device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
   int p = -1;
   if (sel == MOOG_CELL_SAMPLED) p = e.q[e.L.o_maze + MOOG_MAX_MAZE + arg];
+  else if (e.cell_tab_n > 0) {   // the tables maze_generate left in LDS
+    const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
+    if (sel == MOOG_CELL_WALL_RANK) p = arg < e.cell_nw ? (int)tab[arg] : -1;
+    else p = arg < e.cell_tab_n - e.cell_nw ? (int)tab[e.cell_nw + arg] : -1;
+  }
   else if (sel == MOOG_CELL_OPEN_RANK) p = maze_open_cell(e, arg);   // np.argwhere(maze.maze == 0), pacman.py:62
   else {   // Maze.to_sprites: x (column) outer, y (row) inner, maze.py:101-103
     const int N = e.P->maze.size;
@@ -3423,7 +3463,7 @@ __device__ inline void run_genop(Env& e, int oi) {
       wsync();
       return;
     }
-    if (op->cell_sel == MOOG_CELL_GENERATE) { maze_generate(e); return; }
+    if (op->cell_sel == MOOG_CELL_GENERATE) { PROF_T0; maze_generate(e); PROF_ADD(e, 13); return; }
     if (op->cell_sel == MOOG_CELL_SAMPLE) { maze_sample_points(e, op->cell_arg); return; }
   }
   if constexpr (FULL) {
@@ -3453,8 +3493,10 @@ __device__ inline void run_genop(Env& e, int oi) {
   }
   int n = genop_count(e, op);
   if constexpr (FULL) {
+    PROF_T0;
     if (op->cell_sel != MOOG_CELL_NONE && op->cell_sel != MOOG_CELL_HDRAW &&
         !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
+    PROF_ADD(e, 14);
   }
   for (int k = 0; k < op->count_max; ++k) {
     int s = op->slot0 + k;
@@ -3469,8 +3511,8 @@ __device__ inline void run_genop(Env& e, int oi) {
       double fac[MOOG_NUM_FACTORS];
       int vel_f32, angvel_f32;
       if constexpr (FULL) e.cur_slot = s;
-      sample_op_factors<FULL>(e, op, fac, vel_f32, angvel_f32);
-      create_sprite<FULL>(e, s, fac, vel_f32, angvel_f32);
+      { PROF_T0; sample_op_factors<FULL>(e, op, fac, vel_f32, angvel_f32); PROF_ADD(e, 15); }
+      { PROF_T0; create_sprite<FULL>(e, s, fac, vel_f32, angvel_f32); PROF_ADD(e, 12); }
       bool ov = false;
       for (int oj = 0; oj < oi && oj < 64 && !ov; ++oj) {
         if (!((op->avoid_ops >> oj) & 1)) continue;
@@ -3515,6 +3557,8 @@ __device__ inline void env_reset(Env& e) {
     for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) e.f[e.L.o_action + k] = 0;
   }
   wsync();
+  { PROF_T0;
   for (int r = 0; r < P->n_rules; ++r)
     if (P->rules[r].parent < 0) { rule_reset_tree(e, r); rule_step<DYN>(e, r); }
+  PROF_ADD(e, 10); }
 }

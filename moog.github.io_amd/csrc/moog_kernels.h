@@ -148,6 +148,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
+  e.cell_tab_n = 0; e.cell_nw = 0;
 #ifdef MOOG_PROFILE
   for (int k = 0; k < 16; ++k) e.prof[k] = 0;
 #endif
@@ -267,6 +268,12 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
       if (a.reward) a.reward[env] = __builtin_nan("");
       if (a.discount) a.discount[env] = __builtin_nan("");
       if (a.step_type) a.step_type[env] = 0;
+#ifdef MOOG_PROFILE   // tools/reset_profile.py: cycles of the reset and of one of its sections instead of NaN
+      if ((a.dbg & 128) && a.discount) {
+        a.discount[env] = (double)(clock64() - t_begin);
+        if (a.reward) a.reward[env] = (a.dbg >> 8) ? (double)e.prof[((a.dbg >> 8) & 31) - 1] : 0.0;
+      }
+#endif
     }
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);

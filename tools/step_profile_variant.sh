@@ -10,4 +10,4 @@ for t in f3 f4 t3 t4 m3 m4; do
   if [ $t = $TAG ]; then OBJS="$OBJS gpurun_out/moog_step_${TAG}_prof.o"; else OBJS="$OBJS $L/moog_step_$t.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $L/moog_reset_r0.o $L/moog_reset_r1.o $L/moog_engine.o $L/moog_raster.o -o gpurun_out/libmoog_hip_prof.so
-MOOG_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_out/libmoog_hip_prof.so MOOG_PROFILE_ENVS=${MOOG_PROFILE_ENVS:-1024} python tools/step_profile.py "$@" 2>&1 | grep -v amdgpu
+MOOG_HIP_LIB=$GRAFT_REPO_ROOT/gpurun_out/libmoog_hip_prof.so MOOG_PROFILE_ENVS=${MOOG_PROFILE_ENVS:-1024} python ${PROF_SCRIPT:-tools/step_profile.py} "$@" 2>&1 | grep -v amdgpu
