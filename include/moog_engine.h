@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 21
+#define MOOG_ABI_VERSION 22
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -204,6 +204,10 @@ typedef struct {
   int32_t n_cand;   /* DISCRETE: number of candidates                         */
   int32_t cand_off; /* DISCRETE: first candidate in program.cand[]            */
   double a, b;      /* CONST: a ; CONTINUOUS: [a, b)                           */
+  int32_t draw_pos; /* position of this factor's uniform among the draws of one sample of the op (sample_order
+                     * with the direct draws counted in), -1: takes no draw.  Lets the device evaluate the factors
+                     * of a sample in parallel lanes instead of walking sample_order                             */
+  int32_t pad_;
 } moog_factor_t;
 
 /* One sprite-generation op = one `generate_sprites(...)._generate(...)` call
@@ -231,7 +235,7 @@ typedef struct {
                             * 131-154) and runs only when the MOOG_CELL_CHOICE op that drew into o_hdraw[k] picked
                             * alternative cond_value; 0: unconditional.  The alternatives share their slots.      */
   int32_t cond_value;
-  int32_t pad_;
+  int32_t n_draws;         /* uniforms one sample of the op takes (its sampled factors + the direct draws between them) */
   moog_factor_t factors[MOOG_NUM_FACTORS];
 } moog_genop_t;
 

@@ -72,6 +72,7 @@ struct Env {
   double xs_centroid[2], xs_inertia[2];   // centroid / inertia per unit area of a computed shape (MOOG_DIST_EXPR_SHAPE)
   int xs_n;
   unsigned fac_f32, expr_f32;   // float32 samples among the staged factors (MOOG_X_FACTOR); computed factors that came out float32
+  unsigned flat_f32;            // bit k: factor k of the sample just drawn is a float32 Continuous sample
   uint8_t* lst;            // LDS scratch [128]: compacted edge index lists
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
@@ -3017,55 +3018,55 @@ __device__ inline void shape_record(Env& e, int s, int n) {
 // computed from them); only the rare-components kernels compile that in.
 template <bool X>
 __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
-  for (int k = 0; k < MOOG_NUM_FACTORS; ++k) fac[k] = op->factors[k].a;
-  if (op->cell_sel != MOOG_CELL_NONE) {   // factors read off the maze cell the sprite sits on (pacman.py:47-65, maze.py:98-111)
-#pragma unroll
-    for (int k = 0; k < MOOG_NUM_FACTORS; ++k) {
-      PFactor F = &op->factors[k];
-      if (F->kind == MOOG_DIST_MAZE_COORD) fac[k] = e.P->cand[F->cand_off + (F->n_cand ? e.cell_j : e.cell_i)];
-      else if (F->kind == MOOG_DIST_MAZE_SHAPE) fac[k] = F->a + (double)(e.cell_j * e.P->maze.size + e.cell_i);
-    }
-  }
-  // every sampled factor of a flat Product takes exactly one draw, in sample order: all of them at once
-  int ndraw = 0;
-  for (int k = 0; k < op->n_sampled; ++k) {
-    const int fi = op->sample_order[k];
-    if (X && fi >= MOOG_NUM_FACTORS) { ++ndraw; continue; }
-    const int kind = op->factors[fi].kind;
-    ndraw += (kind == MOOG_DIST_CONTINUOUS || kind == MOOG_DIST_DISCRETE) ? 1 : 0;
-  }
+  // Lanes = factors: lane k reads factor k's record (one round trip for all fourteen instead of a chain of
+  // dependent scalar loads per sampled factor), takes its uniform from the op's batch of draws (draw_pos: the
+  // reference's sample order, fixed when the config was lowered) and computes its value; the values then go to
+  // every lane.  This sits inside the rejection loop of the sampler, i.e. on the critical path of every reset.
+  const int kf = e.lane < MOOG_NUM_FACTORS ? e.lane : 0;
+  PFactor F = &op->factors[kf];
+  const int kind = F->kind, f32 = F->f32, n_cand = F->n_cand, cand_off = F->cand_off, dpos = F->draw_pos;
+  const double fa = F->a, fb = F->b;
+  const int ndraw = op->n_draws;
   const double draws = ndraw > 0 ? next_uniforms_lanes(e, ndraw) : 0.0;
-  int kd = 0;
-  for (int k = 0; k < op->n_sampled; ++k) {
-    int fi = op->sample_order[k];
-    if (X && fi >= MOOG_NUM_FACTORS) {   // a direct np.random draw of the initializer, taken between the factor draws
-      const double u = shfl_d(draws, kd++);
-      wsync();
-      if (e.lane == 0) e.f[e.L.o_hdraw + fi - MOOG_NUM_FACTORS] = u;
-      wsync();
-      continue;
-    }
-    PFactor F = &op->factors[fi];
-    double val = F->a;
-    if (F->kind == MOOG_DIST_CONTINUOUS) {
-      double u = shfl_d(draws, kd++);
-      val = F->a + (F->b - F->a) * u;
-      if (F->f32) val = f32r(val);
-    } else if (F->kind == MOOG_DIST_DISCRETE) {
-      double u = shfl_d(draws, kd++);
-      int idx = (int)(u * F->n_cand);
-      if (idx >= F->n_cand) idx = F->n_cand - 1;
-      val = e.P->cand[F->cand_off + idx];
-    }
-    // static indexing keeps `fac` in registers
-#pragma unroll
-    for (int q = 0; q < MOOG_NUM_FACTORS; ++q) if (q == fi) fac[q] = val;
+  const double u = shfl_d(draws, dpos >= 0 ? dpos : 0);
+  double val = fa;
+  if (kind == MOOG_DIST_CONTINUOUS) {
+    val = fa + (fb - fa) * u;
+    if (f32) val = f32r(val);
+  } else if (kind == MOOG_DIST_DISCRETE) {
+    int idx = (int)(u * n_cand);
+    if (idx >= n_cand) idx = n_cand - 1;
+    val = e.P->cand[cand_off + idx];
+  } else if (kind == MOOG_DIST_MAZE_COORD) {   // factors read off the maze cell the sprite sits on (pacman.py:47-65, maze.py:98-111)
+    val = e.P->cand[cand_off + (n_cand ? e.cell_j : e.cell_i)];
+  } else if (kind == MOOG_DIST_MAZE_SHAPE) {
+    val = fa + (double)(e.cell_j * e.P->maze.size + e.cell_i);
   }
+#pragma unroll
+  for (int q = 0; q < MOOG_NUM_FACTORS; ++q) fac[q] = shfl_d(val, q);
+  if constexpr (X) {   // direct np.random draws of the initializer taken between the factor draws: their uniforms to the record
+    if (op->n_sampled > 0 && ndraw > 0) {
+      int kd = 0;
+      for (int k = 0; k < op->n_sampled; ++k) {
+        const int fi = op->sample_order[k];
+        if (fi >= MOOG_NUM_FACTORS) {
+          const double uh = shfl_d(draws, kd);
+          wsync();
+          if (e.lane == 0) e.f[e.L.o_hdraw + fi - MOOG_NUM_FACTORS] = uh;
+          wsync();
+          ++kd;
+        } else {
+          const int kk = op->factors[fi].kind;
+          kd += (kk == MOOG_DIST_CONTINUOUS || kk == MOOG_DIST_DISCRETE) ? 1 : 0;
+        }
+      }
+    }
+  }
+  // which factors are float32 samples (lanes = factors)
+  e.flat_f32 = (unsigned)(__ballot(e.lane < MOOG_NUM_FACTORS && kind == MOOG_DIST_CONTINUOUS && f32 != 0) & 0x3fffull);
   bool any_expr = false;
   if constexpr (X) {
-#pragma unroll
-    for (int q = 0; q < MOOG_NUM_FACTORS; ++q)
-      any_expr = any_expr || op->factors[q].kind == MOOG_DIST_EXPR || op->factors[q].kind == MOOG_DIST_EXPR_SHAPE;
+    any_expr = __any(e.lane < MOOG_NUM_FACTORS && (kind == MOOG_DIST_EXPR || kind == MOOG_DIST_EXPR_SHAPE));
     e.expr_f32 = 0u;
   }
   if (X && any_expr) {   // factors the initializer computed from its draws (after all draws of the op are in)
@@ -3075,21 +3076,21 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
       if (e.lane == 0) reinterpret_cast<double*>(e.lst)[q] = fac[q];
-      if (op->factors[q].kind == MOOG_DIST_CONTINUOUS && op->factors[q].f32) f32m |= 1u << q;
     }
+    f32m = e.flat_f32;
     wsync();
     e.fac_f32 = f32m; e.expr_f32 = 0u;
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
-      PFactor F = &op->factors[q];
-      if (F->kind == MOOG_DIST_EXPR) {
+      PFactor Fq = &op->factors[q];
+      if (Fq->kind == MOOG_DIST_EXPR) {
         int tag = 0;
-        fac[q] = eval_expr(e, F->cand_off, 0, 0, &tag, nullptr);
+        fac[q] = eval_expr(e, Fq->cand_off, 0, 0, &tag, nullptr);
         if (tag == 1) e.expr_f32 |= 1u << q;
       }
-      else if (F->kind == MOOG_DIST_EXPR_SHAPE) {
-        eval_expr(e, F->cand_off, 0, 0, nullptr, nullptr);   // raw vertices -> VERT(cur_slot)
-        shape_record(e, e.cur_slot, F->n_cand);
+      else if (Fq->kind == MOOG_DIST_EXPR_SHAPE) {
+        eval_expr(e, Fq->cand_off, 0, 0, nullptr, nullptr);   // raw vertices -> VERT(cur_slot)
+        shape_record(e, e.cur_slot, Fq->n_cand);
         fac[q] = -1.0;
       }
     }
@@ -3216,15 +3217,13 @@ __device__ inline int genop_count(Env& e, PGenop op) {
 // one `factor_dist.sample()`: the factors and which of them are float32 samples
 template <bool X>
 __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& vel_f32, int& angvel_f32) {
-  PFactor FX = &op->factors[MOOG_FAC_XVEL];
-  PFactor FY = &op->factors[MOOG_FAC_YVEL];
-  PFactor FW = &op->factors[MOOG_FAC_ANGVEL];
-  vel_f32 = FX->kind == MOOG_DIST_CONTINUOUS && FX->f32 && FY->kind == MOOG_DIST_CONTINUOUS && FY->f32;
-  angvel_f32 = FW->kind == MOOG_DIST_CONTINUOUS && FW->f32;
   sample_factors<X>(e, op, fac);
-  unsigned m = 0;
-  for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
-    if (op->factors[k].kind == MOOG_DIST_CONTINUOUS && op->factors[k].f32) m |= 1u << k;
+  unsigned m = e.flat_f32;
+  {
+    const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);
+    vel_f32 = (m & vb) == vb;
+    angvel_f32 = (m >> MOOG_FAC_ANGVEL) & 1u;
+  }
   if (op->code_off >= 0) {   // which factors are float32 samples depends on the branch taken
     run_dist_program(e, op->code_off, fac, m);
     const unsigned vb = (1u << MOOG_FAC_XVEL) | (1u << MOOG_FAC_YVEL);

@@ -451,6 +451,17 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         G.n_sampled = len(entries)
         for k, ent in enumerate(entries):
             G.sample_order[k] = ent
+        # where each factor's uniform sits among the draws of one sample (the device evaluates the factors in lanes)
+        for fi in range(len(_abi.FACTOR_NAMES)):
+            G.factors[fi].draw_pos = -1
+        pos = 0
+        for ent in entries:
+            if ent >= _abi.MOOG_NUM_FACTORS:
+                pos += 1
+            elif G.factors[ent].kind in (_abi.MOOG_DIST_CONTINUOUS, _abi.MOOG_DIST_DISCRETE):
+                G.factors[ent].draw_pos = pos
+                pos += 1
+        G.n_draws = pos
         for sl in slots:
             vcap[sl] = max(vcap[sl], max_nv)   # (sample_generator alternatives share slots)
         op_max_nv[oi] = max_nv
