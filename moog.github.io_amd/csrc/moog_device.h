@@ -3497,8 +3497,31 @@ __device__ inline void run_genop(Env& e, int oi) {
         !maze_select_cell(e, op->cell_sel, op->cell_arg)) n = 0;
     PROF_ADD(e, 14);
   }
-  for (int k = 0; k < op->count_max; ++k) {
-    int s = op->slot0 + k;
+  // without_overlapping: the slot ranges of the ops to avoid, adjacent ones merged, read once per op (the rejection loop
+  // below runs dozens of times per reset: no constant-memory chains inside it).  More than four ranges: the plain loop.
+  int av_lo0 = 0, av_hi0 = 0, av_lo1 = 0, av_hi1 = 0, av_lo2 = 0, av_hi2 = 0, av_lo3 = 0, av_hi3 = 0, n_av = 0;
+  {
+    const unsigned long long avoid = op->avoid_ops;
+    for (int oj = 0; avoid != 0ull && oj < oi && oj < 64; ++oj) {
+      if (!((avoid >> oj) & 1ull)) continue;
+      const int lo = P->ops[oj].slot0, hi = lo + P->ops[oj].count_max;
+      if (n_av == 1 && av_hi0 == lo) av_hi0 = hi;
+      else if (n_av == 2 && av_hi1 == lo) av_hi1 = hi;
+      else if (n_av == 3 && av_hi2 == lo) av_hi2 = hi;
+      else if (n_av == 4 && av_hi3 == lo) av_hi3 = hi;
+      else {
+        if (n_av == 0) { av_lo0 = lo; av_hi0 = hi; }
+        else if (n_av == 1) { av_lo1 = lo; av_hi1 = hi; }
+        else if (n_av == 2) { av_lo2 = lo; av_hi2 = hi; }
+        else if (n_av == 3) { av_lo3 = lo; av_hi3 = hi; }
+        ++n_av;   // (5: too many, see below)
+      }
+    }
+  }
+  const int cmax = op->count_max, slot0 = op->slot0, disjoint = op->disjoint, max_tries = op->max_tries,
+            graceful = op->fail_gracefully;
+  for (int k = 0; k < cmax; ++k) {
+    int s = slot0 + k;
     if (k >= n) {
       wsync();
       if (e.lane == 0) { FLAGS(s) = 0; NV(s) = 0; }
@@ -3513,17 +3536,24 @@ __device__ inline void run_genop(Env& e, int oi) {
       { PROF_T0; sample_op_factors<FULL>(e, op, fac, vel_f32, angvel_f32); PROF_ADD(e, 15); }
       { PROF_T0; create_sprite<FULL>(e, s, fac, vel_f32, angvel_f32); PROF_ADD(e, 12); }
       bool ov = false;
-      for (int oj = 0; oj < oi && oj < 64 && !ov; ++oj) {
-        if (!((op->avoid_ops >> oj) & 1)) continue;
-        PGenop o2 = &P->ops[oj];
-        ov = overlaps_any(e, s, o2->slot0, o2->slot0 + o2->count_max);
+      if (n_av <= 4) {
+        if (n_av > 0) ov = overlaps_any(e, s, av_lo0, av_hi0);
+        if (n_av > 1 && !ov) ov = overlaps_any(e, s, av_lo1, av_hi1);
+        if (n_av > 2 && !ov) ov = overlaps_any(e, s, av_lo2, av_hi2);
+        if (n_av > 3 && !ov) ov = overlaps_any(e, s, av_lo3, av_hi3);
+      } else {
+        for (int oj = 0; oj < oi && oj < 64 && !ov; ++oj) {
+          if (!((op->avoid_ops >> oj) & 1)) continue;
+          PGenop o2 = &P->ops[oj];
+          ov = overlaps_any(e, s, o2->slot0, o2->slot0 + o2->count_max);
+        }
       }
-      if (op->disjoint && !ov) ov = overlaps_any(e, s, op->slot0, s);
+      if (disjoint && !ov) ov = overlaps_any(e, s, slot0, s);
       if (!ov) break;
-      if (count > op->max_tries) {
+      if (count > max_tries) {
         wsync();
-        if (op->fail_gracefully) {   // `return sprites` (sprite_generators.py:93-95): this sprite and the rest of the call are dropped
-          for (int t = k + e.lane; t < op->count_max; t += 64) { FLAGS(op->slot0 + t) = 0; NV(op->slot0 + t) = 0; }
+        if (graceful) {   // `return sprites` (sprite_generators.py:93-95): this sprite and the rest of the call are dropped
+          for (int t = k + e.lane; t < cmax; t += 64) { FLAGS(slot0 + t) = 0; NV(slot0 + t) = 0; }
           wsync();
           return;
         }
