@@ -618,7 +618,7 @@ def _evaluate(node, env):
         return env.get(node.key(), False)
     if op in ('overlaps', 'phase_is'):
         return env.get(node.key(), True)
-    if op == 'meta_num':
+    if op in ('meta_num', 'hdraw', 'selffac', 'slotattr'):
         return env.get(node.key(), False)
     v = [_evaluate(x, env) for x in a]
     if op == 'select':

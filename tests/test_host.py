@@ -311,3 +311,43 @@ def test_raster_sort_key_and_network():
             lo, hi = np.minimum(v[:, a], v[:, b]), np.maximum(v[:, a], v[:, b])
             v[:, a], v[:, b] = lo, hi
         assert (np.diff(v, axis=1) >= 0).all(), n
+
+
+def test_traced_initializer_arithmetic_matches_numpy():
+    """The numpy arithmetic a state_initializer does on its own np.random draws (parallelogram_catch.py:34-68) is
+    carried as expression trees (moog/_symbolic.py Sym / SymVec / SymMat).  Evaluating the trees on given uniforms must
+    give exactly what numpy gives when np.random.uniform returns `low + (high - low) * u` for the same uniforms."""
+    from moog import _symbolic as sy, _trace
+    from moog_demos.example_configs import parallelogram_catch as pc
+
+    def build():
+        corners = pc.random_parallelogram(min_axis_ratio=0.5)
+        shape = 0.075 * corners
+        centres = 0.4 * corners
+        centres += np.array([0.5, 0.5]) - centres[0]
+        return shape, centres
+    with _trace.tracing() as tr:
+        sym_shape, sym_centres = build()
+    assert tr.n_hdraws == 2 and isinstance(sym_shape, sy.SymMat) and sym_centres.shape == (4, 2)
+
+    class Leaves(object):
+        def __init__(self, u):
+            self.u = u
+
+        def get(self, key, boolean):
+            assert key[0] == 'hdraw'
+            return self.u[key[1]]
+    rs = np.random.RandomState(3)
+    real_uniform = np.random.uniform
+    for _ in range(20):
+        u = rs.uniform(size=2)
+        tape = list(u)
+        np.random.uniform = lambda low=0.0, high=1.0, size=None: low + (high - low) * tape.pop(0)
+        try:
+            ref_shape, ref_centres = build()
+        finally:
+            np.random.uniform = real_uniform
+        for sym, ref in ((sym_shape, ref_shape), (sym_centres, ref_centres)):
+            got = np.array([[sy._evaluate(c.node, Leaves(u)) for c in row] for row in sym.rows])
+            # (np.sin / np.cos of an array may differ from the scalar routines in the last bit)
+            assert np.max(np.abs(got - ref)) <= 1e-15, (got, ref)
