@@ -654,9 +654,10 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
  * landing in the under-filled tail of the launch.  NULLs disable. */
 int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_dev);
 
-/* Per-kernel device timing: `enabled` is a bit mask over MOOG_K_* (bit k set: every launch
- * of kernel k is bracketed by HIP events on the launch stream; 0 disables); totals are read
- * back (synchronising) by moog_engine_kernel_time. */
+/* Per-kernel device timing: bits 0-7 of `enabled` are a mask over MOOG_K_* (bit k set: launches of kernel k are
+ * bracketed by HIP events on the launch stream; 0 disables), bits 8-15 hold period - 1: every period-th launch of
+ * a kernel is bracketed (an event pair costs about 5 us of stream time; period 1 = every launch).  Totals and the
+ * number of bracketed launches are read back (synchronising) by moog_engine_kernel_time. */
 int moog_engine_set_timing(moog_engine_t* e, int32_t enabled);
 int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_ms,
                             int64_t* launches);

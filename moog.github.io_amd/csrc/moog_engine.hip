@@ -37,6 +37,7 @@ struct TimedKernel {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double total_ms = 0;
   int64_t launches = 0;
+  int64_t seq = 0;   // launches seen while timing is on (every `period`-th one is bracketed)
 };
 
 struct moog_engine {
@@ -457,7 +458,9 @@ int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view) {
 struct Bracket {
   moog_engine* e; int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
   Bracket(moog_engine* e_, int id_, hipStream_t s_) : e(e_), id(id_), s(s_) {
-    if ((e->timing >> id) & 1) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    // (an event pair costs ~5 us of stream time: `period` > 1 samples the launches instead of bracketing all of them)
+    const int period = ((e->timing >> 8) & 255) + 1;
+    if (((e->timing >> id) & 1) && (e->timed[id].seq++ % period) == 0) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
   }
   ~Bracket() {
     if (a) { hipEventRecord(b, s); e->timed[id].pending.emplace_back(a, b); }

@@ -373,14 +373,16 @@ class BatchedEnvironment(object):
         _engine.check(self._lib, self._lib.moog_engine_set_debug(self._handle, int(step_debug), int(raster_stop)))
 
     # -- kernel timing -------------------------------------------------------------------
-    def set_timing(self, enabled, kernels=None):
+    def set_timing(self, enabled, kernels=None, every=1):
         """Brackets kernel launches with HIP events: all kernels, or only the MOOG_K_* ids in
-        `kernels` (every event pair costs a few microseconds of stream time)."""
+        `kernels`; `every` = n brackets every n-th launch of a kernel (an event pair costs about
+        5 microseconds of stream time, ~2 % of a step when every launch is bracketed)."""
         mask = 0
         if enabled:
             ids = range(_abi.MOOG_K_COUNT) if kernels is None else kernels
             for k in ids:
                 mask |= 1 << int(k)
+            mask |= (max(1, min(256, int(every))) - 1) << 8
         _engine.check(self._lib, self._lib.moog_engine_set_timing(self._handle, mask))
 
     def kernel_time(self, kernel_id):
