@@ -105,6 +105,11 @@ class Sym(object):
     def __bool__(self):
         if self.node.op == 'const':
             return self.node.args[0] != 0
+        if _TRACER is None:
+            # e.g. `while not valid: angle = np.random.uniform(...)` inside a state_initializer (match_to_sample.py:
+            # 33-43): the number of draws would depend on their values
+            raise Unsupported('branching on a value drawn at reset time (a rejection loop over np.random in a '
+                              'state_initializer, sorting drawn values, ...) is not lowered')
         return _TRACER.decide(self.node)
 
     def __float__(self):

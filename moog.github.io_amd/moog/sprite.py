@@ -109,6 +109,13 @@ class Sprite(object):
                 from . import _symbolic
                 return _symbolic.Sym(_symbolic.Node('slotattr', self, name))
             return v
+        if name in ('position', 'velocity', 'vertices', 'overlaps_sprite', 'contains_point', 'color', 'path',
+                    'moment_of_inertia', 'max_radius', 'update_pos_from_vel'):
+            # e.g. bounce_box_contact_prediction.py:113-121 / red_green.py:86-106 step the physics inside the
+            # state_initializer to label or reject a trial
+            raise NotImplementedError(
+                'sprite.%s inside a state_initializer: a Sprite here is a recipe (its factors), live sprites exist on '
+                'the device only; initialisers that simulate the episode on the host are not lowered' % name)
         raise AttributeError(name)
 
 

@@ -351,3 +351,20 @@ def test_traced_initializer_arithmetic_matches_numpy():
             got = np.array([[sy._evaluate(c.node, Leaves(u)) for c in row] for row in sym.rows])
             # (np.sin / np.cos of an array may differ from the scalar routines in the last bit)
             assert np.max(np.abs(got - ref)) <= 1e-15, (got, ref)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
+@pytest.mark.parametrize('name,level,needle', [
+    ('match_to_sample', 3, 'branching on a value drawn at reset time'),
+    ('predators_arena', 2, 'after construction'),
+    ('bounce_box_contact_prediction', 0, 'simulate the episode on the host'),
+    ('red_green', 1, 'np.random calls inside a distribution sampled by generate_sprites')])
+def test_reference_configs_that_do_not_lower_say_why(name, level, needle):
+    """The four reference configs the engine does not run are refused at construction with the reason (no silent
+    freezing of host randomness, no Python fallback)."""
+    spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with pytest.raises(NotImplementedError) as info:
+        _compiler.compile_config(**m.get_config(level))
+    assert needle in str(info.value)
