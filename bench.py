@@ -194,6 +194,9 @@ def main():
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
+    ap.add_argument('--no-fused', action='store_true',
+                    help='separate step / raster launches in every call (default: frames follow their env\'s step, '
+                         'moog_engine_set_fused)')
     ap.add_argument('--lockstep', action='store_true', help='keep the episodes of the batch synchronous')
     ap.add_argument('--no-extras', action='store_true', help='skip the strict-fault-check comparison window')
     args = ap.parse_args()
@@ -240,7 +243,9 @@ def main():
         layer_capacity=example_configs.capacity(args.workload),
         **example_configs.load(args.workload))
     if not args.no_schedule:
-        env.enable_cost_schedule()
+        fused = env.enable_cost_schedule(fused=not args.no_fused)
+    else:
+        fused = False
     env.reset()
     is_grid = env._is_grid
     P = env.compiled.program
@@ -278,7 +283,11 @@ def main():
     # averages (and the roofline figure of the raster kernel) are measurements of the timed steps
     # themselves.  Every 8th launch of each kernel is bracketed (25 samples per kernel in the default window,
     # never fewer than 10): bracketing every launch costs the timed region 20 us per step (2 %), measured.
-    env.set_timing(True, every=max(1, min(8, args.steps // 10)))
+    # When frames follow their env's step (moog_engine_set_fused) the raster work of a call runs beside its step
+    # kernel and has no duration of its own: the sampled calls (every 16th then, 12 in the default window) take the
+    # separate launches, so the kernels are timed alone, by the same events, inside the timed region.
+    every = max(1, min(16 if fused else 8, args.steps // 10))
+    env.set_timing(True, every=every)
     for k in range(_abi.MOOG_K_COUNT):
         env.kernel_time(k)   # clear
     barrier()
@@ -334,6 +343,9 @@ def main():
                                        P.render.height, P.render.width),
                        'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
                        'parallelism': 'env-sharded x%d, no collective' % world,
+                       'launch': ('frames follow their env\'s step (raster grid beside the step kernel); every %dth call takes the '
+                                  'separate launches and is the one whose kernels are timed' % every) if fused
+                                 else 'separate step and raster launches',
                        'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)
                                    if staggered else 'lockstep'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 22
+#define MOOG_ABI_VERSION 23
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -76,6 +76,8 @@ extern "C" {
 #define MOOG_FAULT_PHASE_END 128
 /* MazePhysics: an avatar is on no grid line of the maze (maze_physics.py:87-97 raises ValueError) */
 #define MOOG_FAULT_OFF_GRID 256
+/* moog_engine_set_fused: a frame's workgroup gave up waiting for its env's step (engine error) */
+#define MOOG_FAULT_FRAME_TIMEOUT 512
 #define MOOG_MAX_MAZE 32
 #define MOOG_MAX_MAZE_POINTS 8 /* cells of one sample_distinct_open_points() call */
 #define MOOG_MAX_MAZE_GEN 16   /* size of a maze drawn on the device (its frontier list holds size^2 one-byte cells) */
@@ -653,6 +655,17 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
  * with the rasteriser) so that the expensive envs (clustered contacts) start first instead of
  * landing in the under-filled tail of the launch.  NULLs disable. */
 int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_dev);
+
+/* Frames follow their env's step (pure performance setting, results do not depend on it; needs a schedule).
+ * The step kernel lasts as long as its slowest env while the mean env is done in about a third of that time.  With
+ * `enabled`, a moog_engine_step call with an image output launches, beside the step kernel and on an engine-owned
+ * stream, a small persistent raster grid whose workgroups take the envs in the order they are expected to finish,
+ * wait for each env's step to be stored (a per-env flag in HBM) and draw its frame: most frames are drawn on the
+ * compute units the finished envs have left idle, and only the slowest env's frame follows the step kernel.  The
+ * caller's stream waits for the frames before the call's outputs may be read.  One-tile frames without
+ * anti-aliasing only (MOOG_E_UNSUPPORTED otherwise); calls with injected uniforms, debug settings, or whose raster
+ * launch is being timed (moog_engine_set_timing) take the separate launches. */
+int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
 
 /* Per-kernel device timing: bits 0-7 of `enabled` are a mask over MOOG_K_* (bit k set: launches of kernel k are
  * bracketed by HIP events on the launch stream; 0 disables), bits 8-15 hold period - 1: every period-th launch of

@@ -70,6 +70,17 @@ struct moog_engine {
   hipEvent_t ev_step_done = nullptr, ev_sched_done = nullptr;
   bool sched_pending = false;
   float* cost = nullptr;
+  // moog_engine_set_fused: frames follow their env's step on a second stream (RFollow in moog_raster.h)
+  bool fused = false;
+  int32_t* fused_done = nullptr;   // per-env call numbers
+  uint32_t* fused_ticket = nullptr;
+  int32_t* perm_buf[2] = {nullptr, nullptr};   // the caller's order buffer and the engine's own: the sort alternates while frames read
+  int perm_cur = 0;
+  uint32_t fused_base = 0;
+  int32_t fused_epoch = 0;
+  int fused_resident = 0, fused_groups = 0;
+  hipStream_t fused_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_frames = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
   int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
   int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
@@ -432,6 +443,12 @@ static void drain(TimedKernel& t) {
 int moog_engine_destroy(moog_engine_t* e) {
   if (!e) return MOOG_OK;
   for (int k = 0; k < MOOG_K_COUNT; ++k) drain(e->timed[k]);
+  if (e->fused_done) {
+    hipStreamSynchronize(e->fused_stream);
+    hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_frames);
+    hipStreamDestroy(e->fused_stream);
+    hipFree(e->fused_done); hipFree(e->fused_ticket); hipFree(e->perm_buf[1]);
+  }
   if (e->sched_stream) {
     hipStreamSynchronize(e->sched_stream);
     hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
@@ -455,12 +472,16 @@ int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view) {
   return MOOG_OK;
 }
 
+// (an event pair costs ~5 us of stream time: `period` > 1 samples the launches instead of bracketing all of them)
+static bool sampled(moog_engine* e, int id) {
+  const int period = ((e->timing >> 8) & 255) + 1;
+  return ((e->timing >> id) & 1) && (e->timed[id].seq++ % period) == 0;
+}
+
 struct Bracket {
   moog_engine* e; int id; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
-  Bracket(moog_engine* e_, int id_, hipStream_t s_) : e(e_), id(id_), s(s_) {
-    // (an event pair costs ~5 us of stream time: `period` > 1 samples the launches instead of bracketing all of them)
-    const int period = ((e->timing >> 8) & 255) + 1;
-    if (((e->timing >> id) & 1) && (e->timed[id].seq++ % period) == 0) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+  Bracket(moog_engine* e_, int id_, hipStream_t s_, int on = -1) : e(e_), id(id_), s(s_) {   // on: -1 = sample, else decided
+    if (on < 0 ? sampled(e, id) : on != 0) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
   }
   ~Bracket() {
     if (a) { hipEventRecord(b, s); e->timed[id].pending.emplace_back(a, b); }
@@ -481,10 +502,11 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.step_type = out ? out->step_type : nullptr;
   a.mode = mode;
   a.vslot = e->d_vslot;
-  a.perm = (mode == MODE_STEP) ? e->perm : nullptr;
+  a.perm = (mode == MODE_STEP && e->perm) ? (e->perm_buf[1] ? e->perm_buf[e->perm_cur] : e->perm) : nullptr;
   a.cost = (mode == MODE_STEP) ? e->cost : nullptr;
   a.dbg = e->step_dbg;
   a.fault_flag = e->fault_flag;
+  a.done = nullptr; a.epoch = 0; a.done_wb = 0;
   return a;
 }
 
@@ -513,9 +535,9 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   return r;
 }
 
-static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s) {
+static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1) {
   RArgs r = raster_args(e, image);
-  Bracket br(e, MOOG_K_RASTER, s);
+  Bracket br(e, MOOG_K_RASTER, s, timed);
   if (e->aa <= 1) {
     moog_raster_launch(r, e->raster_lds, s);
   } else {   // pil_renderer.py:111-112: draw on the large canvas, then Image.resize(LANCZOS); a chunk of envs at a time
@@ -569,6 +591,42 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
     e->sched_pending = false;
   }
+  int time_raster = -1;
+  const bool follow = e->fused && e->perm && e->cost && out && out->image && !(inject && inject->uniforms) && !e->step_dbg &&
+                      !e->raster_stop;
+  // (a call whose raster launch is to be timed takes the separate launches below: the kernel is then measured alone)
+  if (follow) time_raster = sampled(e, MOOG_K_RASTER) ? 1 : 0;
+  if (follow && !time_raster) {
+    if (++e->fused_epoch == INT32_MAX) e->fused_epoch = 1;
+    a.done = e->fused_done;
+    a.epoch = e->fused_epoch;
+    a.done_wb = (e->prog.n_rules > 0 || e->dynamic_rules || e->maze_kernel) ? 1 : 0;
+    RArgs r = raster_args(e, out->image);
+    RFollow f;
+    f.done = e->fused_done; f.epoch = e->fused_epoch; f.perm = a.perm; f.resident = e->fused_resident;
+    f.ticket = e->fused_ticket; f.base = e->fused_base; f.spin_cap = 2000000;   // ~2 s
+    f.i32 = e->view.i32; f.fault_flag = e->fault_flag;
+    e->fused_base += (uint32_t)e->fused_groups + (uint32_t)e->n_envs;   // every workgroup draws one ticket past the last frame
+    HIPCHK(hipEventRecord(e->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(e->fused_stream, e->ev_fork, 0));
+    {
+      Bracket br(e, MOOG_K_STEP, s);
+      launch_step(e, s, a);
+    }
+    moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, e->fused_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e->ev_frames, e->fused_stream));
+    HIPCHK(hipEventRecord(e->ev_step_done, s));
+    HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
+    // (the last frames are still reading this call's order: the sort writes the other buffer, beside them)
+    e->perm_cur ^= 1;
+    moog_launch_sched(e->sched_stream, e->cost, e->perm_buf[e->perm_cur], e->n_envs, e->view.i32 + e->L.o_reset_next,
+                      e->L.i32_per_env);
+    HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
+    e->sched_pending = true;
+    HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
+    return MOOG_OK;
+  }
   {
     Bracket br(e, MOOG_K_STEP, s);
     launch_step(e, s, a);
@@ -577,11 +635,12 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   if (e->perm && e->cost) {
     HIPCHK(hipEventRecord(e->ev_step_done, s));
     HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
-    moog_launch_sched(e->sched_stream, e->cost, e->perm, e->n_envs, e->view.i32 + e->L.o_reset_next, e->L.i32_per_env);
+    moog_launch_sched(e->sched_stream, e->cost, e->perm_buf[1] ? e->perm_buf[e->perm_cur] : e->perm, e->n_envs,
+                      e->view.i32 + e->L.o_reset_next, e->L.i32_per_env);
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
   }
-  if (out && out->image) return launch_raster(e, out->image, s);
+  if (out && out->image) return launch_raster(e, out->image, s, time_raster);
   return MOOG_OK;
 }
 
@@ -610,12 +669,44 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
   if (e->sched_pending) { hipEventSynchronize(e->ev_sched_done); e->sched_pending = false; }
   e->perm = perm_dev;
   e->cost = cost_dev;
+  e->perm_buf[0] = perm_dev;
+  e->perm_cur = 0;
+  if (!perm_dev) e->fused = false;
   if (perm_dev && cost_dev && !e->sched_stream) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->sched_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_step_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_sched_done, hipEventDisableTiming));
   }
+  return MOOG_OK;
+}
+
+int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  if (!enabled) { e->fused = false; return MOOG_OK; }
+  if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1)
+    return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing");
+  if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->fused_done) {
+    HIPCHK(hipMalloc(&e->fused_done, sizeof(int32_t) * (size_t)e->n_envs));
+    HIPCHK(hipMemset(e->fused_done, 0, sizeof(int32_t) * (size_t)e->n_envs));
+    HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
+    HIPCHK(hipMalloc(&e->fused_ticket, sizeof(uint32_t)));
+    HIPCHK(hipMemset(e->fused_ticket, 0, sizeof(uint32_t)));
+    HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, e->device));
+    const int per_cu = (int)(160 * 1024 / (e->step_lds ? e->step_lds : 1));
+    e->fused_resident = (per_cu < 4 * e->step_wps ? per_cu : 4 * e->step_wps) * prop.multiProcessorCount;
+    e->fused_groups = prop.multiProcessorCount;   // one per compute unit: two measured 1 % slower (more contention with the steps)
+    { const char* g = getenv("MOOG_FUSED_GROUPS"); if (g && atoi(g) > 0) e->fused_groups = atoi(g); }   // experiments
+    if (e->fused_groups > e->n_envs) e->fused_groups = e->n_envs;
+  }
+  e->perm_buf[0] = e->perm;
+  e->fused = true;
   return MOOG_OK;
 }
 

@@ -70,8 +70,10 @@ __device__ inline void load_record(const Env& e, const HotLayout& h, const moog_
   wsync();
 }
 
+// through: the record is about to be read by another kernel that is running now (moog_engine_set_fused) -- agent-scope
+// stores (sc1: written through this XCD's L2), so that no L2 write-back is needed before the env's flag is raised
 __device__ inline void store_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
-                                    double* gf, int32_t* gq, int32_t* fault_flag = nullptr) {
+                                    double* gf, int32_t* gq, int32_t* fault_flag = nullptr, bool through = false) {
   wsync();
   if (fault_flag && e.lane == 0) {   // rare: tell the host without waiting for it to look at every record
     const int32_t fw = e.q[e.L.o_fault];
@@ -80,13 +82,31 @@ __device__ inline void store_record(const Env& e, const HotLayout& h, const moog
   double2* dst = reinterpret_cast<double2*>(gf);
   const double2* src = reinterpret_cast<const double2*>(e.f);
   const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
+  int4* dsti = reinterpret_cast<int4*>(gq);
+  const int4* srci = reinterpret_cast<const int4*>(e.q);
+  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
+  if (through) {
+    for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
+      if (i >= fa && i < fb) continue;
+      const double2 v = src[i < fa ? i : i - (fb - fa)];
+      __hip_atomic_store(&gf[2 * i], v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gf[2 * i + 1], v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long* gq64 = reinterpret_cast<unsigned long long*>(gq);
+    for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
+      if (i >= ia && i < ib) continue;
+      const int4 v = srci[i < ia ? i : i - (ib - ia)];
+      __hip_atomic_store(&gq64[2 * i], (unsigned long long)(unsigned)v.x | ((unsigned long long)(unsigned)v.y << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&gq64[2 * i + 1], (unsigned long long)(unsigned)v.z | ((unsigned long long)(unsigned)v.w << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
     if (i < fa) dst[i] = src[i];
     else if (i >= fb) dst[i] = src[i - (fb - fa)];
   }
-  int4* dsti = reinterpret_cast<int4*>(gq);
-  const int4* srci = reinterpret_cast<const int4*>(e.q);
-  const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
   for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
     if (i < ia) dsti[i] = srci[i];
     else if (i >= ib) dsti[i] = srci[i - (ib - ia)];
@@ -115,19 +135,23 @@ struct KArgs {
   const int32_t* perm;   // launch order (or null)
   float* cost;           // per-env cycles of this step (or null)
   int32_t* fault_flag;   // host-visible word: OR of every fault bit raised by any env (deferred fault surfacing)
+  int32_t* done;         // moog_engine_set_fused: per env, the number of the last call whose step has been stored (or null)
+  int32_t epoch;         // this call's number
+  int32_t done_wb;       // 1: rules may write record fields straight to HBM -- always write this XCD's L2 back before the flag
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
-__device__ inline void bind_env(Env& e, const KArgs& a, int env) {
+// lds: this wave's record area (the whole dynamic LDS of a one-wave workgroup; the fused launch runs four envs per workgroup)
+__device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* lds = moog_lds, int lane = (int)threadIdx.x) {
   e.P = as_const_prog(a.P);
   e.L = a.H.L;
   const moog_layout_t& H = a.H.L;
-  e.f = reinterpret_cast<double*>(moog_lds);
-  e.q = reinterpret_cast<int32_t*>(moog_lds + (size_t)H.f64_per_env * 8);
-  e.bb = reinterpret_cast<float*>(moog_lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
+  e.f = reinterpret_cast<double*>(lds);
+  e.q = reinterpret_cast<int32_t*>(lds + (size_t)H.f64_per_env * 8);
+  e.bb = reinterpret_cast<float*>(lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
   e.xf = reinterpret_cast<double*>(e.bb + 8 * H.S);       // [S][8] only when S > 64
   double* after_xf = (H.S > 64) ? e.xf + 8 * H.S : e.xf;
   e.voff = reinterpret_cast<int32_t*>(after_xf);
@@ -156,7 +180,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env) {
   e.inj_n = a.inj_n;
   e.seed = a.seed;
   e.env_index = a.env_index0 + env;
-  e.lane = threadIdx.x;
+  e.lane = lane;
 }
 
 // reset_next word: 0 = running, 1 = reset on the next call (environment.py:100-101): the step kernel
@@ -245,15 +269,14 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
 // WPS = waves per SIMD the register allocation is sized for: 4 (128 VGPRs, some scratch) keeps sixteen
 // envs per CU in flight, which is what programs with small state records want; 3 (168 VGPRs, no
 // scratch in the hot loops) is faster once LDS holds fewer than fifteen records per CU anyway.
-template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
-__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
-  int env = blockIdx.x;
-  if (env >= a.n_envs) return;
-  if (a.perm) env = a.perm[env];
+// One env's step (or auto-reset), one wavefront.
+// Returns true when the call reset the env (the reset path writes colours / opacities / shapes straight to HBM).
+template <bool DYN>
+__device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned char* lds, const int lane) {
   const long long t_sched = a.cost ? clock64() : 0;
   int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   Env e;
-  bind_env(e, a, env);
+  bind_env(e, a, env, lds, lane);
   const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   { PROF_T0; load_record(e, a.H, a.L, gf, gq); PROF_ADD(e, 9); }
@@ -275,9 +298,9 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
       }
 #endif
     }
-    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
-    return;
+    return true;
   }
 #endif
   { PROF_T0; bbox_build_all(e); PROF_ADD(e, 9); }
@@ -285,8 +308,8 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
     for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
-    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
-    return;
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
+    return false;
   }
   {
   PROF_T0;
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
-  store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+  store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);
@@ -333,6 +356,23 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
 #ifdef MOOG_PROFILE
     if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 31) - 1];
 #endif
+  }
+  return false;
+}
+
+template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
+__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
+  int env = blockIdx.x;
+  if (env >= a.n_envs) return;
+  if (a.perm) env = a.perm[env];
+  const bool direct = step_env<DYN>(a, env, moog_lds, (int)threadIdx.x);
+  if (a.done) {   // the frame of this env may be drawn now (moog_raster_follow_kernel): record first, then the flag
+    // The record went out with agent-scope stores; whatever the call wrote straight to HBM with ordinary stores (a reset's
+    // colours / opacities / shapes; rules that modify them: done_wb) needs this XCD's L2 written back first.  That
+    // write-back is kept off the common path: 4096 of them per launch cost the step kernel 30 us.
+    if (direct || a.done_wb) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (threadIdx.x == 0) __hip_atomic_store(&a.done[env], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -120,6 +120,24 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   p->total = o;
 }
 
+// moog_engine_set_fused: frames follow their env's step.  A small persistent grid (one workgroup per compute unit) runs
+// on a second stream BESIDE the step kernel; a workgroup takes the next position of the expected finish order, waits
+// until that env's step has been stored (done[env] == epoch: the step wave writes its record with agent-scope stores,
+// then raises the flag), and renders it.  It cannot starve the step kernel: 27 KB of LDS and four waves of <= 80 VGPRs
+// per compute unit leave room for ten stepping envs there, and the grid is too small to fill the compute units by itself.
+struct RFollow {
+  const int32_t* done;     // per env: number of the last call whose step has been stored
+  int32_t epoch;           // this call's number
+  const int32_t* perm;     // the step kernel's launch order (descending expected cost)
+  int32_t resident;        // positions of the launch order that start with the launch (the others start as those finish)
+  uint32_t* ticket;        // running counter of frames handed out (over all calls)
+  uint32_t base;           // its value at the start of this call
+  int32_t spin_cap;        // polls (about a microsecond each) before a workgroup gives up (MOOG_FAULT_FRAME_TIMEOUT)
+  int32_t* i32;            // state records (for the fault word) and the host-visible fault word
+  int32_t* fault_flag;
+};
+void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream);
+
 // moog_raster.hip: the kernel's own translation unit
 // Image.resize(LANCZOS) of a batch of canvases [n][ch][cw][3] -> observations [n][oh][ow][3], flipped; tmp: [n][ch][ow][3]
 struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_t* bv; const int32_t* ch_coef; const int32_t* cv_coef;

@@ -34,6 +34,7 @@ _FAULT_EXC = (
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
     (_abi.MOOG_FAULT_OFF_GRID, ValueError, 'Object is not on the maze grid.'),
+    (_abi.MOOG_FAULT_FRAME_TIMEOUT, RuntimeError, 'fused launch: a frame gave up waiting for its env\'s step.'),
 )
 
 
@@ -105,13 +106,20 @@ class BatchedEnvironment(object):
         self.check_faults = True
         self._cost = self._perm = None
 
-    def enable_cost_schedule(self, enabled=True):
+    def enable_cost_schedule(self, enabled=True, fused=False):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
         previous step (longest-processing-time first): the envs with clustered contacts
         start first instead of landing in the under-filled tail of the launch.  The engine
         re-sorts the order after every step on a side stream.  A pure scheduling hint --
-        results are identical."""
+        results are identical.
+
+        fused=True also asks for ONE launch per step() call (moog_engine_set_fused): each frame is rasterised as
+        soon as its env's step is stored, beside the slower envs' steps.  Returns whether the fused launch is in
+        use (programs it does not cover keep the separate launches)."""
         torch = self._torch
+        self._fused = False
+        if not (enabled and fused):
+            _engine.check(self._lib, self._lib.moog_engine_set_fused(self._handle, 0))
         if enabled:
             self._cost = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
             self._perm = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
@@ -119,9 +127,12 @@ class BatchedEnvironment(object):
                 _engine.check(self._lib, self._lib.moog_engine_set_schedule(
                     self._handle, ctypes.c_void_p(self._perm.data_ptr()),
                     ctypes.c_void_p(self._cost.data_ptr())))
+                if fused:
+                    self._fused = self._lib.moog_engine_set_fused(self._handle, 1) == 0
         else:
             self._cost = self._perm = None
             _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
+        return self._fused
 
     # -- plumbing ---------------------------------------------------------------------
     def _stream(self):

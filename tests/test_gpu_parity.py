@@ -460,6 +460,61 @@ def test_cost_schedule_is_result_neutral():
     assert np.array_equal(outs[0][3], outs[1][3], equal_nan=True)
 
 
+@pytest.mark.parametrize('name,n,steps', [
+    ('colliding_predators_32', 4096, 40),   # no rules: records go out with agent-scope stores, L2 write-back only after a reset
+    ('colliding_predators_32', 333, 60),    # fewer envs than the follow grid has workgroups per round
+    ('chase_avoid_torus', 1024, 130),       # rules (torus wrap, vanish) + nine-copy frames + auto-resets
+    ('functional_maze', 512, 60),           # 128-column frames (two mask words), Booster writes colours straight to HBM
+    ('falling_balls', 1024, 80),
+])
+def test_frames_follow_steps_is_result_neutral(name, n, steps):
+    """moog_engine_set_fused: every frame is drawn beside the step kernel as soon as its env's step is stored.  States,
+    time steps and EVERY frame of every call equal the separate launches' (each call's frames are compared, so a frame
+    drawn from a stale or half-written record cannot hide), with per-kernel timing sampled in between (those calls
+    take the separate launches) and with episodes ending at different steps."""
+    import torch
+    outs = []
+    for fused in (False, True):
+        env = make_env(name, n, seed=12)
+        assert env.enable_cost_schedule(fused=fused) == fused
+        env.reset()
+        if fused:
+            env.set_timing(True, every=5)
+        grid = env._is_grid
+        g = torch.Generator(device='cpu').manual_seed(2)
+        sums, last = [], None
+        for k in range(steps):
+            if grid:
+                a = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
+            else:
+                a = torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1
+            out = env.step(a)
+            img = out.observation['image']
+            # a position-weighted checksum of every env's frame (exact integer arithmetic) + the step types / rewards
+            w = (torch.arange(img[0].numel(), device=img.device, dtype=torch.int64) % 8191) + 1
+            sums.append(((img.reshape(n, -1).to(torch.int64) * w).sum(1).cpu().numpy(), out.step_type.cpu().numpy(),
+                         np.nan_to_num(out.reward.cpu().numpy(), nan=-7.0)))
+            last = img
+        f, q = download(env)
+        env.raise_faults()
+        outs.append((f, q, last.cpu().numpy(), sums))
+        env.close()
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    assert np.array_equal(outs[0][2], outs[1][2])
+    for k, (x, y) in enumerate(zip(outs[0][3], outs[1][3])):
+        assert np.array_equal(x[0], y[0]), 'frames of call %d differ in envs %s' % (k, np.nonzero(x[0] != y[0])[0][:8])
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+
+
+def test_frames_follow_steps_refuses_what_it_does_not_cover():
+    env = make_env('aa_zoo', 8, seed=1)          # anti-aliased renderer
+    assert env.enable_cost_schedule(fused=True) is False
+    env.reset()
+    env.step(env.random_action())
+    env.close()
+
+
 def _simulation_env():
     """The environment of the reference's tests/moog/env_wrappers/test_simulation.py:32-58."""
     import collections

@@ -14,14 +14,14 @@ for sel in [0, 7, 8] + [s for s, _ in SECTIONS]:
     env.check_faults = False
     env.reset()
     env.set_debug(128 | (sel << 8), 0)
-    for k in range(40):
+    for k in range(int(os.environ.get("MOOG_PROFILE_STEPS", 40))):
         ts = env.step(env.random_action())
     res[sel] = (ts.discount.cpu().numpy().copy(), ts.reward.cpu().numpy().copy())
     env.close()
 tot = res[0][0]
 order = np.argsort(-tot)
 heavy = order[:40]
-print('%s, step 40: total cycles  mean %.0f  heaviest-40 mean %.0f  max %.0f' % (name, tot.mean(), tot[heavy].mean(), tot.max()))
+print('%s, step %s: total cycles  mean %%.0f  heaviest-40 mean %%.0f  max %%.0f' % (name, os.environ.get('MOOG_PROFILE_STEPS', '40')) % ( tot.mean(), tot[heavy].mean(), tot.max()))
 cnt = res[0][1] % 1e10
 print('  single path tests / contact searches: mean %.1f / %.1f, heaviest-40 %.1f / %.1f' % (
     (cnt % 100000).mean(), (cnt // 100000).mean(), (cnt[heavy] % 100000).mean(), (cnt[heavy] // 100000).mean()))
