@@ -76,7 +76,6 @@ struct moog_engine {
   uint32_t* fused_ticket = nullptr;
   int32_t* perm_buf[2] = {nullptr, nullptr};   // the caller's order buffer and the engine's own: the sort alternates while frames read
   int perm_cur = 0;
-  uint32_t fused_base = 0;
   int32_t fused_epoch = 0;
   int fused_resident = 0, fused_groups = 0;
   hipStream_t fused_stream = nullptr;
@@ -604,9 +603,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     RArgs r = raster_args(e, out->image);
     RFollow f;
     f.done = e->fused_done; f.epoch = e->fused_epoch; f.perm = a.perm; f.resident = e->fused_resident;
-    f.ticket = e->fused_ticket; f.base = e->fused_base; f.spin_cap = 2000000;   // ~2 s
+    f.ticket = e->fused_ticket; f.spin_cap = 2000000;   // a few seconds
     f.i32 = e->view.i32; f.fault_flag = e->fault_flag;
-    e->fused_base += (uint32_t)e->fused_groups + (uint32_t)e->n_envs;   // every workgroup draws one ticket past the last frame
     HIPCHK(hipEventRecord(e->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(e->fused_stream, e->ev_fork, 0));
     {
@@ -687,13 +685,21 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1)
     return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing");
   if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
+  {   // tools that run one kernel at a time (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) would leave the frames' grid
+      // waiting for a step kernel that cannot start beside it; MOOG_NO_FUSED=1 is the manual switch
+    const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
+    const char* att = getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL");
+    const char* off = getenv("MOOG_NO_FUSED");
+    if ((cc && atoi(cc)) || (att && atoi(att)) || (off && atoi(off)))
+      return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while kernels are serialised (counter collection) or MOOG_NO_FUSED is set");
+  }
   HIPCHK(hipSetDevice(e->device));
   if (!e->fused_done) {
     HIPCHK(hipMalloc(&e->fused_done, sizeof(int32_t) * (size_t)e->n_envs));
     HIPCHK(hipMemset(e->fused_done, 0, sizeof(int32_t) * (size_t)e->n_envs));
     HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
-    HIPCHK(hipMalloc(&e->fused_ticket, sizeof(uint32_t)));
-    HIPCHK(hipMemset(e->fused_ticket, 0, sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
+    HIPCHK(hipMemset(e->fused_ticket, 0, 2 * sizeof(uint32_t)));
     HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));

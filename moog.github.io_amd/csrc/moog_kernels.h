@@ -371,7 +371,12 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
     // colours / opacities / shapes; rules that modify them: done_wb) needs this XCD's L2 written back first.  That
     // write-back is kept off the common path: 4096 of them per launch cost the step kernel 30 us.
     if (direct || a.done_wb) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    else {
+      // every store of the record acknowledged before the flag goes out (a workgroup-scope fence alone emits no wait
+      // here: the flag overtook the record about once in 10^5 frames)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    }
     if (threadIdx.x == 0) __hip_atomic_store(&a.done[env], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

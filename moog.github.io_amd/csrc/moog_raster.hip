@@ -15,9 +15,9 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs 
   const int n = a.n_envs;
   for (;;) {
     if (threadIdx.x == 0) {
-      const unsigned b = atomicAdd(f.ticket, 1u) - f.base;
+      const unsigned b = atomicAdd(f.ticket, 1u);
       int env = -1;
-      if (b < (unsigned)n) {
+      if (b < (unsigned)n && __hip_atomic_load(&f.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)f.epoch) {
         // Positions of the launch order (descending cost) in the order they are expected to finish: the first `resident`
         // start at once and finish lightest first, the ones behind them start as those finish (about as late as two
         // light envs take), and the heaviest quarter of the first round finishes last.
@@ -50,21 +50,29 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs 
 // workgroups would take LDS and wave slots before the step kernel's workgroups and push a quarter of the envs into a
 // third round.  One wavefront polls 64 envs from the light end of the first round and returns when any of them is done
 // (by then every workgroup of the first round started long ago); the follow grid is the next launch on its stream.
-__global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n) {
+__global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n, int a_o_fault) {
   const int r1 = f.resident < n ? f.resident : n;
   const int stride = r1 >= 64 * 8 ? 8 : 1;
   int pos = r1 - 1 - (int)threadIdx.x * stride;
   if (pos < 0) pos = 0;
   const int env = f.perm[pos];
-  for (int spins = 0; spins < f.spin_cap; ++spins) {
+  for (int spins = 0; spins < f.spin_cap / 8; ++spins) {
     const bool mine = __hip_atomic_load(&f.done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch;
     if (__ballot(mine) != 0ull) return;
     __builtin_amdgcn_s_sleep(64);
   }
+  // No env finished in about half a second: the step kernel is not running beside this stream (a tool that serialises
+  // kernels).  The frames of this call are not drawn and the call faults, loudly, instead of waiting frame by frame.
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&f.ticket[1], (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(f.i32 + a_o_fault, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f.fault_flag) __hip_atomic_fetch_or(f.fault_flag, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs);
+  (void)hipMemsetAsync(f.ticket, 0, sizeof(uint32_t), stream);
+  hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs, (int)a.L.o_fault);
   if (a.words > 1) hipLaunchKernelGGL(moog_raster_follow_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
   else hipLaunchKernelGGL(moog_raster_follow_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
 }

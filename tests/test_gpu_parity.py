@@ -507,12 +507,22 @@ def test_frames_follow_steps_is_result_neutral(name, n, steps):
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
 
 
-def test_frames_follow_steps_refuses_what_it_does_not_cover():
+def test_frames_follow_steps_refuses_what_it_does_not_cover(monkeypatch):
     env = make_env('aa_zoo', 8, seed=1)          # anti-aliased renderer
     assert env.enable_cost_schedule(fused=True) is False
     env.reset()
     env.step(env.random_action())
     env.close()
+    # a tool that runs one kernel at a time (rocprofv3 --pmc) would leave the frames' grid waiting for a step kernel that
+    # cannot start beside it: the engine keeps the separate launches there
+    for var in ('ROCPROF_COUNTER_COLLECTION', 'MOOG_NO_FUSED'):
+        monkeypatch.setenv(var, '1')
+        env = make_env('colliding_predators_32', 64, seed=1)
+        assert env.enable_cost_schedule(fused=True) is False
+        env.reset()
+        env.step(env.random_action())
+        env.close()
+        monkeypatch.delenv(var)
 
 
 def _simulation_env():
