@@ -116,6 +116,15 @@ __device__ __forceinline__ void wsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Fields that live in HBM (colours, opacities, shape ids, Portal bits of records too large to stage whole) are written by
+// one lane and read by the others of the SAME wavefront later in the launch: workgroup scope is all that needs (the stores
+// acknowledged before later loads issue; one compute unit, one L1).  __threadfence() -- agent scope -- writes this XCD's
+// whole L2 back and invalidates it on gfx950 (buffer_wbl2 sc1 + buffer_inv sc1), per rule, per env, per step.
+__device__ __forceinline__ void wave_global_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double f32r(double x) { return (double)(float)x; }
 __device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
 
@@ -2215,7 +2224,7 @@ __device__ inline void run_modifier(Env& e, int xmod, int s) {
     }
   }
   if (e.lane == 0) apply_light_stores(e, s, st, vx, vy, w, m, c0, c1, c2, op);
-  __threadfence();   // colours / opacity live in HBM: later rules of this launch may read them
+  wave_global_fence();   // colours / opacity live in HBM: later rules of this launch may read them
   wsync();
 }
 
@@ -2243,7 +2252,7 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
     if (e.P->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
     FLAGS(src) = 0; NV(src) = 0;
   }
-  __threadfence();
+  wave_global_fence();
   wsync();
 }
 
@@ -2345,7 +2354,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         for (int s = P->layer_slot0[l] + e.lane; s < P->layer_slot0[l] + P->layer_nslots[l]; s += 64)
           if (ALIVE(s)) apply_light_stores(e, s, st, vx, vy, w, m, c0, c1, c2, op);
       }
-      __threadfence();
+      wave_global_fence();
       wsync();
       return;
     }
@@ -2445,7 +2454,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (e.lane == 0) FLAGS(s) |= MOOG_F_ALIVE;
         wsync();
       }
-      __threadfence();   // the new sprites' colours / opacity / shape ids are in HBM
+      wave_global_fence();   // the new sprites' colours / opacity / shape ids are in HBM
       return;
     }
   }
@@ -2535,7 +2544,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (entry < 0) {
           wsync();
           if (e.lane == 0) TELE(s) = tele & ~(1 << ri);
-          __threadfence();   // the Portal bits live in HBM
+          wave_global_fence();   // the Portal bits live in HBM
           wsync();
           continue;
         }
@@ -2550,7 +2559,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         }
         set_position(e, s, PX(exs), PY(exs));
         if (e.lane == 0) TELE(s) = tele | (1 << ri);
-        __threadfence();
+        wave_global_fence();
         wsync();
       }
       break;
@@ -2571,8 +2580,8 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             double c2 = 1. - (1. - COL(agent, 2)) * R->p1;
             wsync();
             if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
-          __threadfence();
-            __threadfence();
+          wave_global_fence();
+            wave_global_fence();
             cnt = R->p2;
           }
         } else if (cnt <= 0) {
@@ -2580,7 +2589,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           double c2 = 1. - (1. - COL(agent, 2)) / R->p1;
           wsync();
           if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
-          __threadfence();
+          wave_global_fence();
           cnt = DINF;
         }
       }
@@ -2599,7 +2608,7 @@ __device__ inline void rule_reset(Env& e, int ri) {
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
-  __threadfence();
+  wave_global_fence();
   if (e.lane == 0)
     e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
@@ -3575,11 +3584,11 @@ __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
   for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; vel_unshare(e, s); }
-  __threadfence();
+  wave_global_fence();
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();
   for (int oi = 0; oi < P->n_ops; ++oi) run_genop<DYN>(e, oi);
-  __threadfence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
+  wave_global_fence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {
     for (int t = 0; t < P->n_tasks; ++t) e.f[e.L.o_task + t] = DINF;
