@@ -130,7 +130,7 @@ struct RFollow {
   int32_t epoch;           // this call's number
   const int32_t* perm;     // the step kernel's launch order (descending expected cost)
   int32_t resident;        // positions of the launch order that start with the launch (the others start as those finish)
-  uint32_t* ticket;        // [0] frames handed out in this call (zeroed on the stream before the launch),
+  uint32_t* ticket;        // [0] frames handed out in this call (zeroed by the gate kernel),
                            // [1] the number of the call the gate gave up on (no step kernel beside it: kernels serialised by a tool)
   int32_t spin_cap;        // polls (about a microsecond each) before a workgroup gives up (MOOG_FAULT_FRAME_TIMEOUT)
   int32_t* i32;            // state records (for the fault word) and the host-visible fault word

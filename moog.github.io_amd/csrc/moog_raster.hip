@@ -51,6 +51,9 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs 
 // third round.  One wavefront polls 64 envs from the light end of the first round and returns when any of them is done
 // (by then every workgroup of the first round started long ago); the follow grid is the next launch on its stream.
 __global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n, int a_o_fault) {
+  // (this call's frame counter starts at zero: done here, not by a memset -- a fill kernel needs a wave slot with more
+  //  registers than the step kernel leaves free and would sit in the queue for 300 us)
+  if (threadIdx.x == 0) __hip_atomic_store(&f.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int r1 = f.resident < n ? f.resident : n;
   const int stride = r1 >= 64 * 8 ? 8 : 1;
   int pos = r1 - 1 - (int)threadIdx.x * stride;
@@ -71,7 +74,6 @@ __global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n, 
 }
 
 void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream) {
-  (void)hipMemsetAsync(f.ticket, 0, sizeof(uint32_t), stream);
   hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs, (int)a.L.o_fault);
   if (a.words > 1) hipLaunchKernelGGL(moog_raster_follow_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
   else hipLaunchKernelGGL(moog_raster_follow_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
