@@ -105,6 +105,7 @@ class BatchedEnvironment(object):
         # False = never check.  Runs with injected uniforms / run-time sprite creation check at once.
         self.check_faults = True
         self._cost = self._perm = None
+        self._fused = False
 
     def enable_cost_schedule(self, enabled=True, fused=False):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
@@ -133,6 +134,37 @@ class BatchedEnvironment(object):
             self._cost = self._perm = None
             _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
         return self._fused
+
+    def set_fused(self, enabled):
+        """Frames follow their env's step (moog_engine_set_fused) on / off; needs the cost schedule.  Returns whether
+        the mode is in use afterwards (False when the program or the environment -- counter collection -- rules it out)."""
+        if self._perm is None:
+            enabled = False
+        with self._torch.cuda.device(self.device):
+            self._fused = self._lib.moog_engine_set_fused(self._handle, 1 if enabled else 0) == 0 and bool(enabled)
+        return self._fused
+
+    def tune_launch(self, step_fn, steps=24, settle=4):
+        """Launch-structure autotuning, to be run once the episode mix is stationary: times `steps` calls of
+        `step_fn()` (which must call self.step) with separate step / raster launches and with frames following
+        their env's step, and keeps the faster.  Whether the second pays depends on the workload: it needs a step
+        kernel that is long and heavy-tailed next to the raster work (colliding_predators_32: +4 %; a 100 us step
+        kernel or a program whose rules write record fields straight to HBM: slower).  Returns the mode kept."""
+        import time
+        torch = self._torch
+        took = {}
+        for fused in (False, True):
+            if self.set_fused(fused) != fused:
+                break
+            for _ in range(settle):
+                step_fn()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn()
+            torch.cuda.synchronize(self.device)
+            took[fused] = time.perf_counter() - t0
+        return self.set_fused(True in took and took[True] < 0.99 * took[False])
 
     # -- plumbing ---------------------------------------------------------------------
     def _stream(self):

@@ -507,6 +507,20 @@ def test_frames_follow_steps_is_result_neutral(name, n, steps):
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
 
 
+def test_tune_launch_keeps_a_working_mode():
+    """BatchedEnvironment.tune_launch times both launch structures and keeps one; without a schedule it keeps the separate launches."""
+    env = make_env('colliding_predators_32', 512, seed=2)
+    env.reset()
+    assert env.tune_launch(lambda: env.step(env.random_action()), steps=3, settle=1) is False
+    env.enable_cost_schedule()
+    kept = env.tune_launch(lambda: env.step(env.random_action()), steps=3, settle=1)
+    assert kept in (True, False) and kept == env._fused
+    out = env.step(env.random_action())
+    assert out.observation['image'].shape == (512, 64, 64, 3)
+    env.raise_faults()
+    env.close()
+
+
 def test_frames_follow_steps_refuses_what_it_does_not_cover(monkeypatch):
     env = make_env('aa_zoo', 8, seed=1)          # anti-aliased renderer
     assert env.enable_cost_schedule(fused=True) is False
