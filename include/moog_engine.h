@@ -663,8 +663,11 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
  * wait for each env's step to be stored (a per-env flag in HBM) and draw its frame: most frames are drawn on the
  * compute units the finished envs have left idle, and only the slowest env's frame follows the step kernel.  The
  * caller's stream waits for the frames before the call's outputs may be read.  One-tile frames without
- * anti-aliasing only (MOOG_E_UNSUPPORTED otherwise); calls with injected uniforms, debug settings, or whose raster
- * launch is being timed (moog_engine_set_timing) take the separate launches. */
+ * anti-aliasing only (MOOG_E_UNSUPPORTED otherwise, and while a tool runs one kernel at a time: the environment
+ * variable ROCPROF_COUNTER_COLLECTION that rocprofv3 --pmc sets, or MOOG_NO_FUSED=1); calls with injected uniforms,
+ * debug settings, or whose raster launch is being timed (moog_engine_set_timing) take the separate launches.
+ * Whether the mode pays depends on the workload (a long, heavy-tailed step kernel next to the raster work): the
+ * Python host measures it (BatchedEnvironment.tune_launch). */
 int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
 
 /* Per-kernel device timing: bits 0-7 of `enabled` are a mask over MOOG_K_* (bit k set: launches of kernel k are
