@@ -281,7 +281,7 @@ def main():
     tuned = None
     if not args.no_schedule and not args.no_fused:
         fused = env.tune_launch(one_step)
-        tuned = 'timed against the separate launches before the warm-up (24 calls each)'
+        tuned = 'timed against the separate launches before the warm-up (2 x 24 calls each, alternating)'
     for _ in range(args.warmup):
         one_step()
     # Kernels of the timed region are bracketed by HIP events on the launch stream, so the per-kernel

@@ -315,6 +315,18 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
                                               const double* vb, int nb, const float* da,
                                               const float* db) {
   // da / db: conservative 8-DOPs of a and b
+  // A polygon without a finite vertex (a sprite whose position / angle went NaN or inf) is an EMPTY path for matplotlib
+  // (PathNanRemover), and path_in_path of an empty path is vacuously true: it overlaps everything (see the oracle).
+  // (not gated on the boxes being NaN: the branch costs the step kernel 600 more SGPR spills and 8 % of its time)
+  {
+    bool fin_a = false, fin_b = false;
+    if (e.lane < na) fin_a = isfinite(va[2 * e.lane]) && isfinite(va[2 * e.lane + 1]);
+    if (e.lane < nb) fin_b = isfinite(vb[2 * e.lane]) && isfinite(vb[2 * e.lane + 1]);
+    for (int k = 64 + e.lane; k < na; k += 64) fin_a = fin_a || (isfinite(va[2 * k]) && isfinite(va[2 * k + 1]));
+    for (int k = 64 + e.lane; k < nb; k += 64) fin_b = fin_b || (isfinite(vb[2 * k]) && isfinite(vb[2 * k + 1]));
+    const bool fa = __ballot(fin_a) != 0ull, fb = __ballot(fin_b) != 0ull;
+    if (!fa || !fb) return (na + 1 >= 3 && !fb) || (nb + 1 >= 3 && !fa);
+  }
   bool ka = false, kb = false;
   if (e.lane < na) {
     int i2 = (e.lane + 1 == na) ? 0 : e.lane + 1;
@@ -390,6 +402,13 @@ __device__ inline void dop_scan(const double* v, int n, float* d) {
     double x = v[2 * k], y = v[2 * k + 1], p = x + y, m = x - y;
     l0 = fmin(l0, x); h0 = fmax(h0, x); l1 = fmin(l1, y); h1 = fmax(h1, y);
     l2 = fmin(l2, p); h2 = fmax(h2, p); l3 = fmin(l3, m); h3 = fmax(h3, m);
+  }
+  // no finite vertex at all (fmin / fmax skipped the NaNs, inf made the box infinite): the polygon overlaps everything
+  // for the reference (paths_intersect_filled), so its box must never reject a pair -- NaN compares false
+  if (!(l0 <= h0 && l1 <= h1 && h0 < DINF && l0 > -DINF && h1 < DINF && l1 > -DINF)) {
+    bool any = false;
+    for (int k = 0; k < n; ++k) any = any || (isfinite(v[2 * k]) && isfinite(v[2 * k + 1]));
+    if (!any) l0 = l1 = l2 = l3 = h0 = h1 = h2 = h3 = __builtin_nan("");
   }
   d[0] = (float)l0; d[1] = (float)l1; d[2] = (float)l2; d[3] = (float)l3;
   d[4] = (float)h0; d[5] = (float)h1; d[6] = (float)h2; d[7] = (float)h3;
