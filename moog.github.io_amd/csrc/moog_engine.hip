@@ -89,6 +89,14 @@ struct moog_engine {
   double* s_f64 = nullptr;
   int32_t* s_i32 = nullptr;
   uint8_t* s_bg = nullptr;
+  // wave rasteriser (moog_raster_wave.h): one wavefront per frame from the env's draw list (moog_drawlist.h)
+  bool wave = false;          // the program is eligible and the path is on
+  RWPlan wave_plan{};
+  size_t wave_lds = 0;
+  uint32_t* d_dl = nullptr;   // [n_envs][dl_stride] draw lists
+  int dl_stride = 0;
+  uint32_t* s_dl = nullptr;   // reference draw list of the static prefix's scratch env
+  int wave_nsl = 0;           // entries of round 0 the prefix occupies (0: the wave path does not use the cached picture)
 };
 
 static void free_engine(moog_engine* e) {
@@ -98,6 +106,8 @@ static void free_engine(moog_engine* e) {
   if (e->s_f64) hipFree(e->s_f64);
   if (e->s_i32) hipFree(e->s_i32);
   if (e->s_bg) hipFree(e->s_bg);
+  if (e->d_dl) hipFree(e->d_dl);
+  if (e->s_dl) hipFree(e->s_dl);
   if (e->aa_canvas) hipFree(e->aa_canvas);
   if (e->aa_tmp) hipFree(e->aa_tmp);
   if (e->aa_tables) hipFree(e->aa_tables);
@@ -167,6 +177,7 @@ static int validate(const moog_program_t* p) {
 static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t* inj,
                        const moog_step_out_t* out, int mode, const uint8_t* mask);
 static RArgs raster_args(moog_engine* e, uint8_t* image);
+static DLArgs drawlist_args(moog_engine* e);
 
 // Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS filter (support 3): the window of
 // output sample xx is centred on (xx + 0.5) * scale, weights are normalised in double and rounded to fixed
@@ -261,10 +272,28 @@ static int build_static_prefix(moog_engine* e) {
   RArgs r = raster_args(e, e->s_bg);
   r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
   moog_raster_launch(r, e->raster_lds, 0);
+  if (e->wave) {   // the wave rasteriser compares a frame's prefix with the reference's draw-list entries
+    if (hipMalloc(&e->s_dl, (size_t)e->dl_stride * 4) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(reference draw list) failed");
+    DLArgs d = drawlist_args(e);
+    d.dl = e->s_dl; d.n_envs = 1;
+    moog_drawlist_launch(d, 0);
+  }
   e->view = keep; e->n_envs = keep_n;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(0));
   e->n_static = ns; e->nsv = nsv;
+  if (e->wave) {   // the prefix's sprites must be alive in the reference and fill the front of round 0
+    std::vector<int32_t> q((size_t)e->L.i32_per_env);
+    HIPCHK(hipMemcpy(q.data(), e->s_i32, ib, hipMemcpyDeviceToHost));
+    int lanes = 0;
+    bool ok = true;
+    for (int sl = 0; sl < ns; ++sl) {
+      const int nv = q[e->L.o_nverts + sl];
+      ok = ok && (q[e->L.o_flags + sl] & MOOG_F_ALIVE) && nv > 0 && nv <= DL_MAX_NV;
+      lanes += nv;
+    }
+    e->wave_nsl = (ok && lanes <= 64) ? lanes : 0;
+  }
   return MOOG_OK;
 }
 
@@ -366,6 +395,28 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_lds = pl.total;
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
+  {   // wave rasteriser: eligibility and LDS plan (moog_raster_wave.h)
+    int maxv = 1;
+    for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
+    const int max_rounds = dl_max_rounds(e->L.TOTV, maxv);
+    const char* off = getenv("MOOG_RASTER_WAVE");
+    e->wave = !(off && atoi(off) == 0) && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
+              e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 &&
+              prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
+    if (e->wave) {
+      e->dl_stride = dl_stride_words(max_rounds);
+      int e_rounds = max_rounds < 5 ? max_rounds : 5;   // edge records for five rounds per pass (the headline workload's frames need 4-5)
+      int r_cap = 192;                                  // row records per pass
+      { const char* ec = getenv("MOOG_WAVE_EDGE_ROUNDS"); if (ec && atoi(ec) >= 1) e_rounds = atoi(ec); }   // tuning / tests of the multi-pass path
+      { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) r_cap = atoi(rc); }
+      if (r_cap < e->canvas_h) r_cap = e->canvas_h;   // any one polygon fits
+      if (r_cap > 8000) r_cap = 8000;                 // (row indices travel as 16 bits, 14 bits of item id share the row word)
+      raster_wave_plan(e->canvas_w, e->canvas_h, 64 * e_rounds, r_cap, e->raster_xxcap, &e->wave_plan);
+      e->wave_lds = e->wave_plan.total;
+      { const char* pad = getenv("MOOG_WAVE_LDS_PAD"); if (pad) e->wave_lds += (size_t)atoi(pad); }   // occupancy experiments
+      if (e->wave_lds > 64 * 1024 || hipMalloc(&e->d_dl, (size_t)n_envs * e->dl_stride * 4) != hipSuccess) e->wave = false;
+    }
+  }
   {
     int (*const configure[6])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
                                          moog_configure_step_t4, moog_configure_step_m3, moog_configure_step_m4};
@@ -410,6 +461,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err == hipSuccess) err = (hipError_t)moog_configure_reset_full(e->step_lds);
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
+  if (err == hipSuccess && e->wave) err = (hipError_t)moog_raster_wave_configure(e->wave_lds);
   if (err != hipSuccess) {
     free_engine(e);
     return fail(MOOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(err));
@@ -506,6 +558,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.dbg = e->step_dbg;
   a.fault_flag = e->fault_flag;
   a.done = nullptr; a.epoch = 0; a.done_wb = 0;
+  a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h;
   return a;
 }
 
@@ -534,7 +587,39 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   return r;
 }
 
-static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1) {
+static DLArgs drawlist_args(moog_engine* e) {
+  DLArgs d;
+  d.P = e->d_prog; d.L = e->L; d.f64 = e->view.f64; d.i32 = e->view.i32; d.vslot = e->d_vslot;
+  d.dl = e->d_dl; d.dl_stride = e->dl_stride; d.n_envs = e->n_envs; d.cw = e->canvas_w; d.ch = e->canvas_h;
+  return d;
+}
+
+static RWArgs raster_wave_args(moog_engine* e, uint8_t* image) {
+  RWArgs r;
+  r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
+  r.dl = e->d_dl; r.dl_stride = e->dl_stride; r.n_envs = e->n_envs; r.W = e->canvas_w; r.H = e->canvas_h;
+  r.debug_stop = e->raster_stop; r.xxcap = e->raster_xxcap; r.plan = e->wave_plan;
+  const bool pre = e->n_static > 0 && e->wave_nsl > 0 && e->s_dl;
+  r.n_static = pre ? e->n_static : 0; r.nsl = pre ? e->wave_nsl : 0;
+  r.sref_dl = e->s_dl;
+  r.sref_col = e->s_f64 ? e->s_f64 + e->L.o_color : nullptr;
+  r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
+  r.sbg = e->s_bg;
+  r.perm = nullptr;
+  return r;
+}
+
+// have_dl: the step kernel of this call emitted the draw lists; otherwise they are built from the records first
+static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1, bool have_dl = false) {
+  if (e->wave) {
+    if (!have_dl) moog_drawlist_launch(drawlist_args(e), s);
+    {
+      Bracket br(e, MOOG_K_RASTER, s, timed);
+      moog_raster_wave_launch(raster_wave_args(e, image), e->wave_lds, s);
+    }
+    HIPCHK(hipGetLastError());
+    return MOOG_OK;
+  }
   RArgs r = raster_args(e, image);
   Bracket br(e, MOOG_K_RASTER, s, timed);
   if (e->aa <= 1) {
@@ -625,6 +710,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
     return MOOG_OK;
   }
+  const bool emit = e->wave && out && out->image;
+  if (emit) a.dl = e->d_dl;
   {
     Bracket br(e, MOOG_K_STEP, s);
     launch_step(e, s, a);
@@ -638,7 +725,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
   }
-  if (out && out->image) return launch_raster(e, out->image, s, time_raster);
+  if (out && out->image) return launch_raster(e, out->image, s, time_raster, emit);
   return MOOG_OK;
 }
 

@@ -3,6 +3,7 @@
 // the host side (moog_engine.hip), which only sees the launch functions declared at the bottom.
 #pragma once
 #include "moog_device.h"
+#include "moog_drawlist.h"
 
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
@@ -138,9 +139,22 @@ struct KArgs {
   int32_t* done;         // moog_engine_set_fused: per env, the number of the last call whose step has been stored (or null)
   int32_t epoch;         // this call's number
   int32_t done_wb;       // 1: rules may write record fields straight to HBM -- always write this XCD's L2 back before the flag
+  uint32_t* dl;          // draw lists for the wave rasteriser (moog_drawlist.h), emitted when the record is stored (or null)
+  int32_t dl_stride;     // words per env
+  int32_t dl_cw, dl_ch;  // canvas size
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
+
+// The env's draw list (moog_drawlist.h), from the record in LDS, once the step / reset is complete.  The broad-phase
+// candidate list and the edge-index scratch (contiguous: 96 words) are dead by then and serve as the scratch table.
+__device__ __forceinline__ void emit_drawlist(const Env& e, const KArgs& a, int env) {
+  if (!a.dl) return;
+  wsync();
+  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, e.L.S, e.L.TOTV, e.q + e.L.o_flags, e.q + e.L.o_nverts,
+                       e.f + e.L.o_verts, e.voff, e.vslot, a.dl_cw, a.dl_ch, e.lane, reinterpret_cast<uint32_t*>(e.cand));
+}
+
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
@@ -299,6 +313,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
 #endif
     }
     store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
+    emit_drawlist(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
     return true;
   }
@@ -349,6 +364,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
   store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
+  emit_drawlist(e, a, env);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);

@@ -1,6 +1,7 @@
 // moog_raster.hip -- the rasteriser kernel (see moog_raster.h for the design), its own
 // translation unit so that it builds independently of the step / reset kernels.
 #include "moog_raster_kernel.h"
+#include "moog_raster_wave.h"
 
 template <int WORDS>
 __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS>(a, (int)blockIdx.x, -1); }
@@ -98,6 +99,50 @@ void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
   if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, grid, dim3(R_THREADS), lds_bytes, stream, a);
   else hipLaunchKernelGGL(moog_raster_kernel<1>, grid, dim3(R_THREADS), lds_bytes, stream, a);
+}
+
+// ---- the wave rasteriser: one wavefront per frame (moog_raster_wave.h) ---------------------------------------------
+template <int WORDS>
+__global__ __launch_bounds__(RW_THREADS, 5) void moog_raster_wave_kernel(RWArgs a) {
+  int env = (int)blockIdx.x;
+  if (env >= a.n_envs) return;
+  if (a.perm) env = a.perm[env];
+  raster_wave<WORDS>(a, env);
+}
+
+// Draw lists from state records in HBM (frames of states the step kernel did not produce): one wavefront per env.
+__global__ __launch_bounds__(64) void moog_drawlist_kernel(DLArgs a) {
+  __shared__ uint32_t tbl[DL_SCRATCH_WORDS];
+  __shared__ int32_t voff[RW_MAX_ITEMS];
+  const int env = (int)blockIdx.x;
+  if (env >= a.n_envs) return;
+  PProg P = as_const_prog(a.P);
+  const int lane = (int)threadIdx.x;
+  if (lane < a.L.S) voff[lane] = P->slot_voff[lane];
+  __syncthreads();
+  const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
+  const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
+  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, a.L.S, a.L.TOTV, gq + a.L.o_flags, gq + a.L.o_nverts, gf + a.L.o_verts,
+                       voff, a.vslot, a.cw, a.ch, lane, tbl);
+}
+
+void moog_drawlist_launch(const DLArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(moog_drawlist_kernel, dim3((unsigned)a.n_envs), dim3(64), 0, stream, a);
+}
+
+int moog_raster_wave_configure(size_t lds_bytes) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_wave_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_wave_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  return (int)err;
+}
+
+void moog_raster_wave_launch(const RWArgs& a, size_t lds_bytes, hipStream_t stream) {
+  const dim3 grid((unsigned)a.n_envs);
+  if (a.W > 64) hipLaunchKernelGGL(moog_raster_wave_kernel<2>, grid, dim3(RW_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(moog_raster_wave_kernel<1>, grid, dim3(RW_THREADS), lds_bytes, stream, a);
 }
 
 // ---- Image.resize(size, resample=LANCZOS) (pil_renderer.py:112; Pillow Resample.c, 8 bits per channel): a horizontal

@@ -1273,3 +1273,41 @@ def test_anti_aliasing_sweep(size, aa):
         assert img.shape == (n, size[1], size[0], 3)
         assert np.array_equal(img, o.render()), 'frames differ at step %d' % k
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,rows,edge_rounds', [
+    ('colliding_predators_32', None, None), ('colliding_predators_32', 64, None), ('colliding_predators_32', None, 1),
+    ('colliding_predators_32', 64, 1), ('pong', None, None), ('colliding_predators', None, None),
+    ('falling_balls', None, 1), ('rules_zoo', 64, None), ('lambda_zoo', None, None)])
+def test_wave_rasteriser_matches_workgroup_rasteriser(name, rows, edge_rounds, monkeypatch):
+    """Programs with one-tile frames, no polygon modifier, <= 64 slots and <= 32 vertices per sprite are drawn by the
+    wave rasteriser (one wavefront per frame, from the draw list the step kernel emits); MOOG_RASTER_WAVE=0 selects the
+    workgroup rasteriser.  Both must give the same frames, bit for bit, for frames that come with a step (draw list
+    from the step kernel), for frames of uploaded state (draw list built from the records) and after resets -- also
+    when the wave kernel's row / edge records are capped so that frames take several passes."""
+    import torch
+    n = 192
+    monkeypatch.setenv('MOOG_RASTER_WAVE', '0')
+    ref = make_env(name, n, seed=31, env_index0=17)
+    monkeypatch.setenv('MOOG_RASTER_WAVE', '1')
+    if rows is not None:
+        monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
+    if edge_rounds is not None:
+        monkeypatch.setenv('MOOG_WAVE_EDGE_ROUNDS', str(edge_rounds))
+    env = make_env(name, n, seed=31, env_index0=17)
+    a0 = ref.reset().observation['image'].cpu().numpy()
+    a1 = env.reset().observation['image'].cpu().numpy()
+    assert np.array_equal(a0, a1), 'frames of the reset differ'
+    rs = np.random.RandomState(4)
+    for k in range(14):
+        a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        i0 = ref.step(a).observation['image'].cpu().numpy()
+        i1 = env.step(a).observation['image'].cpu().numpy()
+        bad = np.nonzero((i0 != i1).reshape(n, -1).any(axis=1))[0]
+        assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist(), int(bad.size))
+        f0, q0 = download(ref)
+        f1, q1 = download(env)
+        assert np.array_equal(q0, q1) and np.array_equal(f0, f1, equal_nan=True)
+        o1 = env.observation()['image'].cpu().numpy()   # the same frame from the records
+        assert np.array_equal(o1, i1), 'frame from the records differs from the frame of the step'
