@@ -90,7 +90,8 @@ struct moog_engine {
   int32_t* s_i32 = nullptr;
   uint8_t* s_bg = nullptr;
   // wave rasteriser (moog_raster_wave.h): one wavefront per frame from the env's draw list (moog_drawlist.h)
-  bool wave = false;          // the program is eligible and the path is on
+  bool wave = false;          // the wave rasteriser is on (MOOG_RASTER_WAVE=1; needs draw lists)
+  bool dlist = false;         // the program's frames can be drawn from draw lists (the step kernel emits them)
   RWPlan wave_plan{};
   size_t wave_lds = 0;
   uint32_t* d_dl = nullptr;   // [n_envs][dl_stride] draw lists
@@ -272,7 +273,7 @@ static int build_static_prefix(moog_engine* e) {
   RArgs r = raster_args(e, e->s_bg);
   r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
   moog_raster_launch(r, e->raster_lds, 0);
-  if (e->wave) {   // the wave rasteriser compares a frame's prefix with the reference's draw-list entries
+  if (e->dlist) {   // the draw-list paths compare a frame's prefix with the reference's draw-list entries
     if (hipMalloc(&e->s_dl, (size_t)e->dl_stride * 4) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(reference draw list) failed");
     DLArgs d = drawlist_args(e);
     d.dl = e->s_dl; d.n_envs = 1;
@@ -282,7 +283,7 @@ static int build_static_prefix(moog_engine* e) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(0));
   e->n_static = ns; e->nsv = nsv;
-  if (e->wave) {   // the prefix's sprites must be alive in the reference and fill the front of round 0
+  if (e->dlist) {   // the prefix's sprites must be alive in the reference and fill the front of round 0
     std::vector<int32_t> q((size_t)e->L.i32_per_env);
     HIPCHK(hipMemcpy(q.data(), e->s_i32, ib, hipMemcpyDeviceToHost));
     int lanes = 0;
@@ -399,11 +400,13 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     int maxv = 1;
     for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
     const int max_rounds = dl_max_rounds(e->L.TOTV, maxv);
-    const char* off = getenv("MOOG_RASTER_WAVE");
-    e->wave = !(off && atoi(off) == 0) && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
-              e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 &&
-              prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
-    if (e->wave) {
+    const char* off = getenv("MOOG_RASTER_DL");
+    const char* wv = getenv("MOOG_RASTER_WAVE");
+    e->dlist = !(off && atoi(off) == 0) && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
+               e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 &&
+               prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
+    e->wave = e->dlist && wv && atoi(wv) == 1;
+    if (e->dlist) {
       e->dl_stride = dl_stride_words(max_rounds);
       int e_rounds = max_rounds < 5 ? max_rounds : 5;   // edge records for five rounds per pass (the headline workload's frames need 4-5)
       int r_cap = 192;                                  // row records per pass
@@ -414,7 +417,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       raster_wave_plan(e->canvas_w, e->canvas_h, 64 * e_rounds, r_cap, e->raster_xxcap, &e->wave_plan);
       e->wave_lds = e->wave_plan.total;
       { const char* pad = getenv("MOOG_WAVE_LDS_PAD"); if (pad) e->wave_lds += (size_t)atoi(pad); }   // occupancy experiments
-      if (e->wave_lds > 64 * 1024 || hipMalloc(&e->d_dl, (size_t)n_envs * e->dl_stride * 4) != hipSuccess) e->wave = false;
+      if (e->wave_lds > 64 * 1024) e->wave = false;
+      if (hipMalloc(&e->d_dl, (size_t)n_envs * e->dl_stride * 4) != hipSuccess) e->dlist = e->wave = false;
     }
   }
   {
@@ -584,6 +588,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_nv = e->s_i32 ? e->s_i32 + e->L.o_nverts : nullptr;
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
+  r.dl = nullptr; r.dl_stride = e->dl_stride; r.nsl = 0; r.sref_dl = e->s_dl;
   return r;
 }
 
@@ -621,6 +626,13 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int time
     return MOOG_OK;
   }
   RArgs r = raster_args(e, image);
+  if (e->dlist) {   // the workgroup rasteriser from the draw lists
+    if (!have_dl) moog_drawlist_launch(drawlist_args(e), s);
+    r.dl = e->d_dl;
+    const bool pre = e->n_static > 0 && e->wave_nsl > 0 && e->s_dl;
+    r.nsl = pre ? e->wave_nsl : 0;
+    if (!pre) r.n_static = 0;
+  }
   Bracket br(e, MOOG_K_RASTER, s, timed);
   if (e->aa <= 1) {
     moog_raster_launch(r, e->raster_lds, s);
@@ -710,7 +722,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
     return MOOG_OK;
   }
-  const bool emit = e->wave && out && out->image;
+  const bool emit = e->dlist && out && out->image;
   if (emit) a.dl = e->d_dl;
   {
     Bracket br(e, MOOG_K_STEP, s);

@@ -81,6 +81,11 @@ struct RArgs {
   const int32_t* sref_nv;
   const int32_t* sref_opa;
   const uint8_t* sbg;       // background + prefix, [H][W][3] in output (flipped) order
+  // draw lists (moog_drawlist.h): when set, the vertices come from the env's list instead of the f64 record
+  const uint32_t* dl;
+  int32_t dl_stride;        // words per env
+  int32_t nsl;              // entries of the reference list that the static prefix occupies (0: the list path does not use the cached picture)
+  const uint32_t* sref_dl;  // reference draw list of the static prefix's scratch env
 };
 
 // Edge record, 16 bytes, one per vertex slot (the edge from vertex k to k + 1).

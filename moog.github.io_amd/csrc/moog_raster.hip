@@ -3,8 +3,8 @@
 #include "moog_raster_kernel.h"
 #include "moog_raster_wave.h"
 
-template <int WORDS>
-__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS>(a, (int)blockIdx.x, -1); }
+template <int WORDS, bool DL>
+__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS, DL>(a, (int)blockIdx.x, -1); }
 
 
 // Frames follow their env's step (RFollow in moog_raster.h).
@@ -81,10 +81,16 @@ void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups,
 }
 
 int moog_raster_configure(size_t lds_bytes) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2>),
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_follow_kernel<1>),
@@ -97,8 +103,13 @@ int moog_raster_configure(size_t lds_bytes) {
 
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
-  if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, grid, dim3(R_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(moog_raster_kernel<1>, grid, dim3(R_THREADS), lds_bytes, stream, a);
+  if (a.dl) {
+    if (a.words > 1) hipLaunchKernelGGL((moog_raster_kernel<2, true>), grid, dim3(R_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((moog_raster_kernel<1, true>), grid, dim3(R_THREADS), lds_bytes, stream, a);
+    return;
+  }
+  if (a.words > 1) hipLaunchKernelGGL((moog_raster_kernel<2, false>), grid, dim3(R_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL((moog_raster_kernel<1, false>), grid, dim3(R_THREADS), lds_bytes, stream, a);
 }
 
 // ---- the wave rasteriser: one wavefront per frame (moog_raster_wave.h) ---------------------------------------------

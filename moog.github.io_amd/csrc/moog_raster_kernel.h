@@ -4,6 +4,7 @@
 #define MOOG_RASTER_KERNEL_H_
 #include "moog_device.h"
 #include "moog_raster.h"
+#include "moog_drawlist.h"
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
@@ -496,7 +497,9 @@ __device__ __noinline__ void r_next_pass(RRow* rows, int cap_rows, int* misc, in
 
 // block = index of the workgroup among the launch's raster workgroups; env_of_block >= 0 names the env of a
 // one-tile frame directly (the fused launch renders envs in its own order)
-template <int WORDS>
+// DL: the vertices come from the env's draw list (moog_drawlist.h: live vertices only, already integer canvas points)
+// instead of the f64 record -- one-tile frames without a polygon modifier, <= 64 slots (moog_engine.hip decides).
+template <int WORDS, bool DL = false>
 __device__ __forceinline__ void raster_block(const RArgs& a, const int block, const int env_of_block) {
   // one workgroup = one tile (<= 128 columns x band_h rows) of one env's frame; frames up to 128 x 128 are one tile
   const int tiles = a.tiles_x * a.bands;
@@ -548,7 +551,17 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   // phase 1's first loads go out before the tables are cleared (HBM latency under the clearing)
   unsigned vi_next = 0u;
   double2 v_next = make_double2(0.0, 0.0);
-  if (tid < TOTV) {
+  const uint32_t* dl = DL ? a.dl + (size_t)env * a.dl_stride : nullptr;
+  const int n_entries = DL ? 64 * uni((int)dl[0]) : 0;   // rounds of 64 entries; a round's byte at dl + 4 says how many are used
+  uint2 en_next = make_uint2(0u, 0u);
+  auto load_entry = [&](int ie) -> uint2 {
+    uint2 en = make_uint2(0u, 0u);   // (w1 == 0 never occurs for a used entry: nv >= 1)
+    if (ie < n_entries && (ie & 63) < (int)reinterpret_cast<const uint8_t*>(dl + 4)[ie >> 6])
+      en = *reinterpret_cast<const uint2*>(dl + DL_HDR + 2 * ie);
+    return en;
+  };
+  if (DL) en_next = load_entry(tid);
+  else if (tid < TOTV) {
     vi_next = a.vinfo[tid];
     v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * tid);
   }
@@ -567,11 +580,20 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   // per-sprite colour (the last wave: it has the fewest vertices to convert)
   for (int s = tid - (R_THREADS - 64); s >= 0 && s < S; s += 64) {
     // (every load of the slot goes out at once: one trip to HBM, not one per dependent step)
-    const int flags = gq[a.L.o_flags + s], nvs = gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
+    // (DL: a slot is alive when the draw list has an item for it; its vertex count comes with its first entry)
+    const unsigned s2i = DL ? (unsigned)reinterpret_cast<const uint8_t*>(dl + 12)[s] : 0u;
+    const int flags = DL ? (s2i != 255u ? MOOG_F_ALIVE : 0) : gq[a.L.o_flags + s];
+    const int nvs = DL ? 0 : gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
     const double* col = gf + a.L.o_color + 3 * s;
     const double c0 = col[0], c1 = col[1], c2 = col[2];
     const bool alive = (flags & MOOG_F_ALIVE) != 0 && !(a.build && s >= a.n_static);
-    if (s < NS) {
+    if (DL && s < NS) {
+      const double* rc = a.sref_col + 3 * s;
+      st_bad = st_bad || s2i != (unsigned)s || opa != a.sref_opa[s] ||
+               __double_as_longlong(c0) != __double_as_longlong(rc[0]) ||
+               __double_as_longlong(c1) != __double_as_longlong(rc[1]) ||
+               __double_as_longlong(c2) != __double_as_longlong(rc[2]);
+    } else if (s < NS) {
       const double* rc = a.sref_col + 3 * s;
       st_bad = st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
                __double_as_longlong(c0) != __double_as_longlong(rc[0]) ||
@@ -617,6 +639,25 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   unsigned vi_keep0 = 0u, vi_keep1 = 0u;   // the first two rounds' table entries, reused by phase 2
+  if (DL) {   // entries of the draw list: packed points into the slot's vertex area, item row ranges, vertex counts
+    for (int ie = tid; ie < n_entries; ie += R_THREADS) {
+      const uint2 en = en_next;
+      en_next = load_entry(ie + R_THREADS);
+      const unsigned vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u;   // slot | k << 8 | used
+      if (ie == tid) vi_keep0 = vi; else if (ie == tid + R_THREADS) vi_keep1 = vi;
+      if (NS > 0 && ie < a.nsl) {   // the prefix's entries against the reference's
+        const uint2 ref = *reinterpret_cast<const uint2*>(a.sref_dl + DL_HDR + 2 * ie);
+        st_bad = st_bad || ref.x != en.x || ref.y != en.y;
+      }
+      if (!en.y) continue;
+      const int s = (int)(en.y >> 24), k = (int)((en.y >> 8) & 255u);
+      const int y = (short)(en.x >> 16);
+      reinterpret_cast<unsigned*>(ivert)[(pbase[s] & 0xfffff) + k] = en.x;
+      atomicMin(&item_y[2 * s], y);
+      atomicMax(&item_y[2 * s + 1], y);
+      if (k == 0) atomicOr(reinterpret_cast<unsigned*>(&pbase[s]), ((en.y >> 16) & 255u) << 20);
+    }
+  } else
   for (int idx = tid; idx < TOTV; idx += R_THREADS) {
     const unsigned vi = vi_next;
     const double2 v = v_next;
@@ -653,11 +694,16 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   // ---- 2b: the edge leaving every vertex (ImagingDrawPolygon: add_edge + merge of
   //          horizontal runs); table edges and horizontal heads join the compact list
   for (int c = 0; c < ncopy; ++c) {
-    for (int base0 = 0; base0 < TOTV; base0 += R_THREADS) {
-      const int idx = base0 + tid;
+    for (int base0 = 0; base0 < (DL ? n_entries : TOTV); base0 += R_THREADS) {
+      int idx = base0 + tid;
       int kind = 0;   // 1 table edge, 2 horizontal head
+      unsigned vi = 0u;
+      if (DL) {
+        vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : 0u);
+        if (base0 >= 2 * R_THREADS) { const uint2 en = load_entry(idx); vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u; }
+        idx = (vi >> 31) ? (pbase[vi & 0xffu] & 0xfffff) + (int)((vi >> 8) & 0xffu) : TOTV;   // the vertex slot of the entry
+      } else if (idx < TOTV) vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx]);
       if (idx < TOTV) {
-        const unsigned vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx]);
         int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
         int nv = pbase[s] >> 20;
         if (k < nv && s >= s_lo) {
@@ -707,8 +753,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
         if (lane == 0) pos0 = atomicAdd(&misc[0], __popcll(m));
         pos0 = __shfl(pos0, 0);
         if (kind) list[pos0 + __popcll(m & ((1ull << lane) - 1ull))] =
-            ((base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx])) & 0xffffu) | ((unsigned)c << 16) |
-            (kind == 2 ? 0x80000000u : 0u);
+            (vi & 0xffffu) | ((unsigned)c << 16) | (kind == 2 ? 0x80000000u : 0u);
       }
     }
   }

@@ -1276,21 +1276,25 @@ def test_anti_aliasing_sweep(size, aa):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['list', 'wave'])
 @pytest.mark.parametrize('name,rows,edge_rounds', [
     ('colliding_predators_32', None, None), ('colliding_predators_32', 64, None), ('colliding_predators_32', None, 1),
     ('colliding_predators_32', 64, 1), ('pong', None, None), ('colliding_predators', None, None),
     ('falling_balls', None, 1), ('rules_zoo', 64, None), ('lambda_zoo', None, None)])
-def test_wave_rasteriser_matches_workgroup_rasteriser(name, rows, edge_rounds, monkeypatch):
-    """Programs with one-tile frames, no polygon modifier, <= 64 slots and <= 32 vertices per sprite are drawn by the
-    wave rasteriser (one wavefront per frame, from the draw list the step kernel emits); MOOG_RASTER_WAVE=0 selects the
-    workgroup rasteriser.  Both must give the same frames, bit for bit, for frames that come with a step (draw list
-    from the step kernel), for frames of uploaded state (draw list built from the records) and after resets -- also
-    when the wave kernel's row / edge records are capped so that frames take several passes."""
+def test_draw_list_rasterisers_match_the_record_rasteriser(name, rows, edge_rounds, mode, monkeypatch):
+    """Programs with one-tile frames, no polygon modifier, <= 64 slots and <= 32 vertices per sprite are drawn from DRAW
+    LISTS (live vertices as packed integer canvas points, emitted by the step kernel when it stores the record; built by
+    moog_drawlist_kernel for frames of uploaded state / after a reset): by the workgroup rasteriser ('list', the default)
+    or by the wave rasteriser ('wave', MOOG_RASTER_WAVE=1: two wavefronts per frame).  MOOG_RASTER_DL=0 selects the
+    rasteriser that reads the f64 records.  All three must give the same frames, bit for bit -- frames that come with a
+    step, frames of uploaded state, frames after resets -- also when the row / edge records are capped so that frames
+    take several passes."""
     import torch
     n = 192
-    monkeypatch.setenv('MOOG_RASTER_WAVE', '0')
+    monkeypatch.setenv('MOOG_RASTER_DL', '0')
     ref = make_env(name, n, seed=31, env_index0=17)
-    monkeypatch.setenv('MOOG_RASTER_WAVE', '1')
+    monkeypatch.setenv('MOOG_RASTER_DL', '1')
+    monkeypatch.setenv('MOOG_RASTER_WAVE', '1' if mode == 'wave' else '0')
     if rows is not None:
         monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
     if edge_rounds is not None:
