@@ -1315,3 +1315,48 @@ def test_draw_list_rasterisers_match_the_record_rasteriser(name, rows, edge_roun
         assert np.array_equal(q0, q1) and np.array_equal(f0, f1, equal_nan=True)
         o1 = env.observation()['image'].cpu().numpy()   # the same frame from the records
         assert np.array_equal(o1, i1), 'frame from the records differs from the frame of the step'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,n,pre,steps', [('falling_balls_64', 1024, 30, 12), ('colliding_predators_32', 512, 5, 10)])
+def test_sprites_without_a_finite_vertex(name, n, pre, steps):
+    """A sprite whose position went NaN has no finite vertex: for the reference it overlaps every sprite (matplotlib's empty
+    path) while a collision with it changes nothing.  The engine leaves such pairs out of the collision candidates
+    (moog_device.h broad_pair); the oracle runs the reference's full path.  Non-finite sprites are planted in every third env
+    (a ball / predator with NaN position and vertices; in some envs two of them), then engine and oracle run in lock step:
+    integer records exact, floats <= 1e-9 (NaN where the oracle has NaN), rewards / step types exact, frames bit-exact."""
+    env = make_env(name, n, seed=77, env_index0=5)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=77, env_index0=5)
+    env.reset()
+    rs = np.random.RandomState(3)
+    act = (lambda: rs.randint(0, 5, size=n)) if env._is_grid else (lambda: rs.uniform(-1, 1, size=(n, 2)))
+    for _ in range(pre):
+        env.step(act())
+    f, q = download(env)
+    L, P = env.layout, env.compiled.program
+    planted = 0
+    for i in range(0, n, 3):
+        alive = [s for s in range(4, L.S) if q[i, L.o_flags + s] & 1]
+        for s in rs.choice(alive, size=min(len(alive), 1 + (i // 3) % 2), replace=False):
+            f[i, L.o_pos + 2 * s:L.o_pos + 2 * s + 2] = np.nan
+            v0 = L.o_verts + 2 * P.slot_voff[s]
+            f[i, v0:v0 + 2 * int(q[i, L.o_nverts + s])] = np.nan
+            planted += 1
+    assert planted > n // 4
+    upload(env, f, q)
+    o.f64[:], o.i32[:] = f, q
+    for k in range(steps):
+        a = act()
+        out = env.step(a)
+        o.step(a, render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+        assert np.array_equal(np.isnan(f), np.isnan(o.f64)), 'NaN pattern differs at step %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.where((f == o.f64) | (np.isnan(f) & np.isnan(o.f64)), 0, np.abs(f - o.f64))
+        assert float(np.max(err)) <= 1e-9, (k, float(np.max(err)))
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+        o.f64[:], o.i32[:] = f, q
+        assert np.array_equal(out.observation['image'].cpu().numpy(), o.render()), 'frames differ at step %d' % k
+    env.close()
