@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 23
+#define MOOG_ABI_VERSION 24
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -77,7 +77,8 @@ extern "C" {
 /* MazePhysics: an avatar is on no grid line of the maze (maze_physics.py:87-97 raises ValueError) */
 #define MOOG_FAULT_OFF_GRID 256
 /* moog_engine_set_fused: a frame's workgroup gave up waiting for its env's step (engine error) */
-#define MOOG_FAULT_FRAME_TIMEOUT 512
+#define MOOG_FAULT_FRAME_TIMEOUT 512   /* (no longer raised: a frame that gives up waiting is drawn by the fallback launch) */
+#define MOOG_FAULT_FRAME_MISMATCH 1024 /* MOOG_FUSED_SELFCHECK: a call's frames differ from the ordinary launch's */
 #define MOOG_MAX_MAZE 32
 #define MOOG_MAX_MAZE_POINTS 8 /* cells of one sample_distinct_open_points() call */
 #define MOOG_MAX_MAZE_GEN 16   /* size of a maze drawn on the device (its frontier list holds size^2 one-byte cells) */
@@ -667,8 +668,15 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
  * variable ROCPROF_COUNTER_COLLECTION that rocprofv3 --pmc sets, or MOOG_NO_FUSED=1); calls with injected uniforms,
  * debug settings, or whose raster launch is being timed (moog_engine_set_timing) take the separate launches.
  * Whether the mode pays depends on the workload (a long, heavy-tailed step kernel next to the raster work): the
- * Python host measures it (BatchedEnvironment.tune_launch). */
+ * Python host measures it (BatchedEnvironment.tune_launch).
+ * The mode needs the step kernel to run BESIDE the frames' grid, which HIP does not promise.  It is refused while the
+ * runtime is told to serialise kernels (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, GPU_MAX_HW_QUEUES=1); if kernels are
+ * serialised by something the engine cannot see, the grid gives up after about half a second WITHOUT drawing anything
+ * it is not sure of, a fallback launch behind the step kernel draws that call's whole batch, and the engine leaves the
+ * mode at the next call (one line on stderr): a degraded call is slow, never wrong, never an error.
+ * moog_engine_get_fused reports whether the mode is (still) in use. */
 int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
+int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled);
 
 /* Per-kernel device timing: bits 0-7 of `enabled` are a mask over MOOG_K_* (bit k set: launches of kernel k are
  * bracketed by HIP events on the launch stream; 0 disables), bits 8-15 hold period - 1: every period-th launch of

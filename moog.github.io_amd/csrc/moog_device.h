@@ -82,6 +82,8 @@ struct Env {
   long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
 #endif
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
+  int wrote_direct;        // sticky, per lane: this call stored a colour / opacity / shape id / Portal bit (fields that may
+                           // live in HBM, written with ordinary stores): the frame's hand-over needs an L2 write-back
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -91,14 +93,20 @@ struct Env {
 #define ANG(s) (e.f[e.L.o_angle + (s)])
 #define ANGV(s) (e.f[e.L.o_angvel + (s)])
 #define MASS(s) (e.f[e.L.o_mass + (s)])
-#define COL(s, c) (e.gcol[3 * (s) + (c)])
+// Colours, opacities, shape ids and Portal bits are READ through COL / OPAC / SHAPEID / TELE and WRITTEN through the
+// *_SET forms only: a writer that bypassed them would not be seen by the frames-follow-steps hand-over (moog_kernels.h).
+#define COL(s, c) (static_cast<const double*>(e.gcol)[3 * (s) + (c)])
+#define COL_SET(s, c, v) (const_cast<Env&>(e).wrote_direct = 1, e.gcol[3 * (s) + (c)] = (v))
+#define OPAC_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gopa[(s)] = (v))
+#define SHAPEID_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gshape[(s)] = (v))
+#define TELE_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gtele[(s)] = (v))
 #define INER(s, c) (e.f[e.L.o_inertia + 2 * (s) + (c)])
 #define MAXR(s) (e.f[e.L.o_maxr + (s)])
 #define FLAGS(s) (e.q[e.L.o_flags + (s)])
 #define NV(s) (e.q[e.L.o_nverts + (s)])
-#define OPAC(s) (e.gopa[(s)])
-#define SHAPEID(s) (e.gshape[(s)])
-#define TELE(s) (e.gtele[(s)])
+#define OPAC(s) (static_cast<const int32_t*>(e.gopa)[(s)])
+#define SHAPEID(s) (static_cast<const int32_t*>(e.gshape)[(s)])
+#define TELE(s) (static_cast<const int32_t*>(e.gtele)[(s)])
 #define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
 #define VALIAS(s) (e.q[e.L.o_valias + (s)])
@@ -2220,11 +2228,11 @@ __device__ __forceinline__ void apply_light_stores(Env& e, int s, const XStores&
   FLAGS(s) = fl;
   int fm = sf ? FMASK(s) : 0;
   if (has(MOOG_XA_MASS)) { MASS(s) = m; fm = (fm & ~(1 << MOOG_FAC_MASS)) | ((tag(MOOG_XA_MASS) == 1) << MOOG_FAC_MASS); }
-  if (has(MOOG_XA_C0)) { COL(s, 0) = c0; fm = (fm & ~(1 << MOOG_FAC_C0)) | ((tag(MOOG_XA_C0) == 1) << MOOG_FAC_C0); }
-  if (has(MOOG_XA_C1)) { COL(s, 1) = c1; fm = (fm & ~(1 << MOOG_FAC_C1)) | ((tag(MOOG_XA_C1) == 1) << MOOG_FAC_C1); }
-  if (has(MOOG_XA_C2)) { COL(s, 2) = c2; fm = (fm & ~(1 << MOOG_FAC_C2)) | ((tag(MOOG_XA_C2) == 1) << MOOG_FAC_C2); }
+  if (has(MOOG_XA_C0)) { COL_SET(s, 0, c0); fm = (fm & ~(1 << MOOG_FAC_C0)) | ((tag(MOOG_XA_C0) == 1) << MOOG_FAC_C0); }
+  if (has(MOOG_XA_C1)) { COL_SET(s, 1, c1); fm = (fm & ~(1 << MOOG_FAC_C1)) | ((tag(MOOG_XA_C1) == 1) << MOOG_FAC_C1); }
+  if (has(MOOG_XA_C2)) { COL_SET(s, 2, c2); fm = (fm & ~(1 << MOOG_FAC_C2)) | ((tag(MOOG_XA_C2) == 1) << MOOG_FAC_C2); }
   if (sf) FMASK(s) = fm;
-  if (has(MOOG_XA_OPACITY)) OPAC(s) = (int32_t)op;
+  if (has(MOOG_XA_OPACITY)) OPAC_SET(s, (int32_t)op);
 }
 
 __device__ inline void run_modifier(Env& e, int xmod, int s) {
@@ -2269,10 +2277,10 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
       e.f[L.o_vel + 2 * dst + c] = e.f[L.o_vel + 2 * src + c];
       e.f[L.o_inertia + 2 * dst + c] = e.f[L.o_inertia + 2 * src + c];
     }
-    for (int c = 0; c < 3; ++c) COL(dst, c) = COL(src, c);
+    for (int c = 0; c < 3; ++c) COL_SET(dst, c, COL(src, c));
     ANG(dst) = ANG(src); ANGV(dst) = ANGV(src); MASS(dst) = MASS(src); MAXR(dst) = MAXR(src);
-    FLAGS(dst) = FLAGS(src); NV(dst) = NV(src); OPAC(dst) = OPAC(src); SHAPEID(dst) = SHAPEID(src);
-    TELE(dst) = TELE(src);
+    FLAGS(dst) = FLAGS(src); NV(dst) = NV(src); OPAC_SET(dst, OPAC(src)); SHAPEID_SET(dst, SHAPEID(src));
+    TELE_SET(dst, TELE(src));
     if (e.P->vel_alias) VALIAS(dst) = VALIAS(src);
     if (e.P->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
     FLAGS(src) = 0; NV(src) = 0;
@@ -2568,7 +2576,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         int tele = TELE(s);
         if (entry < 0) {
           wsync();
-          if (e.lane == 0) TELE(s) = tele & ~(1 << ri);
+          if (e.lane == 0) TELE_SET(s, tele & ~(1 << ri));
           wave_global_fence();   // the Portal bits live in HBM
           wsync();
           continue;
@@ -2583,7 +2591,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           ++k;
         }
         set_position(e, s, PX(exs), PY(exs));
-        if (e.lane == 0) TELE(s) = tele | (1 << ri);
+        if (e.lane == 0) TELE_SET(s, tele | (1 << ri));
         wave_global_fence();
         wsync();
       }
@@ -2604,7 +2612,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             double m = MASS(agent) * R->p0;
             double c2 = 1. - (1. - COL(agent, 2)) * R->p1;
             wsync();
-            if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+            if (e.lane == 0) { MASS(agent) = m; COL_SET(agent, 2, c2); }
           wave_global_fence();
             wave_global_fence();
             cnt = R->p2;
@@ -2613,7 +2621,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
           double m = MASS(agent) / R->p0;
           double c2 = 1. - (1. - COL(agent, 2)) / R->p1;
           wsync();
-          if (e.lane == 0) { MASS(agent) = m; COL(agent, 2) = c2; }
+          if (e.lane == 0) { MASS(agent) = m; COL_SET(agent, 2, c2); }
           wave_global_fence();
           cnt = DINF;
         }
@@ -2632,7 +2640,7 @@ __device__ inline void rule_reset(Env& e, int ri) {
   PRule R = &e.P->rules[ri];
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
-    for (int s = e.lane; s < e.P->n_slots; s += 64) TELE(s) &= ~(1 << ri);
+    for (int s = e.lane; s < e.P->n_slots; s += 64) TELE_SET(s, TELE(s) & ~(1 << ri));
   wave_global_fence();
   if (e.lane == 0)
     e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
@@ -2984,7 +2992,7 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
   for (int o = 32; o > 0; o >>= 1) r = fmax(r, shfl_d(r, e.lane ^ o));
   if (e.lane == 0) {
     NV(s) = n;
-    SHAPEID(s) = sid;
+    SHAPEID_SET(s, sid);
     MAXR(s) = r;
     INER(s, 0) = ine0 * (sx * sx);
     INER(s, 1) = ine1 * (sy * sy);
@@ -2993,9 +3001,9 @@ __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f
     VELX(s) = fac[MOOG_FAC_XVEL]; VELY(s) = fac[MOOG_FAC_YVEL];
     ANGV(s) = fac[MOOG_FAC_ANGVEL];
     MASS(s) = fac[MOOG_FAC_MASS];
-    COL(s, 0) = fac[MOOG_FAC_C0]; COL(s, 1) = fac[MOOG_FAC_C1]; COL(s, 2) = fac[MOOG_FAC_C2];
-    OPAC(s) = (int32_t)fac[MOOG_FAC_OPACITY];
-    TELE(s) = 0;
+    COL_SET(s, 0, fac[MOOG_FAC_C0]); COL_SET(s, 1, fac[MOOG_FAC_C1]); COL_SET(s, 2, fac[MOOG_FAC_C2]);
+    OPAC_SET(s, (int32_t)fac[MOOG_FAC_OPACITY]);
+    TELE_SET(s, 0);
     vel_unshare(e, s);
     int fl = 0;
     if (!computed && sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
@@ -3608,7 +3616,7 @@ template <bool DYN>
 __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
-  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE(s) = 0; vel_unshare(e, s); }
+  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s); }
   wave_global_fence();
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();

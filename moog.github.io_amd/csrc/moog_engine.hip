@@ -80,6 +80,10 @@ struct moog_engine {
   int fused_resident = 0, fused_groups = 0;
   hipStream_t fused_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_frames = nullptr;
+  uint32_t* fused_abort = nullptr;   // pinned host word: number of the call whose frames gave up waiting (0: none)
+  bool fused_force_serial = false;   // MOOG_FUSED_FORCE_SERIAL=1 (test aid): the frames' grid runs in front of the step kernel
+  int fused_selfcheck = 0, fused_calls = 0;   // MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again and compared
+  uint8_t* fused_check_img = nullptr;
   TimedKernel timed[MOOG_K_COUNT];
   int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
   int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
@@ -113,6 +117,8 @@ static void free_engine(moog_engine* e) {
   if (e->aa_tmp) hipFree(e->aa_tmp);
   if (e->aa_tables) hipFree(e->aa_tables);
   if (e->fault_flag) hipHostFree(e->fault_flag);
+  if (e->fused_abort) hipHostFree(e->fused_abort);
+  if (e->fused_check_img) hipFree(e->fused_check_img);
   delete e;
 }
 
@@ -687,6 +693,12 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
     e->sched_pending = false;
   }
+  if (e->fused && e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u) {
+    // An earlier call's frames gave up waiting for a step kernel that was not running beside them (its frames were drawn
+    // by the fallback launch): something serialises the kernels -- the separate launches are the right structure then.
+    e->fused = false;
+    fprintf(stderr, "moog: frames could not follow their env's step (kernels are being serialised); the engine uses the separate step / raster launches from now on\n");
+  }
   int time_raster = -1;
   const bool follow = e->fused && e->perm && e->cost && out && out->image && !(inject && inject->uniforms) && !e->step_dbg &&
                       !e->raster_stop;
@@ -696,21 +708,28 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     if (++e->fused_epoch == INT32_MAX) e->fused_epoch = 1;
     a.done = e->fused_done;
     a.epoch = e->fused_epoch;
-    a.done_wb = (e->prog.n_rules > 0 || e->dynamic_rules || e->maze_kernel) ? 1 : 0;
+    { const char* wb = getenv("MOOG_FUSED_ALWAYS_WB"); a.done_wb = (wb && atoi(wb)) ? 1 : 0; }   // (experiments; the kernel derives the need itself)
     RArgs r = raster_args(e, out->image);
     RFollow f;
     f.done = e->fused_done; f.epoch = e->fused_epoch; f.perm = a.perm; f.resident = e->fused_resident;
     f.ticket = e->fused_ticket; f.spin_cap = 2000000;   // a few seconds
-    f.i32 = e->view.i32; f.fault_flag = e->fault_flag;
-    HIPCHK(hipEventRecord(e->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(e->fused_stream, e->ev_fork, 0));
+    f.abort_host = e->fused_abort;
+    if (e->fused_force_serial) {   // test aid: the grid cannot see a finished env, gives up, and the fallback draws the batch
+      f.spin_cap = 4000;
+      moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, s);
+    } else {
+      HIPCHK(hipEventRecord(e->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(e->fused_stream, e->ev_fork, 0));
+    }
     {
       Bracket br(e, MOOG_K_STEP, s);
       launch_step(e, s, a);
     }
-    moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, e->fused_stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e->ev_frames, e->fused_stream));
+    if (!e->fused_force_serial) {
+      moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, e->fused_stream);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(e->ev_frames, e->fused_stream));
+    }
     HIPCHK(hipEventRecord(e->ev_step_done, s));
     HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
     // (the last frames are still reading this call's order: the sort writes the other buffer, beside them)
@@ -719,9 +738,21 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
                       e->L.i32_per_env);
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
-    HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
+    if (!e->fused_force_serial) HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
+    // behind the step kernel and the frames: draws the batch if (and only if) this call's grid gave up
+    moog_raster_fallback_launch(r, e->fused_ticket, e->fused_epoch, e->fused_groups, e->raster_lds, s);
+    if (e->fused_selfcheck > 0 && (++e->fused_calls % e->fused_selfcheck) == 0) {   // the same frames by the ordinary launch
+      const size_t bytes = (size_t)e->n_envs * e->prog.render.width * e->prog.render.height * 3;
+      if (!e->fused_check_img && hipMalloc(&e->fused_check_img, bytes) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(self-check frames) failed");
+      RArgs c = raster_args(e, e->fused_check_img);
+      moog_raster_launch(c, e->raster_lds, s);
+      moog_frames_compare_launch(out->image, e->fused_check_img, bytes, e->fault_flag, e->view.i32 + e->L.o_fault,
+                                 MOOG_FAULT_FRAME_MISMATCH, s);
+    }
+    HIPCHK(hipGetLastError());
     return MOOG_OK;
   }
+
   const bool emit = e->dlist && out && out->image;
   if (emit) a.dl = e->d_dl;
   {
@@ -789,6 +820,11 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
     const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
     const char* att = getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL");
     const char* off = getenv("MOOG_NO_FUSED");
+    const char* ser = getenv("AMD_SERIALIZE_KERNEL");
+    const char* blk = getenv("HIP_LAUNCH_BLOCKING");
+    const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+    if ((ser && atoi(ser)) || (blk && atoi(blk)) || (hwq && atoi(hwq) == 1))
+      return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while the runtime serialises kernels (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING / GPU_MAX_HW_QUEUES=1)");
     if ((cc && atoi(cc)) || (att && atoi(att)) || (off && atoi(off)))
       return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while kernels are serialised (counter collection) or MOOG_NO_FUSED is set");
   }
@@ -799,6 +835,10 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
     HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
     HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
     HIPCHK(hipMemset(e->fused_ticket, 0, 2 * sizeof(uint32_t)));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped));
+    *e->fused_abort = 0u;
+    { const char* fs = getenv("MOOG_FUSED_FORCE_SERIAL"); e->fused_force_serial = fs && atoi(fs) == 1; }
+    { const char* sc = getenv("MOOG_FUSED_SELFCHECK"); e->fused_selfcheck = sc ? atoi(sc) : 0; }
     HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
@@ -811,7 +851,15 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
     if (e->fused_groups > e->n_envs) e->fused_groups = e->n_envs;
   }
   e->perm_buf[0] = e->perm;
+  __atomic_store_n(e->fused_abort, 0u, __ATOMIC_RELAXED);
   e->fused = true;
+  return MOOG_OK;
+}
+
+int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled) {
+  if (!e || !enabled) return fail(MOOG_E_INVALID, "null argument");
+  // (a call's frames that gave up waiting switch the mode off at the next call; report that already)
+  *enabled = (e->fused && !(e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u)) ? 1 : 0;
   return MOOG_OK;
 }
 

@@ -186,6 +186,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
+  e.wrote_direct = 0;
   e.cell_tab_n = 0; e.cell_nw = 0;
 #ifdef MOOG_PROFILE
   for (int k = 0; k < 16; ++k) e.prof[k] = 0;
@@ -315,7 +316,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
     emit_drawlist(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
-    return true;
+    return true;   // (the reset path writes colours / opacities / shapes straight to HBM)
   }
 #endif
   { PROF_T0; bbox_build_all(e); PROF_ADD(e, 9); }
@@ -373,7 +374,9 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 31) - 1];
 #endif
   }
-  return false;
+  // a rule / modifier / run-time sprite creation stored a colour, opacity, shape id or Portal bit (ordinary stores, possibly
+  // to HBM): derived from the writers themselves (COL_SET ... in moog_device.h), not from a host-side list of components
+  return a.done != nullptr && __any(e.wrote_direct != 0);
 }
 
 template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)

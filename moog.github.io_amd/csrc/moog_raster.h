@@ -137,11 +137,17 @@ struct RFollow {
   int32_t resident;        // positions of the launch order that start with the launch (the others start as those finish)
   uint32_t* ticket;        // [0] frames handed out in this call (zeroed by the gate kernel),
                            // [1] the number of the call the gate gave up on (no step kernel beside it: kernels serialised by a tool)
-  int32_t spin_cap;        // polls (about a microsecond each) before a workgroup gives up (MOOG_FAULT_FRAME_TIMEOUT)
-  int32_t* i32;            // state records (for the fault word) and the host-visible fault word
-  int32_t* fault_flag;
+  int32_t spin_cap;        // polls (about a microsecond each) before a workgroup gives up
+  uint32_t* abort_host;    // host-visible word: the number of the call that gave up (the engine then leaves the mode)
 };
+// A call whose gate or a frame gave up waiting (no step kernel beside the grid: kernels serialised by something the engine
+// cannot see) is NOT lost: ticket[1] holds the call's number, the remaining workgroups leave at once, and the fallback
+// launch, which the engine enqueues behind the step kernel of every call, draws the whole batch when (and only when) it
+// finds that number -- otherwise its workgroups return after one load.
 void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream);
+void moog_raster_fallback_launch(const RArgs& a, const uint32_t* ticket, int epoch, int workgroups, size_t lds_bytes, hipStream_t stream);
+// self-check of the mode: the fault bit is raised (summary word + one env's fault word) when the two frame batches differ anywhere
+void moog_frames_compare_launch(const uint8_t* a, const uint8_t* b, size_t bytes, int32_t* fault_flag, int32_t* env_fault, int32_t bit, hipStream_t stream);
 
 // ---- the wave rasteriser (moog_raster_wave.h): one wavefront per frame, input = the env's draw list (moog_drawlist.h)
 #define RW_SLOW 1   // lanes of a wave that run the generic scanline (the crossing list aliases the wave's long-edge list)

@@ -8,6 +8,11 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { ra
 
 
 // Frames follow their env's step (RFollow in moog_raster.h).
+__device__ __forceinline__ void follow_give_up(const RFollow& f) {
+  __hip_atomic_store(&f.ticket[1], (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (f.abort_host) __hip_atomic_store(f.abort_host, (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int WORDS>
 __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs a, RFollow f) {
   // (the frame's env goes from the polling thread to the workgroup through a spare word of the plan's misc area: the
@@ -28,10 +33,12 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs 
         int spins = 0;
         while (__hip_atomic_load(&f.done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch) {
           __builtin_amdgcn_s_sleep(16);
-          if (++spins > f.spin_cap) {
-            __hip_atomic_fetch_or(f.i32 + (size_t)env * a.L.i32_per_env + a.L.o_fault, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_AGENT);
-            if (f.fault_flag) __hip_atomic_fetch_or(f.fault_flag, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          ++spins;
+          // another workgroup (or the gate) gave up: the fallback launch draws every frame of this call
+          if ((spins & 255) == 0 && __hip_atomic_load(&f.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)f.epoch) { env = -1; break; }
+          if (spins > f.spin_cap) {   // never draw a record that may still be in flight
+            follow_give_up(f);
+            env = -1;
             break;
           }
         }
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs 
 // workgroups would take LDS and wave slots before the step kernel's workgroups and push a quarter of the envs into a
 // third round.  One wavefront polls 64 envs from the light end of the first round and returns when any of them is done
 // (by then every workgroup of the first round started long ago); the follow grid is the next launch on its stream.
-__global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n, int a_o_fault) {
+__global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n) {
   // (this call's frame counter starts at zero: done here, not by a memset -- a fill kernel needs a wave slot with more
   //  registers than the step kernel leaves free and would sit in the queue for 300 us)
   if (threadIdx.x == 0) __hip_atomic_store(&f.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -65,17 +72,44 @@ __global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n, 
     if (__ballot(mine) != 0ull) return;
     __builtin_amdgcn_s_sleep(64);
   }
-  // No env finished in about half a second: the step kernel is not running beside this stream (a tool that serialises
-  // kernels).  The frames of this call are not drawn and the call faults, loudly, instead of waiting frame by frame.
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&f.ticket[1], (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_or(f.i32 + a_o_fault, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (f.fault_flag) __hip_atomic_fetch_or(f.fault_flag, MOOG_FAULT_FRAME_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // No env finished in about half a second: the step kernel is not running beside this stream (something serialises the
+  // kernels).  The follow grid leaves without drawing; the fallback launch behind the step kernel draws the batch.
+  if (threadIdx.x == 0) follow_give_up(f);
+}
+
+template <int WORDS>
+__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_fallback_kernel(RArgs a, const uint32_t* ticket, int epoch) {
+  if (__hip_atomic_load(&ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)epoch) return;
+  for (int env = (int)blockIdx.x; env < a.n_envs; env += (int)gridDim.x) {
+    raster_block<WORDS>(a, 0, env);
+    __syncthreads();
   }
 }
 
+__global__ __launch_bounds__(256) void moog_frames_compare_kernel(const uint4* a, const uint4* b, size_t n16, int32_t* fault_flag, int32_t* env_fault, int32_t bit) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+    const uint4 x = a[i], y = b[i];
+    bad = bad || x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) {
+    __hip_atomic_fetch_or(env_fault, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(fault_flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+void moog_frames_compare_launch(const uint8_t* a, const uint8_t* b, size_t bytes, int32_t* fault_flag, int32_t* env_fault, int32_t bit, hipStream_t stream) {
+  hipLaunchKernelGGL(moog_frames_compare_kernel, dim3(512), dim3(256), 0, stream, reinterpret_cast<const uint4*>(a),
+                     reinterpret_cast<const uint4*>(b), bytes / 16, fault_flag, env_fault, bit);
+}
+
+void moog_raster_fallback_launch(const RArgs& a, const uint32_t* ticket, int epoch, int workgroups, size_t lds_bytes, hipStream_t stream) {
+  if (a.words > 1) hipLaunchKernelGGL(moog_raster_fallback_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, ticket, epoch);
+  else hipLaunchKernelGGL(moog_raster_fallback_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, ticket, epoch);
+}
+
 void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs, (int)a.L.o_fault);
+  hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs);
   if (a.words > 1) hipLaunchKernelGGL(moog_raster_follow_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
   else hipLaunchKernelGGL(moog_raster_follow_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
 }
@@ -97,6 +131,12 @@ int moog_raster_configure(size_t lds_bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err == hipSuccess)
     err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_follow_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_fallback_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_fallback_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return (int)err;
 }

@@ -35,6 +35,8 @@ _FAULT_EXC = (
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
     (_abi.MOOG_FAULT_OFF_GRID, ValueError, 'Object is not on the maze grid.'),
     (_abi.MOOG_FAULT_FRAME_TIMEOUT, RuntimeError, 'fused launch: a frame gave up waiting for its env\'s step.'),
+    (_abi.MOOG_FAULT_FRAME_MISMATCH, RuntimeError,
+     'frames that followed their env\'s step differ from the ordinary raster launch (MOOG_FUSED_SELFCHECK).'),
 )
 
 
@@ -142,6 +144,15 @@ class BatchedEnvironment(object):
             enabled = False
         with self._torch.cuda.device(self.device):
             self._fused = self._lib.moog_engine_set_fused(self._handle, 1 if enabled else 0) == 0 and bool(enabled)
+        return self._fused
+
+    @property
+    def fused(self):
+        """Whether frames (still) follow their env's step: the engine leaves the mode by itself when a call's frames had
+        to be drawn by the fallback launch (kernels serialised by something it cannot see)."""
+        v = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_get_fused(self._handle, ctypes.byref(v)))
+        self._fused = bool(v.value)
         return self._fused
 
     def tune_launch(self, step_fn, steps=24, settle=4):

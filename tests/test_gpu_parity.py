@@ -539,6 +539,63 @@ def test_frames_follow_steps_refuses_what_it_does_not_cover(monkeypatch):
         monkeypatch.delenv(var)
 
 
+def test_frames_follow_steps_degrades_instead_of_faulting(monkeypatch):
+    """The mode needs the step kernel to run beside the frames' grid.  MOOG_FUSED_FORCE_SERIAL=1 puts the grid IN FRONT of
+    the step kernel on the same stream -- what a tool that serialises kernels does: the grid cannot see a finished env, gives
+    up without drawing, the fallback launch behind the step kernel draws the batch, and the engine leaves the mode at the
+    next call.  Frames and states equal the separate launches' in every call, nothing raises, the runtime's own
+    serialisation switches are refused up front."""
+    import torch
+    n = 256
+    ref = make_env('colliding_predators_32', n, seed=9)
+    ref.reset()
+    monkeypatch.setenv('MOOG_FUSED_FORCE_SERIAL', '1')
+    env = make_env('colliding_predators_32', n, seed=9)
+    assert env.enable_cost_schedule(fused=True) is True
+    env.reset()
+    assert env.fused is True
+    rs = np.random.RandomState(1)
+    for k in range(6):
+        a = rs.uniform(-1, 1, size=(n, 2))
+        i0 = ref.step(a).observation['image'].cpu().numpy()
+        i1 = env.step(a).observation['image'].cpu().numpy()
+        assert np.array_equal(i0, i1), 'frames of call %d differ' % k
+        if k >= 1:
+            assert env.fused is False   # (the first call's grid gave up: seen by the next call at the latest)
+    f0, q0 = download(ref)
+    f1, q1 = download(env)
+    assert np.array_equal(q0, q1) and np.array_equal(f0, f1, equal_nan=True)
+    env.raise_faults()
+    env.close()
+    monkeypatch.delenv('MOOG_FUSED_FORCE_SERIAL')
+    for var, val in (('AMD_SERIALIZE_KERNEL', '3'), ('HIP_LAUNCH_BLOCKING', '1'), ('GPU_MAX_HW_QUEUES', '1')):
+        monkeypatch.setenv(var, val)
+        e2 = make_env('colliding_predators_32', 64, seed=1)
+        assert e2.enable_cost_schedule(fused=True) is False
+        e2.close()
+        monkeypatch.delenv(var)
+
+
+@pytest.mark.parametrize('name', ['colliding_predators_32', 'functional_maze', 'chase_avoid_torus'])
+def test_frames_follow_steps_self_check(name, monkeypatch):
+    """MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again by the ordinary launch and compared on the device; a
+    difference raises MOOG_FAULT_FRAME_MISMATCH.  Programs whose rules write colours / Portal bits straight to HBM take part:
+    the step kernel derives the L2 write-back from the writers themselves (COL_SET ... in moog_device.h)."""
+    monkeypatch.setenv('MOOG_FUSED_SELFCHECK', '2')
+    n = 1024
+    env = make_env(name, n, seed=4)
+    if env.enable_cost_schedule(fused=True) is not True:
+        pytest.skip('the program does not take the mode')
+    env.reset()
+    for k in range(40):
+        env.step(env.random_action())
+    import torch
+    torch.cuda.synchronize()
+    env.raise_faults()
+    env._poll_faults()
+    env.close()
+
+
 def _simulation_env():
     """The environment of the reference's tests/moog/env_wrappers/test_simulation.py:32-58."""
     import collections
