@@ -134,7 +134,12 @@ __device__ __forceinline__ void wave_global_fence() {
 }
 
 __device__ __forceinline__ double f32r(double x) { return (double)(float)x; }
-__device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(x * x + y * y); }   // norms along an axis: plain sums
+// numpy as installed where the fixtures were recorded (OpenBLAS ddot accumulates with a fused multiply-add): np.dot of two
+// float64 2-vectors = fma(a1, b1, a0 * b0); np.linalg.norm of a 1-D float64 array = sqrt(x.dot(x)).  See the oracle
+// (npdot2 / npnorm in oracle/moog_oracle.c) and tests/golden/npdot.npz.
+__device__ __forceinline__ double npdot2(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+__device__ __forceinline__ double npnorm(double x, double y) { return sqrt(fma(y, y, x * x)); }
 
 // sin / cos of the small per-substep rotation angles (|th| = |angle_vel| / K, typically
 // < 0.01 rad).  For |th| < 2^-5 the Taylor series through th^9 / th^8 is accurate to
@@ -457,7 +462,7 @@ __device__ __forceinline__ bool bbox_apart(const Env& e, int s0, int s1) {
 // its rounding could matter; elsewhere the comparison of squares decides identically.
 __device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
   double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
-  double d2 = dx * dx + dy * dy, r = MAXR(s0) + MAXR(s1), r2 = r * r;
+  double d2 = fma(dy, dy, dx * dx), r = MAXR(s0) + MAXR(s1), r2 = r * r;   // (sprite.py:464: a 1-D norm)
   if (d2 > r2 * (1.0 + 1e-9) && r >= 0) return true;
   if (d2 < r2 * (1.0 - 1e-9)) return false;
   return sqrt(d2) > r;
@@ -589,7 +594,7 @@ __device__ inline bool contains_points1(const Env& e, int s, double x, double y)
 }
 // sprite.py:432-440
 __device__ inline bool contains_point(const Env& e, int s, double x, double y) {
-  if (FLAGS(s) & MOOG_F_SYM_CIRCLE) return norm2(x - PX(s), y - PY(s)) < MAXR(s);
+  if (FLAGS(s) & MOOG_F_SYM_CIRCLE) return npnorm(x - PX(s), y - PY(s)) < MAXR(s);   // sprite.py:436 (1-D)
   return point_in_poly(VERT(s), NV(s), x, y);
 }
 
@@ -895,9 +900,9 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
   int e2 = (e1 + 1 == n1) ? 0 : e1 + 1;
   double dvx = v1[2 * e2] - v1[2 * e1], dvy = v1[2 * e2 + 1] - v1[2 * e1 + 1];
   double nx = dvy, ny = -1 * dvx;
-  double nn = sqrt(nx * nx + ny * ny);
+  double nn = npnorm(nx, ny);
   out.nx = nx / nn; out.ny = ny / nn;
-  double sc = (out.sx * dvx + out.sy * dvy) / (dvx * dvx + dvy * dvy);
+  double sc = npdot2(out.sx, out.sy, dvx, dvy) / npdot2(dvx, dvy, dvx, dvy);
   out.qx = out.sx - dvx * sc;
   out.qy = out.sy - dvy * sc;
   out.status = CV_OK;
@@ -1002,9 +1007,9 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
       int e2 = (e1 + 1 == n1) ? 0 : e1 + 1;
       double dvx = v1[2 * e2] - v1[2 * e1], dvy = v1[2 * e2 + 1] - v1[2 * e1 + 1];
       double tnx = dvy, tny = -1 * dvx;
-      double nn = sqrt(tnx * tnx + tny * tny);
+      double nn = npnorm(tnx, tny);
       nx = tnx / nn; ny = tny / nn;
-      double sc = (bsx * dvx + bsy * dvy) / (dvx * dvx + dvy * dvy);
+      double sc = npdot2(bsx, bsy, dvx, dvy) / npdot2(dvx, dvy, dvx, dvy);
       qx = bsx - dvx * sc;
       qy = bsy - dvy * sc;
       st = CV_OK;
@@ -1037,7 +1042,7 @@ __device__ inline void get_collision_vectors(const Env& e, int s0, int s1, doubl
     a0x = r0.sx; a0y = r0.sy;
   }
   if (r1.status != CV_NONE) { a1x = r1.sx; a1y = r1.sy; }
-  if (norm2(a0x, a0y) > norm2(a1x, a1y)) out = r0;
+  if (npnorm(a0x, a0y) > npnorm(a1x, a1y)) out = r0;
   else out = r1;
 }
 
@@ -1045,7 +1050,7 @@ __device__ inline void get_collision_vectors(const Env& e, int s0, int s1, doubl
 __device__ inline void collide_without_update_angle_vel(Env& e, int s0, int s1, const CVec& c,
                                                         double elasticity, int symmetric) {
   double nx = c.nx, ny = c.ny;
-  double nn = sqrt(nx * nx + ny * ny);
+  double nn = npnorm(nx, ny);
   if (!(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.)) {
     wsync();
     if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_BAD_NORMAL;
@@ -1053,8 +1058,8 @@ __device__ inline void collide_without_update_angle_vel(Env& e, int s0, int s1, 
     return;
   }
   double m0 = MASS(s0), m1 = MASS(s1);
-  double d0 = VELX(s0) * nx + VELY(s0) * ny;
-  double d1 = VELX(s1) * nx + VELY(s1) * ny;
+  double d0 = npdot2(VELX(s0), VELY(s0), nx, ny);
+  double d1 = npdot2(VELX(s1), VELY(s1), nx, ny);
   double v0nx = d0 * nx, v0ny = d0 * ny, v1nx = d1 * nx, v1ny = d1 * ny;
   double cmx, cmy;
   if (symmetric) {
@@ -1074,11 +1079,11 @@ __device__ inline void collide_with_update_angle_vel(Env& e, int s0, int s1, con
   double m0 = MASS(s0), m1 = MASS(s1), w0 = ANGV(s0), w1 = ANGV(s1);
   double i0 = (0 + m0 * INER(s0, 0)) + m0 * INER(s0, 1);
   double i1 = (0 + m1 * INER(s1, 0)) + m1 * INER(s1, 1);
-  double v0 = VELX(s0) * nx + VELY(s0) * ny;
-  double v1 = VELX(s1) * nx + VELY(s1) * ny;
+  double v0 = npdot2(VELX(s0), VELY(s0), nx, ny);
+  double v1 = npdot2(VELX(s1), VELY(s1), nx, ny);
   double c0x = c.px - PX(s0), c0y = c.py - PY(s0);
   double c1x = c.px - PX(s1), c1y = c.py - PY(s1);
-  double r0 = sqrt(c0x * c0x + c0y * c0y), r1 = sqrt(c1x * c1x + c1y * c1y);
+  double r0 = npnorm(c0x, c0y), r1 = npnorm(c1x, c1y);
   double sin0 = (c0x * ny - c0y * nx) / r0, sin1 = (c1x * ny - c1y * nx) / r1;
   double S0 = r0 * sin0, S1 = r1 * sin1;
   double a = m0 + m1 + m0 * m1 * ((S0 * S0 / i0) + (S1 * S1 / i1));
@@ -1103,19 +1108,19 @@ __device__ inline void position_correction(const Env& e, double p0x, double p0y,
   int b1 = ((b0 - 1) % nB + nB) % nB;
   double q0x = vb[2 * b1], q0y = vb[2 * b1 + 1];
   double bx = vb[2 * b0] - q0x, by = vb[2 * b0 + 1] - q0y;
-  double bn = sqrt(bx * bx + by * by);
+  double bn = npnorm(bx, by);
   bx /= bn; by /= bn;
-  double sg = (PX(sB) - q0x) * bx + (PY(sB) - q0y) * by;
+  double sg = npdot2(PX(sB) - q0x, PY(sB) - q0y, bx, by);
   double sgn = isnan(sg) ? sg : (sg > 0 ? 1. : (sg < 0 ? -1. : 0.));
   double nvx = bx * -1 * sgn, nvy = by * -1 * sgn;
   int bwd = ((fwd - 1) % nA + nA) % nA;
   int parity, curi;
-  if ((va[2 * fwd] - p0x) * nvx + (va[2 * fwd + 1] - p0y) * nvy > 0) { parity = 1; curi = fwd; }
-  else if ((va[2 * bwd] - p0x) * nvx + (va[2 * bwd + 1] - p0y) * nvy > 0) { parity = -1; curi = bwd; }
+  if (npdot2(va[2 * fwd] - p0x, va[2 * fwd + 1] - p0y, nvx, nvy) > 0) { parity = 1; curi = fwd; }
+  else if (npdot2(va[2 * bwd] - p0x, va[2 * bwd + 1] - p0y, nvx, nvy) > 0) { parity = -1; curi = bwd; }
   else { out[0] = DINF; out[1] = DINF; return; }
   double worst = 0;
   for (int it = 0; it < 4 * nA; ++it) {
-    double pen = (va[2 * curi] - p0x) * nvx + (va[2 * curi + 1] - p0y) * nvy;
+    double pen = npdot2(va[2 * curi] - p0x, va[2 * curi + 1] - p0y, nvx, nvy);
     if (!(pen > 0)) break;
     if (pen > worst) worst = pen;
     curi = ((curi + parity) % nA + nA) % nA;
@@ -1173,7 +1178,7 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
   position_correction(e, bxA, byA, s0, biA / n1, s1, biA % n1, c0);
   position_correction(e, bxB, byB, s1, biB % n1, s0, biB / n1, c1);
   double cx, cy;
-  if (norm2(c0[0], c0[1]) > norm2(c1[0], c1[1])) {
+  if (npnorm(c0[0], c0[1]) > npnorm(c1[0], c1[1])) {
     cx = -1 * (1 + EPS_COLL) * c0[0]; cy = -1 * (1 + EPS_COLL) * c0[1];
   } else {
     cx = (1 + EPS_COLL) * c0[0]; cy = (1 + EPS_COLL) * c0[1];
@@ -1216,11 +1221,11 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
   if (upd) {  // collisions.py:353-454
     double i0 = (0 + m0 * INER(s0, 0)) + m0 * INER(s0, 1);
     double i1 = (0 + m1 * INER(s1, 0)) + m1 * INER(s1, 1);
-    double v0 = v0x * nx + v0y * ny;
-    double v1 = v1x * nx + v1y * ny;
+    double v0 = npdot2(v0x, v0y, nx, ny);
+    double v1 = npdot2(v1x, v1y, nx, ny);
     double c0x = c.px - n0x, c0y = c.py - n0y;
     double c1x = c.px - n1x, c1y = c.py - n1y;
-    double r0 = sqrt(c0x * c0x + c0y * c0y), r1 = sqrt(c1x * c1x + c1y * c1y);
+    double r0 = npnorm(c0x, c0y), r1 = npnorm(c1x, c1y);
     double sin0 = (c0x * ny - c0y * nx) / r0, sin1 = (c1x * ny - c1y * nx) / r1;
     double S0 = r0 * sin0, S1 = r1 * sin1;
     double a = m0 + m1 + m0 * m1 * ((S0 * S0 / i0) + (S1 * S1 / i1));
@@ -1231,10 +1236,10 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
     dw0 = m0 * dv0 * S0 / i0; dw1 = m1 * dv1 * S1 / i1;
     a0x = dv0 * nx; a0y = dv0 * ny; a1x = dv1 * nx; a1y = dv1 * ny;
   } else {    // collisions.py:292-350
-    double nn = sqrt(nx * nx + ny * ny);
+    double nn = npnorm(nx, ny);
     fault = !(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.);   // np.isclose(norm, 1., atol=1e-4) -> ValueError
-    double q0 = v0x * nx + v0y * ny;
-    double q1 = v1x * nx + v1y * ny;
+    double q0 = npdot2(v0x, v0y, nx, ny);
+    double q1 = npdot2(v1x, v1y, nx, ny);
     double v0nx = q0 * nx, v0ny = q0 * ny, v1nx = q1 * nx, v1ny = q1 * ny;
     double cmx, cmy;
     if (symmetric) {
@@ -1391,7 +1396,7 @@ __device__ inline void force_single_layer(Env& e, PForce F, int a0, int a1, int 
 
 __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K) {
   double dx = PX(s1) - PX(s0), dy = PY(s1) - PY(s0);
-  double dist = sqrt(dx * dx + dy * dy);
+  double dist = npnorm(dx, dy);
   double f0x = 0, f0y = 0, f1x = 0, f1y = 0;
   if (dist != 0.) {
     double ux = dx / dist, uy = dy / dist, mag = 0;
@@ -1473,7 +1478,7 @@ __device__ inline void tether_group(Env& e, PCorr C, int zi, int K, int group) {
         hx = (double)(0.5f * dxf); hy = (double)(0.5f * dyf);
       } else { hx = 0.5 * (VELX(s) / (double)K); hy = 0.5 * (VELY(s) / (double)K); }
       double parx = (PX(s) + hx) - cx, pary = (PY(s) + hy) - cy;
-      radius = sqrt(parx * parx + pary * pary);
+      radius = npnorm(parx, pary);
       parx = parx / radius; pary = pary / radius;
       perpx = 0.0 * parx + (-1.0) * pary; perpy = 1.0 * parx + 0.0 * pary;
     };
@@ -1484,7 +1489,7 @@ __device__ inline void tether_group(Env& e, PCorr C, int zi, int K, int group) {
       double rx, ry;
       if ((FLAGS(s) & MOOG_F_VEL_F32) && f32) { rx = (double)((float)VELX(s) - (float)tvx); ry = (double)((float)VELY(s) - (float)tvy); }
       else { rx = VELX(s) - tvx; ry = VELY(s) - tvy; }
-      double perp_vel = rx * perpx + ry * perpy;
+      double perp_vel = npdot2(rx, ry, perpx, perpy);
       double moi = 0 + MASS(s) * INER(s, 0);
       moi = moi + MASS(s) * INER(s, 1);
       double L = perp_vel * MASS(s) * radius;
@@ -1554,7 +1559,7 @@ __device__ inline void constant_speed(Env& e, PCorr C) {
           ox = (double)((sp * vx) / n); oy = (double)((sp * vy) / n); wr = true;
         }
       } else {
-        double n = sqrt(ox * ox + oy * oy);
+        double n = npnorm(ox, oy);
         if (n != 0.0) { ox = (C->speed * ox) / n; oy = (C->speed * oy) / n; wr = true; }
       }
       wsync();
@@ -1584,7 +1589,7 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
   bool cand = in && s0 != t && (fl0 & fl1 & MOOG_F_ALIVE) && !apart && !nan_box;
   if (cand) {   // circles_apart, on the values already loaded
     const double dx = p0.x - p1.x, dy = p0.y - p1.y;
-    const double d2 = dx * dx + dy * dy, r = r0 + r1, r2 = r * r;
+    const double d2 = fma(dy, dy, dx * dx), r = r0 + r1, r2 = r * r;
     bool ca;
     if (d2 > r2 * (1.0 + 1e-9) && r >= 0) ca = true;
     else if (d2 < r2 * (1.0 - 1e-9)) ca = false;
@@ -2521,7 +2526,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (ALIVE(s)) t = s;
       if (a < 0 || t < 0) break;   // (state[layer][0] of an empty layer raises IndexError in the reference)
       const double dx = PX(a) - PX(t), dy = PY(a) - PY(t);
-      const double dist = sqrt(dx * dx + dy * dy);   // np.linalg.norm
+      const double dist = npnorm(dx, dy);   // np.linalg.norm (1-D)
       const double cnt = e.f[e.L.o_rule + ri];
       wsync();
       if (e.lane == 0) e.f[e.L.o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
