@@ -159,12 +159,41 @@ def free_port():
     return port
 
 
+def visible_gpus():
+    """GPUs this process tree may use, counted WITHOUT initialising HIP in this process (the launcher parent must stay
+    clean: its children are the ones that open the devices).  First the KFD topology in sysfs -- a node with SIMDs is a
+    GPU -- filtered by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are plain index lists; if sysfs is not
+    readable, a short-lived child process asks the runtime (torch.cuda.device_count()) and prints the answer."""
+    n = None
+    try:
+        root = '/sys/class/kfd/kfd/topology/nodes'
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get('simd_count', '0')) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    if n is not None and n > 0:
+        for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+            v = os.environ.get(var)
+            if v is not None and all(t.strip().isdigit() for t in v.split(',') if t.strip()):
+                n = min(n, len([t for t in v.split(',') if t.strip()]))
+        return n
+    try:   # (a child: whatever it initialises dies with it)
+        out = subprocess.check_output([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                                      stderr=subprocess.DEVNULL, timeout=300)
+        return int(out.decode().strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError):
+        return 0
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with
-    torch.distributed.run as child processes.  This process never initialises a GPU
-    (device_count() does not), so nothing is re-executed over a live HIP context."""
-    import torch
-    have = torch.cuda.device_count()
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) with torch.distributed.run as child
+    processes.  This process never touches the HIP runtime (visible_gpus reads sysfs or asks a child), and nothing is
+    re-executed: the ranks are children, this process relays their exit code."""
+    have = visible_gpus()
     if have < args.gpus:
         sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) visible\n' % (args.gpus, have))
         return 2

@@ -130,3 +130,26 @@ def test_two_rank_engine_shards_match_single_engine():
     ret = mgr.dict()
     mp.spawn(_engine_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret.get('same') is True
+
+
+def test_bench_launcher_counts_devices_without_hip(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no launcher) starts its own ranks as child processes.  The parent counts the
+    GPUs from the KFD topology in sysfs (or asks a short-lived child), so it never initialises HIP itself, and it refuses
+    -- exit code 2, one line on stderr -- when fewer than N are visible instead of printing a line with the wrong n_gpus."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    n = bench.visible_gpus()
+    assert isinstance(n, int) and n >= 0
+    assert 'torch' not in bench.__dict__          # (the module does not import torch at load time)
+    want = n + 2
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', str(want), '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 2, (p.returncode, p.stderr[-300:])
+    assert 'only %d GPU(s) visible' % n in p.stderr
+    # a visibility list narrows the count
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0')
+    assert bench.visible_gpus() <= 1
