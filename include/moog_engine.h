@@ -265,9 +265,15 @@ enum {
   MOOG_FORCE_COLLISION,         /* collisions.py:457-584 p0 = elasticity,
                                    symmetric, i0 = update_angle_vel,
                                    i1 = max_recursion_depth                   */
-  MOOG_FORCE_MAZE_WALK          /* maze_walk.py:96-193 RandomMazeWalk: p0 = speed, i0 bit 0 prevent_backtracking,
+  MOOG_FORCE_MAZE_WALK,         /* maze_walk.py:96-193 RandomMazeWalk: p0 = speed, i0 bit 0 prevent_backtracking,
                                    bit 1 allow_wall_backtracking, bit 2 only_turn_at_wall; the maze is
                                    program.maze (Maze.from_state of the wall layer, maze.py:39-84)      */
+  MOOG_FORCE_MAZE_WALK_DET      /* maze_walk.py:203-243 DeterministicMazeWalk: p0 = speed; the prescribed velocities are
+                                   cand[i0 .. i0 + 2 * i1) (x, y pairs), read front to back each time a sprite of the
+                                   layer enters an intersection or stands still -- by whichever sprite comes next, over
+                                   the whole life of the environment (the reference never rewinds the list: reset()
+                                   only re-infers the maze): the number consumed so far is the scalar of the
+                                   MOOG_RULE_STATE_SLOT entry `symmetric` of the rule table                     */
 };
 
 typedef struct {
@@ -330,10 +336,13 @@ enum {
   MOOG_RULE_MODIFY_ON_CONTACT,     /* contact_rules.py:112-141: layers[] x layers1[];
                                       xmod / filter for side 0, xmod1 / filter1 for
                                       side 1 (xmod < 0: no modifier on that side)  */
-  MOOG_RULE_FIXATION               /* fixation.py:17-58: state = consecutive steps during which the first sprite
+  MOOG_RULE_FIXATION,              /* fixation.py:17-58: state = consecutive steps during which the first sprite
                                       of l0 has been within p0 of the first sprite of l1 (the number the
                                       reference keeps in meta_state[key]); conditions read it through
                                       MOOG_X_RULE_STATE                                                   */
+  MOOG_RULE_STATE_SLOT             /* not a rule of the reference: a per-env scalar that belongs to another component
+                                      (DeterministicMazeWalk's read position); never stepped, never reset -- it lives
+                                      as long as the environment, like the Python object it stands for    */
 };
 /* sprite filters: ALWAYS, or the expression at rule.xfilter */
 enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };

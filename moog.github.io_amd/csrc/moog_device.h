@@ -1366,6 +1366,7 @@ __device__ inline bool force_single_newvel(const Env& e, PForce F, int s, int K,
 }
 
 __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K);
+__device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K);
 
 __device__ inline void force_single(Env& e, PForce F, int s, int K) {
   if (F->kind == MOOG_FORCE_RANDOM) {
@@ -1701,6 +1702,36 @@ __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
   maze_set_velocity(e, s, vel[0], vel[1]);
 }
 
+// maze_walk.py:225-243 DeterministicMazeWalk._step_sprite (see the oracle's maze_walk_det_step): the prescribed velocities
+// are read front to back by whichever sprite asks next and never rewound; the read position is the scalar of a
+// MOOG_RULE_STATE_SLOT entry.  A prescribed velocity with a different sign pattern sets the velocity to
+// np.clip(..., -speed, -speed) = (-speed, -speed) (NaN where the sum is NaN); otherwise the velocity is left alone.
+__device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K) {
+  PProg P = e.P;
+  const double speed = F->p0, gs = 1. / P->maze.size, half = 0.5 * gs;
+  const double px = PX(s), py = PY(s);
+  const double vel[2] = {speed * np_sign(VELX(s)), speed * np_sign(VELY(s))};
+  const double nx = px + vel[0] / K, ny = py + vel[1] / K;
+  const long n0 = np_rint_l(px / gs - 0.5), n1 = np_rint_l(py / gs - 0.5);
+  const double ix = gs * n0 + half, iy = gs * n1 + half;
+  const double d_next_cur = (0 + fabs(nx - px)) + fabs(ny - py);
+  const double d_int_next = (0 + fabs(nx - ix)) + fabs(ny - iy);
+  const double d_int_cur = (0 + fabs(nx - ix)) + fabs(ny - iy);   // (measured from next_position, as in the reference)
+  const bool entering = d_next_cur > d_int_cur && d_next_cur > d_int_next;
+  if (!(entering || (vel[0] == 0. && vel[1] == 0.))) return;
+  const int slot = e.L.o_rule + uni(F->symmetric);
+  const int k = (int)e.f[slot];
+  if (k >= F->i1) return;   // `if len(self._step_velocities) > 0`
+  const double new0 = P->cand[F->i0 + 2 * k], new1 = P->cand[F->i0 + 2 * k + 1];
+  wsync();
+  if (e.lane == 0) e.f[slot] = (double)(k + 1);
+  wsync();
+  if (np_sign(new0) != np_sign(vel[0]) || np_sign(new1) != np_sign(vel[1])) {   // np.any(np.sign(new) != np.sign(velocity))
+    const double t0 = (1 - MAZE_EPS) * vel[0] + new0, t1 = (1 - MAZE_EPS) * vel[1] + new1;
+    maze_set_velocity(e, s, isnan(t0) ? t0 : -speed, isnan(t1) ? t1 : -speed);
+  }
+}
+
 // maze_physics.py:48-109 _get_position_affordances (the position itself is returned unchanged)
 __device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[2][2]) {
   PProg P = e.P;
@@ -2011,12 +2042,15 @@ __device__ inline void apply_physics(Env& e) {
       int la = uni(F->layers_a[a]);
       int a0 = uni(P->layer_slot0[la]), a1 = a0 + uni(P->layer_nslots[la]);
       if (n_b == 0) {
-        if (kind != MOOG_FORCE_RANDOM && kind != MOOG_FORCE_MAZE_WALK && !uni(P->vel_alias)) {
+        if (kind != MOOG_FORCE_RANDOM && kind != MOOG_FORCE_MAZE_WALK && kind != MOOG_FORCE_MAZE_WALK_DET && !uni(P->vel_alias)) {
           force_single_layer(e, F, a0, a1, K);
         } else {
           for (int s = a0; s < a1; ++s)
             if (ALIVE(s)) {
-              if constexpr (DYN && MOOG_WITH_MAZE) { if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; } }
+              if constexpr (DYN && MOOG_WITH_MAZE) {
+                if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; }
+                if (kind == MOOG_FORCE_MAZE_WALK_DET) { maze_walk_det_step(e, F, s, K); continue; }
+              }
               force_single(e, F, s, K);
             }
         }
@@ -2640,33 +2674,48 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
   }
 }
 
-// rule.reset() of one table entry; combinators also reset their children (rules_reset_tree)
+// rule.reset() of one table entry, without the random duration of a PHASE (rule_reset_tree draws it, in the reference's order)
 __device__ inline void rule_reset(Env& e, int ri) {
   PRule R = &e.P->rules[ri];
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
     for (int s = e.lane; s < e.P->n_slots; s += 64) TELE_SET(s, TELE(s) & ~(1 << ri));
   wave_global_fence();
-  if (e.lane == 0)
+  if (e.lane == 0 && R->kind != MOOG_RULE_STATE_SLOT)   // (a state slot lives as long as the environment)
     e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
-  if (R->kind == MOOG_RULE_PHASE && R->op == 1) {   // task_phases.py:72: the duration is drawn when the phase is reset
-    const int lo = (int)R->p0, hi = (int)R->p2;
-    int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
-    if (k >= hi - lo) k = hi - lo - 1;
-    wsync();
-    if (e.lane == 0) e.f[e.L.o_rule2 + ri] = (double)(lo + k);
-    wsync();
-  }
 }
 
-// TimedRule.reset / ConditionalRule.reset (timing.py:46-49, conditional.py:56-58): the whole
-// subtree of a top-level rule is the contiguous run of entries that follows it.
+// task_phases.py:69-75 Phase.reset: the one-time and continual rules are reset first, `self._current_duration =
+// self._duration()` comes last -- so a Phase with a random duration draws AFTER everything in its subtree has (a nested
+// random-duration Phase draws before the one that contains it).
+__device__ inline void rule_draw_duration(Env& e, int ri) {
+  PRule R = &e.P->rules[ri];
+  if (!(R->kind == MOOG_RULE_PHASE && R->op == 1)) return;
+  const int lo = (int)R->p0, hi = (int)R->p2;
+  int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
+  if (k >= hi - lo) k = hi - lo - 1;
+  wsync();
+  if (e.lane == 0) e.f[e.L.o_rule2 + ri] = (double)(lo + k);
+  wsync();
+}
+
+// TimedRule.reset / ConditionalRule.reset / Phase.reset (timing.py:46-49, conditional.py:56-58, task_phases.py:69-75): the
+// whole subtree of a top-level rule is the contiguous run of entries that follows it (pre-order).  Scalars are reset in
+// that order; a subtree's duration is drawn when its last entry has been reset (post-order), innermost first.
 __device__ inline void rule_reset_tree(Env& e, int ri) {
   PProg P = e.P;
-  rule_reset(e, ri);
-  for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) rule_reset(e, c);
+  int end = ri + 1;
+  while (end < P->n_rules && P->rules[end].parent >= ri) ++end;
+  for (int c = ri; c < end; ++c) {
+    rule_reset(e, c);
+    const int next_parent = (c + 1 < end) ? P->rules[c + 1].parent : ri - 1;   // subtrees that do not contain entry c + 1 end here
+    for (int a = c; a >= ri && a > next_parent; a = P->rules[a].parent) {
+      rule_draw_duration(e, a);
+      if (P->rules[a].parent < ri) break;
+    }
+  }
 }
 
 // all(pred(s) ...) / any(pred(s) ...) over a layer, or expr(layer[0]) (conditions traced by

@@ -463,7 +463,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       if (prog->ops[o].factors[k].kind == MOOG_DIST_EXPR || prog->ops[o].factors[k].kind == MOOG_DIST_EXPR_SHAPE)
         e->maze_kernel = true;
   // the maze components live in a kernel variant of their own (m3 / m4): their code would only enlarge the others
-  for (int f = 0; f < prog->n_forces; ++f) if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK) e->maze_kernel = true;
+  for (int f = 0; f < prog->n_forces; ++f)
+    if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET) e->maze_kernel = true;
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
   if (prog->maze.random) e->maze_kernel = true;
   if (err == hipSuccess)

@@ -501,6 +501,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     if len(physics._forces) > _abi.MOOG_MAX_FORCES:
         raise ValueError('too many forces')
     maze_layers = set()   # wall layers the maze walks / MazePhysics infer their maze from
+    det_walks = []        # DeterministicMazeWalk forces: (force record, flattened velocity table)
     for fi, entry in enumerate(physics._forces):
         force, args = entry[0], entry[1:]
         F = P.forces[fi]
@@ -536,6 +537,17 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     (int(bool(force._only_turn_at_wall)) << 2))
             maze_layers.add(force._maze_layer)
             _reject_f32_velocity(state, args[0], 'RandomMazeWalk')
+        elif isinstance(force, physics_lib.DeterministicMazeWalk):
+            F.kind, F.p0 = _abi.MOOG_FORCE_MAZE_WALK_DET, force._speed
+            table = []
+            for v in force._step_velocities:
+                v = np.asarray(v, dtype=np.float64).reshape(-1)
+                if v.shape != (2,):
+                    raise ValueError('DeterministicMazeWalk: step_velocities must be 2-vectors')
+                table += [float(v[0]), float(v[1])]
+            det_walks.append((F, table))
+            maze_layers.add(force._maze_layer)
+            _reject_f32_velocity(state, args[0], 'DeterministicMazeWalk')
         elif isinstance(force, physics_lib.Collision):
             pair = True
             F.kind = _abi.MOOG_FORCE_COLLISION
@@ -760,6 +772,21 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.xmod = put_expr(stores=mod)
             R.i0 = 8 | (2 if vec else 0)   # only the layer's first sprite
     P.n_rules = len(flat_rules)
+    # state that belongs to forces: one never-reset scalar per DeterministicMazeWalk (its read position)
+    for F, table in det_walks:
+        if P.n_rules >= _abi.MOOG_MAX_RULES:
+            raise ValueError('too many game rules (a DeterministicMazeWalk keeps its read position in a rule slot)')
+        off = int(P.n_cand)
+        if off + len(table) > _abi.MOOG_MAX_CAND:
+            raise NotImplementedError('DeterministicMazeWalk: velocity table too long (%d values, %d free)'
+                                      % (len(table), _abi.MOOG_MAX_CAND - off))
+        for k, v in enumerate(table):
+            P.cand[off + k] = v
+        P.n_cand = off + len(table)
+        F.i0, F.i1, F.symmetric = off, len(table) // 2, int(P.n_rules)
+        R = P.rules[P.n_rules]
+        R.kind, R.parent = _abi.MOOG_RULE_STATE_SLOT, -1
+        P.n_rules += 1
 
     # ---- task -----------------------------------------------------------------------
     if isinstance(task, tasks_lib.CompositeTask):

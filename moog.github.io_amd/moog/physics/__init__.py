@@ -173,6 +173,18 @@ class RandomMazeWalk(AbstractMazeWalk):
         self._only_turn_at_wall = only_turn_at_wall
 
 
+class DeterministicMazeWalk(AbstractMazeWalk):
+    """Sprites walk the maze along prescribed velocities (maze_walk.py:203-243): each time a sprite of the layer enters an
+    intersection or stands still the next element of `step_velocities` is read -- the list is shared by the sprites and is
+    never rewound, exactly as in the reference (and, as there, a prescribed velocity whose signs differ from the current
+    one's sets the velocity to (-speed, -speed): np.clip(..., -speed, -speed), maze_walk.py:240-243)."""
+
+    def __init__(self, speed, step_velocities, maze_layer='walls'):
+        super(DeterministicMazeWalk, self).__init__(speed, maze_layer=maze_layer)
+        import numpy as np
+        self._step_velocities = [np.array(v) for v in step_velocities]
+
+
 class Physics(AbstractPhysics):
     def __init__(self, *forces, updates_per_env_step=1, corrective_physics=()):
         super(Physics, self).__init__(updates_per_env_step=updates_per_env_step)

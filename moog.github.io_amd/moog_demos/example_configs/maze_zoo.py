@@ -5,7 +5,9 @@ and `RandomMazeWalk` (maze_walk.py:96-193: ghosts wander without backtracking) -
 captured from the reference (tests/golden/maze_zoo_*.npz).  Parameters follow
 moog_demos/example_configs/pacman.py:23-160 where they exist there.
 level 0: 8 x 8 maze, constant_speed (pacman's setting);  level 1: 10 x 10 maze, max_speed instead, ghosts
-that may turn back at walls."""
+that may turn back at walls;  level 2: the 8 x 8 maze with `DeterministicMazeWalk` ghosts (maze_walk.py:203-243: a list of
+prescribed velocities read front to back by whichever ghost reaches an intersection next, never rewound -- across the
+recording's resets too)."""
 import collections
 
 import numpy as np
@@ -36,8 +38,8 @@ MAZES = (
 
 
 def get_config(level):
-    maze = maze_lib.Maze(MAZES[level])
-    speed = 0.02 if level == 0 else 0.03
+    maze = maze_lib.Maze(MAZES[1 if level == 1 else 0])
+    speed = 0.03 if level == 1 else 0.02
     walls = maze.to_sprites(c0=0., c1=0., c2=0.8)
     cells = [maze.grid_side * (0.5 + np.array(p)) for p in np.argwhere(maze.maze == 0)]   # (row, column) -> (y, x)
     ghost_cells = cells[len(cells) // 2:]
@@ -52,10 +54,15 @@ def get_config(level):
         return collections.OrderedDict(
             [('walls', walls), ('prey', prey), ('ghosts', make_ghosts()), ('agent', [agent])])
 
-    walk = (physics_lib.RandomMazeWalk(speed=speed) if level == 0 else
-            physics_lib.RandomMazeWalk(speed=speed, allow_wall_backtracking=True, only_turn_at_wall=True))
+    if level == 2:   # a fixed itinerary: more entries than the recording consumes in its first episodes, fewer than in all
+        rs = np.random.RandomState(5)
+        dirs = [(speed, 0.), (0., speed), (-speed, 0.), (0., -speed), (0., 0.), (speed, speed)]
+        walk = physics_lib.DeterministicMazeWalk(speed=speed, step_velocities=[dirs[k] for k in rs.randint(0, 6, size=70)])
+    else:
+        walk = (physics_lib.RandomMazeWalk(speed=speed) if level == 0 else
+                physics_lib.RandomMazeWalk(speed=speed, allow_wall_backtracking=True, only_turn_at_wall=True))
     maze_physics = (physics_lib.MazePhysics(maze_layer='walls', avatar_layers=('agent', 'ghosts'), constant_speed=speed)
-                    if level == 0 else
+                    if level != 1 else
                     physics_lib.MazePhysics(maze_layer='walls', avatar_layers=('agent', 'ghosts'), max_speed=0.8 * speed))
     physics = physics_lib.Physics((walk, ['ghosts']), updates_per_env_step=1, corrective_physics=[maze_physics])
     task = tasks.CompositeTask(

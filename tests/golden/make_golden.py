@@ -277,8 +277,19 @@ def bookkeeping(env):
                 walk2(list(kids), out)
         return out
     rc2_flat = walk2(list(env.game_rules), [])
+    # forces that keep state of their own: DeterministicMazeWalk pops its list front to back (maze_walk.py:238-239);
+    # what the engine keeps is the number of elements consumed so far
+    fstate = []
+    for entry in getattr(env.physics, '_forces', ()):
+        f = entry[0]
+        if hasattr(f, '_step_velocities'):
+            if not hasattr(f, '_n_initial'):
+                f._n_initial = len(f._step_velocities)
+            fstate.append(float(f._n_initial - len(f._step_velocities)))
+        else:
+            fstate.append(np.nan)
     return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
-                action_mem=action_memory(env.action_space),
+                action_mem=action_memory(env.action_space), force_state=np.array(fstate, dtype=float),
                 task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
                 rule_counters_flat=np.array(rc_flat, dtype=float),
                 rule_counters2_flat=np.array(rc2_flat, dtype=float))
@@ -713,6 +724,7 @@ def main():
         ('rules_zoo_l2', 90, {'prey': 8, '__dynamic__': ('prey',)}, (0,)),
         ('maze_zoo', 120, {}, (0, 1)),
         ('maze_zoo_l1', 120, {}, (0,)),
+        ('maze_zoo_l2', 160, {}, (0, 1)),
         ('pacman', 150, {'walls': 136, 'prey': 48}, (0, 1)),   # the per-episode random maze: walls + prey = 144 cells
         ('pacman_l1', 100, {'walls': 136, 'prey': 75}, (0,)),
         ('sampler_zoo', 60, {'blocks': 8}, (0, 1)),

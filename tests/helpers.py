@@ -166,6 +166,11 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
         flat2 = np.asarray(fx['rule_counters2_flat'][t], np.float64).reshape(-1)
         for r in range(min(P.n_rules, len(flat2))):
             f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[r]) else flat2[r]
+    if 'force_state' in fx:   # forces with state of their own (DeterministicMazeWalk's read position: a MOOG_RULE_STATE_SLOT)
+        fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
+        for fi in range(min(P.n_forces, len(fs))):
+            if P.forces[fi].kind == _abi.MOOG_FORCE_MAZE_WALK_DET:
+                f[L.o_rule + P.forces[fi].symmetric] = fs[fi]
     pm = portal_rule_mask(P)
     for s in range(S):
         nv = int(fx['nverts'][t][s])
@@ -310,6 +315,12 @@ def state_diff(fx, t, c, f64, i32, env=0):
             if P.rules[r].op == 1 and P.rules[r].kind == _abi.MOOG_RULE_PHASE and f[L.o_rule2 + r] != flat2[r]:
                 ints_ok = False
                 detail.append('phase %d duration: %r vs %r' % (r, f[L.o_rule2 + r], flat2[r]))
+    if 'force_state' in fx:
+        fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
+        for fi in range(min(P.n_forces, len(fs))):
+            if P.forces[fi].kind == _abi.MOOG_FORCE_MAZE_WALK_DET and f[L.o_rule + P.forces[fi].symmetric] != fs[fi]:
+                ints_ok = False
+                detail.append('force %d state: %r vs %r' % (fi, f[L.o_rule + P.forces[fi].symmetric], fs[fi]))
     if P.maze.random:
         rows = maze_rows_from_fixture(fx, t, c)
         if not np.array_equal(q[L.o_maze:L.o_maze + len(rows)], rows):

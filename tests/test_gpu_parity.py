@@ -18,7 +18,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
         ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1),
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
-        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0),
+        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
         ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
@@ -130,7 +130,7 @@ def test_reset_sampler_vs_reference(name, seed):
                                   'functional_maze', 'falling_balls', 'colliding_predators_32',
                                   'forces_zoo', 'tether_zoo_l1', 'tether_zoo_l3', 'tether_zoo_l4',
                                   'distrib_zoo', 'rules_zoo_l0', 'rules_zoo_l1', 'rules_zoo_l2',
-                                  'lambda_zoo', 'first_person_predators_prey', 'maze_zoo', 'maze_zoo_l1',
+                                  'lambda_zoo', 'first_person_predators_prey', 'maze_zoo', 'maze_zoo_l1', 'maze_zoo_l2',
                                   'pacman', 'pacman_l1'])
 def test_engine_vs_oracle_own_rng(name):
     """Same Philox streams on both sides, 64 envs, resets included: integer
