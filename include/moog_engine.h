@@ -687,6 +687,12 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
 int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
 int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled);
 
+/* Usage of the dynamic layers (layers that rules append to: the reference's unbounded Python lists, create_sprites.py,
+ * change_layer.py; here `layer_capacity` slots, overflow = MOOG_FAULT_LAYER_FULL).  Per layer, over all envs and calls
+ * since create: high_water[l] = the most sprites an append ever needed room for (capacity + 1 once the layer overflowed),
+ * dropped[l] = appends that found the layer full.  Both arrays have MOOG_MAX_LAYERS entries.  Synchronises the device. */
+int moog_engine_layer_usage(moog_engine_t* e, int32_t* high_water, int32_t* dropped);
+
 /* Per-kernel device timing: bits 0-7 of `enabled` are a mask over MOOG_K_* (bit k set: launches of kernel k are
  * bracketed by HIP events on the launch stream; 0 disables), bits 8-15 hold period - 1: every period-th launch of
  * a kernel is bracketed (an event pair costs about 5 us of stream time; period 1 = every launch).  Totals and the

@@ -82,6 +82,8 @@ struct Env {
   long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
 #endif
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
+  int32_t* layer_hw;       // global [2 * MOOG_MAX_LAYERS] or null: per dynamic layer, the most sprites an append ever wanted
+                           // room for (over all envs and calls), then the number of appends dropped because the layer was full
   int wrote_direct;        // sticky, per lane: this call stored a colour / opacity / shape id / Portal bit (fields that may
                            // live in HBM, written with ordinary stores): the frame's hand-over needs an L2 write-back
 };
@@ -2344,9 +2346,14 @@ __device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the
   PProg P = e.P;
   int n = 0;
   for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) n += ALIVE(s) ? 1 : 0;
+  if (e.layer_hw && e.lane == 0)   // sizing hint for layer_capacity (the reference's lists are unbounded)
+    __hip_atomic_fetch_max(&e.layer_hw[l], n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n >= P->layer_nslots[l]) {
     wsync();
-    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_LAYER_FULL;
+    if (e.lane == 0) {
+      e.q[e.L.o_fault] |= MOOG_FAULT_LAYER_FULL;
+      if (e.layer_hw) __hip_atomic_fetch_add(&e.layer_hw[MOOG_MAX_LAYERS + l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     wsync();
     return -1;
   }

@@ -84,6 +84,7 @@ struct moog_engine {
   bool fused_force_serial = false;   // MOOG_FUSED_FORCE_SERIAL=1 (test aid): the frames' grid runs in front of the step kernel
   int fused_selfcheck = 0, fused_calls = 0;   // MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again and compared
   uint8_t* fused_check_img = nullptr;
+  int32_t* layer_hw = nullptr;   // [2 * MOOG_MAX_LAYERS]: high-water mark / dropped appends of the dynamic layers
   TimedKernel timed[MOOG_K_COUNT];
   int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
   int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
@@ -119,6 +120,7 @@ static void free_engine(moog_engine* e) {
   if (e->fault_flag) hipHostFree(e->fault_flag);
   if (e->fused_abort) hipHostFree(e->fused_abort);
   if (e->fused_check_img) hipFree(e->fused_check_img);
+  if (e->layer_hw) hipFree(e->layer_hw);
   delete e;
 }
 
@@ -484,6 +486,14 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     return fail(MOOG_E_NOMEM, "hipHostMalloc(fault flag) failed");
   }
   *e->fault_flag = 0;
+  for (int l = 0; l < prog->n_layers; ++l)
+    if (prog->layer_dynamic[l] && !e->layer_hw) {
+      if (hipMalloc(&e->layer_hw, 2 * MOOG_MAX_LAYERS * sizeof(int32_t)) != hipSuccess ||
+          hipMemset(e->layer_hw, 0, 2 * MOOG_MAX_LAYERS * sizeof(int32_t)) != hipSuccess) {
+        free_engine(e);
+        return fail(MOOG_E_NOMEM, "hipMalloc(layer usage) failed");
+      }
+    }
   int rc2 = build_static_prefix(e);
   if (rc2 == MOOG_OK) rc2 = setup_anti_aliasing(e);
   if (rc2) { free_engine(e); return rc2; }
@@ -570,6 +580,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.fault_flag = e->fault_flag;
   a.done = nullptr; a.epoch = 0; a.done_wb = 0;
   a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h;
+  a.layer_hw = e->layer_hw;
   return a;
 }
 
@@ -854,6 +865,17 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   e->perm_buf[0] = e->perm;
   __atomic_store_n(e->fused_abort, 0u, __ATOMIC_RELAXED);
   e->fused = true;
+  return MOOG_OK;
+}
+
+int moog_engine_layer_usage(moog_engine_t* e, int32_t* high_water, int32_t* dropped) {
+  if (!e || !high_water || !dropped) return fail(MOOG_E_INVALID, "null argument");
+  int32_t host[2 * MOOG_MAX_LAYERS] = {0};
+  if (e->layer_hw) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(host, e->layer_hw, sizeof(host), hipMemcpyDeviceToHost));   // (synchronises with the null stream's work)
+  }
+  for (int l = 0; l < MOOG_MAX_LAYERS; ++l) { high_water[l] = host[l]; dropped[l] = host[MOOG_MAX_LAYERS + l]; }
   return MOOG_OK;
 }
 

@@ -142,6 +142,7 @@ struct KArgs {
   uint32_t* dl;          // draw lists for the wave rasteriser (moog_drawlist.h), emitted when the record is stored (or null)
   int32_t dl_stride;     // words per env
   int32_t dl_cw, dl_ch;  // canvas size
+  int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
@@ -187,6 +188,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
   e.wrote_direct = 0;
+  e.layer_hw = a.layer_hw;
   e.cell_tab_n = 0; e.cell_nw = 0;
 #ifdef MOOG_PROFILE
   for (int k = 0; k < 16; ++k) e.prof[k] = 0;

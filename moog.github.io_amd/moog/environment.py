@@ -222,6 +222,19 @@ class BatchedEnvironment(object):
         bits = ctypes.c_int32()
         _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 1, ctypes.byref(bits)))
 
+    def layer_usage(self):
+        """Usage of the layers that rules append to (the reference's unbounded lists; here `layer_capacity` slots):
+        {layer: dict(capacity=, high_water=, dropped=)} over all envs and calls since the environment was made --
+        high_water is the most sprites an append ever needed room for (capacity + 1 once the layer overflowed), dropped
+        the appends that found the layer full.  The sizing hint for `layer_capacity`.  Synchronises the device."""
+        P = self.compiled.program
+        hw = (ctypes.c_int32 * _abi.MOOG_MAX_LAYERS)()
+        dr = (ctypes.c_int32 * _abi.MOOG_MAX_LAYERS)()
+        self._torch.cuda.synchronize(self.device)
+        _engine.check(self._lib, self._lib.moog_engine_layer_usage(self._handle, hw, dr))
+        return {name: dict(capacity=int(P.layer_nslots[li]), high_water=int(hw[li]), dropped=int(dr[li]))
+                for li, name in enumerate(self.compiled.layer_names) if P.layer_dynamic[li]}
+
     def raise_faults(self):
         """Re-raises device-side per-env faults with the reference's exception types."""
         faults = self.state_i32[:, self.layout.o_fault]
@@ -233,6 +246,10 @@ class BatchedEnvironment(object):
         for bit, exc, msg in _FAULT_EXC:
             if allbits & bit:
                 env = int((faults & bit).nonzero()[0].item())
+                if bit == _abi.MOOG_FAULT_LAYER_FULL:   # which layer, and how much room it asked for
+                    full = {k: v for k, v in self.layer_usage().items() if v['dropped'] > 0}
+                    msg += ' Overflowing layers: %s -- pass layer_capacity={layer: slots} with more than high_water ' \
+                           'slots (the reference\'s lists are unbounded; env.layer_usage() reports the demand).' % (full,)
                 raise exc('%s (env %d)' % (msg, env))
 
     # -- dm_env surface (environment.py:82-131) ------------------------------------------

@@ -23,6 +23,8 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             count_min, count_max = lo, hi - 1
         else:
             count_min = count_max = int(n)
+        if count_max == 0:   # no sprite, no draw (sprite_generators.py:77-105 loops zero times): not an op at all
+            return []
         t.suspend = True
         try:
             sprites = [sprite_lib.Sprite(**factor_dist.sample()) for _ in range(count_max)]

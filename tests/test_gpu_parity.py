@@ -796,10 +796,23 @@ def test_dynamic_layer_overflow_is_reported():
     env = environment.BatchedEnvironment(num_envs=64, seed=2, layer_capacity={'predators': 1, 'prey': 1},
                                          **example_configs.load('rules_zoo_l1'))
     env.reset()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError) as err:
         for _ in range(12):
             env.step(np.zeros((64, 2)))
     assert bool((env.field('alive')[:, env.compiled.layer_slots['predators'][0]]).any())
+    # the error names the overflowing layers and the demand; layer_usage() is the sizing hint
+    assert 'Overflowing layers' in str(err.value) and 'high_water' in str(err.value)
+    use = env.layer_usage()
+    assert set(use) == {'predators', 'prey'}
+    assert any(u['dropped'] > 0 and u['high_water'] == u['capacity'] + 1 for u in use.values())
+    # with room to spare nothing is dropped and the high-water mark is the capacity to ask for
+    env2 = environment.BatchedEnvironment(num_envs=64, seed=2, layer_capacity={'predators': 24, 'prey': 24},
+                                          **example_configs.load('rules_zoo_l1'))
+    env2.reset()
+    for _ in range(12):
+        env2.step(np.zeros((64, 2)))
+    use2 = env2.layer_usage()
+    assert all(u['dropped'] == 0 and 1 <= u['high_water'] <= u['capacity'] for u in use2.values()), use2
 
 
 def test_raw_state_observer():
