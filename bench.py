@@ -61,6 +61,17 @@ def raster_bytes_per_env(env):
     return float(P.render.height * P.render.width * 3 + per_env.mean().item())
 
 
+def raster_kernel_name():
+    """Which rasteriser the engine runs for an eligible program (moog_engine.hip): the workgroup rasteriser fed from the
+    draw lists the step kernel emits (default), the wave rasteriser (MOOG_RASTER_WAVE=1), or the workgroup rasteriser
+    reading the f64 records (MOOG_RASTER_DL=0)."""
+    if os.environ.get('MOOG_RASTER_DL') == '0':
+        return 'moog_raster_kernel<1, false> (vertices from the f64 records)'
+    if os.environ.get('MOOG_RASTER_WAVE') == '1':
+        return 'moog_raster_wave_kernel<1> (two wavefronts per frame, draw lists)'
+    return 'moog_raster_kernel<1, true> (vertices from the draw lists the step kernel emits)'
+
+
 def raster_traffic(workload, n_envs):
     """HBM bytes per raster launch as profiled offline (rocprofv3 PMC passes of this
     workload, tools/prof.sh -> profiles/raster_traffic.json; the record names the
@@ -311,6 +322,11 @@ def main():
     if not args.no_schedule and not args.no_fused:
         fused = env.tune_launch(one_step)
         tuned = 'timed against the separate launches before the warm-up (2 x 24 calls each, alternating)'
+        if use_dist:   # one launch structure for the whole node: the mode is kept only if every rank kept it
+            agree = -sharding.max_over_ranks(-(1.0 if fused else 0.0), device=dev if backend == 'nccl' else None)
+            if fused and agree < 1.0:
+                fused = env.set_fused(False)
+            tuned += '; kept only if every rank keeps it'
     for _ in range(args.warmup):
         one_step()
     # Kernels of the timed region are bracketed by HIP events on the launch stream, so the per-kernel
@@ -380,6 +396,8 @@ def main():
                        'launch': (('frames follow their env\'s step (raster grid beside the step kernel); every %dth call takes the '
                                    'separate launches and is the one whose kernels are timed' % every) if fused
                                   else 'separate step and raster launches') + ((' -- ' + tuned) if tuned else ''),
+                       'launch_tuning_ms_per_step': ({k.replace('_s_per_call', ''): round(v * 1e3, 4) for k, v in env.last_tune.items()}
+                                                     if getattr(env, 'last_tune', None) else None),
                        'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)
                                    if staggered else 'lockstep'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -388,9 +406,12 @@ def main():
                          'traffic_source': (tr.get('source', 'profiles/raster_traffic.json') + ' (offline rocprofv3 PMC passes, '
                                             'not this run)') if tr else None,
                          'algorithmic_bytes_per_launch': n * rb,
-                         'kernel': 'moog_raster_kernel', 'avg_kernel_us': r_avg_s * 1e6,
+                         'kernel': raster_kernel_name(), 'avg_kernel_us': r_avg_s * 1e6, 'kernel_samples': int(r_n),
                          'algorithmic_bytes_per_env': rb},
             'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items() if v[1] > 0},
+            'kernels_avg_us_note': ('HIP-event brackets inside the timed region; with frames following steps the sampled calls '
+                                    '(every %dth) take the separate launches, so these are separate-launch samples' % every) if fused
+                                   else ('HIP-event brackets around every %dth launch inside the timed region' % every),
             'faulted_envs': faults,
         }
         line.update(extras)

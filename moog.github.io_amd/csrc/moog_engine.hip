@@ -481,7 +481,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   }
   { const char* ds = getenv("MOOG_STEP_DEBUG"); e->step_dbg = ds ? atoi(ds) : 0; }
   { const char* ds = getenv("MOOG_RASTER_STOP"); e->raster_stop = ds ? atoi(ds) : 0; }
-  if (hipHostMalloc(reinterpret_cast<void**>(&e->fault_flag), sizeof(int32_t), hipHostMallocMapped) != hipSuccess) {
+  // (coherent = fine-grained: the kernels' system-scope atomics and the host's atomic read / clear meet in the same memory)
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->fault_flag), sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     free_engine(e);
     return fail(MOOG_E_NOMEM, "hipHostMalloc(fault flag) failed");
   }
@@ -847,11 +848,24 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
     HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
     HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
     HIPCHK(hipMemset(e->fused_ticket, 0, 2 * sizeof(uint32_t)));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     *e->fused_abort = 0u;
     { const char* fs = getenv("MOOG_FUSED_FORCE_SERIAL"); e->fused_force_serial = fs && atoi(fs) == 1; }
     { const char* sc = getenv("MOOG_FUSED_SELFCHECK"); e->fused_selfcheck = sc ? atoi(sc) : 0; }
-    HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
+    {   // MOOG_FUSED_CU_STRIDE=k (experiment): the frames' grid only runs on every k-th compute unit, the others keep
+        // their whole LDS for stepping envs
+      const char* cs = getenv("MOOG_FUSED_CU_STRIDE");
+      const int stride = cs ? atoi(cs) : 0;
+      if (stride > 1) {
+        hipDeviceProp_t pr;
+        HIPCHK(hipGetDeviceProperties(&pr, e->device));
+        std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0u);
+        for (int cu = 0; cu < pr.multiProcessorCount; cu += stride) mask[cu >> 5] |= 1u << (cu & 31);
+        HIPCHK(hipExtStreamCreateWithCUMask(&e->fused_stream, (uint32_t)mask.size(), mask.data()));
+      } else {
+        HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
+      }
+    }
     HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
     hipDeviceProp_t prop;

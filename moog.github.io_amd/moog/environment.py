@@ -176,6 +176,8 @@ class BatchedEnvironment(object):
                     step_fn()
                 torch.cuda.synchronize(self.device)
                 took[fused] += time.perf_counter() - t0
+        # (what was measured, for the caller's records: seconds per call in each mode)
+        self.last_tune = {'separate_s_per_call': took[False] / (2 * steps), 'fused_s_per_call': took[True] / (2 * steps)}
         return self.set_fused(took[True] < 0.995 * took[False])
 
     # -- plumbing ---------------------------------------------------------------------
@@ -236,7 +238,12 @@ class BatchedEnvironment(object):
                 for li, name in enumerate(self.compiled.layer_names) if P.layer_dynamic[li]}
 
     def raise_faults(self):
-        """Re-raises device-side per-env faults with the reference's exception types."""
+        """Re-raises device-side per-env faults with the reference's exception types.
+
+        Faults are STICKY, like a broken environment in the reference: the per-env fault words (and the engine's summary
+        word that _poll_faults reads) stay set, so every later reset() / step() / observation() raises again until
+        clear_faults() -- after which the faulted envs should be reset.  The one engine-origin condition,
+        MOOG_FAULT_FRAME_MISMATCH of the fused mode's self-check, is reported once and cleared."""
         faults = self.state_i32[:, self.layout.o_fault]
         if not bool((faults != 0).any().item()):
             return
@@ -246,6 +253,12 @@ class BatchedEnvironment(object):
         for bit, exc, msg in _FAULT_EXC:
             if allbits & bit:
                 env = int((faults & bit).nonzero()[0].item())
+                if bit == _abi.MOOG_FAULT_FRAME_MISMATCH:   # engine-origin: report once
+                    self.state_i32[:, self.layout.o_fault] &= ~bit
+                    got = ctypes.c_int32()
+                    _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 0, ctypes.byref(got)))
+                    if got.value == bit:   # (other faults keep the summary word set: they are sticky)
+                        _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 1, ctypes.byref(got)))
                 if bit == _abi.MOOG_FAULT_LAYER_FULL:   # which layer, and how much room it asked for
                     full = {k: v for k, v in self.layer_usage().items() if v['dropped'] > 0}
                     msg += ' Overflowing layers: %s -- pass layer_capacity={layer: slots} with more than high_water ' \

@@ -5,9 +5,13 @@ import torch
 from moog import environment, _abi
 from moog_demos import example_configs
 
+# capacities of the layers rules append to, sized from env.layer_usage() (the recipes' own LAYER_CAPACITY values are the
+# ones the reference fixtures were recorded with and are too small for a 4096-env batch's tail)
+BENCH_CAPACITY = {'first_person_predators_prey': {'prey': 32, 'predators': 96}, 'rules_zoo_l1': {'prey': 24, 'predators': 24}}
+
 def run(name, n, steps=30, observers=True, **kw):
     cfg = example_configs.load(name) if not kw else __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, **kw)
-    env = environment.BatchedEnvironment(num_envs=n, seed=1, layer_capacity=example_configs.capacity(name), **cfg)
+    env = environment.BatchedEnvironment(num_envs=n, seed=1, layer_capacity=BENCH_CAPACITY.get(name, example_configs.capacity(name)), **cfg)
     env.check_faults = False
     env.reset()
     for _ in range(5):
@@ -22,6 +26,9 @@ def run(name, n, steps=30, observers=True, **kw):
     faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
     print('%-24s N=%6d  %10.0f env-steps/s  step %.0f us  raster %.0f us  reset %.0f us  faults %d' % (
         name, n, n * steps / dt, *(ks[k][0] / max(ks[k][1], 1) * 1e3 for k in ('step', 'raster', 'reset')), faults), flush=True)
+    use = env.layer_usage()
+    if use:
+        print('    dynamic layers:', use, flush=True)
 
 run('chase_avoid_torus', 4096)
 run('colliding_predators_32', 4096)
