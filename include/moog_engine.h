@@ -651,6 +651,11 @@ int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev,
 int moog_engine_step(moog_engine_t* e, const void* actions_dev,
                      const moog_inject_t* inject, const moog_step_out_t* out,
                      void* hip_stream);
+/* Element type of the action buffer of a Joystick (and of the Joystick components of a Composite): 0 = float64 (default),
+ * 1 = float32, the dtype of the reference's action spec (joystick.py:42-43).  With float32 actions the reference's
+ * `self._scaling_factor * action` is a float32 product (numpy: the Python float is the weak operand); the engine then
+ * computes exactly that.  Grid actions stay int32; SetPosition components read the same buffer and use the values as they are. */
+int moog_engine_set_action_dtype(moog_engine_t* e, int32_t float32);
 /* env.physics.step(env.state) only (tests/runtime_benchmark.py:101-107). */
 int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject,
                              void* hip_stream);

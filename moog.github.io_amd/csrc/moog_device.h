@@ -2971,7 +2971,8 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
 }
 
 // ---- action spaces ---------------------------------------------------------------------------
-__device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, int grid_action) {
+// f32: the caller's actions are float32 (joystick.py:42-43): `scaling_factor * action` is then a float32 product
+__device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, int grid_action, bool f32 = false) {
   PProg P = e.P;
   PAction A = (k == 0) ? &P->action : &P->more_actions[k - 1];
   const int om = e.L.o_action + 2 * k;
@@ -2989,7 +2990,8 @@ __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, in
   if (A->kind == MOOG_ACTION_JOYSTICK) {
     double ax = ax_in, ay = A->constrained_lr ? 0. : ay_in;
     m0 *= A->momentum; m1 *= A->momentum;
-    m0 += A->scaling_factor * ax; m1 += A->scaling_factor * ay;
+    if (f32) { m0 += (double)((float)A->scaling_factor * (float)ax); m1 += (double)((float)A->scaling_factor * (float)ay); }
+    else { m0 += A->scaling_factor * ax; m1 += A->scaling_factor * ay; }
   } else {
     double mx = (grid_action == 0) ? -1. : (grid_action == 1 ? 1. : 0.);
     double my = (grid_action == 2) ? -1. : (grid_action == 3 ? 1. : 0.);

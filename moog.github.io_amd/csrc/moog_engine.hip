@@ -84,6 +84,7 @@ struct moog_engine {
   bool fused_force_serial = false;   // MOOG_FUSED_FORCE_SERIAL=1 (test aid): the frames' grid runs in front of the step kernel
   int fused_selfcheck = 0, fused_calls = 0;   // MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again and compared
   uint8_t* fused_check_img = nullptr;
+  int act_f32 = 0;               // moog_engine_set_action_dtype: the action buffer holds float32 values
   int32_t* layer_hw = nullptr;   // [2 * MOOG_MAX_LAYERS]: high-water mark / dropped appends of the dynamic layers
   TimedKernel timed[MOOG_K_COUNT];
   int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
@@ -582,6 +583,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.done = nullptr; a.epoch = 0; a.done_wb = 0;
   a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h;
   a.layer_hw = e->layer_hw;
+  a.act_f32 = e->act_f32;
   return a;
 }
 
@@ -879,6 +881,12 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   e->perm_buf[0] = e->perm;
   __atomic_store_n(e->fused_abort, 0u, __ATOMIC_RELAXED);
   e->fused = true;
+  return MOOG_OK;
+}
+
+int moog_engine_set_action_dtype(moog_engine_t* e, int32_t float32) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  e->act_f32 = float32 ? 1 : 0;
   return MOOG_OK;
 }
 

@@ -143,6 +143,7 @@ struct KArgs {
   int32_t dl_stride;     // words per env
   int32_t dl_cw, dl_ch;  // canvas size
   int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
+  int32_t act_f32;       // 1: `actions` holds float32 values (moog_engine_set_action_dtype)
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
@@ -335,19 +336,27 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
   const int n_rules = uni(P->n_rules);
   for (int r = 0; r < n_rules; ++r)
     if (P->rules[r].parent < 0) rule_step<DYN>(e, r);
+  const bool af32 = a.act_f32 != 0;
   if (uni(P->n_actions) > 1) {   // composite.py:61-62: every sub-space, in keyword order
     const int na = uni(P->n_actions);
-    const double* act = reinterpret_cast<const double*>(a.actions) + (size_t)2 * na * env;
-    for (int k = 0; k < na; ++k) action_step(e, k, act[2 * k], act[2 * k + 1], (int)act[2 * k]);
+    for (int k = 0; k < na; ++k) {
+      double x, y;
+      if (af32) { const float* act = reinterpret_cast<const float*>(a.actions) + (size_t)2 * na * env; x = act[2 * k]; y = act[2 * k + 1]; }
+      else { const double* act = reinterpret_cast<const double*>(a.actions) + (size_t)2 * na * env; x = act[2 * k]; y = act[2 * k + 1]; }
+      action_step(e, k, x, y, (int)x, af32);
+    }
   } else {
     double ax = 0, ay = 0;
     int ga = 4;
     if (P->action.kind == MOOG_ACTION_GRID) ga = reinterpret_cast<const int32_t*>(a.actions)[env];
-    else {
+    else if (af32) {
+      ax = reinterpret_cast<const float*>(a.actions)[2 * env];
+      ay = reinterpret_cast<const float*>(a.actions)[2 * env + 1];
+    } else {
       ax = reinterpret_cast<const double*>(a.actions)[2 * env];
       ay = reinterpret_cast<const double*>(a.actions)[2 * env + 1];
     }
-    action_step(e, 0, ax, ay, ga);
+    action_step(e, 0, ax, ay, ga, af32);
   }
   PROF_ADD(e, 10);
   }

@@ -17,7 +17,7 @@ SYMBOLS = (
     'moog_engine_step', 'moog_engine_physics_only', 'moog_engine_render',
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
     'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
-    'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage',
+    'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
 )
 
 _LIB = None
@@ -62,6 +62,7 @@ def load_library(path=None):
     lib.moog_engine_set_timing.argtypes = [vp, i32]
     lib.moog_engine_set_fused.argtypes = [vp, i32]
     lib.moog_engine_get_fused.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.moog_engine_set_action_dtype.argtypes = [vp, i32]
     lib.moog_engine_layer_usage.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.moog_engine_set_debug.argtypes = [vp, i32, i32]
     lib.moog_engine_static_prefix.argtypes = [vp, ctypes.POINTER(i32), vp, vp]

@@ -108,6 +108,7 @@ class BatchedEnvironment(object):
         self.check_faults = True
         self._cost = self._perm = None
         self._fused = False
+        self._action_f32 = False
 
     def enable_cost_schedule(self, enabled=True, fused=False):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
@@ -293,7 +294,14 @@ class BatchedEnvironment(object):
             a = torch.as_tensor(action, device=self.device).to(torch.int32).contiguous()
             assert a.shape == (self.num_envs,)
         else:
-            a = torch.as_tensor(action, device=self.device).to(torch.float64).contiguous()
+            a = torch.as_tensor(action, device=self.device)
+            # float32 actions -- the dtype of the reference's Joystick spec (joystick.py:42-43) -- stay float32: the
+            # reference then multiplies by scaling_factor in float32, and so does the engine
+            f32 = a.dtype == torch.float32
+            if f32 != self._action_f32:
+                _engine.check(self._lib, self._lib.moog_engine_set_action_dtype(self._handle, 1 if f32 else 0))
+                self._action_f32 = f32
+            a = (a if f32 else a.to(torch.float64)).contiguous()
             assert a.shape == (self.num_envs, 2)
         if self._host_rules or self._meta_state_initializer is not None:
             # environment.py:100-104: an auto-reset re-initialises the meta-state; either way

@@ -314,6 +314,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
     skip = caps_by_layer.pop('__skip__', 0)   # un-recorded steps after the reset: the recording starts from a later state
     sub_calls = tuple(caps_by_layer.pop('__sub_calls__', ()))   # further calls whose sub-step states are recorded
     script = caps_by_layer.pop('__script__', None)   # (env, call, RandomState) -> action: a policy instead of random actions
+    action_f32 = bool(caps_by_layer.pop('__action_f32__', False))   # hand the reference float32 actions (joystick.py:42-43)
     TAPE = Tape(seed)
     act_rs = np.random.RandomState(1000 + seed)
     env = environment.Environment(**cfg)
@@ -406,6 +407,9 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         else:
             action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
             ref_action = action if is_grid else np.array(action)
+            if action_f32 and not is_grid:   # the recorded action is the float32 value (as float64)
+                ref_action = np.array(action, dtype=np.float32)
+                action = ref_action.astype(np.float64)
         will_reset = env.reset_next_step
         if (t <= n_sub_steps or t in sub_calls) and not will_reset:
             state_box['log'] = []
@@ -420,7 +424,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
         push(ts, action, TAPE.take())
 
     out = {'layer_names': np.array(layer_names), 'layer_caps': np.array(caps, np.int32),
-           'K': np.int32(K), 'is_grid': np.int32(is_grid)}
+           'K': np.int32(K), 'is_grid': np.int32(is_grid), 'action_f32': np.int32(action_f32)}
     umax = max(1, max(len(r['uniforms']) for r in rows))
     U = np.full((len(rows), umax), np.nan)
     for i, r in enumerate(rows):
@@ -698,6 +702,8 @@ def main():
         ('pong', 96, {}, (0, 1)),
         ('chase_avoid_torus', 64, {}, (0, 1)),
         ('colliding_predators', 64, {}, (0, 1)),
+        ('colliding_predators', 48, {'__action_f32__': True}, (2,)),   # float32 actions: scaling_factor * action in float32
+        ('chase_avoid_torus', 48, {'__action_f32__': True}, (2,)),
         ('functional_maze', 96, {'prey': 4}, (0, 1)),
         ('falling_balls', 48, {}, (0,)),
         ('colliding_predators_32', 40, {}, (0,)),

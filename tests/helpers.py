@@ -76,6 +76,8 @@ class OracleEnv(object):
 
     def step(self, actions, uniforms=None, render=True):
         u, nu = self._inj(uniforms)
+        # float32 actions (the reference's Joystick spec): the scaling is a float32 product
+        self.lib.oracle_set_action_f32(1 if getattr(actions, 'dtype', None) == np.float32 else 0)
         if self.P.n_actions > 1:   # Composite: [n, n_actions, 2] (a Grid move in component 0)
             a = np.ascontiguousarray(actions, np.float64).reshape(self.n, 2 * self.P.n_actions)
             af, ai = a, None
@@ -347,6 +349,15 @@ def state_diff(fx, t, c, f64, i32, env=0):
                 ints_ok = False
                 detail.append('rule state %d: %r vs %r' % (r, f[L.o_rule + r], flat[r]))
     return dict(float=max(err.values()), err=err, ints_ok=ints_ok, detail='; '.join(detail))
+
+
+def action_of(fx, t):
+    """The action of recorded call t, in the dtype the reference was handed (float32 for recordings made with the
+    Joystick spec's own dtype, tests/golden/make_golden.py `__action_f32__`)."""
+    a = np.asarray(fx['action'][t])
+    if 'action_f32' in fx and int(fx['action_f32']):
+        a = a.astype(np.float32)
+    return a
 
 
 def uniforms_of(fx, t):

@@ -9,7 +9,7 @@ from helpers import compiled, fixture, records_from_fixture, state_diff
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
-        ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
+        ('colliding_predators', 0), ('colliding_predators', 1), ('colliding_predators', 2), ('chase_avoid_torus', 2), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
         ('falling_balls_64', 0), ('falling_balls_64', 1), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
         ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
@@ -71,7 +71,7 @@ def test_teacher_forced_vs_reference(name, seed):
     for i, t in enumerate(ts):
         records_from_fixture(fx, t - 1, c, f64, i32, env=i)
     upload(env, f64, i32)
-    actions = np.stack([np.asarray(fx['action'][t]) for t in ts])
+    actions = np.stack([helpers.action_of(fx, t) for t in ts])
     env.check_faults = False
     out = env.step(actions, injected_uniforms=padded_uniforms(fx, ts))
     f, q = download(env)
@@ -101,7 +101,7 @@ def test_free_running_vs_reference(name, seed):
     upload(env, f64, i32)
     env.check_faults = False
     for t in range(1, T):
-        a = np.asarray(fx['action'][t])
+        a = helpers.action_of(fx, t)
         a = a.reshape((1,) + a.shape) if a.ndim == 2 else a.reshape((1, 2) if not fx['is_grid'] else (1,))
         out = env.step(a, injected_uniforms=padded_uniforms(fx, [t]))
         f, q = download(env)

@@ -11,7 +11,7 @@ import helpers
 from helpers import OracleEnv, compiled, fixture, records_from_fixture, state_diff, uniforms_of
 
 RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus', 1),
-        ('colliding_predators', 0), ('colliding_predators', 1), ('functional_maze', 0),
+        ('colliding_predators', 0), ('colliding_predators', 1), ('colliding_predators', 2), ('chase_avoid_torus', 2), ('functional_maze', 0),
         ('functional_maze', 1), ('falling_balls', 0), ('colliding_predators_32', 0),
         ('falling_balls_64', 0), ('falling_balls_64', 1), ('forces_zoo', 0), ('forces_zoo', 1), ('chase_avoid_torus_l1', 0),
         ('tether_zoo_l0', 0), ('tether_zoo_l1', 0), ('tether_zoo_l2', 0), ('tether_zoo_l3', 0),
@@ -47,7 +47,7 @@ def test_teacher_forced_steps(name, seed):
     worst = 0.0
     for t in range(1, T):
         records_from_fixture(fx, t - 1, c, o.f64, o.i32)
-        o.step(fx['action'][t], uniforms=uniforms_of(fx, t))
+        o.step(helpers.action_of(fx, t), uniforms=uniforms_of(fx, t))
         d = state_diff(fx, t, c, o.f64, o.i32)
         assert d['ints_ok'], (t, d)
         assert d['float'] <= TOL, (t, d)
@@ -117,7 +117,7 @@ def test_free_running_window(name, seed):
     T = min([len(fx['step_type']), 65, FREE_WINDOW.get((name, seed), 65)])
     records_from_fixture(fx, 0, c, o.f64, o.i32)
     for t in range(1, T):
-        o.step(fx['action'][t], uniforms=uniforms_of(fx, t), render=(t == T - 1))
+        o.step(helpers.action_of(fx, t), uniforms=uniforms_of(fx, t), render=(t == T - 1))
         d = state_diff(fx, t, c, o.f64, o.i32)
         assert d['ints_ok'], (t, d)
         assert d['float'] <= TOL, (t, d)
@@ -147,7 +147,7 @@ def test_substeps(name, seed):
         # separable -> instead compare full-step result, and substeps for configs without
         # rules/action effects on the first substep inputs.
         o.f64[:], o.i32[:] = f0, q0
-        o.step(fx['action'][t], uniforms=u, render=False)
+        o.step(helpers.action_of(fx, t), uniforms=u, render=False)
         d = state_diff(fx, t, c, o.f64, o.i32)
         assert d['ints_ok'] and d['float'] <= TOL, (t, d)
         last = fx['sub_pos'][step][-1]
