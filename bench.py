@@ -62,14 +62,14 @@ def raster_bytes_per_env(env):
 
 
 def raster_kernel_name():
-    """Which rasteriser the engine runs for an eligible program (moog_engine.hip): the workgroup rasteriser fed from the
-    draw lists the step kernel emits (default), the wave rasteriser (MOOG_RASTER_WAVE=1), or the workgroup rasteriser
-    reading the f64 records (MOOG_RASTER_DL=0)."""
-    if os.environ.get('MOOG_RASTER_DL') == '0':
-        return 'moog_raster_kernel<1, false> (vertices from the f64 records)'
+    """Which rasteriser the engine runs (moog_engine.hip): the workgroup rasteriser reading the f64 records (default), the
+    same from the draw lists the step kernel emits (MOOG_RASTER_DL=1), or the wave rasteriser from the lists' edge records
+    (MOOG_RASTER_WAVE=1) -- the two opt-in paths cost the step kernel more than they save."""
     if os.environ.get('MOOG_RASTER_WAVE') == '1':
-        return 'moog_raster_wave_kernel<1> (two wavefronts per frame, draw lists)'
-    return 'moog_raster_kernel<1, true> (vertices from the draw lists the step kernel emits)'
+        return 'moog_raster_wave_kernel<1> (two wavefronts per frame, edge records from the draw lists)'
+    if os.environ.get('MOOG_RASTER_DL') == '1':
+        return 'moog_raster_kernel<1, true> (points from the draw lists the step kernel emits)'
+    return 'moog_raster_kernel<1, false> (vertices from the f64 records)'
 
 
 def raster_traffic(workload, n_envs):

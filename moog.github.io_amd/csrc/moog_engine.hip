@@ -345,6 +345,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
                 (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
                 (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
+  if ((size_t)HL.o_verts * 8 < (size_t)DL_SCRATCH_A) e->step_lds += DL_SCRATCH_A + 16;   // the draw-list emission's scratch (moog_kernels.h emit_drawlist)
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     free_engine(e);
@@ -409,9 +410,14 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     int maxv = 1;
     for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
     const int max_rounds = dl_max_rounds(e->L.TOTV, maxv);
-    const char* off = getenv("MOOG_RASTER_DL");
+    // Draw lists are OPT-IN (MOOG_RASTER_DL=1: the workgroup rasteriser reads the points from the list; MOOG_RASTER_WAVE=1:
+    // the wave rasteriser reads the edge records).  Measured on the headline workload (profiles/r03_raster_experiments.txt):
+    // the emission runs at the end of every env's step, i.e. on the critical path of the step kernel's slowest wavefront,
+    // and costs it more (+15 us for the points, +30 us with the edge records) than the rasterisers save (-2.5 / -19 us).
+    const char* on = getenv("MOOG_RASTER_DL");
     const char* wv = getenv("MOOG_RASTER_WAVE");
-    e->dlist = !(off && atoi(off) == 0) && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
+    const bool want = (on && atoi(on) == 1) || (wv && atoi(wv) == 1);
+    e->dlist = want && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
                e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 &&
                prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
     e->wave = e->dlist && wv && atoi(wv) == 1;
@@ -581,7 +587,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.dbg = e->step_dbg;
   a.fault_flag = e->fault_flag;
   a.done = nullptr; a.epoch = 0; a.done_wb = 0;
-  a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h;
+  a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h; a.dl_deep = e->wave ? 1 : 0;
   a.layer_hw = e->layer_hw;
   a.act_f32 = e->act_f32;
   return a;
@@ -616,7 +622,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
 static DLArgs drawlist_args(moog_engine* e) {
   DLArgs d;
   d.P = e->d_prog; d.L = e->L; d.f64 = e->view.f64; d.i32 = e->view.i32; d.vslot = e->d_vslot;
-  d.dl = e->d_dl; d.dl_stride = e->dl_stride; d.n_envs = e->n_envs; d.cw = e->canvas_w; d.ch = e->canvas_h;
+  d.dl = e->d_dl; d.dl_stride = e->dl_stride; d.n_envs = e->n_envs; d.cw = e->canvas_w; d.ch = e->canvas_h; d.deep = e->wave ? 1 : 0;
   return d;
 }
 

@@ -142,21 +142,26 @@ struct KArgs {
   uint32_t* dl;          // draw lists for the wave rasteriser (moog_drawlist.h), emitted when the record is stored (or null)
   int32_t dl_stride;     // words per env
   int32_t dl_cw, dl_ch;  // canvas size
+  int32_t dl_deep;       // 1: with the edge records (the wave rasteriser's input); 0: packed points only
   int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
   int32_t act_f32;       // 1: `actions` holds float32 values (moog_engine_set_action_dtype)
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
 
-// The env's draw list (moog_drawlist.h), from the record in LDS, once the step / reset is complete.  The broad-phase
-// candidate list and the edge-index scratch (contiguous: 96 words) are dead by then and serve as the scratch table.
+// The env's draw list (moog_drawlist.h), from the record in LDS, once the step / reset is complete and the record is
+// stored.  Scratch: the broad-phase candidate list, the edge-index scratch and the candidate bit matrix (contiguous, 896
+// bytes) are dead by then, and so is the head of the f64 record (positions, velocities, ... -- everything in front of the
+// vertices); records too small for that get DL_SCRATCH_A extra bytes behind the bit matrix (moog_engine.hip step_lds).
 __device__ __forceinline__ void emit_drawlist(const Env& e, const KArgs& a, int env) {
   if (!a.dl) return;
   wsync();
-  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, e.L.S, e.L.TOTV, e.q + e.L.o_flags, e.q + e.L.o_nverts,
-                       e.f + e.L.o_verts, e.voff, e.vslot, a.dl_cw, a.dl_ch, e.lane, reinterpret_cast<uint32_t*>(e.cand));
+  unsigned char* sa = ((size_t)e.L.o_verts * 8 >= (size_t)DL_SCRATCH_A)
+                          ? reinterpret_cast<unsigned char*>(e.f)
+                          : reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.rowm + 64) + 15) & ~(uintptr_t)15);
+  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, e.L.S, e.q + e.L.o_flags, e.q + e.L.o_nverts, e.f + e.L.o_verts,
+                       e.voff, a.dl_cw, a.dl_ch, e.lane, sa, reinterpret_cast<unsigned char*>(e.cand), a.dl_deep != 0);
 }
-
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 

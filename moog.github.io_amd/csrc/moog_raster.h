@@ -160,7 +160,7 @@ void moog_frames_compare_launch(const uint8_t* a, const uint8_t* b, size_t bytes
 #define RW_THREADS (64 * RW_WAVES)
 
 struct RWPlan {   // LDS carve-up (byte offsets), computed once on the host
-  unsigned o_edge, o_rows, o_rpts, o_attr, o_sgn, o_item_y, o_rgba, o_rowbase, o_iinfo, o_rowitems, o_rowitem, o_long, o_pend, o_dummy, o_misc, total;
+  unsigned o_edge, o_rows, o_item_y, o_rgba, o_rowbase, o_iinfo, o_rowitems, o_rowitem, o_long, o_pend, o_dummy, o_misc, total;
   int32_t e_cap;   // edge records (a multiple of 64: rounds per pass)
   int32_t r_cap;   // row records per pass (>= canvas height)
 };
@@ -196,9 +196,6 @@ __host__ __device__ inline void raster_wave_plan(int W, int H, int e_cap, int r_
     p->o_edge = o; o = r_align(o + (l1 > l2 ? l1 : l2));
   }
   p->o_rows = o; o = r_align(o + (size_t)r_cap * sizeof(RRow));
-  p->o_rpts = o; o = r_align(o + 68 * 4 * RW_WAVES);          // a wave's round of packed points (+ slack)
-  p->o_attr = o; o = r_align(o + 64 * 16 * RW_WAVES);         // a wave's round of edge attributes (corner fix-up search)
-  p->o_sgn = o; o = r_align(o + 64 * RW_WAVES);
   p->o_item_y = o; o = r_align(o + RW_MAX_ITEMS * 8);         // ymin, ymax (ints, atomics)
   p->o_rgba = o; o = r_align(o + RW_MAX_ITEMS * 4);
   p->o_rowbase = o; o = r_align(o + RW_MAX_ITEMS * 4);        // first row record - first row
@@ -225,6 +222,7 @@ struct DLArgs {   // moog_drawlist_kernel: draw lists from state records in HBM
   int32_t dl_stride;
   int32_t n_envs;
   int32_t cw, ch;
+  int32_t deep;   // 1: with the edge records (moog_drawlist.h)
 };
 void moog_drawlist_launch(const DLArgs& a, hipStream_t stream);
 int moog_raster_wave_configure(size_t lds_bytes);

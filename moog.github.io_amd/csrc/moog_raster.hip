@@ -163,7 +163,8 @@ __global__ __launch_bounds__(RW_THREADS, 5) void moog_raster_wave_kernel(RWArgs 
 
 // Draw lists from state records in HBM (frames of states the step kernel did not produce): one wavefront per env.
 __global__ __launch_bounds__(64) void moog_drawlist_kernel(DLArgs a) {
-  __shared__ uint32_t tbl[DL_SCRATCH_WORDS];
+  __shared__ __attribute__((aligned(16))) unsigned char sa[DL_SCRATCH_A];
+  __shared__ __attribute__((aligned(16))) unsigned char sb[DL_SCRATCH_B];
   __shared__ int32_t voff[RW_MAX_ITEMS];
   const int env = (int)blockIdx.x;
   if (env >= a.n_envs) return;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(64) void moog_drawlist_kernel(DLArgs a) {
   __syncthreads();
   const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, a.L.S, a.L.TOTV, gq + a.L.o_flags, gq + a.L.o_nverts, gf + a.L.o_verts,
-                       voff, a.vslot, a.cw, a.ch, lane, tbl);
+  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, a.L.S, gq + a.L.o_flags, gq + a.L.o_nverts, gf + a.L.o_verts, voff,
+                       a.cw, a.ch, lane, sa, sb, a.deep != 0);
 }
 
 void moog_drawlist_launch(const DLArgs& a, hipStream_t stream) {

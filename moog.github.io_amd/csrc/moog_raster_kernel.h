@@ -554,10 +554,13 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   const uint32_t* dl = DL ? a.dl + (size_t)env * a.dl_stride : nullptr;
   const int n_entries = DL ? 64 * uni((int)dl[0]) : 0;   // rounds of 64 entries; a round's byte at dl + 4 says how many are used
   uint2 en_next = make_uint2(0u, 0u);
+  auto entry_of = [&](const uint32_t* list, int ie) -> uint2 {   // {packed point, info word} of entry ie (moog_drawlist.h)
+    const uint32_t* rnd = list + DL_HDR + DL_ROUND_WORDS * (ie >> 6);
+    return make_uint2(rnd[4 * (ie & 63)], rnd[256 + (ie & 63)] & ~DL_INFO_HEAD);
+  };
   auto load_entry = [&](int ie) -> uint2 {
     uint2 en = make_uint2(0u, 0u);   // (w1 == 0 never occurs for a used entry: nv >= 1)
-    if (ie < n_entries && (ie & 63) < (int)reinterpret_cast<const uint8_t*>(dl + 4)[ie >> 6])
-      en = *reinterpret_cast<const uint2*>(dl + DL_HDR + 2 * ie);
+    if (ie < n_entries && (ie & 63) < (int)reinterpret_cast<const uint8_t*>(dl + 4)[ie >> 6]) en = entry_of(dl, ie);
     return en;
   };
   if (DL) en_next = load_entry(tid);
@@ -646,7 +649,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
       const unsigned vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u;   // slot | k << 8 | used
       if (ie == tid) vi_keep0 = vi; else if (ie == tid + R_THREADS) vi_keep1 = vi;
       if (NS > 0 && ie < a.nsl) {   // the prefix's entries against the reference's
-        const uint2 ref = *reinterpret_cast<const uint2*>(a.sref_dl + DL_HDR + 2 * ie);
+        const uint2 ref = entry_of(a.sref_dl, ie);
         st_bad = st_bad || ref.x != en.x || ref.y != en.y;
       }
       if (!en.y) continue;

@@ -15,7 +15,7 @@
 //   * frames whose polygons need more row or edge records than the LDS plan holds take several PASSES over item
 //     ranges; the partially composed frame round-trips through the output (L2), as in the workgroup kernel.
 //
-// Eligible programs (moog_engine.hip raster_wave_eligible): one tile (canvas <= 128 x 128), no anti-aliasing, no
+// Eligible programs (moog_engine.hip): one tile (canvas <= 128 x 128), no anti-aliasing, no
 // polygon modifier, <= 64 sprite slots, <= 32 vertices per sprite.  Everything else takes the workgroup kernel.
 #ifndef MOOG_RASTER_WAVE_H_
 #define MOOG_RASTER_WAVE_H_
@@ -97,61 +97,6 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   return v;
 }
 
-__device__ __forceinline__ unsigned rw_pack(int x, int y) { return (unsigned)(unsigned short)x | ((unsigned)(unsigned short)y << 16); }
-
-// Corner fix-up search.  tip_decide (moog_raster_kernel.h) lets an EARLIER table edge K decide the fix-up of edge E's
-// first (last) row when K has the same upper (lower) end point, leans the same way (sign of dx, never 0) and crosses that
-// row at the same x as polygon_generic computes it; the first such K in edge order decides.  All of that is a property of
-// the two edges alone, so every edge publishes an ATTRIBUTE record {upper point, x on its first row, lower point, x on
-// its last row} + the sign of its dx, and an edge scans the records of its polygon's earlier edges once, in order (lanes
-// of a polygon read the same record: a broadcast).  Edges that cannot decide anything (horizontal, vertical) publish
-// points no vertex can have.  The replacement values are computed once, after the scan.
-struct RAttr { unsigned tw, xt, bw, xb; };
-#define RW_NOPOINT 0x80008000u   // (canvas points are clamped to +-32000)
-
-// tip_decide's replacement value once K is known to decide: E's and K's crossings of the row next to the tip row
-__device__ __forceinline__ short tip_value(const REdge& E, const REdge& K, int y, float x, bool top) {
-  const int off = top ? 1 : -1;
-  const float adj = (float)(y + off - (int)E.y0) * E.dx + (float)E.x0;
-  const float adjo = (float)(y + off - (int)K.y0) * K.dx + (float)K.x0;
-  short vv = R_NONE;
-  if (adj > x && adjo > x) {
-    const float v = (float)(pil_round_up(fminf(adj, adjo)) - 1);
-    if (v > x) vv = (short)(int)v;
-  } else if (adj < x && adjo < x) {
-    const float v = (float)(pil_round_up(fmaxf(adj, adjo)) + 1);
-    if (v < x) vv = (short)(int)v;
-  }
-  return vv;
-}
-
-// reg / attr / sgns: the records of the polygon's edges (index = edge); the caller has published this round's records.
-__device__ __forceinline__ void tip_search(const REdge* reg, const RAttr* attr, const signed char* sgns, int k, const REdge& E,
-                                           const RAttr& mine, int sgn, bool need_top, bool need_bot, int emin, int emax,
-                                           short* vtop, short* vbot) {
-  bool open_top = need_top && sgn != 0, open_bot = need_bot && sgn != 0;
-  int kt = -1, kb = -1;
-  const unsigned long long mt = (unsigned long long)mine.tw | ((unsigned long long)mine.xt << 32);
-  const unsigned long long mb = (unsigned long long)mine.bw | ((unsigned long long)mine.xb << 32);
-  for (int e = 0; __any(e < k && (open_top || open_bot)); ++e) {
-    const uint4 A = *reinterpret_cast<const uint4*>(attr + e);
-    const int S = sgns[e];
-    const bool act = e < k && S == sgn;
-    const bool ht = act && open_top && ((unsigned long long)A.x | ((unsigned long long)A.y << 32)) == mt;
-    const bool hb = act && open_bot && ((unsigned long long)A.z | ((unsigned long long)A.w << 32)) == mb;
-    kt = ht ? e : kt; open_top = open_top && !ht;
-    kb = hb ? e : kb; open_bot = open_bot && !hb;
-  }
-  short vt = R_NONE, vb = R_NONE;
-  if (__any(kt >= 0 || kb >= 0)) {
-    const REdge KT = reg[kt >= 0 ? kt : 0], KB = reg[kb >= 0 ? kb : 0];
-    const short a = tip_value(E, KT, emin, __uint_as_float(mine.xt), true), b = tip_value(E, KB, emax, __uint_as_float(mine.xb), false);
-    vt = kt >= 0 ? a : R_NONE;
-    vb = kb >= 0 ? b : R_NONE;
-  }
-  *vtop = vt; *vbot = vb;
-}
-
 // One crossing of table edge E with row y (push_crossing of moog_raster_kernel.h without the queues: a row that needs the
 // generic routine only gets its flag, the row stage finds it).
 __device__ __forceinline__ void push_row(RRow* rows, int rb, const REdge& E, int emin, int emax, int pymax, short vtop, short vbot, int y) {
@@ -193,19 +138,16 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
   const int E_ROUNDS = e_cap >> 6;
   REdge* edges = reinterpret_cast<REdge*>(moog_lds + pl.o_edge);
   RRow* rows = reinterpret_cast<RRow*>(moog_lds + pl.o_rows);
-  unsigned* rpts = reinterpret_cast<unsigned*>(moog_lds + pl.o_rpts) + 68 * wv;   // this wave's round
   int* item_y = reinterpret_cast<int*>(moog_lds + pl.o_item_y);
   unsigned* item_rgba = reinterpret_cast<unsigned*>(moog_lds + pl.o_rgba);
   int* rowbase = reinterpret_cast<int*>(moog_lds + pl.o_rowbase);
   unsigned* iinfo = reinterpret_cast<unsigned*>(moog_lds + pl.o_iinfo);
   unsigned long long* rowitems = reinterpret_cast<unsigned long long*>(moog_lds + pl.o_rowitems);
   uint8_t* rowitem = reinterpret_cast<uint8_t*>(moog_lds + pl.o_rowitem);
-    const int long_words = ((RW_LONG + RW_VLONG) > a.xxcap * RW_SLOW ? (RW_LONG + RW_VLONG) : a.xxcap * RW_SLOW);
+  unsigned short* pend = reinterpret_cast<unsigned short*>(moog_lds + pl.o_pend) + RW_PEND * wv;   // this wave's rare rows
+  const int long_words = ((RW_LONG + RW_VLONG) > a.xxcap * RW_SLOW ? (RW_LONG + RW_VLONG) : a.xxcap * RW_SLOW);
   unsigned* longlist = reinterpret_cast<unsigned*>(moog_lds + pl.o_long) + ((long_words + 3) & ~3) * wv;   // this wave's long edges (the others push their rows themselves)
   float* xxs = reinterpret_cast<float*>(longlist);
-  RAttr* attrs = reinterpret_cast<RAttr*>(moog_lds + pl.o_attr) + 64 * wv;             // this wave's round: edge attributes
-  signed char* sgns = reinterpret_cast<signed char*>(moog_lds + pl.o_sgn) + 64 * wv;
-  unsigned short* pend = reinterpret_cast<unsigned short*>(moog_lds + pl.o_pend) + RW_PEND * wv;   // this wave's rare rows
   int* misc = reinterpret_cast<int*>(moog_lds + pl.o_misc);      // shared: [5] / [6] the prefix's entries / colours differ
   int* wmisc = misc + 8 + 8 * wv;                                // per wave: [1] long list, [4] very long edges, [7] spare
   unsigned short* dummy = reinterpret_cast<unsigned short*>(moog_lds + pl.o_dummy) + 64 * wv + lane;   // where masked-off key stores go
@@ -220,13 +162,16 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
   auto round_first = [&](int r) -> int {   // first item of round r (n_items behind the last round)
     return r >= n_rounds ? n_items : __builtin_amdgcn_readlane(my_first, r & (DL_MAX_ROUNDS - 1));
   };
-  auto load_entry = [&](int r) -> uint2 {
-    uint2 en = make_uint2(0u, 0u);
-    if (r < n_rounds && lane < round_lanes(r)) en = *reinterpret_cast<const uint2*>(dl + DL_HDR + 2 * (r * 64 + lane));
+  struct Entry { uint4 e; unsigned info; };   // an edge record and its info word
+  auto load_entry = [&](int r) -> Entry {
+    Entry en;
+    en.e = make_uint4(0u, 0u, 0u, 0u); en.info = 0u;
+    if (r < n_rounds && lane < round_lanes(r)) { en.e = dl_edges(dl, r)[lane]; en.info = dl_infos(dl, r)[lane]; }
     return en;
   };
-  // the first rounds of this wave: on their way while the tables are cleared
-  uint2 en_a = load_entry(wv), en_b = load_entry(wv + RW_WAVES), en_c = load_entry(wv + 2 * RW_WAVES);
+  // the first rounds of this wave: on their way while the tables are set up
+  Entry en_a = load_entry(wv), en_b = load_entry(wv + RW_WAVES), en_c = load_entry(wv + 2 * RW_WAVES);
+  const unsigned iyw = lane < n_items ? dl[28 + lane] : 0u;
   const int NS = a.n_static;
   if (wv == RW_WAVES - 1) {   // colours: lane = sprite slot
     bool st_bad = false;
@@ -252,6 +197,17 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
     const bool any_bad = __any(st_bad);
     if (lane == 0) misc[6] = any_bad ? 1 : 0;
   }
+  if (wv == 0) {   // row ranges of the items (from the list), the prefix's entries against the reference's
+    if (lane < n_items) { item_y[2 * lane] = (short)(iyw & 0xffffu); item_y[2 * lane + 1] = (short)(iyw >> 16); }
+    bool bad = false;
+    if (NS > 0 && lane < a.nsl) {
+      const uint4 re = dl_edges(a.sref_dl, 0)[lane];
+      const unsigned ri = dl_infos(a.sref_dl, 0)[lane];
+      bad = lane >= round_lanes(0) || re.x != en_a.e.x || re.y != en_a.e.y || re.z != en_a.e.z || re.w != en_a.e.w || ri != en_a.info;
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) misc[5] = any_bad ? 1 : 0;
+  }
   for (int i = tid; i < r_cap; i += RW_THREADS) {
     uint4* r = reinterpret_cast<uint4*>(rows + i);
     r[0] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -259,25 +215,6 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
   }
   for (int y = tid; y < H; y += RW_THREADS) rowitems[y] = 0ull;
   if (lane < 8) wmisc[lane] = 0;
-  // ---- item row ranges: every round of the draw list, the wave's rounds ----------------------------------------------
-  {
-    bool bad = false;
-    for (int r = wv; r < n_rounds; r += RW_WAVES) {
-      const uint2 en = en_a;
-      en_a = en_b; en_b = en_c; en_c = load_entry(r + 3 * RW_WAVES);   // (three rounds ahead)
-      const bool valid = lane < round_lanes(r);
-      const int g = (int)(en.y & 255u), k = (int)((en.y >> 8) & 255u);
-      const int py = (short)(en.x >> 16);
-      if (r == 0 && NS > 0 && lane < a.nsl) {   // the prefix's entries against the reference's
-        const uint2 ref = *reinterpret_cast<const uint2*>(a.sref_dl + DL_HDR + 2 * lane);
-        bad = !valid || ref.x != en.x || ref.y != en.y;
-      }
-      if (valid && k == 0) { item_y[2 * g] = py; item_y[2 * g + 1] = py; }
-      wsync();
-      if (valid && k != 0) { atomicMin(&item_y[2 * g], py); atomicMax(&item_y[2 * g + 1], py); }
-    }
-    if (wv == 0) { const bool any_bad = __any(bad); if (lane == 0) misc[5] = any_bad ? 1 : 0; }
-  }
   rw_barrier();
   const bool prefix_ok = NS > 0 && n_items >= NS && n_rounds > 0 && misc[5] == 0 && misc[6] == 0;
   const unsigned bgx = ((unsigned)P->render.bg[0] & 255u) | (((unsigned)P->render.bg[1] & 255u) << 8) |
@@ -292,7 +229,7 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
     // ---- row records of the pass's items (lane = item; both waves compute the same) ---------------------------
     int r_lo = 0;
     while (r_lo + 1 < n_rounds && round_first(r_lo + 1) <= g_lo) ++r_lo;
-    en_a = load_entry(r_lo + wv); en_b = load_entry(r_lo + wv + RW_WAVES); en_c = load_entry(r_lo + wv + 2 * RW_WAVES);
+    if (!first_pass || r_lo != 0) { en_a = load_entry(r_lo + wv); en_b = load_entry(r_lo + wv + RW_WAVES); en_c = load_entry(r_lo + wv + 2 * RW_WAVES); }
     const int g_edge = round_first(r_lo + E_ROUNDS);   // the items behind it have no edge records in this pass
     int g_hi, total_rows;
     {
@@ -319,88 +256,37 @@ __device__ __forceinline__ void raster_wave(const RWArgs& a, const int env) {
     int r_hi = r_lo;
     while (r_hi + 1 < n_rounds && round_first(r_hi + 1) < g_hi) ++r_hi;
 
-    // ---- the wave's rounds: edges, corner fix-ups, crossing pushes -----------------------------------------------
+    // ---- the wave's rounds: the edges of the list mark their heads' rows and push their crossings --------------------
     if (a.debug_stop != 2 && g_hi > g_lo)
     for (int r = r_lo + wv; r <= r_hi; r += RW_WAVES) {
-      const uint2 en = en_a;
+      const Entry en = en_a;
       en_a = en_b; en_b = en_c; en_c = load_entry(r + 3 * RW_WAVES);   // (three rounds ahead)
       const bool valid = lane < round_lanes(r);
-      const int g = valid ? (int)(en.y & 255u) : 255, k = (int)((en.y >> 8) & 255u), nv = valid ? (int)((en.y >> 16) & 255u) : 0;
+      const int g = valid ? (int)(en.info & 255u) : 255, k = (int)((en.info >> 8) & 255u), nv = valid ? (int)((en.info >> 16) & 127u) : 0;
       const bool active = valid && g >= g_lo && g < g_hi;
       const int ebase = (r - r_lo) * 64;
-      rpts[lane] = en.x;
-      wsync();
-      // ---- the edge leaving the vertex (ImagingDrawPolygon: add_edge + merge of horizontal runs) ----------------
-      const short2* pv = reinterpret_cast<const short2*>(rpts) + (lane - k);
+      REdge E;
+      E.x0 = (short)(en.e.x & 0xffffu); E.y0 = (short)(en.e.x >> 16); E.x1 = (short)(en.e.y & 0xffffu); E.y1 = (short)(en.e.y >> 16);
+      E.dx = __uint_as_float(en.e.z); E.vtop = (short)(en.e.w & 0xffffu); E.vbot = (short)(en.e.w >> 16);
+      const int x0 = E.x0, y0 = E.y0, x1 = E.x1, y1 = E.y1;
+      const bool tbl = active && y0 != y1;
+      const bool head = active && (en.info & DL_INFO_HEAD) != 0u;
       const int iy1 = active ? item_y[2 * g + 1] : 0;
       const int rb = active ? rowbase[g] : 0;
-      const bool closing = (k + 1 == nv);
-      const short2 p1 = pv[closing ? 0 : k + 1];
-      const short2 pp = pv[k >= 1 ? k - 1 : 0];
-      const int x0 = (short)(en.x & 0xffffu), y0 = (short)(en.x >> 16), x1 = p1.x, y1 = p1.y;
-      const bool tbl = active && y0 != y1;
-      bool head = active && y0 == y1 && !(closing && x0 == x1);   // last == first: no closing edge
-      if (k >= 1 && !closing) {
-        const bool ab = pp.y == y0 && ((x1 > x0 && x0 > pp.x) || (x1 < x0 && x0 < pp.x));
-        // three equal vertices in a row (tiny circles): this zero-length head repeats the one before it
-        const bool rep = pp.x == x0 && pp.y == y0 && x1 == x0;
-        head = head && !ab && !rep;
-      }
-      REdge E;
-      E.x0 = (short)x0; E.y0 = (short)y0; E.x1 = (short)x1; E.y1 = (short)y1; E.vtop = R_NONE; E.vbot = R_NONE;
-      E.dx = ((float)(x1 - x0)) / (float)(tbl ? y1 - y0 : 1);
-      if (!tbl) E.dx = 0.0f;
-      if (__any(head)) {
-        if (head) {   // extend over the following absorbed edges (never the closing edge)
-          short hx = (short)x1;
-          int q = k + 1;
-          short2 prev, cur;
-          prev.x = (short)x0; prev.y = (short)y0; cur = p1;
-          while (q <= nv - 2) {
-            const short2 nxt = pv[q + 1];
-            const bool ab = (cur.y == nxt.y) && (prev.y == cur.y) &&
-                            ((nxt.x > cur.x && cur.x > prev.x) || (nxt.x < cur.x && cur.x < prev.x));
-            if (!ab) break;
-            hx = nxt.x; prev = cur; cur = nxt; ++q;
-          }
-          const short xmin = x0 < hx ? (short)x0 : hx, xmax = x0 < hx ? hx : (short)x0;
-          E.dx = __int_as_float((int)((unsigned)(unsigned short)xmin | ((unsigned)(unsigned short)xmax << 16)));
-        }
-      }
-      const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
-      const int sgn = tbl ? (E.dx > 0.0f ? 1 : (E.dx < 0.0f ? -1 : 0)) : 0;
-      RAttr mine;
-      {
-        const bool up = y0 < y1;
-        const unsigned w0 = rw_pack(x0, y0), w1 = rw_pack(x1, y1);
-        mine.tw = sgn != 0 ? (up ? w0 : w1) : RW_NOPOINT;
-        mine.bw = sgn != 0 ? (up ? w1 : w0) : RW_NOPOINT;
-        mine.xt = __float_as_uint((float)(emin - y0) * E.dx + (float)x0);
-        mine.xb = __float_as_uint((float)(emax - y0) * E.dx + (float)x0);
-      }
-      *reinterpret_cast<uint4*>(attrs + lane) = make_uint4(mine.tw, mine.xt, mine.bw, mine.xb);
-      sgns[lane] = (signed char)sgn;
       if (active) {
-        edges[ebase + lane] = E;
+        *reinterpret_cast<uint4*>(edges + ebase + lane) = en.e;
         if (k == 0) iinfo[g] = (unsigned)(ebase + lane) | ((unsigned)nv << 16);
       }
-      wsync();
       if (a.debug_stop == 3) continue;
       // ---- horizontal heads mark their row ----------------------------------------------------------------------
       if (__any(head)) {
         if (head && y0 >= 0 && y0 < H) atomicOr(&rows[rb + y0].hbits, 1u << (k & 31));
       }
-      // ---- corner fix-up partners, then the crossings of the edge's first four rows ------------------------------
+      // ---- the crossings of the edge's first four rows -----------------------------------------------------------
       const int pymax = iy1 > H ? H : iy1;    // polygon_generic clamps ymax to ysize
-      short vtop = R_NONE, vbot = R_NONE;
-      if (a.debug_stop != 31)
-      tip_search(edges + ebase + (lane - k), attrs + (lane - k), sgns + (lane - k), k, E, mine, sgn, emin >= 0 && emin < H,
-                 emax < H && emax >= pymax, emin, emax, &vtop, &vbot);
-      if (a.debug_stop == 32) continue;
+      const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
+      const short vtop = E.vtop, vbot = E.vbot;
       const int ya = emin < 0 ? 0 : emin, yb = emax > H - 1 ? H - 1 : emax;
-      if (__any(tbl && yb - ya >= 4 && (vtop != R_NONE || vbot != R_NONE))) {   // (listed long edges read them back)
-        if (tbl) { edges[ebase + lane].vtop = vtop; edges[ebase + lane].vbot = vbot; }
-      }
       unsigned pos[4], key[4], nn[4];
       bool on[4], fix[4], gen[4];
 #pragma unroll
