@@ -5,10 +5,13 @@ os.environ['MOOG_STEP_DEBUG'] = '128'
 import numpy as np, torch
 from moog import environment
 from moog_demos import example_configs
-env = environment.BatchedEnvironment(num_envs=4096, seed=1, **example_configs.load('colliding_predators_32'))
+NAME = sys.argv[1] if len(sys.argv) > 1 else 'colliding_predators_32'
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+env = environment.BatchedEnvironment(num_envs=N, seed=1, **example_configs.load(NAME))
 env.check_faults = False
 env.reset()
-for k in range(60):
+for k in range(STEPS):
     ts = env.step(env.random_action())
     if k % 10 == 9:
         c = ts.discount.cpu().numpy()
@@ -23,4 +26,4 @@ for k in range(60):
             coef[0], coef[1], coef[2], npath.mean(), nresp.mean()),
             [(int(c[i]), int(npath[i]), int(nresp[i])) for i in order])
         q = np.percentile(c, [0, 10, 50, 90, 99, 99.9, 100])
-        print('step %d cycles/env: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f  mean %.0f' % ((k,) + tuple(q) + (c.mean(),)))
+        print('step %d cycles/env: min %.0f p10 %.0f p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f  mean %.0f  slowest/mean %.2f' % ((k,) + tuple(q) + (c.mean(), c.max() / c.mean())))

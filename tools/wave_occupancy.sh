@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 run() {
   rm -rf $R/gpurun_out/prof_o && mkdir -p $R/gpurun_out/prof_o
   env "$@" rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_o/trace -o r1 -- python3 $R/tools/raster_only.py > $R/gpurun_out/prof_o/log 2>&1
-  echo "$@ :" $(python3 $R/tools/prof_summary.py $R/gpurun_out/prof_o | grep raster_wave | awk '{print $(NF-3)}')
+  echo "$@ :" $(python3 $R/tools/prof_summary.py $R/gpurun_out/prof_o | grep -E "raster_wave|moog_raster_kernel" | awk '{print $(NF-3)}')
 }
 run X=0
 for pad in 3000 6000 10000 15000 24000 36000; do run MOOG_WAVE_LDS_PAD=$pad; done

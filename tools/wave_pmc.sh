@@ -2,7 +2,7 @@
 # usage: bash tools/wave_pmc.sh [stops...]   (default 3 4 5 0; 3 = no pushes / rows / compose, 4 = no rows / compose, 5 = no compose)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for stop in ${@:-2 3 32 4 5 31 0}; do
+for stop in ${@:-2 3 4 5 0}; do
   rm -rf $R/gpurun_out/prof_w && mkdir -p $R/gpurun_out/prof_w
   MOOG_RASTER_STOP=$stop rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $R/gpurun_out/prof_w/pmc_sq -o r1 -- python3 $R/tools/raster_only.py > $R/gpurun_out/prof_w/log1 2>&1
   echo "== stop $stop (per frame)"
