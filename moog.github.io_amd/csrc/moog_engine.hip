@@ -59,8 +59,11 @@ struct moog_engine {
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
   int aa = 1, canvas_w = 0, canvas_h = 0, aa_chunk = 0;
-  uint8_t* aa_canvas = nullptr;   // [aa_chunk][canvas_h][canvas_w][3]
-  uint8_t* aa_tmp = nullptr;      // [aa_chunk][canvas_h][width][3]
+  int pad_w = 0;                  // canvas_w rounded up to a multiple of 16: the width the rasteriser draws (pil_renderer.py:64-66
+                                  // accepts any size; the extra columns are what Pillow would draw on a wider image, and are dropped)
+  uint8_t* pad_img = nullptr;     // [n_envs][canvas_h][pad_w][3] when pad_w != canvas_w without anti-aliasing (cropped into the caller's frames)
+  uint8_t* aa_canvas = nullptr;   // [aa_chunk][canvas_h][pad_w][3]
+  uint8_t* aa_tmp = nullptr;      // [aa_chunk][canvas_h][width rounded up to 4][3]
   int32_t* aa_tables = nullptr;   // bounds + coefficients of both axes
   RResize aa_resize{};
   int raster_chunk = 0, raster_words = 0, raster_iwords = 0, raster_hwords = 1, raster_xxcap = 4;
@@ -116,6 +119,7 @@ static void free_engine(moog_engine* e) {
   if (e->d_dl) hipFree(e->d_dl);
   if (e->s_dl) hipFree(e->s_dl);
   if (e->aa_canvas) hipFree(e->aa_canvas);
+  if (e->pad_img) hipFree(e->pad_img);
   if (e->aa_tmp) hipFree(e->aa_tmp);
   if (e->aa_tables) hipFree(e->aa_tables);
   if (e->fault_flag) hipHostFree(e->fault_flag);
@@ -178,8 +182,8 @@ static int validate(const moog_program_t* p) {
   {
     const int aa = p->render.aa > 1 ? p->render.aa : 1;
     const long long cw = (long long)aa * p->render.width, ch = (long long)aa * p->render.height;
-    if (cw % 16 != 0 || cw < 16 || cw > 8192 || ch < 1 || ch > 8192 || aa > 16)
-      return fail(MOOG_E_UNSUPPORTED, "render size unsupported (canvas width % 16 == 0, 16 <= canvas width <= 8192, canvas height <= 8192)");
+    if (cw < 1 || cw > 8192 || ch < 1 || ch > 8192 || aa > 16)
+      return fail(MOOG_E_UNSUPPORTED, "render size unsupported (1 <= anti_aliasing x width, height <= 8192, anti_aliasing <= 16)");
   }
   return MOOG_OK;
 }
@@ -246,15 +250,16 @@ static int setup_anti_aliasing(moog_engine* e) {
     if (b1 - b0 > hspan) hspan = b1 - b0;
   }
   hspan = (hspan + 7) & ~3;
-  e->aa_resize = RResize{e->canvas_w, e->canvas_h, ow, oh, kh, kv, dbh, dbv, dch, dcv, hspan};
+  const int tstride = (ow + 3) & ~3;
+  e->aa_resize = RResize{e->canvas_w, e->canvas_h, ow, oh, kh, kv, dbh, dbv, dch, dcv, hspan, e->pad_w, tstride};
   // canvases of a chunk of envs at a time: at most 1 GiB of scratch
-  const size_t canvas = (size_t)e->canvas_w * e->canvas_h * 3;
+  const size_t canvas = (size_t)e->pad_w * e->canvas_h * 3;
   size_t chunk = ((size_t)1 << 30) / canvas;
   if (chunk < 1) chunk = 1;
   if (chunk > (size_t)e->n_envs) chunk = (size_t)e->n_envs;
   e->aa_chunk = (int)chunk;
   if (hipMalloc(&e->aa_canvas, chunk * canvas) != hipSuccess ||
-      hipMalloc(&e->aa_tmp, chunk * (size_t)e->canvas_h * ow * 3) != hipSuccess)
+      hipMalloc(&e->aa_tmp, chunk * (size_t)e->canvas_h * tstride * 3) != hipSuccess)
     return fail(MOOG_E_NOMEM, "hipMalloc(anti-aliasing canvas) failed");
   return MOOG_OK;
 }
@@ -266,7 +271,7 @@ static int build_static_prefix(moog_engine* e) {
   const int ns = getenv("MOOG_RASTER_NO_STATIC") ? 0 : static_prefix_slots(&e->prog, &nsv);
   if (ns == 0) return MOOG_OK;
   const size_t fb = (size_t)e->L.f64_per_env * 8, ib = (size_t)e->L.i32_per_env * 4;
-  const size_t pb = (size_t)e->canvas_w * e->canvas_h * 3;
+  const size_t pb = (size_t)e->pad_w * e->canvas_h * 3;
   if (hipMalloc(&e->s_f64, fb) != hipSuccess || hipMalloc(&e->s_i32, ib) != hipSuccess ||
       hipMalloc(&e->s_bg, pb) != hipSuccess)
     return fail(MOOG_E_NOMEM, "hipMalloc(static prefix) failed");
@@ -358,10 +363,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->aa = prog->render.aa > 1 ? prog->render.aa : 1;
     e->canvas_w = e->aa * prog->render.width;
     e->canvas_h = e->aa * prog->render.height;
-    int tw = e->canvas_w <= 128 ? e->canvas_w : 128;
-    while (e->canvas_w % tw != 0) tw -= 16;
+    e->pad_w = (e->canvas_w + 15) & ~15;
+    int tw = e->pad_w <= 128 ? e->pad_w : 128;
+    while (e->pad_w % tw != 0) tw -= 16;
     e->raster_tile_w = tw;
-    e->raster_tiles_x = e->canvas_w / tw;
+    e->raster_tiles_x = e->pad_w / tw;
     e->raster_band_h = e->canvas_h <= 128 ? e->canvas_h : 64;
     e->raster_bands = (e->canvas_h + e->raster_band_h - 1) / e->raster_band_h;
     int W = e->raster_tile_w, H = e->raster_band_h;   // (the LDS plan is per tile)
@@ -418,7 +424,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     const char* wv = getenv("MOOG_RASTER_WAVE");
     const bool want = (on && atoi(on) == 1) || (wv && atoi(wv) == 1);
     e->dlist = want && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
-               e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 &&
+               e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 && e->pad_w == e->canvas_w &&
                prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
     e->wave = e->dlist && wv && atoi(wv) == 1;
     if (e->dlist) {
@@ -504,6 +510,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     }
   int rc2 = build_static_prefix(e);
   if (rc2 == MOOG_OK) rc2 = setup_anti_aliasing(e);
+  if (rc2 == MOOG_OK && e->aa <= 1 && e->pad_w != e->canvas_w &&
+      hipMalloc(&e->pad_img, (size_t)n_envs * e->canvas_h * e->pad_w * 3) != hipSuccess)
+    rc2 = fail(MOOG_E_NOMEM, "hipMalloc(16-aligned frames) failed");
   if (rc2) { free_engine(e); return rc2; }
   *out = e;
   return MOOG_OK;
@@ -605,7 +614,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;
   r.tile_w = e->raster_tile_w; r.band_h = e->raster_band_h; r.tiles_x = e->raster_tiles_x; r.bands = e->raster_bands;
-  r.canvas_w = e->canvas_w; r.canvas_h = e->canvas_h; r.flip = e->aa > 1 ? 0 : 1;
+  r.canvas_w = e->pad_w; r.scale_w = e->canvas_w; r.canvas_h = e->canvas_h; r.flip = e->aa > 1 ? 0 : 1;
   r.iwords = e->raster_iwords; r.hwords = e->raster_hwords; r.xxcap = e->raster_xxcap;
   r.debug_stop = e->raster_stop;
   r.n_static = e->n_static; r.nsv = e->nsv; r.build = 0;
@@ -661,7 +670,11 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int time
     if (!pre) r.n_static = 0;
   }
   Bracket br(e, MOOG_K_RASTER, s, timed);
-  if (e->aa <= 1) {
+  if (e->aa <= 1 && e->pad_w != e->canvas_w) {   // drawn 16-aligned, cropped into the caller's frames
+    r.image = e->pad_img;
+    moog_raster_launch(r, e->raster_lds, s);
+    moog_crop_launch(e->pad_img, image, (size_t)e->n_envs * e->canvas_h, e->pad_w * 3, e->canvas_w * 3, s);
+  } else if (e->aa <= 1) {
     moog_raster_launch(r, e->raster_lds, s);
   } else {   // pil_renderer.py:111-112: draw on the large canvas, then Image.resize(LANCZOS); a chunk of envs at a time
     const size_t frame = (size_t)e->prog.render.width * e->prog.render.height * 3;
@@ -833,8 +846,8 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
 int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
   if (!enabled) { e->fused = false; return MOOG_OK; }
-  if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1)
-    return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing");
+  if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1 || e->pad_w != e->canvas_w)
+    return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing, of a width that is a multiple of 16");
   if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
   {   // tools that run one kernel at a time (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) would leave the frames' grid
       // waiting for a step kernel that cannot start beside it; MOOG_NO_FUSED=1 is the manual switch
@@ -920,8 +933,11 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
   if (image_dev && e->n_static > 0) {
     HIPCHK(hipSetDevice(e->device));
     if (e->aa > 1) return fail(MOOG_E_UNSUPPORTED, "the cached picture of an anti-aliased renderer is canvas sized");
-    HIPCHK(hipMemcpyAsync(image_dev, e->s_bg, (size_t)e->prog.render.width * e->prog.render.height * 3,
-                          hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
+    if (e->pad_w != e->canvas_w)
+      moog_crop_launch(e->s_bg, image_dev, (size_t)e->canvas_h, e->pad_w * 3, e->canvas_w * 3, (hipStream_t)hip_stream);
+    else
+      HIPCHK(hipMemcpyAsync(image_dev, e->s_bg, (size_t)e->prog.render.width * e->prog.render.height * 3,
+                            hipMemcpyDeviceToDevice, (hipStream_t)hip_stream));
   }
   return MOOG_OK;
 }

@@ -60,7 +60,10 @@ struct RArgs {
   int32_t band_h;      // rows per workgroup tile
   int32_t tiles_x;     // tiles per canvas row
   int32_t bands;       // tile rows per canvas
-  int32_t canvas_w, canvas_h;   // the canvas: anti_aliasing x the observation size (pil_renderer.py:65-66)
+  int32_t canvas_w, canvas_h;   // the canvas in memory: anti_aliasing x the observation size (pil_renderer.py:65-66), the width
+                                // rounded up to a multiple of 16 (the rasteriser works in 16-pixel segments)
+  int32_t scale_w;     // the canvas width the vertices are scaled by (= canvas_w unless that was rounded up: the extra
+                       // columns are drawn like Pillow would draw a wider image and cropped by the caller)
   int32_t flip;        // 1: rows are written bottom-up (np.flipud, pil_renderer.py:118); 0 for a canvas that is down-sampled next
   int32_t iwords;      // 32-bit words of a segment's item bitmask
   int32_t hwords;      // 32-bit words of an item's head bitmask
@@ -231,7 +234,10 @@ void moog_raster_wave_launch(const RWArgs& a, size_t lds_bytes, hipStream_t stre
 // moog_raster.hip: the kernel's own translation unit
 // Image.resize(LANCZOS) of a batch of canvases [n][ch][cw][3] -> observations [n][oh][ow][3], flipped; tmp: [n][ch][ow][3]
 struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_t* bv; const int32_t* ch_coef; const int32_t* cv_coef;
-                 int32_t hspan; /* bytes of a canvas row that 256 consecutive output columns read, at most (+ alignment slack) */ };
+                 int32_t hspan; /* bytes of a canvas row that 256 consecutive output columns read, at most (+ alignment slack) */
+                 int32_t cstride, tstride; /* pixels per canvas row / per row of the intermediate picture in memory (multiples of 4) */ };
+// Rows of `row_bytes` bytes out of rows `in_stride` bytes apart (frames whose width is not a multiple of 16 are drawn wider).
+void moog_crop_launch(const uint8_t* in, uint8_t* out, size_t rows, int in_stride, int row_bytes, hipStream_t stream);
 void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream);
 int moog_raster_configure(size_t lds_bytes);   // hipFuncSetAttribute(max dynamic LDS); returns a hipError_t
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream);

@@ -216,11 +216,11 @@ __global__ __launch_bounds__(256) void moog_resize_h_kernel(RResize r, const uin
   const int x0 = (int)blockIdx.x * 256, xx = x0 + (int)threadIdx.x;
   const int xl = (x0 + 255 < r.ow) ? x0 + 255 : r.ow - 1;
   const int b0 = (3 * r.bh[2 * x0]) & ~3, b1 = 3 * (r.bh[2 * xl] + r.bh[2 * xl + 1]);
-  const uint8_t* rowp = in + row * (size_t)r.cw * 3;
+  const uint8_t* rowp = in + row * (size_t)r.cstride * 3;
   const uint32_t* src = reinterpret_cast<const uint32_t*>(rowp + b0);
   uint32_t* dst = reinterpret_cast<uint32_t*>(stage);
   const int ndw = (b1 - b0 + 3) >> 2;
-  const int row_dw = (r.cw * 3 - b0) >> 2;   // dwords left in the row (its length is a multiple of 4)
+  const int row_dw = (r.cstride * 3 - b0) >> 2;   // dwords left in the row (its length in memory is a multiple of 4)
   for (int t = threadIdx.x; t < ndw; t += 256) dst[t] = t < row_dw ? src[t] : 0u;
   __syncthreads();
   if (xx >= r.ow) return;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void moog_resize_h_kernel(RResize r, const uin
   const uint8_t* p = stage + (3 * xmin - b0);
   int s0 = 1 << (R_PRECISION_BITS - 1), s1 = s0, s2 = s0;
   for (int x = 0; x < xmax; ++x) { const int kk = k[x]; s0 += p[3 * x] * kk; s1 += p[3 * x + 1] * kk; s2 += p[3 * x + 2] * kk; }
-  uint8_t* o = tmp + (row * r.ow + xx) * 3;
+  uint8_t* o = tmp + (row * r.tstride + xx) * 3;
   o[0] = (uint8_t)r_clip8(s0); o[1] = (uint8_t)r_clip8(s1); o[2] = (uint8_t)r_clip8(s2);
 }
 
@@ -237,21 +237,37 @@ __global__ __launch_bounds__(256) void moog_resize_h_kernel(RResize r, const uin
 // thread takes four consecutive bytes (one dword load per tap).  grid: x = dword blocks of a row, y = output row, z = env.
 __global__ __launch_bounds__(256) void moog_resize_v_kernel(RResize r, const uint8_t* tmp, uint8_t* out, int n) {
   const int d = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  const int row_dw = (r.ow * 3) >> 2;
+  const int row_dw = (r.tstride * 3) >> 2;
   if (d >= row_dw) return;
   const int yy = (int)blockIdx.y;
   const size_t env = blockIdx.z;
   const int ymin = r.bv[2 * yy], ymax = r.bv[2 * yy + 1];
   const int32_t* k = r.cv_coef + (size_t)yy * r.kv;
-  const uint8_t* p = tmp + (env * r.ch + ymin) * (size_t)r.ow * 3 + 4 * (size_t)d;
+  const uint8_t* p = tmp + (env * r.ch + ymin) * (size_t)r.tstride * 3 + 4 * (size_t)d;
   int s0 = 1 << (R_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
   for (int y = 0; y < ymax; ++y) {
     const int kk = k[y];
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)y * r.ow * 3);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(p + (size_t)y * r.tstride * 3);
     s0 += (int)(w & 255u) * kk; s1 += (int)((w >> 8) & 255u) * kk; s2 += (int)((w >> 16) & 255u) * kk; s3 += (int)(w >> 24) * kk;
   }
-  uint8_t* o = out + (env * r.oh + (r.oh - 1 - yy)) * (size_t)r.ow * 3 + 4 * (size_t)d;
-  o[0] = (uint8_t)r_clip8(s0); o[1] = (uint8_t)r_clip8(s1); o[2] = (uint8_t)r_clip8(s2); o[3] = (uint8_t)r_clip8(s3);
+  uint8_t* o = out + (env * r.oh + (r.oh - 1 - yy)) * (size_t)r.ow * 3;   // (rows of the frame need not be dword aligned)
+  const int b = 4 * d, nb = r.ow * 3;
+  if (b < nb) o[b] = (uint8_t)r_clip8(s0);
+  if (b + 1 < nb) o[b + 1] = (uint8_t)r_clip8(s1);
+  if (b + 2 < nb) o[b + 2] = (uint8_t)r_clip8(s2);
+  if (b + 3 < nb) o[b + 3] = (uint8_t)r_clip8(s3);
+}
+
+__global__ __launch_bounds__(256) void moog_crop_kernel(const uint8_t* in, uint8_t* out, size_t rows, int in_stride, int row_bytes) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint8_t* src = in + row * (size_t)in_stride;
+  uint8_t* dst = out + row * (size_t)row_bytes;
+  for (int b = threadIdx.x & 63; b < row_bytes; b += 64) dst[b] = src[b];
+}
+
+void moog_crop_launch(const uint8_t* in, uint8_t* out, size_t rows, int in_stride, int row_bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(moog_crop_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, in, out, rows, in_stride, row_bytes);
 }
 
 void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream) {
@@ -259,10 +275,10 @@ void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, u
   const size_t rows = (size_t)n * r.ch;   // (grid.y is limited to 65535: the rest goes to z)
   const unsigned gy = (unsigned)(rows < 65535u ? rows : 65535u), gz = (unsigned)((rows + 65534u) / 65535u);
   hipLaunchKernelGGL(moog_resize_h_kernel, dim3(bx, gy, gz), dim3(256), (size_t)r.hspan, stream, r, canvas, tmp, n);
-  const unsigned bd = (unsigned)(((r.ow * 3 >> 2) + 255) / 256);
+  const unsigned bd = (unsigned)(((r.tstride * 3 >> 2) + 255) / 256);
   for (int e0 = 0; e0 < n; e0 += 65535) {   // (grid.z likewise)
     const int m = n - e0 < 65535 ? n - e0 : 65535;
     hipLaunchKernelGGL(moog_resize_v_kernel, dim3(bd, (unsigned)r.oh, (unsigned)m), dim3(256), 0, stream, r,
-                       tmp + (size_t)e0 * r.ch * r.ow * 3, out + (size_t)e0 * r.oh * r.ow * 3, m);
+                       tmp + (size_t)e0 * r.ch * r.tstride * 3, out + (size_t)e0 * r.oh * r.ow * 3, m);
   }
 }

@@ -611,7 +611,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
     bool in_tile = true;
     if (tiles > 1 && alive && !torus && P->render.polymod != MOOG_POLYMOD_FIRST_PERSON) {
       const double px = gf[a.L.o_pos + 2 * s], py = gf[a.L.o_pos + 2 * s + 1], rad = gf[a.L.o_maxr + s];
-      const double x0 = (px - rad) * (double)WF - 2.0, x1 = (px + rad) * (double)WF + 2.0;
+      const double x0 = (px - rad) * (double)a.scale_w - 2.0, x1 = (px + rad) * (double)a.scale_w + 2.0;
       const double y0 = (py - rad) * (double)H - 2.0, y1 = (py + rad) * (double)H + 2.0;
       if (x1 < (double)xoff || x0 > (double)(xoff + W) || y1 < (double)yb0 || y0 > (double)yb1) in_tile = false;
     }
@@ -680,7 +680,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
       double vx = v.x, vy = v.y;
       if (torus) { vx = vx + (double)(c / 3 - 1); vy = vy + (double)(c % 3 - 1); }
       if (first_person) { vx = vx + fpx; vy = vy + fpy; }
-      int ix = pil_int((double)WF * vx), iy = pil_int((double)H * vy);
+      int ix = pil_int((double)a.scale_w * vx), iy = pil_int((double)H * vy);
       short2 o; o.x = clamp16(ix); o.y = clamp16(iy);
       ivert[c * TOTV + idx] = o;
       int it = s * ncopy + c;

@@ -3,7 +3,9 @@
 reference moog/observers/pil_renderer.py:64-66,111-112), non-square observations, translucent sprites on a
 coloured background -- pinned by golden vectors captured from the reference (tests/golden/aa_zoo_*.npz).
 level 0: 64 x 48 observation, anti_aliasing 3;  level 1: 32 x 32, anti_aliasing 2, TorusGeometry;
-level 2: 128 x 128, anti_aliasing 2 (a 256 x 256 canvas: several tiles of the rasteriser)."""
+level 2: 128 x 128, anti_aliasing 2 (a 256 x 256 canvas: several tiles of the rasteriser);
+levels 3-5: sizes that are no multiples of 16 or 4 (pil_renderer.py:64-66 takes any size): 50 x 37, anti_aliasing 1;
+30 x 22, anti_aliasing 3 (a 90 x 66 canvas); 150 x 41, anti_aliasing 1, TorusGeometry (two tiles, the second one partly off the frame)."""
 import collections
 
 import numpy as np
@@ -15,7 +17,8 @@ from moog.state_initialization import sprite_generators
 
 def get_config(level):
     size, aa, modifier = [((64, 48), 3, None), ((32, 32), 2, polygon_modifiers.TorusGeometry(['movers', 'agent'])),
-                          ((128, 128), 2, None)][level]
+                          ((128, 128), 2, None), ((50, 37), 1, None), ((30, 22), 3, None),
+                          ((150, 41), 1, polygon_modifiers.TorusGeometry(['movers', 'agent']))][level]
     mover_factors = distribs.Product(
         [distribs.Continuous('x', 0.15, 0.85), distribs.Continuous('y', 0.15, 0.85),
          distribs.Discrete('shape', ['triangle', 'star_5', 'circle', 'spoke_4']),

@@ -746,6 +746,9 @@ def main():
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),
         ('aa_zoo_l2', 12, {}, (0,)),
+        ('aa_zoo_l3', 30, {}, (0,)),
+        ('aa_zoo_l4', 30, {}, (0,)),
+        ('aa_zoo_l5', 30, {}, (0,)),
     ]
     for name, n_calls, caps, seeds in plan:
         for seed in seeds:

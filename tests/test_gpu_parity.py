@@ -18,7 +18,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
         ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1),
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
-        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
+        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
         ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
@@ -229,6 +229,29 @@ def test_static_prefix_cache_and_fallback(name, monkeypatch):
     env2 = make_env(name, n, seed=5, env_index0=40)
     upload(env2, f, q)
     assert np.array_equal(env2.observation()['image'].cpu().numpy(), img)
+
+
+@pytest.mark.parametrize('size', [(64, 64), (50, 37), (150, 41)])
+def test_static_prefix_picture(size):
+    """moog_engine_static_prefix hands out the cached picture of the leading constant sprites in frame layout
+    (uint8[H, W, 3], also when the rasteriser drew it 16-aligned): equal to the oracle's frame of a state in which
+    every other sprite is gone."""
+    from moog import environment, observers
+    from moog_demos import example_configs
+    cfg = example_configs.load('colliding_predators_32')
+    old = cfg['observers']['image']
+    cfg['observers'] = {'image': observers.PILRenderer(image_size=size, bg_color=old._bg_color, color_to_rgb=old.color_to_rgb)}
+    env = environment.BatchedEnvironment(num_envs=4, seed=5, **cfg)
+    o = helpers.OracleEnv(env.compiled, n_envs=4, seed=5)
+    env.reset()
+    ns, pic = env.static_prefix()
+    assert ns == 4 and tuple(pic.shape) == (size[1], size[0], 3)
+    f, q = download(env)
+    L = env.layout
+    q[:, L.o_flags + ns:L.o_flags + L.S] &= ~1
+    o.f64[:], o.i32[:] = f, q
+    assert np.array_equal(pic.cpu().numpy(), o.render()[0])
+    env.close()
 
 
 def test_philox_bit_exact():
@@ -1316,11 +1339,14 @@ def test_example_configs_run(name, levels):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('size,aa', [((64, 64), 2), ((64, 48), 3), ((32, 32), 4), ((48, 64), 5), ((16, 16), 8),
-                                     ((32, 16), 16), ((512, 256), 2), ((272, 272), 3), ((1024, 64), 2)])
+                                     ((32, 16), 16), ((512, 256), 2), ((272, 272), 3), ((1024, 64), 2),
+                                     ((50, 37), 1), ((17, 9), 1), ((1000, 30), 1), ((131, 131), 1), ((30, 22), 3), ((17, 9), 2),
+                                     ((33, 35), 7), ((201, 77), 2), ((1, 1), 1), ((5, 3), 16)])
 def test_anti_aliasing_sweep(size, aa):
     """PILRenderer(anti_aliasing=aa) (pil_renderer.py:64-66,111-112) over scale factors 2..16 and frame shapes whose
     rows span one and several blocks of the resize kernels: canvas + both LANCZOS passes against the oracle's
-    restatement of Pillow's resample (itself pinned by tests/golden/resize.npz)."""
+    restatement of Pillow's resample (itself pinned by tests/golden/resize.npz).  Any size is accepted, as by the
+    reference: a canvas whose width is no multiple of 16 is drawn 16-aligned and cropped."""
     from moog import environment, observers
     from moog_demos import example_configs
     cfg = example_configs.load('colliding_predators_32')
