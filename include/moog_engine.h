@@ -119,14 +119,20 @@ enum {
   MOOG_CELL_SAMPLED,    /* the cell_arg-th point of that sample                                            */
   MOOG_CELL_OPEN_RANK,  /* the cell_arg-th open cell in np.argwhere order (rows outer; pacman.py:62-65)     */
   MOOG_CELL_WALL_RANK,  /* the cell_arg-th wall cell in Maze.to_sprites order (columns outer; maze.py:101-103) */
-  MOOG_CELL_HDRAW,      /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW) */
+  MOOG_CELL_HDRAW,      /* not a cell: an op without sprites that takes direct draw cell_arg (MOOG_X_HDRAW).  code_off >= 0:
+                         * the accept test of a rejection loop over this draw (`while not ok: a = np.random.uniform(..);
+                         * ok = test(a)`, match_to_sample.py:33-43): the draw is retaken, one uniform per try, until the
+                         * expression at dcode[code_off] is true (MOOG_DIST_MAX_TRIES tries: MOOG_FAULT_SAMPLER_EXHAUSTED) */
   MOOG_CELL_CHOICE,     /* not a cell: np.random.choice(count_max alternatives, p) of a sample_generator: the picked index
                          * goes to o_hdraw[cell_arg]; factors[0].cand_off >= 0: the normalised cumulative
                          * probabilities in program.cand (searchsorted(cdf, u, 'right')), else int(u * n) (no draw
                          * for n == 1)                                                                            */
-  MOOG_CELL_SHUFFLE     /* not a cell: sprite_generators.shuffle (sprite_generators.py:157-183): the live sprites in
+  MOOG_CELL_SHUFFLE,    /* not a cell: sprite_generators.shuffle (sprite_generators.py:157-183): the live sprites in
                          * slots slot0 .. slot0 + cell_arg - 1 (a packed prefix) are permuted as np.random.shuffle
                          * permutes their list; slot slot0 + cell_arg is a spare used while swapping              */
+  MOOG_CELL_HEXPR       /* not a cell: o_hdraw[cell_arg] = the value of the expression at dcode[code_off] -- a value the
+                         * initializer computed from its draws and uses several times (the compare-exchange outputs of
+                         * np.sort over drawn values, match_to_sample.py:46); read back with MOOG_X_HDRAW            */
 };
 
 /* Distribution programs.  A factor distribution that is not a flat Product of
@@ -185,8 +191,16 @@ enum {
   MOOG_X_HDRAW,      /* push uniform a of this reset (the a-th direct np.random call of the initializer)        */
   MOOG_X_SLOT_ATTR,  /* push attribute a (MOOG_XA_*) of sprite slot b (a factor copied from an earlier sprite)  */
   MOOG_X_STORE_VERT, /* pop -> component a of the raw shape being built (vertex a / 2, x or y)                   */
-  MOOG_X_FACTOR      /* push factor a (MOOG_FAC_*) of the sprite being created, as just sampled: the argument of a
+  MOOG_X_FACTOR,     /* push factor a (MOOG_FAC_*) of the sprite being created, as just sampled: the argument of a
                       * DependentDistribution's dependent_fn (distributions.py:420-475)                           */
+  MOOG_X_SLOT_CONST, /* push cand[a + slot of sprite b]: `sprite.metadata[key]`, a per-slot constant of the config
+                      * (match_to_sample.py:120-124,171; NaN where the config stored none)                        */
+  MOOG_X_FMA,        /* pop c, b, a; push fma(a, b, c) -- float64: ONE rounding, what np.dot / 1-D np.linalg.norm of
+                      * float64 2-vectors do (OpenBLAS ddot); float32 operands: a * b + c, two roundings */
+  MOOG_X_RULE_STATE2,/* push the second state scalar of rule a (o_rule2: a Phase's drawn duration, the second
+                      * uniform of a MOOG_RULE_DRAWS rule)                                                       */
+  MOOG_X_ZIP_ATTR    /* push attribute a of the sprite at sprite 0's list position in layer b: the partner of a
+                      * `for t, c in zip(state[A], state[B])` loop in a config-local rule (match_to_sample.py:71) */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -340,9 +354,13 @@ enum {
                                       of l0 has been within p0 of the first sprite of l1 (the number the
                                       reference keeps in meta_state[key]); conditions read it through
                                       MOOG_X_RULE_STATE                                                   */
-  MOOG_RULE_STATE_SLOT             /* not a rule of the reference: a per-env scalar that belongs to another component
+  MOOG_RULE_STATE_SLOT,            /* not a rule of the reference: a per-env scalar that belongs to another component
                                       (DeterministicMazeWalk's read position); never stepped, never reset -- it lives
                                       as long as the environment, like the Python object it stands for    */
+  MOOG_RULE_DRAWS                  /* the np.random calls at the top of a config-local rule's step (match_to_sample.py:
+                                      68-69): i0 = 1 or 2 uniforms taken when the rule is stepped, kept in the rule's
+                                      two state scalars (o_rule, o_rule2) for the MODIFY_SPRITES rules that follow it
+                                      (MOOG_X_RULE_STATE / MOOG_X_RULE_STATE2)                             */
 };
 /* sprite filters: ALWAYS, or the expression at rule.xfilter */
 enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };

@@ -2154,6 +2154,22 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
     if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_SLOT_CONST) { v[n] = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
+    if (op == MOOG_X_RULE_STATE2) { v[n] = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
+      const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
+      int t; v[n] = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
+    }
+    if (op == MOOG_X_FMA) {   // np.dot / 1-D np.linalg.norm of float64 2-vectors: one rounding (npdot2); float32: two
+      n -= 2;
+      const double a = v[n - 1], b = v[n], c = v[n + 1];
+      const int ta = XTAG(n - 1), tb = XTAG(n), tc = XTAG(n + 1);
+      const bool any2 = ta == 2 || tb == 2 || tc == 2, any1 = ta == 1 || tb == 1 || tc == 1;
+      if (any1 && !any2) { const float p = (float)a * (float)b; v[n - 1] = (double)(p + (float)c); }
+      else v[n - 1] = fma(a, b, c);
+      XSETTAG(n - 1, any2 ? 2 : (any1 ? 1 : 0));
+      continue;
+    }
     if constexpr (MOOG_WITH_MAZE != 0) {   // reset-time expressions: only in the kernels that carry every component
       if (op == MOOG_X_HDRAW) { v[n] = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
       if (op == MOOG_X_SLOT_ATTR) { int t; v[n] = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
@@ -2381,6 +2397,14 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
   PProg P = e.P;
   PRule R = &P->rules[ri];
   if constexpr (DYN) {
+    if (R->kind == MOOG_RULE_DRAWS) {   // the np.random calls at the top of a config-local rule's step
+      const double u0 = next_uniform(e);
+      const double u1 = R->i0 > 1 ? next_uniform(e) : 0.0;
+      wsync();
+      if (e.lane == 0) { e.f[e.L.o_rule + ri] = u0; e.f[e.L.o_rule2 + ri] = u1; }
+      wsync();
+      return;
+    }
     if (R->kind == MOOG_RULE_VANISH_BY_FILTER) {   // vanish.py:31-39,58-61
       const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
       for (int s = a0; s < a1; ++s) {
@@ -3572,9 +3596,21 @@ __device__ inline void run_genop(Env& e, int oi) {
   }
   if constexpr (FULL) {
     if (op->cell_sel == MOOG_CELL_HDRAW) {   // a direct np.random draw of the initializer
-      const double u = next_uniform(e);
+      for (int tries = 0;; ++tries) {
+        const double u = next_uniform(e);
+        wsync();
+        if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = u;
+        wsync();
+        if (op->code_off < 0) break;   // (no rejection loop around it)
+        if (eval_expr(e, op->code_off, 0, 0, nullptr, nullptr) != 0.0) break;
+        if (tries >= MOOG_DIST_MAX_TRIES) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+      }
+      return;
+    }
+    if (op->cell_sel == MOOG_CELL_HEXPR) {   // a value computed from the draws, kept for several readers
+      const double v = eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
       wsync();
-      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = u;
+      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = v;
       wsync();
       return;
     }

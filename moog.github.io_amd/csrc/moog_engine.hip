@@ -452,7 +452,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   for (int r = 0; r < prog->n_rules; ++r) {
     int k = prog->rules[r].kind;
     if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES ||
-        k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT)
+        k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT || k == MOOG_RULE_DRAWS)
       e->dynamic_rules = true;
   }
   for (int t = 0; t < prog->n_tasks; ++t) {

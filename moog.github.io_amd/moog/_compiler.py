@@ -25,7 +25,7 @@ from .observers import polygon_modifiers
 from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
-    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names'])
+    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index'])
 
 
 class _ShapeTable(object):
@@ -85,12 +85,19 @@ def _fill_layers(dst, names, layer_index):
     return len(names)
 
 
+_REF_COUNTER, _REF_INDEX = [0], {}
+
+
 def _flatten_rules(rules, parent=-1, depth=0, out=None):
     """Pre-order list of (rule, parent index) over TimedRule / ConditionalRule nesting."""
     out = [] if out is None else out
-    for r in rules:
+    expanded = [(k, r) for r0 in rules for k, r in enumerate(rules_lib.expand_local_rule(r0))]
+    for k, r in expanded:
         if getattr(r, 'host_side', False):
             continue
+        if k == 0:   # (position of the config's own rule in a pre-order walk of its rule objects: fixtures use it)
+            _REF_COUNTER[0] += 1
+        _REF_INDEX[id(r)] = _REF_COUNTER[0] - 1 if k == 0 else -1
         out.append((r, parent))
         if isinstance(r, (rules_lib.TimedRule, rules_lib.ConditionalRule, rules_lib.Phase,
                           rules_lib.PhaseSequence)):
@@ -141,7 +148,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # Layers that rules append to (CreateSprites, ChangeLayer's new_layer) behave like the
     # reference's Python lists: live sprites stay packed at the front of the layer's slots
     # in list order, and the layer gets spare slots (`layer_capacity`, default +8).
+    _REF_COUNTER[0] = 0
+    _REF_INDEX.clear()
     flat_rules = _flatten_rules(tuple(game_rules))
+    rule_ref_index = [_REF_INDEX[id(r)] for r, _ in flat_rules]
     dynamic = []
     for r, _ in flat_rules:
         if isinstance(r, rules_lib.CreateSprites):
@@ -295,9 +305,16 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             G.code_off = -1
             op_max_nv[oi] = 0
             continue
-        if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE: randomness, no sprite
+        if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE / HDRAW / HEXPR: randomness or a computed value, no sprite
             G.cell_sel, G.cell_arg = op.cell
             G.code_off = -1
+            if isinstance(op, _trace.HExprOp):
+                G.code_off = put_code(_symbolic.emit(op.node, [], None))
+            elif getattr(op, 'accept', None):   # the accept test(s) of a rejection loop over this draw
+                node = op.accept[0]
+                for extra in op.accept[1:]:
+                    node = _symbolic.Node('and', node, extra)
+                G.code_off = put_code(_symbolic.emit(node, [], None))
             op_max_nv[oi] = 0
             continue
         cell = traced_maze.cell_of(sprites[0])
@@ -635,7 +652,29 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 raise NotImplementedError('two rules publish meta_state[%r]' % (r._meta_state_fixation_key,))
             fixation_keys[r._meta_state_fixation_key] = ri
 
+    meta_tables = {}
+
     def resolve_phase(key, name):
+        if key == 'meta':   # sprite.metadata[name]: one value per slot (spare slots of dynamic layers: the layer's last recipe)
+            if name not in meta_tables:
+                off = int(P.n_cand)
+                if off + S > _abi.MOOG_MAX_CAND:
+                    raise NotImplementedError('sprite.metadata[%r]: no room for a per-slot table' % (name,))
+                last = float('nan')
+                for sl, sp in enumerate(slot_sprite):
+                    if sp is not None:   # (a spare slot of a dynamic layer keeps the value of the recipe before it)
+                        md = sp.factors.get('metadata')
+                        last = float('nan')
+                        if isinstance(md, dict) and name in md:
+                            v = md[name]
+                            if not isinstance(v, (bool, int, float, np.integer, np.floating, np.bool_)):
+                                raise NotImplementedError('sprite.metadata[%r] = %r: only numbers and bools are lowered'
+                                                          % (name, v))
+                            last = float(v)
+                    P.cand[off + sl] = last
+                P.n_cand = off + S
+                meta_tables[name] = off
+            return meta_tables[name]
         if key is None:   # an overlap test against state[name][0]
             return layer_index(name)
         if name is None:  # the number a Fixation rule keeps under this key
@@ -713,7 +752,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.p0 = float(r._fixation_threshold)
         elif isinstance(r, rules_lib.Phase):
             R.kind = _abi.MOOG_RULE_PHASE
-            R.i0 = len(r._one_time_rules)
+            R.i0 = sum(1 for x in r._one_time_rules for y in rules_lib.expand_local_rule(x)
+                       if not getattr(y, 'host_side', False))
             R.p0 = r._duration
             if r._random_duration is not None:   # np.random.randint(lo, hi), drawn whenever the phase is reset
                 R.op, R.p0, R.p2 = 1, float(r._random_duration[0]), float(r._random_duration[1])
@@ -752,6 +792,32 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 light = set(mod) <= {'x_vel', 'y_vel', 'angle_vel', 'mass', 'c0', 'c1', 'c2', 'opacity'}
                 if const_only and light and fnode is None and not r._sample_one and R.filter == _abi.MOOG_FILTER_ALWAYS:
                     R.i0 |= 16
+        elif isinstance(r, rules_lib._RuleDraws):
+            R.kind, R.i0 = _abi.MOOG_RULE_DRAWS, int(r.n)
+            P.rule_state2 = 1
+        elif isinstance(r, rules_lib._ModifyTraced):
+            R.kind, R.filter = _abi.MOOG_RULE_MODIFY_SPRITES, _abi.MOOG_FILTER_ALWAYS
+            R.n_layers = _fill_layers(R.layers, [r.layer], layer_index)
+            where = {}
+            for d in r.draws:
+                di = [i for i, (x, _) in enumerate(flat_rules) if x is d][0]
+                for j in range(d.n):
+                    where[d.first + j] = (di, j)
+
+            def zip_resolver(key, name, _where=where, _layer=r.layer):
+                if key == 'rdraw':
+                    return _where[name]
+                if key is None:   # a zipped partner layer: same number of sprites, fixed slots
+                    if name in dynamic or _layer in dynamic or len(state[name]) != len(state[_layer]):
+                        raise NotImplementedError('a rule that zips layers of different or changing sizes')
+                    return layer_index(name)
+                return resolve_phase(key, name)
+            code = []
+            for attr, n in r.mod.items():
+                _symbolic.emit(n, code, zip_resolver)
+                code.append(dict(op=_abi.MOOG_X_STORE, a=_symbolic.ATTRS.index(attr)))
+            R.xmod = put_code(code)
+            R.i0 = 2 if r.vec else 0
         elif isinstance(r, rules_lib.Portal):
             R.kind = _abi.MOOG_RULE_PORTAL
             R.l0, R.l1 = layer_index(r._teleporting_layer), layer_index(r._portal_layer)
@@ -921,7 +987,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 '(layer %r)' % (layer_names[P.slot_layer[sl]],))
 
     layer_slots = {name: (P.layer_slot0[i], P.layer_nslots[i]) for i, name in enumerate(layer_names)}
-    c = Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P), [])
+    # rule_ref_index: program rule -> index of the config's rule object it stands for in a pre-order walk of the config's
+    # rule forest (-1: a rule the lowering added: the extra parts of an expanded config-local rule, state slots of forces)
+    c = Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P), [],
+                 rule_ref_index + [-1] * (int(P.n_rules) - len(rule_ref_index)))
     # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
     c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
     return c

@@ -106,10 +106,12 @@ class Sym(object):
         if self.node.op == 'const':
             return self.node.args[0] != 0
         if _TRACER is None:
-            # e.g. `while not valid: angle = np.random.uniform(...)` inside a state_initializer (match_to_sample.py:
-            # 33-43): the number of draws would depend on their values
-            raise Unsupported('branching on a value drawn at reset time (a rejection loop over np.random in a '
-                              'state_initializer, sorting drawn values, ...) is not lowered')
+            # `while not valid: angle = np.random.uniform(...)` inside a state_initializer (match_to_sample.py:33-43):
+            # the rejection loop over the latest draw is the one branch on drawn values that is lowered
+            from . import _trace
+            if _trace.active() is None:
+                raise Unsupported('bool() of a symbolic value outside a traced function')
+            return _trace.active().retry_decide(self.node)
         return _TRACER.decide(self.node)
 
     def __float__(self):
@@ -154,6 +156,40 @@ def _ufunc(ufunc, method, inputs, kwargs):
         else:
             out.append(Sym(Node(name, *args)))
     return SymVec(out) if n else out[0]
+
+
+def _matmul(m, v):
+    """np.matmul(constant matrix, symbolic vector) (match_to_sample.py:73: a rotation by 90 degrees): row sums in index
+    order.  Exact whatever BLAS does when every row has at most one entry that is not 0 (checked)."""
+    m = np.asarray(m, dtype=np.float64) if not isinstance(m, (SymVec, SymMat)) else None
+    if m is None or m.ndim != 2 or not isinstance(v, SymVec) or m.shape[1] != len(v.items):
+        raise Unsupported('np.matmul other than (constant matrix) @ (symbolic vector)')
+    if any(np.count_nonzero(row) > 1 for row in m):
+        raise Unsupported('np.matmul with a row of several non-zero entries (BLAS rounding is not restated)')
+    out = []
+    for row in m:
+        acc = None
+        for c, x in zip(row, v.items):
+            t = Sym(const(float(c), True)) * x
+            acc = t if acc is None else acc + t
+        out.append(acc)
+    return SymVec(out)
+
+
+def sort_network(items, let):
+    """np.sort of a short list that holds drawn values: compare-exchange steps whose outputs are kept as computed
+    cells (`let`), so that every later use reads a value instead of re-deriving a tree of min / max."""
+    vals = [v if isinstance(v, Sym) else Sym(lift(float(v))) for v in items]
+    n = len(vals)
+    for i in range(n):
+        for j in range(n - 1 - i):
+            a, b = vals[j], vals[j + 1]
+            if a.node.op == 'const' and b.node.op == 'const':
+                lo, hi = min(a.node.args[0], b.node.args[0]), max(a.node.args[0], b.node.args[0])
+                vals[j], vals[j + 1] = Sym(const(lo, True)), Sym(const(hi, True))
+            else:
+                vals[j], vals[j + 1] = let(Node('min', a.node, b.node)), let(Node('max', a.node, b.node))
+    return SymVec(vals)
 
 
 class SymVec(object):
@@ -215,13 +251,18 @@ class SymVec(object):
         return r
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if ufunc.__name__ == 'matmul' and method == '__call__' and len(inputs) == 2 and not kwargs:
+            return _matmul(inputs[0], inputs[1])
         return _ufunc(ufunc, method, inputs, kwargs)
 
     def __array_function__(self, func, types, args, kwargs):
         name = getattr(func, '__name__', '')
         if name == 'norm' and len(args) == 1 and not kwargs:     # np.linalg.norm: sqrt(dot(x, x))
+            its = args[0].items
+            if len(its) == 2:   # float64 2-vectors: OpenBLAS ddot = fma(x1, x1, x0 * x0) (plain sums in float32)
+                return Sym(Node('sqrt', Node('fma', its[1].node, its[1].node, (its[0] * its[0]).node)))
             acc = None
-            for a in args[0].items:
+            for a in its:
                 t = a * a
                 acc = t if acc is None else acc + t
             return Sym(Node('sqrt', acc.node))
@@ -232,6 +273,8 @@ class SymVec(object):
             b, lb = _elems(args[1])
             if la != lb or la is None:
                 raise Unsupported('np.dot shapes')
+            if la == 2:   # (as np.linalg.norm above)
+                return Sym(Node('fma', lift(a[1]), lift(b[1]), (Sym(lift(a[0])) * Sym(lift(b[0]))).node))
             acc = None
             for x, y in zip(a, b):
                 t = Sym(lift(x)) * Sym(lift(y))
@@ -246,6 +289,8 @@ class SymVec(object):
             return SymMat([[c[i] for c in cols] for i in range(len(cols[0]))])
         if name == 'copy' and len(args) == 1:
             return SymVec(list(args[0].items))
+        if name == 'matmul' and len(args) == 2:
+            return _matmul(args[0], args[1])
         if name == 'clip' and len(args) == 3:
             return np.minimum(np.maximum(args[0], args[1]), args[2])
         raise Unsupported('numpy.%s on symbolic values' % name)
@@ -358,6 +403,8 @@ class SymSprite(object):
         return w[name] if name in w else Sym(Node('attr', self._index, name))
 
     def __getattr__(self, name):
+        if name == 'metadata':   # constant per slot (the sprite's `metadata` factor): a table lookup on the device
+            return _SymMetadata(self._index)
         if name == 'position':
             return SymVec([self._get('x'), self._get('y')])
         if name == 'velocity':
@@ -381,6 +428,20 @@ class SymSprite(object):
         if name not in SETTABLE:
             raise Unsupported('assigning sprite.%s is not lowered' % name)
         self._written[name] = Sym(lift(value))
+
+
+class _SymMetadata(object):
+    """`sprite.metadata` inside a traced function: `[key]` is the number / bool the config stored under that key
+    for the sprite's slot (sprite.py:248-253: metadata is never touched by the engine)."""
+
+    def __init__(self, index):
+        self._index = index
+
+    def __getitem__(self, key):
+        return Sym(Node('meta', self._index, key))
+
+    def get(self, key, default=None):
+        raise Unsupported('sprite.metadata.get(...) in a lowered function (index it: metadata[key])')
 
 
 class _Tracer(object):
@@ -508,6 +569,134 @@ def trace_rule_step(step_fn):
     return layer, mod, '__vec_velocity' in sp._written
 
 
+class _ZSprite(SymSprite):
+    """Representative i of layer `layer` in a traced rule step: its attributes are Node('zattr', layer, i, attr)."""
+
+    def __init__(self, layer, i):
+        SymSprite.__init__(self, i)
+        object.__setattr__(self, '_layer', layer)
+
+    def _get(self, name):
+        w = self._written
+        return w[name] if name in w else Sym(Node('zattr', self._layer, self._index, name))
+
+
+class _ZLayer(object):
+    def __init__(self, owner, name):
+        self._owner, self._name = owner, name
+
+    def __iter__(self):
+        return iter(self._owner.sprites(self._name))
+
+    def __len__(self):
+        raise Unsupported('len(state[layer]) is not symbolic')
+
+    def __getitem__(self, i):
+        raise Unsupported('indexing a layer in a rule that loops over layers')
+
+
+class _ZState(object):
+    def __init__(self):
+        self.layers = {}
+
+    def sprites(self, name):
+        if name not in self.layers:
+            self.layers[name] = [_ZSprite(name, i) for i in range(2)]
+        return self.layers[name]
+
+    def __getitem__(self, name):
+        return _ZLayer(self, name)
+
+
+def _zmap(node, fn):
+    if node.op == 'zattr':
+        return fn(node)
+    if node.op in ('const', 'rdraw', 'phase_is', 'meta_num'):
+        return node
+    return Node(node.op, *[_zmap(a, fn) if isinstance(a, Node) else a for a in node.args])
+
+
+def trace_rule_zip(step_fn):
+    """Lowers the `step(state, meta_state)` of a config-local rule that (a) takes draws from np.random.uniform /
+    randint and (b) loops over one layer, or over several layers in lock step (`for t, c in zip(state[A], state[B])`),
+    assigning attributes computed from the draws and from the attributes of the sprites of that iteration
+    (match_to_sample.py:66-79).  The step runs once on two representatives per layer; the second must repeat the first
+    with the index shifted, which is what tells the lock-step loop from nested loops.  Returns (number of draws,
+    [(layer, {attr: node}, velocity assigned as a whole)]) -- nodes over 'attr' (the sprite itself), 'zipattr' (its
+    partner in another layer), 'rdraw'."""
+    global _TRACER
+    st = _ZState()
+    draws = []
+
+    def rdraw():
+        draws.append(len(draws))
+        return Sym(Node('rdraw', draws[-1]))
+
+    def fake_uniform(low=0.0, high=1.0, size=None):
+        if size is not None:
+            raise Unsupported('np.random.uniform(size=...) in a rule step')
+        return low + (high - low) * rdraw()
+
+    def fake_randint(low, high=None, size=None, dtype=int):
+        if size is not None:
+            raise Unsupported('np.random.randint(size=...) in a rule step')
+        if high is None:
+            low, high = 0, low
+        return int(low) + Sym(Node('floor', (rdraw() * float(int(high) - int(low))).node))   # a + int(u * (b - a))
+    saved = (np.random.uniform, np.random.randint)
+    np.random.uniform, np.random.randint = fake_uniform, fake_randint
+    tr = _Tracer()
+    prev, _TRACER = _TRACER, tr
+    try:
+        step_fn(st, _SymMeta())
+    finally:
+        _TRACER = prev
+        np.random.uniform, np.random.randint = saved
+    if tr.trail:
+        raise Unsupported('a config-local rule that branches on the state or on its draws')
+    out, written_attrs = [], set()
+    for layer, reps in st.layers.items():
+        w0 = {k: v.node for k, v in reps[0]._written.items() if not k.startswith('__')}
+        w1 = {k: v.node for k, v in reps[1]._written.items() if not k.startswith('__')}
+        if not w0 and not w1:
+            continue
+        shifted = {k: _zmap(n, lambda z: Node('zattr', z.args[0], 1 - z.args[1], z.args[2])) for k, n in w1.items()}
+        if set(w0) != set(w1) or any(w0[k].key() != shifted[k].key() for k in w0):
+            raise Unsupported('a config-local rule whose loop does not treat every sprite of a layer alike')
+        mod = {}
+        for k, n in w0.items():
+            def own(z, _layer=layer):
+                if z.args[1] != 0:
+                    raise Unsupported('a config-local rule that reads the sprites of another iteration (nested loops)')
+                return Node('attr', 0, z.args[2]) if z.args[0] == _layer else Node('zipattr', z.args[0], z.args[2])
+            mod[k] = _zmap(n, own)
+            written_attrs.add(k)
+        for a, b in (('x_vel', 'y_vel'), ('y_vel', 'x_vel'), ('x', 'y'), ('y', 'x')):
+            if a in mod and b not in mod:
+                mod[b] = Node('attr', 0, b)
+        out.append((layer, mod, '__vec_velocity' in reps[0]._written))
+    if not out:
+        raise Unsupported('a config-local rule that modifies no sprite')
+
+    def reads(n, acc):
+        if n.op in ('attr',):
+            acc.add(n.args[1])
+        elif n.op == 'zipattr':
+            acc.add(n.args[1])
+        for a in n.args:
+            if isinstance(a, Node):
+                reads(a, acc)
+        return acc
+    read_attrs = set()
+    for _, mod, _v in out:
+        for k, n in mod.items():
+            if not (n.op == 'attr' and n.args[1] == k):
+                reads(n, read_attrs)
+    if read_attrs & written_attrs:   # a later iteration / layer would see the new value: order-dependent
+        raise Unsupported('a config-local rule that reads an attribute it also assigns')
+    return len(draws), out
+
+
 # ---- state-level conditions ---------------------------------------------------------------------
 class _SymLayer(object):
     """`state[layer]` inside a traced condition.  Iteration yields two representative sprites
@@ -586,7 +775,7 @@ def _substitute(node, old, new):
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
-    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac'):
+    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -594,7 +783,9 @@ def _substitute(node, old, new):
 def _sprites_of(node, acc):
     if node.op in ('attr', 'overlaps'):
         acc.add(node.args[0])
-    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac'):
+    elif node.op == 'meta':
+        acc.add(node.args[0])
+    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -759,14 +950,27 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_FACTOR, a=_abi.FACTOR_NAMES.index(node.args[0])))
     elif node.op == 'hdraw':      # a direct np.random draw of the state_initializer (reset-time expressions)
         out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(node.args[0])))
+    elif node.op == 'meta':       # sprite.metadata[key]: resolver('meta', key) gives the per-slot table in program.cand
+        if resolver is None:
+            raise Unsupported('sprite.metadata outside a rule / task function')
+        out.append(dict(op=_abi.MOOG_X_SLOT_CONST, a=int(resolver('meta', node.args[1])), b=int(node.args[0])))
     elif node.op == 'slotattr':   # a factor of an earlier sprite; resolver('slot', sprite) gives its slot
         if resolver is None:
             raise Unsupported('sprite factor reference outside a state_initializer')
         out.append(dict(op=_abi.MOOG_X_SLOT_ATTR, a=ATTRS.index(node.args[1]), b=int(resolver('slot', node.args[0]))))
-    elif node.op == 'select':
+    elif node.op == 'rdraw':      # draw k of the config-local rule this code belongs to; resolver('rdraw', k) -> (rule, which scalar)
+        if resolver is None:
+            raise Unsupported('a step-time draw outside a rule')
+        rule, which = resolver('rdraw', node.args[0])
+        out.append(dict(op=_abi.MOOG_X_RULE_STATE2 if which else _abi.MOOG_X_RULE_STATE, a=int(rule)))
+    elif node.op == 'zipattr':    # attribute of the sprite at the same list index in another layer; resolver(None, L) -> L's index
+        if resolver is None:
+            raise Unsupported('a zipped sprite outside a rule')
+        out.append(dict(op=_abi.MOOG_X_ZIP_ATTR, a=ATTRS.index(node.args[1]), b=int(resolver(None, node.args[0]))))
+    elif node.op in ('select', 'fma'):
         for a in node.args:
             emit(a, out, resolver)
-        out.append(dict(op=_abi.MOOG_X_SELECT))
+        out.append(dict(op=_abi.MOOG_X_SELECT if node.op == 'select' else _abi.MOOG_X_FMA))
     elif node.op in _BIN:
         emit(node.args[0], out, resolver)
         emit(node.args[1], out, resolver)

@@ -37,6 +37,17 @@ class HDrawOp(GenOp):
         self.cell = (_abi.MOOG_CELL_HDRAW, index)
 
 
+class HExprOp(GenOp):
+    """A value the initializer computed from its draws and uses more than once (the outputs of a sorting network over
+    drawn values, match_to_sample.py:46): evaluated once per reset into direct-draw slot `index`, read like a draw."""
+
+    def __init__(self, index, node, seq):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.index, self.node, self.seq = index, node, seq
+        from . import _abi
+        self.cell = (_abi.MOOG_CELL_HEXPR, index)
+
+
 class ShuffleOp(GenOp):
     """sprite_generators.shuffle: permutes the slots of `members` (generated just before) at every reset."""
 
@@ -63,6 +74,12 @@ class Tracer(object):
         self.alias_keep = []        # (keeps those placeholders alive: ids must stay unique)
         self.maze = None            # the per-reset random maze of the initializer (maze_lib/_traced.py)
         self.seq = 0                # order of sampling events (deferred factor samples and direct draws)
+        # rejection loops over a direct draw (`while not ok: a = np.random.uniform(..); ok = test(a)`, match_to_sample.py:
+        # 33-43): the draw they redo, the accept conditions seen so far, the condition being probed
+        self.retry_op = None
+        self.retry_confirmed = []
+        self.retry_probe = None
+        self.retry_reuse = False
 
     def next_seq(self):
         self.seq += 1
@@ -73,12 +90,66 @@ class Tracer(object):
         from . import _abi, _symbolic
         if getattr(self, 'suspend', False):
             raise NotImplementedError('np.random calls inside a distribution sampled by generate_sprites')
+        if self.retry_reuse:   # the loop body of a rejection loop runs again: the same draw, taken anew on the device
+            self.retry_reuse = False
+            return _symbolic.Sym(_symbolic.Node('hdraw', self.retry_op.index))
+        if self.retry_probe is not None:
+            raise _symbolic.Unsupported('a rejection loop that takes more than one np.random draw per try')
         if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
             raise NotImplementedError('more than %d direct np.random draws per reset' % _abi.MOOG_MAX_HDRAWS)
         k = self.n_hdraws
         self.n_hdraws += 1
-        self.add_op(HDrawOp(k, self.next_seq()))
+        op = HDrawOp(k, self.next_seq())
+        op.accept = []
+        self.add_op(op)
+        self.retry_op, self.retry_confirmed, self.retry_probe = op, [], None
         return _symbolic.Sym(_symbolic.Node('hdraw', k))
+
+    def let(self, node):
+        """A computed value kept in a direct-draw slot (evaluated once per reset, in op order)."""
+        from . import _abi, _symbolic
+        if self.retry_probe is not None:
+            raise _symbolic.Unsupported('a rejection loop with side effects')
+        if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+            raise NotImplementedError('more than %d direct np.random draws / computed values per reset' % _abi.MOOG_MAX_HDRAWS)
+        k = self.n_hdraws
+        self.n_hdraws += 1
+        self.add_op(HExprOp(k, node, self.next_seq()))
+        return _symbolic.Sym(_symbolic.Node('hdraw', k))
+
+    def retry_decide(self, node):
+        """bool() of a value computed from the LATEST direct draw inside the initializer.  The only control flow that is
+        lowered is the rejection loop: when the test fails the code draws again and tests again.  Probed once: the
+        first bool() answers False; the code must then ask for a draw (handed the same symbolic draw again) and
+        arrive at the structurally same test, which answers True and becomes an accept condition of that draw -- the
+        device redraws until all of a draw's conditions hold (one uniform per try, as in the reference)."""
+        from . import _symbolic
+        op = self.retry_op
+        found = set()
+
+        def walk(n):
+            if n.op == 'hdraw':
+                found.add(n.args[0])
+            for a in n.args:
+                if isinstance(a, _symbolic.Node):
+                    walk(a)
+        walk(node)
+        if op is None or self.ops[-1] is not op or op.index not in found or max(found) != op.index:
+            raise _symbolic.Unsupported('branching on a value drawn at reset time other than the accept test of a '
+                                        'rejection loop over the latest np.random draw')
+        key = node.key()
+        if key in self.retry_confirmed:
+            return True
+        if self.retry_probe is not None:
+            if key != self.retry_probe or self.retry_reuse:
+                raise _symbolic.Unsupported('branching on a drawn value that is not a rejection loop (the failed test '
+                                            'was not repeated on a fresh draw)')
+            self.retry_probe = None
+            self.retry_confirmed.append(key)
+            op.accept.append(node)
+            return True
+        self.retry_probe, self.retry_reuse = key, True
+        return False
 
     def choose(self, generators, p, args, kwargs):
         """sample_generator: runs every alternative; their ops become conditional on the drawn index."""
@@ -107,6 +178,9 @@ class Tracer(object):
         return first
 
     def add_op(self, op):
+        if self.retry_probe is not None:
+            from . import _symbolic
+            raise _symbolic.Unsupported('a rejection loop with side effects')
         self.ops.append(op)
         for k, s in enumerate(op.sprites):
             self.op_of[id(s)] = (op, k)
@@ -187,9 +261,24 @@ def tracing():
         setattr(np.random, name, refuse(name))
     np.random.uniform = fake_uniform
     np.random.binomial = fake_binomial
+    real_sort = np.sort
+
+    def fake_sort(a, *args, **kwargs):   # np.sort of a list with drawn values: a sorting network over computed cells
+        from . import _symbolic
+        items = list(a.items) if isinstance(a, _symbolic.SymVec) else (list(a) if isinstance(a, (list, tuple)) else None)
+        if items is None or not any(isinstance(v, _symbolic.Sym) for v in items):
+            return real_sort(a, *args, **kwargs)
+        if args or kwargs:
+            raise NotImplementedError('np.sort(..., axis / kind / order) of drawn values')
+        return _symbolic.sort_network(items, t.let)
+    np.sort = fake_sort
     try:
         yield t
+        if t.retry_probe is not None:
+            from . import _symbolic
+            raise _symbolic.Unsupported('branching on a drawn value that is not a rejection loop')
     finally:
+        np.sort = real_sort
         np.random.randint = real_randint
         for name, fn in blocked.items():
             setattr(np.random, name, fn)

@@ -102,6 +102,49 @@ class Portal(AbstractRule):
         self._portal_layer = portal_layer
 
 
+class _RuleDraws(AbstractRule):
+    """Lowering product: the np.random draws a config-local rule takes when stepped (first, second)."""
+
+    def __init__(self, first, n):
+        self.first, self.n = first, n
+
+
+class _ModifyTraced(AbstractRule):
+    """Lowering product: the attribute writes of a traced config-local rule to every sprite of `layer`."""
+
+    def __init__(self, layer, mod, vec, draws):
+        self.layer, self.mod, self.vec, self.draws = layer, mod, vec, draws
+
+
+def expand_local_rule(r):
+    """A config-local rule class whose step() draws from np.random and loops over layers (match_to_sample.py:53-79)
+    becomes [draws ...] + one traced modifier per assigned layer; every other rule stays itself."""
+    known = (VanishOnContact, VanishByFilter, ChangeLayer, ModifyOnContact, CreateSprites, KeepNearCenter, Fixation,
+             Phase, PhaseSequence, TimedRule, ConditionalRule, ModifySprites, Portal, _RuleDraws, _ModifyTraced)
+    if isinstance(r, known) or lookup_lowering(r) is not None or getattr(r, 'host_side', False):
+        return [r]
+    if getattr(r, '_moog_expanded', None) is not None:
+        return r._moog_expanded
+    r._moog_expanded = _expand(r)
+    return r._moog_expanded
+
+
+def _expand(r):
+    from .. import _symbolic
+    try:
+        _symbolic.trace_rule_step(r.step)
+        return [r]               # the simple form (first sprite of one layer): lowered where the rule table is filled
+    except (NotImplementedError, AttributeError, TypeError):
+        pass
+    try:
+        n, mods = _symbolic.trace_rule_zip(r.step)
+    except (NotImplementedError, AttributeError, TypeError) as exc:
+        raise NotImplementedError('game rule %r has no device lowering (see game_rules.register_lowering): %s'
+                                  % (type(r).__name__, exc))
+    draws = [_RuleDraws(k, min(2, n - k)) for k in range(0, n, 2)]
+    return draws + [_ModifyTraced(layer, mod, vec, draws) for layer, mod, vec in mods]
+
+
 class KeepNearCenter(AbstractRule):
     """re_center.py:11-58: when the first sprite of agent_layer strays more than a grid cell
     from (0.5, 0.5), every sprite of layers_to_center (and the agent) is shifted back by one

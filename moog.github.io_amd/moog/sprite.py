@@ -25,6 +25,13 @@ class SymbolicFactor(object):
         self.seq = t.next_seq() if t is not None else 0   # when the reference would have drawn it
         self.owner = None                                  # (sprite, factor name) that carries the draw
 
+    def __deepcopy__(self, memo):
+        # `copy.deepcopy(factors)` of a sampled dict (match_to_sample.py:128) copies VALUES in the reference: the copy is
+        # the same draw, not a new one
+        return self
+
+    __copy__ = lambda self: self
+
 
 class ExprFactor(SymbolicFactor):
     """A factor value the initializer computed from its own np.random draws / from other sprites' factors: an
@@ -90,6 +97,11 @@ class Sprite(object):
     def __setattr__(self, name, value):
         # `sprite.mass = ...` after construction (e.g. predators_arena.py:88-89 inside its
         # state_initializer) is host logic the recipe cannot carry: refuse instead of ignoring it
+        if name == 'metadata' and 'factors' in self.__dict__:
+            # a label the config hangs on a sprite (match_to_sample.py:120-124): constant per slot, read by traced
+            # reward functions / filters as `s.metadata[key]`
+            self.factors['metadata'] = value
+            return
         if name in FACTOR_NAMES and 'factors' in self.__dict__:
             raise NotImplementedError(
                 'assigning sprite.%s after construction is not lowered; pass it to Sprite(...) or '

@@ -3,7 +3,9 @@ trial structure of match_to_sample.py:214-262: a screen phase, a visible phase, 
 whose one-time rules cover the targets and set them moving, and a response phase with a
 continual ModifyOnContact; the Reset task tests the state and the phase name the sequence
 publishes in the meta-state (:176-186).  A stand-alone Phase with an end condition runs next
-to the sequence.
+to the sequence.  Level 1: random durations (task_phases.py:72: drawn in reset, AFTER the phase's
+own rules were reset) on a phase of the sequence and on a stand-alone phase that holds another
+random-duration phase as its continual rule -- the inner duration is drawn first.
 """
 import collections
 
@@ -17,7 +19,7 @@ from moog import sprite
 from moog import tasks
 
 
-def get_config(_=0):
+def get_config(level=0):
     positions = [(0.25, 0.7), (0.5, 0.75), (0.75, 0.7)]
 
     def state_initializer():
@@ -54,7 +56,7 @@ def get_config(_=0):
     motion_phase = gr.Phase(
         one_time_rules=[gr.ModifySprites('covers', _make_opaque),
                         gr.ModifySprites(('targets', 'covers'), _drift)],
-        duration=4, name='motion')
+        duration=4 if level == 0 else (lambda: np.random.randint(3, 7)), name='motion')
     response_phase = gr.Phase(
         one_time_rules=[gr.ModifySprites('cue', _make_opaque), gr.ModifySprites(('targets', 'covers'), _stop),
                         gr.ModifySprites(('agent', 'cue'), _unglue)],
@@ -67,6 +69,11 @@ def get_config(_=0):
     fade = gr.Phase(
         continual_rules=gr.ModifySprites('cue', lambda s: setattr(s, 'c2', s.c2 * 0.9)),
         end_condition=lambda state: any(s.x > 0.6 for s in state['agent']), name='fade')
+    if level == 1:
+        inner = gr.Phase(
+            continual_rules=gr.ModifySprites('cue', lambda s: setattr(s, 'c2', s.c2 * 0.9)),
+            duration=lambda: np.random.randint(2, 5), name='inner')
+        fade = gr.Phase(continual_rules=inner, duration=lambda: np.random.randint(6, 10), name='outer')
 
     def _should_reset(state, meta_state):
         return state['covers'][0].opacity == 0 and meta_state['phase'] == 'response'

@@ -134,6 +134,21 @@ def track_and_fixate(env, t, rs):
     return np.clip(goal + rs.uniform(-0.03, 0.03, size=2), 0., 1.)
 
 
+def _seek_cover(index):
+    def policy(env, t, rs):
+        """Policy for match_to_sample: once the response phase lets the agent move, steer it onto cover `index` (0 is
+        the one whose disc the cue matches)."""
+        if env.meta_state.get('phase', '') != 'response':
+            return rs.uniform(-1., 1., size=2)
+        covers = env.state['covers']
+        d = np.array(covers[index % len(covers)].position, dtype=float) - np.array(env.state['agent'][0].position, dtype=float)
+        return np.clip(d / max(np.linalg.norm(d), 1e-9) + rs.uniform(-0.2, 0.2, size=2), -1., 1.)
+    return policy
+
+
+seek_match, seek_other = _seek_cover(0), _seek_cover(1)
+
+
 def patch_numpy_random():
     np.random.uniform = _uniform
     np.random.rand = _rand
@@ -155,6 +170,8 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
         return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
+    if name in ('match_to_sample_l2', 'match_to_sample_l3', 'match_to_sample_l4'):   # (the level is the number of targets)
+        return importlib.import_module('moog_demos.example_configs.match_to_sample').get_config(int(name[-1]))
     if name in ('multi_tracking_with_feature_l1', 'multi_tracking_with_feature_l3'):
         return importlib.import_module('moog_demos.example_configs.multi_tracking_with_feature').get_config(int(name[-1]))
     if name == 'pacman_l1':   # level 1: three ghosts, 10 x 10 maze
@@ -720,6 +737,7 @@ def main():
         ('lambda_zoo', 90, {'bin': 8, '__dynamic__': ('bin',)}, (0, 1)),
         ('cond_zoo', 120, {'extras': 8, '__dynamic__': ('extras',)}, (0, 1)),
         ('phase_zoo', 120, {}, (0, 1)),
+        ('phase_zoo_l1', 120, {}, (0, 1)),
         ('actions_zoo', 60, {}, (0, 1)),
         ('actions_zoo_l1', 40, {}, (0,)),
         ('cleanup', 150, {'__bias__': [[0., -0.7], [0., 0.7], [0.3, -0.5]]}, (0, 1)),
@@ -742,6 +760,10 @@ def main():
         ('parallelogram_catch_l2', 60, {'__vmax__': SNAP_VMAX}, (0,)),
         ('multi_tracking_with_feature_l3', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0, 1)),
         ('multi_tracking_with_feature_l1', 230, {'__vmax__': SNAP_VMAX, '__script__': track_and_fixate}, (0,)),
+        ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
+        ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (1,)),
+        ('match_to_sample_l4', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
+        ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
         ('dependent_zoo', 50, {}, (0, 1)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),

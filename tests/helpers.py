@@ -117,6 +117,13 @@ def fixture(name, seed=0):
         return {k: z[k] for k in z.files}
 
 
+def ref_rules(c, n_ref):
+    """(program rule, index of the config's rule object in the fixture's pre-order walk) for the rules that stand for a
+    rule object of the config (a config-local rule may be lowered to several program rules, _compiler.rule_ref_index)."""
+    ref = getattr(c, 'rule_ref_index', None) or list(range(c.program.n_rules))
+    return [(r, k) for r, k in enumerate(ref) if 0 <= k < n_ref]
+
+
 def portal_rule_mask(P):
     m = 0
     for r in range(P.n_rules):
@@ -161,13 +168,15 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
             f[L.o_rule + r] = rc[k]
     if 'rule_counters_flat' in fx:   # newer fixtures: every rule of the pre-order forest
         flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
-        for r in range(min(P.n_rules, len(flat))):
-            if not np.isnan(flat[r]):
-                f[L.o_rule + r] = flat[r]
+        for r, k in ref_rules(c, len(flat)):
+            if not np.isnan(flat[k]):
+                f[L.o_rule + r] = flat[k]
     if P.rule_state2:   # the duration a Phase drew when it was reset
         flat2 = np.asarray(fx['rule_counters2_flat'][t], np.float64).reshape(-1)
-        for r in range(min(P.n_rules, len(flat2))):
-            f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[r]) else flat2[r]
+        for r in range(P.n_rules):
+            f[L.o_rule2 + r] = 0.0
+        for r, k in ref_rules(c, len(flat2)):
+            f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[k]) else flat2[k]
     if 'force_state' in fx:   # forces with state of their own (DeterministicMazeWalk's read position: a MOOG_RULE_STATE_SLOT)
         fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
         for fi in range(min(P.n_forces, len(fs))):
@@ -307,16 +316,16 @@ def state_diff(fx, t, c, f64, i32, env=0):
             q[L.o_step_count], q[L.o_reset_next], fx['step_count'][t], fx['reset_next'][t]))
     if 'rule_counters_flat' in fx:   # every rule of the pre-order forest (NaN: the reference rule keeps no number)
         flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
-        for r in range(min(P.n_rules, len(flat))):
-            if not np.isnan(flat[r]) and f[L.o_rule + r] != flat[r]:
+        for r, k in ref_rules(c, len(flat)):
+            if not np.isnan(flat[k]) and f[L.o_rule + r] != flat[k]:
                 ints_ok = False
-                detail.append('rule %d state: %r vs %r' % (r, f[L.o_rule + r], flat[r]))
+                detail.append('rule %d state: %r vs %r' % (r, f[L.o_rule + r], flat[k]))
     if P.rule_state2:
         flat2 = np.asarray(fx['rule_counters2_flat'][t], np.float64).reshape(-1)
-        for r in range(min(P.n_rules, len(flat2))):
-            if P.rules[r].op == 1 and P.rules[r].kind == _abi.MOOG_RULE_PHASE and f[L.o_rule2 + r] != flat2[r]:
+        for r, k in ref_rules(c, len(flat2)):
+            if P.rules[r].op == 1 and P.rules[r].kind == _abi.MOOG_RULE_PHASE and f[L.o_rule2 + r] != flat2[k]:
                 ints_ok = False
-                detail.append('phase %d duration: %r vs %r' % (r, f[L.o_rule2 + r], flat2[r]))
+                detail.append('phase %d duration: %r vs %r' % (r, f[L.o_rule2 + r], flat2[k]))
     if 'force_state' in fx:
         fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
         for fi in range(min(P.n_forces, len(fs))):
@@ -344,10 +353,10 @@ def state_diff(fx, t, c, f64, i32, env=0):
             detail.append('rule counter %d: %r vs %r' % (k, f[L.o_rule + r], rc[k]))
     if 'rule_counters_flat' in fx:
         flat = np.asarray(fx['rule_counters_flat'][t], np.float64).reshape(-1)
-        for r in range(min(P.n_rules, len(flat))):
-            if not np.isnan(flat[r]) and f[L.o_rule + r] != flat[r]:
+        for r, k in ref_rules(c, len(flat)):
+            if not np.isnan(flat[k]) and f[L.o_rule + r] != flat[k]:
                 ints_ok = False
-                detail.append('rule state %d: %r vs %r' % (r, f[L.o_rule + r], flat[r]))
+                detail.append('rule state %d: %r vs %r' % (r, f[L.o_rule + r], flat[k]))
     return dict(float=max(err.values()), err=err, ints_ok=ints_ok, detail='; '.join(detail))
 
 

@@ -47,7 +47,8 @@ def test_missing_library_fails_loudly(tmp_path):
                                         ('functional_maze', 0), ('falling_balls', 0),
                                         ('first_person_predators_prey', 0), ('cleanup', 0), ('pacman', 0),
                                         ('pacman', 1), ('parallelogram_catch', 0), ('parallelogram_catch', 2),
-                                        ('multi_tracking_with_feature', 3)])
+                                        ('multi_tracking_with_feature', 3), ('match_to_sample', 2),
+                                        ('match_to_sample', 3), ('match_to_sample', 4)])
 def test_reference_configs_load_unchanged(name, level):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
@@ -197,8 +198,10 @@ def test_config_callables_are_traced_symbolically():
         assert bool(got) == want
     mod, vec = sy.trace_modifier(lambda s: setattr(s, 'position', np.remainder(s.position, 1)))
     assert set(mod) == {'x', 'y'} and mod['x'].op == 'rem' and not vec
+    node = sy.trace_value(lambda s: 1 if s.metadata['k'] else -1, 1)   # per-slot constants of the config (match_to_sample.py:171)
+    assert node.op == 'select' and node.args[0].op == 'meta' and node.args[0].args == (0, 'k')
     with pytest.raises(sy.Unsupported):
-        sy.trace_value(lambda s: s.metadata['k'], 1)
+        sy.trace_value(lambda s: s.path, 1)
 
 
 def test_chain_generators_is_a_sequence_of_ops():
@@ -355,12 +358,11 @@ def test_traced_initializer_arithmetic_matches_numpy():
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
 @pytest.mark.parametrize('name,level,needle', [
-    ('match_to_sample', 3, 'branching on a value drawn at reset time'),
     ('predators_arena', 2, 'after construction'),
     ('bounce_box_contact_prediction', 0, 'simulate the episode on the host'),
     ('red_green', 1, 'np.random calls inside a distribution sampled by generate_sprites')])
 def test_reference_configs_that_do_not_lower_say_why(name, level, needle):
-    """The four reference configs the engine does not run are refused at construction with the reason (no silent
+    """The reference configs the engine does not run are refused at construction with the reason (no silent
     freezing of host randomness, no Python fallback)."""
     spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
     m = importlib.util.module_from_spec(spec)
@@ -368,3 +370,40 @@ def test_reference_configs_that_do_not_lower_say_why(name, level, needle):
     with pytest.raises(NotImplementedError) as info:
         _compiler.compile_config(**m.get_config(level))
     assert needle in str(info.value)
+
+
+def test_rejection_loops_over_draws_are_the_only_branches_on_draws():
+    """`while not ok: a = np.random.uniform(..); ok = test(a)` in a state_initializer (match_to_sample.py:33-43) becomes
+    a redraw loop on the device: the tracer answers the first test with False, must be handed the same test on a fresh
+    draw, and records it as the draw's accept condition.  Any other branch on a drawn value is refused; np.sort of
+    drawn values becomes compare-exchange cells."""
+    from moog import _trace, _symbolic as sy
+
+    def spread(n, gap):
+        picked = [0.]
+        while len(picked) < n:
+            a = np.random.uniform(gap, 6. - gap)
+            if all([np.abs(a - b) > gap for b in picked]):
+                picked.append(a)
+        return np.sort(picked)
+    with _trace.tracing() as tr:
+        out = spread(3, 0.5)
+    draws = [op for op in tr.ops if isinstance(op, _trace.HDrawOp)]
+    lets = [op for op in tr.ops if isinstance(op, _trace.HExprOp)]
+    assert [len(op.accept) for op in draws] == [1, 2] and len(out) == 3
+    assert len(lets) == 6 and all(v.node.op == 'hdraw' for v in out)   # three compare-exchange steps, two cells each
+    # a two-way branch on a draw is not a rejection loop
+    def coin():
+        return 1. if np.random.uniform() < 0.5 else 2.
+    with pytest.raises(sy.Unsupported):
+        with _trace.tracing():
+            coin()
+    # neither is a loop that takes two draws per try
+    def pair():
+        while True:
+            a, b = np.random.uniform(), np.random.uniform()
+            if a + b < 1.:
+                return a
+    with pytest.raises(sy.Unsupported):
+        with _trace.tracing():
+            pair()
