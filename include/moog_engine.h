@@ -130,9 +130,14 @@ enum {
   MOOG_CELL_SHUFFLE,    /* not a cell: sprite_generators.shuffle (sprite_generators.py:157-183): the live sprites in
                          * slots slot0 .. slot0 + cell_arg - 1 (a packed prefix) are permuted as np.random.shuffle
                          * permutes their list; slot slot0 + cell_arg is a spare used while swapping              */
-  MOOG_CELL_HEXPR       /* not a cell: o_hdraw[cell_arg] = the value of the expression at dcode[code_off] -- a value the
+  MOOG_CELL_HEXPR,      /* not a cell: o_hdraw[cell_arg] = the value of the expression at dcode[code_off] -- a value the
                          * initializer computed from its draws and uses several times (the compare-exchange outputs of
                          * np.sort over drawn values, match_to_sample.py:46); read back with MOOG_X_HDRAW            */
+  MOOG_CELL_PSTATE      /* not a cell: a number the initializer's object keeps ACROSS episodes (predators_arena.py:56,
+                         * 88-94: the auto-curriculum's predator mass).  It lives in the state scalar of the
+                         * MOOG_RULE_STATE_SLOT rule cell_arg, which resets never clear: the env's first reset stores
+                         * factors[0].a there (and marks the slot's second scalar), every later reset stores the value
+                         * of the update expression at dcode[code_off] (which reads the slot with MOOG_X_RULE_STATE) */
 };
 
 /* Distribution programs.  A factor distribution that is not a flat Product of

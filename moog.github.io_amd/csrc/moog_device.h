@@ -3607,6 +3607,15 @@ __device__ inline void run_genop(Env& e, int oi) {
       }
       return;
     }
+    if (op->cell_sel == MOOG_CELL_PSTATE) {   // a number the initializer keeps across episodes (never cleared by resets)
+      const int ri = op->cell_arg;
+      const bool first = e.f[e.L.o_rule2 + ri] == 0.0;
+      const double v = first ? op->factors[0].a : eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
+      wsync();
+      if (e.lane == 0) { e.f[e.L.o_rule + ri] = v; e.f[e.L.o_rule2 + ri] = 1.0; }
+      wsync();
+      return;
+    }
     if (op->cell_sel == MOOG_CELL_HEXPR) {   // a value computed from the draws, kept for several readers
       const double v = eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
       wsync();

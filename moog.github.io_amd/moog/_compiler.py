@@ -25,7 +25,8 @@ from .observers import polygon_modifiers
 from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
-    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index'])
+    'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index',
+                 'pstate_slots'])
 
 
 class _ShapeTable(object):
@@ -121,10 +122,86 @@ def _reject_f32_velocity(state, layers, what):
                     raise NotImplementedError('%s over sprites whose velocity is sampled by Continuous' % what)
 
 
+def _trace_persistent_state(state_initializer, meta_state_initializer, game_rules, first, saved):
+    """An initializer that is a method of an object which keeps numbers ACROSS episodes (predators_arena.py:29-106: an
+    auto-curriculum adapts `self._mass` at every reset after the first, once the meta-state exists).  The first trace
+    saw the first episode.  Here the meta-state initializer is called as the environment would have (environment.py:
+    86-88), one more initializer run on plain numbers shows which attributes change, and the initializer is traced
+    again with those attributes symbolic: their new values are the per-reset updates, and the factors computed from
+    them read a per-env slot that resets never clear.  Returns (tracer, state) of that second trace, with one PStateOp
+    per such attribute in front of the ops, or None when the initializer keeps nothing."""
+    owner = getattr(state_initializer, '__self__', None)
+    if owner is None or saved is None:
+        return None
+    if meta_state_initializer is None:
+        for k, v in saved.items():
+            setattr(owner, k, v)
+        return None
+    numeric = {k: v for k, v in saved.items() if isinstance(v, float)}
+    if not numeric:
+        return None
+    try:
+        meta_state_initializer()
+        with _trace.tracing():
+            state_initializer()
+        changed = [k for k, v in numeric.items() if vars(owner).get(k) != v]
+        if not changed:
+            return None
+        if any(getattr(r, 'host_side', False) for r, _ in _flatten_host_rules(game_rules)):
+            raise NotImplementedError('a state_initializer that keeps numbers across episodes next to rules that '
+                                      'modify the meta-state on the host')
+        for k in changed:
+            setattr(owner, k, _symbolic.Sym(_symbolic.Node('pstate', k)))
+        with _trace.tracing() as tr:
+            state = state_initializer()
+        updates = {}
+        for k in changed:
+            v = vars(owner).get(k)
+            if not isinstance(v, _symbolic.Sym):
+                raise NotImplementedError('persistent initializer attribute %r is replaced by a non-numeric value' % k)
+            updates[k] = v.node
+        if [type(op) for op in tr.ops] != [type(op) for op in first.ops] or \
+                [len(op.sprites) for op in tr.ops] != [len(op.sprites) for op in first.ops]:
+            raise NotImplementedError('a state_initializer whose later episodes build a different state than the first')
+        # The sprites read the attribute AFTER its update (predators_arena.py:88-96), i.e. the slot's content once the
+        # PStateOp has run: the update's expression inside a factor is that slot; the old value is not available there.
+        keys = {updates[k].key(): k for k in changed}
+
+        def after(node):
+            if node.key() in keys:
+                return _symbolic.Node('pstate', keys[node.key()])
+            if node.op == 'pstate':
+                raise NotImplementedError('a sprite factor computed from the value a persistent attribute had BEFORE '
+                                          'this reset\'s update')
+            return _symbolic.Node(node.op, *[after(a) if isinstance(a, _symbolic.Node) else a for a in node.args])
+        for sprites in state.values():
+            for sp in sprites:
+                for fname, val in sp.factors.items():
+                    if isinstance(val, sprite_lib.ExprFactor):
+                        val.node = after(val.node)
+        tr.ops[:0] = [_trace.PStateOp(k, numeric[k], updates[k]) for k in changed]
+        return tr, state
+    finally:
+        for k in list(vars(owner)):
+            if k not in saved:
+                delattr(owner, k)
+        for k, v in saved.items():
+            setattr(owner, k, v)
+
+
+def _flatten_host_rules(rules, out=None):
+    out = [] if out is None else out
+    for r in (rules if isinstance(rules, (list, tuple)) else (rules,)):
+        out.append((r, None))
+        kids = getattr(r, '_rules', None)
+        if kids:
+            _flatten_host_rules(list(kids), out)
+    return out
+
+
 def compile_config(state_initializer, physics, task, action_space, observers, game_rules=(),
                    meta_state_initializer=None, layer_capacity=None, keep_sprite_factors=False):
     # meta_state lives on the host (environment.py keeps it for `ModifyMetaState`)
-    del meta_state_initializer
     P = _abi.Program()
     P.abi_version = _abi.MOOG_ABI_VERSION
     if keep_sprite_factors:   # scale / aspect_ratio per sprite in the records (LoggingEnvironment)
@@ -132,8 +209,13 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     shapes = _ShapeTable(P)
 
     # ---- trace the state initializer (environment.py:86) -----------------------
+    owner = getattr(state_initializer, '__self__', None)
+    owner_vars = dict(vars(owner)) if hasattr(owner, '__dict__') else None   # (tracing must leave the config's objects as they were)
     with _trace.tracing() as tr:
         state = state_initializer()
+    persistent = _trace_persistent_state(state_initializer, meta_state_initializer, game_rules, tr, owner_vars)
+    if persistent is not None:
+        tr, state = persistent
     if not isinstance(state, dict):
         raise TypeError('state_initializer must return an OrderedDict of sprite lists')
     layer_names = list(state.keys())
@@ -278,6 +360,14 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                         wall_shape0 = sid
                     if sid != wall_shape0 + x * n + y:
                         raise NotImplementedError('maze wall squares that coincide with other shapes of the config')
+    # numbers the initializer keeps across episodes (_trace_persistent_state): state-slot rules behind the config's rules
+    pstate_names = [op.name for op in tr.ops if isinstance(op, _trace.PStateOp)]
+    pstate_slot = {name: len(flat_rules) + k for k, name in enumerate(pstate_names)}
+
+    def pstate_resolver(key, name):
+        if key != 'pstate':
+            raise NotImplementedError('persistent initializer state computed from %r' % (key,))
+        return pstate_slot[name]
     for oi, (op, sprites) in enumerate(ops):
         G = P.ops[oi]
         runtime = oi >= n_reset_ops
@@ -308,7 +398,12 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE / HDRAW / HEXPR: randomness or a computed value, no sprite
             G.cell_sel, G.cell_arg = op.cell
             G.code_off = -1
-            if isinstance(op, _trace.HExprOp):
+            if isinstance(op, _trace.PStateOp):
+                G.cell_arg = pstate_slot[op.name]
+                G.code_off = put_code(_symbolic.emit(op.node, [], pstate_resolver))
+                G.factors[0].a = op.init
+                P.rule_state2 = 1
+            elif isinstance(op, _trace.HExprOp):
                 G.code_off = put_code(_symbolic.emit(op.node, [], None))
             elif getattr(op, 'accept', None):   # the accept test(s) of a rejection loop over this draw
                 node = op.accept[0]
@@ -385,6 +480,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     raise NotImplementedError('a computed value as factor %r' % (fname,))
 
                 def slot_resolver(key, ref, _oi=oi):
+                    if key == 'pstate':
+                        return pstate_slot[ref]
                     if key != 'slot' or id(ref) not in slot_of:
                         raise NotImplementedError('a factor copied from a sprite that is not in the state')
                     if op_index_of_sprite[id(ref)] >= _oi:
@@ -838,6 +935,13 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.xmod = put_expr(stores=mod)
             R.i0 = 8 | (2 if vec else 0)   # only the layer's first sprite
     P.n_rules = len(flat_rules)
+    for name in pstate_names:   # (their indices were handed out above: directly behind the config's rules)
+        if P.n_rules >= _abi.MOOG_MAX_RULES:
+            raise ValueError('too many game rules (a number the initializer keeps across episodes takes a rule slot)')
+        assert pstate_slot[name] == int(P.n_rules)
+        R = P.rules[P.n_rules]
+        R.kind, R.parent = _abi.MOOG_RULE_STATE_SLOT, -1
+        P.n_rules += 1
     # state that belongs to forces: one never-reset scalar per DeterministicMazeWalk (its read position)
     for F, table in det_walks:
         if P.n_rules >= _abi.MOOG_MAX_RULES:
@@ -989,8 +1093,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     layer_slots = {name: (P.layer_slot0[i], P.layer_nslots[i]) for i, name in enumerate(layer_names)}
     # rule_ref_index: program rule -> index of the config's rule object it stands for in a pre-order walk of the config's
     # rule forest (-1: a rule the lowering added: the extra parts of an expanded config-local rule, state slots of forces)
+    # pstate_slots: (attribute of the initializer's object kept across episodes, rule slot that holds it per env)
     c = Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P), [],
-                 rule_ref_index + [-1] * (int(P.n_rules) - len(rule_ref_index)))
+                 rule_ref_index + [-1] * (int(P.n_rules) - len(rule_ref_index)), sorted(pstate_slot.items()))
     # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
     c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
     return c

@@ -775,7 +775,8 @@ def _substitute(node, old, new):
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
-    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr'):
+    if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr',
+                   'pstate'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -785,7 +786,8 @@ def _sprites_of(node, acc):
         acc.add(node.args[0])
     elif node.op == 'meta':
         acc.add(node.args[0])
-    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr'):
+    elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr',
+                         'pstate'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -950,6 +952,10 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_FACTOR, a=_abi.FACTOR_NAMES.index(node.args[0])))
     elif node.op == 'hdraw':      # a direct np.random draw of the state_initializer (reset-time expressions)
         out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(node.args[0])))
+    elif node.op == 'pstate':     # a number the initializer keeps across episodes; resolver('pstate', name) -> its slot
+        if resolver is None:
+            raise Unsupported('persistent initializer state outside a state_initializer')
+        out.append(dict(op=_abi.MOOG_X_RULE_STATE, a=int(resolver('pstate', node.args[0]))))
     elif node.op == 'meta':       # sprite.metadata[key]: resolver('meta', key) gives the per-slot table in program.cand
         if resolver is None:
             raise Unsupported('sprite.metadata outside a rule / task function')

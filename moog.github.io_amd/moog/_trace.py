@@ -48,6 +48,18 @@ class HExprOp(GenOp):
         self.cell = (_abi.MOOG_CELL_HEXPR, index)
 
 
+class PStateOp(GenOp):
+    """A number the initializer's object keeps ACROSS episodes and updates at every reset but the first
+    (predators_arena.py:56,88-94: the auto-curriculum's predator mass): lives in a per-env slot that resets never clear;
+    `node` is the update over Node('pstate', name), `init` the value of the first episode."""
+
+    def __init__(self, name, init, node):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.name, self.init, self.node = name, float(init), node
+        from . import _abi
+        self.cell = (_abi.MOOG_CELL_PSTATE, -1)   # (the slot's rule index is filled in by the compiler)
+
+
 class ShuffleOp(GenOp):
     """sprite_generators.shuffle: permutes the slots of `members` (generated just before) at every reset."""
 

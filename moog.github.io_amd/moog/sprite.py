@@ -102,7 +102,14 @@ class Sprite(object):
             # reward functions / filters as `s.metadata[key]`
             self.factors['metadata'] = value
             return
-        if name in FACTOR_NAMES and 'factors' in self.__dict__:
+        if name in FACTOR_NAMES and name != 'shape' and 'factors' in self.__dict__:
+            # `s.mass = value` right after construction inside the initializer (predators_arena.py:95-96) is the same
+            # recipe as Sprite(mass=value) -- unless the factor was sampled: the reference drew it and then dropped it
+            from . import _symbolic
+            if isinstance(value, (int, float, np.integer, np.floating, _symbolic.Sym)) and \
+                    not isinstance(value, bool) and name not in self.sample_order:
+                self.factors[name] = self._adopt({name: value})[name]
+                return
             raise NotImplementedError(
                 'assigning sprite.%s after construction is not lowered; pass it to Sprite(...) or '
                 'through the factor distribution' % name)

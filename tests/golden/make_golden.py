@@ -170,6 +170,8 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
         return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
+    if name in ('predators_arena_l1', 'predators_arena_l2', 'predators_arena_l3'):   # (the level is the number of predators)
+        return importlib.import_module('moog_demos.example_configs.predators_arena').get_config(int(name[-1]))
     if name in ('match_to_sample_l2', 'match_to_sample_l3', 'match_to_sample_l4'):   # (the level is the number of targets)
         return importlib.import_module('moog_demos.example_configs.match_to_sample').get_config(int(name[-1]))
     if name in ('multi_tracking_with_feature_l1', 'multi_tracking_with_feature_l3'):
@@ -305,11 +307,19 @@ def bookkeeping(env):
             fstate.append(float(f._n_initial - len(f._step_velocities)))
         else:
             fstate.append(np.nan)
-    return dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
-                action_mem=action_memory(env.action_space), force_state=np.array(fstate, dtype=float),
-                task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
-                rule_counters_flat=np.array(rc_flat, dtype=float),
-                rule_counters2_flat=np.array(rc2_flat, dtype=float))
+    books = dict(step_count=env.step_count, reset_next=int(env.reset_next_step),
+                 action_mem=action_memory(env.action_space), force_state=np.array(fstate, dtype=float),
+                 task_counters=np.array(tc, dtype=float), rule_counters=np.array(rc, dtype=float),
+                 rule_counters_flat=np.array(rc_flat, dtype=float),
+                 rule_counters2_flat=np.array(rc2_flat, dtype=float))
+    # numbers the initializer's own object keeps across episodes (predators_arena.py:56: the curriculum's mass), by
+    # attribute name in sorted order
+    owner = getattr(getattr(env.state_initializer, 'wrapped', env.state_initializer), '__self__', None)
+    keep = sorted(k for k, v in vars(owner).items() if isinstance(v, float)) if hasattr(owner, '__dict__') else []
+    if keep:
+        books['init_state'] = np.array([getattr(owner, k) for k in keep], dtype=float)
+        books['init_state_names'] = np.array(keep)
+    return books
 
 
 def make_slot_map(env, layer_names, caps):
@@ -381,6 +391,7 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
             off += cap
         init_box.update(names=names, caps=caps_, slot_of=m)
         return state
+    init_and_map.wrapped = real_init   # (bookkeeping reads the numbers its object keeps across episodes)
     env.state_initializer = init_and_map
 
     ts = env.reset()
@@ -764,6 +775,10 @@ def main():
         ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (1,)),
         ('match_to_sample_l4', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
         ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
+        ('predators_arena_l2', 260, {}, (0,)),   # ten resets: the curriculum's mass after every one of them
+        ('predators_arena_l2', 120, {}, (1,)),
+        ('predators_arena_l1', 120, {}, (0,)),
+        ('predators_arena_l3', 100, {}, (0,)),
         ('dependent_zoo', 50, {}, (0, 1)),
         ('aa_zoo', 30, {}, (0,)),
         ('aa_zoo_l1', 30, {}, (0,)),

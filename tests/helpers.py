@@ -177,6 +177,12 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
             f[L.o_rule2 + r] = 0.0
         for r, k in ref_rules(c, len(flat2)):
             f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[k]) else flat2[k]
+    if getattr(c, 'pstate_slots', None):   # numbers the initializer keeps across episodes: never cleared by resets
+        names = [str(x) for x in np.asarray(fx['init_state_names'][t]).reshape(-1)]
+        vals = np.asarray(fx['init_state'][t], np.float64).reshape(-1)
+        for name, ri in c.pstate_slots:
+            f[L.o_rule + ri] = vals[names.index(name)]
+            f[L.o_rule2 + ri] = 1.0
     if 'force_state' in fx:   # forces with state of their own (DeterministicMazeWalk's read position: a MOOG_RULE_STATE_SLOT)
         fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
         for fi in range(min(P.n_forces, len(fs))):
@@ -326,6 +332,13 @@ def state_diff(fx, t, c, f64, i32, env=0):
             if P.rules[r].op == 1 and P.rules[r].kind == _abi.MOOG_RULE_PHASE and f[L.o_rule2 + r] != flat2[k]:
                 ints_ok = False
                 detail.append('phase %d duration: %r vs %r' % (r, f[L.o_rule2 + r], flat2[k]))
+    if getattr(c, 'pstate_slots', None):
+        names = [str(x) for x in np.asarray(fx['init_state_names'][t]).reshape(-1)]
+        vals = np.asarray(fx['init_state'][t], np.float64).reshape(-1)
+        for name, ri in c.pstate_slots:
+            if f[L.o_rule + ri] != vals[names.index(name)]:
+                ints_ok = False
+                detail.append('initializer state %s: %r vs %r' % (name, f[L.o_rule + ri], vals[names.index(name)]))
     if 'force_state' in fx:
         fs = np.asarray(fx['force_state'][t], np.float64).reshape(-1)
         for fi in range(min(P.n_forces, len(fs))):
