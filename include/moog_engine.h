@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 24
+#define MOOG_ABI_VERSION 25
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -133,6 +133,15 @@ enum {
   MOOG_CELL_HEXPR,      /* not a cell: o_hdraw[cell_arg] = the value of the expression at dcode[code_off] -- a value the
                          * initializer computed from its draws and uses several times (the compare-exchange outputs of
                          * np.sort over drawn values, match_to_sample.py:46); read back with MOOG_X_HDRAW            */
+  MOOG_CELL_SIMULATE,   /* not a cell: the look-ahead an initializer runs on the state it has just built (bounce_box_contact_
+                         * prediction.py:40-50: `while True: if <test>: return ..; physics.step(state)`).  Repeats:
+                         * evaluate the expression at dcode[code_off] -- 0: go on, k > 0: the loop's k-th exit --; on an
+                         * exit store k in o_hdraw[cell_arg] and stop, otherwise run one env step of the program's
+                         * physics (updates_per_env_step sub-steps, physics.py:88-117; no rules, no task, no action).
+                         * count_max = iteration limit (MOOG_FAULT_SAMPLER_EXHAUSTED beyond it)                     */
+  MOOG_CELL_STORE,      /* not a cell: attribute writes to the already built sprite in slot cell_arg (`s.position = ..`,
+                         * `s.velocity = ..` after the look-ahead, :117-119): the modifier code at dcode[code_off],
+                         * applied with the setters' semantics (sprite.py:616-652)                                 */
   MOOG_CELL_PSTATE      /* not a cell: a number the initializer's object keeps ACROSS episodes (predators_arena.py:56,
                          * 88-94: the auto-curriculum's predator mass).  It lives in the state scalar of the
                          * MOOG_RULE_STATE_SLOT rule cell_arg, which resets never clear: the env's first reset stores
@@ -204,8 +213,11 @@ enum {
                       * float64 2-vectors do (OpenBLAS ddot); float32 operands: a * b + c, two roundings */
   MOOG_X_RULE_STATE2,/* push the second state scalar of rule a (o_rule2: a Phase's drawn duration, the second
                       * uniform of a MOOG_RULE_DRAWS rule)                                                       */
-  MOOG_X_ZIP_ATTR    /* push attribute a of the sprite at sprite 0's list position in layer b: the partner of a
+  MOOG_X_ZIP_ATTR,   /* push attribute a of the sprite at sprite 0's list position in layer b: the partner of a
                       * `for t, c in zip(state[A], state[B])` loop in a config-local rule (match_to_sample.py:71) */
+  MOOG_X_OVERLAPS_SLOTS /* push (sprite in slot a).overlaps_sprite(sprite in slot b), 0 when either is gone: tests
+                      * between fixed sprites in an initializer's look-ahead and in state-level task functions
+                      * (bounce_box_contact_prediction.py:42,125-131)                                             */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -532,8 +544,13 @@ typedef struct {
   double shape_verts[MOOG_MAX_SHAPE_VERTS][2]; /* centred, CCW, unit shapes    */
   double cand[MOOG_MAX_CAND];                  /* DISCRETE candidates / probs  */
   int32_t n_dcode;
-  int32_t pad_;
+  int32_t born_rule;   /* Sprites the config builds OUTSIDE its state_initializer are the same Python objects in every
+                        * episode of the reference: whatever a rule did to them (match_to_sample.py:89-90,205: the
+                        * screen, made transparent once) they keep across resets.  1 + index of the MOOG_RULE_STATE_SLOT
+                        * (op 2) that says "this env has been reset before": from then on the slots marked in
+                        * slot_persist are not rebuilt by a reset.  0: no such sprites.                            */
   moog_dinstr_t dcode[MOOG_MAX_DCODE];         /* distribution programs        */
+  uint8_t slot_persist[MOOG_MAX_SLOTS];        /* 1: built outside the initializer (see born_rule) */
 } moog_program_t;
 
 /* ---- state record layout ------------------------------------------------------

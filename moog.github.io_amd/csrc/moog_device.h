@@ -2185,6 +2185,11 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
         continue;
       }
     }
+    if (op == MOOG_X_OVERLAPS_SLOTS) {   // two fixed sprites (an initializer's look-ahead, state-level task functions)
+      const bool ov = ALIVE(I->a) && ALIVE(I->b) && overlaps(e, I->a, I->b);
+      v[n] = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
+      continue;
+    }
     if (op == MOOG_X_OVERLAPS_FIRST) {   // sprite.overlaps_sprite(state[L][0])
       const int sp = I->b ? s1 : s0;
       int first = -1;
@@ -2975,7 +2980,11 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
       if (cnt == DINF) {
         if constexpr (DYN) hit = task_condition_x(e, T); else hit = task_condition(e, T);
       }
-      if (hit) { r = T->p0; cnt = T->p1; }
+      if (hit) {   // reset.py:55-58: reward_fn(state) when the condition first holds
+        r = T->p0;
+        if constexpr (DYN) { if (T->xreward >= 0) { int t2 = 0; r = eval_expr(e, T->xreward, 0, 0, &t2, nullptr); } }
+        cnt = T->p1;
+      }
       else r = 0.;
       cnt -= 1;
       tsr = (cnt < 0);
@@ -3607,6 +3616,26 @@ __device__ inline void run_genop(Env& e, int oi) {
       }
       return;
     }
+    if (op->cell_sel == MOOG_CELL_SIMULATE) {   // the initializer's look-ahead: physics steps until one of its exits holds
+      bbox_build_all(e);
+      const int K = uni(e.P->updates_per_env_step);
+      int exit_k = 0;
+      for (int it = 0;; ++it) {
+        exit_k = (int)eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
+        if (exit_k != 0) break;
+        if (it >= op->count_max) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+        for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
+      }
+      wsync();
+      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = (double)exit_k;
+      wsync();
+      return;
+    }
+    if (op->cell_sel == MOOG_CELL_STORE) {   // `sprite.position = ...` / `.velocity = ...` on a built sprite
+      bbox_build_all(e);
+      run_modifier(e, op->code_off, op->cell_arg);
+      return;
+    }
     if (op->cell_sel == MOOG_CELL_PSTATE) {   // a number the initializer keeps across episodes (never cleared by resets)
       const int ri = op->cell_arg;
       const bool first = e.f[e.L.o_rule2 + ri] == 0.0;
@@ -3724,11 +3753,21 @@ template <bool DYN>
 __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
-  for (int s = e.lane; s < P->n_slots; s += 64) { FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s); }
+  // sprites the config built outside its initializer are not rebuilt once the env has been reset before (program.born_rule)
+  const bool born = P->born_rule > 0 && e.f[e.L.o_rule + P->born_rule - 1] != 0.0;
+  for (int s = e.lane; s < P->n_slots; s += 64) {
+    if (born && P->slot_persist[s]) { TELE_SET(s, 0); continue; }
+    FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s);
+  }
   wave_global_fence();
   if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
   wsync();
-  for (int oi = 0; oi < P->n_ops; ++oi) run_genop<DYN>(e, oi);
+  if (born) bbox_build_all(e);   // the kept sprites' boxes (scratch, normally made when a sprite is built): the sampler tests against them
+  for (int oi = 0; oi < P->n_ops; ++oi) {
+    if (born && P->ops[oi].cell_sel == MOOG_CELL_NONE && !P->ops[oi].runtime && P->slot_persist[P->ops[oi].slot0]) continue;
+    run_genop<DYN>(e, oi);
+  }
+  if (P->born_rule > 0) { wsync(); if (e.lane == 0) e.f[e.L.o_rule + P->born_rule - 1] = 1.0; wsync(); }
   wave_global_fence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {

@@ -122,6 +122,90 @@ def _reject_f32_velocity(state, layers, what):
                     raise NotImplementedError('%s over sprites whose velocity is sampled by Continuous' % what)
 
 
+def _trace_initializer(state_initializer):
+    """Traces the state_initializer.  An initializer that steps the physics in a loop to look ahead (bounce_box_contact_
+    prediction.py:40-50,113-119) is run once per path through the loop body -- the tracer answers the body's tests on
+    live sprites from a forced list, as moog/_symbolic.py explores config lambdas -- and the paths are merged: the loop
+    becomes one SimOp whose expression says which exit (if any) the current state takes, and what the exits hand to the
+    rest of the initializer (sprite metadata) becomes a value selected by the exit taken."""
+    with _trace.tracing() as tr:
+        state = state_initializer()
+    if tr.sim_op is None:
+        return tr, state
+
+    def index_sprites(st):
+        return {id(sp): (name, i) for name, sprites in st.items() for i, sp in enumerate(sprites)}
+
+    def canon(node, where):   # sprite objects of a run -> (layer, index)
+        args = []
+        for a in node.args:
+            if isinstance(a, _symbolic.Node):
+                args.append(canon(a, where))
+            elif isinstance(a, sprite_lib.Sprite):
+                if id(a) not in where:
+                    raise NotImplementedError('a look-ahead test on a sprite that is not in the returned state')
+                args.append(where[id(a)])
+            else:
+                args.append(a)
+        return _symbolic.Node(node.op, *args)
+
+    paths, exits, forced, plan = [], [], [], None
+    cur_tr, cur_state = tr, state
+    while True:
+        where = index_sprites(cur_state)
+        trail = [(canon(n, where), v) for n, v in cur_tr.sim_trail]
+        if cur_tr.sim_steps == 0:   # this path leaves the loop
+            exits.append((cur_tr, cur_state))
+            paths.append((trail, len(exits), None))
+            if plan is None:
+                plan = [v for _, v in trail]
+        else:
+            paths.append((trail, 0, None))
+        if len(paths) > _symbolic.MAX_PATHS:
+            raise NotImplementedError('too many paths through the look-ahead loop of the state_initializer')
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            break
+        forced = [v for _, v in trail[:k]] + [False]
+        with _trace.tracing(sim_forced=forced, sim_exit_plan=plan) as cur_tr:
+            cur_state = state_initializer()
+        if cur_tr.sim_op is None:
+            raise NotImplementedError('a state_initializer whose look-ahead loop is not always reached')
+    base_tr, base_state = exits[0]
+    cell = base_tr.sim_op.index
+
+    def uncanon(node):   # (layer, index) -> the sprite objects of the run the program is built from
+        return _symbolic.Node(node.op, *[uncanon(a) if isinstance(a, _symbolic.Node) else
+                                         (base_state[a[0]][a[1]] if isinstance(a, tuple) else a) for a in node.args])
+    base_tr.sim_op.node = uncanon(_symbolic._merge(paths, lambda p: _symbolic.const(float(p[1]))))
+    # what the exits hand on: metadata values that differ from exit to exit become a selection by the exit taken
+    for other_tr, other_state in exits[1:]:
+        if [type(op) for op in other_tr.ops] != [type(op) for op in base_tr.ops] or \
+                [(n, len(v)) for n, v in other_state.items()] != [(n, len(v)) for n, v in base_state.items()]:
+            raise NotImplementedError('a state_initializer that builds different states after different outcomes of its look-ahead')
+    for name, sprites in base_state.items():
+        for i, sp in enumerate(sprites):
+            mds = [st[name][i].factors.get('metadata') for _, st in exits]
+            if not any(isinstance(m, dict) for m in mds):
+                continue
+            if not all(isinstance(m, dict) and set(m) == set(mds[0]) for m in mds):
+                raise NotImplementedError('sprite metadata whose keys depend on the outcome of the look-ahead')
+            for key in mds[0]:
+                vals = [m[key] for m in mds]
+                if all(v == vals[0] for v in vals):
+                    continue
+                if not all(isinstance(v, (bool, int, float, np.integer, np.floating, np.bool_)) for v in vals):
+                    raise NotImplementedError('sprite.metadata[%r] set to non-numbers by the look-ahead' % (key,))
+                node = _symbolic.const(float(vals[-1]))
+                for j in range(len(vals) - 2, -1, -1):
+                    test = _symbolic.Node('eq', _symbolic.Node('hdraw', cell), _symbolic.const(float(j + 1)))
+                    node = _symbolic.Node('select', test, _symbolic.const(float(vals[j])), node)
+                sp.factors['metadata'][key] = _symbolic.Sym(node)
+    return base_tr, base_state
+
+
 def _trace_persistent_state(state_initializer, meta_state_initializer, game_rules, first, saved):
     """An initializer that is a method of an object which keeps numbers ACROSS episodes (predators_arena.py:29-106: an
     auto-curriculum adapts `self._mass` at every reset after the first, once the meta-state exists).  The first trace
@@ -211,8 +295,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # ---- trace the state initializer (environment.py:86) -----------------------
     owner = getattr(state_initializer, '__self__', None)
     owner_vars = dict(vars(owner)) if hasattr(owner, '__dict__') else None   # (tracing must leave the config's objects as they were)
-    with _trace.tracing() as tr:
-        state = state_initializer()
+    tr, state = _trace_initializer(state_initializer)
     persistent = _trace_persistent_state(state_initializer, meta_state_initializer, game_rules, tr, owner_vars)
     if persistent is not None:
         tr, state = persistent
@@ -363,6 +446,18 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # numbers the initializer keeps across episodes (_trace_persistent_state): state-slot rules behind the config's rules
     pstate_names = [op.name for op in tr.ops if isinstance(op, _trace.PStateOp)]
     pstate_slot = {name: len(flat_rules) + k for k, name in enumerate(pstate_names)}
+    # sprites built outside the initializer keep what rules did to them across resets (program.born_rule)
+    persist_slots = [sl for sl, sp in enumerate(slot_sprite) if sp is not None and getattr(sp, 'built_outside', False)
+                     and id(sp) not in traced_ids]
+    born_rule = len(flat_rules) + len(pstate_names) if persist_slots else -1
+    for sl in persist_slots:
+        P.slot_persist[sl] = 1
+    P.born_rule = born_rule + 1
+
+    def live_resolver(key, ref):   # sprites named by the initializer's look-ahead / put-back code -> their slots
+        if key != 'slot' or id(ref) not in slot_of:
+            raise NotImplementedError('the state_initializer looks at a sprite that is not in the returned state')
+        return slot_of[id(ref)]
 
     def pstate_resolver(key, name):
         if key != 'pstate':
@@ -398,13 +493,25 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         if not sprites:   # MOOG_CELL_GENERATE / MOOG_CELL_SAMPLE / HDRAW / HEXPR: randomness or a computed value, no sprite
             G.cell_sel, G.cell_arg = op.cell
             G.code_off = -1
-            if isinstance(op, _trace.PStateOp):
+            if isinstance(op, _trace.SimOp):
+                if getattr(tr, 'sim_physics', physics) is not physics:
+                    raise NotImplementedError('the state_initializer steps a physics object other than the environment\'s')
+                G.code_off = put_code(_symbolic.emit(op.node, [], live_resolver))
+                G.count_max = 100000
+            elif isinstance(op, _trace.StoreOp):
+                G.cell_arg = live_resolver('slot', op.sprite)
+                code = []
+                for attr, n in op.stores.items():
+                    _symbolic.emit(n, code, live_resolver)
+                    code.append(dict(op=_abi.MOOG_X_STORE, a=_symbolic.ATTRS.index(attr)))
+                G.code_off = put_code(code)
+            elif isinstance(op, _trace.PStateOp):
                 G.cell_arg = pstate_slot[op.name]
                 G.code_off = put_code(_symbolic.emit(op.node, [], pstate_resolver))
                 G.factors[0].a = op.init
                 P.rule_state2 = 1
             elif isinstance(op, _trace.HExprOp):
-                G.code_off = put_code(_symbolic.emit(op.node, [], None))
+                G.code_off = put_code(_symbolic.emit(op.node, [], live_resolver))
             elif getattr(op, 'accept', None):   # the accept test(s) of a rejection loop over this draw
                 node = op.accept[0]
                 for extra in op.accept[1:]:
@@ -751,7 +858,27 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
 
     meta_tables = {}
 
+    def fixed_sprite(where):
+        lname, k = where
+        if lname in dynamic or k >= len(state[lname]):
+            raise NotImplementedError('state[%r][%d] in a task function: the layer must hold that sprite for the whole '
+                                      'episode' % (lname, k))
+        return state[lname][k]
+
     def resolve_phase(key, name):
+        if key == 'slot':   # a sprite named by position in a task function, (layer, k)
+            return slot_of[id(fixed_sprite(name))] if isinstance(name, tuple) else slot_of[id(name)]
+        if key == 'lmeta':
+            lname, k, mkey = name
+            md = fixed_sprite((lname, k)).factors.get('metadata')
+            if not isinstance(md, dict) or mkey not in md:
+                raise NotImplementedError('state[%r][%d].metadata[%r] is read by a task function but never set' % (lname, k, mkey))
+            v = md[mkey]
+            if isinstance(v, _symbolic.Sym):
+                return v.node
+            if not isinstance(v, (bool, int, float, np.integer, np.floating, np.bool_)):
+                raise NotImplementedError('sprite.metadata[%r] = %r: only numbers and bools are lowered' % (mkey, v))
+            return _symbolic.const(float(v))
         if key == 'meta':   # sprite.metadata[name]: one value per slot (spare slots of dynamic layers: the layer's last recipe)
             if name not in meta_tables:
                 off = int(P.n_cand)
@@ -942,6 +1069,13 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         R = P.rules[P.n_rules]
         R.kind, R.parent = _abi.MOOG_RULE_STATE_SLOT, -1
         P.n_rules += 1
+    if born_rule >= 0:
+        if P.n_rules >= _abi.MOOG_MAX_RULES:
+            raise ValueError('too many game rules (sprites built outside the initializer take a rule slot)')
+        assert born_rule == int(P.n_rules)
+        R = P.rules[P.n_rules]
+        R.kind, R.parent, R.op = _abi.MOOG_RULE_STATE_SLOT, -1, 2
+        P.n_rules += 1
     # state that belongs to forces: one never-reset scalar per DeterministicMazeWalk (its read position)
     for F, table in det_walks:
         if P.n_rules >= _abi.MOOG_MAX_RULES:
@@ -988,6 +1122,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             else:
                 T.cond_value = val
             T.p0, T.p1 = float(t.reward_value()), float(t._steps_after_condition)
+            T.xreward = -1
+            rnode = t.reward_node()
+            if rnode is not None:   # reset.py:57: reward_fn(state), evaluated when the condition first holds
+                T.xreward = put_expr(rnode)
         elif isinstance(t, tasks_lib.StayAlive):
             T.kind = _abi.MOOG_TASK_STAY_ALIVE
             T.i0, T.p0 = int(t._reward_period), float(t._reward_value)

@@ -65,6 +65,12 @@ def lift(v):
 _TRACER = None
 
 
+def _has_live(node):
+    if node.op in ('live', 'overlaps_slots'):
+        return True
+    return any(isinstance(a, Node) and _has_live(a) for a in node.args)
+
+
 class Sym(object):
     """A symbolic scalar."""
     __array_priority__ = 1000
@@ -111,6 +117,8 @@ class Sym(object):
             from . import _trace
             if _trace.active() is None:
                 raise Unsupported('bool() of a symbolic value outside a traced function')
+            if _has_live(self.node):   # a test on the sprites as they are: the look-ahead loop of an initializer
+                return _trace.active().sim_decide(self.node)
             return _trace.active().retry_decide(self.node)
         return _TRACER.decide(self.node)
 
@@ -288,6 +296,10 @@ class SymVec(object):
                 return SymMat([list(c) for c in cols])
             return SymMat([[c[i] for c in cols] for i in range(len(cols[0]))])
         if name == 'copy' and len(args) == 1:
+            from . import _trace
+            t = _trace.active()
+            if t is not None and t.live and _TRACER is None:   # np.copy(sprite.position): the value NOW, kept in a cell
+                return SymVec([t.let(a.node) if _has_live(a.node) else a for a in args[0].items])
             return SymVec(list(args[0].items))
         if name == 'matmul' and len(args) == 2:
             return _matmul(args[0], args[1])
@@ -770,13 +782,94 @@ class _SymMeta(object):
         return _SymMetaValue(key)
 
 
+class _FixedMetadata(object):
+    def __init__(self, where):
+        self._where = where
+
+    def __getitem__(self, key):
+        return Sym(Node('lmeta', self._where[0], self._where[1], key))
+
+
+class _FixedSprite(object):
+    """`state[layer][k]` in a state-level task function that names its sprites by position (bounce_box_contact_
+    prediction.py:123-133): attributes, overlap tests with other such sprites, metadata."""
+
+    def __init__(self, layer, k):
+        self._where = (layer, int(k))
+
+    def overlaps_sprite(self, other):
+        if not isinstance(other, _FixedSprite):
+            raise Unsupported('overlaps_sprite between a positional sprite and a quantified one')
+        return Sym(Node('overlaps_slots', self._where, other._where))
+
+    def __getattr__(self, name):
+        if name == 'metadata':
+            return _FixedMetadata(self._where)
+        if name == 'position':
+            return SymVec([Sym(Node('live', self._where, k)) for k in ('x', 'y')])
+        if name == 'velocity':
+            return SymVec([Sym(Node('live', self._where, k)) for k in ('x_vel', 'y_vel')])
+        if name in ATTRS:
+            return Sym(Node('live', self._where, name))
+        raise Unsupported('sprite.%s is not available to lowered functions' % name)
+
+
+class _FixedLayer(object):
+    def __init__(self, name):
+        self._name = name
+
+    def __getitem__(self, i):
+        if not isinstance(i, (int, np.integer)) or i < 0:
+            raise Unsupported('state[layer][%r]' % (i,))
+        return _FixedSprite(self._name, i)
+
+    def __iter__(self):
+        raise Unsupported('iterating a layer in a function that also names sprites by position')
+
+    def __len__(self):
+        raise Unsupported('len(state[layer]) is not symbolic')
+
+
+class _FixedState(object):
+    def __getitem__(self, name):
+        return _FixedLayer(name)
+
+
+def trace_state_fixed(fn, with_meta=False):
+    """Expression of a state-level function (`condition(state)`, `reward_fn(state)`) that only looks at sprites named
+    by position, `state[layer][k]`: their attributes, overlap tests between them, their metadata.  Leaves carry
+    (layer, k); the compiler turns them into slots of layers whose size never changes."""
+    global _TRACER
+    paths, forced = [], []
+    while True:
+        tr = _Tracer()
+        tr.forced = list(forced)
+        prev, _TRACER = _TRACER, tr
+        try:
+            ret = fn(_FixedState(), _SymMeta()) if with_meta else fn(_FixedState())
+        finally:
+            _TRACER = prev
+        if ret is None or isinstance(ret, (SymVec, SymMat)):
+            raise Unsupported('a state-level function must return a number or a bool')
+        paths.append((list(tr.trail), ret, []))
+        if len(paths) > MAX_PATHS:
+            raise Unsupported('too many execution paths in a lowered state function')
+        trail = tr.trail
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            return _merge(paths, lambda p: lift(p[1]))
+        forced = [v for _, v in trail[:k]] + [False]
+
+
 def _substitute(node, old, new):
     if node.op == 'attr':
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr',
-                   'pstate'):
+                   'pstate', 'live', 'overlaps_slots', 'lmeta'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -787,7 +880,7 @@ def _sprites_of(node, acc):
     elif node.op == 'meta':
         acc.add(node.args[0])
     elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr',
-                         'pstate'):
+                         'pstate', 'live', 'overlaps_slots', 'lmeta'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -952,6 +1045,19 @@ def emit(node, out, resolver=None):
         out.append(dict(op=_abi.MOOG_X_FACTOR, a=_abi.FACTOR_NAMES.index(node.args[0])))
     elif node.op == 'hdraw':      # a direct np.random draw of the state_initializer (reset-time expressions)
         out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(node.args[0])))
+    elif node.op == 'live':       # attribute of a sprite as it is now (not its recipe); resolver('slot', sprite) -> its slot
+        if resolver is None:
+            raise Unsupported('a live sprite attribute outside a state_initializer')
+        out.append(dict(op=_abi.MOOG_X_SLOT_ATTR, a=ATTRS.index(node.args[1]), b=int(resolver('slot', node.args[0]))))
+    elif node.op == 'overlaps_slots':   # sprite_a.overlaps_sprite(sprite_b) for two fixed sprites
+        if resolver is None:
+            raise Unsupported('an overlap test between fixed sprites outside a state_initializer / state function')
+        out.append(dict(op=_abi.MOOG_X_OVERLAPS_SLOTS, a=int(resolver('slot', node.args[0])),
+                        b=int(resolver('slot', node.args[1]))))
+    elif node.op == 'lmeta':      # metadata[key] of the sprite at (layer, k): resolver('lmeta', ...) -> a node (constant or
+        if resolver is None:      # a value the initializer's look-ahead selected)
+            raise Unsupported('sprite metadata outside a task function')
+        emit(resolver('lmeta', node.args), out, resolver)
     elif node.op == 'pstate':     # a number the initializer keeps across episodes; resolver('pstate', name) -> its slot
         if resolver is None:
             raise Unsupported('persistent initializer state outside a state_initializer')

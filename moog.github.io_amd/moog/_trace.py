@@ -60,6 +60,30 @@ class PStateOp(GenOp):
         self.cell = (_abi.MOOG_CELL_PSTATE, -1)   # (the slot's rule index is filled in by the compiler)
 
 
+class SimOp(GenOp):
+    """The initializer runs the episode's physics forward to learn something about the trial (bounce_box_contact_
+    prediction.py:40-50: `while True: if <test>: return ...; physics.step(state)`).  `node`: 0 while the loop goes on,
+    k > 0 when it leaves through its k-th exit (filled in by the compiler from all explored paths); the exit taken goes
+    to direct-draw slot `index`."""
+
+    def __init__(self, index, seq):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.index, self.seq, self.node = index, seq, None
+        from . import _abi
+        self.cell = (_abi.MOOG_CELL_SIMULATE, index)
+
+
+class StoreOp(GenOp):
+    """`sprite.position = ...` / `sprite.velocity = ...` on an already built sprite (bounce_box_contact_prediction.py:
+    117-119: the targets are put back where they started once the look-ahead is done)."""
+
+    def __init__(self, sprite, stores, vec):
+        GenOp.__init__(self, None, 0, 0, False, [], 0, [])
+        self.sprite, self.stores, self.vec = sprite, stores, vec
+        from . import _abi
+        self.cell = (_abi.MOOG_CELL_STORE, -1)
+
+
 class ShuffleOp(GenOp):
     """sprite_generators.shuffle: permutes the slots of `members` (generated just before) at every reset."""
 
@@ -92,6 +116,14 @@ class Tracer(object):
         self.retry_confirmed = []
         self.retry_probe = None
         self.retry_reuse = False
+        # a look-ahead loop that steps the physics inside the initializer (SimOp): explored path by path
+        self.live = False           # sprites are read as they ARE (their slots), no longer as their recipes
+        self.sim_op = None
+        self.sim_forced = []        # answers of the first pass through the loop body (the path this run explores)
+        self.sim_exit_plan = None   # answers that leave the loop (a known exit), used after this run's first physics step
+        self.sim_trail = []         # (node, answer) of the first pass
+        self.sim_steps = 0
+        self.sim_pass_i = 0
 
     def next_seq(self):
         self.seq += 1
@@ -163,6 +195,46 @@ class Tracer(object):
         self.retry_probe, self.retry_reuse = key, True
         return False
 
+    def go_live(self):
+        if self.retry_probe is not None:
+            from . import _symbolic
+            raise _symbolic.Unsupported('a rejection loop with side effects')
+        self.live = True
+
+    def sim_decide(self, node):
+        """bool() of a value read off the live sprites inside the initializer: a test of the look-ahead loop."""
+        from . import _abi, _symbolic
+        if self.sim_op is None:
+            if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+                raise NotImplementedError('more than %d direct np.random draws / computed values per reset' % _abi.MOOG_MAX_HDRAWS)
+            self.sim_op = SimOp(self.n_hdraws, self.next_seq())
+            self.n_hdraws += 1
+            self.add_op(self.sim_op)
+        elif self.ops[-1] is not self.sim_op:
+            raise _symbolic.Unsupported('tests on live sprites after the look-ahead loop of a state_initializer')
+        if self.sim_steps == 0:   # the path this run explores
+            i = len(self.sim_trail)
+            v = self.sim_forced[i] if i < len(self.sim_forced) else True
+            self.sim_trail.append((node, v))
+            return v
+        plan = self.sim_exit_plan   # a later pass: leave through a known exit
+        if plan is None or self.sim_pass_i >= len(plan):
+            raise _symbolic.Unsupported('a look-ahead loop whose first branch does not leave the loop')
+        v = plan[self.sim_pass_i]
+        self.sim_pass_i += 1
+        return v
+
+    def sim_step(self):
+        """physics.step(state) inside the initializer."""
+        from . import _symbolic
+        self.go_live()
+        if self.sim_op is None or self.ops[-1] is not self.sim_op:
+            raise _symbolic.Unsupported('physics.step(state) in a state_initializer outside a look-ahead loop with an exit test')
+        self.sim_steps += 1
+        self.sim_pass_i = 0
+        if self.sim_steps > 2:
+            raise _symbolic.Unsupported('a look-ahead loop that the known exit does not leave')
+
     def choose(self, generators, p, args, kwargs):
         """sample_generator: runs every alternative; their ops become conditional on the drawn index."""
         from . import _abi
@@ -224,9 +296,10 @@ def note_sprite(s):
 
 
 @contextlib.contextmanager
-def tracing():
+def tracing(sim_forced=(), sim_exit_plan=None):
     global _ACTIVE
     t = Tracer()
+    t.sim_forced, t.sim_exit_plan = list(sim_forced), sim_exit_plan
     prev = _ACTIVE
     _ACTIVE = t
     real_randint = np.random.randint

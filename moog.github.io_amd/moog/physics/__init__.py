@@ -186,6 +186,17 @@ class DeterministicMazeWalk(AbstractMazeWalk):
 
 
 class Physics(AbstractPhysics):
+    def step(self, state):
+        """abstract_physics.py:39-42.  The engine steps the physics on the device; the one host-side call that is
+        lowered is the look-ahead an initializer runs on its freshly built state (bounce_box_contact_prediction.py:48):
+        recorded by the tracer as one env step of this physics inside the reset."""
+        from .. import _trace
+        t = _trace.active()
+        if t is None:
+            raise RuntimeError('physics.step(state) runs on the device; on the host it is only traced inside a state_initializer')
+        t.sim_physics = self
+        t.sim_step()
+
     def __init__(self, *forces, updates_per_env_step=1, corrective_physics=()):
         super(Physics, self).__init__(updates_per_env_step=updates_per_env_step)
         self._forces = forces

@@ -64,6 +64,10 @@ class Sprite(object):
         if unknown:
             raise TypeError('unknown sprite factors: %s' % sorted(unknown))
         self.factors = dict(_DEFAULTS)
+        from . import _trace
+        # built while no initializer is being traced = built once by the config: ONE Python object for all episodes
+        # of the reference, so what rules do to it outlives resets (_compiler: slot_persist)
+        self.built_outside = _trace.active() is None
         self.factors.update(self._adopt(factors))
         self.sample_order = [k for k in factors if isinstance(self.factors[k], SymbolicFactor) and
                              not isinstance(self.factors[k], (ExprFactor, ExprShape))]
@@ -94,7 +98,28 @@ class Sprite(object):
     def is_symbolic(self):
         return any(isinstance(v, SymbolicFactor) for v in self.factors.values())
 
+    def overlaps_sprite(self, other):
+        """Inside a traced initializer: the overlap test of the two sprites as they are at that point (the look-ahead
+        loops of bounce_box_contact_prediction.py:42 / red_green.py:102-103)."""
+        from . import _trace, _symbolic
+        t = _trace.active()
+        if t is None or not isinstance(other, Sprite):
+            raise NotImplementedError('sprite.overlaps_sprite outside a traced state_initializer')
+        t.go_live()
+        return _symbolic.Sym(_symbolic.Node('overlaps_slots', self, other))
+
     def __setattr__(self, name, value):
+        if name in ('position', 'velocity') and 'factors' in self.__dict__:
+            # put back / moved after construction inside the initializer (bounce_box_contact_prediction.py:117-119)
+            from . import _trace, _symbolic
+            t = _trace.active()
+            v, ln = _symbolic._elems(value)
+            if t is None or ln != 2:
+                raise NotImplementedError('assigning sprite.%s after construction outside a traced state_initializer' % name)
+            t.go_live()
+            keys = ('x', 'y') if name == 'position' else ('x_vel', 'y_vel')
+            t.add_op(_trace.StoreOp(self, {k: _symbolic.lift(e) for k, e in zip(keys, v)}, name == 'velocity'))
+            return
         # `sprite.mass = ...` after construction (e.g. predators_arena.py:88-89 inside its
         # state_initializer) is host logic the recipe cannot carry: refuse instead of ignoring it
         if name == 'metadata' and 'factors' in self.__dict__:
@@ -117,6 +142,21 @@ class Sprite(object):
 
     def __getattr__(self, name):
         f = self.__dict__.get('factors')
+        if f is not None and name in ('position', 'velocity') or (f is not None and name in f and name != 'metadata'
+                                                                   and name != 'shape'):
+            # once the initializer looks at the sprites as they ARE (it read a position, tested an overlap, stepped the
+            # physics), attribute reads are live values of the sprite's slot, no longer its recipe
+            from . import _trace, _symbolic
+            t = _trace.active()
+            if t is not None and name in ('position', 'velocity'):
+                t.go_live()
+            if t is not None and t.live and not getattr(t, 'suspend', False):
+                if name == 'position':
+                    return _symbolic.SymVec([_symbolic.Sym(_symbolic.Node('live', self, k)) for k in ('x', 'y')])
+                if name == 'velocity':
+                    return _symbolic.SymVec([_symbolic.Sym(_symbolic.Node('live', self, k)) for k in ('x_vel', 'y_vel')])
+                if name in _symbolic.ATTRS:
+                    return _symbolic.Sym(_symbolic.Node('live', self, name))
         if f is not None and name in f:
             v = f[name]
             # a symbolic factor read back by the initializer (`Sprite(x=other.x)`, `1. - other.y`) is a value to
@@ -128,7 +168,7 @@ class Sprite(object):
                 from . import _symbolic
                 return _symbolic.Sym(_symbolic.Node('slotattr', self, name))
             return v
-        if name in ('position', 'velocity', 'vertices', 'overlaps_sprite', 'contains_point', 'color', 'path',
+        if name in ('position', 'velocity', 'vertices', 'contains_point', 'color', 'path',
                     'moment_of_inertia', 'max_radius', 'update_pos_from_vel'):
             # e.g. bounce_box_contact_prediction.py:113-121 / red_green.py:86-106 step the physics inside the
             # state_initializer to label or reject a trial

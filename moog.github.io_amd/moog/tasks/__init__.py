@@ -58,8 +58,8 @@ class Reset(AbstractTask):
         (pong.py:87).  Returns (cond_kind, layer_name, value).
         """
         cond = self._condition
+        from .. import _symbolic
         try:   # all(...) / any(...) over one layer, or a test of its first sprite
-            from .. import _symbolic
             kind, layer, node = _symbolic.trace_state_condition(cond, with_meta=self._with_meta)
             code = {'all': _abi.MOOG_COND_ALL_EXPR, 'any': _abi.MOOG_COND_ANY_EXPR,
                     'first': _abi.MOOG_COND_FIRST_EXPR, 'plain': _abi.MOOG_COND_FIRST_EXPR}[kind]
@@ -69,6 +69,10 @@ class Reset(AbstractTask):
                     and node.args[1].op == 'const'):
                 return code, layer, node
         except NotImplementedError:
+            try:   # sprites named by position: state[L][k] attributes, overlaps, metadata (bounce_box_contact_prediction.py:123-137)
+                return _abi.MOOG_COND_FIRST_EXPR, layer_names[0], _symbolic.trace_state_fixed(cond, self._with_meta)
+            except (NotImplementedError, AttributeError, TypeError):
+                pass
             if self._with_meta:
                 raise
 
@@ -126,7 +130,23 @@ class Reset(AbstractTask):
             value = None
         if isinstance(value, (int, float, np.integer, np.floating)) and not isinstance(value, bool):
             return float(value)
-        raise NotImplementedError('Reset(reward_fn=...) that reads the state is not lowered')
+        return 0.   # (reward_node() carries it)
+
+    def reward_node(self):
+        """Expression of a reward_fn that reads the state (sprites named by position), or None for a constant."""
+        if self._reward_fn is None:
+            return None
+        try:
+            value = self._reward_fn(None)
+            if isinstance(value, (int, float, np.integer, np.floating)) and not isinstance(value, bool):
+                return None
+        except Exception:  # pylint: disable=broad-except
+            pass
+        from .. import _symbolic
+        try:
+            return _symbolic.trace_state_fixed(self._reward_fn)
+        except (AttributeError, TypeError) as exc:
+            raise NotImplementedError('Reset(reward_fn=...) is not lowered: %s' % (exc,))
 
 
 class StayAlive(AbstractTask):

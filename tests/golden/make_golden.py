@@ -149,6 +149,19 @@ def _seek_cover(index):
 seek_match, seek_other = _seek_cover(0), _seek_cover(1)
 
 
+def _answer(side_of_episode):
+    def policy(env, t, rs):
+        """Policy for bounce_box_contact_prediction (Grid actions): watch for a while, then walk the token into one of
+        the two response boxes -- left = 'they will touch', right = 'they will not' -- alternating by episode."""
+        box = policy.episode = getattr(policy, 'episode', 0)
+        if env.step_count == 0:
+            policy.episode = box + 1
+        if env.step_count < 22:
+            return int(rs.randint(2, 5))       # up / down / nothing: stays between the boxes
+        return side_of_episode[box % len(side_of_episode)]
+    return policy
+
+
 def patch_numpy_random():
     np.random.uniform = _uniform
     np.random.rand = _rand
@@ -170,6 +183,9 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
         return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
+    if name in ('bounce_box_contact_prediction', 'bounce_box_contact_prediction_l1'):   # (the level is `translucent_occluder`)
+        return importlib.import_module('moog_demos.example_configs.bounce_box_contact_prediction').get_config(
+            name.endswith('_l1'))
     if name in ('predators_arena_l1', 'predators_arena_l2', 'predators_arena_l3'):   # (the level is the number of predators)
         return importlib.import_module('moog_demos.example_configs.predators_arena').get_config(int(name[-1]))
     if name in ('match_to_sample_l2', 'match_to_sample_l3', 'match_to_sample_l4'):   # (the level is the number of targets)
@@ -434,6 +450,9 @@ def record_config(name, cfg, seed, n_calls, caps_by_layer, n_sub_steps=2):
                 action = ref_action.copy()
         else:
             action = int(act_rs.randint(5)) if is_grid else act_rs.uniform(-1., 1., size=2)
+            if script is not None:   # a policy instead of random actions
+                action = script(env, t, act_rs)
+                action = int(action) if is_grid else np.asarray(action, dtype=float)
             ref_action = action if is_grid else np.array(action)
             if action_f32 and not is_grid:   # the recorded action is the float32 value (as float64)
                 ref_action = np.array(action, dtype=np.float32)
@@ -775,6 +794,8 @@ def main():
         ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (1,)),
         ('match_to_sample_l4', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
         ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
+        ('bounce_box_contact_prediction', 110, {'__script__': _answer([0, 1, 1, 0])}, (0,)),
+        ('bounce_box_contact_prediction_l1', 110, {'__script__': _answer([1, 0, 0, 1])}, (0,)),
         ('predators_arena_l2', 260, {}, (0,)),   # ten resets: the curriculum's mass after every one of them
         ('predators_arena_l2', 120, {}, (1,)),
         ('predators_arena_l1', 120, {}, (0,)),

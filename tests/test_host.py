@@ -49,7 +49,8 @@ def test_missing_library_fails_loudly(tmp_path):
                                         ('pacman', 1), ('parallelogram_catch', 0), ('parallelogram_catch', 2),
                                         ('multi_tracking_with_feature', 3), ('match_to_sample', 2),
                                         ('match_to_sample', 3), ('match_to_sample', 4), ('predators_arena', 1),
-                                        ('predators_arena', 2), ('predators_arena', 3)])
+                                        ('predators_arena', 2), ('predators_arena', 3),
+                                        ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction', 1)])
 def test_reference_configs_load_unchanged(name, level):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
@@ -359,7 +360,6 @@ def test_traced_initializer_arithmetic_matches_numpy():
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
 @pytest.mark.parametrize('name,level,needle', [
-    ('bounce_box_contact_prediction', 0, 'simulate the episode on the host'),
     ('red_green', 1, 'np.random calls inside a distribution sampled by generate_sprites')])
 def test_reference_configs_that_do_not_lower_say_why(name, level, needle):
     """The reference configs the engine does not run are refused at construction with the reason (no silent
