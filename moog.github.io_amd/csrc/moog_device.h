@@ -68,6 +68,7 @@ struct Env {
   unsigned cur_fmask;      // float32 factors of the sprite being created
   int cell_i, cell_j;      // maze cell (row, column) of the sprite being created (MOOG_CELL_* ops)
   int cur_slot;            // slot of the sprite being created (a computed shape is staged in its vertex area)
+  int restart;             // set by a generation op: the initializer starts over (red_green.py:155,203)
   int cell_tab_n, cell_nw; // rank -> cell table of the episode's maze in LDS (cells; wall cells), 0: none
   double xs_centroid[2], xs_inertia[2];   // centroid / inertia per unit area of a computed shape (MOOG_DIST_EXPR_SHAPE)
   int xs_n;
@@ -3621,6 +3622,9 @@ __device__ inline void run_genop(Env& e, int oi) {
       const int K = uni(e.P->updates_per_env_step);
       int exit_k = 0;
       for (int it = 0;; ++it) {
+        wsync();
+        if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg + 1] = (double)it;   // `for step in range(n)`: the loop counter
+        wsync();
         exit_k = (int)eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
         if (exit_k != 0) break;
         if (it >= op->count_max) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
@@ -3629,6 +3633,7 @@ __device__ inline void run_genop(Env& e, int oi) {
       wsync();
       if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = (double)exit_k;
       wsync();
+      if (exit_k > 0 && exit_k < 31 && ((op->max_tries >> exit_k) & 1)) e.restart = 1;   // `return state_initializer()`
       return;
     }
     if (op->cell_sel == MOOG_CELL_STORE) {   // `sprite.position = ...` / `.velocity = ...` on a built sprite
@@ -3699,8 +3704,11 @@ __device__ inline void run_genop(Env& e, int oi) {
   }
   const int cmax = op->count_max, slot0 = op->slot0, disjoint = op->disjoint, max_tries = op->max_tries,
             graceful = op->fail_gracefully;
+  // cell_arg > 0 (plain sprite ops): the call's k-th sprite lives in slot slot0 + cand[cell_arg - 1 + k] (the config spread
+  // the call's sprites over its state in another order, red_green.py:157-183); earlier sprites of the call = the live ones
+  const int perm = (op->cell_sel == MOOG_CELL_NONE && op->cell_arg > 0) ? op->cell_arg - 1 : -1;
   for (int k = 0; k < cmax; ++k) {
-    int s = slot0 + k;
+    int s = slot0 + (perm >= 0 ? (int)P->cand[perm + k] : k);
     if (k >= n) {
       wsync();
       if (e.lane == 0) { FLAGS(s) = 0; NV(s) = 0; }
@@ -3727,13 +3735,17 @@ __device__ inline void run_genop(Env& e, int oi) {
           ov = overlaps_any(e, s, o2->slot0, o2->slot0 + o2->count_max);
         }
       }
-      if (disjoint && !ov) ov = overlaps_any(e, s, slot0, s);
+      if (disjoint && !ov) ov = overlaps_any(e, s, slot0, perm >= 0 ? slot0 + cmax : s);
       if (!ov) break;
       if (count > max_tries) {
         wsync();
         if (graceful) {   // `return sprites` (sprite_generators.py:93-95): this sprite and the rest of the call are dropped
-          for (int t = k + e.lane; t < cmax; t += 64) { FLAGS(slot0 + t) = 0; NV(slot0 + t) = 0; }
+          for (int t = k + e.lane; t < cmax; t += 64) {
+            const int st = slot0 + (perm >= 0 ? (int)P->cand[perm + t] : t);
+            FLAGS(st) = 0; NV(st) = 0;
+          }
           wsync();
+          if (graceful == 2) e.restart = 1;   // the config measures the result and starts over (red_green.py:152-155)
           return;
         }
         if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
@@ -3754,18 +3766,25 @@ __device__ inline void env_reset(Env& e) {
   PProg P = e.P;
   wsync();
   // sprites the config built outside its initializer are not rebuilt once the env has been reset before (program.born_rule)
-  const bool born = P->born_rule > 0 && e.f[e.L.o_rule + P->born_rule - 1] != 0.0;
-  for (int s = e.lane; s < P->n_slots; s += 64) {
-    if (born && P->slot_persist[s]) { TELE_SET(s, 0); continue; }
-    FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s);
-  }
-  wave_global_fence();
-  if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
-  wsync();
-  if (born) bbox_build_all(e);   // the kept sprites' boxes (scratch, normally made when a sprite is built): the sampler tests against them
-  for (int oi = 0; oi < P->n_ops; ++oi) {
-    if (born && P->ops[oi].cell_sel == MOOG_CELL_NONE && !P->ops[oi].runtime && P->slot_persist[P->ops[oi].slot0]) continue;
-    run_genop<DYN>(e, oi);
+  bool born = P->born_rule > 0 && e.f[e.L.o_rule + P->born_rule - 1] != 0.0;
+  for (int attempt = 0;; ++attempt) {   // (an initializer may start over: `return state_initializer()`, red_green.py:155,203)
+    for (int s = e.lane; s < P->n_slots; s += 64) {
+      if (born && P->slot_persist[s]) { TELE_SET(s, 0); continue; }
+      FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s);
+    }
+    wave_global_fence();
+    if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
+    wsync();
+    if (born) bbox_build_all(e);   // the kept sprites' boxes (scratch, normally made when a sprite is built): the sampler tests against them
+    e.restart = 0;
+    for (int oi = 0; oi < P->n_ops && !e.restart; ++oi) {
+      if (born && P->ops[oi].cell_sel == MOOG_CELL_NONE && !P->ops[oi].runtime && P->slot_persist[P->ops[oi].slot0]) continue;
+      run_genop<DYN>(e, oi);
+    }
+    if (!e.restart) break;
+    if (attempt >= 10000) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+    // the sprites built outside the initializer exist from the first pass on: a second pass keeps them as a later episode does
+    if (P->born_rule > 0) born = true;
   }
   if (P->born_rule > 0) { wsync(); if (e.lane == 0) e.f[e.L.o_rule + P->born_rule - 1] = 1.0; wsync(); }
   wave_global_fence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them

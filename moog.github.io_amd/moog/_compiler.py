@@ -26,7 +26,7 @@ from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
     'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index',
-                 'pstate_slots'])
+                 'pstate_slots', 'dynamic_meta'])
 
 
 class _ShapeTable(object):
@@ -124,15 +124,48 @@ def _reject_f32_velocity(state, layers, what):
 
 def _trace_initializer(state_initializer):
     """Traces the state_initializer.  An initializer that steps the physics in a loop to look ahead (bounce_box_contact_
-    prediction.py:40-50,113-119) is run once per path through the loop body -- the tracer answers the body's tests on
-    live sprites from a forced list, as moog/_symbolic.py explores config lambdas -- and the paths are merged: the loop
-    becomes one SimOp whose expression says which exit (if any) the current state takes, and what the exits hand to the
-    rest of the initializer (sprite metadata) becomes a value selected by the exit taken."""
-    with _trace.tracing() as tr:
-        state = state_initializer()
-    if tr.sim_op is None:
-        return tr, state
+    prediction.py:40-50,113-119; red_green.py:92-116,193-203) is run once per path through the loop body -- the tracer
+    answers the body's tests on live sprites from a forced list, as moog/_symbolic.py explores config lambdas -- and the
+    paths are merged: the loop becomes one SimOp whose expression says which exit (if any) the current state takes; what
+    the exits hand to the rest of the initializer (sprite metadata) becomes a value selected by the exit taken; an exit
+    after which the initializer calls itself again is a restart of the whole reset.  Generators that may come out short
+    (fail_gracefully) and whose result the initializer measures are probed the same way."""
+    glob = getattr(state_initializer, '__globals__', None)
+    had_range = glob is not None and 'range' in glob
+    old_range = glob.get('range') if had_range else None
+    if glob is not None:
+        glob['range'] = _trace.traced_range
 
+    def run(**kw):
+        with _trace.tracing(**kw) as t:
+            try:
+                st = state_initializer()
+            except _trace.Restarted:
+                st = None
+        return t, st
+    try:
+        tr, state = run()
+        if tr.sim_op is None and state is None:
+            raise NotImplementedError('a state_initializer that always starts over')
+        if tr.sim_op is not None:
+            tr, state = _explore_look_ahead(run, tr, state)
+        # generators whose short result the initializer reacts to
+        for key in sorted(tr.len_observed):
+            t2, st2 = run(short_op=key)
+            if st2 is None:
+                tr.ops[key].restart_if_short = True
+            elif [type(op) for op in t2.ops] != [type(op) for op in tr.ops]:
+                raise NotImplementedError('a state_initializer that builds a different state when a generator comes out short')
+        return tr, state
+    finally:
+        if glob is not None:
+            if had_range:
+                glob['range'] = old_range
+            else:
+                glob.pop('range', None)
+
+
+def _explore_look_ahead(run, tr, state):
     def index_sprites(st):
         return {id(sp): (name, i) for name, sprites in st.items() for i, sp in enumerate(sprites)}
 
@@ -149,45 +182,82 @@ def _trace_initializer(state_initializer):
                 args.append(a)
         return _symbolic.Node(node.op, *args)
 
+    # A run that starts over has no state of its own to name its sprites by; its tests are named through the sprite
+    # order of the run's generation ops instead, which every run shares with the base run.
+    def op_sprites(t):
+        return [sp for op in t.ops for sp in op.sprites]
+
     paths, exits, forced, plan = [], [], [], None
     cur_tr, cur_state = tr, state
+    raw = []
     while True:
-        where = index_sprites(cur_state)
-        trail = [(canon(n, where), v) for n, v in cur_tr.sim_trail]
-        if cur_tr.sim_steps == 0:   # this path leaves the loop
-            exits.append((cur_tr, cur_state))
-            paths.append((trail, len(exits), None))
-            if plan is None:
-                plan = [v for _, v in trail]
-        else:
-            paths.append((trail, 0, None))
-        if len(paths) > _symbolic.MAX_PATHS:
+        raw.append((cur_tr, cur_state, cur_tr.sim_steps == 0))
+        trail_answers = [v for _, v in cur_tr.sim_trail]
+        if cur_tr.sim_steps == 0 and plan is None:
+            plan = list(trail_answers)
+        if len(raw) > _symbolic.MAX_PATHS:
             raise NotImplementedError('too many paths through the look-ahead loop of the state_initializer')
-        k = len(trail) - 1
-        while k >= 0 and trail[k][1] is False:
+        k = len(trail_answers) - 1
+        while k >= 0 and trail_answers[k] is False:
             k -= 1
         if k < 0:
             break
-        forced = [v for _, v in trail[:k]] + [False]
-        with _trace.tracing(sim_forced=forced, sim_exit_plan=plan) as cur_tr:
-            cur_state = state_initializer()
+        forced = trail_answers[:k] + [False]
+        cur_tr, cur_state = run(sim_forced=forced, sim_exit_plan=plan)
         if cur_tr.sim_op is None:
             raise NotImplementedError('a state_initializer whose look-ahead loop is not always reached')
-    base_tr, base_state = exits[0]
+    finished = [(t, st) for t, st, is_exit in raw if is_exit and st is not None]
+    if not finished:
+        raise NotImplementedError('a state_initializer whose look-ahead never lets it finish')
+    base_tr, base_state = finished[0]
+    base_where = index_sprites(base_state)
+    base_ops = op_sprites(base_tr)
+    statics = {id(sp): sp for sprites in base_state.values() for sp in sprites}
+    restart_mask = 0
+    n_exit = 0
+    exit_of = {}
+    for t, st, is_exit in raw:
+        mine = op_sprites(t)
+        if len(mine) != len(base_ops) and st is not None:
+            raise NotImplementedError('a state_initializer that builds different states after different outcomes of its look-ahead')
+        # sprites of this run -> (layer, index) of the base run's state: generated ones by generation order, the others
+        # (built outside the initializer / static) are the same objects in every run
+        where = {}
+        for a, b in zip(mine, base_ops):
+            if id(b) in base_where:
+                where[id(a)] = base_where[id(b)]
+        for sid in statics:
+            where.setdefault(sid, base_where[sid])
+        if st is not None:
+            for name, sprites in st.items():
+                for i, sp in enumerate(sprites):
+                    where.setdefault(id(sp), (name, i))
+        trail = [(canon(n, where), v) for n, v in t.sim_trail]
+        idx = 0
+        if is_exit:
+            n_exit += 1
+            idx = n_exit
+            exit_of[id(t)] = idx
+            if st is None:
+                restart_mask |= 1 << idx
+        paths.append((trail, idx, None))
+    if n_exit > 30:
+        raise NotImplementedError('a look-ahead loop with more than 30 exits')
     cell = base_tr.sim_op.index
 
     def uncanon(node):   # (layer, index) -> the sprite objects of the run the program is built from
         return _symbolic.Node(node.op, *[uncanon(a) if isinstance(a, _symbolic.Node) else
                                          (base_state[a[0]][a[1]] if isinstance(a, tuple) else a) for a in node.args])
     base_tr.sim_op.node = uncanon(_symbolic._merge(paths, lambda p: _symbolic.const(float(p[1]))))
+    base_tr.sim_op.restart_mask = restart_mask
     # what the exits hand on: metadata values that differ from exit to exit become a selection by the exit taken
-    for other_tr, other_state in exits[1:]:
+    for other_tr, other_state in finished[1:]:
         if [type(op) for op in other_tr.ops] != [type(op) for op in base_tr.ops] or \
                 [(n, len(v)) for n, v in other_state.items()] != [(n, len(v)) for n, v in base_state.items()]:
             raise NotImplementedError('a state_initializer that builds different states after different outcomes of its look-ahead')
     for name, sprites in base_state.items():
         for i, sp in enumerate(sprites):
-            mds = [st[name][i].factors.get('metadata') for _, st in exits]
+            mds = [st[name][i].factors.get('metadata') for _, st in finished]
             if not any(isinstance(m, dict) for m in mds):
                 continue
             if not all(isinstance(m, dict) and set(m) == set(mds[0]) for m in mds):
@@ -200,9 +270,14 @@ def _trace_initializer(state_initializer):
                     raise NotImplementedError('sprite.metadata[%r] set to non-numbers by the look-ahead' % (key,))
                 node = _symbolic.const(float(vals[-1]))
                 for j in range(len(vals) - 2, -1, -1):
-                    test = _symbolic.Node('eq', _symbolic.Node('hdraw', cell), _symbolic.const(float(j + 1)))
+                    test = _symbolic.Node('eq', _symbolic.Node('hdraw', cell),
+                                          _symbolic.const(float(exit_of[id(finished[j][0])])))
                     node = _symbolic.Node('select', test, _symbolic.const(float(vals[j])), node)
                 sp.factors['metadata'][key] = _symbolic.Sym(node)
+                if not hasattr(base_tr, 'dynamic_meta'):
+                    base_tr.dynamic_meta = []
+                base_tr.dynamic_meta.append((sp, key, cell, {exit_of[id(finished[j][0])]: float(vals[j])
+                                                             for j in range(len(vals))}))
     return base_tr, base_state
 
 
@@ -455,6 +530,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     P.born_rule = born_rule + 1
 
     def live_resolver(key, ref):   # sprites named by the initializer's look-ahead / put-back code -> their slots
+        if key == 'simstep':
+            return [op.index for op in tr.ops if isinstance(op, _trace.SimOp)][0] + 1
         if key != 'slot' or id(ref) not in slot_of:
             raise NotImplementedError('the state_initializer looks at a sprite that is not in the returned state')
         return slot_of[id(ref)]
@@ -498,6 +575,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     raise NotImplementedError('the state_initializer steps a physics object other than the environment\'s')
                 G.code_off = put_code(_symbolic.emit(op.node, [], live_resolver))
                 G.count_max = 100000
+                G.max_tries = int(getattr(op, 'restart_mask', 0))   # exits after which the initializer starts over
             elif isinstance(op, _trace.StoreOp):
                 G.cell_arg = live_resolver('slot', op.sprite)
                 code = []
@@ -534,13 +612,27 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     raise ValueError('a generated sprite is missing from the returned state')
             slots = [slot_of[id(s)] for s in sprites]
             if slots != list(range(slots[0], slots[0] + len(slots))):
-                raise ValueError('sprites of one generator call must stay contiguous and ordered')
+                # the call's sprites end up in other places of the state than in call order (red_green.py:157-183: the
+                # first two obstacles become the layers 'red' and 'green' behind the rest): still one contiguous run of
+                # slots, filled through a table
+                lo = min(slots)
+                if sorted(slots) != list(range(lo, lo + len(slots))) or cell is not None:
+                    raise ValueError('sprites of one generator call must occupy one contiguous run of slots')
+                if cand_n + len(slots) > _abi.MOOG_MAX_CAND:
+                    raise ValueError('too many Discrete candidates')
+                G.cell_arg = 1 + cand_n
+                for sl in slots:
+                    P.cand[cand_n] = float(sl - lo)
+                    cand_n += 1
+                slots = list(range(lo, lo + len(slots)))
             G.slot0 = slots[0]
         G.count_max = len(sprites)
         G.count_min = len(sprites) if op is None else op.count_min
         G.disjoint = 0 if op is None else int(op.disjoint)
         G.max_tries = 0 if op is None else int(op.max_tries)
         G.fail_gracefully = int(bool(getattr(op, 'fail_gracefully', False)))
+        if getattr(op, 'restart_if_short', False):
+            G.fail_gracefully = 2   # ... and the initializer starts over when the call came out short (red_green.py:152-155)
         avoid = 0
         if op is not None and not runtime:
             for a in op.avoid:
@@ -554,6 +646,15 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 avoid |= (1 << aj)
         G.avoid_ops = avoid
         proto = sprites[0]
+        for other in sprites[1:]:   # one recipe per call: a factor assigned after the call must be the same for all its sprites
+            for fname in _abi.FACTOR_NAMES:
+                a, b = proto.factors[fname], other.factors[fname]
+                if isinstance(a, sprite_lib.ExprFactor) != isinstance(b, sprite_lib.ExprFactor) or \
+                        (isinstance(a, sprite_lib.ExprFactor) and a.node.key() != b.node.key()) or \
+                        (isinstance(a, (int, float, np.integer, np.floating)) and
+                         isinstance(b, (int, float, np.integer, np.floating)) and float(a) != float(b)):
+                    raise NotImplementedError('sprites of one generator call were given different values of %r after the call'
+                                              % (fname,))
         order = [k for k in proto.sample_order   # factors read off a maze cell take no draw
                  if not isinstance(proto.factors[k], (traced_maze.CellShape, traced_maze.CellIndex))]
         G.n_sampled = len(order)
@@ -857,6 +958,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             fixation_keys[r._meta_state_fixation_key] = ri
 
     meta_tables = {}
+    meta_sides = {}   # while a pair function is lowered: sprite index -> the layers that side ranges over
 
     def fixed_sprite(where):
         lname, k = where
@@ -880,6 +982,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 raise NotImplementedError('sprite.metadata[%r] = %r: only numbers and bools are lowered' % (mkey, v))
             return _symbolic.const(float(v))
         if key == 'meta':   # sprite.metadata[name]: one value per slot (spare slots of dynamic layers: the layer's last recipe)
+            idx, name = name
+            side = meta_sides.get(idx)
+            if side is not None and len(side) == 1 and side[0] not in dynamic and len(state[side[0]]) == 1:
+                return 'node', resolve_phase('lmeta', (side[0], 0, name))   # one fixed sprite: its own value
             if name not in meta_tables:
                 off = int(P.n_cand)
                 if off + S > _abi.MOOG_MAX_CAND:
@@ -898,7 +1004,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                     P.cand[off + sl] = last
                 P.n_cand = off + S
                 meta_tables[name] = off
-            return meta_tables[name]
+            return 'table', meta_tables[name]
         if key is None:   # an overlap test against state[name][0]
             return layer_index(name)
         if name is None:  # the number a Fixation rule keeps under this key
@@ -1107,6 +1213,8 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             T.n1 = _fill_layers(T.layers1, t._layers_1, layer_index)
             T.p1 = float(t._reset_steps_after_contact)
             T.xcond = T.xreward = -1
+            meta_sides.clear()
+            meta_sides.update({0: list(t._layers_0), 1: list(t._layers_1)})
             if callable(t._reward):
                 T.xreward = put_expr(_symbolic.trace_value(t._reward, 2))
             else:
@@ -1233,7 +1341,11 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # rule forest (-1: a rule the lowering added: the extra parts of an expanded config-local rule, state slots of forces)
     # pstate_slots: (attribute of the initializer's object kept across episodes, rule slot that holds it per env)
     c = Compiled(P, layer_names, layer_slots, obs_key, _abi.layout_of(P), [],
-                 rule_ref_index + [-1] * (int(P.n_rules) - len(rule_ref_index)), sorted(pstate_slot.items()))
+                 rule_ref_index + [-1] * (int(P.n_rules) - len(rule_ref_index)), sorted(pstate_slot.items()),
+                 # (slot, metadata key, cell that holds the look-ahead's exit, {exit: value}) of the metadata values
+                 # an initializer's look-ahead decides
+                 [(slot_of[id(sp)], key, cell, table) for sp, key, cell, table in getattr(tr, 'dynamic_meta', [])
+                  if id(sp) in slot_of])
     # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
     c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
     return c

@@ -66,7 +66,7 @@ _TRACER = None
 
 
 def _has_live(node):
-    if node.op in ('live', 'overlaps_slots'):
+    if node.op in ('live', 'overlaps_slots', 'simstep'):
         return True
     return any(isinstance(a, Node) and _has_live(a) for a in node.args)
 
@@ -869,7 +869,7 @@ def _substitute(node, old, new):
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr',
-                   'pstate', 'live', 'overlaps_slots', 'lmeta'):
+                   'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -880,7 +880,7 @@ def _sprites_of(node, acc):
     elif node.op == 'meta':
         acc.add(node.args[0])
     elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr',
-                         'pstate', 'live', 'overlaps_slots', 'lmeta'):
+                         'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -1049,6 +1049,10 @@ def emit(node, out, resolver=None):
         if resolver is None:
             raise Unsupported('a live sprite attribute outside a state_initializer')
         out.append(dict(op=_abi.MOOG_X_SLOT_ATTR, a=ATTRS.index(node.args[1]), b=int(resolver('slot', node.args[0]))))
+    elif node.op == 'simstep':    # the loop counter of the initializer's look-ahead; resolver('simstep', None) -> its cell
+        if resolver is None:
+            raise Unsupported('a look-ahead loop counter outside a state_initializer')
+        out.append(dict(op=_abi.MOOG_X_HDRAW, a=int(resolver('simstep', None))))
     elif node.op == 'overlaps_slots':   # sprite_a.overlaps_sprite(sprite_b) for two fixed sprites
         if resolver is None:
             raise Unsupported('an overlap test between fixed sprites outside a state_initializer / state function')
@@ -1065,7 +1069,11 @@ def emit(node, out, resolver=None):
     elif node.op == 'meta':       # sprite.metadata[key]: resolver('meta', key) gives the per-slot table in program.cand
         if resolver is None:
             raise Unsupported('sprite.metadata outside a rule / task function')
-        out.append(dict(op=_abi.MOOG_X_SLOT_CONST, a=int(resolver('meta', node.args[1])), b=int(node.args[0])))
+        how, what = resolver('meta', (node.args[0], node.args[1]))
+        if how == 'table':
+            out.append(dict(op=_abi.MOOG_X_SLOT_CONST, a=int(what), b=int(node.args[0])))
+        else:   # the sprite on that side is one fixed sprite: its metadata value itself (a constant, or what the
+            emit(what, out, resolver)   # initializer's look-ahead selected)
     elif node.op == 'slotattr':   # a factor of an earlier sprite; resolver('slot', sprite) gives its slot
         if resolver is None:
             raise Unsupported('sprite factor reference outside a state_initializer')

@@ -100,8 +100,16 @@ class ChoiceOp(GenOp):
         self.index, self.n, self.p = index, n, p
 
 
+class Restarted(Exception):
+    """The traced initializer called itself (`return state_initializer()`): the path being explored starts over."""
+
+
 class Tracer(object):
     def __init__(self):
+        self.generators_run = set()   # ids of the generator closures called so far (a second call = the initializer recursed)
+        self.len_observed = set()     # fail_gracefully ops whose result's length / truth the initializer asked for
+        self.short_op = None          # the op this run pretends came out one sprite short
+        self.collected, self.replay, self.replay_i = [], None, 0
         self.ops = []               # GenOp, in randomness-consumption order
         self.op_of = {}             # id(sprite) -> (op, k)
         self.randint_calls = []
@@ -124,6 +132,7 @@ class Tracer(object):
         self.sim_trail = []         # (node, answer) of the first pass
         self.sim_steps = 0
         self.sim_pass_i = 0
+        self.sim_seen = {}          # answers given in the current pass, by test
 
     def next_seq(self):
         self.seq += 1
@@ -132,6 +141,19 @@ class Tracer(object):
     def hdraw(self):
         """A new direct draw: a symbolic uniform in [0, 1)."""
         from . import _abi, _symbolic
+        if getattr(self, 'suspend', False) == 'collect':   # a draw of a config-local distribution inside generate_sprites
+            if self.replay is not None:
+                if self.replay_i >= len(self.replay):
+                    raise NotImplementedError('a distribution that takes a varying number of draws')
+                k = self.replay[self.replay_i][0]
+                self.replay_i += 1
+                return _symbolic.Sym(_symbolic.Node('hdraw', k))
+            if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+                raise NotImplementedError('more than %d direct np.random draws per reset' % _abi.MOOG_MAX_HDRAWS)
+            k = self.n_hdraws
+            self.n_hdraws += 1
+            self.collected.append((k, self.next_seq()))
+            return _symbolic.Sym(_symbolic.Node('hdraw', k))
         if getattr(self, 'suspend', False):
             raise NotImplementedError('np.random calls inside a distribution sampled by generate_sprites')
         if self.retry_reuse:   # the loop body of a rejection loop runs again: the same draw, taken anew on the device
@@ -205,23 +227,27 @@ class Tracer(object):
         """bool() of a value read off the live sprites inside the initializer: a test of the look-ahead loop."""
         from . import _abi, _symbolic
         if self.sim_op is None:
-            if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+            if self.n_hdraws + 2 > _abi.MOOG_MAX_HDRAWS:
                 raise NotImplementedError('more than %d direct np.random draws / computed values per reset' % _abi.MOOG_MAX_HDRAWS)
-            self.sim_op = SimOp(self.n_hdraws, self.next_seq())
-            self.n_hdraws += 1
+            self.sim_op = SimOp(self.n_hdraws, self.next_seq())   # two cells: the exit taken, the loop counter
+            self.n_hdraws += 2
             self.add_op(self.sim_op)
         elif self.ops[-1] is not self.sim_op:
             raise _symbolic.Unsupported('tests on live sprites after the look-ahead loop of a state_initializer')
+        key = node.key()
+        if key in self.sim_seen:   # the same test again within one pass (`0 if red_overlap else 1`, red_green.py:110)
+            return self.sim_seen[key]
         if self.sim_steps == 0:   # the path this run explores
             i = len(self.sim_trail)
             v = self.sim_forced[i] if i < len(self.sim_forced) else True
             self.sim_trail.append((node, v))
-            return v
-        plan = self.sim_exit_plan   # a later pass: leave through a known exit
-        if plan is None or self.sim_pass_i >= len(plan):
-            raise _symbolic.Unsupported('a look-ahead loop whose first branch does not leave the loop')
-        v = plan[self.sim_pass_i]
-        self.sim_pass_i += 1
+        else:                     # a later pass: leave through a known exit
+            plan = self.sim_exit_plan
+            if plan is None or self.sim_pass_i >= len(plan):
+                raise _symbolic.Unsupported('a look-ahead loop whose first branch does not leave the loop')
+            v = plan[self.sim_pass_i]
+            self.sim_pass_i += 1
+        self.sim_seen[key] = v
         return v
 
     def sim_step(self):
@@ -232,6 +258,7 @@ class Tracer(object):
             raise _symbolic.Unsupported('physics.step(state) in a state_initializer outside a look-ahead loop with an exit test')
         self.sim_steps += 1
         self.sim_pass_i = 0
+        self.sim_seen = {}
         if self.sim_steps > 2:
             raise _symbolic.Unsupported('a look-ahead loop that the known exit does not leave')
 
@@ -295,11 +322,39 @@ def note_sprite(s):
         t.add_op(op)
 
 
+class _SimRange(object):
+    """`for step in range(n)` around the look-ahead of an initializer (red_green.py:101): the counter is symbolic (the
+    device counts physics steps in a cell), and 'the range is used up' is one more exit test of the loop."""
+
+    def __init__(self, t, n):
+        self.t, self.n = t, int(n)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        from . import _symbolic
+        step = _symbolic.Sym(_symbolic.Node('simstep'))
+        if bool(step >= self.n):
+            raise StopIteration
+        return step
+
+
+def traced_range(*args):
+    """Stands in for the builtin `range` in the config module while its initializer is traced: once the initializer
+    looks at live sprites, a one-argument range is the look-ahead's step loop."""
+    t = _ACTIVE
+    if t is not None and t.live and len(args) == 1 and t.sim_steps == 0 and (t.sim_op is None or t.ops[-1] is t.sim_op) \
+            and not getattr(t, 'suspend', False):
+        return _SimRange(t, args[0])
+    return range(*args)
+
+
 @contextlib.contextmanager
-def tracing(sim_forced=(), sim_exit_plan=None):
+def tracing(sim_forced=(), sim_exit_plan=None, short_op=None):
     global _ACTIVE
     t = Tracer()
-    t.sim_forced, t.sim_exit_plan = list(sim_forced), sim_exit_plan
+    t.sim_forced, t.sim_exit_plan, t.short_op = list(sim_forced), sim_exit_plan, short_op
     prev = _ACTIVE
     _ACTIVE = t
     real_randint = np.random.randint

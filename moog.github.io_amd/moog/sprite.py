@@ -130,9 +130,18 @@ class Sprite(object):
         if name in FACTOR_NAMES and name != 'shape' and 'factors' in self.__dict__:
             # `s.mass = value` right after construction inside the initializer (predators_arena.py:95-96) is the same
             # recipe as Sprite(mass=value) -- unless the factor was sampled: the reference drew it and then dropped it
-            from . import _symbolic
+            from . import _symbolic, _trace
             if isinstance(value, (int, float, np.integer, np.floating, _symbolic.Sym)) and \
                     not isinstance(value, bool) and name not in self.sample_order:
+                t = _trace.active()
+                mine = t.op_of.get(id(self)) if t is not None else None
+                if mine is not None and len(mine[0].sprites) > 1 and not isinstance(value, _symbolic.Sym) \
+                        and name in ('c0', 'c1', 'c2', 'opacity'):
+                    # ONE sprite of a generator call is repainted (red_green.py:161-167: two of the obstacles become
+                    # red and green): a store right after the call, the recipe stays the generator's.  (Other factors
+                    # set this way must get the same value on every sprite of the call: checked by the compiler.)
+                    t.add_op(_trace.StoreOp(self, {name: _symbolic.lift(value)}, False))
+                    return
                 self.factors[name] = self._adopt({name: value})[name]
                 return
             raise NotImplementedError(

@@ -272,4 +272,6 @@ def is_flat(dist):
         return all(is_flat(c) for c in dist.components)
     if isinstance(dist, DependentDistribution):   # its dependent factors are expressions of the op's own draws
         return is_flat(dist._independent_distrib)
+    if type(dist).__module__ != __name__:   # a distribution class of the config's own (red_green.py:31-64): its sample()
+        return True                         # ran on symbolic draws, its factors are expressions of the op's draws
     return False

@@ -8,6 +8,25 @@ from .. import _trace
 from .. import sprite as sprite_lib
 
 
+class _Generated(list):
+    """What a fail_gracefully generator returned.  While tracing it always holds every placeholder; a config that
+    asks `len(result) < n` / `not result` (red_green.py:152-155) is probed: in the run that explores op `short`, the list
+    claims to be one sprite short -- if the initializer then starts over, the op is marked 'restart when short'."""
+
+    def _short(self):
+        t = _trace.active()
+        if t is not None:
+            t.len_observed.add(self.op_key)
+            return t.short_op == self.op_key
+        return False
+
+    def __len__(self):
+        return list.__len__(self) - (1 if self._short() else 0)
+
+    def __bool__(self):
+        return list.__len__(self) - (1 if self._short() else 0) > 0
+
+
 def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
                      fail_gracefully=False):
     def _generate(disjoint=False, without_overlapping=[]):
@@ -16,6 +35,9 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             raise RuntimeError(
                 'sprite generators only run inside an environment (the state_initializer is '
                 'lowered to the device-side sampler; there is no host sampling path)')
+        if id(_generate) in t.generators_run:   # the initializer called itself: `return state_initializer()` (red_green.py:155,203)
+            raise _trace.Restarted()
+        t.generators_run.add(id(_generate))
         n_calls = len(t.randint_calls)
         n = num_sprites() if callable(num_sprites) else num_sprites
         if len(t.randint_calls) > n_calls:
@@ -25,15 +47,35 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             count_min = count_max = int(n)
         if count_max == 0:   # no sprite, no draw (sprite_generators.py:77-105 loops zero times): not an op at all
             return []
-        t.suspend = True
+        # A component distribution of the config's own may call rng.uniform in sample() (red_green.py:31-48): those are
+        # draws of every try of the sampler, interleaved with the factor samples; the first placeholder records them,
+        # the others replay the same symbolic draws
+        t.suspend = 'collect'
+        t.collected, t.replay = [], None
         try:
-            sprites = [sprite_lib.Sprite(**factor_dist.sample()) for _ in range(count_max)]
+            sprites = []
+            for k in range(count_max):
+                if k == 1:
+                    t.replay = list(t.collected)
+                t.replay_i = 0
+                sprites.append(sprite_lib.Sprite(**factor_dist.sample()))
         finally:
             t.suspend = False
+            t.replay = None
         op = _trace.GenOp(factor_dist, count_min, count_max, bool(disjoint),
                           list(without_overlapping), int(max_recursion_depth), sprites)
         op.fail_gracefully = bool(fail_gracefully)   # (:93-95) return the sprites made so far instead of raising
+        if t.collected:
+            proto = sprites[0]
+            own = sorted((proto.factors[k].seq, ('factor', k)) for k in proto.sample_order)
+            merged = sorted(own + [(seq, ('hdraw', idx)) for idx, seq in t.collected])
+            op.draw_seq = [item for _, item in merged]
         t.add_op(op)
+        if fail_gracefully:
+            out = _Generated(sprites)
+            out.op_key = len(t.ops) - 1
+            op.gen_key = out.op_key
+            return out
         return sprites
 
     return _generate

@@ -149,7 +149,7 @@ def _seek_cover(index):
 seek_match, seek_other = _seek_cover(0), _seek_cover(1)
 
 
-def _answer(side_of_episode):
+def _answer(side_of_episode, idle=(2, 5)):
     def policy(env, t, rs):
         """Policy for bounce_box_contact_prediction (Grid actions): watch for a while, then walk the token into one of
         the two response boxes -- left = 'they will touch', right = 'they will not' -- alternating by episode."""
@@ -157,7 +157,7 @@ def _answer(side_of_episode):
         if env.step_count == 0:
             policy.episode = box + 1
         if env.step_count < 22:
-            return int(rs.randint(2, 5))       # up / down / nothing: stays between the boxes
+            return int(rs.randint(*idle))      # up / down / nothing: stays between the boxes
         return side_of_episode[box % len(side_of_episode)]
     return policy
 
@@ -183,6 +183,9 @@ def load_amd_config(name):
         return importlib.import_module('moog_demos.example_configs.' + name).get_config(0)
     if name in ('parallelogram_catch_l1', 'parallelogram_catch_l2'):   # moving pellets
         return importlib.import_module('moog_demos.example_configs.parallelogram_catch').get_config(int(name[-1]))
+    if name in ('red_green', 'red_green_l1', 'red_green_l2', 'red_green_l3'):   # (the level is the number of obstacles)
+        return importlib.import_module('moog_demos.example_configs.red_green').get_config(
+            int(name[-1]) if name[-1].isdigit() else 0)
     if name in ('bounce_box_contact_prediction', 'bounce_box_contact_prediction_l1'):   # (the level is `translucent_occluder`)
         return importlib.import_module('moog_demos.example_configs.bounce_box_contact_prediction').get_config(
             name.endswith('_l1'))
@@ -261,6 +264,24 @@ def snapshot(env, layer_names, caps, slot_of):
     for ks in owners.values():
         if len(ks) > 1:
             d['vel_group'][ks] = 1 + min(ks)
+    # numbers / bools the config keeps in sprite.metadata (e.g. what an initializer's look-ahead found out,
+    # bounce_box_contact_prediction.py:116, red_green.py:199): by sorted key, NaN where a sprite has none
+    metas = {}
+    for name in layer_names:
+        for i, s in enumerate(env.state[name]):
+            md = getattr(s, 'metadata', None)
+            if isinstance(md, dict):
+                k = int(offs[name]) + i if name in DYNAMIC_LAYERS else slot_of[s.id]
+                for key, val in md.items():
+                    if isinstance(val, (bool, int, float, np.integer, np.floating, np.bool_)) or val is None:
+                        metas.setdefault(str(key), {})[k] = np.nan if val is None else float(val)
+    if metas:
+        keys = sorted(metas)
+        d['meta_keys'] = np.array(keys)
+        d['meta_vals'] = np.full((S, len(keys)), np.nan)
+        for j, key in enumerate(keys):
+            for k, val in metas[key].items():
+                d['meta_vals'][k, j] = val
     return d
 
 
@@ -794,6 +815,9 @@ def main():
         ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (1,)),
         ('match_to_sample_l4', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
         ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
+        ('red_green_l1', 110, {'__script__': _answer([1, 0, 0, 1], (4, 5))}, (0,)),   # (right = red, left = green)
+        ('red_green', 80, {'__script__': _answer([0, 1, 1, 0], (4, 5))}, (0,)),
+        ('red_green_l3', 80, {'__script__': _answer([1, 1, 0, 0], (4, 5))}, (0,)),
         ('bounce_box_contact_prediction', 110, {'__script__': _answer([0, 1, 1, 0])}, (0,)),
         ('bounce_box_contact_prediction_l1', 110, {'__script__': _answer([1, 0, 0, 1])}, (0,)),
         ('predators_arena_l2', 260, {}, (0,)),   # ten resets: the curriculum's mass after every one of them

@@ -177,6 +177,13 @@ def records_from_fixture(fx, t, c, f64=None, i32=None, env=0):
             f[L.o_rule2 + r] = 0.0
         for r, k in ref_rules(c, len(flat2)):
             f[L.o_rule2 + r] = 0.0 if np.isnan(flat2[k]) else flat2[k]
+    for slot, key, cell, table in (getattr(c, 'dynamic_meta', None) or []):
+        # what the initializer's look-ahead stored in a sprite's metadata: the engine keeps the exit the look-ahead took
+        keys = [str(x) for x in np.asarray(fx['meta_keys'][t]).reshape(-1)]
+        val = float(np.asarray(fx['meta_vals'][t])[slot, keys.index(key)])
+        match = [ex for ex, v in table.items() if v == val or (np.isnan(v) and np.isnan(val))]
+        assert match, ('metadata value the look-ahead cannot produce', key, val, table)
+        f[L.o_hdraw + cell] = float(match[0])
     if getattr(c, 'pstate_slots', None):   # numbers the initializer keeps across episodes: never cleared by resets
         names = [str(x) for x in np.asarray(fx['init_state_names'][t]).reshape(-1)]
         vals = np.asarray(fx['init_state'][t], np.float64).reshape(-1)

@@ -50,7 +50,8 @@ def test_missing_library_fails_loudly(tmp_path):
                                         ('multi_tracking_with_feature', 3), ('match_to_sample', 2),
                                         ('match_to_sample', 3), ('match_to_sample', 4), ('predators_arena', 1),
                                         ('predators_arena', 2), ('predators_arena', 3),
-                                        ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction', 1)])
+                                        ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction', 1),
+                                        ('red_green', 0), ('red_green', 1), ('red_green', 2), ('red_green', 3)])
 def test_reference_configs_load_unchanged(name, level):
     """The reference's own config files import this repo's `moog` and lower to the
     same program as the re-stated recipes."""
@@ -358,18 +359,24 @@ def test_traced_initializer_arithmetic_matches_numpy():
             assert np.max(np.abs(got - ref)) <= 1e-15, (got, ref)
 
 
-@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not present')
-@pytest.mark.parametrize('name,level,needle', [
-    ('red_green', 1, 'np.random calls inside a distribution sampled by generate_sprites')])
-def test_reference_configs_that_do_not_lower_say_why(name, level, needle):
-    """The reference configs the engine does not run are refused at construction with the reason (no silent
-    freezing of host randomness, no Python fallback)."""
-    spec = importlib.util.spec_from_file_location('ref_' + name, os.path.join(REF, name + '.py'))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
+def test_what_is_not_lowered_says_why():
+    """Every one of the reference's 14 example configs lowers (test_reference_configs_load_unchanged); what the lowering
+    does not cover is refused at construction with the reason -- no silent freezing of host randomness, no Python
+    fallback: a draw numpy's generator would take once at build time, a branch on a drawn value that is no rejection
+    loop, physics stepped in an initializer outside a look-ahead loop with an exit test."""
+    from moog import _trace, _symbolic as sy, physics as physics_lib, sprite
     with pytest.raises(NotImplementedError) as info:
-        _compiler.compile_config(**m.get_config(level))
-    assert needle in str(info.value)
+        with _trace.tracing():
+            np.random.normal()
+    assert 'np.random.normal' in str(info.value)
+    with pytest.raises(sy.Unsupported):
+        with _trace.tracing():
+            _ = 1. if np.random.uniform() < 0.5 else 2.
+    phys = physics_lib.Physics(updates_per_env_step=1)
+    with pytest.raises(sy.Unsupported) as info:
+        with _trace.tracing():
+            phys.step({'a': [sprite.Sprite(x=0.5, y=0.5)]})
+    assert 'look-ahead' in str(info.value)
 
 
 def test_rejection_loops_over_draws_are_the_only_branches_on_draws():
