@@ -1,4 +1,5 @@
-"""Per-config throughput of the engine (BASELINE.json configs 2-5), kernel times."""
+"""Per-config throughput of the engine (BASELINE.json configs 2-5 and the other lowered configs), kernel times:
+reset, 5 warm-up calls, then `steps` timed calls with random actions (HIP-event kernel times of those calls)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'moog.github.io_amd'))
 import torch
@@ -46,3 +47,10 @@ run('cleanup', 4096, steps=60)
 run('maze_zoo', 4096, steps=60)
 run('pacman', 1024, steps=60)
 run('pacman', 4096, steps=60)
+# the reference configs unlocked in rounds 2 and 3 (their own files load unchanged)
+run('parallelogram_catch', 4096, steps=60)
+run('multi_tracking_with_feature_l3', 4096, steps=60)
+run('match_to_sample_l3', 4096, steps=60)
+run('predators_arena_l2', 4096, steps=60)
+run('bounce_box_contact_prediction', 1024, steps=60)   # (a reset plays the episode forward: ~200 physics steps inside it)
+run('red_green_l1', 1024, steps=60)                    # (likewise, and rejects unusable trials)
