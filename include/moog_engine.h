@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 25
+#define MOOG_ABI_VERSION 26
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -215,6 +215,9 @@ enum {
                       * uniform of a MOOG_RULE_DRAWS rule)                                                       */
   MOOG_X_ZIP_ATTR,   /* push attribute a of the sprite at sprite 0's list position in layer b: the partner of a
                       * `for t, c in zip(state[A], state[B])` loop in a config-local rule (match_to_sample.py:71) */
+  MOOG_X_HDRAW_T,    /* push o_hdraw[a] with the dtype tag kept in o_hdraw[a + 1] (0 weak, 1 float32, 2 float64): a
+                      * MOOG_CELL_HEXPR cell with count_min = 1, e.g. np.copy(sprite.velocity) of a float32 velocity
+                      * that is assigned back later (bounce_box_contact_prediction.py:113-119)                     */
   MOOG_X_OVERLAPS_SLOTS /* push (sprite in slot a).overlaps_sprite(sprite in slot b), 0 when either is gone: tests
                       * between fixed sprites in an initializer's look-ahead and in state-level task functions
                       * (bounce_box_contact_prediction.py:42,125-131)                                             */

@@ -2157,6 +2157,9 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_SLOT_CONST) { v[n] = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
     if (op == MOOG_X_RULE_STATE2) { v[n] = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if constexpr (MOOG_WITH_MAZE != 0) {
+      if (op == MOOG_X_HDRAW_T) { v[n] = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
+    }
     if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
       const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
       int t; v[n] = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
@@ -3651,9 +3654,13 @@ __device__ inline void run_genop(Env& e, int oi) {
       return;
     }
     if (op->cell_sel == MOOG_CELL_HEXPR) {   // a value computed from the draws, kept for several readers
-      const double v = eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
+      int tag = 0;
+      const double v = eval_expr(e, op->code_off, 0, 0, &tag, nullptr);
       wsync();
-      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = v;
+      if (e.lane == 0) {
+        e.f[e.L.o_hdraw + op->cell_arg] = v;
+        if (op->count_min) e.f[e.L.o_hdraw + op->cell_arg + 1] = (double)tag;   // (np.copy keeps the dtype)
+      }
       wsync();
       return;
     }

@@ -590,6 +590,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 P.rule_state2 = 1
             elif isinstance(op, _trace.HExprOp):
                 G.code_off = put_code(_symbolic.emit(op.node, [], live_resolver))
+                G.count_min = int(bool(op.tagged))   # the value's numpy dtype tag goes to the next cell
             elif getattr(op, 'accept', None):   # the accept test(s) of a rejection loop over this draw
                 node = op.accept[0]
                 for extra in op.accept[1:]:

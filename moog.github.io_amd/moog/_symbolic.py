@@ -299,7 +299,7 @@ class SymVec(object):
             from . import _trace
             t = _trace.active()
             if t is not None and t.live and _TRACER is None:   # np.copy(sprite.position): the value NOW, kept in a cell
-                return SymVec([t.let(a.node) if _has_live(a.node) else a for a in args[0].items])
+                return SymVec([t.let(a.node, tagged=True) if _has_live(a.node) else a for a in args[0].items])
             return SymVec(list(args[0].items))
         if name == 'matmul' and len(args) == 2:
             return _matmul(args[0], args[1])
@@ -869,7 +869,7 @@ def _substitute(node, old, new):
     if node.op == 'overlaps':
         return Node('overlaps', new if node.args[0] == old else node.args[0], node.args[1])
     if node.op in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'meta', 'rdraw', 'zattr', 'zipattr',
-                   'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep'):
+                   'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep', 'hdrawt'):
         return node
     return Node(node.op, *[_substitute(a, old, new) if isinstance(a, Node) else a for a in node.args])
 
@@ -880,7 +880,7 @@ def _sprites_of(node, acc):
     elif node.op == 'meta':
         acc.add(node.args[0])
     elif node.op not in ('const', 'phase_is', 'meta_num', 'hdraw', 'slotattr', 'selffac', 'rdraw', 'zattr', 'zipattr',
-                         'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep'):
+                         'pstate', 'live', 'overlaps_slots', 'lmeta', 'simstep', 'hdrawt'):
         for a in node.args:
             if isinstance(a, Node):
                 _sprites_of(a, acc)
@@ -1062,6 +1062,8 @@ def emit(node, out, resolver=None):
         if resolver is None:      # a value the initializer's look-ahead selected)
             raise Unsupported('sprite metadata outside a task function')
         emit(resolver('lmeta', node.args), out, resolver)
+    elif node.op == 'hdrawt':     # a computed cell that carries its numpy dtype in the next cell (np.copy of a live attribute)
+        out.append(dict(op=_abi.MOOG_X_HDRAW_T, a=int(node.args[0])))
     elif node.op == 'pstate':     # a number the initializer keeps across episodes; resolver('pstate', name) -> its slot
         if resolver is None:
             raise Unsupported('persistent initializer state outside a state_initializer')

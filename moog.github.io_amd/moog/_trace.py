@@ -41,9 +41,9 @@ class HExprOp(GenOp):
     """A value the initializer computed from its draws and uses more than once (the outputs of a sorting network over
     drawn values, match_to_sample.py:46): evaluated once per reset into direct-draw slot `index`, read like a draw."""
 
-    def __init__(self, index, node, seq):
+    def __init__(self, index, node, seq, tagged=False):
         GenOp.__init__(self, None, 0, 0, False, [], 0, [])
-        self.index, self.node, self.seq = index, node, seq
+        self.index, self.node, self.seq, self.tagged = index, node, seq, tagged
         from . import _abi
         self.cell = (_abi.MOOG_CELL_HEXPR, index)
 
@@ -171,17 +171,20 @@ class Tracer(object):
         self.retry_op, self.retry_confirmed, self.retry_probe = op, [], None
         return _symbolic.Sym(_symbolic.Node('hdraw', k))
 
-    def let(self, node):
-        """A computed value kept in a direct-draw slot (evaluated once per reset, in op order)."""
+    def let(self, node, tagged=False):
+        """A computed value kept in a direct-draw slot (evaluated once per reset, in op order).  tagged: a copy of a live
+        sprite attribute (np.copy(sprite.velocity)) keeps its numpy dtype in a second cell -- a float32 velocity put back
+        later is a float32 array again."""
         from . import _abi, _symbolic
         if self.retry_probe is not None:
             raise _symbolic.Unsupported('a rejection loop with side effects')
-        if self.n_hdraws >= _abi.MOOG_MAX_HDRAWS:
+        n = 2 if tagged else 1
+        if self.n_hdraws + n > _abi.MOOG_MAX_HDRAWS:
             raise NotImplementedError('more than %d direct np.random draws / computed values per reset' % _abi.MOOG_MAX_HDRAWS)
         k = self.n_hdraws
-        self.n_hdraws += 1
-        self.add_op(HExprOp(k, node, self.next_seq()))
-        return _symbolic.Sym(_symbolic.Node('hdraw', k))
+        self.n_hdraws += n
+        self.add_op(HExprOp(k, node, self.next_seq(), tagged))
+        return _symbolic.Sym(_symbolic.Node('hdrawt' if tagged else 'hdraw', k))
 
     def retry_decide(self, node):
         """bool() of a value computed from the LATEST direct draw inside the initializer.  The only control flow that is

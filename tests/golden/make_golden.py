@@ -149,6 +149,17 @@ def _seek_cover(index):
 seek_match, seek_other = _seek_cover(0), _seek_cover(1)
 
 
+def _go_to(env, t, rs):
+    """Policy for lookahead_zoo (Joystick): after a few idle steps steer the agent to the left pocket, the right pocket
+    or the floor, a different goal every episode."""
+    ep = _go_to.episode = getattr(_go_to, 'episode', 0) + (1 if env.step_count == 0 else 0)
+    if env.step_count < 6:
+        return rs.uniform(-0.2, 0.2, size=2)
+    goal = [np.array([0.2, 0.3]), np.array([0.8, 0.3]), np.array([0.5, 0.1])][ep % 3]
+    d = goal - np.array(env.state['agent'][0].position, dtype=float) - 6. * np.array(env.state['agent'][0].velocity, dtype=float)
+    return np.clip(4. * d + rs.uniform(-0.1, 0.1, size=2), -1., 1.)
+
+
 def _answer(side_of_episode, idle=(2, 5)):
     def policy(env, t, rs):
         """Policy for bounce_box_contact_prediction (Grid actions): watch for a while, then walk the token into one of
@@ -815,6 +826,8 @@ def main():
         ('match_to_sample_l3', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (1,)),
         ('match_to_sample_l4', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_match}, (0,)),
         ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
+        ('lookahead_zoo', 140, {'__script__': _go_to}, (0, 1)),
+        ('lookahead_zoo_l1', 140, {'__script__': _go_to}, (0, 1)),
         ('red_green_l1', 110, {'__script__': _answer([1, 0, 0, 1], (4, 5))}, (0,)),   # (right = red, left = green)
         ('red_green', 80, {'__script__': _answer([0, 1, 1, 0], (4, 5))}, (0,)),
         ('red_green_l3', 80, {'__script__': _answer([1, 1, 0, 0], (4, 5))}, (0,)),
