@@ -319,8 +319,8 @@ def _trace_persistent_state(state_initializer, meta_state_initializer, game_rule
             if not isinstance(v, _symbolic.Sym):
                 raise NotImplementedError('persistent initializer attribute %r is replaced by a non-numeric value' % k)
             updates[k] = v.node
-        if [type(op) for op in tr.ops] != [type(op) for op in first.ops] or \
-                [len(op.sprites) for op in tr.ops] != [len(op.sprites) for op in first.ops]:
+        first_state = getattr(first, 'state_shape', None)
+        if first_state is not None and first_state != [(n, len(v)) for n, v in state.items()]:
             raise NotImplementedError('a state_initializer whose later episodes build a different state than the first')
         # The sprites read the attribute AFTER its update (predators_arena.py:88-96), i.e. the slot's content once the
         # PStateOp has run: the update's expression inside a factor is that slot; the old value is not available there.
@@ -371,6 +371,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     owner = getattr(state_initializer, '__self__', None)
     owner_vars = dict(vars(owner)) if hasattr(owner, '__dict__') else None   # (tracing must leave the config's objects as they were)
     tr, state = _trace_initializer(state_initializer)
+    tr.state_shape = [(n, len(v)) for n, v in state.items()] if isinstance(state, dict) else None
     persistent = _trace_persistent_state(state_initializer, meta_state_initializer, game_rules, tr, owner_vars)
     if persistent is not None:
         tr, state = persistent
