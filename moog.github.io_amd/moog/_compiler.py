@@ -136,8 +136,11 @@ def _trace_initializer(state_initializer):
     if glob is not None:
         glob['range'] = _trace.traced_range
 
+    code = getattr(getattr(state_initializer, '__func__', state_initializer), '__code__', None)
+
     def run(**kw):
         with _trace.tracing(**kw) as t:
+            t.init_code = code
             try:
                 st = state_initializer()
             except _trace.Restarted:

@@ -106,7 +106,7 @@ class Restarted(Exception):
 
 class Tracer(object):
     def __init__(self):
-        self.generators_run = set()   # ids of the generator closures called so far (a second call = the initializer recursed)
+        self.init_code = None         # code object of the initializer being traced (recursion = it starts over)
         self.len_observed = set()     # fail_gracefully ops whose result's length / truth the initializer asked for
         self.short_op = None          # the op this run pretends came out one sprite short
         self.collected, self.replay, self.replay_i = [], None, 0
@@ -141,6 +141,7 @@ class Tracer(object):
     def hdraw(self):
         """A new direct draw: a symbolic uniform in [0, 1)."""
         from . import _abi, _symbolic
+        self.check_restart()
         if getattr(self, 'suspend', False) == 'collect':   # a draw of a config-local distribution inside generate_sprites
             if self.replay is not None:
                 if self.replay_i >= len(self.replay):
@@ -219,6 +220,20 @@ class Tracer(object):
             return True
         self.retry_probe, self.retry_reuse = key, True
         return False
+
+    def check_restart(self):
+        """Raises Restarted when the traced initializer has called itself (`return state_initializer()`, red_green.py:
+        155,203): two frames of its code on the stack.  Called where the initializer does something traceable."""
+        if self.init_code is None:
+            return
+        import sys
+        f, depth = sys._getframe(1), 0
+        while f is not None:
+            if f.f_code is self.init_code:
+                depth += 1
+                if depth > 1:
+                    raise Restarted()
+            f = f.f_back
 
     def go_live(self):
         if self.retry_probe is not None:
@@ -310,6 +325,7 @@ def note_sprite(s):
     t = _ACTIVE
     if t is None or getattr(t, 'suspend', False):
         return
+    t.check_restart()
     if s.is_symbolic:
         op = GenOp(None, 1, 1, False, [], 0, [s])
         # The sprite's own factor samples were taken (in the reference) when `dist.sample()` ran; direct draws made

@@ -35,9 +35,7 @@ def generate_sprites(factor_dist, num_sprites=1, max_recursion_depth=int(1e4),
             raise RuntimeError(
                 'sprite generators only run inside an environment (the state_initializer is '
                 'lowered to the device-side sampler; there is no host sampling path)')
-        if id(_generate) in t.generators_run:   # the initializer called itself: `return state_initializer()` (red_green.py:155,203)
-            raise _trace.Restarted()
-        t.generators_run.add(id(_generate))
+        t.check_restart()   # the initializer called itself: `return state_initializer()` (red_green.py:155,203)
         n_calls = len(t.randint_calls)
         n = num_sprites() if callable(num_sprites) else num_sprites
         if len(t.randint_calls) > n_calls:

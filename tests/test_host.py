@@ -414,3 +414,29 @@ def test_rejection_loops_over_draws_are_the_only_branches_on_draws():
     with pytest.raises(sy.Unsupported):
         with _trace.tracing():
             pair()
+
+
+def test_a_generator_called_twice_is_not_a_restart():
+    """`return state_initializer()` (red_green.py:155,203) is recognised by the initializer's own code appearing twice
+    on the stack, not by a generator being called again: two batches from one generator stay two ops."""
+    import collections
+    from moog.state_initialization import distributions as distribs, sprite_generators
+    gen = sprite_generators.generate_sprites(
+        distribs.Product([distribs.Continuous('x', 0.1, 0.9), distribs.Continuous('y', 0.1, 0.9)], shape='square', scale=0.1),
+        num_sprites=2, fail_gracefully=True)
+
+    def init():
+        first = gen()
+        second = gen(without_overlapping=first)
+        return collections.OrderedDict([('a', first), ('b', second)])
+    tr, state = _compiler._trace_initializer(init)
+    assert len(tr.ops) == 2 and [len(v) for v in state.values()] == [2, 2]
+    assert not any(getattr(op, 'restart_if_short', False) for op in tr.ops)
+
+    def init_again():
+        got = gen()
+        if len(got) < 2:
+            return init_again()
+        return collections.OrderedDict([('a', got)])
+    tr, state = _compiler._trace_initializer(init_again)
+    assert len(tr.ops) == 1 and tr.ops[0].restart_if_short
