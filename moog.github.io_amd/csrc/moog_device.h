@@ -504,6 +504,24 @@ __device__ inline bool overlaps_any(const Env& e, int s, int t0, int t1) {
   return false;
 }
 
+// The live sprites of slots [t0, t1) that sprite s may overlap (bounding circle and box not apart; s itself when it is in the
+// range), visited in slot order: fn(t) runs the exact test.  Lanes = the other sprites for the rejects -- what a loop over
+// overlaps() does one sprite per wave pass (rules and tasks that test one sprite against whole layers).
+template <class Fn>
+__device__ inline void for_each_near(const Env& e, int s, int t0, int t1, Fn fn) {
+  for (int base = t0; base < t1; base += 64) {
+    const int t = base + e.lane;
+    bool cand = false;
+    if (t < t1 && ALIVE(t)) cand = (t == s) || (!circles_apart(e, s, t) && !bbox_apart(e, s, t));
+    unsigned long long m = __ballot(cand);
+    while (m) {
+      const int tt = base + __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      fn(tt);
+    }
+  }
+}
+
 // Narrow phase of up to four broad-phase candidates at once, sixteen lanes each.  About nine
 // candidates in ten do not overlap, and a lone Path.intersects_path keeps ~10 lanes busy, so the
 // ordered pair loop first asks how many of its next candidates are decided "no overlap" by the very
@@ -2514,10 +2532,9 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             if (!ALIVE(s)) continue;
             if (!sprite_filter_x(e, side ? R->filter1 : R->filter, side ? R->xfilter1 : R->xfilter, s)) continue;
             bool any = false;
-            for (int b = 0; b < nb; ++b) {
+            for (int b = 0; b < nb && !any; ++b) {
               const int lb = side ? R->layers[b] : R->layers1[b];
-              for (int t = P->layer_slot0[lb]; t < P->layer_slot0[lb] + P->layer_nslots[lb]; ++t)
-                if (t != s && ALIVE(t) && overlaps(e, s, t)) any = true;
+              any = overlaps_any(e, s, P->layer_slot0[lb], P->layer_slot0[lb] + P->layer_nslots[lb]);   // (never s itself)
             }
             if (any) run_modifier(e, xmod, s);
           }
@@ -2577,8 +2594,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       for (int s = a0; s < a1; ++s) {
         if (!ALIVE(s)) continue;
         bool kill = false;
-        for (int t = b0; t < b1; ++t)
-          if (ALIVE(t) && overlaps(e, s, t)) kill = true;
+        for_each_near(e, s, b0, b1, [&](int t) { if (!kill && overlaps(e, s, t, true)) kill = true; });
         if (kill) {
           wsync();
           if (e.lane == 0) FLAGS(s) |= MOOG_F_TMP;
@@ -2685,8 +2701,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         if (cnt == DINF) {
           int b0 = P->layer_slot0[R->l1], b1 = b0 + P->layer_nslots[R->l1];
           bool any = false;
-          for (int t = b0; t < b1; ++t)
-            if (ALIVE(t) && overlaps(e, agent, t)) any = true;
+          for_each_near(e, agent, b0, b1, [&](int t) { if (!any && overlaps(e, agent, t, true)) any = true; });
           if (any) {
             double m = MASS(agent) * R->p0;
             double c2 = 1. - (1. - COL(agent, 2)) * R->p1;
@@ -2786,8 +2801,9 @@ __device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
     PProg P = e.P;
     int n = 0;
     for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0]; ++s)
-      for (int t = P->layer_slot0[R->l1]; t < P->layer_slot0[R->l1] + P->layer_nslots[R->l1]; ++t)
-        if (ALIVE(s) && ALIVE(t) && overlaps(e, s, t)) ++n;
+      if (ALIVE(s))
+        for_each_near(e, s, P->layer_slot0[R->l1], P->layer_slot0[R->l1] + P->layer_nslots[R->l1],
+                      [&](int t) { if (overlaps(e, s, t, true)) ++n; });
     return n;
   }
   if (R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR)
@@ -2961,19 +2977,19 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
           for (int b = 0; b < T->n1; ++b) {
             int lb = T->layers1[b];
             int b0 = P->layer_slot0[lb], b1 = b0 + P->layer_nslots[lb];
-            for (int s1 = b0; s1 < b1; ++s1) {
-              if (!ALIVE(s1)) continue;
+            // (the pair condition is a pure expression: asking it only of the pairs whose boxes touch changes nothing)
+            for_each_near(e, s0, b0, b1, [&](int s1) {
               if constexpr (DYN) {
-                if (T->xcond >= 0 && eval_expr(e, T->xcond, s0, s1, nullptr, nullptr) == 0) continue;
+                if (T->xcond >= 0 && eval_expr(e, T->xcond, s0, s1, nullptr, nullptr) == 0) return;
               }
-              if (overlaps(e, s0, s1)) {
+              if (overlaps(e, s0, s1, true)) {
                 r = T->p0; rt = 0;
                 if constexpr (DYN) {
                   if (T->xreward >= 0) r = eval_expr(e, T->xreward, s0, s1, &rt, nullptr);
                 }
                 if (cnt == DINF) cnt = T->p1;
               }
-            }
+            });
           }
         }
       }
