@@ -2166,9 +2166,9 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
   wsync();
 #define XTAG(i) ((int)((tags >> (2 * (i))) & 3u))
 #define XSETTAG(i, t) tags = (tags & ~(3u << (2 * (i)))) | ((unsigned)(t) << (2 * (i)))
-  for (int pc = off;; ++pc) {
-    PDinstr I = &P->dcode[pc];
-    const int op = I->op;
+  for (int pc = uni(off);; ++pc) {   // (the code pointer is wave uniform: scalar fetches, not one vector load per instruction)
+    PDinstr I = &P->dcode[uni(pc)];
+    const int op = uni(I->op);
     if (op == MOOG_X_END) break;
     if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
@@ -2376,12 +2376,79 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
 __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the vanished entries
   PProg P = e.P;
   if (!P->layer_dynamic[l]) return;
-  int j = P->layer_slot0[l];
-  const int s1 = P->layer_slot0[l] + P->layer_nslots[l];
-  for (int s = P->layer_slot0[l]; s < s1; ++s) {
-    if (!ALIVE(s)) continue;
-    if (s != j) move_slot(e, j, s);
-    ++j;
+  const int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
+  // nothing to do when the live sprites already are a prefix of the layer
+  {
+    bool gap = false;
+    int live = 0;
+    for (int base = s0; base < s1; base += 64) {
+      const int t = base + e.lane;
+      const unsigned long long m = __ballot(t < s1 && ALIVE(t));
+      const int n_here = __popcll(m), span = (s1 - base < 64) ? s1 - base : 64;
+      (void)span;
+      if (m != ((n_here >= 64) ? ~0ull : ((1ull << n_here) - 1ull)) || (n_here > 0 && live != base - s0)) gap = true;
+      live += n_here;
+    }
+    if (!gap) return;
+  }
+  // 1. vertices and boxes, sprite by sprite in list order (64 lanes per sprite): a sprite only ever moves down, into
+  //    the vertex area of a slot whose own sprite has moved on or is gone
+  {
+    int j = s0;
+    for (int s = s0; s < s1; ++s) {
+      if (!ALIVE(s)) continue;
+      if (s != j) {
+        const int n2 = 2 * NV(s);
+        double* vd = VERT(j);
+        const double* vs = VERT(s);
+        for (int k = e.lane; k < n2; k += 64) vd[k] = vs[k];
+        if (e.lane < 8) BB(j, e.lane) = BB(s, e.lane);
+        wsync();
+      }
+      ++j;
+    }
+  }
+  // 2. the per-sprite fields, lanes = sprites, 64 slots at a time in list order: every lane reads its sprite (some
+  //    fields live in HBM: one round trip for all of them instead of one per field per sprite), the moved-from slots
+  //    are cleared, then every lane writes its sprite to its new slot
+  const moog_layout_t& L = e.L;
+  const bool alias = e.P->vel_alias != 0, facs = e.P->sprite_factors != 0;
+  int j0 = s0;
+  for (int base = s0; base < s1; base += 64) {
+    const int t = base + e.lane;
+    const bool live = t < s1 && ALIVE(t);
+    const unsigned long long m = __ballot(live);
+    const int dst = j0 + __popcll(m & ((1ull << e.lane) - 1ull));
+    const bool mv = live && dst != t;
+    double px = 0, py = 0, vx = 0, vy = 0, ix = 0, iy = 0, c0 = 0, c1 = 0, c2 = 0, an = 0, av = 0, ms = 0, mr = 0, sc = 0, as = 0;
+    int fl = 0, nv = 0, op = 0, sh = 0, te = 0, va = 0, fm = 0;
+    if (mv) {
+      px = e.f[L.o_pos + 2 * t]; py = e.f[L.o_pos + 2 * t + 1];
+      vx = e.f[L.o_vel + 2 * t]; vy = e.f[L.o_vel + 2 * t + 1];
+      ix = e.f[L.o_inertia + 2 * t]; iy = e.f[L.o_inertia + 2 * t + 1];
+      c0 = COL(t, 0); c1 = COL(t, 1); c2 = COL(t, 2);
+      an = ANG(t); av = ANGV(t); ms = MASS(t); mr = MAXR(t);
+      fl = FLAGS(t); nv = NV(t); op = OPAC(t); sh = SHAPEID(t); te = TELE(t);
+      if (alias) va = VALIAS(t);
+      if (facs) { sc = SCALE(t); as = ASPECT(t); fm = FMASK(t); }
+    }
+    wave_global_fence();
+    wsync();
+    if (mv) { FLAGS(t) = 0; NV(t) = 0; }
+    wsync();
+    if (mv) {
+      e.f[L.o_pos + 2 * dst] = px; e.f[L.o_pos + 2 * dst + 1] = py;
+      e.f[L.o_vel + 2 * dst] = vx; e.f[L.o_vel + 2 * dst + 1] = vy;
+      e.f[L.o_inertia + 2 * dst] = ix; e.f[L.o_inertia + 2 * dst + 1] = iy;
+      COL_SET(dst, 0, c0); COL_SET(dst, 1, c1); COL_SET(dst, 2, c2);
+      ANG(dst) = an; ANGV(dst) = av; MASS(dst) = ms; MAXR(dst) = mr;
+      FLAGS(dst) = fl; NV(dst) = nv; OPAC_SET(dst, op); SHAPEID_SET(dst, sh); TELE_SET(dst, te);
+      if (alias) VALIAS(dst) = va;
+      if (facs) { SCALE(dst) = sc; ASPECT(dst) = as; FMASK(dst) = fm; }
+    }
+    wave_global_fence();
+    wsync();
+    j0 += __popcll(m);
   }
 }
 
