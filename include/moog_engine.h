@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 26
+#define MOOG_ABI_VERSION 27
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -383,7 +383,11 @@ enum {
                                       (MOOG_X_RULE_STATE / MOOG_X_RULE_STATE2)                             */
 };
 /* sprite filters: ALWAYS, or the expression at rule.xfilter */
-enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1 };
+enum { MOOG_FILTER_ALWAYS = 0, MOOG_FILTER_EXPR = 1,
+       MOOG_FILTER_EXPR_LANES = 2   /* as EXPR, and the expression only reads its own sprite (constants, attributes, metadata,
+                                     * rule scalars; arithmetic, comparisons, select): the engine may evaluate it for the 64
+                                     * sprites of a layer at once, one per lane (program.xstack_depth stack entries per lane) */
+};
 /* conditions of CONDITIONAL */
 enum {
   MOOG_RCOND_BERNOULLI = 1,     /* np.random.binomial(1, p0): one uniform u, value u < p0 */
@@ -547,6 +551,9 @@ typedef struct {
   double shape_verts[MOOG_MAX_SHAPE_VERTS][2]; /* centred, CCW, unit shapes    */
   double cand[MOOG_MAX_CAND];                  /* DISCRETE candidates / probs  */
   int32_t n_dcode;
+  int32_t xstack_depth; /* deepest value stack among the MOOG_FILTER_EXPR_LANES expressions (0: none) */
+  int32_t pad_x_;
+  int32_t pad_y_;
   int32_t born_rule;   /* Sprites the config builds OUTSIDE its state_initializer are the same Python objects in every
                         * episode of the reference: whatever a rule did to them (match_to_sample.py:89-90,205: the
                         * screen, made transparent once) they keep across resets.  1 + index of the MOOG_RULE_STATE_SLOT

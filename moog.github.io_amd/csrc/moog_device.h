@@ -78,6 +78,7 @@ struct Env {
   int32_t* voff;           // LDS copy of program.slot_voff [S]
   uint16_t* cand;          // LDS scratch [CAND_CAP]: broad-phase survivors (s0 << 8 | s1)
   unsigned long long* rowm; // LDS scratch [64]: candidate bit matrix of a layer against itself
+  double* xstack;          // LDS [program.xstack_depth][64] or null: per-lane value stacks of eval_expr_t<true>
   int n_path, n_resp, n_disj;   // profiling counters (path tests, contact searches, make_disjoint calls)
 #ifdef MOOG_PROFILE
   long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
@@ -2157,10 +2158,16 @@ __device__ inline float np_remf(float a, float b) {
   return mod;
 }
 
-__device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
+// LANES: every lane evaluates the expression for ITS OWN sprite (s0 / s1 differ per lane; the code is still fetched once per
+// wave): filters over whole layers, 64 sprites per pass instead of one.  The value stack is then per lane, in e.xstack
+// (program.xstack_depth entries per lane); only pure one-sprite expressions take this path (MOOG_FILTER_EXPR_LANES).
+template <bool LANES>
+__device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
   PProg P = e.P;
-  double* v = reinterpret_cast<double*>(e.cand);          // [MOOG_X_STACK]
-  double* sv = v + MOOG_X_STACK;                           // pending writes [13]
+  double* vbase = LANES ? e.xstack + e.lane : reinterpret_cast<double*>(e.cand);   // [MOOG_X_STACK] (x 64 lanes, lane-minor)
+  double* sv = reinterpret_cast<double*>(e.cand) + MOOG_X_STACK;   // pending writes [13] (never with LANES)
+  constexpr int VS = LANES ? 64 : 1;
+#define v(i) vbase[(i) * VS]
   unsigned tags = 0;                                       // 2 bits per stack entry
   int n = 0;
   wsync();
@@ -2170,38 +2177,38 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     PDinstr I = &P->dcode[uni(pc)];
     const int op = uni(I->op);
     if (op == MOOG_X_END) break;
-    if (op == MOOG_X_CONST) { v[n] = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
-    if (op == MOOG_X_ATTR) { int t; v[n] = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
-    if (op == MOOG_X_RULE_STATE) { v[n] = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
-    if (op == MOOG_X_SLOT_CONST) { v[n] = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
-    if (op == MOOG_X_RULE_STATE2) { v[n] = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_CONST) { v(n) = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
+    if (op == MOOG_X_ATTR) { int t; v(n) = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE) { v(n) = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_SLOT_CONST) { v(n) = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
+    if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
     if constexpr (MOOG_WITH_MAZE != 0) {
-      if (op == MOOG_X_HDRAW_T) { v[n] = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
+      if (op == MOOG_X_HDRAW_T) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
     }
     if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
       const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
-      int t; v[n] = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
+      int t; v(n) = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
     }
     if (op == MOOG_X_FMA) {   // np.dot / 1-D np.linalg.norm of float64 2-vectors: one rounding (npdot2); float32: two
       n -= 2;
-      const double a = v[n - 1], b = v[n], c = v[n + 1];
+      const double a = v(n - 1), b = v(n), c = v(n + 1);
       const int ta = XTAG(n - 1), tb = XTAG(n), tc = XTAG(n + 1);
       const bool any2 = ta == 2 || tb == 2 || tc == 2, any1 = ta == 1 || tb == 1 || tc == 1;
-      if (any1 && !any2) { const float p = (float)a * (float)b; v[n - 1] = (double)(p + (float)c); }
-      else v[n - 1] = fma(a, b, c);
+      if (any1 && !any2) { const float p = (float)a * (float)b; v(n - 1) = (double)(p + (float)c); }
+      else v(n - 1) = fma(a, b, c);
       XSETTAG(n - 1, any2 ? 2 : (any1 ? 1 : 0));
       continue;
     }
     if constexpr (MOOG_WITH_MAZE != 0) {   // reset-time expressions: only in the kernels that carry every component
-      if (op == MOOG_X_HDRAW) { v[n] = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
-      if (op == MOOG_X_SLOT_ATTR) { int t; v[n] = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
+      if (op == MOOG_X_HDRAW) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
+      if (op == MOOG_X_SLOT_ATTR) { int t; v(n) = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
       if (op == MOOG_X_STORE_VERT) {   // raw shape coordinate -> the vertex area of the slot being created
         --n;
-        if (e.lane == 0) VERT(e.cur_slot)[I->a] = v[n];
+        if (e.lane == 0) VERT(e.cur_slot)[I->a] = v(n);
         continue;
       }
       if (op == MOOG_X_FACTOR) {   // a factor of the sprite being created, staged by sample_factors
-        v[n] = reinterpret_cast<const double*>(e.lst)[I->a];
+        v(n) = reinterpret_cast<const double*>(e.lst)[I->a];
         XSETTAG(n, ((e.fac_f32 >> I->a) & 1u) ? 1 : 0);
         ++n;
         continue;
@@ -2209,7 +2216,7 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
     }
     if (op == MOOG_X_OVERLAPS_SLOTS) {   // two fixed sprites (an initializer's look-ahead, state-level task functions)
       const bool ov = ALIVE(I->a) && ALIVE(I->b) && overlaps(e, I->a, I->b);
-      v[n] = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
+      v(n) = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
       continue;
     }
     if (op == MOOG_X_OVERLAPS_FIRST) {   // sprite.overlaps_sprite(state[L][0])
@@ -2218,26 +2225,26 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
       for (int q = P->layer_slot0[I->a]; q < P->layer_slot0[I->a] + P->layer_nslots[I->a] && first < 0; ++q)
         if (ALIVE(q)) first = q;
       const bool ov = first >= 0 && overlaps(e, sp, first);
-      v[n] = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
+      v(n) = ov ? 1.0 : 0.0; XSETTAG(n, 0); ++n;
       continue;
     }
     if (op == MOOG_X_STORE) {
       --n;
       st->mask |= 1u << I->a;
       st->tags = (st->tags & ~(3u << (2 * I->a))) | ((unsigned)XTAG(n) << (2 * I->a));
-      sv[I->a] = v[n];
+      sv[I->a] = v(n);
       continue;
     }
     if (op == MOOG_X_SELECT) {
       n -= 2;
-      const bool c = v[n - 1] != 0;
+      const bool c = v(n - 1) != 0;
       const int t = c ? XTAG(n) : XTAG(n + 1);
-      v[n - 1] = c ? v[n] : v[n + 1];
+      v(n - 1) = c ? v(n) : v(n + 1);
       XSETTAG(n - 1, t);
       continue;
     }
     if (op >= MOOG_X_NEG && op <= MOOG_X_SIGN) {
-      const double a = v[n - 1];
+      const double a = v(n - 1);
       const bool f32 = XTAG(n - 1) == 1;
       double r = a;
       switch (op) {
@@ -2251,11 +2258,11 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
         case MOOG_X_SIGN: r = (a > 0) ? 1.0 : ((a < 0) ? -1.0 : a); break;
         default: break;
       }
-      v[n - 1] = r;
+      v(n - 1) = r;
       continue;
     }
     --n;
-    const double a = v[n - 1], b = v[n];
+    const double a = v(n - 1), b = v(n);
     const int ta = XTAG(n - 1), tb = XTAG(n);
     const bool f32 = (ta == 1 || tb == 1) && ta != 2 && tb != 2;
     int rt = (ta == 2 || tb == 2) ? 2 : ((ta == 1 || tb == 1) ? 1 : 0);
@@ -2279,15 +2286,20 @@ __device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag
       case MOOG_X_OR: r = (a != 0) || (b != 0); rt = 0; break;
       default: break;
     }
-    v[n - 1] = r;
+    v(n - 1) = r;
     XSETTAG(n - 1, rt);
   }
-  const double top = n > 0 ? v[n - 1] : 0.0;
+  const double top = n > 0 ? v(n - 1) : 0.0;
   if (out_tag) *out_tag = n > 0 ? XTAG(n - 1) : 0;
 #undef XTAG
 #undef XSETTAG
+#undef v
   wsync();
   return top;
+}
+
+__device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
+  return eval_expr_t<false>(e, off, s0, s1, out_tag, st);
 }
 
 // the attribute writes of a modifier (sprite.py setters :540-664)
@@ -2501,6 +2513,15 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
     }
     if (R->kind == MOOG_RULE_VANISH_BY_FILTER) {   // vanish.py:31-39,58-61
       const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      if (R->filter == MOOG_FILTER_EXPR_LANES && e.xstack) {   // lanes = the layer's sprites
+        for (int base = a0; base < a1; base += 64) {
+          const int t = base + e.lane;
+          const bool live = t < a1 && ALIVE(t);
+          const bool hit = eval_expr_t<true>(e, R->xfilter, live ? t : a0, live ? t : a0, nullptr, nullptr) != 0;
+          if (live && hit) FLAGS(t) &= ~MOOG_F_ALIVE;
+          wsync();
+        }
+      } else
       for (int s = a0; s < a1; ++s) {
         if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
         wsync();
@@ -2512,6 +2533,15 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
     }
     if (R->kind == MOOG_RULE_CHANGE_LAYER) {       // change_layer.py:36-46
       const int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
+      if (R->filter == MOOG_FILTER_EXPR_LANES && e.xstack) {
+        for (int base = a0; base < a1; base += 64) {
+          const int t = base + e.lane;
+          const bool live = t < a1 && ALIVE(t);
+          const bool hit = eval_expr_t<true>(e, R->xfilter, live ? t : a0, live ? t : a0, nullptr, nullptr) != 0;
+          if (live && hit) FLAGS(t) |= MOOG_F_TMP;
+          wsync();
+        }
+      } else
       for (int s = a0; s < a1; ++s) {
         if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
         wsync();
@@ -2560,6 +2590,18 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       int n = 0;
       for (int a = 0; a < R->n_layers; ++a) {
         const int l = R->layers[a];
+        if (R->filter == MOOG_FILTER_EXPR_LANES && e.xstack) {
+          const int l0 = P->layer_slot0[l], l1 = l0 + P->layer_nslots[l];
+          for (int base = l0; base < l1; base += 64) {
+            const int t = base + e.lane;
+            const bool live = t < l1 && ALIVE(t);
+            const bool hit = eval_expr_t<true>(e, R->xfilter, live ? t : l0, live ? t : l0, nullptr, nullptr) != 0;
+            if (live && hit) FLAGS(t) |= MOOG_F_TMP;
+            wsync();
+            n += __popcll(__ballot(live && hit));
+          }
+          continue;
+        }
         for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) {
           if (!ALIVE(s) || !sprite_filter(e, R, s)) continue;
           wsync();

@@ -53,6 +53,7 @@ struct moog_engine {
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
   int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
+  int32_t xstack_off = 0;
   bool dynamic_rules = false;
   bool maze_kernel = false;   // the program uses MazePhysics / a maze walk / a per-reset maze
   RPlan raster_plan_{};
@@ -351,6 +352,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
                 (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
                 (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
   if ((size_t)HL.o_verts * 8 < (size_t)DL_SCRATCH_A) e->step_lds += DL_SCRATCH_A + 16;   // the draw-list emission's scratch (moog_kernels.h emit_drawlist)
+  if (prog->xstack_depth > 0) {   // per-lane value stacks of the lane-parallel filter evaluator (moog_device.h eval_expr_t<true>)
+    e->step_lds = (e->step_lds + 15) & ~(size_t)15;
+    e->xstack_off = (int32_t)e->step_lds;
+    e->step_lds += (size_t)prog->xstack_depth * 64 * 8;
+  }
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   if (e->step_lds > 160 * 1024) {
     free_engine(e);
@@ -599,6 +605,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h; a.dl_deep = e->wave ? 1 : 0;
   a.layer_hw = e->layer_hw;
   a.act_f32 = e->act_f32;
+  a.xstack_off = e->xstack_off;
   return a;
 }
 

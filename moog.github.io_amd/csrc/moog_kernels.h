@@ -145,6 +145,7 @@ struct KArgs {
   int32_t dl_deep;       // 1: with the edge records (the wave rasteriser's input); 0: packed points only
   int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
   int32_t act_f32;       // 1: `actions` holds float32 values (moog_engine_set_action_dtype)
+  int32_t xstack_off;    // byte offset of the per-lane expression stacks in a wave's LDS area (Env::xstack), 0: none
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
@@ -179,6 +180,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
   e.rowm = reinterpret_cast<unsigned long long*>(e.lst + 128);
+  e.xstack = a.xstack_off > 0 ? reinterpret_cast<double*>(lds + a.xstack_off) : nullptr;
   if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
   else e.gcol = e.f + H.o_color;
   if (a.H.i_cut1 > a.H.i_cut0) {
