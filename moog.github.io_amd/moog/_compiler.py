@@ -1027,13 +1027,15 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         'CONST', 'ATTR', 'ADD', 'SUB', 'MUL', 'DIV', 'REM', 'MIN', 'MAX', 'LT', 'LE', 'GT', 'GE', 'EQ', 'NE', 'AND', 'OR', 'NEG',
         'ABS', 'SQRT', 'SIN', 'COS', 'FLOOR', 'NOT', 'SIGN', 'SELECT', 'RULE_STATE', 'RULE_STATE2', 'SLOT_CONST', 'FMA'))
 
-    def put_filter(node):
+    def put_filter(node, layers):
         """A sprite filter's code; (offset, filter kind): expressions that only read their own sprite may be evaluated
-        for the 64 sprites of a layer at once (MOOG_FILTER_EXPR_LANES)."""
+        for the 64 sprites of a layer at once (MOOG_FILTER_EXPR_LANES) -- chosen when the rule ranges over at least 32
+        slots: the per-lane stacks cost LDS (half a KB per stack entry), which costs resident envs on small programs."""
         code = _symbolic.emit(node, [], resolve_phase)
         off = put_code(code)
         d = _symbolic.depth(code)
-        if all(ins['op'] in LANE_OPS for ins in code) and d <= 12:
+        slots = sum(int(P.layer_nslots[layer_index(l)]) for l in layers)
+        if all(ins['op'] in LANE_OPS for ins in code) and d <= 12 and slots >= 32:
             P.xstack_depth = max(int(P.xstack_depth), d)
             return off, _abi.MOOG_FILTER_EXPR_LANES
         return off, _abi.MOOG_FILTER_EXPR
@@ -1060,13 +1062,13 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.l0 = layer_index(r._layer)
             R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
             if fnode is not None:
-                R.xfilter, R.filter = put_filter(fnode)
+                R.xfilter, R.filter = put_filter(fnode, [r._layer])
         elif isinstance(r, rules_lib.ChangeLayer):
             R.kind = _abi.MOOG_RULE_CHANGE_LAYER
             R.l0, R.l1 = layer_index(r._old_layer), layer_index(r._new_layer)
             R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
             if fnode is not None:
-                R.xfilter, R.filter = put_filter(fnode)
+                R.xfilter, R.filter = put_filter(fnode, [r._old_layer])
         elif isinstance(r, rules_lib.ModifyOnContact):
             R.kind = _abi.MOOG_RULE_MODIFY_ON_CONTACT
             R.n_layers = _fill_layers(R.layers, list(r._layers_0), layer_index)
@@ -1132,7 +1134,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.kind, R.filter, fnode, mod, vec = r.classify()
             R.n_layers = _fill_layers(R.layers, r._layers, layer_index)
             if fnode is not None:
-                R.xfilter, R.filter = put_filter(fnode)
+                R.xfilter, R.filter = put_filter(fnode, r._layers)
             if mod is not None:
                 R.xmod = put_expr(stores=mod)
                 R.i0 = int(bool(r._sample_one)) | (2 if vec else 0)
