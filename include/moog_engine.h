@@ -255,7 +255,9 @@ typedef struct {
   int32_t slot0;        /* first sprite slot filled                           */
   int32_t count_min;    /* n ~ randint(count_min, count_max + 1)              */
   int32_t count_max;    /* slots reserved                                     */
-  int32_t disjoint;     /* _generate(disjoint=True)                           */
+  int32_t disjoint;     /* bit 0: _generate(disjoint=True).  bit 1 (value 2): a constant one-sprite op -- no draw,
+                         * no rejection test, factors CONST / MAZE_COORD / MAZE_SHAPE only: an engine may build a run of
+                         * such ops at once (they do not see each other); the result is the same either way     */
   int32_t max_tries;    /* max_recursion_depth (default 1e4)                  */
   int32_t n_sampled;    /* number of random factors                           */
   int32_t sample_order[MOOG_MAX_OP_DRAWS]; /* factor ids in draw order; MOOG_NUM_FACTORS + k: direct draw k */

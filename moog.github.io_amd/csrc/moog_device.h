@@ -3834,7 +3834,7 @@ __device__ inline void run_genop(Env& e, int oi) {
       }
     }
   }
-  const int cmax = op->count_max, slot0 = op->slot0, disjoint = op->disjoint, max_tries = op->max_tries,
+  const int cmax = op->count_max, slot0 = op->slot0, disjoint = op->disjoint & 1, max_tries = op->max_tries,
             graceful = op->fail_gracefully;
   // cell_arg > 0 (plain sprite ops): the call's k-th sprite lives in slot slot0 + cand[cell_arg - 1 + k] (the config spread
   // the call's sprites over its state in another order, red_green.py:157-183); earlier sprites of the call = the live ones
@@ -3892,6 +3892,88 @@ __device__ inline void run_genop(Env& e, int oi) {
   }
 }
 
+// A run of consecutive ONE-SPRITE ops without draws, rejection tests or computed factors (op->disjoint == 2, set by the
+// lowering: the wall squares and pellets of a maze, the constant sprites of any config), lanes = ops: every lane builds
+// its own sprite with the arithmetic of sample_factors / create_sprite / set_position / dop_scan.  Such ops do not see
+// each other, so building up to 64 of them at once is the same as one after the other (pacman: 184 of 189 ops, each
+// ~30 k cycles of dependent constant-memory reads on its own).  Needs the rank -> cell tables of this reset in LDS when
+// cells are selected by rank (otherwise the caller takes the ordinary path).
+__device__ inline void run_static_batch(Env& e, int oi0, int nb) {
+  PProg P = e.P;
+  wsync();
+  if (e.lane < nb) {
+    PGenop op = &P->ops[oi0 + e.lane];
+    const int s = op->slot0;
+    bool have = true;
+    int ci = 0, cj = 0;
+    if (op->cell_sel != MOOG_CELL_NONE) {
+      int p = -1;
+      if (op->cell_sel == MOOG_CELL_SAMPLED) p = e.q[e.L.o_maze + MOOG_MAX_MAZE + op->cell_arg];
+      else {
+        const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
+        if (op->cell_sel == MOOG_CELL_WALL_RANK) p = op->cell_arg < e.cell_nw ? (int)tab[op->cell_arg] : -1;
+        else p = op->cell_arg < e.cell_tab_n - e.cell_nw ? (int)tab[e.cell_nw + op->cell_arg] : -1;
+      }
+      have = p >= 0;
+      ci = p >> 8; cj = p & 255;
+    }
+    if (!have) { FLAGS(s) = 0; NV(s) = 0; }
+    else {
+      double fac[MOOG_NUM_FACTORS];
+#pragma unroll
+      for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
+        PFactor F = &op->factors[q];
+        double v = F->a;                                                              // MOOG_DIST_CONST
+        if (F->kind == MOOG_DIST_MAZE_COORD) v = P->cand[F->cand_off + (F->n_cand ? cj : ci)];
+        else if (F->kind == MOOG_DIST_MAZE_SHAPE) v = F->a + (double)(cj * P->maze.size + ci);
+        fac[q] = v;
+      }
+      const int sid = (int)fac[MOOG_FAC_SHAPE];
+      PShape sh = &P->shapes[sid];
+      const double x = fac[MOOG_FAC_X], y = fac[MOOG_FAC_Y];
+      const double angle = fac[MOOG_FAC_ANGLE], scale = fac[MOOG_FAC_SCALE], aspect = fac[MOOG_FAC_ASPECT];
+      const double sx = scale, sy = scale * aspect;
+      const double c = cos(angle), sn = sin(angle);
+      const double m00 = c * sx, m01 = (-sn) * sy, m10 = sn * sx, m11 = c * sy;
+      int n = sh->nverts;
+      if (n > P->slot_vcap[s]) n = P->slot_vcap[s];
+      double* v = VERT(s);
+      double r = -1.0;
+      for (int k = 0; k < n; ++k) {
+        const double ux = P->shape_verts[sh->voff + k][0], uy = P->shape_verts[sh->voff + k][1];
+        const double vx = (m00 * ux + m01 * uy) + x, vy = (m10 * ux + m11 * uy) + y;
+        v[2 * k] = vx; v[2 * k + 1] = vy;
+        r = fmax(r, norm2(vx - x, vy - y));
+      }
+      NV(s) = n;
+      SHAPEID_SET(s, sid);
+      MAXR(s) = r;
+      INER(s, 0) = sh->inertia[0] * (sx * sx);
+      INER(s, 1) = sh->inertia[1] * (sy * sy);
+      ANG(s) = angle;
+      VELX(s) = fac[MOOG_FAC_XVEL]; VELY(s) = fac[MOOG_FAC_YVEL];
+      ANGV(s) = fac[MOOG_FAC_ANGVEL];
+      MASS(s) = fac[MOOG_FAC_MASS];
+      COL_SET(s, 0, fac[MOOG_FAC_C0]); COL_SET(s, 1, fac[MOOG_FAC_C1]); COL_SET(s, 2, fac[MOOG_FAC_C2]);
+      OPAC_SET(s, (int32_t)fac[MOOG_FAC_OPACITY]);
+      TELE_SET(s, 0);
+      if (P->vel_alias) VALIAS(s) = 0;
+      int fl = MOOG_F_ALIVE;
+      if (sh->is_circle && aspect == 1) fl |= MOOG_F_SYM_CIRCLE;
+      FLAGS(s) = fl;
+      if (P->sprite_factors) { SCALE(s) = scale; ASPECT(s) = aspect; FMASK(s) = 0; }
+      // set_position(x + centroid): the path moves by the difference to the position just stored (sprite.py:616-633)
+      const double nx = x + sh->centroid[0], ny = y + sh->centroid[1];
+      const double dx = nx - x, dy = ny - y;
+      for (int k = 0; k < n; ++k) { v[2 * k] = v[2 * k] + dx; v[2 * k + 1] = v[2 * k + 1] + dy; }
+      PX(s) = nx; PY(s) = ny;
+      dop_scan(v, n, &BB(s, 0));
+    }
+  }
+  wave_global_fence();
+  wsync();
+}
+
 // environment.py:82-96
 template <bool DYN>
 __device__ inline void env_reset(Env& e) {
@@ -3911,6 +3993,17 @@ __device__ inline void env_reset(Env& e) {
     e.restart = 0;
     for (int oi = 0; oi < P->n_ops && !e.restart; ++oi) {
       if (born && P->ops[oi].cell_sel == MOOG_CELL_NONE && !P->ops[oi].runtime && P->slot_persist[P->ops[oi].slot0]) continue;
+      if (P->ops[oi].disjoint == 2) {   // constant one-sprite ops: as many as follow each other, 64 lanes at a time
+        bool tables = true;
+        int nb = 0;
+        while (nb < 64 && oi + nb < P->n_ops && P->ops[oi + nb].disjoint == 2 &&
+               !(born && P->ops[oi + nb].cell_sel == MOOG_CELL_NONE && P->slot_persist[P->ops[oi + nb].slot0])) {
+          const int cs = P->ops[oi + nb].cell_sel;
+          if ((cs == MOOG_CELL_WALL_RANK || cs == MOOG_CELL_OPEN_RANK) && e.cell_tab_n <= 0) tables = false;
+          ++nb;
+        }
+        if (tables && nb >= 2) { run_static_batch(e, oi, nb); oi += nb - 1; continue; }
+      }
       run_genop<DYN>(e, oi);
     }
     if (!e.restart) break;

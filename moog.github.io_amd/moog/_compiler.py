@@ -789,6 +789,15 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                 G.factors[ent].draw_pos = pos
                 pos += 1
         G.n_draws = pos
+        # a constant one-sprite op (no draw, no rejection test, no computed factor): the engine may build a run of such
+        # ops side by side, one per lane (bit 1 of `disjoint`; the oracle builds them one after the other)
+        if (not runtime and len(sprites) == 1 and G.count_min == 1 and pos == 0 and not G.avoid_ops and not G.disjoint
+                and G.code_off < 0 and not G.cond_hdraw and not G.fail_gracefully and
+                G.cell_sel in (_abi.MOOG_CELL_NONE, _abi.MOOG_CELL_SAMPLED, _abi.MOOG_CELL_OPEN_RANK, _abi.MOOG_CELL_WALL_RANK)
+                and not (G.cell_sel == _abi.MOOG_CELL_NONE and G.cell_arg) and
+                all(G.factors[fi].kind in (_abi.MOOG_DIST_CONST, _abi.MOOG_DIST_MAZE_COORD, _abi.MOOG_DIST_MAZE_SHAPE)
+                    for fi in range(len(_abi.FACTOR_NAMES)))):
+            G.disjoint = 2
         for sl in slots:
             vcap[sl] = max(vcap[sl], max_nv)   # (sample_generator alternatives share slots)
         op_max_nv[oi] = max_nv
@@ -1337,7 +1346,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             tested.update(R.layers1[i] for i in range(R.n_layers1))
         elif R.kind == _abi.MOOG_RULE_CREATE_SPRITES:
             tested.update(R.layers[i] for i in range(R.n_layers))
-            if R.n_layers or P.ops[R.op].disjoint:
+            if R.n_layers or (P.ops[R.op].disjoint & 1):
                 tested.add(R.l0)
     for ti in range(P.n_tasks):
         T = P.tasks[ti]
@@ -1346,7 +1355,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             tested.update(T.layers1[i] for i in range(T.n1))
     for oi in range(P.n_ops):
         G = P.ops[oi]
-        if G.runtime or not (G.avoid_ops or G.disjoint):
+        if G.runtime or not (G.avoid_ops or (G.disjoint & 1)):
             continue
         tested.add(P.slot_layer[G.slot0])
         for oj in range(oi):
