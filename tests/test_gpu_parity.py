@@ -1452,3 +1452,73 @@ def test_sprites_without_a_finite_vertex(name, n, pre, steps):
         o.f64[:], o.i32[:] = f, q
         assert np.array_equal(out.observation['image'].cpu().numpy(), o.render()), 'frames differ at step %d' % k
     env.close()
+
+
+@pytest.mark.gpu
+def test_filters_over_big_layers_lane_parallel():
+    """Filters that only read their own sprite are evaluated for 64 sprites of a layer at once, one per lane, when the
+    rule ranges over >= 32 slots (MOOG_FILTER_EXPR_LANES, eval_expr_t<true>): VanishByFilter, ChangeLayer and ModifySprites
+    on layers of 48 and 70 slots (more than one pass of 64 lanes), dtype-sensitive filters (float32 velocities), list
+    compaction after the vanishes -- engine against the oracle (which walks the sprites one by one) in lock step."""
+    import collections
+    from moog import action_spaces, environment, game_rules as gr, observers, physics as physics_lib, sprite, tasks, _abi
+    from moog.state_initialization import distributions as distribs, sprite_generators
+
+    def get_config():
+        dots = distribs.Product(
+            [distribs.Continuous('x', 0.05, 0.95), distribs.Continuous('y', 0.05, 0.95),
+             distribs.Continuous('x_vel', -0.03, 0.03), distribs.Continuous('y_vel', -0.03, 0.03),
+             distribs.Continuous('c0', 0., 1.), distribs.Discrete('opacity', [255, 128])],
+            shape='triangle', scale=0.03, c1=1., c2=1.)
+        make_dots = sprite_generators.generate_sprites(dots, num_sprites=60)
+        make_more = sprite_generators.generate_sprites(dots, num_sprites=40)
+
+        def state_initializer():
+            return collections.OrderedDict([('dots', make_dots()), ('more', make_more()), ('bin', []),
+                                            ('agent', [sprite.Sprite(x=0.5, y=0.5, shape='square', scale=0.05, c0=0.3, c1=1., c2=1.)])])
+
+        def leaving(s):
+            low = (s.position < 0.1) * (s.velocity < 0.)
+            high = (s.position > 0.9) * (s.velocity > 0.)
+            return any(low) or any(high)
+
+        def faint(s):
+            return s.opacity < 200 and s.c0 > 0.5 and np.abs(s.x_vel) + np.abs(s.y_vel) > 0.02
+
+        def brake(s):
+            s.velocity = s.velocity * 0.5
+            s.c2 = 0.5
+
+        rules = (gr.VanishByFilter('dots', leaving), gr.ChangeLayer('more', 'bin', filter_fn=leaving),
+                 gr.ModifySprites(('dots', 'more'), brake, filter_fn=faint))
+        return {
+            'state_initializer': state_initializer,
+            'physics': physics_lib.Physics((physics_lib.Drag(coeff_friction=0.01), ['dots', 'more']), updates_per_env_step=2),
+            'task': tasks.CompositeTask(tasks.ContactReward(1, layers_0='agent', layers_1=('dots', 'more')), timeout_steps=25),
+            'action_space': action_spaces.Joystick(scaling_factor=0.02, action_layers='agent'),
+            'observers': {'image': observers.PILRenderer(image_size=(64, 64), color_to_rgb='hsv_to_rgb')},
+            'game_rules': rules,
+        }
+    n = 48
+    env = environment.BatchedEnvironment(num_envs=n, seed=21, env_index0=300, layer_capacity={'dots': 70, 'more': 48, 'bin': 48},
+                                         **get_config())
+    P = env.compiled.program
+    assert int(P.xstack_depth) > 0 and [P.rules[r].filter for r in range(3)] == [_abi.MOOG_FILTER_EXPR_LANES] * 3
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=21, env_index0=300)
+    env.reset()
+    o.reset(render=False)
+    rs = np.random.RandomState(4)
+    for k in range(60):
+        a = rs.uniform(-1, 1, size=(n, 2))
+        out = env.step(a)
+        o.step(a, render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at step %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.where(f == o.f64, 0, np.abs(f - o.f64))
+        assert float(np.nanmax(err)) <= 1e-9, (k, float(np.nanmax(err)))
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        o.f64[:], o.i32[:] = f, q
+    assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
+    env.raise_faults()
+    env.close()
