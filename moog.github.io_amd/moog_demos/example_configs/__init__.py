@@ -13,7 +13,7 @@ import re
 
 NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 'falling_balls',
          'first_person_predators_prey', 'cleanup', 'pacman', 'parallelogram_catch', 'multi_tracking_with_feature_l3', 'match_to_sample_l3', 'predators_arena_l2', 'bounce_box_contact_prediction', 'red_green_l1',
-         'colliding_predators_32', 'falling_balls_64', 'forces_zoo', 'tether_zoo', 'distrib_zoo', 'rules_zoo', 'lambda_zoo', 'cond_zoo', 'phase_zoo', 'actions_zoo', 'aa_zoo', 'maze_zoo', 'sampler_zoo', 'dependent_zoo', 'lookahead_zoo', 'tracing_zoo')
+         'colliding_predators_32', 'falling_balls_64', 'forces_zoo', 'tether_zoo', 'distrib_zoo', 'rules_zoo', 'lambda_zoo', 'cond_zoo', 'phase_zoo', 'actions_zoo', 'aa_zoo', 'maze_zoo', 'sampler_zoo', 'dependent_zoo', 'lookahead_zoo', 'tracing_zoo', 'combo_zoo')
 
 
 def capacity(name):

@@ -828,6 +828,7 @@ def main():
         ('match_to_sample_l2', 175, {'__vmax__': SNAP_VMAX, '__script__': seek_other}, (0,)),
         ('tracing_zoo', 130, {'__script__': lambda env, t, rs: np.array([rs.uniform(-0.4, 0.4), rs.uniform(0.2, 1.)])}, (0, 1)),
         ('tracing_zoo_l1', 150, {}, (0, 1)),
+        ('combo_zoo', 130, {'__action_f32__': True}, (0, 1)),
         ('lookahead_zoo', 140, {'__script__': _go_to}, (0, 1)),
         ('lookahead_zoo_l1', 140, {'__script__': _go_to}, (0, 1)),
         ('red_green_l1', 110, {'__script__': _answer([1, 0, 0, 1], (4, 5))}, (0,)),   # (right = red, left = green)

@@ -16,7 +16,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('tether_zoo_l4', 0), ('distrib_zoo', 0), ('distrib_zoo', 1),
         ('rules_zoo_l0', 0), ('rules_zoo_l1', 0), ('rules_zoo_l1', 1),
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
-        ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1), ('phase_zoo_l1', 0), ('phase_zoo_l1', 1), ('match_to_sample_l3', 0), ('match_to_sample_l3', 1), ('match_to_sample_l4', 0), ('match_to_sample_l2', 0), ('predators_arena_l2', 0), ('predators_arena_l2', 1), ('predators_arena_l1', 0), ('predators_arena_l3', 0), ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction_l1', 0), ('red_green_l1', 0), ('red_green', 0), ('red_green_l3', 0), ('lookahead_zoo', 0), ('lookahead_zoo', 1), ('lookahead_zoo_l1', 0), ('lookahead_zoo_l1', 1), ('tracing_zoo', 0), ('tracing_zoo', 1), ('tracing_zoo_l1', 0), ('tracing_zoo_l1', 1),
+        ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1), ('phase_zoo_l1', 0), ('phase_zoo_l1', 1), ('match_to_sample_l3', 0), ('match_to_sample_l3', 1), ('match_to_sample_l4', 0), ('match_to_sample_l2', 0), ('predators_arena_l2', 0), ('predators_arena_l2', 1), ('predators_arena_l1', 0), ('predators_arena_l3', 0), ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction_l1', 0), ('red_green_l1', 0), ('red_green', 0), ('red_green_l3', 0), ('lookahead_zoo', 0), ('lookahead_zoo', 1), ('lookahead_zoo_l1', 0), ('lookahead_zoo_l1', 1), ('tracing_zoo', 0), ('tracing_zoo', 1), ('tracing_zoo_l1', 0), ('tracing_zoo_l1', 1), ('combo_zoo', 0), ('combo_zoo', 1),
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
         ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
@@ -132,7 +132,7 @@ def test_reset_sampler_vs_reference(name, seed):
                                   'distrib_zoo', 'rules_zoo_l0', 'rules_zoo_l1', 'rules_zoo_l2',
                                   'lambda_zoo', 'first_person_predators_prey', 'maze_zoo', 'maze_zoo_l1', 'maze_zoo_l2',
                                   'pacman', 'pacman_l1', 'match_to_sample_l3', 'match_to_sample_l4', 'predators_arena_l2',
-                                  'bounce_box_contact_prediction', 'red_green_l1', 'lookahead_zoo', 'lookahead_zoo_l1', 'tracing_zoo', 'tracing_zoo_l1'])
+                                  'bounce_box_contact_prediction', 'red_green_l1', 'lookahead_zoo', 'lookahead_zoo_l1', 'tracing_zoo', 'tracing_zoo_l1', 'combo_zoo'])
 def test_engine_vs_oracle_own_rng(name):
     """Same Philox streams on both sides, 64 envs, resets included: integer
     records bit-exact, floats <= 1e-9, frames bit-exact from the engine state."""
