@@ -9,7 +9,9 @@ from moog_demos import example_configs
 name = sys.argv[1] if len(sys.argv) > 1 else 'colliding_predators_32'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 230
-env = environment.BatchedEnvironment(num_envs=n, seed=23, layer_capacity=example_configs.capacity(name), **example_configs.load(name))
+# (the recipes' own LAYER_CAPACITY values are the ones the reference fixtures were recorded with: too small for thousands of random-policy envs)
+ROOM = {'first_person_predators_prey': {'prey': 32, 'predators': 96}, 'rules_zoo_l1': {'prey': 24, 'predators': 24}}
+env = environment.BatchedEnvironment(num_envs=n, seed=23, layer_capacity=ROOM.get(name, example_configs.capacity(name)), **example_configs.load(name))
 o = helpers.OracleEnv(env.compiled, n_envs=n, seed=23)
 env.reset(); o.reset(render=False)
 rs = np.random.RandomState(4); t0 = time.time(); worst = 0.0; resets = 0
