@@ -29,4 +29,6 @@ run('all rules', lambda r: False)
 run('without VanishByFilter', lambda r: isinstance(r, gr.VanishByFilter))
 run('VanishByFilter, one-comparison filter', lambda r: False, cheap=True)
 run('without KeepNearCenter', lambda r: isinstance(r, gr.KeepNearCenter))
+run('without the ConditionalRules (CreateSprites)', lambda r: isinstance(r, gr.ConditionalRule))
+run('without any rule', lambda r: True)
 run('without VanishOnContact', lambda r: isinstance(r, gr.VanishOnContact))
