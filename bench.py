@@ -239,6 +239,10 @@ def main():
                          'moog_engine_set_fused)')
     ap.add_argument('--lockstep', action='store_true', help='keep the episodes of the batch synchronous')
     ap.add_argument('--no-extras', action='store_true', help='skip the strict-fault-check comparison window')
+    ap.add_argument('--sub-batches', type=int, default=1,
+                    help='G > 1: the batch is stepped as G asynchronous sub-batches, one HIP stream each '
+                         '(moog.environment.SubBatchedEnvironment): an ADDITIONAL line, the synchronous whole-batch '
+                         'step is the headline')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -278,10 +282,18 @@ def main():
     n = args.envs_per_gpu
     index0 = sharding.shard_range(n * world, rank, world)[0]
 
-    env = environment.BatchedEnvironment(
-        num_envs=n, device=dev, seed=2024, env_index0=index0,
-        layer_capacity=example_configs.capacity(args.workload),
-        **example_configs.load(args.workload))
+    G = max(1, args.sub_batches)
+    if G > 1:
+        env = environment.SubBatchedEnvironment(
+            num_envs=n, sub_batches=G, device=dev, seed=2024, env_index0=index0,
+            layer_capacity=example_configs.capacity(args.workload),
+            **example_configs.load(args.workload))
+        args.no_fused = args.no_extras = True
+    else:
+        env = environment.BatchedEnvironment(
+            num_envs=n, device=dev, seed=2024, env_index0=index0,
+            layer_capacity=example_configs.capacity(args.workload),
+            **example_configs.load(args.workload))
     if not args.no_schedule:
         env.enable_cost_schedule()
     fused = False
@@ -300,8 +312,15 @@ def main():
         acts = torch.empty((ring, n, 2), dtype=torch.float64, device=dev).uniform_(-1.0, 1.0)
     step_no = [0]
 
+    m = n // G
+
     def one_step():
-        env.step(acts[step_no[0] % ring])
+        a = acts[step_no[0] % ring]
+        if G > 1:   # every sub-batch queues its step behind its own previous call only: no whole-batch barrier
+            for g in range(G):
+                env.step_async(g, a[g * m:(g + 1) * m])
+        else:
+            env.step(a)
         step_no[0] += 1
 
     def barrier():
@@ -375,7 +394,8 @@ def main():
         achieved = (n * rb / r_avg_s) / 1e9 if r_avg_s > 0 else 0.0
         tr = raster_traffic(args.workload, n)
         line = {
-            'metric': 'env steps/sec (whole node), 4096 envs x 32 sprites, 64x64 obs',
+            'metric': 'env steps/sec (whole node), %d envs x %d sprites, %dx%d obs' % (
+                n, P.n_slots, P.render.height, P.render.width),
             'value': total_steps / dt_max,
             'unit': 'env steps/sec',
             'n_gpus': world,
@@ -393,9 +413,13 @@ def main():
                                        P.render.height, P.render.width),
                        'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
                        'parallelism': 'env-sharded x%d, no collective' % world,
-                       'launch': (('frames follow their env\'s step (raster grid beside the step kernel); every %dth call takes the '
+                       'launch': (('%d asynchronous sub-batches of %d envs, one HIP stream each: step -> frames -> next step '
+                                   'chained per sub-batch, no whole-batch barrier between calls (SubBatchedEnvironment.step_async)'
+                                   % (G, m)) if G > 1 else
+                                  ('frames follow their env\'s step (raster grid beside the step kernel); every %dth call takes the '
                                    'separate launches and is the one whose kernels are timed' % every) if fused
                                   else 'separate step and raster launches') + ((' -- ' + tuned) if tuned else ''),
+                       'sub_batches': G,
                        'launch_tuning_ms_per_step': ({k.replace('_s_per_call', ''): round(v * 1e3, 4) for k, v in env.last_tune.items()}
                                                      if getattr(env, 'last_tune', None) else None),
                        'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 27
+#define MOOG_ABI_VERSION 28
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -397,8 +397,10 @@ enum {
   MOOG_RCOND_ALL_EXPR,          /* as MOOG_COND_ALL_EXPR .. FIRST_EXPR: layer l0, expression   */
   MOOG_RCOND_ANY_EXPR,          /*   xfilter; FIRST_EXPR's value is the repeat count           */
   MOOG_RCOND_FIRST_EXPR,
-  MOOG_RCOND_COUNT_EXPR         /* sum of expression xfilter over the sprites of layer l0 (a loop that
+  MOOG_RCOND_COUNT_EXPR,        /* sum of expression xfilter over the sprites of layer l0 (a loop that
                                    accumulates per-sprite terms, cleanup.py:181-190)                 */
+  MOOG_RCOND_STATE_EXPR         /* = MOOG_COND_STATE_EXPR (7): the expression reads no layer's sprites (the current phase,
+                                   rule scalars, the meta-state): evaluated unconditionally             */
 };
 
 /* Rules form a forest in pre-order: `parent` is the index of the enclosing TIMED /
@@ -439,7 +441,9 @@ enum {
   MOOG_COND_ALL_Y_LT,           /* lambda state: all(s.y < c for s in state[L]) */
   MOOG_COND_ALL_EXPR,           /* all(pred(s) for s in state[L])             */
   MOOG_COND_ANY_EXPR,           /* any(pred(s) for s in state[L])             */
-  MOOG_COND_FIRST_EXPR          /* expr(state[L][0])                          */
+  MOOG_COND_FIRST_EXPR,         /* expr(state[L][0])                          */
+  MOOG_COND_STATE_EXPR = 7      /* expr(state, meta_state): sprites named by slot (state[L][k]) or no sprite at all --
+                                   evaluated whatever the layers hold (no "first live sprite" to anchor it to) */
 };
 
 typedef struct {
@@ -778,6 +782,15 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
  * `raster_stop` = k truncates the raster kernel after phase k.  The initial values come from the
  * environment variables MOOG_STEP_DEBUG / MOOG_RASTER_STOP, read once by moog_engine_create. */
 int moog_engine_set_debug(moog_engine_t* e, int32_t step_debug, int32_t raster_stop);
+
+/* Section sampling of the step kernel (a profiling aid; an engine created with the environment variable MOOG_WATCH=1 and a
+ * library whose step kernel was built with -DMOOG_WATCH, tools/build_variant.sh): a second wavefront beside every env's
+ * samples, every few hundred cycles, the section id the stepping wavefront last announced (one LDS store per section
+ * entry: the stepped wavefront is not slowed by clock reads).  Copies the per-env sample counts of the calls since the
+ * last clear, [n_envs][MOOG_WATCH_SECTIONS], to `host_out` (synchronises) and optionally clears them.  Without
+ * MOOG_WATCH=1 the call fails with MOOG_E_UNSUPPORTED. */
+#define MOOG_WATCH_SECTIONS 32
+int moog_engine_read_watch(moog_engine_t* e, int32_t* host_out, int32_t clear);
 
 #ifdef __cplusplus
 }

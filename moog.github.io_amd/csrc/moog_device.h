@@ -30,6 +30,20 @@ typedef const MOOG_CONST moog_rule_t* PRule;
 typedef const MOOG_CONST moog_task_t* PTask;
 typedef const MOOG_CONST moog_action_t* PAction;
 typedef const MOOG_CONST moog_shape_t* PShape;
+// One entry of the flattened force list: a (force, layer a, layer b) combination of physics.py:96-108 with everything its
+// loop header needs in 64 contiguous bytes (one scalar load), built once per engine on the host (moog_flatten_forces in
+// moog_kernels.h).  The nested loops over program.forces read ~10 dependent scalars per combination -- force kind, list
+// lengths, layer ids, slot ranges, the Collision parameters -- ten times per env-step: 6 % of the contact-heavy envs'
+// cycles and 12 % of the typical env's sat in those headers (profiles/r04_step_sections.txt).
+struct FOp {
+  int32_t fi, kind;          // index into program.forces (the rarely used kinds still read their record), MOOG_FORCE_*
+  int32_t a0, a1, b0, b1;    // slot ranges of the two layers (b0 = b1 = 0 for a one-layer force)
+  int32_t symmetric, i0, i1; // as in moog_force_t
+  int32_t n_b;               // 0: one-layer force
+  double p0, p1;
+  int32_t pad[2];
+};
+typedef const MOOG_CONST FOp* PFOp;
 typedef const MOOG_CONST moog_genop_t* PGenop;
 typedef const MOOG_CONST moog_factor_t* PFactor;
 __device__ __forceinline__ PProg as_const_prog(const moog_program_t* p) {
@@ -44,6 +58,16 @@ __device__ __forceinline__ PProg as_const_prog(const moog_program_t* p) {
 #define PROF_T0
 #define PROF_ADD(e_, k)
 #endif
+// Section announcements for the sampling watcher (moog_kernels.h, -DMOOG_WATCH builds only): one LDS store, no wait.
+#ifdef MOOG_WATCH
+#define SEC(e_, id) do { if ((e_).secw && (e_).lane == 0) __hip_atomic_store((e_).secw, (id), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+#else
+#define SEC(e_, id) do { } while (0)
+#endif
+enum { SEC_PROLOGUE = 0, SEC_RULES = 1, SEC_FORCES = 2, SEC_BROAD = 3, SEC_LIST = 4, SEC_BATCH_FORM = 5, SEC_BATCH = 6, SEC_PATH = 7,
+       SEC_SEARCH_CONTAIN = 8, SEC_SEARCH_MATRIX = 9, SEC_SEARCH_ROWS = 10, SEC_SEARCH_FINISH = 11, SEC_RESOLVE = 12, SEC_DISJOINT = 13,
+       SEC_RETEST = 14, SEC_PAIR_SCAN = 15, SEC_PAIR_CONSUME = 16, SEC_INT_POSE = 17, SEC_INT_LONG = 18, SEC_INT_VERTS = 19,
+       SEC_INT_BOXES = 20, SEC_TASK = 21, SEC_STORE = 22, SEC_STEP_CONTROL = 23, SEC_CONSUME = 24, SEC_SEARCH_SELECT = 25 };
 #define EPS_COLL 1e-2    // collisions.py:46
 #define MOOG_F_TMP 0x100 // scratch flag bit (vanish marks)
 #define DINF (__builtin_inf())
@@ -52,6 +76,8 @@ struct Env {
   double* f;               // LDS f64 record (hot fields only, see HotLayout)
   int32_t* q;              // LDS i32 record (hot fields only)
   PProg P;                 // lowered config (constant address space)
+  PFOp fops;               // flattened force list (constant address space)
+  int n_fops;
   moog_layout_t L;         // layout of the LDS records
   double* gcol;            // this env's colours / opacity / shape ids in HBM: fields the step
   int32_t* gopa;           //   path never reads are not staged in LDS (LDS per env sets how many
@@ -63,7 +89,6 @@ struct Env {
   int64_t env_index;
   int lane;
   float* bb;               // LDS scratch [S][8]: conservative 8-DOP (lo x, y, x+y, x-y; hi x, y, x+y, x-y)
-  double* xf;              // LDS scratch [S][8]: per-sprite integrate transform (only when S > 64)
   const int16_t* vslot;    // global [TOTV]: vertex index -> slot
   unsigned cur_fmask;      // float32 factors of the sprite being created
   int cell_i, cell_j;      // maze cell (row, column) of the sprite being created (MOOG_CELL_* ops)
@@ -82,6 +107,9 @@ struct Env {
   int n_path, n_resp, n_disj;   // profiling counters (path tests, contact searches, make_disjoint calls)
 #ifdef MOOG_PROFILE
   long long prof[16];      // cycles per section (tools/step_profile.sh builds with -DMOOG_PROFILE)
+#endif
+#ifdef MOOG_WATCH
+  int32_t* secw;           // LDS word the watcher wavefront samples (moog_engine_read_watch), or null
 #endif
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
   int32_t* layer_hw;       // global [2 * MOOG_MAX_LAYERS] or null: per dynamic layer, the most sprites an append ever wanted
@@ -264,26 +292,34 @@ __device__ __forceinline__ bool mpl_isclose(double a, double b) {
   return fabs(a - b) <= fmax(1e-10 * fmax(fabs(a), fabs(b)), 1e-13);
 }
 
-__device__ inline bool segments_intersect(double x1, double y1, double x2, double y2, double x3,
-                                          double y3, double x4, double y4) {
+// 0: no intersection, the segments are not parallel; 1: collinear segments that overlap; 2: a crossing of two non-parallel
+// segments; 4: parallel segments, no intersection.  Answers 0 and 2 are the same with the two segments exchanged: den, n1, n2
+// become -den, -n2, -n1 exactly (products commute, a - b = -(b - a)), so u1 and u2 trade places and the test is symmetric in
+// them; the parallel branch measures from the first segment's end points and is not symmetric in general (answers 1, 4).
+__device__ inline int segments_intersect_kind(double x1, double y1, double x2, double y2, double x3,
+                                              double y3, double x4, double y4) {
   double den = ((y4 - y3) * (x2 - x1)) - ((x4 - x3) * (y2 - y1));
   if (mpl_isclose(den, 0.0)) {
     double t_area = (x2 * y3 - x3 * y2) - x1 * (y3 - y2) + y1 * (x3 - x2);
     if (mpl_isclose(t_area, 0.0)) {
       if (x1 == x2 && x2 == x3) {
-        return (fmin(y1, y2) <= fmin(y3, y4) && fmin(y3, y4) <= fmax(y1, y2)) ||
-               (fmin(y3, y4) <= fmin(y1, y2) && fmin(y1, y2) <= fmax(y3, y4));
+        return ((fmin(y1, y2) <= fmin(y3, y4) && fmin(y3, y4) <= fmax(y1, y2)) ||
+                (fmin(y3, y4) <= fmin(y1, y2) && fmin(y1, y2) <= fmax(y3, y4))) ? 1 : 4;
       }
-      return (fmin(x1, x2) <= fmin(x3, x4) && fmin(x3, x4) <= fmax(x1, x2)) ||
-             (fmin(x3, x4) <= fmin(x1, x2) && fmin(x1, x2) <= fmax(x3, x4));
+      return ((fmin(x1, x2) <= fmin(x3, x4) && fmin(x3, x4) <= fmax(x1, x2)) ||
+              (fmin(x3, x4) <= fmin(x1, x2) && fmin(x1, x2) <= fmax(x3, x4))) ? 1 : 4;
     }
-    return false;
+    return 4;
   }
   double n1 = ((x4 - x3) * (y1 - y3)) - ((y4 - y3) * (x1 - x3));
   double n2 = ((x2 - x1) * (y1 - y3)) - ((y2 - y1) * (x1 - x3));
   double u1 = n1 / den, u2 = n2 / den;
-  return (u1 > 0.0 || mpl_isclose(u1, 0.0)) && (u1 < 1.0 || mpl_isclose(u1, 1.0)) &&
-         (u2 > 0.0 || mpl_isclose(u2, 0.0)) && (u2 < 1.0 || mpl_isclose(u2, 1.0));
+  return ((u1 > 0.0 || mpl_isclose(u1, 0.0)) && (u1 < 1.0 || mpl_isclose(u1, 1.0)) &&
+          (u2 > 0.0 || mpl_isclose(u2, 0.0)) && (u2 < 1.0 || mpl_isclose(u2, 1.0))) ? 2 : 0;
+}
+__device__ inline bool segments_intersect(double x1, double y1, double x2, double y2, double x3,
+                                          double y3, double x4, double y4) {
+  return (segments_intersect_kind(x1, y1, x2, y2, x3, y3, x4, y4) & 3) != 0;
 }
 
 // even-odd crossing test, one lane, polygon vertices in LDS
@@ -328,9 +364,14 @@ __device__ __forceinline__ bool seg_outside_dop_r(double x1, double y1, double x
          fmin(m1, m2) > (double)hi.w + BB_MARGIN || fmax(m1, m2) < (double)lo.w - BB_MARGIN;
 }
 
+// *proper (when given): the answer is the same with a and b exchanged -- true because two non-parallel edges cross
+// (segments_intersect_kind 2), or false without a pair of parallel edges among those tested (the culls and the two
+// containment tests are symmetric in a and b as a set)
 __device__ inline bool paths_intersect_filled(const Env& e, const double* va, int na,
                                               const double* vb, int nb, const float* da,
-                                              const float* db) {
+                                              const float* db, bool* proper = nullptr) {
+  if (proper) *proper = false;
+  bool parallel = false;
   // da / db: conservative 8-DOPs of a and b
   // A polygon without a finite vertex (a sprite whose position / angle went NaN or inf) is an EMPTY path for matplotlib
   // (PathNanRemover), and path_in_path of an empty path is vacuously true: it overlaps everything (see the oracle).
@@ -364,7 +405,7 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
     wsync();
     for (int base = 0; base < total; base += 64) {
       int idx = base + e.lane;
-      bool hit = false;
+      int hit = 0;
       if (idx < total) {
         int ia = (total <= 4096) ? div_small(idx, cb) : idx / cb, ib = idx - ia * cb;
         int i = e.lst[ia], j = e.lst[64 + ib];
@@ -376,10 +417,15 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
         if (!apart) {
           bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
           bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
-          if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
+          if (!dega && !degb) hit = segments_intersect_kind(x11, y11, x12, y12, x21, y21, x22, y22);
         }
       }
-      if (__ballot(hit) != 0ull) { wsync(); return true; }
+      if (__ballot((hit & 3) != 0) != 0ull) {
+        if (proper) *proper = __ballot(hit == 2) != 0ull;
+        wsync();
+        return true;
+      }
+      parallel = parallel || __ballot(hit == 4) != 0ull;
     }
     wsync();
   }
@@ -398,6 +444,7 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
     if (e.lane < na) out = !point_in_poly(vb, nb, va[2 * e.lane], va[2 * e.lane + 1]);
     if (__ballot(out) == 0ull) return true;
   }
+  if (proper) *proper = !parallel;
   return false;
 }
 
@@ -474,7 +521,8 @@ __device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
 
 // sprite.py:462-484.  `prechecked`: the caller has already evaluated the bounding
 // circle / box rejects on the current state (broad phase).
-__device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = false) {
+__device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = false, bool* proper = nullptr) {
+  if (proper) *proper = false;
   if (!prechecked) {
     if (circles_apart(e, s0, s1)) return false;
     if (bbox_apart(e, s0, s1)) return false;
@@ -482,8 +530,10 @@ __device__ inline bool overlaps(const Env& e, int s0, int s1, bool prechecked = 
   if (e.dbg & 8) return false;
   if (e.dbg & 128) const_cast<Env&>(e).n_path++;
   PROF_T0;
-  const bool hit = paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0));
+  SEC(e, SEC_PATH);
+  const bool hit = paths_intersect_filled(e, VERT(s0), NV(s0), VERT(s1), NV(s1), &BB(s0, 0), &BB(s1, 0), proper);
   PROF_ADD(e, 0);
+  SEC(e, SEC_STEP_CONTROL);
   return hit;
 }
 
@@ -544,10 +594,12 @@ __device__ __forceinline__ int nth_set_bit16(unsigned m, int k) {
   return pos;
 }
 
+#define CAND_SKIP 0xFFFF   // a candidate entry struck from the list (collision_same_layer): counts as rejected
 __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   const int grp = e.lane >> 4, gl = e.lane & 15;
-  const bool active = grp < n;
-  const int pr = active ? (int)e.cand[c + grp] : 0;
+  const int pr0 = grp < n ? (int)e.cand[c + grp] : CAND_SKIP;
+  const bool active = pr0 != CAND_SKIP;
+  const int pr = active ? pr0 : 0;
   const int s0 = pr >> 8, t = pr & 255;
   // (all the loads that depend only on the pair go out together: this routine is a chain of LDS round
   //  trips on the critical path of a contact-heavy env)
@@ -583,7 +635,7 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   const unsigned ga = (unsigned)(ma >> (16 * grp)) & 0xffffu, gb = (unsigned)(mb >> (16 * grp)) & 0xffffu;
   const int ca = __popc(ga), cb = __popc(gb), total = ca * cb;
   slow = slow || total > 16;
-  bool hit = false;
+  int hit = 0;
   if (active && !slow && gl < total) {
     // gl / cb for gl < 16, 1 <= cb <= 16 (the quotient of a half-integer is never near an integer)
     const int ia = (int)(((float)gl + 0.5f) / (float)cb), ib = gl - ia * cb;
@@ -598,14 +650,17 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
     if (!apart) {
       bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
       bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
-      if (!dega && !degb) hit = segments_intersect(x11, y11, x12, y12, x21, y21, x22, y22);
+      if (!dega && !degb) hit = segments_intersect_kind(x11, y11, x12, y12, x21, y21, x22, y22);
     }
   }
-  const unsigned long long stop = __ballot(hit || slow), slows = __ballot(slow);
+  const unsigned long long stop = __ballot((hit & 3) != 0 || slow), slows = __ballot(slow), props = __ballot(hit == 2);
   int r = 0;
   while (r < n && ((stop >> (16 * r)) & 0xffffull) == 0ull) ++r;
-  // bit 8: the candidate that ended the prefix is a proven overlap (its edges cross)
-  if (r < n && ((slows >> (16 * r)) & 0xffffull) == 0ull) r |= 256;
+  // bit 8: the candidate that ended the prefix is a proven overlap (its edges cross); bit 9: two non-parallel edges do
+  if (r < n && ((slows >> (16 * r)) & 0xffffull) == 0ull) {
+    if ((props >> (16 * r)) & 0xffffull) r |= 512;
+    r |= 256;
+  }
   return r;
 }
 
@@ -640,96 +695,163 @@ __device__ inline void set_position(Env& e, int s, double nx, double ny) {
 // sprite.py:426-430 update_pos_from_vel for EVERY live sprite (physics.py:114-117),
 // including the reference's float32 propagation (see oracle).  Phase 1, lanes =
 // sprites: new position, translation delta, rotation coefficients (the per-sprite
-// sin/cos run in parallel).  Phase 2, lanes = vertices of all sprites: translate
-// (position setter, sprite.py:616-633) then rotate about the new position (angle
-// setter, :531-540, matplotlib rotate_around).  Per-vertex arithmetic is exactly
-// the reference's; sprites are independent so the order does not matter.
+// sin/cos run in parallel).  Phase 2, lanes = (sprite, part): L = 4, 2 or 1 lanes per sprite (64 / L >= S), each
+// walking every L-th vertex of its sprite's list: translate (position setter, sprite.py:616-633) then rotate about
+// the new position (angle setter, :531-540, matplotlib rotate_around), and the exact 8-DOP of a sprite that rotated
+// from the very vertices it has just written.  Per-vertex arithmetic is exactly the reference's; sprites are
+// independent so the order does not matter.  (Round 3 walked the vertex ARRAY 64 slots at a time -- capacity, not live
+// vertices: 8 rounds on the headline workload, each fetching its sprite's transform through 14 ds_bpermute and its
+// slot through a global load, then a third phase re-reading the vertices for the boxes: 13.2 k cycles per call for a
+// lone wavefront, a fifth of the mean env's step.)
+#define LONG_NV_PER_PART 4   // integrate_all: a vertex list of more than 4 x this is "long"
+__device__ __forceinline__ double rdlane_d(double v, int lane) {   // lane: wave uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ inline void integrate_all(Env& e, double dt) {
   PProg P = e.P;
   const int S = P->n_slots;
-  const bool in_regs = (S <= 64);   // per-sprite transform lives in lane s and is fetched by shuffles
   wsync();
-  double r0 = 0, r1 = 0, r2 = 1, r3 = 0, r4 = 0, r5 = 0, r6 = 0;   // ddx, ddy, a, b, tx, ty, mode
-  for (int s = e.lane; s < S; s += 64) {
-    double x0 = 0, x1 = 0, x2 = 1, x3 = 0, x4 = 0, x5 = 0, x6 = 0;
-    int fl = FLAGS(s);
-    if (fl & MOOG_F_ALIVE) {
-      double dx, dy;
-      if (fl & MOOG_F_VEL_F32) {
-        float dtf = (float)dt;
-        dx = (double)(dtf * (float)VELX(s));
-        dy = (double)(dtf * (float)VELY(s));
-      } else {
-        dx = dt * VELX(s);
-        dy = dt * VELY(s);
-      }
-      double ox = PX(s), oy = PY(s);
-      double nx = ox + dx, ny = oy + dy;
-      double ddx = nx - ox, ddy = ny - oy;
-      double w = ANGV(s);
-      double a = 1, b = 0, tx = 0, ty = 0, mode = 1.0, dth_abs = 0;
-      if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
-        double dth;
-        if (fl & MOOG_F_ANGVEL_F32) {
-          float t = (float)dt * (float)w;
-          float a_old = (float)ANG(s);
-          float a_new = a_old + t;
-          dth = (double)(a_new - a_old);
-          ANG(s) = (double)a_new;
-        } else {
-          double a_old = ANG(s);
-          double a_new = a_old + dt * w;
-          dth = a_new - a_old;
-          ANG(s) = a_new;
+  for (int sbase = 0; sbase < S; sbase += 64) {
+    // lanes per sprite in this chunk of (at most) 64 sprites
+    const int nchunk = S - sbase < 64 ? S - sbase : 64;
+    const int Lp = nchunk <= 16 ? 4 : (nchunk <= 32 ? 2 : 1);
+    const int Sp = 64 / Lp;                       // sprites per pass = lane stride between the parts of one sprite
+    // ---- phase 1: lane = sprite sbase + lane
+    SEC(e, SEC_INT_POSE);
+    double r0 = 0, r1 = 0, r2 = 1, r3 = 0, r4 = 0, r5 = 0;   // ddx, ddy, a, b, tx, ty
+    int rmode = 0;                                           // 0 dead, 1 translate, 2 translate + rotate
+    {
+      const int s = sbase + e.lane;
+      if (e.lane < nchunk) {
+        int fl = FLAGS(s);
+        if (fl & MOOG_F_ALIVE) {
+          double dx, dy;
+          if (fl & MOOG_F_VEL_F32) {
+            float dtf = (float)dt;
+            dx = (double)(dtf * (float)VELX(s));
+            dy = (double)(dtf * (float)VELY(s));
+          } else {
+            dx = dt * VELX(s);
+            dy = dt * VELY(s);
+          }
+          double ox = PX(s), oy = PY(s);
+          double nx = ox + dx, ny = oy + dy;
+          double ddx = nx - ox, ddy = ny - oy;
+          double w = ANGV(s);
+          double a = 1, b = 0, tx = 0, ty = 0;
+          rmode = 1;
+          if (w != 0.0) {  // `if self._angle_vel:` (NaN is truthy)
+            double dth;
+            if (fl & MOOG_F_ANGVEL_F32) {
+              float t = (float)dt * (float)w;
+              float a_old = (float)ANG(s);
+              float a_new = a_old + t;
+              dth = (double)(a_new - a_old);
+              ANG(s) = (double)a_new;
+            } else {
+              double a_old = ANG(s);
+              double a_new = a_old + dt * w;
+              dth = a_new - a_old;
+              ANG(s) = a_new;
+            }
+            sincos_small(dth, &b, &a);
+            tx = (a * (-nx) - b * (-ny)) + nx;
+            ty = (b * (-nx) + a * (-ny)) + ny;
+            rmode = 2;
+          }
+          r0 = ddx; r1 = ddy; r2 = a; r3 = b; r4 = tx; r5 = ty;
+          PX(s) = nx; PY(s) = ny;
+          if (rmode != 2) dop_translate(&BB(s, 0), ddx, ddy);
         }
-        sincos_small(dth, &b, &a);
-        tx = (a * (-nx) - b * (-ny)) + nx;
-        ty = (b * (-nx) + a * (-ny)) + ny;
-        mode = 2.0;
-        dth_abs = dth;
       }
-      x0 = ddx; x1 = ddy; x2 = a; x3 = b; x4 = tx; x5 = ty; x6 = mode;
-      PX(s) = nx; PY(s) = ny;
-      if (mode != 2.0) dop_translate(&BB(s, 0), ddx, ddy);
-      (void)dth_abs;
     }
-    if (in_regs) { r0 = x0; r1 = x1; r2 = x2; r3 = x3; r4 = x4; r5 = x5; r6 = x6; }
-    else {
-      double* x = &e.xf[8 * s];
-      x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3; x[4] = x4; x[5] = x5; x[6] = x6;
+    // ---- phase 2a: a few sprites with long vertex lists (the agent's 30-gon among 10-gons) would set the trip count of
+    //      the per-sprite loops below: the whole wave walks such a list, lanes = vertices (transform by readlane)
+    SEC(e, SEC_INT_LONG);
+    unsigned long long longm = __ballot(e.lane < nchunk && rmode != 0 && NV(sbase + (e.lane < nchunk ? e.lane : 0)) > 4 * LONG_NV_PER_PART);
+    if (__popcll(longm) > 4) longm = 0ull;   // (many of them -- falling_balls' discs: the per-sprite loops are the better shape)
+    const unsigned long long coopm = longm;
+    while (longm) {
+      const int l = __ffsll((long long)longm) - 1;
+      longm &= longm - 1ull;
+      const int s = sbase + l;
+      const double x0 = rdlane_d(r0, l), x1 = rdlane_d(r1, l), x2 = rdlane_d(r2, l), x3 = rdlane_d(r3, l);
+      const double x4 = rdlane_d(r4, l), x5 = rdlane_d(r5, l);
+      const bool rot = __builtin_amdgcn_readlane(rmode, l) == 2;
+      double* v = VERT(s);
+      const int n = NV(s);
+      for (int k = e.lane; k < n; k += 64) {
+        double2 p = *reinterpret_cast<const double2*>(v + 2 * k);
+        double vx = p.x + x0, vy = p.y + x1;
+        if (rot) {
+          const double rx = (x2 * vx + (-x3) * vy) + x4;
+          const double ry = (x3 * vx + x2 * vy) + x5;
+          vx = rx; vy = ry;
+        }
+        p.x = vx; p.y = vy;
+        *reinterpret_cast<double2*>(v + 2 * k) = p;
+      }
+      if (rot) {   // (rare: one lane scans, as at kernel start)
+        wsync();
+        if (e.lane == 0) dop_scan(v, n, &BB(s, 0));
+      }
     }
-  }
-  wsync();
-  double* vall = &e.f[e.L.o_verts];
-  const int TOTV = e.L.TOTV;
-  for (int base = 0; base < TOTV; base += 64) {
-    int idx = base + e.lane;
-    bool in = idx < TOTV;
-    int s = in ? (int)e.vslot[idx] : 0;   // vertex -> slot table (shared by all envs, cache resident)
-    double x0, x1, x2, x3, x4, x5, mode;
-    if (in_regs) {
-      x0 = shfl_d(r0, s); x1 = shfl_d(r1, s); x2 = shfl_d(r2, s); x3 = shfl_d(r3, s);
-      x4 = shfl_d(r4, s); x5 = shfl_d(r5, s); mode = shfl_d(r6, s);
-    } else {
-      const double* x = &e.xf[8 * s];
-      x0 = x[0]; x1 = x[1]; x2 = x[2]; x3 = x[3]; x4 = x[4]; x5 = x[5]; mode = x[6];
+    // ---- phase 2b: lane = (sprite sl, part h); the transform comes from lane sl
+    SEC(e, SEC_INT_VERTS);
+    const int sl = e.lane & (Sp - 1), h = e.lane / Sp;
+    double x0 = r0, x1 = r1, x2 = r2, x3 = r3, x4 = r4, x5 = r5;
+    int mode = rmode;
+    if (Lp > 1) {
+      x0 = shfl_d(r0, sl); x1 = shfl_d(r1, sl); x2 = shfl_d(r2, sl); x3 = shfl_d(r3, sl);
+      x4 = shfl_d(r4, sl); x5 = shfl_d(r5, sl); mode = __shfl(rmode, sl);
     }
-    int k = idx - e.voff[s];
-    if (!in || mode == 0.0 || k >= NV(s)) continue;
-    double vx = vall[2 * idx] + x0, vy = vall[2 * idx + 1] + x1;
-    if (mode == 2.0) {
-      double rx = (x2 * vx + (-x3) * vy) + x4;
-      double ry = (x3 * vx + x2 * vy) + x5;
-      vx = rx; vy = ry;
+    const int s = sbase + sl;
+    const bool on = sl < nchunk && mode != 0 && !((coopm >> sl) & 1ull);
+    const int n = on ? NV(s) : 0;
+    double* v = on ? VERT(s) : &e.f[e.L.o_verts];
+    const float FINF = __builtin_inff();
+    float l0 = FINF, l1 = FINF, l2 = FINF, l3 = FINF, h0 = -FINF, h1 = -FINF, h2 = -FINF, h3 = -FINF;
+    int fin = 0;
+    const bool rot = mode == 2;
+    // (branch-free body, the next vertex in flight while this one is transformed; the box in float32: rounding is monotonic,
+    //  so the extremes of the rounded coordinates are the rounded extremes dop_scan computes; fminf / fmaxf skip NaNs as there)
+    int k = h;
+    double2 p = make_double2(0, 0);
+    if (k < n) p = *reinterpret_cast<const double2*>(v + 2 * k);
+    while (k < n) {
+      const int kn = k + Lp;
+      double2 pn = p;
+      if (kn < n) pn = *reinterpret_cast<const double2*>(v + 2 * kn);
+      double vx = p.x + x0, vy = p.y + x1;
+      const double rx = (x2 * vx + (-x3) * vy) + x4;
+      const double ry = (x3 * vx + x2 * vy) + x5;
+      vx = rot ? rx : vx; vy = rot ? ry : vy;
+      *reinterpret_cast<double2*>(v + 2 * k) = make_double2(vx, vy);
+      const float fx = (float)vx, fy = (float)vy, fp = (float)(vx + vy), fm = (float)(vx - vy);
+      l0 = fminf(l0, fx); h0 = fmaxf(h0, fx); l1 = fminf(l1, fy); h1 = fmaxf(h1, fy);
+      l2 = fminf(l2, fp); h2 = fmaxf(h2, fp); l3 = fminf(l3, fm); h3 = fmaxf(h3, fm);
+      fin |= (int)isfinite(vx) & (int)isfinite(vy);
+      p = pn; k = kn;
     }
-    vall[2 * idx] = vx; vall[2 * idx + 1] = vy;
-  }
-  wsync();
-  // exact boxes of the sprites that rotated (lanes = sprites, each scans its vertices)
-  for (int s = e.lane; s < S; s += 64) {
-    double mode = in_regs ? r6 : e.xf[8 * s + 6];
-    if (mode != 2.0) continue;
-    dop_scan(VERT(s), NV(s), &BB(s, 0));
+    // ---- exact boxes of the sprites that rotated: combine the parts, part 0 writes (dop_scan's rule for a polygon
+    //      without a finite vertex: a NaN box never rejects a pair)
+    SEC(e, SEC_INT_BOXES);
+    if (Lp > 1) {
+      for (int o = Sp; o < 64; o <<= 1) {
+        l0 = fminf(l0, __shfl_xor(l0, o)); h0 = fmaxf(h0, __shfl_xor(h0, o));
+        l1 = fminf(l1, __shfl_xor(l1, o)); h1 = fmaxf(h1, __shfl_xor(h1, o));
+        l2 = fminf(l2, __shfl_xor(l2, o)); h2 = fmaxf(h2, __shfl_xor(h2, o));
+        l3 = fminf(l3, __shfl_xor(l3, o)); h3 = fmaxf(h3, __shfl_xor(h3, o));
+        fin |= __shfl_xor(fin, o);
+      }
+    }
+    if (on && rot && h == 0) {
+      if (!(l0 <= h0 && l1 <= h1 && h0 < FINF && l0 > -FINF && h1 < FINF && l1 > -FINF) && !fin)
+        l0 = l1 = l2 = l3 = h0 = h1 = h2 = h3 = __builtin_nanf("");
+      float* d = &BB(s, 0);
+      *reinterpret_cast<float4*>(d) = make_float4(l0, l1, l2, l3);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(h0, h1, h2, h3);
+    }
   }
   wsync();
 }
@@ -934,6 +1056,13 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
 // vertices): lanes 0-31 run directed(s1, s0), lanes 32-63 directed(s0, s1), with the very
 // arithmetic of directed_collision_vectors; the two dependent chains overlap instead of adding up.
 __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int sb, double dt, CVec& ra, CVec& rb) {
+#ifdef MOOG_PROFILE
+  long long prof_t_ = clock64();
+#define PROF_LAP(k) { const long long n_ = clock64(); const_cast<Env&>(e).prof[k] += n_ - prof_t_; prof_t_ = n_; }
+#else
+#define PROF_LAP(k)
+#endif
+  SEC(e, SEC_SEARCH_CONTAIN);
   const int h = e.lane >> 5, j = e.lane & 31, hb = h << 5;
   const int s0 = h ? sa : sb, s1 = h ? sb : sa;
   const double* v0 = VERT(s0);
@@ -969,9 +1098,13 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
   const unsigned long long call = __ballot(contained);
   const unsigned cmh = (unsigned)(call >> hb);
   ra.status = CV_NONE; rb.status = CV_NONE;
+  PROF_LAP(12);
   if (call == 0ull) return;
+  SEC(e, SEC_SEARCH_MATRIX);
   double m[6];
   relative_motion_matrix(e, s0, s1, dt, m);
+  PROF_LAP(13);
+  SEC(e, SEC_SEARCH_ROWS);
   const double ds1x = e2x - e1x, ds1y = e2y - e1y;
   bool anycross = false;
   int ci = -1, e1 = 0;
@@ -1020,6 +1153,8 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
       if (take) { ci = l; bv = dist; e1 = best; ca = bca; bpx = cpx; bpy = cpy; bsx = dfx; bsy = dfy; }
     }
   }
+  PROF_LAP(14);
+  SEC(e, SEC_SEARCH_FINISH);
   // this half's result (uniform within the half), then one lane of each half speaks for it
   int st = CV_NONE;
   double nx = 0, ny = 0, qx = 0, qy = 0;
@@ -1046,10 +1181,13 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
   ra.ny = shfl_d(ny, 0); rb.ny = shfl_d(ny, 32);
   ra.qx = shfl_d(qx, 0); rb.qx = shfl_d(qx, 32);
   ra.qy = shfl_d(qy, 0); rb.qy = shfl_d(qy, 32);
+  PROF_LAP(15);
 }
 
 // collisions.py:235-289
-__device__ inline void get_collision_vectors(const Env& e, int s0, int s1, double dt, CVec& out) {
+// *mirror_status (when given): the status the call with s0 and s1 exchanged would return on the same state.  That call
+// runs the same two directed searches and picks between them by the same two norms, compared the other way round.
+__device__ inline void get_collision_vectors(const Env& e, int s0, int s1, double dt, CVec& out, int* mirror_status = nullptr) {
   CVec r0, r1;
   if (NV(s0) <= 32 && NV(s1) <= 32 && !(e.dbg & 64)) {
     directed_collision_vectors_pair(e, s0, s1, dt, r0, r1);
@@ -1057,6 +1195,7 @@ __device__ inline void get_collision_vectors(const Env& e, int s0, int s1, doubl
     directed_collision_vectors(e, s1, s0, dt, r0);
     directed_collision_vectors(e, s0, s1, dt, r1);
   }
+  SEC(e, SEC_SEARCH_SELECT);
   double a0x = 0, a0y = 0, a1x = 0, a1y = 0;
   if (r0.status != CV_NONE) {
     r0.nx = -1. * r0.nx; r0.ny = -1. * r0.ny;
@@ -1064,7 +1203,9 @@ __device__ inline void get_collision_vectors(const Env& e, int s0, int s1, doubl
     a0x = r0.sx; a0y = r0.sy;
   }
   if (r1.status != CV_NONE) { a1x = r1.sx; a1y = r1.sy; }
-  if (npnorm(a0x, a0y) > npnorm(a1x, a1y)) out = r0;
+  const double n0 = npnorm(a0x, a0y), n1 = npnorm(a1x, a1y);
+  if (mirror_status) *mirror_status = (n1 > n0) ? r1.status : r0.status;
+  if (n0 > n1) out = r0;
   else out = r1;
 }
 
@@ -1219,9 +1360,8 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
 // as six in-place updates; here every new value is computed from registers first (same
 // arithmetic, same order) and the state is written once: lanes = vertices for the two
 // path translations, lane 0 for the scalars.
-__device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const CVec& c,
+__device__ inline void resolve_contact(Env& e, double elasticity, int s0, int s1, const CVec& c,
                                        int symmetric, int upd) {
-  const double elasticity = F->p0;
   const int f0 = FLAGS(s0), f1 = FLAGS(s1);
   // --- pop-out (collisions.py:548-555)
   double p0x = PX(s0), p0y = PY(s0), p1x = PX(s1), p1y = PY(s1);
@@ -1308,26 +1448,44 @@ __device__ inline void resolve_contact(Env& e, PForce F, int s0, int s1, const C
 // phase must then be redone for the following pairs); velocity-only outcomes and
 // "future contact" no-ops return false.
 // `known_hit`: the caller has already seen the two paths intersect on the current state
-__device__ inline bool collision_step(Env& e, PForce F, int s0, int s1, int K, bool known_hit = false) {
-  const int symmetric = uni(F->symmetric), upd = uni(F->i0), maxdepth = uni(F->i1);
+// `mirror_noop` (when given): set when this call changed nothing AND the call with s0 and s1 exchanged would change
+// nothing either as long as neither sprite is touched: either the paths do not overlap, by tests that are symmetric in the
+// two sprites (paths_intersect_filled's *proper), or they cross in a pair of non-parallel edges (so overlaps_sprite is true
+// both ways round, segments_intersect_kind) and the exchanged search ends "future contact" too.
+struct CollP { int symmetric, upd, maxdepth; double elasticity; };   // Collision(...) parameters (wave uniform)
+__device__ inline bool collision_step(Env& e, const CollP& F, int s0, int s1, int K, bool known_hit = false, bool proper_hit = false,
+                                      bool* mirror_noop = nullptr) {
+  const int symmetric = F.symmetric, upd = F.upd, maxdepth = F.maxdepth;
   s0 = uni(s0); s1 = uni(s1);
   bool moved = false;
+  if (mirror_noop) *mirror_noop = false;
   for (int depth = 0; depth <= maxdepth; ++depth) {
+    SEC(e, SEC_STEP_CONTROL);
     if (s0 == s1) return moved;
-    if (!(known_hit && depth == 0) && !overlaps(e, s0, s1, depth == 0)) return moved;
+    bool proper = proper_hit;
+    if (!(known_hit && depth == 0) && !overlaps(e, s0, s1, depth == 0, &proper)) {
+      if (mirror_noop && depth == 0) *mirror_noop = proper;   // no overlap, and none the other way round
+      return moved;
+    }
     if (e.dbg & 16) return moved;
     if (e.dbg & 128) e.n_resp++;
     double dt = 1. / K;
     CVec c;
-    { PROF_T0; get_collision_vectors(e, s0, s1, dt, c); PROF_ADD(e, 1); }
+    int mirror = CV_NONE;
+    { PROF_T0; get_collision_vectors(e, s0, s1, dt, c, &mirror); PROF_ADD(e, 1); }
     if (c.status == CV_NONE) {
+#ifndef MOOG_COUNT_PREFIX
       if (e.dbg & 128) e.n_disj++;
+#endif
+      SEC(e, SEC_DISJOINT);
       PROF_T0; make_disjoint(e, s0, s1, symmetric); PROF_ADD(e, 2);
       moved = true;
     } else if (c.status == CV_FUTURE) {
+      if (mirror_noop && depth == 0) *mirror_noop = proper && mirror == CV_FUTURE;
       return moved;
     } else {
-      PROF_T0; resolve_contact(e, F, s0, s1, c, symmetric, upd); PROF_ADD(e, 3);
+      SEC(e, SEC_RESOLVE);
+      PROF_T0; resolve_contact(e, F.elasticity, s0, s1, c, symmetric, upd); PROF_ADD(e, 3);
       moved = true;
     }
   }
@@ -1468,7 +1626,7 @@ __device__ inline void tether_members(Env& e, PCorr C, int zi, F f) {
 // _tether_sprites (:43-91) for one group, run by lane 0.  Masses are Python floats (the
 // lowering rejects sampled masses); the velocity sums follow numpy's float32 / float64
 // promotion exactly as the oracle restates it.
-__device__ inline void tether_group(Env& e, PCorr C, int zi, int K, int group) {
+__device__ __forceinline__ void tether_group(Env& e, PCorr C, int zi, int K, int group) {
   int n = 0;
   double total_mass = 0;
   tether_members(e, C, zi, [&](int s) { ++n; total_mass = total_mass + MASS(s); });
@@ -1889,7 +2047,7 @@ __device__ inline void maze_physics(Env& e, PCorr C) {
 // the narrow phase; as soon as a pair actually overlapped (state may have changed),
 // the list is discarded and rebuilt from the next pair on.
 #define CAND_CAP 128   // list entries; a full list is consumed before the scan continues
-__device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, int b0,
+__device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int a1, int b0,
                                             int b1, int K) {
   const int nB = b1 - b0, total = (a1 - a0) * nB;
   int start = 0;
@@ -1899,6 +2057,7 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
     int count = 0, scanned = start;
     wsync();
     PROF_T0;
+    SEC(e, SEC_PAIR_SCAN);
     while (scanned < total && count <= CAND_CAP - 64) {
       // Every load of the round goes out before anything is tested (a lane's pair is known from its index
       // alone), so a round costs one LDS round trip instead of a chain of dependent ones: this loop is
@@ -1921,11 +2080,17 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
     bool rebuilt = false;
     for (int c = 0; c < count; ++c) {
       bool known_hit = false;
+      SEC(e, SEC_PAIR_CONSUME);
       if (count - c >= 2 && !(e.dbg & (4 | 32))) {   // skip the leading candidates that do not overlap
         PROF_T0;
+        SEC(e, SEC_BATCH);
         const int n = count - c < 4 ? count - c : 4;
         const int rr = uni(narrow_reject_prefix(e, c, n)), r = rr & 255;
+#ifdef MOOG_COUNT_PREFIX
+        if (e.dbg & 128) { e.n_disj += 1 + 1000 * n; }
+#endif
         PROF_ADD(e, 8);
+        SEC(e, SEC_PAIR_CONSUME);
         known_hit = (rr & 256) != 0;
         c += r;
         if (r == n) { --c; continue; }   // all of them: on to the next batch
@@ -1948,12 +2113,13 @@ __device__ inline void collision_layer_pair(Env& e, PForce F, int a0, int a1, in
 // the sprites it moved are re-tested (one round) instead of re-scanning every later pair.  The ordered
 // candidate list the narrow phase consumes is written from the matrix, rows in order, bits in order:
 // exactly the list the ordered scan would build.
-__device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, int K) {
+__device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int a1, int K) {
   const int n = a1 - a0, total = n * n;
-  const int symmetric = uni(F->symmetric);
+  const int symmetric = F.symmetric;
   unsigned long long* rowm = e.rowm;
   wsync();
   PROF_T0;
+  SEC(e, SEC_BROAD);
   if (e.lane < n) rowm[e.lane] = 0ull;
   wsync();
   {   // unordered pairs by rounds of a round-robin: row r pairs column c with c + r + 1 (mod n)
@@ -1972,14 +2138,22 @@ __device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, in
   }
   wsync();
   PROF_ADD(e, 4);
+  // Lane r: the columns c for which the ordered pair (a0 + r, a0 + c) is known to change nothing -- its mirror image
+  // (a0 + c, a0 + r) was visited earlier in this sub-step, overlapped in a pair of non-parallel edges and ended "future
+  // contact" both ways round (collision_step's mirror_noop), and neither sprite has been touched since.  The reference
+  // visits both orders (physics.py:103-108); in the contact-heavy envs that set the kernel's duration three searches in
+  // four end "future contact", and a pair that overlaps without colliding does so twice in every sub-step.
+  unsigned long long skipbits = 0ull;
+  const bool use_skip = !uni(e.P->vel_alias);   // (velocity arrays shared across sprites: a contact elsewhere may touch the pair)
   int start = 0;
   while (start < total) {
     // ---- the ordered list of candidates with flattened index >= start, as many whole rows as fit --------
     PROF_T0;
+    SEC(e, SEC_LIST);
     const int srow = div_small(start, n), scol = start - srow * n;
     unsigned long long bits = 0ull;
     if (e.lane < n && e.lane >= srow) {
-      bits = rowm[e.lane];
+      bits = rowm[e.lane] & ~skipbits;
       if (e.lane == srow) bits &= ~((1ull << scol) - 1ull);
     }
     const int cnt = __popcll(bits);
@@ -2012,23 +2186,44 @@ __device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, in
     PROF_ADD(e, 4);
     // ---- consume ----------------------------------------------------------------------------
     bool rebuilt = false;
+    // The mirror image (j, i) of a pair (i, j), i < j, that turned out to be a no-op both ways round is struck from the list
+    // (when the list reaches that far; `skipbits` keeps it out of later lists); a struck entry counts as rejected.
+    auto mark_mirror = [&](int s0k, int tk) {   // (s0k, tk): wave uniform, tk > s0k
+      const int j = tk - a0, i = s0k - a0;
+      if (e.lane == j) {
+        skipbits |= 1ull << i;
+        // (row j > the current row >= srow: `bits` is lane j's whole row as listed)
+        if (j < rows_end && ((bits >> i) & 1ull)) e.cand[(inc - cnt) + __popcll(bits & ((1ull << i) - 1ull))] = (uint16_t)CAND_SKIP;
+      }
+    };
     for (int c = 0; c < count; ++c) {
-      bool known_hit = false;
-      if (count - c >= 2 && !(e.dbg & (4 | 32))) {   // skip the leading candidates that do not overlap
+      bool known_hit = false, proper_hit = false;
+      SEC(e, SEC_CONSUME);
+      if (count - c >= 2 && !(e.dbg & (4 | 32))) {   // pass over the leading candidates that do not overlap
         PROF_T0;
+        SEC(e, SEC_BATCH);
         const int nn = count - c < 4 ? count - c : 4;
         const int rr = uni(narrow_reject_prefix(e, c, nn)), r = rr & 255;
+#ifdef MOOG_COUNT_PREFIX   // (analysis builds: batches in the make_disjoint counter, tools/heavy_bench.py)
+        if (e.dbg & 128) { e.n_disj += 1 + 1000 * nn; }
+#endif
+        SEC(e, SEC_CONSUME);
         PROF_ADD(e, 8);
         known_hit = (rr & 256) != 0;
+        proper_hit = (rr & 512) != 0;
         c += r;
         if (r == nn) { --c; continue; }   // all of them: on to the next batch
       }
       const int pr = uni((int)e.cand[c]);
+      if (pr == CAND_SKIP) continue;
       const int s0 = pr >> 8, t = pr & 255;
-      if (!(e.dbg & 4) && collision_step(e, F, s0, t, K, known_hit)) {
+      if (e.dbg & 4) continue;
+      bool noop = false;
+      if (collision_step(e, F, s0, t, K, known_hit, proper_hit, &noop)) {
         start = (s0 - a0) * n + (t - a0) + 1;
         // re-test the pairs of the sprites the contact moved (s0; t as well when symmetric)
         PROF_T0;
+        SEC(e, SEC_RETEST);
         for (int w = 0; w < (symmetric ? 2 : 1); ++w) {
           const int m = (w ? t : s0) - a0;
           wsync();
@@ -2041,10 +2236,16 @@ __device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, in
           }
           wsync();
         }
+        // what was known about pairs of s0 or t is stale (position, velocity or angular velocity changed)
+        skipbits &= ~((1ull << (s0 - a0)) | (1ull << (t - a0)));
+        if (e.lane == s0 - a0 || e.lane == t - a0) skipbits = 0ull;
         PROF_ADD(e, 4);
         rebuilt = true;
         break;
       }
+      SEC(e, SEC_CONSUME);
+      // nothing changed, and nothing would with the sprites exchanged: the mirror image (t, s0) comes later in this sub-step
+      if (noop && use_skip && t > s0 && !(e.dbg & 512)) { mark_mirror(s0, t); wsync(); }
     }
     if (!rebuilt) start = scanned;
   }
@@ -2053,48 +2254,45 @@ __device__ inline void collision_same_layer(Env& e, PForce F, int a0, int a1, in
 // physics.py:88-117 (one substep).  DYN: the kernel variant that carries the rarely used components (here the maze
 // walk / MazePhysics, whose scratch frame must not weigh on the plain step kernel).
 template <bool DYN>
-__device__ inline void apply_physics(Env& e) {
+__device__ __forceinline__ void apply_physics(Env& e) {   // (forced: see the note at moog_step_kernel)
   PProg P = e.P;
   const int K = uni(P->updates_per_env_step);
-  const int n_forces = uni(P->n_forces);
-  for (int fi = 0; fi < n_forces; ++fi) {
-    PForce F = &P->forces[fi];
-    const int n_a = uni(F->n_a), n_b = uni(F->n_b), kind = uni(F->kind);
-    for (int a = 0; a < n_a; ++a) {
-      int la = uni(F->layers_a[a]);
-      int a0 = uni(P->layer_slot0[la]), a1 = a0 + uni(P->layer_nslots[la]);
-      if (n_b == 0) {
-        if (kind != MOOG_FORCE_RANDOM && kind != MOOG_FORCE_MAZE_WALK && kind != MOOG_FORCE_MAZE_WALK_DET && !uni(P->vel_alias)) {
-          force_single_layer(e, F, a0, a1, K);
-        } else {
-          for (int s = a0; s < a1; ++s)
-            if (ALIVE(s)) {
-              if constexpr (DYN && MOOG_WITH_MAZE) {
-                if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; }
-                if (kind == MOOG_FORCE_MAZE_WALK_DET) { maze_walk_det_step(e, F, s, K); continue; }
-              }
-              force_single(e, F, s, K);
-            }
-        }
+  const int n_fops = e.n_fops;
+  for (int k = 0; k < n_fops; ++k) {
+    SEC(e, SEC_FORCES);
+    PFOp op = &e.fops[k];
+    const int kind = uni(op->kind), n_b = uni(op->n_b);
+    const int a0 = uni(op->a0), a1 = uni(op->a1), b0 = uni(op->b0), b1 = uni(op->b1);
+    if (kind == MOOG_FORCE_COLLISION) {
+      if (!(e.dbg & 1)) {
+        PROF_T0;
+        CollP cp;
+        cp.symmetric = uni(op->symmetric); cp.upd = uni(op->i0); cp.maxdepth = uni(op->i1); cp.elasticity = op->p0;
+        if (a0 == b0 && a1 == b1 && a1 - a0 <= 64 && a1 - a0 >= 2) collision_same_layer(e, cp, a0, a1, K);
+        else collision_layer_pair(e, cp, a0, a1, b0, b1, K);
+        PROF_ADD(e, 7);
+      }
+      continue;
+    }
+    PForce F = &P->forces[uni(op->fi)];
+    if (n_b == 0) {
+      if (kind != MOOG_FORCE_RANDOM && kind != MOOG_FORCE_MAZE_WALK && kind != MOOG_FORCE_MAZE_WALK_DET && !uni(P->vel_alias)) {
+        force_single_layer(e, F, a0, a1, K);
       } else {
-        for (int b = 0; b < n_b; ++b) {
-          int lb = uni(F->layers_b[b]);
-          int b0 = uni(P->layer_slot0[lb]), b1 = b0 + uni(P->layer_nslots[lb]);
-          if (kind == MOOG_FORCE_COLLISION) {
-            if (!(e.dbg & 1)) {
-              PROF_T0;
-              if (a0 == b0 && a1 == b1 && a1 - a0 <= 64 && a1 - a0 >= 2) collision_same_layer(e, F, a0, a1, K);
-              else collision_layer_pair(e, F, a0, a1, b0, b1, K);
-              PROF_ADD(e, 7);
+        for (int s = a0; s < a1; ++s)
+          if (ALIVE(s)) {
+            if constexpr (DYN && MOOG_WITH_MAZE) {
+              if (kind == MOOG_FORCE_MAZE_WALK) { maze_walk_step(e, F, s, K); continue; }
+              if (kind == MOOG_FORCE_MAZE_WALK_DET) { maze_walk_det_step(e, F, s, K); continue; }
             }
-          } else {
-            for (int s0 = a0; s0 < a1; ++s0) {
-              if (!ALIVE(s0)) continue;
-              for (int s1 = b0; s1 < b1; ++s1)
-                if (ALIVE(s1)) force_pair_newton(e, F, s0, s1, K);
-            }
+            force_single(e, F, s, K);
           }
-        }
+      }
+    } else {
+      for (int s0 = a0; s0 < a1; ++s0) {
+        if (!ALIVE(s0)) continue;
+        for (int s1 = b0; s1 < b1; ++s1)
+          if (ALIVE(s1)) force_pair_newton(e, F, s0, s1, K);
       }
     }
   }
@@ -2886,6 +3084,7 @@ __device__ inline void rule_reset_tree(Env& e, int ri) {
 // moog/_symbolic.py trace_state_condition; MOOG_COND_* and MOOG_RCOND_* share the numbering)
 __device__ inline double layer_condition(Env& e, int kind, int layer, int xoff) {
   PProg P = e.P;
+  if (kind == MOOG_COND_STATE_EXPR) return eval_expr(e, xoff, 0, 0, nullptr, nullptr);   // (no sprite of its own: s0 / s1 unused)
   const int a0 = P->layer_slot0[layer], a1 = a0 + P->layer_nslots[layer];
   if (kind == MOOG_COND_FIRST_EXPR) {
     for (int s = a0; s < a1; ++s)
@@ -2915,7 +3114,7 @@ __device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
                       [&](int t) { if (overlaps(e, s, t, true)) ++n; });
     return n;
   }
-  if (R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR)
+  if ((R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR) || R->cond == MOOG_RCOND_STATE_EXPR)
     return (int)layer_condition(e, R->cond, R->l0, R->xfilter);
   if (R->cond == MOOG_RCOND_COUNT_EXPR) {   // accumulated per-sprite terms
     PProg P = e.P;
@@ -3061,7 +3260,7 @@ __device__ inline bool task_condition(const Env& e, PTask T) {
 }
 // conditions that run the expression evaluator (DYN kernels only)
 __device__ inline bool task_condition_x(Env& e, PTask T) {
-  if (T->cond >= MOOG_COND_ALL_EXPR && T->cond <= MOOG_COND_FIRST_EXPR)
+  if ((T->cond >= MOOG_COND_ALL_EXPR && T->cond <= MOOG_COND_FIRST_EXPR) || T->cond == MOOG_COND_STATE_EXPR)
     return layer_condition(e, T->cond, T->cond_layer, T->xcond) != 0;
   return task_condition(e, T);
 }

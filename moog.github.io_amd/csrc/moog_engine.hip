@@ -53,7 +53,12 @@ struct moog_engine {
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
   int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
+  int prio_pm[3] = {0, 0, 0};   // wave priorities by launch rank, per mille of the batch (KArgs::prio_t)
   int32_t xstack_off = 0;
+  FOp* d_fops = nullptr;        // flattened force list (moog_flatten_forces)
+  int32_t n_fops = 0;
+  int32_t* watch = nullptr;     // section sampling (MOOG_WATCH=1): [n_envs][MOOG_WATCH_SECTIONS]
+  int32_t watch_off = 0;
   bool dynamic_rules = false;
   bool maze_kernel = false;   // the program uses MazePhysics / a maze walk / a per-reset maze
   RPlan raster_plan_{};
@@ -127,6 +132,8 @@ static void free_engine(moog_engine* e) {
   if (e->fused_abort) hipHostFree(e->fused_abort);
   if (e->fused_check_img) hipFree(e->fused_check_img);
   if (e->layer_hw) hipFree(e->layer_hw);
+  if (e->watch) hipFree(e->watch);
+  if (e->d_fops) hipFree(e->d_fops);
   delete e;
 }
 
@@ -347,9 +354,16 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       err = hipMemcpy(e->d_vinfo, vi.data(), vi.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "vertex table"); }
   }
+  {
+    const std::vector<FOp> fops = moog_flatten_forces(prog);
+    e->n_fops = (int32_t)fops.size();
+    err = hipMalloc(&e->d_fops, (fops.size() + 1) * sizeof(FOp));
+    if (err == hipSuccess && !fops.empty()) err = hipMemcpy(e->d_fops, fops.data(), fops.size() * sizeof(FOp), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "force list"); }
+  }
   const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
-                (size_t)e->L.S * 4 * 8 + (e->L.S > 64 ? (size_t)e->L.S * 8 * 8 : 0) +
+                (size_t)e->L.S * 4 * 8 +
                 (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
   if ((size_t)HL.o_verts * 8 < (size_t)DL_SCRATCH_A) e->step_lds += DL_SCRATCH_A + 16;   // the draw-list emission's scratch (moog_kernels.h emit_drawlist)
   if (prog->xstack_depth > 0) {   // per-lane value stacks of the lane-parallel filter evaluator (moog_device.h eval_expr_t<true>)
@@ -358,6 +372,17 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->step_lds += (size_t)prog->xstack_depth * 64 * 8;
   }
   { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
+  { const char* w = getenv("MOOG_WATCH");   // section sampling (moog_engine_read_watch): two words of LDS for the watcher
+    if (w && atoi(w) == 1) {
+      e->step_lds = (e->step_lds + 15) & ~(size_t)15;
+      e->watch_off = (int32_t)e->step_lds;
+      e->step_lds += 16;
+      if (hipMalloc(&e->watch, (size_t)n_envs * MOOG_WATCH_SECTIONS * sizeof(int32_t)) != hipSuccess ||
+          hipMemset(e->watch, 0, (size_t)n_envs * MOOG_WATCH_SECTIONS * sizeof(int32_t)) != hipSuccess) {
+        free_engine(e);
+        return fail(MOOG_E_NOMEM, "hipMalloc(watch) failed");
+      }
+    } }
   if (e->step_lds > 160 * 1024) {
     free_engine(e);
     return fail(MOOG_E_UNSUPPORTED, "state record does not fit in 160 KB of LDS");
@@ -454,6 +479,17 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     for (int v = 0; v < 6 && err == hipSuccess; ++v) err = (hipError_t)configure[v](e->step_lds);
     e->step_wps = (160 * 1024 / (e->step_lds ? e->step_lds : 1)) <= 14 ? 3 : 4;
     { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) e->step_wps = atoi(w); }   // experiments
+    if (err == hipSuccess) err = (hipError_t)moog_configure_step_f2(e->step_lds);
+    { const char* w = getenv("MOOG_STEP_WPS"); if (w && atoi(w) == 2) e->step_wps = 2; }   // (plain programs only: launch_step)
+    {   // MOOG_STEP_PRIO="a,b,c": per mille of the launch order that runs at wave priority 3 / >= 2 / >= 1 ("0": off)
+      const char* pr = getenv("MOOG_STEP_PRIO");
+      int a = 0, b = 0, c = 0;
+      if (pr && sscanf(pr, "%d,%d,%d", &a, &b, &c) >= 1) {
+        if (b < a) b = a;
+        if (c < b) c = b;
+        e->prio_pm[0] = a; e->prio_pm[1] = b; e->prio_pm[2] = c;
+      }
+    }
   }
   for (int r = 0; r < prog->n_rules; ++r) {
     int k = prog->rules[r].kind;
@@ -464,8 +500,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   for (int t = 0; t < prog->n_tasks; ++t) {
     if (prog->tasks[t].kind == MOOG_TASK_CONTACT_REWARD && (prog->tasks[t].xcond >= 0 || prog->tasks[t].xreward >= 0))
       e->dynamic_rules = true;
-    if (prog->tasks[t].kind == MOOG_TASK_RESET && prog->tasks[t].cond >= MOOG_COND_ALL_EXPR)
-      e->dynamic_rules = true;
+    if (prog->tasks[t].kind == MOOG_TASK_RESET && (prog->tasks[t].cond >= MOOG_COND_ALL_EXPR || prog->tasks[t].xreward >= 0))
+      e->dynamic_rules = true;   // (a reward_fn that reads the state is an expression too: task_reward<DYN> evaluates it)
   }
   for (int r = 0; r < prog->n_rules; ++r)
     if ((prog->rules[r].kind == MOOG_RULE_CONDITIONAL || prog->rules[r].kind == MOOG_RULE_PHASE) &&
@@ -606,12 +642,16 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.layer_hw = e->layer_hw;
   a.act_f32 = e->act_f32;
   a.xstack_off = e->xstack_off;
+  a.watch = (mode == MODE_STEP) ? e->watch : nullptr; a.watch_off = e->watch_off;
+  a.fops = e->d_fops; a.n_fops = e->n_fops;
+  for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
   return a;
 }
 
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   static const moog_step_launch_fn launch[6] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
                                                 moog_launch_step_t4, moog_launch_step_m3, moog_launch_step_m4};
+  if (e->step_wps == 2 && !e->maze_kernel && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
   launch[(e->maze_kernel ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
 }
 
@@ -960,6 +1000,17 @@ int moog_engine_set_debug(moog_engine_t* e, int32_t step_debug, int32_t raster_s
   if (!e) return fail(MOOG_E_INVALID, "null engine");
   e->step_dbg = step_debug;
   e->raster_stop = raster_stop;
+  return MOOG_OK;
+}
+
+int moog_engine_read_watch(moog_engine_t* e, int32_t* host_out, int32_t clear) {
+  if (!e || !host_out) return fail(MOOG_E_INVALID, "null argument");
+  if (!e->watch) return fail(MOOG_E_UNSUPPORTED, "section sampling needs an engine created with MOOG_WATCH=1");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t bytes = (size_t)e->n_envs * MOOG_WATCH_SECTIONS * sizeof(int32_t);
+  HIPCHK(hipMemcpy(host_out, e->watch, bytes, hipMemcpyDeviceToHost));
+  if (clear) HIPCHK(hipMemset(e->watch, 0, bytes));
   return MOOG_OK;
 }
 

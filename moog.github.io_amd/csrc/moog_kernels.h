@@ -114,6 +114,27 @@ __device__ inline void store_record(const Env& e, const HotLayout& h, const moog
   }
 }
 
+// The (force, layer a, layer b) combinations of a program in the order physics.py:96-108 visits them.
+#include <vector>
+inline std::vector<FOp> moog_flatten_forces(const moog_program_t* p) {
+  std::vector<FOp> out;
+  for (int fi = 0; fi < p->n_forces; ++fi) {
+    const moog_force_t& F = p->forces[fi];
+    for (int a = 0; a < F.n_a; ++a) {
+      FOp op = {};
+      op.fi = fi; op.kind = F.kind; op.symmetric = F.symmetric; op.i0 = F.i0; op.i1 = F.i1; op.p0 = F.p0; op.p1 = F.p1;
+      op.a0 = p->layer_slot0[F.layers_a[a]]; op.a1 = op.a0 + p->layer_nslots[F.layers_a[a]];
+      op.n_b = F.n_b;
+      if (F.n_b == 0) { out.push_back(op); continue; }
+      for (int b = 0; b < F.n_b; ++b) {
+        op.b0 = p->layer_slot0[F.layers_b[b]]; op.b1 = op.b0 + p->layer_nslots[F.layers_b[b]];
+        out.push_back(op);
+      }
+    }
+  }
+  return out;
+}
+
 struct KArgs {
   const moog_program_t* P;
   moog_layout_t L;       // layout of the records in HBM (the ABI's)
@@ -146,6 +167,12 @@ struct KArgs {
   int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
   int32_t act_f32;       // 1: `actions` holds float32 values (moog_engine_set_action_dtype)
   int32_t xstack_off;    // byte offset of the per-lane expression stacks in a wave's LDS area (Env::xstack), 0: none
+  const FOp* fops;       // flattened force list (moog_flatten_forces) and its length
+  int32_t n_fops;
+  int32_t* watch;        // section sampling (moog_engine_read_watch): [n_envs][MOOG_WATCH_SECTIONS] sample counts, or null
+  int32_t watch_off;     // byte offset of the watcher's words in the workgroup's LDS
+  int32_t prio_t[3];     // wave priorities by launch rank (with `perm`: descending cost of the previous step): workgroups
+                         // [0, t0) issue at priority 3, [t0, t1) at 2, [t1, t2) at 1, the rest at 0; all zero: off
 };
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
@@ -169,18 +196,21 @@ extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 // lds: this wave's record area (the whole dynamic LDS of a one-wave workgroup; the fused launch runs four envs per workgroup)
 __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* lds = moog_lds, int lane = (int)threadIdx.x) {
   e.P = as_const_prog(a.P);
+  e.fops = (PFOp)(unsigned long long)a.fops;
+  e.n_fops = a.n_fops;
   e.L = a.H.L;
   const moog_layout_t& H = a.H.L;
   e.f = reinterpret_cast<double*>(lds);
   e.q = reinterpret_cast<int32_t*>(lds + (size_t)H.f64_per_env * 8);
   e.bb = reinterpret_cast<float*>(lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
-  e.xf = reinterpret_cast<double*>(e.bb + 8 * H.S);       // [S][8] only when S > 64
-  double* after_xf = (H.S > 64) ? e.xf + 8 * H.S : e.xf;
-  e.voff = reinterpret_cast<int32_t*>(after_xf);
+  e.voff = reinterpret_cast<int32_t*>(e.bb + 8 * H.S);
   e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
   e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
   e.rowm = reinterpret_cast<unsigned long long*>(e.lst + 128);
   e.xstack = a.xstack_off > 0 ? reinterpret_cast<double*>(lds + a.xstack_off) : nullptr;
+#ifdef MOOG_WATCH
+  e.secw = a.watch ? reinterpret_cast<int32_t*>(__builtin_assume_aligned(lds + a.watch_off, 16)) : nullptr;
+#endif
   if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
   else e.gcol = e.f + H.o_color;
   if (a.H.i_cut1 > a.H.i_cut0) {
@@ -339,6 +369,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
   }
   {
   PROF_T0;
+  SEC(e, SEC_RULES);
   // environment.py:98-126
   const int n_rules = uni(P->n_rules);
   for (int r = 0; r < n_rules; ++r)
@@ -368,6 +399,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
   PROF_ADD(e, 10);
   }
   { PROF_T0; for (int k = 0; k < K; ++k) apply_physics<DYN>(e); PROF_ADD(e, 6); }
+  SEC(e, SEC_TASK);
   int sc = e.q[e.L.o_step_count] + 1;
   wsync();
   if (e.lane == 0) e.q[e.L.o_step_count] = sc;
@@ -382,6 +414,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
+  SEC(e, SEC_STORE);
   store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
   emit_drawlist(e, a, env);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
@@ -398,11 +431,51 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
 }
 
 template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
-__global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
+// Every device function must end up inlined into this kernel: the env's descriptor (`Env`: pointers and the layout's offsets)
+// has to live in registers.  One function left out of line takes it by reference through scratch memory, ~1000 cycles per
+// access: round 4 measured this kernel at 1270 instead of 800 us the day the inliner's cost model left apply_physics out
+// (hence the __forceinline__ there; tests/test_host.py::test_step_kernels_have_no_calls checks the built objects).
+#ifdef MOOG_WATCH
+#define MOOG_STEP_THREADS 128   // the env's wavefront + its watcher
+#else
+#define MOOG_STEP_THREADS 64
+#endif
+__global__ __launch_bounds__(MOOG_STEP_THREADS, WPS) void moog_step_kernel(KArgs a) {
   int env = blockIdx.x;
   if (env >= a.n_envs) return;
+#ifdef MOOG_WATCH
+  if (a.watch) {
+    int32_t* w = reinterpret_cast<int32_t*>(__builtin_assume_aligned(moog_lds + a.watch_off, 16));   // w[0]: the section announced, w[1]: 1 when the env is done
+    if (threadIdx.x == 0) { w[0] = 0; w[1] = 0; }
+    __syncthreads();
+    if (threadIdx.x >= 64) {   // the watcher: one sample every ~256 cycles, histogram in registers of lane 64 + section
+      const int lane = (int)threadIdx.x - 64;
+      int count = 0;
+      while (__hip_atomic_load(&w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+        const int sec = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == (sec & (MOOG_WATCH_SECTIONS - 1))) ++count;
+        __builtin_amdgcn_s_sleep(3);
+      }
+      const int real = a.perm ? a.perm[env] : env;
+      if (lane < MOOG_WATCH_SECTIONS) atomicAdd(&a.watch[(size_t)real * MOOG_WATCH_SECTIONS + lane], count);
+      return;
+    }
+  } else if (threadIdx.x >= 64) return;
+#endif
+  // The launch lasts as long as its slowest env, and a wavefront that shares its SIMD with two others issues an
+  // instruction every ~9 cycles instead of every ~5: the envs that were expensive in the previous step (they come first in
+  // the launch order) get the SIMD's issue slots ahead of their neighbours.  A scheduling hint: no result depends on it.
+  if (a.perm && a.prio_t[2] > 0) {
+    const int b = (int)blockIdx.x;
+    if (b < a.prio_t[0]) __builtin_amdgcn_s_setprio(3);
+    else if (b < a.prio_t[1]) __builtin_amdgcn_s_setprio(2);
+    else if (b < a.prio_t[2]) __builtin_amdgcn_s_setprio(1);
+  }
   if (a.perm) env = a.perm[env];
   const bool direct = step_env<DYN>(a, env, moog_lds, (int)threadIdx.x);
+#ifdef MOOG_WATCH
+  if (a.watch && threadIdx.x == 0) { int32_t* w = reinterpret_cast<int32_t*>(__builtin_assume_aligned(moog_lds + a.watch_off, 16)); __hip_atomic_store(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
   if (a.done) {   // the frame of this env may be drawn now (moog_raster_follow_kernel): record first, then the flag
     // The record went out with agent-scope stores; whatever the call wrote straight to HBM with ordinary stores (a reset's
     // colours / opacities / shapes; rules that modify them: done_wb) needs this XCD's L2 written back first.  That
@@ -422,12 +495,14 @@ __global__ __launch_bounds__(64, WPS) void moog_step_kernel(KArgs a) {
 // ---- launch functions (one translation unit each, so that they compile in parallel) ------------------
 // variant = (dynamic rules ? 2 : 0) + (waves per SIMD == 4 ? 1 : 0)
 typedef void (*moog_step_launch_fn)(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+void moog_launch_step_f2(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_f3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_f4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_t3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_t4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_m3(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
 void moog_launch_step_m4(int n_envs, size_t lds, hipStream_t s, const KArgs& a);
+int moog_configure_step_f2(size_t lds);
 int moog_configure_step_f3(size_t lds);
 int moog_configure_step_f4(size_t lds);
 int moog_configure_step_t3(size_t lds);

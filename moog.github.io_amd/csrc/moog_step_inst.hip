@@ -10,7 +10,7 @@
 #define MOOG_CAT(a, b) MOOG_CAT_(a, b)
 
 void MOOG_CAT(moog_launch_step_, MOOG_STEP_TAG)(int n_envs, size_t lds, hipStream_t s, const KArgs& a) {
-  hipLaunchKernelGGL((moog_step_kernel<MOOG_STEP_DYN != 0, MOOG_STEP_WPS, MOOG_STEP_DYN>), dim3(n_envs), dim3(64), lds, s, a);
+  hipLaunchKernelGGL((moog_step_kernel<MOOG_STEP_DYN != 0, MOOG_STEP_WPS, MOOG_STEP_DYN>), dim3(n_envs), dim3(MOOG_STEP_THREADS), lds, s, a);
 }
 
 int MOOG_CAT(moog_configure_step_, MOOG_STEP_TAG)(size_t lds) {

@@ -18,6 +18,7 @@ SYMBOLS = (
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
     'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
     'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
+    'moog_engine_read_watch',
 )
 
 _LIB = None

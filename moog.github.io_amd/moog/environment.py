@@ -45,13 +45,15 @@ class BatchedEnvironment(object):
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
                  meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0,
-                 layer_capacity=None, keep_sprite_factors=False):
+                 layer_capacity=None, keep_sprite_factors=False, _compiled=None, _buffers=None):
         import torch
         self._torch = torch
         self._lib = _engine.load_library()  # raises when the HIP extension is missing
         if not torch.cuda.is_available():
             raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
-        self.compiled = _compiler.compile_config(
+        # (_compiled / _buffers: a SubBatchedEnvironment builds its parts over one lowered program and slices of one set of
+        #  tensors)
+        self.compiled = _compiled if _compiled is not None else _compiler.compile_config(
             state_initializer, physics, task, action_space, observers, game_rules,
             meta_state_initializer, layer_capacity=layer_capacity,
             keep_sprite_factors=keep_sprite_factors)
@@ -73,14 +75,12 @@ class BatchedEnvironment(object):
         P, L = self.compiled.program, self.compiled.layout
         self.layout = L
         n = self.num_envs
-        with torch.cuda.device(self.device):
-            self.state_f64 = torch.zeros((n, L.f64_per_env), dtype=torch.float64, device=self.device)
-            self.state_i32 = torch.zeros((n, L.i32_per_env), dtype=torch.int32, device=self.device)
-            self.reward = torch.full((n,), float('nan'), dtype=torch.float64, device=self.device)
-            self.discount = torch.full((n,), float('nan'), dtype=torch.float64, device=self.device)
-            self.step_type = torch.zeros((n,), dtype=torch.int32, device=self.device)
-            self.image = torch.zeros((n, P.render.height, P.render.width, 3), dtype=torch.uint8,
-                                     device=self.device)
+        if _buffers is not None:
+            (self.state_f64, self.state_i32, self.reward, self.discount, self.step_type, self.image) = _buffers
+        else:
+            with torch.cuda.device(self.device):
+                (self.state_f64, self.state_i32, self.reward, self.discount, self.step_type,
+                 self.image) = self.allocate_buffers(torch, L, P, n, self.device)
         self._handle = ctypes.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(self.device):   # (the engine calls hipSetDevice: keep torch's current device)
@@ -109,6 +109,16 @@ class BatchedEnvironment(object):
         self._cost = self._perm = None
         self._fused = False
         self._action_f32 = False
+
+    @staticmethod
+    def allocate_buffers(torch, L, P, n, device):
+        """The state records and step outputs of n envs (the engine borrows their device pointers)."""
+        return (torch.zeros((n, L.f64_per_env), dtype=torch.float64, device=device),
+                torch.zeros((n, L.i32_per_env), dtype=torch.int32, device=device),
+                torch.full((n,), float('nan'), dtype=torch.float64, device=device),
+                torch.full((n,), float('nan'), dtype=torch.float64, device=device),
+                torch.zeros((n,), dtype=torch.int32, device=device),
+                torch.zeros((n, P.render.height, P.render.width, 3), dtype=torch.uint8, device=device))
 
     def enable_cost_schedule(self, enabled=True, fused=False):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
@@ -559,6 +569,166 @@ class BatchedEnvironment(object):
             self.close()
         except Exception:  # pylint: disable=broad-except
             pass
+
+
+class SubBatchedEnvironment(object):
+    """N envs stepped as G independent sub-batches, each on its own HIP stream (an EnvPool-style surface):
+
+        env = SubBatchedEnvironment(num_envs=4096, sub_batches=4, **config)
+        env.reset()
+        for g in range(env.sub_batches): env.step_async(g, actions_g)      # returns at once
+        ts_g = env.recv(g)                                                 # TimeStep views of sub-batch g
+
+    A `step()` of the whole batch lasts as long as its slowest env (contact-heavy envs take 2.5-3 x the mean,
+    DESIGN 3.1), and the next call cannot start before it: the machine idles behind that barrier.  Sub-batches are
+    chained only with themselves -- step -> frames -> next step on the sub-batch's stream -- so one sub-batch's slow
+    tail runs beside another's head, and frames of one beside steps of another, by plain stream concurrency.
+
+    Results do not depend on G: the parts are ordinary engine handles over contiguous slices of ONE set of tensors
+    (`state_f64`, `image`, ... are whole-batch tensors here), and the random streams are keyed by the global env
+    index, so env i computes exactly what it computes in a BatchedEnvironment of num_envs.
+
+    Stream contract: `step_async(g, a)` makes sub-batch g's stream wait for the work already queued on the caller's
+    current stream (the producer of `a`); `recv(g)` makes the caller's current stream wait for sub-batch g.  A consumer
+    that wants the overlap must not funnel every sub-batch through one stream between recv and step_async: use
+    `stream(g)` (e.g. `with torch.cuda.stream(env.stream(g))`) for the per-sub-batch policy work, or queue several
+    steps ahead.  `step(actions)` / `reset()` are the synchronous whole-batch forms."""
+
+    def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
+                 meta_state_initializer=None, num_envs=1, sub_batches=2, device=None, seed=0, env_index0=0,
+                 layer_capacity=None, keep_sprite_factors=False):
+        import torch
+        self._torch = torch
+        if meta_state_initializer is not None or any(getattr(r, 'host_side', False) for r in game_rules):
+            raise NotImplementedError('SubBatchedEnvironment: host-side meta-state rules step the whole batch on the host')
+        G = int(sub_batches)
+        if G < 1 or num_envs % G != 0:
+            raise ValueError('num_envs (%d) must be a multiple of sub_batches (%d)' % (num_envs, G))
+        self.num_envs, self.sub_batches = int(num_envs), G
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.compiled = _compiler.compile_config(
+            state_initializer, physics, task, action_space, observers, game_rules, None,
+            layer_capacity=layer_capacity, keep_sprite_factors=keep_sprite_factors)
+        P, L = self.compiled.program, self.compiled.layout
+        self.layout = L
+        with torch.cuda.device(self.device):
+            bufs = BatchedEnvironment.allocate_buffers(torch, L, P, self.num_envs, self.device)
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(G)]
+        (self.state_f64, self.state_i32, self.reward, self.discount, self.step_type, self.image) = bufs
+        m = self.num_envs // G
+        self.part_envs = m
+        self.parts = []
+        for g in range(G):
+            views = tuple(b[g * m:(g + 1) * m] for b in bufs)
+            self.parts.append(BatchedEnvironment(
+                state_initializer, physics, task, action_space, observers, game_rules, None,
+                num_envs=m, device=self.device, seed=seed, env_index0=int(env_index0) + g * m,
+                _compiled=self.compiled, _buffers=views))
+        self.physics, self.task, self.action_space = physics, task, action_space
+        self.observers, self.game_rules = observers, game_rules
+        self._is_grid = self.parts[0]._is_grid
+        self._pending = [None] * G   # per sub-batch: the event of its last queued call
+
+    def stream(self, g):
+        return self._streams[g]
+
+    def part_slice(self, g):
+        return slice(g * self.part_envs, (g + 1) * self.part_envs)
+
+    def enable_cost_schedule(self, enabled=True):
+        """Cost-ordered launch inside every sub-batch (BatchedEnvironment.enable_cost_schedule; the frames-follow-steps
+        launch is not used here: overlap comes from the streams)."""
+        for g, p in enumerate(self.parts):
+            with self._torch.cuda.stream(self._streams[g]):
+                p.enable_cost_schedule(enabled)
+
+    def _enqueue(self, g, fn):
+        torch = self._torch
+        s = self._streams[g]
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            out = fn()
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self._pending[g] = ev
+        return out
+
+    def step_async(self, g, action):
+        """Queues one step of sub-batch g (actions [num_envs / G, ...]) on its stream and returns."""
+        if hasattr(action, 'record_stream') and action.is_cuda:
+            action.record_stream(self._streams[g])
+        self._enqueue(g, lambda: self.parts[g].step(action))
+
+    def reset_async(self, g):
+        self._enqueue(g, lambda: self.parts[g].reset())
+
+    def recv(self, g):
+        """TimeStep of sub-batch g's last queued call (views of the whole-batch tensors); the caller's current stream
+        waits for it."""
+        if self._pending[g] is not None:
+            self._torch.cuda.current_stream(self.device).wait_event(self._pending[g])
+        return self.parts[g]._timestep()
+
+    def _join(self):
+        cur = self._torch.cuda.current_stream(self.device)
+        for ev in self._pending:
+            if ev is not None:
+                cur.wait_event(ev)
+
+    def _timestep(self):
+        return dm_env.TimeStep(self.step_type, self.reward, self.discount, {'image': self.image})
+
+    def reset(self):
+        for g in range(self.sub_batches):
+            self.reset_async(g)
+        self._join()
+        return self._timestep()
+
+    def step(self, action):
+        """Whole-batch synchronous form: every sub-batch steps, the caller's stream waits for all of them."""
+        m = self.part_envs
+        for g in range(self.sub_batches):
+            self.step_async(g, action[g * m:(g + 1) * m])
+        self._join()
+        return self._timestep()
+
+    def random_action(self):
+        torch = self._torch
+        if self._is_grid:
+            return torch.randint(0, 5, (self.num_envs,), dtype=torch.int32, device=self.device)
+        return torch.rand((self.num_envs, 2), dtype=torch.float64, device=self.device) * 2 - 1
+
+    def observation_spec(self):
+        return self.parts[0].observation_spec()
+
+    def action_spec(self):
+        return self.parts[0].action_spec()
+
+    def raise_faults(self):
+        self._torch.cuda.synchronize(self.device)
+        for p in self.parts:
+            p.raise_faults()
+
+    def set_timing(self, enabled, kernels=None, every=1):
+        for p in self.parts:
+            p.set_timing(enabled, kernels, every)
+
+    def kernel_time(self, kernel_id):
+        """(total ms, launches) summed over the sub-batches' engines."""
+        ms, cnt = 0.0, 0
+        for p in self.parts:
+            a, b = p.kernel_time(kernel_id)
+            ms += a
+            cnt += b
+        return ms, cnt
+
+    def field(self, name):
+        return BatchedEnvironment.field(self, name)
+
+    def close(self):
+        self._torch.cuda.synchronize(self.device)
+        for p in self.parts:
+            p.close()
 
 
 class Environment(object):

@@ -379,7 +379,7 @@ def classify_condition(condition):
     # reads the state: all / any over a layer, the layer's first sprite, or the current phase
     kind, layer, node = _symbolic.trace_state_condition(condition, with_meta=(nargs == 2))
     code = {'all': _abi.MOOG_RCOND_ALL_EXPR, 'any': _abi.MOOG_RCOND_ANY_EXPR,
-            'first': _abi.MOOG_RCOND_FIRST_EXPR, 'plain': _abi.MOOG_RCOND_FIRST_EXPR,
+            'first': _abi.MOOG_RCOND_FIRST_EXPR, 'plain': _abi.MOOG_RCOND_STATE_EXPR,
             'count': _abi.MOOG_RCOND_COUNT_EXPR}[kind]
     return code, 0., ((layer, layer) if layer is not None else None), node
 

@@ -62,7 +62,7 @@ class Reset(AbstractTask):
         try:   # all(...) / any(...) over one layer, or a test of its first sprite
             kind, layer, node = _symbolic.trace_state_condition(cond, with_meta=self._with_meta)
             code = {'all': _abi.MOOG_COND_ALL_EXPR, 'any': _abi.MOOG_COND_ANY_EXPR,
-                    'first': _abi.MOOG_COND_FIRST_EXPR, 'plain': _abi.MOOG_COND_FIRST_EXPR}[kind]
+                    'first': _abi.MOOG_COND_FIRST_EXPR, 'plain': _abi.MOOG_COND_STATE_EXPR}[kind]
             if layer is None:
                 layer = layer_names[0]
             if not (kind == 'all' and node.op == 'lt' and node.args[0].key() == ('attr', 0, 'y')
@@ -70,7 +70,8 @@ class Reset(AbstractTask):
                 return code, layer, node
         except NotImplementedError:
             try:   # sprites named by position: state[L][k] attributes, overlaps, metadata (bounce_box_contact_prediction.py:123-137)
-                return _abi.MOOG_COND_FIRST_EXPR, layer_names[0], _symbolic.trace_state_fixed(cond, self._with_meta)
+                # (evaluated whatever the layers hold: the expression is anchored to slots, not to a layer's first live sprite)
+                return _abi.MOOG_COND_STATE_EXPR, layer_names[0], _symbolic.trace_state_fixed(cond, self._with_meta)
             except (NotImplementedError, AttributeError, TypeError):
                 pass
             if self._with_meta:

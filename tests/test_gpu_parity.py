@@ -527,6 +527,76 @@ def test_frames_follow_steps_is_result_neutral(name, n, steps):
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
 
 
+@pytest.mark.parametrize('name,n,G,steps', [('colliding_predators_32', 768, 4, 30), ('chase_avoid_torus', 512, 2, 25),
+                                             ('functional_maze', 256, 8, 25), ('falling_balls_64', 256, 2, 12)])
+def test_sub_batches_are_result_neutral(name, n, G, steps):
+    """SubBatchedEnvironment: G asynchronous sub-batches, one stream each, queued several calls ahead without a join.  Every
+    env's states, time steps and EVERY frame of every call equal those of one BatchedEnvironment of n envs (the random
+    streams are keyed by the global env index; the parts only differ in how their launches interleave)."""
+    import torch
+    from moog import environment
+    from moog_demos import example_configs
+    g = torch.Generator(device='cpu').manual_seed(5)
+    grid = None
+    acts = []
+    ref = make_env(name, n, seed=21)
+    grid = ref._is_grid
+    for k in range(steps):
+        acts.append((torch.randint(0, 5, (n,), generator=g, dtype=torch.int32) if grid
+                     else torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1).cuda())
+    w = None
+
+    def digest(ts):
+        img = ts.observation['image']
+        ww = (torch.arange(img[0].numel(), device=img.device, dtype=torch.int64) % 8191) + 1
+        return ((img.reshape(img.shape[0], -1).to(torch.int64) * ww).sum(1).cpu().numpy(), ts.step_type.cpu().numpy(),
+                np.nan_to_num(ts.reward.cpu().numpy(), nan=-7.0), np.nan_to_num(ts.discount.cpu().numpy(), nan=-7.0))
+
+    ref.enable_cost_schedule()
+    ref.reset()
+    want = [digest(ref.step(a)) for a in acts]
+    wf, wq = download(ref)
+    ref.close()
+
+    env = environment.SubBatchedEnvironment(num_envs=n, sub_batches=G, seed=21,
+                                            layer_capacity=example_configs.capacity(name), **example_configs.load(name))
+    env.enable_cost_schedule()
+    env.reset()
+    m = n // G
+    got = [[None] * G for _ in range(steps)]
+    # sub-batch g runs `lead[g]` calls ahead of the slowest one: the streams really interleave different calls
+    lead = [(3 * g) % 5 for g in range(G)]
+    done = [0] * G
+    for k in range(steps + max(lead)):
+        for gi in range(G):
+            kk = k + lead[gi] - max(lead)
+            if 0 <= kk < steps:
+                env.step_async(gi, acts[kk][gi * m:(gi + 1) * m])
+                got[kk][gi] = digest(env.recv(gi))   # (the digest reads on the caller's stream, behind recv's wait)
+                done[gi] += 1
+    assert done == [steps] * G
+    torch.cuda.synchronize()
+    f, q = env.state_f64.cpu().numpy(), env.state_i32.cpu().numpy()
+    env.raise_faults()
+    env.close()
+    assert np.array_equal(q, wq)
+    assert np.array_equal(f, wf, equal_nan=True)
+    for k in range(steps):
+        for part in range(4):
+            cat = np.concatenate([got[k][gi][part] for gi in range(G)])
+            assert np.array_equal(cat, want[k][part]), 'call %d, output %d differs in envs %s' % (
+                k, part, np.nonzero(cat != want[k][part])[0][:8])
+    # the synchronous whole-batch form
+    env = environment.SubBatchedEnvironment(num_envs=n, sub_batches=G, seed=21,
+                                            layer_capacity=example_configs.capacity(name), **example_configs.load(name))
+    env.reset()
+    for k in range(3):
+        d = digest(env.step(acts[k]))
+        for part in range(4):
+            assert np.array_equal(d[part], want[k][part])
+    env.close()
+
+
 def test_tune_launch_keeps_a_working_mode():
     """BatchedEnvironment.tune_launch times both launch structures and keeps one; without a schedule it keeps the separate launches."""
     env = make_env('colliding_predators_32', 512, seed=2)

@@ -29,6 +29,8 @@ for a, b in log:
     if a == -1:
         cur = per_env.setdefault(int(b), [])
         cur.append([])
+    elif a < -1:
+        continue   # (outcome records of tools/dbg/contact_stats.py)
     elif cur is not None:
         cur[-1].append((int(a), int(b)))
 contacts, rounds = [], []
