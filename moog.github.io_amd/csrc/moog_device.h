@@ -314,8 +314,8 @@ __device__ inline int segments_intersect_kind(double x1, double y1, double x2, d
   double n1 = ((x4 - x3) * (y1 - y3)) - ((y4 - y3) * (x1 - x3));
   double n2 = ((x2 - x1) * (y1 - y3)) - ((y2 - y1) * (x1 - x3));
   double u1 = n1 / den, u2 = n2 / den;
-  return ((u1 > 0.0 || mpl_isclose(u1, 0.0)) && (u1 < 1.0 || mpl_isclose(u1, 1.0)) &&
-          (u2 > 0.0 || mpl_isclose(u2, 0.0)) && (u2 < 1.0 || mpl_isclose(u2, 1.0))) ? 2 : 0;
+  return (((u1 > 0.0) | mpl_isclose(u1, 0.0)) & ((u1 < 1.0) | mpl_isclose(u1, 1.0)) &
+          ((u2 > 0.0) | mpl_isclose(u2, 0.0)) & ((u2 < 1.0) | mpl_isclose(u2, 1.0))) ? 2 : 0;
 }
 __device__ inline bool segments_intersect(double x1, double y1, double x2, double y2, double x3,
                                           double y3, double x4, double y4) {
@@ -330,10 +330,8 @@ __device__ inline bool point_in_poly(const double* v, int n, double tx, double t
   for (int i = 0; i < n; ++i) {
     int j = (i + 1 == n) ? 0 : i + 1;
     double x1 = v[2 * j], y1 = v[2 * j + 1];
-    int f0 = (y0 >= ty), f1 = (y1 >= ty);
-    if (f0 != f1) {
-      if (((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == (bool)f1) inside ^= 1;
-    }
+    const int f0 = (y0 >= ty), f1 = (y1 >= ty);
+    inside ^= (int)(f0 != f1) & (int)(((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == (bool)f1);
     x0 = x1; y0 = y1;
   }
   return inside != 0;
@@ -345,23 +343,36 @@ __device__ inline bool point_in_poly(const double* v, int n, double tx, double t
 // anything, so those are compacted first and the lanes enumerate just the surviving
 // edge pairs; the "every vertex of b inside a" test needs b's box inside a's box.
 #define BB_MARGIN 1e-5
-__device__ __forceinline__ bool seg_outside_dop(double x1, double y1, double x2, double y2,
-                                                const float* d) {
-  double p1 = x1 + y1, p2 = x2 + y2, m1 = x1 - y1, m2 = x2 - y2;
-  return fmin(x1, x2) > (double)d[4] + BB_MARGIN || fmax(x1, x2) < (double)d[0] - BB_MARGIN ||
-         fmin(y1, y2) > (double)d[5] + BB_MARGIN || fmax(y1, y2) < (double)d[1] - BB_MARGIN ||
-         fmin(p1, p2) > (double)d[6] + BB_MARGIN || fmax(p1, p2) < (double)d[2] - BB_MARGIN ||
-         fmin(m1, m2) > (double)d[7] + BB_MARGIN || fmax(m1, m2) < (double)d[3] - BB_MARGIN;
-}
-
-// the same with the 8-DOP already in registers (lo = x, y, x+y, x-y minima; hi = the maxima)
+// (Straight-line code on purpose, here and in the other culls: `a || b` over double comparisons compiles to a branch per
+//  term -- exec-mask save, s_cbranch_execz, restore -- and fmin / fmax of loaded values to a canonicalising v_max first; a
+//  lone wavefront pays ~10-30 cycles per branch.  `both end points beyond the bound` is the same cull without min / max; a
+//  NaN coordinate compares false and keeps the edge, which is conservative: such an edge intersects nothing anyway.)
+// the 8-DOP in registers (lo = x, y, x+y, x-y minima; hi = the maxima)
 __device__ __forceinline__ bool seg_outside_dop_r(double x1, double y1, double x2, double y2, const float4& lo,
                                                   const float4& hi) {
-  double p1 = x1 + y1, p2 = x2 + y2, m1 = x1 - y1, m2 = x2 - y2;
-  return fmin(x1, x2) > (double)hi.x + BB_MARGIN || fmax(x1, x2) < (double)lo.x - BB_MARGIN ||
-         fmin(y1, y2) > (double)hi.y + BB_MARGIN || fmax(y1, y2) < (double)lo.y - BB_MARGIN ||
-         fmin(p1, p2) > (double)hi.z + BB_MARGIN || fmax(p1, p2) < (double)lo.z - BB_MARGIN ||
-         fmin(m1, m2) > (double)hi.w + BB_MARGIN || fmax(m1, m2) < (double)lo.w - BB_MARGIN;
+  const double p1 = x1 + y1, p2 = x2 + y2, m1 = x1 - y1, m2 = x2 - y2;
+  const double hx = (double)hi.x + BB_MARGIN, hy = (double)hi.y + BB_MARGIN, hp = (double)hi.z + BB_MARGIN, hm = (double)hi.w + BB_MARGIN;
+  const double lx = (double)lo.x - BB_MARGIN, ly = (double)lo.y - BB_MARGIN, lp = (double)lo.z - BB_MARGIN, lm = (double)lo.w - BB_MARGIN;
+  return ((x1 > hx) & (x2 > hx)) | ((x1 < lx) & (x2 < lx)) | ((y1 > hy) & (y2 > hy)) | ((y1 < ly) & (y2 < ly)) |
+         ((p1 > hp) & (p2 > hp)) | ((p1 < lp) & (p2 < lp)) | ((m1 > hm) & (m2 > hm)) | ((m1 < lm) & (m2 < lm));
+}
+__device__ __forceinline__ bool seg_outside_dop(double x1, double y1, double x2, double y2, const float* d) {
+  return seg_outside_dop_r(x1, y1, x2, y2, *reinterpret_cast<const float4*>(d), *reinterpret_cast<const float4*>(d + 4));
+}
+// a point against an 8-DOP
+__device__ __forceinline__ bool point_outside_dop(double x, double y, const float* d) {
+  const float4 lo = *reinterpret_cast<const float4*>(d), hi = *reinterpret_cast<const float4*>(d + 4);
+  const double p = x + y, m = x - y;
+  return (x > (double)hi.x + BB_MARGIN) | (x < (double)lo.x - BB_MARGIN) | (y > (double)hi.y + BB_MARGIN) | (y < (double)lo.y - BB_MARGIN) |
+         (p > (double)hi.z + BB_MARGIN) | (p < (double)lo.z - BB_MARGIN) | (m > (double)hi.w + BB_MARGIN) | (m < (double)lo.w - BB_MARGIN);
+}
+// two segments whose axis-aligned boxes are more than BB_MARGIN apart
+__device__ __forceinline__ bool segs_apart(double x11, double y11, double x12, double y12, double x21, double y21, double x22, double y22) {
+  const double M = BB_MARGIN;
+  return ((x11 > x21 + M) & (x11 > x22 + M) & (x12 > x21 + M) & (x12 > x22 + M)) |
+         ((x21 > x11 + M) & (x21 > x12 + M) & (x22 > x11 + M) & (x22 > x12 + M)) |
+         ((y11 > y21 + M) & (y11 > y22 + M) & (y12 > y21 + M) & (y12 > y22 + M)) |
+         ((y21 > y11 + M) & (y21 > y12 + M) & (y22 > y11 + M) & (y22 > y12 + M));
 }
 
 // *proper (when given): the answer is the same with a and b exchanged -- true because two non-parallel edges cross
@@ -412,8 +423,7 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
         int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
         double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
         double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
-        bool apart = fmin(x11, x12) > fmax(x21, x22) + BB_MARGIN || fmin(x21, x22) > fmax(x11, x12) + BB_MARGIN ||
-                     fmin(y11, y12) > fmax(y21, y22) + BB_MARGIN || fmin(y21, y22) > fmax(y11, y12) + BB_MARGIN;
+        const bool apart = segs_apart(x11, y11, x12, y12, x21, y21, x22, y22);
         if (!apart) {
           bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
           bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
@@ -430,16 +440,14 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
     wsync();
   }
   // path_in_path: all vertices of b inside a (possible only if box(b) within box(a))
-  if (na + 1 >= 3 && nb > 0 &&
-      !(db[0] < da[0] - BB_MARGIN || db[1] < da[1] - BB_MARGIN || db[4] > da[4] + BB_MARGIN ||
-        db[5] > da[5] + BB_MARGIN)) {
+  if ((na + 1 >= 3) & (nb > 0) &
+      !((db[0] < da[0] - BB_MARGIN) | (db[1] < da[1] - BB_MARGIN) | (db[4] > da[4] + BB_MARGIN) | (db[5] > da[5] + BB_MARGIN))) {
     bool out = false;
     if (e.lane < nb) out = !point_in_poly(va, na, vb[2 * e.lane], vb[2 * e.lane + 1]);
     if (__ballot(out) == 0ull) return true;
   }
-  if (nb + 1 >= 3 && na > 0 &&
-      !(da[0] < db[0] - BB_MARGIN || da[1] < db[1] - BB_MARGIN || da[4] > db[4] + BB_MARGIN ||
-        da[5] > db[5] + BB_MARGIN)) {
+  if ((nb + 1 >= 3) & (na > 0) &
+      !((da[0] < db[0] - BB_MARGIN) | (da[1] < db[1] - BB_MARGIN) | (da[4] > db[4] + BB_MARGIN) | (da[5] > db[5] + BB_MARGIN))) {
     bool out = false;
     if (e.lane < na) out = !point_in_poly(vb, nb, va[2 * e.lane], va[2 * e.lane + 1]);
     if (__ballot(out) == 0ull) return true;
@@ -504,8 +512,8 @@ __device__ __forceinline__ bool bbox_apart(const Env& e, int s0, int s1) {
   const float* a = &BB(s0, 0);
   const float* b = &BB(s1, 0);
   const float M = (float)BB_MARGIN;
-  return a[0] > b[4] + M || b[0] > a[4] + M || a[1] > b[5] + M || b[1] > a[5] + M ||
-         a[2] > b[6] + M || b[2] > a[6] + M || a[3] > b[7] + M || b[3] > a[7] + M;
+  return (a[0] > b[4] + M) | (b[0] > a[4] + M) | (a[1] > b[5] + M) | (b[1] > a[5] + M) |
+         (a[2] > b[6] + M) | (b[2] > a[6] + M) | (a[3] > b[7] + M) | (b[3] > a[7] + M);
 }
 
 // `np.linalg.norm(p0 - p1) > r0 + r1` (sprite.py:464-466).  The square root is only
@@ -514,8 +522,8 @@ __device__ __forceinline__ bool bbox_apart(const Env& e, int s0, int s1) {
 __device__ __forceinline__ bool circles_apart(const Env& e, int s0, int s1) {
   double dx = PX(s0) - PX(s1), dy = PY(s0) - PY(s1);
   double d2 = fma(dy, dy, dx * dx), r = MAXR(s0) + MAXR(s1), r2 = r * r;   // (sprite.py:464: a 1-D norm)
-  if (d2 > r2 * (1.0 + 1e-9) && r >= 0) return true;
-  if (d2 < r2 * (1.0 - 1e-9)) return false;
+  const bool far = (d2 > r2 * (1.0 + 1e-9)) & (r >= 0), near = d2 < r2 * (1.0 - 1e-9);
+  if (far | near) return far;
   return sqrt(d2) > r;
 }
 
@@ -616,15 +624,13 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   const int gb1 = (gl < nb) ? gl : 0, gb2 = (gl + 1 >= nb) ? 0 : gl + 1;
   const double2 a1 = *reinterpret_cast<const double2*>(va + 2 * ga1), a2 = *reinterpret_cast<const double2*>(va + 2 * ga2);
   const double2 b1 = *reinterpret_cast<const double2*>(vb + 2 * gb1), b2 = *reinterpret_cast<const double2*>(vb + 2 * gb2);
-  bool slow = na > 16 || nb > 16;
+  bool slow = (na > 16) | (nb > 16);
   // the "all vertices of one inside the other" tests would run (box within box): not here
-  slow = slow || (na + 1 >= 3 && nb > 0 &&
-                  !(bl.x < al.x - BB_MARGIN || bl.y < al.y - BB_MARGIN || bh.x > ah.x + BB_MARGIN ||
-                    bh.y > ah.y + BB_MARGIN));
-  slow = slow || (nb + 1 >= 3 && na > 0 &&
-                  !(al.x < bl.x - BB_MARGIN || al.y < bl.y - BB_MARGIN || ah.x > bh.x + BB_MARGIN ||
-                    ah.y > bh.y + BB_MARGIN));
-  slow = slow && active;
+  slow |= (na + 1 >= 3) & (nb > 0) &
+          !((bl.x < al.x - BB_MARGIN) | (bl.y < al.y - BB_MARGIN) | (bh.x > ah.x + BB_MARGIN) | (bh.y > ah.y + BB_MARGIN));
+  slow |= (nb + 1 >= 3) & (na > 0) &
+          !((al.x < bl.x - BB_MARGIN) | (al.y < bl.y - BB_MARGIN) | (ah.x > bh.x + BB_MARGIN) | (ah.y > bh.y + BB_MARGIN));
+  slow &= active;
   if (__ballot(slow) & 0xffffull) return 0;   // the first candidate takes the ordinary path anyway
   bool ka = false, kb = false;
   if (active && !slow) {
@@ -645,8 +651,7 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
     const double2 p21 = *reinterpret_cast<const double2*>(vb + 2 * j), p22 = *reinterpret_cast<const double2*>(vb + 2 * j2);
     const double x11 = p11.x, y11 = p11.y, x12 = p12.x, y12 = p12.y;
     const double x21 = p21.x, y21 = p21.y, x22 = p22.x, y22 = p22.y;
-    bool apart = fmin(x11, x12) > fmax(x21, x22) + BB_MARGIN || fmin(x21, x22) > fmax(x11, x12) + BB_MARGIN ||
-                 fmin(y11, y12) > fmax(y21, y22) + BB_MARGIN || fmin(y21, y22) > fmax(y11, y12) + BB_MARGIN;
+    const bool apart = segs_apart(x11, y11, x12, y12, x21, y21, x22, y22);
     if (!apart) {
       bool dega = mpl_isclose((x11 - x12) * (x11 - x12) + (y11 - y12) * (y11 - y12), 0);
       bool degb = mpl_isclose((x21 - x22) * (x21 - x22) + (y21 - y22) * (y21 - y22), 0);
@@ -959,7 +964,7 @@ __device__ inline void directed_collision_vectors(const Env& e, int s0, int s1, 
     cx = v0[2 * e.lane]; cy = v0[2 * e.lane + 1];
     if (disc) contained = norm2(cx - PX(s1), cy - PY(s1)) <= MAXR(s1);   // sprite.py:453-456
     else  // a point outside s1's vertex box (or non-finite) cannot be inside the polygon
-      maybe = isfinite(cx) && isfinite(cy) && !seg_outside_dop(cx, cy, cx, cy, &BB(s1, 0));
+      maybe = (int)isfinite(cx) & (int)isfinite(cy) & (int)!point_outside_dop(cx, cy, &BB(s1, 0));
   }
   // even-odd test of the few remaining points, one at a time, lanes = edges of s1
   // (matplotlib point_in_path_impl: parity of the edge toggles, order independent)
@@ -1079,7 +1084,7 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
   if (j < n0) {
     cx = v0[2 * j]; cy = v0[2 * j + 1];
     if (disc) contained = norm2(cx - PX(s1), cy - PY(s1)) <= MAXR(s1);
-    else maybe = isfinite(cx) && isfinite(cy) && !seg_outside_dop(cx, cy, cx, cy, &BB(s1, 0));
+    else maybe = (int)isfinite(cx) & (int)isfinite(cy) & (int)!point_outside_dop(cx, cy, &BB(s1, 0));
   }
   unsigned mbh = (unsigned)(__ballot(maybe) >> hb);
   while (__any(mbh != 0u)) {
@@ -1087,11 +1092,8 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
     const int l = on ? __ffs((int)mbh) - 1 : 0;
     if (on) mbh &= mbh - 1u;
     double tx = shfl_d(cx, hb + l), ty = shfl_d(cy, hb + l);
-    bool toggle = false;
-    if (on && j < n1) {
-      bool f0 = (e1y >= ty), f1 = (e2y >= ty);
-      if (f0 != f1) toggle = (((e2y - ty) * (e1x - e2x) >= (e2x - tx) * (e1y - e2y)) == f1);
-    }
+    const bool f0 = (e1y >= ty), f1 = (e2y >= ty);
+    const bool toggle = (int)on & (int)(j < n1) & (int)(f0 != f1) & (int)(((e2y - ty) * (e1x - e2x) >= (e2x - tx) * (e1y - e2y)) == f1);
     const int par = __popc((unsigned)(__ballot(toggle) >> hb)) & 1;
     if (on && j == l) contained = (par != 0);
   }
@@ -1120,15 +1122,12 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
     double pvx = (m[0] * rcx + m[1] * rcy) + m[2];
     double pvy = (m[3] * rcx + m[4] * rcy) + m[5];
     double ds0x = rcx - pvx, ds0y = rcy - pvy;
-    bool crossing = false;
-    double cav = -DINF;
-    if (on && j < n1) {
-      double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
-      double mx = e1x - pvx, my = e1y - pvy;
-      double B = (mx * ds0y - my * ds0x) / den;
-      crossing = (B >= 0) && (B <= 1);
-      if (crossing) cav = (mx * ds1y - my * ds1x) / den;
-    }
+    // (evaluated in every lane: the two quotients cost less than the branches around them)
+    const double den = (ds0x * ds1y - ds0y * ds1x) + EPS_INTERP;
+    const double mx = e1x - pvx, my = e1y - pvy;
+    const double B = (mx * ds0y - my * ds0x) / den;
+    const bool crossing = (int)on & (int)(j < n1) & (int)(B >= 0) & (int)(B <= 1);
+    const double cav = crossing ? (mx * ds1y - my * ds1x) / den : -DINF;   // cross_a only matters where the edge is crossed
     double ab = fabs(1. - cav);
     const unsigned crossm = (unsigned)(__ballot(crossing) >> hb);
     if (on) anycross = anycross || (crossm != 0u);
@@ -1144,13 +1143,12 @@ __device__ inline void directed_collision_vectors_pair(const Env& e, int sa, int
     double dfx = rcx - cpx, dfy = rcy - cpy;
     double dist = norm2(dfx, dfy);
     if (dist == DINF) dist = 0;
-    if (on) {
-      bool take;
-      if (ci < 0) { take = true; cnan = isnan(dist); }
-      else if (cnan) take = false;
-      else if (isnan(dist)) { take = true; cnan = true; }
-      else take = dist > bv;
-      if (take) { ci = l; bv = dist; e1 = best; ca = bca; bpx = cpx; bpy = cpy; bsx = dfx; bsy = dfy; }
+    {   // np.argmax over the rows so far: first maximum, NaN wins
+      const bool first = ci < 0, dn = isnan(dist);
+      const bool take = (int)on & ((int)first | ((int)!cnan & ((int)dn | (int)(dist > bv))));
+      cnan = on ? (first ? dn : (cnan | dn)) : cnan;
+      ci = take ? l : ci; bv = take ? dist : bv; e1 = take ? best : e1; ca = take ? bca : ca;
+      bpx = take ? cpx : bpx; bpy = take ? cpy : bpy; bsx = take ? dfx : bsx; bsy = take ? dfy : bsy;
     }
   }
   PROF_LAP(14);
@@ -1313,7 +1311,7 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
       double mx = vb[2 * j] - va[2 * i], my = vb[2 * j + 1] - va[2 * i + 1];
       double A = (mx * ds1y - my * ds1x) / den;
       double B = (mx * ds0y - my * ds0x) / den;
-      if ((A > 0) && (A < 1) && (B > 0) && (B < 1)) {
+      if ((A > 0) & (A < 1) & (B > 0) & (B < 1)) {
         double cpx = va[2 * i] + A * ds0x, cpy = va[2 * i + 1] + A * ds0y;
         ++cnt;
         double dA = norm2(cpx - ax, cpy - ay), dB = norm2(cpx - bxc, cpy - byc);
@@ -1759,25 +1757,22 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
   const double2 p0 = *reinterpret_cast<const double2*>(&PX(s0)), p1 = *reinterpret_cast<const double2*>(&PX(t));
   const double r0 = MAXR(s0), r1 = MAXR(t);
   const float M = (float)BB_MARGIN;
-  const bool apart = al.x > bh.x + M || bl.x > ah.x + M || al.y > bh.y + M || bl.y > ah.y + M ||
-                     al.z > bh.z + M || bl.z > ah.z + M || al.w > bh.w + M || bl.w > ah.w + M;
+  const bool apart = (al.x > bh.x + M) | (bl.x > ah.x + M) | (al.y > bh.y + M) | (bl.y > ah.y + M) |
+                     (al.z > bh.z + M) | (bl.z > ah.z + M) | (al.w > bh.w + M) | (bl.w > ah.w + M);
   // A sprite without a finite vertex (NaN box: dop_scan / dop_translate) "overlaps" everything for the reference, but a
   // collision with it changes nothing: neither polygon has a vertex inside the other or a crossing, get_collision_vectors
   // finds no contact, _make_disjoint (collisions.py:586-655) sees fewer than two crossings and returns -- at every depth
   // of the recursion.  Such pairs are left out of the candidates (falling_balls_64: 1 % of the envs hold such a ball after
   // 120 steps, and each paired it with all 63 others in every substep).
-  const bool nan_box = !(al.x == al.x) || !(bl.x == bl.x);
-  bool cand = in && s0 != t && (fl0 & fl1 & MOOG_F_ALIVE) && !apart && !nan_box;
-  if (cand) {   // circles_apart, on the values already loaded
-    const double dx = p0.x - p1.x, dy = p0.y - p1.y;
-    const double d2 = fma(dy, dy, dx * dx), r = r0 + r1, r2 = r * r;
-    bool ca;
-    if (d2 > r2 * (1.0 + 1e-9) && r >= 0) ca = true;
-    else if (d2 < r2 * (1.0 - 1e-9)) ca = false;
-    else ca = sqrt(d2) > r;
-    cand = !ca;
-  }
-  return cand;
+  const bool nan_box = !(al.x == al.x) | !(bl.x == bl.x);
+  bool cand = (int)in & (int)(s0 != t) & (int)((fl0 & fl1 & MOOG_F_ALIVE) != 0) & (int)!apart & (int)!nan_box;
+  // circles_apart, on the values already loaded (computed for every lane: cheaper than a branch around it)
+  const double dx = p0.x - p1.x, dy = p0.y - p1.y;
+  const double d2 = fma(dy, dy, dx * dx), r = r0 + r1, r2 = r * r;
+  const bool far = (d2 > r2 * (1.0 + 1e-9)) & (r >= 0), near = d2 < r2 * (1.0 - 1e-9);
+  bool ca = far;
+  if (cand & !(far | near)) ca = sqrt(d2) > r;   // (the square root only where its rounding could matter)
+  return cand & !ca;
 }
 
 // ---- mazes: maze_lib/maze.py Maze, physics/maze_walk.py RandomMazeWalk, physics/maze_physics.py MazePhysics.
