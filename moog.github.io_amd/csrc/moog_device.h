@@ -151,7 +151,10 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 // Single-wave workgroup: LDS operations of one wave execute in order, so
 // cross-lane visibility only needs the compiler/waitcnt fence.
 __device__ __forceinline__ void wsync() {
-  // LDS only ("local"): do not also drain outstanding global loads (vmcnt) here
+  // LDS only ("local"): do not also drain outstanding global loads (vmcnt) here.
+  // (Round 4 tried a wavefront-scope fence instead -- compile-time ordering only, no s_waitcnt; the LDS unit executes one
+  //  wavefront's operations in order -- and measured nothing: 652 vs 655 us; nine waits in ten are needed by the load that
+  //  follows anyway.  The waiting form stays.)
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local");
   __builtin_amdgcn_wave_barrier();
 }
@@ -1291,7 +1294,9 @@ __device__ inline void position_correction(const Env& e, double p0x, double p0y,
 
 // collisions.py:586-655.  Lanes = edge pairs; only the crossing closest to each
 // sprite's centre (lowest row-major index on ties) and the crossing count are needed.
-__device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
+// Returns false when it left the state alone (fewer than two crossings, collisions.py:618-619): the caller then knows that
+// no sprite moved (a pair that keeps overlapping that way -- two tips crossing -- comes back twice in every sub-step).
+__device__ inline bool make_disjoint(Env& e, int s0, int s1, int symmetric) {
   const double* va = VERT(s0);
   const double* vb = VERT(s1);
   int n0 = NV(s0), n1 = NV(s1);
@@ -1323,7 +1328,7 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
   // wave reductions: total count; argmin (distance, then index)
   int tot = cnt;
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-  if (tot <= 1) return;
+  if (tot <= 1) return false;
   for (int o = 32; o > 0; o >>= 1) {
     double od = shfl_d(bdA, e.lane ^ o), ox = shfl_d(bxA, e.lane ^ o), oy = shfl_d(byA, e.lane ^ o);
     int oi = __shfl_xor(biA, o);
@@ -1351,6 +1356,7 @@ __device__ inline void make_disjoint(Env& e, int s0, int s1, int symmetric) {
   } else {
     set_position(e, s0, PX(s0) + cx, PY(s0) + cy);
   }
+  return true;
 }
 
 // collisions.py:548-576: position pop-out by `perpendicular` followed by the impulse
@@ -1476,8 +1482,9 @@ __device__ inline bool collision_step(Env& e, const CollP& F, int s0, int s1, in
       if (e.dbg & 128) e.n_disj++;
 #endif
       SEC(e, SEC_DISJOINT);
-      PROF_T0; make_disjoint(e, s0, s1, symmetric); PROF_ADD(e, 2);
-      moved = true;
+      PROF_T0; const bool dm = make_disjoint(e, s0, s1, symmetric); PROF_ADD(e, 2);
+      moved = moved || dm;
+      if (!dm) return moved;   // (state untouched: the next depth would repeat this very call)
     } else if (c.status == CV_FUTURE) {
       if (mirror_noop && depth == 0) *mirror_noop = proper && mirror == CV_FUTURE;
       return moved;
@@ -2108,6 +2115,10 @@ __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int 
 // the sprites it moved are re-tested (one round) instead of re-scanning every later pair.  The ordered
 // candidate list the narrow phase consumes is written from the matrix, rows in order, bits in order:
 // exactly the list the ordered scan would build.
+// (Tried in round 4 and dropped, both measured with tools/fn_bench.py: the matrix for two different layers -- the list
+//  builder's prefix sums cost the three small scans of the headline workload more than re-scanning after a contact,
+//  20.9 k cycles per sub-step against 18.9 k; and filling the matrix with lane = row sprite walking its partners -- fewer
+//  loads, but a dependent LDS round trip per partner instead of one per 64 pairs: 27.5 k.)
 __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int a1, int K) {
   const int n = a1 - a0, total = n * n;
   const int symmetric = F.symmetric;
