@@ -218,9 +218,11 @@ enum {
   MOOG_X_HDRAW_T,    /* push o_hdraw[a] with the dtype tag kept in o_hdraw[a + 1] (0 weak, 1 float32, 2 float64): a
                       * MOOG_CELL_HEXPR cell with count_min = 1, e.g. np.copy(sprite.velocity) of a float32 velocity
                       * that is assigned back later (bounce_box_contact_prediction.py:113-119)                     */
-  MOOG_X_OVERLAPS_SLOTS /* push (sprite in slot a).overlaps_sprite(sprite in slot b), 0 when either is gone: tests
+  MOOG_X_OVERLAPS_SLOTS,/* push (sprite in slot a).overlaps_sprite(sprite in slot b), 0 when either is gone: tests
                       * between fixed sprites in an initializer's look-ahead and in state-level task functions
                       * (bounce_box_contact_prediction.py:42,125-131)                                             */
+  MOOG_X_ARG         /* push the scalar argument of the function being evaluated, a float64: the distance handed to a
+                      * DistanceForce's force_fn (distance_fn_force.py:36, MOOG_FORCE_DISTANCE_EXPR)               */
 };
 /* sprite attributes of X_ATTR / X_STORE (sprite.py:505-664 properties) */
 enum {
@@ -310,6 +312,10 @@ enum {
                                    the whole life of the environment (the reference never rewinds the list: reset()
                                    only re-infers the maze): the number consumed so far is the scalar of the
                                    MOOG_RULE_STATE_SLOT entry `symmetric` of the rule table                     */
+  ,
+  MOOG_FORCE_DISTANCE_EXPR      /* distance_fn_force.py:16-47 DistanceForce with any scalar force_fn(distance), traced by
+                                   moog/_symbolic.py trace_scalar_fn: the magnitude is the expression at dcode[i0] with the
+                                   distance as MOOG_X_ARG; `symmetric` as for the other pair forces               */
 };
 
 typedef struct {
@@ -353,7 +359,12 @@ enum {
                                       generation op, layers[] = without_overlapping */
   MOOG_RULE_TIMED,                 /* timing.py:46-59 TimedRule / DelayedRule /
                                       TemporaryRule: p0 start, p1 stop (inf allowed);
-                                      steps its children while start <= 0 < stop  */
+                                      steps its children while start <= 0 < stop.  op = 1: a callable
+                                      interval -- the start is np.random.randint(p0, p2), drawn when the
+                                      rule is reset (timing.py:47, before its children are), the stop is
+                                      start + p1; op = 2: the start is p0, the stop np.random.randint(p1,
+                                      p2).  The drawn width stop - start is the rule's second scalar
+                                      (o_rule2)                                                          */
   MOOG_RULE_CONDITIONAL,           /* conditional.py:60-63: steps its children
                                       cond(state) times                           */
   MOOG_RULE_MODIFY_SPRITES,        /* modify_sprites.py:35-52: layers[], filter,

@@ -114,6 +114,7 @@ struct Env {
   int dbg;                 // profiling aid: bit0 skip collisions, bit1 skip integrate, bit2 skip narrow phase
   int32_t* layer_hw;       // global [2 * MOOG_MAX_LAYERS] or null: per dynamic layer, the most sprites an append ever wanted
                            // room for (over all envs and calls), then the number of appends dropped because the layer was full
+  double xarg;             // the argument of the function being evaluated (MOOG_X_ARG)
   int wrote_direct;        // sticky, per lane: this call stored a colour / opacity / shape id / Portal bit (fields that may
                            // live in HBM, written with ordinary stores): the frame's hand-over needs an L2 write-back
 };
@@ -1580,6 +1581,9 @@ __device__ inline void force_single_layer(Env& e, PForce F, int a0, int a1, int 
   wsync();
 }
 
+struct XStores;
+__device__ inline double eval_expr(Env& e, int off, int s0, int s1, int* out_tag, XStores* st);
+template <bool DYN>
 __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K) {
   double dx = PX(s1) - PX(s0), dy = PY(s1) - PY(s0);
   double dist = npnorm(dx, dy);
@@ -1595,6 +1599,8 @@ __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K
       if (!F->i1 && dist < eh) mag = 0;
     } else if (F->kind == MOOG_FORCE_DISTANCE_SPRING) {
       mag = -1. * F->p0 * (dist - F->p1);
+    } else if (F->kind == MOOG_FORCE_DISTANCE_EXPR) {   // any force_fn(distance), traced (the kernels with the expression VM)
+      if constexpr (DYN) { e.xarg = dist; mag = eval_expr(e, F->i0, s0, s1, nullptr, nullptr); }
     }
     f1x = mag * ux; f1y = mag * uy;
     if (F->symmetric) { f0x = -1 * f1x; f0y = -1 * f1y; }
@@ -2298,7 +2304,7 @@ __device__ __forceinline__ void apply_physics(Env& e) {   // (forced: see the no
       for (int s0 = a0; s0 < a1; ++s0) {
         if (!ALIVE(s0)) continue;
         for (int s1 = b0; s1 < b1; ++s1)
-          if (ALIVE(s1)) force_pair_newton(e, F, s0, s1, K);
+          if (ALIVE(s1)) force_pair_newton<DYN>(e, F, s0, s1, K);
       }
     }
   }
@@ -2386,6 +2392,7 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
     if (op == MOOG_X_RULE_STATE) { v(n) = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_SLOT_CONST) { v(n) = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
     if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_ARG) { v(n) = e.xarg; XSETTAG(n, 2); ++n; continue; }   // (np.linalg.norm gives a float64)
     if constexpr (MOOG_WITH_MAZE != 0) {
       if (op == MOOG_X_HDRAW_T) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
     }
@@ -3053,6 +3060,17 @@ __device__ inline void rule_reset(Env& e, int ri) {
     e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
+  if (R->kind == MOOG_RULE_TIMED && R->op != 0) {   // a callable interval: drawn here, before the children are reset (timing.py:47)
+    const int lo = (int)(R->op == 1 ? R->p0 : R->p1), hi = (int)R->p2;
+    int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
+    if (k >= hi - lo) k = hi - lo - 1;
+    wsync();
+    if (e.lane == 0) {
+      e.f[e.L.o_rule + ri] = (R->op == 1) ? (double)(lo + k) : R->p0;
+      e.f[e.L.o_rule2 + ri] = (R->op == 1) ? R->p1 : (double)(lo + k) - R->p0;
+    }
+    wsync();
+  }
 }
 
 // task_phases.py:69-75 Phase.reset: the one-time and continual rules are reset first, `self._current_duration =
@@ -3155,7 +3173,8 @@ __device__ inline RuleGate rule_open(Env& e, int ri) {
   RuleGate g = {0, -1, 0, true};
   const double st = e.f[e.L.o_rule + ri];
   if (R->kind == MOOG_RULE_TIMED) {
-    g.n = (st <= 0 && st + (R->p1 - R->p0) > 0) ? 1 : 0;
+    const double width = R->op != 0 ? e.f[e.L.o_rule2 + ri] : (R->p1 - R->p0);
+    g.n = (st <= 0 && st + width > 0) ? 1 : 0;
     // the countdown happens after the children in the reference; they never read it
     wsync();
     if (e.lane == 0) e.f[e.L.o_rule + ri] = st - 1;

@@ -508,11 +508,19 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
       e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
   for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
+  for (int f = 0; f < prog->n_forces; ++f)   // a traced force_fn runs in the expression evaluator
+    if (prog->forces[f].kind == MOOG_FORCE_DISTANCE_EXPR) e->dynamic_rules = true;
   for (int r = 0; r < prog->n_rules; ++r)
     if (prog->rules[r].kind == MOOG_RULE_FIXATION || (prog->rules[r].kind == MOOG_RULE_PHASE && prog->rules[r].op == 1))
       e->dynamic_rules = true;
-  for (int k = 0; k < prog->n_dcode; ++k)   // assigning sprite.angle turns the path: in the kernels that carry every component
+  for (int k = 0; k < prog->n_dcode; ++k) {   // assigning sprite.angle turns the path: in the kernels that carry every component
     if (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE) e->maze_kernel = true;
+    // expressions that name sprites by slot (state-level task functions: Reset(condition / reward_fn), and the reset-time
+    // code) use opcodes only those kernels' evaluator carries (moog_device.h eval_expr_t: MOOG_WITH_MAZE)
+    const int op = prog->dcode[k].op;
+    if (op == MOOG_X_SLOT_ATTR || op == MOOG_X_HDRAW || op == MOOG_X_HDRAW_T || op == MOOG_X_STORE_VERT || op == MOOG_X_FACTOR)
+      e->maze_kernel = true;
+  }
   for (int o = 0; o < prog->n_ops; ++o) if (prog->ops[o].cell_sel != MOOG_CELL_NONE) e->maze_kernel = true;   // maze / draw / shuffle ops
   if (prog->n_hdraws > 0) e->maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
   for (int o = 0; o < prog->n_ops; ++o)

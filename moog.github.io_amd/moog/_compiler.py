@@ -860,7 +860,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             fn = force._force_fn
             pair = True
             F.symmetric = int(force._symmetric)
-            if fn.kind == 'linear':
+            if force._force_node is not None:   # any scalar function of the distance, traced
+                F.kind = _abi.MOOG_FORCE_DISTANCE_EXPR
+                F.i0 = put_code(_symbolic.emit(force._force_node, []))
+            elif fn.kind == 'linear':
                 F.kind = _abi.MOOG_FORCE_DISTANCE_LINEAR
                 F.p0, F.p1 = fn.params['zero_intercept'], fn.params['slope']
                 F.i0, F.i1 = int(fn.params['apply_distant_force']), int(fn.params['apply_nearby_force'])
@@ -1132,6 +1135,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         elif isinstance(r, rules_lib.TimedRule):
             R.kind = _abi.MOOG_RULE_TIMED
             R.p0, R.p1 = r._step_interval
+            if r._random is not None:   # a callable interval: one np.random.randint draw per reset (game_rules.TimedRule)
+                R.op, R.p0, R.p1, R.p2 = r._random
+                P.rule_state2 = 1
         elif isinstance(r, rules_lib.ConditionalRule):
             R.kind = _abi.MOOG_RULE_CONDITIONAL
             R.cond, R.p0, lay, node = r.classify()

@@ -527,6 +527,37 @@ def trace_value(fn, n_sprites):
     return _merge(paths, leaf)
 
 
+def trace_scalar_fn(fn):
+    """Expression of `fn(x)` for one scalar argument x (a DistanceForce's force_fn(distance), distance_fn_force.py:36): the
+    argument is the node ('arg',), a float64 as np.linalg.norm returns it; branches on it become selects."""
+    global _TRACER
+    paths, forced = [], []
+    while True:
+        tr = _Tracer()
+        tr.forced = list(forced)
+        prev, _TRACER = _TRACER, tr
+        try:
+            ret = fn(Sym(Node('arg')))
+        finally:
+            _TRACER = prev
+        paths.append((list(tr.trail), ret, []))
+        if len(paths) > MAX_PATHS:
+            raise Unsupported('too many execution paths in a lowered function')
+        trail = tr.trail
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            break
+        forced = [v for _, v in trail[:k]] + [False]
+
+    def leaf(p):
+        if isinstance(p[1], SymVec) or p[1] is None:
+            raise Unsupported('a lowered scalar function must return a number')
+        return lift(p[1])
+    return _merge(paths, leaf)
+
+
 def trace_modifier(fn):
     """{attr: expression} of the attribute writes of `fn(sprite)`; and whether the velocity
     was assigned as a whole (a fresh ndarray in the reference)."""
@@ -1037,6 +1068,9 @@ def emit(node, out, resolver=None):
             raise Unsupported('overlap test outside a state condition')
         out.append(dict(op=_abi.MOOG_X_OVERLAPS_FIRST, a=resolver(None, node.args[1]), b=int(node.args[0])))
         return out
+    if node.op == 'arg':   # the scalar argument of a traced one-argument function (trace_scalar_fn)
+        out.append(dict(op=_abi.MOOG_X_ARG))
+        return out
     if node.op == 'const':
         out.append(dict(op=_abi.MOOG_X_CONST, x=node.args[0], b=int(node.args[1])))
     elif node.op == 'attr':
@@ -1111,9 +1145,11 @@ def depth(code):
     for ins in code:
         op = ins['op']
         if op in (_abi.MOOG_X_CONST, _abi.MOOG_X_ATTR, _abi.MOOG_X_RULE_STATE, _abi.MOOG_X_OVERLAPS_FIRST,
-                  _abi.MOOG_X_HDRAW, _abi.MOOG_X_SLOT_ATTR, _abi.MOOG_X_FACTOR):
+                  _abi.MOOG_X_HDRAW, _abi.MOOG_X_SLOT_ATTR, _abi.MOOG_X_FACTOR, _abi.MOOG_X_RULE_STATE2,
+                  _abi.MOOG_X_SLOT_CONST, _abi.MOOG_X_ZIP_ATTR, _abi.MOOG_X_HDRAW_T, _abi.MOOG_X_OVERLAPS_SLOTS,
+                  _abi.MOOG_X_ARG):
             d += 1
-        elif op == _abi.MOOG_X_SELECT:
+        elif op in (_abi.MOOG_X_SELECT, _abi.MOOG_X_FMA):
             d -= 2
         elif op in (_abi.MOOG_X_STORE, _abi.MOOG_X_STORE_VERT):
             d -= 1

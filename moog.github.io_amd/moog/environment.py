@@ -53,6 +53,20 @@ class BatchedEnvironment(object):
             raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
         # (_compiled / _buffers: a SubBatchedEnvironment builds its parts over one lowered program and slices of one set of
         #  tensors)
+        # layer_capacity: {layer: slots} for the layers rules append to (the reference's lists are unbounded,
+        # create_sprites.py:34, change_layer.py:43; the engine's are slots), None for the default (initial count + 8), or
+        # 'auto' / {'auto': True, layer: initial slots, ...}: start from those capacities and GROW -- whenever a step leaves
+        # a layer's high-water mark (moog_engine_layer_usage) within a quarter of its capacity, the engine is re-created with
+        # that layer doubled and every env's records are moved to the new layout before the next call (_grow_layers).
+        self._auto_capacity = False
+        if layer_capacity == 'auto':
+            self._auto_capacity, layer_capacity = True, None
+        elif isinstance(layer_capacity, dict) and layer_capacity.get('auto'):
+            self._auto_capacity = True
+            layer_capacity = {k: v for k, v in layer_capacity.items() if k != 'auto'}
+        self._config_args = (state_initializer, physics, task, action_space, observers, game_rules, meta_state_initializer)
+        self._keep_sprite_factors = keep_sprite_factors
+        self._seed, self._env_index0 = int(seed), int(env_index0)
         self.compiled = _compiled if _compiled is not None else _compiler.compile_config(
             state_initializer, physics, task, action_space, observers, game_rules,
             meta_state_initializer, layer_capacity=layer_capacity,
@@ -248,6 +262,93 @@ class BatchedEnvironment(object):
         return {name: dict(capacity=int(P.layer_nslots[li]), high_water=int(hw[li]), dropped=int(dr[li]))
                 for li, name in enumerate(self.compiled.layer_names) if P.layer_dynamic[li]}
 
+    def _grow_if_close(self):
+        """layer_capacity='auto': doubles the layers whose high-water mark has come within a quarter of their capacity.
+        Nothing has been dropped at that point (a dropped append raises, as ever), so the state moves over intact."""
+        use = self.layer_usage()
+        grow = {name: max(2 * u['capacity'], u['high_water'] + 4) for name, u in use.items()
+                if u['dropped'] == 0 and 4 * u['high_water'] >= 3 * u['capacity']}
+        if grow:
+            self._grow_layers(grow)
+
+    def _grow_layers(self, new_caps):
+        """Re-creates the engine with larger capacities for the given layers ({layer: slots}) and moves every env's state
+        records to the new layout: a sprite keeps its layer and its position in the layer's list, everything that is not per
+        slot (task / rule / action state, counters, the random streams' positions) is copied as is."""
+        torch = self._torch
+        old_c, old_L = self.compiled, self.layout
+        old_P = old_c.program
+        caps = {name: int(old_P.layer_nslots[li]) for li, name in enumerate(old_c.layer_names) if old_P.layer_dynamic[li]}
+        caps.update({k: int(v) for k, v in new_caps.items()})
+        new_c = _compiler.compile_config(*self._config_args, layer_capacity=caps, keep_sprite_factors=self._keep_sprite_factors)
+        P, L = new_c.program, new_c.layout
+        assert list(new_c.layer_names) == list(old_c.layer_names)
+        # index maps: for every word of a new record, the word of the old record it comes from (-1: zero)
+        src_f = np.full(L.f64_per_env, -1, np.int64)
+        src_q = np.full(L.i32_per_env, -1, np.int64)
+        slot_map = []   # (old slot, new slot)
+        for li in range(P.n_layers):
+            o0, n_old, n0 = int(old_P.layer_slot0[li]), int(old_P.layer_nslots[li]), int(P.layer_slot0[li])
+            assert int(P.layer_nslots[li]) >= n_old
+            slot_map += [(o0 + k, n0 + k) for k in range(n_old)]
+        for name, width in (('o_pos', 2), ('o_vel', 2), ('o_angle', 1), ('o_angvel', 1), ('o_mass', 1), ('o_color', 3),
+                            ('o_inertia', 2), ('o_maxr', 1), ('o_scale', 1), ('o_aspect', 1)):
+            a, b = getattr(old_L, name), getattr(L, name)
+            if a < 0 or b < 0:
+                assert a < 0 and b < 0, name
+                continue
+            for so, sn in slot_map:
+                src_f[b + width * sn:b + width * (sn + 1)] = np.arange(a + width * so, a + width * (so + 1))
+        for so, sn in slot_map:   # vertices
+            vo, vn, cap = int(old_P.slot_voff[so]), int(P.slot_voff[sn]), int(old_P.slot_vcap[so])
+            assert int(P.slot_vcap[sn]) >= cap
+            src_f[L.o_verts + 2 * vn:L.o_verts + 2 * (vn + cap)] = np.arange(old_L.o_verts + 2 * vo, old_L.o_verts + 2 * (vo + cap))
+        n_act = 2 * max(1, int(P.n_actions))
+        for name, count in (('o_action', n_act), ('o_task', int(P.n_tasks)), ('o_rule', int(P.n_rules)),
+                            ('o_hdraw', int(P.n_hdraws)), ('o_rule2', int(P.n_rules))):
+            a, b = getattr(old_L, name), getattr(L, name)
+            if a >= 0 and b >= 0 and count > 0:
+                src_f[b:b + count] = np.arange(a, a + count)
+        for name in ('o_flags', 'o_nverts', 'o_opacity', 'o_shape', 'o_tele', 'o_valias', 'o_fmask'):
+            a, b = getattr(old_L, name), getattr(L, name)
+            if a < 0 or b < 0:
+                assert a < 0 and b < 0, name
+                continue
+            for so, sn in slot_map:
+                src_q[b + sn] = a + so
+        for name, count in (('o_step_count', 1), ('o_reset_next', 1), ('o_fault', 1), ('o_rng', 4),
+                            ('o_maze', _abi.MOOG_MAX_MAZE + _abi.MOOG_MAX_MAZE_POINTS)):
+            a, b = getattr(old_L, name), getattr(L, name)
+            if a >= 0 and b >= 0:
+                src_q[b:b + count] = np.arange(a, a + count)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            def move(old, src, dtype):
+                idx = torch.as_tensor(np.where(src < 0, 0, src), device=self.device)
+                keep = torch.as_tensor(src >= 0, device=self.device)
+                new = old.index_select(1, idx)
+                return torch.where(keep.unsqueeze(0), new, torch.zeros((), dtype=dtype, device=self.device)).contiguous()
+            new_f = move(self.state_f64, src_f, torch.float64)
+            new_q = move(self.state_i32, src_q, torch.int32)
+            # the new engine, over the new records (outputs stay where they are)
+            had_schedule, had_fused, f32 = self._perm is not None, self._fused, self._action_f32
+            self._lib.moog_engine_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+            self.compiled, self.layout = new_c, L
+            self.state_f64, self.state_i32 = new_f, new_q
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            _engine.check(self._lib, self._lib.moog_engine_create(
+                ctypes.byref(P), self.num_envs, dev_index, self._seed, self._env_index0, ctypes.byref(self._handle)))
+            view = _abi.StateView()
+            view.f64 = ctypes.cast(self.state_f64.data_ptr(), ctypes.POINTER(ctypes.c_double))
+            view.i32 = ctypes.cast(self.state_i32.data_ptr(), ctypes.POINTER(ctypes.c_int32))
+            _engine.check(self._lib, self._lib.moog_engine_load_state(self._handle, ctypes.byref(view)))
+            if f32:
+                _engine.check(self._lib, self._lib.moog_engine_set_action_dtype(self._handle, 1))
+        if had_schedule:
+            self.enable_cost_schedule(True, fused=had_fused)
+        self.capacity_growths = getattr(self, 'capacity_growths', []) + [dict(caps)]
+
     def raise_faults(self):
         """Re-raises device-side per-env faults with the reference's exception types.
 
@@ -342,6 +443,8 @@ class BatchedEnvironment(object):
         if self.check_faults == 'sync' or (self.check_faults and (injected_uniforms is not None or self._dynamic_layers)):
             self.raise_faults()
         del keep
+        if self._auto_capacity and self._dynamic_layers:
+            self._grow_if_close()
         return self._timestep()
 
     def _pack_composite(self, action):

@@ -213,13 +213,58 @@ class CreateSprites(AbstractRule):
         self._without_overlapping = tuple(without_overlapping)
 
 
+def _probe_randint(fn):
+    """Calls fn() twice with np.random.randint replaced -- once returning its low bound, once its highest value -- and
+    returns ([(low, high) of every draw], value at the low bounds, value at the high bounds)."""
+    real = np.random.randint
+    out = []
+    for pick_high in (False, True):
+        seen = []
+
+        def probe(low, high=None, size=None, dtype=int, _seen=seen, _hi=pick_high):
+            if high is None:
+                low, high = 0, low
+            if size is not None:
+                raise NotImplementedError('np.random.randint with a size in a rule\'s interval')
+            _seen.append((int(low), int(high)))
+            return int(high) - 1 if _hi else int(low)
+        np.random.randint = probe
+        try:
+            value = fn()
+        finally:
+            np.random.randint = real
+        out.append((seen, value))
+    if out[0][0] != out[1][0]:
+        raise NotImplementedError('a rule interval whose draws depend on each other')
+    return out[0][0], out[0][1], out[1][1]
+
+
 class TimedRule(AbstractRule):
     """timing.py:18-59: steps `rules` while _steps_until_start <= 0 < _steps_until_stop;
-    both count down once per call.  Callable (random) intervals are not lowered."""
+    both count down once per call.  A callable `step_interval` (timing.py:28-31,47) is drawn whenever the rule is reset;
+    the forms that are lowered take ONE np.random.randint draw: a random start with a fixed width (stop - start does not
+    depend on the draw; DelayedRule(lambda: np.random.randint(a, b), ...)) or a fixed start with a random stop
+    (TemporaryRule(lambda: np.random.randint(a, b), ...)) -- the draw is made on the device."""
 
     def __init__(self, step_interval, rules):
+        self._random = None   # (op, p0, p1, p2) of MOOG_RULE_TIMED
         if callable(step_interval):
-            raise NotImplementedError('TimedRule with a callable step_interval is not lowered')
+            draws, lo, hi = _probe_randint(step_interval)
+            lo = (float(lo[0]), float(lo[1]))
+            hi = (float(hi[0]), float(hi[1]))
+            if not draws:
+                step_interval = lo
+            elif len(draws) != 1:
+                raise NotImplementedError('a callable step_interval with more than one np.random.randint draw is not lowered')
+            else:
+                a, b = draws[0]
+                if lo[0] == a and hi[0] == b - 1 and (lo[1] - lo[0] == hi[1] - hi[0] or (np.isinf(lo[1]) and np.isinf(hi[1]))):
+                    self._random = (1, float(a), lo[1] - lo[0], float(b))          # start = randint(a, b), width fixed
+                elif lo[0] == hi[0] and lo[1] == a and hi[1] == b - 1:
+                    self._random = (2, lo[0], float(a), float(b))                  # stop = randint(a, b), start fixed
+                else:
+                    raise NotImplementedError('a callable step_interval other than (randint, randint + c) / (c, randint) is not lowered')
+                step_interval = lo
         self._step_interval = (float(step_interval[0]), float(step_interval[1]))
         if not isinstance(rules, (list, tuple)):
             rules = (rules,)
@@ -231,8 +276,15 @@ class DelayedRule(TimedRule):
 
     def __init__(self, steps_until_start, rules, duration=np.inf):
         if callable(steps_until_start) or callable(duration):
-            raise NotImplementedError('DelayedRule with callable arguments is not lowered')
-        super(DelayedRule, self).__init__((steps_until_start, steps_until_start + duration), rules)
+            start = steps_until_start if callable(steps_until_start) else (lambda: steps_until_start)
+            dur = duration if callable(duration) else (lambda: duration)
+
+            def interval():   # timing.py:84-86: the start is drawn first
+                t0 = start()
+                return (t0, t0 + dur())
+            super(DelayedRule, self).__init__(interval, rules)
+        else:
+            super(DelayedRule, self).__init__((steps_until_start, steps_until_start + duration), rules)
 
 
 class TemporaryRule(TimedRule):
@@ -240,8 +292,9 @@ class TemporaryRule(TimedRule):
 
     def __init__(self, steps_until_stop, rules):
         if callable(steps_until_stop):
-            raise NotImplementedError('TemporaryRule with a callable argument is not lowered')
-        super(TemporaryRule, self).__init__((0, steps_until_stop), rules)
+            super(TemporaryRule, self).__init__(lambda: (0, steps_until_stop()), rules)
+        else:
+            super(TemporaryRule, self).__init__((0, steps_until_stop), rules)
 
 
 class Phase(AbstractRule):

@@ -88,11 +88,21 @@ def spring_force_fn(spring_constant, equilibrium=0):
 
 
 class DistanceForce(AbstractNewtonianForce):
+    """distance_fn_force.py:16-47.  `force_fn` is linear_force_fn(...) / spring_force_fn(...) (two dedicated force kinds) or
+    any Python function of the scalar distance: that one is traced once with a symbolic argument (moog/_symbolic.py
+    trace_scalar_fn: arithmetic, comparisons, `if` on the distance, np.sqrt / sin / cos / abs / minimum / maximum ...) and
+    evaluated by the device's expression evaluator for every pair, in float64 as np.linalg.norm hands the distance over."""
+
     def __init__(self, force_fn, symmetric=False):
+        self._force_node = None
         if not isinstance(force_fn, _ForceFn):
-            raise NotImplementedError(
-                'DistanceForce needs linear_force_fn(...) or spring_force_fn(...); arbitrary '
-                'Python force functions cannot be lowered to the device')
+            if not callable(force_fn):
+                raise TypeError('DistanceForce force_fn must be callable')
+            from .. import _symbolic
+            try:
+                self._force_node = _symbolic.trace_scalar_fn(force_fn)
+            except _symbolic.Unsupported as exc:
+                raise NotImplementedError('DistanceForce force_fn is not lowered: %s' % (exc,))
         self._force_fn = force_fn
         self._symmetric = symmetric
 

@@ -23,11 +23,19 @@ class CompositeTask(AbstractTask):
 class ContactReward(AbstractTask):
     def __init__(self, reward_fn, layers_0, layers_1, condition=None,
                  reset_steps_after_contact=np.inf):
-        # contact_reward.py:44-58: a number or reward_fn(sprite_0, sprite_1); condition takes
-        # (sprite_0, sprite_1) -- the 3-argument form reads meta_state, which lives on the host
+        # contact_reward.py:44-63: a number or reward_fn(sprite_0, sprite_1); condition takes (sprite_0, sprite_1) or
+        # (sprite_0, sprite_1, meta_state).  What a lowered function may read of the meta-state is what lives on the device:
+        # the phase a PhaseSequence publishes (`meta_state['phase'] == 'name'`) and the counts Fixation rules publish
+        # (moog/_symbolic.py _SymMetaValue); anything else raises NotImplementedError when the config is compiled.
         self._reward = reward_fn
-        if condition is not None and len(inspect.signature(condition).parameters) != 2:
-            raise NotImplementedError('ContactReward condition(s0, s1, meta_state) is not lowered')
+        if condition is not None:
+            n_args = len(inspect.signature(condition).parameters)
+            if n_args == 3:
+                from .. import _symbolic
+                cond3 = condition
+                condition = lambda s0, s1: cond3(s0, s1, _symbolic._SymMeta())   # noqa: E731
+            elif n_args != 2:
+                raise ValueError('ContactReward condition must take (sprite_0, sprite_1) or (sprite_0, sprite_1, meta_state)')
         self._condition = condition
         if not isinstance(layers_0, (list, tuple)):
             layers_0 = [layers_0]

@@ -332,9 +332,19 @@ def bookkeeping(env):
         return out
     rc_flat = walk(list(env.game_rules), [])
 
-    def walk2(rules, out):   # second scalar per rule: the duration a Phase drew when it was reset (task_phases.py:72)
+    def second_of(r):
+        # the duration a Phase drew when it was reset (task_phases.py:72); the width stop - start of a TimedRule (timing.py:47:
+        # both count down together, so the difference is what stays fixed between resets)
+        if hasattr(r, '_current_duration'):
+            return float(r._current_duration)
+        if hasattr(r, '_steps_until_stop') and hasattr(r, '_steps_until_start'):
+            a, b = float(r._steps_until_start), float(r._steps_until_stop)
+            return np.inf if np.isinf(b) and not np.isinf(a) else b - a
+        return np.nan
+
+    def walk2(rules, out):   # second scalar per rule
         for r in rules:
-            out.append(float(getattr(r, '_current_duration', np.nan)))
+            out.append(second_of(r))
             kids = getattr(r, '_phases', None)
             if kids is None and hasattr(r, '_one_time_rules'):
                 kids = list(r._one_time_rules) + list(r._continual_rules)
@@ -847,6 +857,8 @@ def main():
         ('aa_zoo_l3', 30, {}, (0,)),
         ('aa_zoo_l4', 30, {}, (0,)),
         ('aa_zoo_l5', 30, {}, (0,)),
+        ('callables_zoo', 70, {}, (0, 1)),      # round 4: traced force_fn, callable rule intervals, ContactReward with meta_state
+        ('callables_zoo_l1', 50, {}, (0,)),
     ]
     for name, n_calls, caps, seeds in plan:
         for seed in seeds:

@@ -18,7 +18,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
         ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1), ('phase_zoo_l1', 0), ('phase_zoo_l1', 1), ('match_to_sample_l3', 0), ('match_to_sample_l3', 1), ('match_to_sample_l4', 0), ('match_to_sample_l2', 0), ('predators_arena_l2', 0), ('predators_arena_l2', 1), ('predators_arena_l1', 0), ('predators_arena_l3', 0), ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction_l1', 0), ('red_green_l1', 0), ('red_green', 0), ('red_green_l3', 0), ('lookahead_zoo', 0), ('lookahead_zoo', 1), ('lookahead_zoo_l1', 0), ('lookahead_zoo_l1', 1), ('tracing_zoo', 0), ('tracing_zoo', 1), ('tracing_zoo_l1', 0), ('tracing_zoo_l1', 1), ('combo_zoo', 0), ('combo_zoo', 1),
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
-        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
+        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('callables_zoo', 0), ('callables_zoo', 1), ('callables_zoo_l1', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
         ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),
@@ -109,7 +109,10 @@ def test_free_running_vs_reference(name, seed):
         assert d['ints_ok'], (t, d)
         assert d['float'] <= TOL, (t, d)
         assert int(out.step_type[0]) == int(fx['step_type'][t])
-        assert helpers.same_or_nan(float(out.reward[0]), fx['reward'][t])
+        # (a reward that is a function of the float state -- Reset(reward_fn=lambda state: 10 * x + 1), callables_zoo --
+        #  drifts with it: inside the same budget as the state; every other reward is exact)
+        r, want = float(out.reward[0]), float(fx['reward'][t])
+        assert helpers.same_or_nan(r, want) or abs(r - want) <= TOL * max(1.0, abs(want)), (t, r, want)
     assert np.array_equal(out.observation['image'][0].cpu().numpy(), fx['image'][T - 1])
 
 
@@ -595,6 +598,43 @@ def test_sub_batches_are_result_neutral(name, n, G, steps):
         for part in range(4):
             assert np.array_equal(d[part], want[k][part])
     env.close()
+
+
+def test_layer_capacity_auto_grows_transparently():
+    """layer_capacity='auto' (the reference's layers are unbounded Python lists, create_sprites.py:34, change_layer.py:43):
+    first_person_predators_prey started from the fixtures' capacities -- which a 256-env random-policy batch overflows
+    within ~60 calls (LAYER_FULL with fixed capacities) -- grows its layers when their high-water mark comes close, and every
+    call's time steps and frames equal those of an engine that had roomy layers from the start."""
+    import torch
+    from moog import environment
+    from moog_demos import example_configs
+    name, n, steps = 'first_person_predators_prey', 256, 90
+    cfg = example_configs.load(name)
+    small = dict(example_configs.capacity(name))
+    big = environment.BatchedEnvironment(num_envs=n, seed=5, layer_capacity={'prey': 32, 'predators': 96}, **cfg)
+    auto = environment.BatchedEnvironment(num_envs=n, seed=5, layer_capacity=dict(small, auto=True), **cfg)
+    big.reset()
+    auto.reset()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for k in range(steps):
+        a = torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1
+        x, y = big.step(a), auto.step(a)
+        assert torch.equal(x.step_type, y.step_type), k
+        assert torch.equal(torch.nan_to_num(x.reward, nan=-7.), torch.nan_to_num(y.reward, nan=-7.)), k
+        assert torch.equal(x.observation['image'], y.observation['image']), 'frames differ at call %d' % k
+    grown = getattr(auto, 'capacity_growths', [])
+    assert grown, 'the batch never came close to the fixtures\' capacities: the test does not exercise the growth'
+    use = auto.layer_usage()
+    assert all(u['dropped'] == 0 for u in use.values()), use
+    # the same sprites, layer by layer (slots differ: the layers are wider)
+    for env_i in (0, n // 2, n - 1):
+        sa, sb = big.sprites(env_i), auto.sprites(env_i)
+        for layer in sa:
+            assert len(sa[layer]) == len(sb[layer]), layer
+            for p, q in zip(sa[layer], sb[layer]):
+                assert p['x'] == q['x'] and p['y'] == q['y'] and np.array_equal(p['vertices'], q['vertices'])
+    big.close()
+    auto.close()
 
 
 def test_tune_launch_keeps_a_working_mode():
@@ -1230,6 +1270,53 @@ def test_falling_balls_64_pile_up():
         img = out.observation['image'].cpu().numpy()
         assert np.array_equal(img, o.render())
         env.close()
+
+
+def test_falling_balls_64_pile_at_rest():
+    """BASELINE config 5 where it is most expensive (11 ms per step in round 3): the pile AT REST, calls 100-130 of an
+    episode -- hundreds of path tests and contact searches per env and call, recursion depth 2, balls stacked on balls.
+    2048 envs run alone to call 100; then 24 calls in lock step with the oracle (integer records exact, floats <= 1e-9,
+    rewards / step types exact, final frames bit-exact), and from the same state a free-running window of 6 calls, no
+    state copied in between (integers exact, floats inside BASELINE.json's 1e-5)."""
+    n, pre, steps, free = 2048, 100, 24, 6
+    env = make_env('falling_balls_64', n, seed=37, env_index0=0)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=37, env_index0=0)
+    env.reset()
+    rs = np.random.RandomState(13)
+    for _ in range(pre):
+        env.step(rs.randint(0, 5, size=n))
+    f0, q0 = download(env)
+    L = env.layout
+    y = f0[:, L.o_pos + 1:L.o_pos + 2 * L.S:2][:, 4:]
+    assert (y < 0.3).mean() > 0.1, 'no pile on the floor'
+    acts = [rs.randint(0, 5, size=n) for _ in range(steps)]
+    # free-running window first (then the lock-step run restarts from the saved state)
+    o.f64[:], o.i32[:] = f0, q0
+    worst = 0.0
+    for k in range(free):
+        out = env.step(acts[k])
+        o.step(acts[k], render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'free-running: int state differs at call %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.where((f == o.f64) | (np.isnan(f) & np.isnan(o.f64)), 0, np.abs(f - o.f64))
+        worst = max(worst, float(np.max(err)))
+        assert worst <= TOL, (k, worst)
+    upload(env, f0, q0)
+    o.f64[:], o.i32[:] = f0, q0
+    for k in range(steps):
+        out = env.step(acts[k])
+        o.step(acts[k], render=False)
+        f, q = download(env)
+        assert np.array_equal(q, o.i32), 'int state differs at call %d' % k
+        with np.errstate(invalid='ignore'):
+            err = np.where((f == o.f64) | (np.isnan(f) & np.isnan(o.f64)), 0, np.abs(f - o.f64))
+        assert float(np.max(err)) <= 1e-9, (k, float(np.max(err)))
+        assert np.array_equal(out.step_type.cpu().numpy(), o.step_type)
+        assert helpers.same_or_nan(out.reward.cpu().numpy(), o.reward)
+        o.f64[:], o.i32[:] = f, q
+    assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
+    env.close()
 
 
 def test_make_disjoint_path_is_taken():

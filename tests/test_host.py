@@ -106,11 +106,18 @@ def test_program_contents():
 
 
 def test_unsupported_components_raise():
-    from moog import tasks, physics
-    with pytest.raises(NotImplementedError):   # meta_state lives on the host
-        tasks.ContactReward(1., 'a', 'b', condition=lambda a, b, meta_state: True)
+    from moog import game_rules, observers, tasks, physics
+    # lowered since round 4 (tests/golden/callables_zoo*.npz pin them against the reference)
+    tasks.ContactReward(1., 'a', 'b', condition=lambda a, b, meta_state: meta_state['phase'] == 'go')
+    assert physics.DistanceForce(lambda d: 0.1 * d if d < 1 else 0.)._force_node is not None
+    assert game_rules.DelayedRule(lambda: np.random.randint(2, 5), ())._random == (1, 2.0, np.inf, 5.0)
+    # still refused, with a message: what the tracer cannot follow
     with pytest.raises(NotImplementedError):
-        physics.DistanceForce(lambda d: d)
+        physics.DistanceForce(lambda d: float(d) ** 2)            # float() of a traced value
+    with pytest.raises(NotImplementedError):
+        game_rules.TimedRule(lambda: (np.random.randint(0, 3), np.random.randint(5, 9)), ())   # two draws
+    with pytest.raises(NotImplementedError):
+        observers.PILRenderer(image_size=(8, 8), color_to_rgb=lambda c: c)   # the rasteriser has no expression evaluator
     with pytest.raises(NotImplementedError):
         tasks.Reset(condition=lambda state: len(state['x']) > 3).classify(['x', 'y'])
 

@@ -33,17 +33,18 @@ def make(n):
 
 
 if mode == 'capture':
-    n = 4096
+    n = int(os.environ.get('CAPTURE_ENVS', 4096))
     env = make(n)
     env.reset()
     env.set_debug(128, 0)
     F, Q, A, C = [], [], [], []
-    for k in range(62):
+    AT = tuple(int(x) for x in os.environ.get('CAPTURE_AT', '25,40,50,60').split(','))
+    for k in range(max(AT) + 2):
         a = env.random_action()
-        if k in (25, 40, 50, 60):
+        if k in AT:
             f0, q0 = env.state_f64.clone(), env.state_i32.clone()
         ts = env.step(a)
-        if k in (25, 40, 50, 60):
+        if k in AT:
             c = ts.discount.clone()
             c[ts.step_type == 0] = 0
             top = torch.argsort(-c)[:TOP] if 'RANDOM_SAMPLE' not in os.environ else torch.randperm(n, device=c.device)[:TOP]
