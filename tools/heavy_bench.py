@@ -56,7 +56,7 @@ if mode == 'capture':
     print('saved', path('gpurun_out'))
     sys.exit(0)
 
-src = path('tools/ubench') if os.path.exists(path('tools/ubench')) else path('gpurun_out')
+src = next(path(d) for d in ('tools/ubench', 'tools/ubench/build', 'gpurun_out') if os.path.exists(path(d)))   # (big captures: build/, untracked)
 d = np.load(src)
 m = d['f64'].shape[0]
 sections = '--sections' in sys.argv

@@ -1,0 +1,128 @@
+"""Assembles profiles/r04_* from one `bash tools/r04_collect.sh` run (gpurun_out/r04/)."""
+import json, os, re
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+o = os.path.join(R, 'gpurun_out', 'r04')
+P = os.path.join(R, 'profiles')
+rd = lambda n: ''.join(l for l in open(os.path.join(o, n)) if 'amdgpu.ids' not in l)
+lines, runs = rd('bench.txt').splitlines(), {}
+for i, l in enumerate(lines):
+    if l.startswith('==') and i + 1 < len(lines):
+        try:
+            runs[l] = json.loads(lines[i + 1])
+        except ValueError:
+            pass
+A0, A, SB, F5 = (runs[k] for k in list(runs)[:4])
+prof = rd('prof_summary.txt')
+num = lambda kern, ctr: float(re.search(re.escape(kern) + r'.*?' + ctr + r'\s+\d+\s+([\d.]+)', prof).group(1))
+RK, SK = 'moog_raster_kernel<1, false>(RArgs)', 'moog_step_kernel<false, 3, 0>(KArgs)'
+fk, wk = num(RK, 'FETCH_SIZE'), num(RK, 'WRITE_SIZE')
+sfk, swk = num(SK, 'FETCH_SIZE'), num(SK, 'WRITE_SIZE')
+rv, rs, rl = (num(RK, c) for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'))
+sv, ss, sl = (num(SK, c) for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS'))
+sbc, sla = num(SK, 'SQ_LDS_BANK_CONFLICT'), num(SK, 'SQ_LDS_IDX_ACTIVE')
+rbc, rla = num(RK, 'SQ_LDS_BANK_CONFLICT'), num(RK, 'SQ_LDS_IDX_ACTIVE')
+issue = lambda *x: sum(x) / 1024 * 1.27e-3
+ku = lambda d: (d['kernels_avg_us']['step'], d['kernels_avg_us']['raster'])
+hdr = '''# r04 current (end of round 4) -- MI355X (gpurun box: gfx950, 256 CUs), one gpurun call (tools/r04_collect.sh) on the final build
+# Part 1: un-profiled bench lines (python bench.py = --steps 200 --warmup 20).  The default line is what the driver runs:
+#   %.2f M env-steps/s, %.4f ms per step (round 3: 4.70 M, 0.872 ms); step kernel %.0f us (754), raster %.0f us (95), HIP events in the
+#   timed region.  The launch-structure tuning (BatchedEnvironment.tune_launch) now keeps the SEPARATE launches: with a 655 us step
+#   kernel the frames-follow-steps grid no longer pays.  --sub-batches 2 (two asynchronous halves, one stream each,
+#   SubBatchedEnvironment) is the additional line VERDICT r03 item 2 asked for: %.2f M.  BASELINE config 5: %.3f M (round 3: 0.70 M).
+# Part 2: bash tools/prof.sh: rocprofv3 --kernel-trace --stats on 'python3 bench.py --no-cpu-baseline --no-extras --steps 60 --warmup 5'
+#   and separate --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | lanes / LDS conflicts) on '--steps 10 --warmup 2' (the trace includes
+#   the launch-structure tuning's fused calls: moog_raster_follow / gate kernels; the PMC passes run with separate launches).
+# FETCH_SIZE / WRITE_SIZE are KB per launch; gfx950 correction (2 x FETCH_SIZE for wide coalesced reads):
+#   raster traffic = 2 * %.1f KB + %.1f KB = %.1f MB / launch vs 59.3 MB algorithmic (the default raster kernel is round 3's code);
+#   step traffic = 2 * %.1f KB + %.1f KB = %.1f MB / launch (round 3: 205 MB) vs 20.1 MB algorithmic (S * 153 + 16 B per env).
+# issue: raster (%.1f M VALU + %.1f M SALU + %.1f M LDS) / 1024 SIMDs x 1.27 ns = %.0f us of a %.0f us kernel;
+#        step (%.1f M + %.1f M + %.1f M) / 1024 x 1.27 ns = %.0f us of a %.0f us kernel (round 3: 181.6 M + 90.6 M + 20.8 M, 363 of 754 us):
+#        the kernel is still as long as its slowest envs (r04_step_tail.txt) -- those got shorter, not the instruction total.
+# LDS bank conflicts: step %.1f %% of LDS-active cycles (%.1f M / %.1f M; round 3: 32.5 %%), raster %.1f %% (unchanged code).
+
+''' % (A0['value'] / 1e6, A0['ms_per_step'], ku(A0)[0], ku(A0)[1], SB['value'] / 1e6, F5['value'] / 1e6,
+       fk, wk, (2 * fk + wk) * 1024 / 1e6, sfk, swk, (2 * sfk + swk) * 1024 / 1e6,
+       rv / 1e6, rs / 1e6, rl / 1e6, issue(rv, rs, rl), ku(A)[1], sv / 1e6, ss / 1e6, sl / 1e6, issue(sv, ss, sl), ku(A)[0],
+       100 * sbc / sla, sbc / 1e6, sla / 1e6, 100 * rbc / rla)
+open(os.path.join(P, 'r04_current.txt'), 'w').write(hdr + rd('bench.txt') + '\n' + prof)
+tj = os.path.join(P, 'raster_traffic.json')
+d = json.load(open(tj))
+d['_comment'] = d['_comment'].replace('r03_current', 'r04_current')
+d['colliding_predators_32'].update(fetch_kb=fk, write_kb=wk, traffic_bytes=int((2 * fk + wk) * 1024),
+                                   source='profiles/r04_current.txt (FETCH_SIZE x 2 + WRITE_SIZE, 243 launches, end-of-round-4 build)')
+json.dump(d, open(tj, 'w'), indent=1)
+open(os.path.join(P, 'r04_bench_configs.txt'), 'w').write('''# r04: python tools/bench_configs.py on MI355X (final build of round 4): every lowered config at a production batch, separate launches:
+# reset, 5 warm-up calls, then 30 / 60 / 10 timed calls with random actions; step / raster / reset = HIP-event kernel times of those calls.
+# (early in a lock-step episode -- not the stationary mix of bench.py: the headline's 4.1 M here is 5.4 M there.)
+# Against profiles/r03_bench_configs.txt: the collision path's work of this round (DESIGN 3.1) shows in every config that collides;
+# the configs whose resets play physics forward (bounce_box_contact_prediction, red_green) did NOT get faster -- their kernels are the
+# variants that carry every component, whose rarely used paths stay calls (DESIGN 3.1 "what stays out of line") -- VERDICT r03 item 4
+# (a reset pool filled by a background kernel) is designed in DESIGN 9 and not built.
+''' + rd('bench_configs.txt'))
+open(os.path.join(P, 'r04_bench_ranks.txt'), 'w').write('''# r04: bash tools/bench_ranks.sh on a 1-GPU MI355X box: bench.py's multi-rank path (shard offsets, barrier, MAX over ranks, one JSON
+# line from rank 0) with two ranks sharing cuda:0 over gloo, for the headline config and BASELINE config 5; the device count the
+# launcher parent derives from sysfs without touching HIP; one rank with the RCCL group initialised.  (Two ranks of 4096 envs on one
+# GPU: 7.0 M env-steps/s = what ONE rank delivers at 8192 envs, 7.2 M in r04_sweeps.txt -- the gain is the batch size, not the ranks.)
+''' + rd('bench_ranks.txt'))
+open(os.path.join(P, 'r04_sweeps.txt'), 'w').write('''# r04: python tools/r04_exp.py (bench.py --no-fused --no-cpu-baseline --no-extras --steps 100 --warmup 10 under the named settings), final
+# build, one MI355X.  step / raster = HIP-event kernel averages inside the timed region.
+# n*: batch size per GPU (VERDICT r03 item 2 asked for this sweep).  The step kernel lasts as long as its slowest env, whatever the
+#   batch (516 us at 1024 envs -- a quarter of the machine -- 656 us at 4096): throughput grows with the batch because the tail is paid once
+#   per launch (8.3 M env-steps/s at 16384 envs).  The "6.43 M with two ranks on one GPU" of round 3 was this effect (8192 envs on the GPU).
+# sub*: the batch stepped as G asynchronous sub-batches, one HIP stream each (SubBatchedEnvironment.step_async; GPU_MAX_HW_QUEUES raised
+#   so that every stream has a hardware queue: with the default four, G = 4 ran two sub-batches at a time, 2.9 M).  G = 2: +5 %
+#   (5.65 vs 5.40 M at 4096 envs; 7.79 vs 7.22 M at 8192).  G >= 4: slower than the whole batch -- 4096 one-wave envs fill the
+#   machine 1.33 times over already, so sub-batches add no parallelism, and each sub-batch pays its own tail and its own launches.
+# wps4 / wps2: the register-allocation variants (128 VGPRs with scratch / 206 VGPRs without spills, two waves per SIMD): both slower.
+# prio: s_setprio by launch rank (heaviest quarter of the batch at priority 3, ...): no effect -- the heavy wavefront is not losing
+#   issue slots to its neighbours, it is waiting for its own dependent chain (r04_latency.txt, r04_step_sections.txt).
+''' + rd('sweeps.txt'))
+open(os.path.join(P, 'r04_step_tail.txt'), 'w').write('''# r04: python tools/step_tail.py <config> <envs> <calls> -- per-env cycle counts of moog_step_kernel inside a full launch (s_memtime at
+# entry / exit of each wavefront), every 10th call.  Part 1: colliding_predators_32, 4096 envs; part 2: falling_balls_64, 8192 envs,
+# calls 99 - 129 (the pile at rest, then the reset wave).  Round 3 (r03_step_tail.txt): colliding_predators mean 0.70 - 0.82 M, max
+# 1.9 - 2.6 M, fit 0.57 - 0.64 M + 23 - 28 k x path tests; falling_balls at rest mean 1.8 - 2.5 M, max 4.8 - 9.1 M, reset wave 6.1 M / 19.1 M.
+# (the third number of a "slowest" entry packs make_disjoint calls x 100000 + contact searches)
+''' + rd('step_tail.txt'))
+open(os.path.join(P, 'r04_step_sections.txt'), 'w').write('''# r04: where the step kernel's slowest envs spend their cycles -- the "instruction-level evidence" VERDICT r03 item 1 asked for.
+# Neither the thread-trace decoder (rocprofv3 --att: no librocprof-trace-decoder in this image) nor PC sampling (rocprofv3
+# --pc-sampling-*: "not supported on any of the agents" on this pool) is available, so the evidence is built from four tools of this repo:
+#  1. tools/heavy_bench.py: the pre-step records and actions of the 256 heaviest envs of four calls, captured once and REPLAYED -- tiled over
+#     256 envs (one wavefront per CU: the env's own dependent chain) and over 3072 (three waves per SIMD).  Identical work every run.
+#  2. section sampling (-DMOOG_WATCH builds, moog_engine_read_watch): a second wavefront beside every env's samples, every ~256 cycles,
+#     the section id the stepping wavefront last announced with one LDS store -- no clock reads in the stepped wavefront: the replay
+#     takes 0.980 M cycles with the watcher against 0.971 M without (the clock-read profile of rounds 1 - 3 cost 25 - 40 %).
+#  3. tools/fn_bench.py (r04_fn_bench.txt): single device functions on those records, cycles per call for a lone wavefront.
+#  4. tools/ubench/latency.hip (r04_latency.txt): what one dependent operation costs a lone wavefront on gfx950.
+# Reading: a heavy env of the headline workload takes 0.97 M cycles alone on its SIMD and 1.26 M beside two others (round 3: 1.20 M /
+# 1.55 M): the kernel is bound by the env's own dependent chain -- 166 k instructions per env-step at ~6 cycles each plus ~30 per taken
+# branch and ~65 per dependent LDS round trip -- not by issue arbitration (s_setprio changes nothing, r04_sweeps.txt).
+# falling_balls_64's replay prints nan cycle means: some of its captured envs reset in the replayed call (their counters are not
+# written); the watcher's shares are over the stepping envs.
+''' + rd('sections.txt'))
+open(os.path.join(P, 'r04_fn_bench.txt'), 'w').write('''# r04: python tools/fn_bench.py -- single device functions of the step path on the captured heavy envs (and on a random sample of envs),
+# cycles per call for a lone wavefront (256 envs, one per CU); libfn_bench_r03 = the same harness compiled against round 3's
+# csrc (git show 15b2f65:...), libfn_bench = this round's.  "substep: ..." lines run apply_physics with parts switched off
+# (forces only / + integrate / + broad phase and candidate lists); the narrow phase and the contact search cannot be separated that way
+# (without contact resolution the overlapping pairs stay overlapping), their split is in r04_step_sections.txt.
+#   get_collision_vectors 7.7 -> 6.6 k, path test 4.7 -> 3.5 k, narrow batch 3.8 -> 2.9 k: straight-line culls (no short-circuit
+#   branches, no fmin / fmax canonicalisation); integrate_all 11.0 -> 6.5 k: lane-per-sprite vertex walk; force loop 3.9 -> 2.1 k:
+#   flattened force list; one whole sub-step of a heavy env 123 -> 91 k, of a typical env 59 -> 47 k.
+# Tried and dropped (measured the same way): broad-phase matrix filled with lane = row sprite walking its partners 18.9 -> 27.5 k per
+#   sub-step; the matrix for two different layers 18.9 -> 20.9 k; the containment test of the contact search as a per-lane loop over
+#   the partner's edges 6.65 -> 7.3 k per search; hole-skipping batch formation for mirrored clean rejects 735 -> 765 us per launch.
+''' + rd('fn_bench.txt'))
+open(os.path.join(P, 'r04_latency.txt'), 'w').write('''# r04: tools/ubench/latency.hip -- s_memtime cycles per operation of dependent chains run by ONE wavefront on an otherwise empty
+# MI355X CU (gfx950, ~2.3 GHz shader clock).  "unrolled" lines amortise the loop's own taken branch (~34 cycles: compare "dependent
+# v_fma_f64" 40.1 with "... unrolled x16" 5.9).  What the step kernel's chain is made of: ~6 cycles per VALU or SALU instruction even
+# when independent, ~24 per not-taken branch with its compare, ~30 per taken branch, 60 - 72 per dependent LDS read / ds_bpermute,
+# 60 (scalar cache) - 180 (L2) per dependent scalar load, ~100 per fp64 division, ~150 per fp64 square root, ~750 - 1000 per scratch
+# store + load (what an out-of-line function costs per access to the env descriptor, DESIGN 3.1).
+''' + rd('latency.txt'))
+open(os.path.join(P, 'r04_heavy_pmc.txt'), 'w').write('''# r04: bash tools/r04_heavy_pmc.sh -- rocprofv3 --pmc passes over the replay of the 256 heavy envs alone (one wavefront per CU):
+# the instruction mix of ONE heavy env-step = counter / 256.  Round 3's kernel on the same replay: 97.2 k VALU + 48.7 k SALU + 10.0 k LDS
+# + 9.4 k branches = 166 k instructions in 1.20 M cycles; this round's (below): 85.1 k + 36.8 k + 6.8 k + 5.7 k = 135 k in 0.99 M cycles.
+# (SQ_WAVE_CYCLES / SQ_ACTIVE_* count in units of 4 cycles.)
+''' + rd('heavy_pmc.txt'))
+open(os.path.join(P, 'r04_runtime_benchmark_phases.txt'), 'w').write('''# r04: moog_demos/runtime_benchmark.py (the counterpart of the reference's tests/runtime_benchmark.py) on MI355X, final build
+''' + rd('runtime_benchmark.txt'))
+print(hdr)
