@@ -187,15 +187,25 @@ def visible_gpus():
     except (OSError, ValueError):
         n = None
     if n is not None and n > 0:
+        opaque = False   # a *_VISIBLE_DEVICES list of UUIDs (GPU-xxxx): sysfs cannot tell which nodes it names
         for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
             v = os.environ.get(var)
-            if v is not None and all(t.strip().isdigit() for t in v.split(',') if t.strip()):
-                n = min(n, len([t for t in v.split(',') if t.strip()]))
-        return n
+            if v is None:
+                continue
+            toks = [t.strip() for t in v.split(',') if t.strip()]
+            if all(t.isdigit() for t in toks):
+                n = min(n, len(toks))
+            else:
+                n = min(n, len(toks))
+                opaque = True
+        if not opaque:
+            return n
+        # (sysfs also lists GPUs this container may not open: with an opaque filter ask a child what the runtime really sees)
     try:   # (a child: whatever it initialises dies with it)
         out = subprocess.check_output([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
                                       stderr=subprocess.DEVNULL, timeout=300)
-        return int(out.decode().strip().splitlines()[-1])
+        seen = int(out.decode().strip().splitlines()[-1])
+        return seen if not n else min(n, seen)
     except (subprocess.SubprocessError, ValueError, IndexError):
         return 0
 

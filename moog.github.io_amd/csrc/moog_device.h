@@ -1600,7 +1600,9 @@ __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K
     } else if (F->kind == MOOG_FORCE_DISTANCE_SPRING) {
       mag = -1. * F->p0 * (dist - F->p1);
     } else if (F->kind == MOOG_FORCE_DISTANCE_EXPR) {   // any force_fn(distance), traced (the kernels with the expression VM)
+#ifndef MOOG_NO_DISTANCE_EXPR   // (A/B builds)
       if constexpr (DYN) { e.xarg = dist; mag = eval_expr(e, F->i0, s0, s1, nullptr, nullptr); }
+#endif
     }
     f1x = mag * ux; f1y = mag * uy;
     if (F->symmetric) { f0x = -1 * f1x; f0y = -1 * f1y; }
@@ -2202,11 +2204,12 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
     // (when the list reaches that far; `skipbits` keeps it out of later lists); a struck entry counts as rejected.
     auto mark_mirror = [&](int s0k, int tk) {   // (s0k, tk): wave uniform, tk > s0k
       const int j = tk - a0, i = s0k - a0;
-      if (e.lane == j) {
-        skipbits |= 1ull << i;
-        // (row j > the current row >= srow: `bits` is lane j's whole row as listed)
-        if (j < rows_end && ((bits >> i) & 1ull)) e.cand[(inc - cnt) + __popcll(bits & ((1ull << i) - 1ull))] = (uint16_t)CAND_SKIP;
-      }
+      if (e.lane == j) skipbits |= 1ull << i;
+      // struck from the list in hand, wherever it is: the lanes look at the (at most CAND_CAP = 128) entries together -- keeping
+      // the list builder's per-row offsets alive for this instead cost the kernels that carry the expression VM 200 VGPR spills
+      const int key = (tk << 8) | s0k;
+      for (int k = e.lane; k < count; k += 64)
+        if ((int)e.cand[k] == key) e.cand[k] = (uint16_t)CAND_SKIP;
     };
     for (int c = 0; c < count; ++c) {
       bool known_hit = false, proper_hit = false;

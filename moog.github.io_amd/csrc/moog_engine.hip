@@ -87,6 +87,7 @@ struct moog_engine {
   int perm_cur = 0;
   int32_t fused_epoch = 0;
   int fused_resident = 0, fused_groups = 0;
+  bool fused_ready = false;   // every allocation / stream / event of the fused mode exists
   hipStream_t fused_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_frames = nullptr;
   uint32_t* fused_abort = nullptr;   // pinned host word: number of the call whose frames gave up waiting (0: none)
@@ -582,12 +583,12 @@ static void drain(TimedKernel& t) {
 int moog_engine_destroy(moog_engine_t* e) {
   if (!e) return MOOG_OK;
   for (int k = 0; k < MOOG_K_COUNT; ++k) drain(e->timed[k]);
-  if (e->fused_done) {
-    hipStreamSynchronize(e->fused_stream);
-    hipEventDestroy(e->ev_fork); hipEventDestroy(e->ev_frames);
-    hipStreamDestroy(e->fused_stream);
-    hipFree(e->fused_done); hipFree(e->fused_ticket); hipFree(e->perm_buf[1]);
-  }
+  if (e->fused_stream) { hipStreamSynchronize(e->fused_stream); hipStreamDestroy(e->fused_stream); }
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  if (e->ev_frames) hipEventDestroy(e->ev_frames);
+  if (e->fused_done) hipFree(e->fused_done);
+  if (e->fused_ticket) hipFree(e->fused_ticket);
+  if (e->perm_buf[1]) hipFree(e->perm_buf[1]);
   if (e->sched_stream) {
     hipStreamSynchronize(e->sched_stream);
     hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
@@ -918,13 +919,14 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
       return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while kernels are serialised (counter collection) or MOOG_NO_FUSED is set");
   }
   HIPCHK(hipSetDevice(e->device));
-  if (!e->fused_done) {
-    HIPCHK(hipMalloc(&e->fused_done, sizeof(int32_t) * (size_t)e->n_envs));
+  if (!e->fused_ready) {   // (keyed on a flag set at the END of the block: a failed allocation half way is retried, not dereferenced)
+    if (!e->fused_done) HIPCHK(hipMalloc(&e->fused_done, sizeof(int32_t) * (size_t)e->n_envs));
     HIPCHK(hipMemset(e->fused_done, 0, sizeof(int32_t) * (size_t)e->n_envs));
-    HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
-    HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
+    if (!e->perm_buf[1]) HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
+    if (!e->fused_ticket) HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
     HIPCHK(hipMemset(e->fused_ticket, 0, 2 * sizeof(uint32_t)));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    if (!e->fused_abort)
+      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     *e->fused_abort = 0u;
     { const char* fs = getenv("MOOG_FUSED_FORCE_SERIAL"); e->fused_force_serial = fs && atoi(fs) == 1; }
     { const char* sc = getenv("MOOG_FUSED_SELFCHECK"); e->fused_selfcheck = sc ? atoi(sc) : 0; }
@@ -937,13 +939,13 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
         HIPCHK(hipGetDeviceProperties(&pr, e->device));
         std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0u);
         for (int cu = 0; cu < pr.multiProcessorCount; cu += stride) mask[cu >> 5] |= 1u << (cu & 31);
-        HIPCHK(hipExtStreamCreateWithCUMask(&e->fused_stream, (uint32_t)mask.size(), mask.data()));
+        if (!e->fused_stream) HIPCHK(hipExtStreamCreateWithCUMask(&e->fused_stream, (uint32_t)mask.size(), mask.data()));
       } else {
-        HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
+        if (!e->fused_stream) HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
       }
     }
-    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
+    if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    if (!e->ev_frames) HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, e->device));
     const int per_cu = (int)(160 * 1024 / (e->step_lds ? e->step_lds : 1));
@@ -951,6 +953,7 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
     e->fused_groups = prop.multiProcessorCount;   // one per compute unit: two measured 1 % slower (more contention with the steps)
     { const char* g = getenv("MOOG_FUSED_GROUPS"); if (g && atoi(g) > 0) e->fused_groups = atoi(g); }   // experiments
     if (e->fused_groups > e->n_envs) e->fused_groups = e->n_envs;
+    e->fused_ready = true;
   }
   e->perm_buf[0] = e->perm;
   __atomic_store_n(e->fused_abort, 0u, __ATOMIC_RELAXED);
