@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 28
+#define MOOG_ABI_VERSION 29
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -758,6 +758,24 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
  * moog_engine_get_fused reports whether the mode is (still) in use. */
 int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
 int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled);
+
+/* Reset pool (programs whose initializer is expensive: bounce_box_contact_prediction.py:88-119 and red_green.py:120-203
+ * play the episode forward inside state_initializer -- MOOG_CELL_SIMULATE -- which on one wavefront takes as long as a
+ * hundred env steps of the whole batch, inside the launch every env waits for).  With the pool on, the NEXT episode of
+ * every env is built by a background launch on a stream of the engine's own while the current one is being stepped, and
+ * the step kernel takes the finished record over when the episode ends (environment.py:100-101) instead of running the
+ * initializer.  Results are the same with and without the pool, bit for bit: a reset's draws come from the episode's
+ * own segment of the env's stream (counter = episode << 32 | draw), and what else a reset reads -- the sprites built
+ * outside the initializer (slot_persist) -- is compared with the live record when the pool's record is taken over; a
+ * record that does not match (the host reset the env or loaded a state meanwhile) is dropped and the env is reset in
+ * place.  An env whose record is not ready when its episode ends waits for a fill that is under way, or is reset in
+ * place.  Not available (MOOG_E_UNSUPPORTED): programs of the plain kernels (their resets are cheap), programs with a
+ * MOOG_CELL_PSTATE op (the reset depends on the episode that has just ended), a runtime that serialises kernels.
+ * Calls with injected uniforms never use the pool.  Costs 2 records per env of device memory.
+ * moog_engine_get_reset_pool: whether it is on, and (synchronising the device) stats[5] = fill launches so far, episodes
+ * opened from the pool, episodes opened by a reset in place, pool records rejected, take-overs that had to wait for a fill. */
+int moog_engine_set_reset_pool(moog_engine_t* e, int32_t enabled);
+int moog_engine_get_reset_pool(moog_engine_t* e, int32_t* enabled, int64_t* stats);
 
 /* Usage of the dynamic layers (layers that rules append to: the reference's unbounded Python lists, create_sprites.py,
  * change_layer.py; here `layer_capacity` slots, overflow = MOOG_FAULT_LAYER_FULL).  Per layer, over all envs and calls

@@ -4208,6 +4208,10 @@ __device__ inline void env_reset(Env& e) {
   wsync();
   // sprites the config built outside its initializer are not rebuilt once the env has been reset before (program.born_rule)
   bool born = P->born_rule > 0 && e.f[e.L.o_rule + P->born_rule - 1] != 0.0;
+  // every episode draws from its own segment of the env's stream (counter = episode << 32 | draw): a reset's draws do not
+  // depend on how many the previous episode took, so episode E + 1 can be built while E is running (the reset pool)
+  if (e.lane == 0) { e.q[e.L.o_rng + 1] = (int32_t)((uint32_t)e.q[e.L.o_rng + 1] + 1u); e.q[e.L.o_rng] = 0; }
+  wsync();
   for (int attempt = 0;; ++attempt) {   // (an initializer may start over: `return state_initializer()`, red_green.py:155,203)
     for (int s = e.lane; s < P->n_slots; s += 64) {
       if (born && P->slot_persist[s]) { TELE_SET(s, 0); continue; }

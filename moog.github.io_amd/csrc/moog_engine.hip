@@ -94,6 +94,18 @@ struct moog_engine {
   bool fused_force_serial = false;   // MOOG_FUSED_FORCE_SERIAL=1 (test aid): the frames' grid runs in front of the step kernel
   int fused_selfcheck = 0, fused_calls = 0;   // MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again and compared
   uint8_t* fused_check_img = nullptr;
+  // moog_engine_set_reset_pool: the next episode of every env is built beside the step kernels (moog_kernels.h "reset pool")
+  static constexpr int POOL_STREAMS = 8;
+  int pool_streams = 2;   // the ones in use: hardware queues the runtime has (GPU_MAX_HW_QUEUES, default 4) minus the caller's and the sort's
+  bool pool_on = false, pool_ready = false;
+  int32_t* pool_state = nullptr;   // [n_envs] 0 empty / 1 being filled / 2 ready
+  int32_t* pool_tag = nullptr;     // [n_envs] episode of the pool record
+  unsigned long long* pool_stats = nullptr;   // [4] KArgs::pool_stats
+  double* pool_f64[2] = {nullptr, nullptr};   // [n_envs][f64_per_env]: the fill's inputs, the record after its reset
+  int32_t* pool_i32[2] = {nullptr, nullptr};
+  hipStream_t pool_stream[POOL_STREAMS] = {};   // fills run here, call k's on stream k % pool_streams
+  hipEvent_t ev_pool = nullptr;    // the call a fill follows
+  int64_t pool_fills = 0;          // fill launches so far
   int act_f32 = 0;               // moog_engine_set_action_dtype: the action buffer holds float32 values
   int32_t* layer_hw = nullptr;   // [2 * MOOG_MAX_LAYERS]: high-water mark / dropped appends of the dynamic layers
   TimedKernel timed[MOOG_K_COUNT];
@@ -133,6 +145,13 @@ static void free_engine(moog_engine* e) {
   if (e->fused_abort) hipHostFree(e->fused_abort);
   if (e->fused_check_img) hipFree(e->fused_check_img);
   if (e->layer_hw) hipFree(e->layer_hw);
+  for (int k = 0; k < moog_engine::POOL_STREAMS; ++k)
+    if (e->pool_stream[k]) { hipStreamSynchronize(e->pool_stream[k]); hipStreamDestroy(e->pool_stream[k]); }
+  if (e->ev_pool) hipEventDestroy(e->ev_pool);
+  if (e->pool_state) hipFree(e->pool_state);
+  if (e->pool_tag) hipFree(e->pool_tag);
+  if (e->pool_stats) hipFree(e->pool_stats);
+  for (int k = 0; k < 2; ++k) { if (e->pool_f64[k]) hipFree(e->pool_f64[k]); if (e->pool_i32[k]) hipFree(e->pool_i32[k]); }
   if (e->watch) hipFree(e->watch);
   if (e->d_fops) hipFree(e->d_fops);
   delete e;
@@ -604,11 +623,19 @@ int moog_engine_layout(const moog_engine_t* e, moog_layout_t* out) {
   return MOOG_OK;
 }
 
+static int pool_drop(moog_engine* e, hipStream_t s);
+
 int moog_engine_load_state(moog_engine_t* e, const moog_state_view_t* view) {
   if (!e || !view || !view->f64 || !view->i32) return fail(MOOG_E_INVALID, "null state view");
   if (((uintptr_t)view->f64 & 15) || ((uintptr_t)view->i32 & 15))
     return fail(MOOG_E_INVALID, "state buffers must be 16-byte aligned");
   e->view = *view;
+  if (e->pool_on) {   // other records: whatever the pool holds was built from the old ones
+    HIPCHK(hipSetDevice(e->device));
+    const int rc = pool_drop(e, 0);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(0));
+  }
   return MOOG_OK;
 }
 
@@ -653,6 +680,10 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.xstack_off = e->xstack_off;
   a.watch = (mode == MODE_STEP) ? e->watch : nullptr; a.watch_off = e->watch_off;
   a.fops = e->d_fops; a.n_fops = e->n_fops;
+  const bool pool = e->pool_on && mode == MODE_STEP && !(inj && inj->uniforms);
+  a.pool_state = pool ? e->pool_state : nullptr; a.pool_tag = e->pool_tag; a.pool_stats = e->pool_stats;
+  for (int k = 0; k < 2; ++k) { a.pool_f64[k] = e->pool_f64[k]; a.pool_i32[k] = e->pool_i32[k]; }
+  a.live_f64 = nullptr; a.live_i32 = nullptr;
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
   return a;
 }
@@ -749,6 +780,35 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int time
   return MOOG_OK;
 }
 
+// Reset pool: one fill launch behind the call that has just been enqueued on `s`, on the side streams in turn.  A fill
+// serves every env whose pool is empty when it STARTS (not just this call's), so of the launches that pile up on a
+// stream behind a fill that is under way (~10 ms of look-ahead per env; calls come every fraction of a millisecond) the
+// first does the work and the rest are grids of early exits: each stream always has the next fill ready to start, whether
+// the caller synchronises every call or runs hundreds of calls ahead of the device.
+// The fill reads the live records while later calls step them: see pool_adopt for why that is sound.
+static int pool_kick(moog_engine* e, hipStream_t s) {
+  hipStream_t ps = e->pool_stream[e->pool_fills % e->pool_streams];
+  HIPCHK(hipEventRecord(e->ev_pool, s));
+  HIPCHK(hipStreamWaitEvent(ps, e->ev_pool, 0));
+  KArgs a = make_args(e, nullptr, nullptr, nullptr, MODE_FILL, nullptr);
+  a.live_f64 = e->view.f64; a.live_i32 = e->view.i32;
+  a.f64 = e->pool_f64[1]; a.i32 = e->pool_i32[1];
+  a.pool_state = e->pool_state;
+  a.fault_flag = nullptr;   // (a fault of the pool's record reaches the host when the record is adopted and stored)
+  a.dbg = 0;
+  moog_launch_reset_full(e->n_envs, e->step_lds, ps, a);
+  HIPCHK(hipGetLastError());
+  ++e->pool_fills;
+  return MOOG_OK;
+}
+
+// every pool record is dropped (the host reset the envs, or handed other records over): fills under way finish first
+static int pool_drop(moog_engine* e, hipStream_t s) {
+  for (int k = 0; k < e->pool_streams; ++k) HIPCHK(hipStreamSynchronize(e->pool_stream[k]));
+  HIPCHK(hipMemsetAsync(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs, s));
+  return MOOG_OK;
+}
+
 static int ready(moog_engine* e) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
   if (!e->view.f64) return fail(MOOG_E_INVALID, "moog_engine_load_state has not been called");
@@ -762,11 +822,13 @@ int moog_engine_reset(moog_engine_t* e, const uint8_t* env_mask_dev, const moog_
   if (rc) return rc;
   hipStream_t s = (hipStream_t)hip_stream;
   KArgs a = make_args(e, nullptr, inject, out, MODE_RESET_MASK, env_mask_dev);
+  if (e->pool_on && (rc = pool_drop(e, s)) != MOOG_OK) return rc;
   {
     Bracket br(e, MOOG_K_RESET, s);
     (e->maze_kernel ? moog_launch_reset_full : moog_launch_reset_plain)(e->n_envs, e->step_lds, s, a);
   }
   HIPCHK(hipGetLastError());
+  if (e->pool_on && !(inject && inject->uniforms) && (rc = pool_kick(e, s)) != MOOG_OK) return rc;
   if (out && out->image) return launch_raster(e, out->image, s);
   return MOOG_OK;
 }
@@ -815,6 +877,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
       Bracket br(e, MOOG_K_STEP, s);
       launch_step(e, s, a);
     }
+    if (a.pool_state && (rc = pool_kick(e, s)) != MOOG_OK) return rc;
     if (!e->fused_force_serial) {
       moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, e->fused_stream);
       HIPCHK(hipGetLastError());
@@ -850,6 +913,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     launch_step(e, s, a);
   }
   HIPCHK(hipGetLastError());
+  if (a.pool_state && (rc = pool_kick(e, s)) != MOOG_OK) return rc;
   if (e->perm && e->cost) {
     HIPCHK(hipEventRecord(e->ev_step_done, s));
     HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
@@ -895,6 +959,71 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
     HIPCHK(hipStreamCreateWithFlags(&e->sched_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_step_done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&e->ev_sched_done, hipEventDisableTiming));
+  }
+  return MOOG_OK;
+}
+
+int moog_engine_set_reset_pool(moog_engine_t* e, int32_t enabled) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  if (!enabled) {
+    if (e->pool_on) { const int rc = pool_drop(e, 0); if (rc) return rc; HIPCHK(hipStreamSynchronize(0)); }
+    e->pool_on = false;
+    return MOOG_OK;
+  }
+  if (!e->maze_kernel)
+    return fail(MOOG_E_UNSUPPORTED, "the reset pool lives in the kernels that carry every component; this program runs the plain ones (its resets are cheap)");
+  for (int o = 0; o < e->prog.n_ops; ++o)
+    if (e->prog.ops[o].cell_sel == MOOG_CELL_PSTATE)
+      return fail(MOOG_E_UNSUPPORTED, "the reset pool cannot serve a program whose initializer keeps a number across episodes (MOOG_CELL_PSTATE): its resets depend on how the previous episode went");
+  {
+    const char* ser = getenv("AMD_SERIALIZE_KERNEL");
+    const char* blk = getenv("HIP_LAUNCH_BLOCKING");
+    const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+    const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
+    if ((ser && atoi(ser)) || (blk && atoi(blk)) || (hwq && atoi(hwq) == 1) || (cc && atoi(cc)))
+      return fail(MOOG_E_UNSUPPORTED, "the reset pool needs kernels to run beside each other (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING / GPU_MAX_HW_QUEUES=1 / counter collection serialise them)");
+  }
+  if (!e->pool_ready) {
+    const size_t n = (size_t)e->n_envs;
+    if (!e->pool_state) HIPCHK(hipMalloc(&e->pool_state, sizeof(int32_t) * n));
+    if (!e->pool_tag) HIPCHK(hipMalloc(&e->pool_tag, sizeof(int32_t) * n));
+    if (!e->pool_stats) { HIPCHK(hipMalloc(&e->pool_stats, 4 * sizeof(unsigned long long))); HIPCHK(hipMemset(e->pool_stats, 0, 4 * sizeof(unsigned long long))); }
+    for (int k = 0; k < 2; ++k) {
+      if (!e->pool_f64[k]) HIPCHK(hipMalloc(&e->pool_f64[k], sizeof(double) * n * (size_t)e->L.f64_per_env));
+      if (!e->pool_i32[k]) HIPCHK(hipMalloc(&e->pool_i32[k], sizeof(int32_t) * n * (size_t)e->L.i32_per_env));
+    }
+    {   // streams that share a hardware queue with the caller's would put its step kernels behind a fill
+      const char* hwq = getenv("GPU_MAX_HW_QUEUES");
+      const int queues = (hwq && atoi(hwq) > 0) ? atoi(hwq) : 4;
+      e->pool_streams = queues - 2 < 1 ? 1 : (queues - 2 > moog_engine::POOL_STREAMS ? moog_engine::POOL_STREAMS : queues - 2);
+      const char* ps = getenv("MOOG_POOL_STREAMS");   // experiments
+      if (ps && atoi(ps) > 0 && atoi(ps) <= moog_engine::POOL_STREAMS) e->pool_streams = atoi(ps);
+    }
+    for (int k = 0; k < e->pool_streams; ++k)
+      if (!e->pool_stream[k]) HIPCHK(hipStreamCreateWithFlags(&e->pool_stream[k], hipStreamNonBlocking));
+    if (!e->ev_pool) HIPCHK(hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming));
+    e->pool_ready = true;
+  }
+  HIPCHK(hipMemset(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs));
+  HIPCHK(hipMemset(e->pool_tag, 0, sizeof(int32_t) * (size_t)e->n_envs));
+  e->pool_on = true;
+  return MOOG_OK;
+}
+
+int moog_engine_get_reset_pool(moog_engine_t* e, int32_t* enabled, int64_t* stats) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  if (enabled) *enabled = e->pool_on ? 1 : 0;
+  if (stats) {
+    stats[0] = e->pool_fills;
+    for (int k = 1; k < 5; ++k) stats[k] = 0;
+    if (e->pool_stats) {   // (synchronises the device)
+      unsigned long long h[4];
+      HIPCHK(hipSetDevice(e->device));
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(h, e->pool_stats, sizeof(h), hipMemcpyDeviceToHost));
+      for (int k = 0; k < 4; ++k) stats[1 + k] = (int64_t)h[k];
+    }
   }
   return MOOG_OK;
 }

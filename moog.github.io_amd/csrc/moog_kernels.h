@@ -171,11 +171,20 @@ struct KArgs {
   int32_t n_fops;
   int32_t* watch;        // section sampling (moog_engine_read_watch): [n_envs][MOOG_WATCH_SECTIONS] sample counts, or null
   int32_t watch_off;     // byte offset of the watcher's words in the workgroup's LDS
+  // reset pool (moog_engine_set_reset_pool; the kernels that carry every component only): per env one record of the NEXT
+  // episode, built by a fill launch (MODE_FILL) beside the step kernels and adopted by the step kernel when the episode ends
+  int32_t* pool_state;   // [n_envs] 0 empty, 1 being filled, 2 ready; null: no pool
+  int32_t* pool_tag;     // [n_envs] the episode (high word of the draw counter) the pool record opens
+  double* pool_f64[2];   // [0] the record as the fill read it (the reset's inputs are validated against it), [1] the record after
+  int32_t* pool_i32[2];  //     the reset; same layout and strides as the live records
+  unsigned long long* pool_stats;   // [4] episodes opened from the pool / by a reset in place / pool records rejected / adoptions that waited for a fill
+  const double* live_f64;    // MODE_FILL: the live records (a.f64 / a.i32 are pool_f64[1] / pool_i32[1] then)
+  const int32_t* live_i32;
   int32_t prio_t[3];     // wave priorities by launch rank (with `perm`: descending cost of the previous step): workgroups
                          // [0, t0) issue at priority 3, [t0, t1) at 2, [t1, t2) at 1, the rest at 0; all zero: off
 };
 
-enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2 };
+enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_FILL = 3 };
 
 // The env's draw list (moog_drawlist.h), from the record in LDS, once the step / reset is complete and the record is
 // stored.  Scratch: the broad-phase candidate list, the edge-index scratch and the candidate bit matrix (contiguous, 896
@@ -238,6 +247,138 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.lane = lane;
 }
 
+// =====================================================================================
+// reset pool (the kernels that carry every component): DESIGN 3.2
+// =====================================================================================
+// A reset's result is a function of (seed, env, episode) -- every episode draws from its own segment of the stream,
+// env_reset -- and of what outlives resets: the sprites built outside the initializer (program.slot_persist, kept once
+// born_rule's slot is set) and the MOOG_RULE_STATE_SLOT scalars.  So episode E + 1 can be built while E runs: a fill
+// launch copies the live record, resets the copy and raises the env's flag; when E ends the step kernel checks that the
+// inputs the fill read still equal the live ones, bit for bit, and takes the record over instead of running the reset
+// (otherwise it resets in place, as without a pool).  Programs whose reset reads a state scalar (MOOG_CELL_PSTATE)
+// are not eligible (moog_engine_set_reset_pool refuses them).
+#if MOOG_WITH_MAZE
+// the per-slot words of two records (HBM layout) agree, for every slot the reset keeps
+__device__ inline bool pool_inputs_equal(const Env& e, const moog_layout_t& G, const double* af, const int32_t* aq,
+                                         const double* bf, const int32_t* bq) {
+  PProg P = e.P;
+  bool same = true;
+  const bool born = P->born_rule > 0;
+  if (born) {
+    same = __double_as_longlong(af[G.o_rule + P->born_rule - 1]) == __double_as_longlong(bf[G.o_rule + P->born_rule - 1]);
+    for (int s = e.lane; s < G.S; s += 64) {
+      if (!P->slot_persist[s]) continue;
+      #define PEQ_F(o, k) (__double_as_longlong(af[(o) + (k)]) == __double_as_longlong(bf[(o) + (k)]))
+      #define PEQ_I(o) (aq[(o) + s] == bq[(o) + s])
+      bool q = PEQ_F(G.o_pos, 2 * s) && PEQ_F(G.o_pos, 2 * s + 1) && PEQ_F(G.o_vel, 2 * s) && PEQ_F(G.o_vel, 2 * s + 1) &&
+               PEQ_F(G.o_angle, s) && PEQ_F(G.o_angvel, s) && PEQ_F(G.o_mass, s) && PEQ_F(G.o_color, 3 * s) &&
+               PEQ_F(G.o_color, 3 * s + 1) && PEQ_F(G.o_color, 3 * s + 2) && PEQ_F(G.o_inertia, 2 * s) &&
+               PEQ_F(G.o_inertia, 2 * s + 1) && PEQ_F(G.o_maxr, s);
+      if (G.o_scale >= 0) q = q && PEQ_F(G.o_scale, s) && PEQ_F(G.o_aspect, s);
+      q = q && PEQ_I(G.o_flags) && PEQ_I(G.o_nverts) && PEQ_I(G.o_opacity) && PEQ_I(G.o_shape);
+      if (G.o_valias >= 0) q = q && PEQ_I(G.o_valias);
+      if (G.o_fmask >= 0) q = q && PEQ_I(G.o_fmask);
+      int nv = aq[G.o_nverts + s];
+      if (nv > P->slot_vcap[s]) nv = P->slot_vcap[s];
+      const int v0 = G.o_verts + 2 * P->slot_voff[s];
+      for (int k = 0; k < 2 * nv; ++k) q = q && PEQ_F(v0, k);
+      #undef PEQ_F
+      #undef PEQ_I
+      same = same && q;
+    }
+  }
+  return __all(same);
+}
+
+__device__ inline void pool_copy_record(const moog_layout_t& G, int lane, const double* sf, const int32_t* sq, double* df, int32_t* dq) {
+  const double2* a = reinterpret_cast<const double2*>(sf);
+  double2* b = reinterpret_cast<double2*>(df);
+  for (int i = lane; i < G.f64_per_env / 2; i += 64) b[i] = a[i];
+  const int4* c = reinterpret_cast<const int4*>(sq);
+  int4* d = reinterpret_cast<int4*>(dq);
+  for (int i = lane; i < G.i32_per_env / 4; i += 64) d[i] = c[i];
+}
+
+// Step kernel, an env whose episode has ended, its live record staged in LDS: takes the pool's record over when it is
+// ready (waiting for a fill that is under way: its wave is resident and shorter than a reset from scratch), opens the
+// episode the live record expects and was built from the inputs the live record holds now.  true: the record in LDS (and
+// the fields that live in HBM only) are the new episode's; false: the caller resets in place.
+// *held: the env's flag is 4 now -- no fill may claim the env before the new episode's record is in memory (a fill that
+// copied the old episode's record would build the episode that is just starting once more, for the next take-over to
+// reject); the caller hands the flag back with pool_release after store_record.
+__device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, int32_t* gq, int* held) {
+  *held = 0;
+  if (!a.pool_state || e.inj) return false;
+  int st = 0, waited = 0;
+  if (e.lane == 0) {
+    for (int spins = 0; spins < 400000; ++spins) {   // (a bound, not a protocol: a few tenths of a second)
+      st = __hip_atomic_load(&a.pool_state[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (st == 1) { waited = 1; __builtin_amdgcn_s_sleep(32); continue; }
+      if (st == 0) {   // nothing built, nothing under way: keep the fills out and reset in place
+        int expect = 0;
+        if (__hip_atomic_compare_exchange_strong(&a.pool_state[env], &expect, 4, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) { st = 4; break; }
+        continue;   // (a fill claimed the env this instant: wait for it)
+      }
+      break;
+    }
+  }
+  st = __shfl(st, 0);
+  waited = __shfl(waited, 0);
+  if (st != 2) {   // 4: ours, empty.  1: a fill that did not finish in time -- its record, for an episode that will have passed, gets rejected later
+    *held = st == 4;
+    if (e.lane == 0) atomicAdd(&a.pool_stats[1], 1ull);
+    return false;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const size_t fo = (size_t)env * a.L.f64_per_env, qo = (size_t)env * a.L.i32_per_env;
+  const double* pre_f = a.pool_f64[0] + fo; const int32_t* pre_q = a.pool_i32[0] + qo;
+  const double* post_f = a.pool_f64[1] + fo; const int32_t* post_q = a.pool_i32[1] + qo;
+  const unsigned episode = (unsigned)e.q[e.L.o_rng + 1] + 1u;
+  bool ok = (unsigned)a.pool_tag[env] == episode;
+  ok = ok && pool_inputs_equal(e, a.L, pre_f, pre_q, gf, gq);
+  wsync();
+  if (e.lane == 0) __hip_atomic_store(&a.pool_state[env], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *held = 1;
+  if (!ok) {   // stale: the host edited the records, or something changed a kept sprite after the fill read it
+    if (e.lane == 0) { atomicAdd(&a.pool_stats[1], 1ull); atomicAdd(&a.pool_stats[2], 1ull); }
+    return false;
+  }
+  // what outlives a reset: sticky fault bits, the state slots (never reset; a reset that reads one is not eligible)
+  const int32_t fault = e.q[e.L.o_fault];
+  const int r = e.lane < a.L.R ? e.lane : 0;
+  const double keep = e.f[e.L.o_rule + r];
+  const double keep2 = e.L.o_rule2 >= 0 ? e.f[e.L.o_rule2 + r] : 0.0;
+  wsync();
+  load_record(e, a.H, a.L, post_f, post_q);
+  if (a.H.f_cut1 > a.H.f_cut0)
+    for (int i = a.H.f_cut0 + e.lane; i < a.H.f_cut1; i += 64) gf[i] = post_f[i];
+  if (a.H.i_cut1 > a.H.i_cut0)
+    for (int i = a.H.i_cut0 + e.lane; i < a.H.i_cut1; i += 64) gq[i] = post_q[i];
+  if (e.lane < a.L.R && e.P->rules[e.lane].kind == MOOG_RULE_STATE_SLOT) {
+    e.f[e.L.o_rule + e.lane] = keep;
+    if (e.L.o_rule2 >= 0) e.f[e.L.o_rule2 + e.lane] = keep2;
+  }
+  if (e.lane == 0) {
+    e.q[e.L.o_fault] |= fault;
+    atomicAdd(&a.pool_stats[0], 1ull);
+    if (waited) atomicAdd(&a.pool_stats[3], 1ull);
+  }
+  wave_global_fence();
+  wsync();
+  return true;
+}
+
+// the new episode's record is stored: fills may claim the env again (they read the record from memory: this XCD's L2 first)
+__device__ inline void pool_release(const KArgs& a, int env, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(&a.pool_state[env], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ __forceinline__ bool pool_adopt(Env&, const KArgs&, int, double*, int32_t*, int* held) { *held = 0; return false; }
+__device__ __forceinline__ void pool_release(const KArgs&, int, int) {}
+#endif
+
 // reset_next word: 0 = running, 1 = reset on the next call (environment.py:100-101): the step kernel
 // resets such an env instead of stepping it (its action is ignored, the timestep is FIRST).
 #ifdef MOOG_DEFINE_RESET_KERNELS
@@ -247,14 +388,49 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   if (env >= a.n_envs) return;
   int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   if (a.mask != nullptr && a.mask[env] == 0) return;
+  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
+#if MOOG_WITH_MAZE
+  if (a.mode == MODE_FILL) {   // reset pool: a.f64 / a.i32 are the pool's records; claim the env, copy its live record, reset the copy
+    int won = 0;
+    if (threadIdx.x == 0) {
+      int expect = 0;
+      won = __hip_atomic_compare_exchange_strong(&a.pool_state[env], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+    }
+    if (!__shfl(won, 0)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double* lf = a.live_f64 + (size_t)env * a.L.f64_per_env;
+    const int32_t* lq = a.live_i32 + (size_t)env * a.L.i32_per_env;
+    // (the step kernels may be storing this record right now: what the reset reads of it is validated when the record is
+    //  adopted, pool_adopt; the rest it overwrites)
+    pool_copy_record(a.L, (int)threadIdx.x, lf, lq, a.pool_f64[0] + (size_t)env * a.L.f64_per_env,
+                     a.pool_i32[0] + (size_t)env * a.L.i32_per_env);
+    pool_copy_record(a.L, (int)threadIdx.x, a.pool_f64[0] + (size_t)env * a.L.f64_per_env,
+                     a.pool_i32[0] + (size_t)env * a.L.i32_per_env, gf, gq);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
   Env e;
   bind_env(e, a, env);
-  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   load_record(e, a.H, a.L, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
   env_reset<true>(e);
   wsync();
+#if MOOG_WITH_MAZE
+  if (a.mode == MODE_FILL) {
+    if (e.lane == 0) e.q[e.L.o_reset_next] = 0;
+    const int32_t tag = e.q[e.L.o_rng + 1];
+    store_record(e, a.H, a.L, gf, gq, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record (and what the reset wrote straight to HBM) before the flag
+    if (e.lane == 0) {
+      a.pool_tag[env] = tag;
+      __hip_atomic_store(&a.pool_state[env], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+#endif
   if (e.lane == 0) {
     e.q[e.L.o_reset_next] = 0;
     if (a.reward) a.reward[env] = __builtin_nan("");
@@ -339,7 +515,8 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
   wsync();
 #ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
   if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
-    env_reset<DYN>(e);
+    int held = 0;
+    if (!(DYN && pool_adopt(e, a, env, gf, gq, &held))) env_reset<DYN>(e);   // (the next episode may be waiting in the reset pool)
     wsync();
     if (e.lane == 0) {
       e.q[e.L.o_reset_next] = 0;
@@ -354,6 +531,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
 #endif
     }
     store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
+    if (DYN && held) pool_release(a, env, e.lane);
     emit_drawlist(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
     return true;   // (the reset path writes colours / opacities / shapes straight to HBM)

@@ -18,7 +18,7 @@ SYMBOLS = (
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
     'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
     'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
-    'moog_engine_read_watch',
+    'moog_engine_read_watch', 'moog_engine_set_reset_pool', 'moog_engine_get_reset_pool',
 )
 
 _LIB = None
@@ -38,6 +38,12 @@ def load_library(path=None):
     # one already resident when the engine library resolves libamdhip64, so that
     # both share one runtime (streams, device pointers).
     import torch  # noqa: F401
+    # Kernels of different streams run beside each other only on different hardware queues, and the runtime's default is 4
+    # for the whole process: the sub-batches (SubBatchedEnvironment) and the reset pool's fills need more.  The HIP runtime
+    # reads the variable when it initialises, so this only takes effect in a process that has not touched the GPU yet (and
+    # never overrides the caller's own setting).
+    if 'GPU_MAX_HW_QUEUES' not in os.environ and not torch.cuda.is_initialized():
+        os.environ['GPU_MAX_HW_QUEUES'] = '16'
     if not os.path.exists(path):
         raise EngineError(
             'HIP engine library not found at %s -- build it with '
@@ -63,6 +69,8 @@ def load_library(path=None):
     lib.moog_engine_set_timing.argtypes = [vp, i32]
     lib.moog_engine_set_fused.argtypes = [vp, i32]
     lib.moog_engine_get_fused.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.moog_engine_set_reset_pool.argtypes = [vp, i32]
+    lib.moog_engine_get_reset_pool.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
     lib.moog_engine_set_action_dtype.argtypes = [vp, i32]
     lib.moog_engine_layer_usage.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.moog_engine_set_debug.argtypes = [vp, i32, i32]

@@ -45,10 +45,15 @@ class BatchedEnvironment(object):
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
                  meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0,
-                 layer_capacity=None, keep_sprite_factors=False, _compiled=None, _buffers=None):
+                 layer_capacity=None, keep_sprite_factors=False, reset_pool='auto', _compiled=None, _buffers=None):
         import torch
         self._torch = torch
         self._lib = _engine.load_library()  # raises when the HIP extension is missing
+        # reset_pool: build every env's NEXT episode beside the step kernels and take it over when the episode ends
+        # (moog_engine_set_reset_pool; same results, bit for bit).  'auto': on for configs whose state_initializer plays
+        # physics forward (bounce_box_contact_prediction, red_green: a reset there costs as much as a hundred steps of the
+        # whole batch) when the engine can (see self.reset_pool); True: on, or EngineError; False: off.
+        self._reset_pool_arg = reset_pool
         if not torch.cuda.is_available():
             raise _engine.EngineError('no HIP device available: the MOOG engine has no CPU path')
         # (_compiled / _buffers: a SubBatchedEnvironment builds its parts over one lowered program and slices of one set of
@@ -123,6 +128,35 @@ class BatchedEnvironment(object):
         self._cost = self._perm = None
         self._fused = False
         self._action_f32 = False
+        self._apply_reset_pool()
+
+    def _apply_reset_pool(self):
+        want = self._reset_pool_arg
+        P = self.compiled.program
+        if want == 'auto':
+            want = any(P.ops[o].cell_sel == _abi.MOOG_CELL_SIMULATE for o in range(P.n_ops))
+            strict = False
+        else:
+            strict = bool(want)
+        self.reset_pool_refusal = None
+        if want:
+            with self._torch.cuda.device(self.device):
+                rc = self._lib.moog_engine_set_reset_pool(self._handle, 1)
+            if rc != 0:
+                if strict:
+                    _engine.check(self._lib, rc)
+                self.reset_pool_refusal = self._lib.moog_last_error().decode()
+
+    @property
+    def reset_pool(self):
+        """The engine's reset pool: {'on', 'fills' (fill launches), 'adopted' (episodes opened from the pool), 'in_place'
+        (episodes opened by a reset inside the step kernel), 'rejected' (pool records dropped by the input check), 'waited'
+        (take-overs that waited for a fill)}; synchronises.  `reset_pool_refusal` holds the engine's reason when
+        reset_pool='auto' wanted the pool and could not have it."""
+        on, st = ctypes.c_int32(), (ctypes.c_int64 * 5)()
+        _engine.check(self._lib, self._lib.moog_engine_get_reset_pool(self._handle, ctypes.byref(on), st))
+        return dict(on=bool(on.value), fills=int(st[0]), adopted=int(st[1]), in_place=int(st[2]), rejected=int(st[3]),
+                    waited=int(st[4]))
 
     @staticmethod
     def allocate_buffers(torch, L, P, n, device):
@@ -347,6 +381,7 @@ class BatchedEnvironment(object):
                 _engine.check(self._lib, self._lib.moog_engine_set_action_dtype(self._handle, 1))
         if had_schedule:
             self.enable_cost_schedule(True, fused=had_fused)
+        self._apply_reset_pool()
         self.capacity_growths = getattr(self, 'capacity_growths', []) + [dict(caps)]
 
     def raise_faults(self):

@@ -600,6 +600,112 @@ def test_sub_batches_are_result_neutral(name, n, G, steps):
     env.close()
 
 
+def observable_state(env, f, q):
+    """What a record says about the episode: every scalar field, and the per-slot fields of the sprites that exist (a dead
+    slot's leftovers -- the values of whichever sprite lived there last -- are nothing a component ever reads)."""
+    from moog import _abi
+    L, P = env.layout, env.compiled.program
+    S = L.S
+    alive = (q[:, L.o_flags:L.o_flags + S] & _abi.MOOG_F_ALIVE) != 0
+    out = {}
+    for name, width in (('o_pos', 2), ('o_vel', 2), ('o_angle', 1), ('o_angvel', 1), ('o_mass', 1), ('o_color', 3),
+                        ('o_inertia', 2), ('o_maxr', 1), ('o_scale', 1), ('o_aspect', 1)):
+        o = getattr(L, name)
+        if o >= 0:
+            v = f[:, o:o + width * S].reshape(len(f), S, width).copy()
+            v[~alive] = 0
+            out[name] = v
+    for name in ('o_flags', 'o_nverts', 'o_opacity', 'o_shape', 'o_tele', 'o_valias', 'o_fmask'):
+        o = getattr(L, name)
+        if o >= 0:
+            v = q[:, o:o + S].copy()
+            v[~alive] = 0
+            out[name] = v
+    nv = np.where(alive, q[:, L.o_nverts:L.o_nverts + S], 0)
+    verts = []
+    for s_ in range(S):
+        vo, cap = int(P.slot_voff[s_]), int(P.slot_vcap[s_])
+        v = f[:, L.o_verts + 2 * vo:L.o_verts + 2 * (vo + cap)].reshape(len(f), cap, 2).copy()
+        v[np.arange(cap)[None, :] >= nv[:, s_:s_ + 1]] = 0
+        verts.append(v.reshape(len(f), -1))
+    out['verts'] = np.concatenate(verts, axis=1)
+    n_act = 2 * max(1, int(P.n_actions))
+    for name, count in (('o_action', n_act), ('o_task', int(P.n_tasks)), ('o_rule', int(P.n_rules)), ('o_hdraw', int(P.n_hdraws)),
+                        ('o_rule2', int(P.n_rules))):
+        o = getattr(L, name)
+        if o >= 0 and count > 0:
+            out[name] = f[:, o:o + count]
+    for name, count in (('o_step_count', 1), ('o_reset_next', 1), ('o_fault', 1), ('o_rng', 2),
+                        ('o_maze', _abi.MOOG_MAX_MAZE + _abi.MOOG_MAX_MAZE_POINTS)):
+        o = getattr(L, name)
+        if o >= 0:
+            out[name] = q[:, o:o + count]
+    return out
+
+
+@pytest.mark.parametrize('name,n,steps,min_episodes', [('bounce_box_contact_prediction', 96, 260, 192), ('red_green_l1', 64, 200, 64),
+                                                       ('maze_zoo', 128, 150, 1), ('pacman', 32, 60, 1)])
+def test_reset_pool_is_result_neutral(name, n, steps, min_episodes):
+    """moog_engine_set_reset_pool: the next episode of every env is built on a side stream while the current one runs,
+    and taken over by the step kernel when the episode ends.  Time steps, EVERY frame of every call and the final
+    records equal those of an engine that resets in place, bit for bit -- over several episodes per env, with a host-side
+    reset of some envs in the middle, and with records edited behind the engine's back: the episode counter of some envs
+    moved on, a sprite built outside the initializer recoloured (pool records built before that are stale and must be
+    rejected, not used)."""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(11)
+    acts = None
+
+    def digest(ts):
+        img = ts.observation['image']
+        ww = (torch.arange(img[0].numel(), device=img.device, dtype=torch.int64) % 8191) + 1
+        return ((img.reshape(img.shape[0], -1).to(torch.int64) * ww).sum(1).cpu().numpy(), ts.step_type.cpu().numpy(),
+                np.nan_to_num(ts.reward.cpu().numpy(), nan=-7.0), np.nan_to_num(ts.discount.cpu().numpy(), nan=-7.0))
+
+    def run(pool):
+        nonlocal acts
+        env = make_env(name, n, seed=33, reset_pool=pool)
+        if acts is None:
+            grid = env._is_grid
+            acts = [(torch.randint(0, 5, (n,), generator=g, dtype=torch.int32) if grid
+                     else torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1).cuda() for _ in range(steps)]
+        env.check_faults = False
+        env.reset()
+        out = []
+        mask = torch.zeros(n, dtype=torch.bool, device='cuda')
+        mask[::3] = True
+        L, P = env.layout, env.compiled.program
+        persist = [s_ for s_ in range(L.S) if P.slot_persist[s_]] if P.born_rule > 0 else []
+        for k in range(steps):
+            if k == steps // 3:   # the draws of these envs' next episodes come from another segment than the pool assumed
+                env.state_i32[1::4, L.o_rng + 1] += 5
+            if k == steps // 2:
+                env.reset(mask)   # (a third of the envs start a new episode; the engine drops its pool)
+            if k == (2 * steps) // 3 and persist:   # an input of the reset changes after the fills have read it
+                env.state_f64[2::5, L.o_color + 3 * persist[0]] += 1.0
+            out.append(digest(env.step(acts[k])))
+        f, q = download(env)
+        stats = env.reset_pool
+        obs = observable_state(env, f, q)
+        env.close()
+        return out, obs, stats
+
+    want, wobs, wstats = run(False)
+    got, gobs, gstats = run(True)
+    assert not wstats['on'] and gstats['on']
+    episodes = sum(int((d[1] == 0).sum()) for d in want)
+    assert episodes >= min_episodes, 'the run is too short to exercise the pool: %d episode starts' % episodes
+    assert gstats['adopted'] > 0 and gstats['adopted'] + gstats['in_place'] == episodes, (gstats, episodes)
+    if min_episodes > 1:
+        assert gstats['rejected'] > 0   # the edited records
+    for k in range(steps):
+        for part in range(4):
+            assert np.array_equal(got[k][part], want[k][part]), 'call %d, output %d differs in envs %s (pool %s)' % (
+                k, part, np.nonzero(got[k][part] != want[k][part])[0][:8], gstats)
+    for key in wobs:
+        assert np.array_equal(gobs[key], wobs[key], equal_nan=True), (key, gstats)
+
+
 def test_layer_capacity_auto_grows_transparently():
     """layer_capacity='auto' (the reference's layers are unbounded Python lists, create_sprites.py:34, change_layer.py:43):
     first_person_predators_prey started from the fixtures' capacities -- which a 256-env random-policy batch overflows

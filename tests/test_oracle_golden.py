@@ -411,3 +411,24 @@ def test_numpy_dot_and_norm_roundings():
     a32, b32 = a.astype(np.float32), b.astype(np.float32)
     assert np.array_equal(a32[:, 0] * b32[:, 0] + a32[:, 1] * b32[:, 1], z['dot32'])
     assert np.array_equal(np.sqrt(a32[:, 0] * a32[:, 0] + a32[:, 1] * a32[:, 1]), z['norm32'])
+
+
+def test_reset_draws_come_from_the_episodes_own_segment():
+    """The property the engine's reset pool rests on (include/moog_engine.h moog_engine_set_reset_pool): an env's draw counter is
+    episode << 32 | draw, a reset opens the next segment, so the state a reset builds depends on (seed, env, episode number)
+    and not on how many draws the episode before it took."""
+    c = compiled('colliding_predators')
+    L = c.layout
+    a = helpers.OracleEnv(c, n_envs=4, seed=9)
+    b = helpers.OracleEnv(c, n_envs=4, seed=9)
+    a.reset(render=False)
+    b.reset(render=False)
+    assert np.array_equal(a.i32[:, L.o_rng + 1], np.ones(4, np.int32))     # episode 1 ...
+    assert (a.i32[:, L.o_rng] > 0).all()                                  # ... took its draws from segment 1
+    first = a.f64.copy()
+    b.i32[:, L.o_rng] += 1000      # as if episode 1 of `b` had taken a thousand more draws than that of `a`
+    a.reset(render=False)
+    b.reset(render=False)
+    assert np.array_equal(a.i32[:, L.o_rng + 1], 2 * np.ones(4, np.int32))
+    assert np.array_equal(a.f64, b.f64) and np.array_equal(a.i32, b.i32)
+    assert not np.array_equal(a.f64, first)    # (another episode, other draws)
