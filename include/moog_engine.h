@@ -806,6 +806,18 @@ int moog_engine_poll_faults(moog_engine_t* e, int32_t clear, int32_t* bits);
  * when `image_dev` is not NULL, copies the cached picture [height][width][3] there. */
 int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image_dev, void* hip_stream);
 
+/* The per-env prefix: leading sprites that stay put within an episode but differ between envs and episodes (a random
+ * maze's walls, pacman.py:62-65).  Every env keeps a picture of its own prefix and a snapshot of the record it was drawn
+ * from; before the frames of a call are drawn, a check launch compares each env's live prefix with its snapshot bit for
+ * bit, the pictures of the envs that differ (a reset, an edited record) are drawn again, and the frame launch composes
+ * the remaining sprites on top of the pictures -- the same pixels as drawing everything (pil_renderer.py:104-111 draws in
+ * slot order).  The prefix starts as the leading slots the initializer creates at rest and SHRINKS to the first slot seen
+ * changing in the middle of an episode (food that gets eaten), so what it covers is what really stays put.  Costs a frame
+ * and a record per env of device memory and two small launches per call; used for frames of several tiles (wider or
+ * taller than 128 pixels) when it covers at least 32 slots and 8 more than the static prefix; MOOG_RASTER_ENV_BG=0 in the
+ * environment turns it off, =1 on for any frame size.  Returns the number of slots it covers now (0: unused). */
+int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots);
+
 /* Profiling aids, both 0 in production (they make results wrong: timing only).  `step_debug`: bit
  * mask that switches parts of the step kernel off / writes cycle counters instead of outputs;
  * `raster_stop` = k truncates the raster kernel after phase k.  The initial values come from the

@@ -117,6 +117,14 @@ struct moog_engine {
   double* s_f64 = nullptr;
   int32_t* s_i32 = nullptr;
   uint8_t* s_bg = nullptr;
+  // per-env prefix (RArgs::sbg_env_stride): leading sprites that stay put within an episode but differ between envs
+  int pe_ns = 0, pe_nsv = 0;        // slots / vertex slots of the prefix (0: off); shrinks to the slots that really stay put
+  double* pe_f64 = nullptr;         // [n_envs] snapshot of the record each env's picture was drawn from
+  int32_t* pe_i32 = nullptr;
+  uint8_t* pe_bg = nullptr;         // [n_envs][canvas_h][pad_w][3]
+  int32_t* pe_valid = nullptr;      // [n_envs] the env has a picture
+  int32_t* pe_build = nullptr;      // [n_envs] this call's build launch draws the env's picture
+  int32_t* pe_min = nullptr;        // pinned host word: first slot of the prefix seen changing in the middle of an episode
   // wave rasteriser (moog_raster_wave.h): one wavefront per frame from the env's draw list (moog_drawlist.h)
   bool wave = false;          // the wave rasteriser is on (MOOG_RASTER_WAVE=1; needs draw lists)
   bool dlist = false;         // the program's frames can be drawn from draw lists (the step kernel emits them)
@@ -148,6 +156,12 @@ static void free_engine(moog_engine* e) {
   for (int k = 0; k < moog_engine::POOL_STREAMS; ++k)
     if (e->pool_stream[k]) { hipStreamSynchronize(e->pool_stream[k]); hipStreamDestroy(e->pool_stream[k]); }
   if (e->ev_pool) hipEventDestroy(e->ev_pool);
+  if (e->pe_f64) hipFree(e->pe_f64);
+  if (e->pe_i32) hipFree(e->pe_i32);
+  if (e->pe_bg) hipFree(e->pe_bg);
+  if (e->pe_valid) hipFree(e->pe_valid);
+  if (e->pe_build) hipFree(e->pe_build);
+  if (e->pe_min) hipHostFree(e->pe_min);
   if (e->pool_state) hipFree(e->pool_state);
   if (e->pool_tag) hipFree(e->pool_tag);
   if (e->pool_stats) hipFree(e->pool_stats);
@@ -176,6 +190,32 @@ static int static_prefix_slots(const moog_program_t* p, int* nsv) {
   }
   int ns = 0, nv = 0;
   while (ns < p->n_slots && ns < 32 && ok[ns] && p->slot_voff[ns] == nv) { nv += p->slot_vcap[ns]; ++ns; }
+  *nsv = nv;
+  return ns;
+}
+
+// Per-env prefix: leading slots whose sprites are created at rest by the initializer (whatever their positions: a maze's
+// walls, food on its cells) and that no op's code writes to afterwards.  A guess like the one above: the check launch
+// compares every frame's prefix with the env's snapshot, and slots that turn out to change within episodes (food that gets
+// eaten) shorten the prefix (launch_raster).
+static int env_prefix_slots(const moog_program_t* p, int* nsv) {
+  *nsv = 0;
+  if (p->render.polymod != MOOG_POLYMOD_NONE) return 0;
+  std::vector<char> ok((size_t)(p->n_slots > 0 ? p->n_slots : 1), 0);
+  for (int oi = 0; oi < p->n_ops; ++oi) {
+    const moog_genop_t& op = p->ops[oi];
+    if (op.runtime || op.cell_sel == MOOG_CELL_STORE) continue;
+    bool c = true;
+    for (int k = MOOG_FAC_XVEL; k <= MOOG_FAC_ANGVEL; ++k)
+      if (k == MOOG_FAC_XVEL || k == MOOG_FAC_YVEL || k == MOOG_FAC_ANGVEL) c = c && op.factors[k].kind == MOOG_DIST_CONST && op.factors[k].a == 0;
+    if (!c) continue;
+    for (int sl = op.slot0; sl < op.slot0 + op.count_max && sl < p->n_slots; ++sl)
+      if (sl >= 0 && !p->layer_dynamic[p->slot_layer[sl]]) ok[sl] = 1;
+  }
+  for (int oi = 0; oi < p->n_ops; ++oi)
+    if (p->ops[oi].cell_sel == MOOG_CELL_STORE && p->ops[oi].cell_arg >= 0 && p->ops[oi].cell_arg < p->n_slots) ok[p->ops[oi].cell_arg] = 0;
+  int ns = 0, nv = 0;
+  while (ns < p->n_slots && ok[ns] && p->slot_voff[ns] == nv) { nv += p->slot_vcap[ns]; ++ns; }
   *nsv = nv;
   return ns;
 }
@@ -340,6 +380,34 @@ static int build_static_prefix(moog_engine* e) {
   return MOOG_OK;
 }
 
+// Per-env prefix (RArgs::sbg_env_stride): worth its memory (a frame and a record per env) and its two extra launches per
+// call when it covers many sprites of a frame that takes several workgroups -- measured (profiles/r04_env_prefix.txt):
+// pacman's 256 x 256 frames (136 walls, 8 tiles) 2.51 -> 1.73 ms per 4096; one-tile frames (maze_zoo, functional_maze)
+// lose 0.09 ms to the check and the build launch and gain nothing, their workgroups being bound by fixed costs.
+// MOOG_RASTER_ENV_BG=0 turns it off, =1 turns it on whatever the frame size (A/B runs, tests).
+static int setup_env_prefix(moog_engine* e) {
+  const char* sw = getenv("MOOG_RASTER_ENV_BG");
+  if ((sw && atoi(sw) == 0) || e->aa > 1 || e->wave) return MOOG_OK;
+  const bool forced = sw && atoi(sw) == 1;
+  int nsv = 0;
+  const int ns = env_prefix_slots(&e->prog, &nsv);
+  const size_t frame = (size_t)e->canvas_h * e->pad_w * 3;
+  if (ns < 16 || ns < e->n_static + 8 || (size_t)e->n_envs * frame > ((size_t)4 << 30)) return MOOG_OK;
+  if (!forced && (e->raster_tiles_x * e->raster_bands < 2 || ns < 32)) return MOOG_OK;
+  const size_t n = (size_t)e->n_envs;
+  if (hipMalloc(&e->pe_f64, n * e->L.f64_per_env * 8) != hipSuccess || hipMalloc(&e->pe_i32, n * e->L.i32_per_env * 4) != hipSuccess ||
+      hipMalloc(&e->pe_bg, n * frame) != hipSuccess || hipMalloc(&e->pe_valid, n * 4) != hipSuccess ||
+      hipMalloc(&e->pe_build, n * 4) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&e->pe_min), sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    (void)hipGetLastError();   // no room: the frames are drawn without it
+    return MOOG_OK;
+  }
+  HIPCHK(hipMemset(e->pe_valid, 0, n * 4));
+  *e->pe_min = INT32_MAX;
+  e->pe_ns = ns; e->pe_nsv = nsv;
+  return MOOG_OK;
+}
+
 int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t device_id, uint64_t seed,
                        int64_t env_index0, moog_engine_t** out) {
   if (!out) return fail(MOOG_E_INVALID, "null out");
@@ -420,6 +488,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_tile_w = tw;
     e->raster_tiles_x = e->pad_w / tw;
     e->raster_band_h = e->canvas_h <= 128 ? e->canvas_h : 64;
+    { const char* bh = getenv("MOOG_RASTER_BAND_H"); if (bh && atoi(bh) >= 16 && atoi(bh) <= e->canvas_h) e->raster_band_h = atoi(bh); }   // experiments
     e->raster_bands = (e->canvas_h + e->raster_band_h - 1) / e->raster_band_h;
     int W = e->raster_tile_w, H = e->raster_band_h;   // (the LDS plan is per tile)
     int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
@@ -580,6 +649,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     }
   int rc2 = build_static_prefix(e);
   if (rc2 == MOOG_OK) rc2 = setup_anti_aliasing(e);
+  if (rc2 == MOOG_OK) rc2 = setup_env_prefix(e);
   if (rc2 == MOOG_OK && e->aa <= 1 && e->pad_w != e->canvas_w &&
       hipMalloc(&e->pad_img, (size_t)n_envs * e->canvas_h * e->pad_w * 3) != hipSuccess)
     rc2 = fail(MOOG_E_NOMEM, "hipMalloc(16-aligned frames) failed");
@@ -711,8 +781,36 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_nv = e->s_i32 ? e->s_i32 + e->L.o_nverts : nullptr;
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
+  r.sbg_env_stride = 0; r.env_build = nullptr;
   r.dl = nullptr; r.dl_stride = e->dl_stride; r.nsl = 0; r.sref_dl = e->s_dl;
   return r;
+}
+
+// Per-env prefix: validates every env's picture against its live record, draws the stale ones again, and points the frame
+// launch's arguments at the pictures.  (The launches that do not pass through here -- frames that follow their env's step,
+// anti-aliased canvases -- draw every sprite; the next launch that does re-validates, so nothing goes stale unseen.)
+static int use_env_prefix(moog_engine* e, RArgs& r, hipStream_t s) {
+  if (e->pe_ns <= 0) return MOOG_OK;
+  const int seen = __atomic_load_n(e->pe_min, __ATOMIC_RELAXED);
+  if (seen < e->pe_ns) {   // slots from `seen` on do change within episodes: they leave the prefix, every picture is drawn again
+    e->pe_ns = seen < 8 ? 0 : seen;
+    e->pe_nsv = e->pe_ns > 0 ? e->prog.slot_voff[e->pe_ns] : 0;
+    __atomic_store_n(e->pe_min, INT32_MAX, __ATOMIC_RELAXED);
+    if (e->pe_ns <= 0) return MOOG_OK;
+    HIPCHK(hipMemsetAsync(e->pe_valid, 0, sizeof(int32_t) * (size_t)e->n_envs, s));
+  }
+  PCArgs c;
+  c.P = e->d_prog; c.L = e->L; c.f64 = e->view.f64; c.i32 = e->view.i32; c.s_f64 = e->pe_f64; c.s_i32 = e->pe_i32;
+  c.valid = e->pe_valid; c.build = e->pe_build; c.min_changed = e->pe_min; c.n_envs = e->n_envs; c.n_static = e->pe_ns;
+  moog_prefix_check_launch(c, s);
+  RArgs b = r;
+  b.image = e->pe_bg; b.n_static = e->pe_ns; b.nsv = e->pe_nsv; b.build = 1; b.env_build = e->pe_build; b.debug_stop = 0;
+  b.sbg = nullptr; b.sbg_env_stride = 0; b.dl = nullptr; b.nsl = 0;
+  moog_raster_launch(b, e->raster_lds, s);
+  r.n_static = e->pe_ns; r.nsv = e->pe_nsv; r.sbg = e->pe_bg;
+  r.sbg_env_stride = (size_t)e->canvas_h * e->pad_w * 3;
+  r.nsl = 0;
+  return MOOG_OK;
 }
 
 static DLArgs drawlist_args(moog_engine* e) {
@@ -757,6 +855,7 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int time
     if (!pre) r.n_static = 0;
   }
   Bracket br(e, MOOG_K_RASTER, s, timed);
+  if (e->aa <= 1 && !r.dl) { const int rc = use_env_prefix(e, r, s); if (rc) return rc; }
   if (e->aa <= 1 && e->pad_w != e->canvas_w) {   // drawn 16-aligned, cropped into the caller's frames
     r.image = e->pad_img;
     moog_raster_launch(r, e->raster_lds, s);
@@ -1111,6 +1210,14 @@ int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled) {
   if (!e || !enabled) return fail(MOOG_E_INVALID, "null argument");
   // (a call's frames that gave up waiting switch the mode off at the next call; report that already)
   *enabled = (e->fused && !(e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u)) ? 1 : 0;
+  return MOOG_OK;
+}
+
+int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots) {
+  if (!e || !n_slots) return fail(MOOG_E_INVALID, "null argument");
+  int ns = e->pe_ns;
+  if (ns > 0) { const int seen = __atomic_load_n(e->pe_min, __ATOMIC_RELAXED); if (seen < ns) ns = seen < 8 ? 0 : seen; }
+  *n_slots = ns;
   return MOOG_OK;
 }
 

@@ -84,6 +84,13 @@ struct RArgs {
   const int32_t* sref_nv;
   const int32_t* sref_opa;
   const uint8_t* sbg;       // background + prefix, [H][W][3] in output (flipped) order
+  // Per-env prefix (programs whose leading sprites never move but differ from env to env and episode to episode -- a
+  // maze's walls): every env has a picture of its own, sbg + env * sbg_env_stride, and a snapshot of the record it was
+  // drawn from; a check launch (moog_prefix_check_launch) compares the live prefix with the snapshot before the frames are
+  // drawn and names the envs whose picture a `build` launch has to draw again (env_build).  The frame launch then skips
+  // the prefix of every env without comparing anything.
+  size_t sbg_env_stride;    // bytes between the envs' pictures; 0: one picture for all (the comparison is the frame kernel's)
+  const int32_t* env_build; // build launches: [n_envs] 1 = draw this env's picture, 0 = the workgroup has nothing to do; null: every env
   // draw lists (moog_drawlist.h): when set, the vertices come from the env's list instead of the f64 record
   const uint32_t* dl;
   int32_t dl_stride;        // words per env
@@ -241,3 +248,16 @@ void moog_crop_launch(const uint8_t* in, uint8_t* out, size_t rows, int in_strid
 void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream);
 int moog_raster_configure(size_t lds_bytes);   // hipFuncSetAttribute(max dynamic LDS); returns a hipError_t
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream);
+// Per-env prefix check: one wavefront per env compares the first n_static slots of the live record (alive bit, vertex count,
+// opacity, colour, live vertices) with the env's snapshot.  Different, or no picture yet (valid[env] == 0): the record is
+// copied to the snapshot, build[env] = 1, valid[env] = 1; equal: build[env] = 0.  A change in the middle of an episode
+// (step_count != 0) of an env that had a picture lowers *min_changed (host-visible) to the first slot that changed: the
+// engine shortens the prefix to the slots that really stay put.
+struct PCArgs {
+  const moog_program_t* P; moog_layout_t L;
+  const double* f64; const int32_t* i32;   // live records
+  double* s_f64; int32_t* s_i32;           // snapshots, same layout
+  int32_t* valid; int32_t* build; int32_t* min_changed;
+  int32_t n_envs, n_static;
+};
+void moog_prefix_check_launch(const PCArgs& a, hipStream_t stream);

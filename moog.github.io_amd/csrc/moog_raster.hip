@@ -266,6 +266,54 @@ __global__ __launch_bounds__(256) void moog_crop_kernel(const uint8_t* in, uint8
   for (int b = threadIdx.x & 63; b < row_bytes; b += 64) dst[b] = src[b];
 }
 
+__global__ __launch_bounds__(64) void moog_prefix_check_kernel(PCArgs a) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= a.n_envs) return;
+  PProg P = as_const_prog(a.P);
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
+  double* sf = a.s_f64 + (size_t)env * L.f64_per_env;
+  int32_t* sq = a.s_i32 + (size_t)env * L.i32_per_env;
+  const int had = a.valid[env];
+  int first_bad = a.n_static;
+  if (had) {
+    for (int s = lane; s < a.n_static; s += 64) {
+      const int fl = gq[L.o_flags + s], nv = gq[L.o_nverts + s];
+      bool bad = ((fl ^ sq[L.o_flags + s]) & MOOG_F_ALIVE) != 0;
+      if (fl & MOOG_F_ALIVE) {
+        bad = bad || nv != sq[L.o_nverts + s] || gq[L.o_opacity + s] != sq[L.o_opacity + s];
+        for (int k = 0; k < 3; ++k)
+          bad = bad || __double_as_longlong(gf[L.o_color + 3 * s + k]) != __double_as_longlong(sf[L.o_color + 3 * s + k]);
+        const int v0 = L.o_verts + 2 * P->slot_voff[s];
+        const int n2 = 2 * (nv < P->slot_vcap[s] ? nv : P->slot_vcap[s]);
+        for (int k = 0; k < n2; ++k) bad = bad || __double_as_longlong(gf[v0 + k]) != __double_as_longlong(sf[v0 + k]);
+      }
+      if (bad && s < first_bad) first_bad = s;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(first_bad, o); first_bad = other < first_bad ? other : first_bad; }
+  }
+  const bool rebuild = !had || first_bad < a.n_static;
+  if (rebuild) {
+    const double2* src = reinterpret_cast<const double2*>(gf);
+    double2* dst = reinterpret_cast<double2*>(sf);
+    for (int i = lane; i < L.f64_per_env / 2; i += 64) dst[i] = src[i];
+    const int4* srci = reinterpret_cast<const int4*>(gq);
+    int4* dsti = reinterpret_cast<int4*>(sq);
+    for (int i = lane; i < L.i32_per_env / 4; i += 64) dsti[i] = srci[i];
+  }
+  if (lane == 0) {
+    a.build[env] = rebuild ? 1 : 0;
+    a.valid[env] = 1;
+    if (had && first_bad < a.n_static && gq[L.o_step_count] != 0)
+      __hip_atomic_fetch_min(a.min_changed, first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+void moog_prefix_check_launch(const PCArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(moog_prefix_check_kernel, dim3((unsigned)a.n_envs), dim3(64), 0, stream, a);
+}
+
 void moog_crop_launch(const uint8_t* in, uint8_t* out, size_t rows, int in_stride, int row_bytes, hipStream_t stream) {
   hipLaunchKernelGGL(moog_crop_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, in, out, rows, in_stride, row_bytes);
 }

@@ -507,6 +507,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   if (benv >= a.n_envs) return;
   const int tile_id = block - benv * tiles;
   const int env = env_of_block >= 0 ? env_of_block : benv;
+  if (a.build && a.env_build && a.env_build[env] == 0) return;   // (per-env prefix: this env's picture is up to date)
   const int band = tile_id / a.tiles_x;
   PProg P = as_const_prog(a.P);
   const int WF = a.canvas_w, H = a.canvas_h;   // the whole canvas (anti_aliasing x the observation)
@@ -563,14 +564,19 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
     if (ie < n_entries && (ie & 63) < (int)reinterpret_cast<const uint8_t*>(dl + 4)[ie >> 6]) en = entry_of(dl, ie);
     return en;
   };
-  if (DL) en_next = load_entry(tid);
-  else if (tid < TOTV) {
-    vi_next = a.vinfo[tid];
-    v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * tid);
-  }
   // static prefix: this thread's share of the comparison with the reference record
-  const int NS = a.build ? 0 : a.n_static;
+  const bool per_env = a.sbg_env_stride != 0;   // the env's own picture, validated by the check launch: nothing to compare here
+  const int NS = (a.build || per_env) ? 0 : a.n_static;
+  const int NSE = (per_env && !a.build) ? a.n_static : 0;   // slots that are in the env's picture: dead as far as this frame goes
+  // ... and whole rounds of them are left out of the per-slot and per-vertex loops (their vertex slots are the record's first)
+  const int S0 = DL ? 0 : (NSE & ~63), V0 = (DL || NSE == 0) ? 0 : ((int)a.nsv / R_THREADS) * R_THREADS;
+  const uint8_t* sbg = a.sbg + (size_t)env * a.sbg_env_stride;
   bool st_bad = false;
+  if (DL) en_next = load_entry(tid);
+  else if (V0 + tid < TOTV) {
+    vi_next = a.vinfo[V0 + tid];
+    v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (V0 + tid));
+  }
   // ---- 0: clear the per-item tables and the row records ---------------------------------
   for (int i = tid; i < items; i += R_THREADS) { item_y[2 * i] = 0x7fffffff; item_y[2 * i + 1] = -0x7fffffff; }
   for (int i = tid; i < items * hwords; i += R_THREADS) headmask[i] = 0u;
@@ -581,7 +587,11 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   }
   if (tid < 8) misc[tid] = 0;   // ([5]: some thread found the static prefix different from the reference)
   // per-sprite colour (the last wave: it has the fewest vertices to convert)
-  for (int s = tid - (R_THREADS - 64); s >= 0 && s < S; s += 64) {
+  for (int s = tid; s < S0; s += R_THREADS) {   // (slots of the env's picture: no vertices, no colour)
+    pbase[s] = P->slot_voff[s];
+    for (int c = 0; c < ncopy; ++c) item_rgba[s * ncopy + c] = 0u;
+  }
+  for (int s = S0 + tid - (R_THREADS - 64); s >= S0 && s < S; s += 64) {
     // (every load of the slot goes out at once: one trip to HBM, not one per dependent step)
     // (DL: a slot is alive when the draw list has an item for it; its vertex count comes with its first entry)
     const unsigned s2i = DL ? (unsigned)reinterpret_cast<const uint8_t*>(dl + 12)[s] : 0u;
@@ -589,7 +599,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
     const int nvs = DL ? 0 : gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
     const double* col = gf + a.L.o_color + 3 * s;
     const double c0 = col[0], c1 = col[1], c2 = col[2];
-    const bool alive = (flags & MOOG_F_ALIVE) != 0 && !(a.build && s >= a.n_static);
+    const bool alive = (flags & MOOG_F_ALIVE) != 0 && !(a.build && s >= a.n_static) && s >= NSE;
     if (DL && s < NS) {
       const double* rc = a.sref_col + 3 * s;
       st_bad = st_bad || s2i != (unsigned)s || opa != a.sref_opa[s] ||
@@ -661,10 +671,10 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
       if (k == 0) atomicOr(reinterpret_cast<unsigned*>(&pbase[s]), ((en.y >> 16) & 255u) << 20);
     }
   } else
-  for (int idx = tid; idx < TOTV; idx += R_THREADS) {
+  for (int idx = V0 + tid; idx < TOTV; idx += R_THREADS) {
     const unsigned vi = vi_next;
     const double2 v = v_next;
-    if (idx == tid) vi_keep0 = vi; else if (idx == tid + R_THREADS) vi_keep1 = vi;
+    if (idx == V0 + tid) vi_keep0 = vi; else if (idx == V0 + tid + R_THREADS) vi_keep1 = vi;
     if (idx + R_THREADS < TOTV) {   // the next round's loads
       vi_next = a.vinfo[idx + R_THREADS];
       v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (idx + R_THREADS));
@@ -692,12 +702,12 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   __syncthreads();
   if (a.debug_stop == 2) return;
   // slots below s_lo are already in the cached picture
-  const int s_lo = (NS > 0 && misc[5] == 0) ? NS : 0;
+  const int s_lo = per_env ? NSE : ((NS > 0 && misc[5] == 0) ? NS : 0);
 
   // ---- 2b: the edge leaving every vertex (ImagingDrawPolygon: add_edge + merge of
   //          horizontal runs); table edges and horizontal heads join the compact list
   for (int c = 0; c < ncopy; ++c) {
-    for (int base0 = 0; base0 < (DL ? n_entries : TOTV); base0 += R_THREADS) {
+    for (int base0 = V0; base0 < (DL ? n_entries : TOTV); base0 += R_THREADS) {
       int idx = base0 + tid;
       int kind = 0;   // 1 table edge, 2 horizontal head
       unsigned vi = 0u;
@@ -705,7 +715,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
         vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : 0u);
         if (base0 >= 2 * R_THREADS) { const uint2 en = load_entry(idx); vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u; }
         idx = (vi >> 31) ? (pbase[vi & 0xffu] & 0xfffff) + (int)((vi >> 8) & 0xffu) : TOTV;   // the vertex slot of the entry
-      } else if (idx < TOTV) vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : a.vinfo[idx]);
+      } else if (idx < TOTV) vi = base0 == V0 ? vi_keep0 : (base0 == V0 + R_THREADS ? vi_keep1 : a.vinfo[idx]);
       if (idx < TOTV) {
         int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
         int nv = pbase[s] >> 20;
@@ -1048,7 +1058,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
         bool any = false;
         for (int iw = 0; iw < iwords; ++iw) any = any || segitems[seg * iwords + iw] != 0u;
         if (!any) {
-          const uint4* src = reinterpret_cast<const uint4*>(a.sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3);
+          const uint4* src = reinterpret_cast<const uint4*>(sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3);
           const uint4 c0 = src[0], c1 = src[1], c2 = src[2];
           dst[0] = c0; dst[1] = c1; dst[2] = c2;
           continue;
@@ -1059,7 +1069,7 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
 #pragma unroll
         for (int i = 0; i < 16; ++i) px[i] = bgx;
       } else {  // continue from the previous pass, or from the cached picture of the static prefix
-        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(a.sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3) : dst;
+        const uint4* src = from_cache ? reinterpret_cast<const uint4*>(sbg + ((size_t)(a.flip ? H - 1 - y : y) * WF + xoff + x0) * 3) : dst;
         uint4 q0 = src[0], q1 = src[1], q2 = src[2];
         unsigned d[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 #pragma unroll

@@ -158,6 +158,13 @@ class BatchedEnvironment(object):
         return dict(on=bool(on.value), fills=int(st[0]), adopted=int(st[1]), in_place=int(st[2]), rejected=int(st[3]),
                     waited=int(st[4]))
 
+    @property
+    def env_prefix_slots(self):
+        """Leading sprite slots the rasteriser keeps in a cached picture per env (moog_engine_env_prefix); 0: unused."""
+        v = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_env_prefix(self._handle, ctypes.byref(v)))
+        return int(v.value)
+
     @staticmethod
     def allocate_buffers(torch, L, P, n, device):
         """The state records and step outputs of n envs (the engine borrows their device pointers)."""

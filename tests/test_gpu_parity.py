@@ -141,7 +141,10 @@ def test_engine_vs_oracle_own_rng(name):
     records bit-exact, floats <= 1e-9, frames bit-exact from the engine state."""
     import torch
     n, steps = 64, 24
-    env = make_env(name, n, seed=11, env_index0=1000)
+    # (the recipes' own LAYER_CAPACITY values are the ones the reference fixtures were recorded with: one env; 64 envs of
+    #  random play ask for more room in the layers rules append to)
+    kw = {'layer_capacity': {'prey': 24, 'predators': 24}} if name == 'rules_zoo_l1' else {}
+    env = make_env(name, n, seed=11, env_index0=1000, **kw)
     o = helpers.OracleEnv(env.compiled, n_envs=n, seed=11, env_index0=1000)
     env.reset()
     o.reset(render=False)
@@ -704,6 +707,47 @@ def test_reset_pool_is_result_neutral(name, n, steps, min_episodes):
                 k, part, np.nonzero(got[k][part] != want[k][part])[0][:8], gstats)
     for key in wobs:
         assert np.array_equal(gobs[key], wobs[key], equal_nan=True), (key, gstats)
+
+
+@pytest.mark.parametrize('name,n,steps,walls,edit', [('pacman', 48, 70, 136, 100), ('maze_zoo', 96, 60, None, 20),
+                                                     ('pacman_l1', 32, 40, None, 3)])
+def test_env_prefix_frames_equal(name, n, steps, walls, edit, monkeypatch):
+    """Per-env prefix of the rasteriser (moog_engine_env_prefix): every env's leading sprites that stay put within an episode
+    (a random maze's walls) live in a cached picture of the env's own.  EVERY frame of every call -- across resets, while
+    food is being eaten (which shortens the prefix to the walls), after a record was edited behind the engine's back --
+    equals the frame of an engine that draws every sprite every time."""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(3)
+
+    def run(on):
+        monkeypatch.setenv('MOOG_RASTER_ENV_BG', '1' if on else '0')
+        env = make_env(name, n, seed=5)
+        env.check_faults = False
+        grid = env._is_grid
+        gg = torch.Generator(device='cpu').manual_seed(3)
+        frames = [env.reset().observation['image'].cpu().numpy().copy()]
+        slots = [env.env_prefix_slots]
+        L = env.layout
+        for k in range(steps):
+            a = (torch.randint(0, 5, (n,), generator=gg, dtype=torch.int32) if grid
+                 else torch.rand((n, 2), generator=gg, dtype=torch.float64) * 2 - 1)
+            if k == steps // 2:   # a wall of some envs recoloured by hand: their pictures are stale
+                env.state_f64[::7, L.o_color + 3 * edit + 1] += 0.125
+            if k == steps // 2 + 5:
+                env.reset(torch.arange(n) % 5 == 0)
+            frames.append(env.step(a).observation['image'].cpu().numpy().copy())
+            slots.append(env.env_prefix_slots)
+        env.close()
+        return frames, slots
+
+    want, s0 = run(False)
+    got, s1 = run(True)
+    assert max(s0) == 0
+    if walls is not None:   # the prefix settles on the walls (food gets eaten, ghosts move), then ends at the sprite that was edited
+        assert s1[steps // 2 - 1] == walls and s1[-1] == edit, s1
+    for k in range(len(want)):
+        assert np.array_equal(got[k], want[k]), 'frame of call %d differs in envs %s (prefix %s)' % (
+            k, np.nonzero((got[k] != want[k]).reshape(n, -1).any(1))[0][:8], s1[k])
 
 
 def test_layer_capacity_auto_grows_transparently():

@@ -55,9 +55,9 @@ open(os.path.join(P, 'r04_bench_configs.txt'), 'w').write('''# r04: python tools
 # reset, 5 warm-up calls, then 30 / 60 / 10 timed calls with random actions; step / raster / reset = HIP-event kernel times of those calls.
 # (early in a lock-step episode -- not the stationary mix of bench.py: the headline's 4.1 M here is 5.4 M there.)
 # Against profiles/r03_bench_configs.txt: the collision path's work of this round (DESIGN 3.1) shows in every config that collides;
-# the configs whose resets play physics forward (bounce_box_contact_prediction, red_green) did NOT get faster -- their kernels are the
-# variants that carry every component, whose rarely used paths stay calls (DESIGN 3.1 "what stays out of line") -- VERDICT r03 item 4
-# (a reset pool filled by a background kernel) is designed in DESIGN 9 and not built.
+# the configs whose resets play physics forward (bounce_box_contact_prediction, red_green) run with the reset pool (DESIGN 3.2,
+# profiles/r04_reset_pool.txt has the A/B runs; round 3: 87 k / 38 k env-steps/s), pacman with the per-env prefix (DESIGN 3.3,
+# profiles/r04_env_prefix.txt).  bench_configs.py does not synchronise between calls: the host runs far ahead of the device.
 ''' + rd('bench_configs.txt'))
 open(os.path.join(P, 'r04_bench_ranks.txt'), 'w').write('''# r04: bash tools/bench_ranks.sh on a 1-GPU MI355X box: bench.py's multi-rank path (shard offsets, barrier, MAX over ranks, one JSON
 # line from rank 0) with two ranks sharing cuda:0 over gloo, for the headline config and BASELINE config 5; the device count the
@@ -126,3 +126,20 @@ open(os.path.join(P, 'r04_heavy_pmc.txt'), 'w').write('''# r04: bash tools/r04_h
 open(os.path.join(P, 'r04_runtime_benchmark_phases.txt'), 'w').write('''# r04: moog_demos/runtime_benchmark.py (the counterpart of the reference's tests/runtime_benchmark.py) on MI355X, final build
 ''' + rd('runtime_benchmark.txt'))
 print(hdr)
+
+if os.path.exists(os.path.join(o, 'reset_pool.txt')):
+    open(os.path.join(P, 'r04_reset_pool.txt'), 'w').write('''# r04: python tools/pool_bench.py 1024 4096 on MI355X, final build -- the reset pool (DESIGN 3.2, moog_engine_set_reset_pool) off and
+# on ('auto') for the two reference configs whose state_initializer plays the episode forward.  Wall-clock env-steps/s of 60 (off) /
+# 600 (on) calls with random actions after a warm-up, frames drawn, no synchronisation between calls.  The dict is the engine's own
+# count (moog_engine_get_reset_pool): fill launches, episodes opened from the pool, episodes opened by a reset inside the step kernel,
+# pool records rejected by the input check, take-overs that had to wait for a fill under way.
+''' + rd('reset_pool.txt'))
+if os.path.exists(os.path.join(o, 'env_prefix.txt')):
+    open(os.path.join(P, 'r04_env_prefix.txt'), 'w').write('''# r04: python tools/dbg/pacman_bench.py on MI355X, final build -- the rasteriser's per-env prefix (DESIGN 3.3, moog_engine_env_prefix) forced
+# off (MOOG_RASTER_ENV_BG=0) and on (=1) for the configs with many at-rest sprites that differ from env to env (bench_configs.py's
+# measurement: kernel times by HIP events).  Forced on, the one-tile configs lose the two extra launches' 0.09 ms and gain nothing:
+# the engine's default uses the prefix for multi-tile frames only (pacman).  Band heights for pacman's 256 x 256 frames
+# (MOOG_RASTER_BAND_H, raster launch per 4096 frames with / without the prefix): 64 rows 1.73 / 2.51 ms, 128 rows 2.06 / 2.86 ms,
+# 256 rows 1.65 / 2.45 ms.  Phases of the launch with the prefix settled at 136 slots (tools/raster_phases.py pacman, kernel
+# truncated after each phase, us): tables + colours 215, vertices 379, edges + scans 653, rows 996, spans 1211, compose 1649.
+''' + rd('env_prefix.txt'))

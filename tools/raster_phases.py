@@ -8,8 +8,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "colliding_predators_32"
 kw = dict(image_size=(int(sys.argv[2]),) * 2) if len(sys.argv) > 2 else {}
 env = environment.BatchedEnvironment(num_envs=4096, seed=1, **(__import__("moog_demos.example_configs." + name, fromlist=["x"]).get_config(0, **kw) if kw else example_configs.load(name)))
 env.reset()
-for _ in range(3):
+for _ in range(int(os.environ.get('MOOG_WARM_STEPS', '3'))):
     env.step(env.random_action())
+    torch.cuda.synchronize()   # (the per-env prefix settles from what the host has seen of earlier calls)
+print('per-env prefix slots:', env.env_prefix_slots)
 for stop in [int(x) for x in os.environ.get('MOOG_RASTER_STOPS', '1,2,3,4,5,0').split(',')]:
     env.set_debug(0, stop)
     for _ in range(3):
