@@ -768,10 +768,11 @@ int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled);
  * own segment of the env's stream (counter = episode << 32 | draw), and what else a reset reads -- the sprites built
  * outside the initializer (slot_persist) -- is compared with the live record when the pool's record is taken over; a
  * record that does not match (the host reset the env or loaded a state meanwhile) is dropped and the env is reset in
- * place.  An env whose record is not ready when its episode ends waits for a fill that is under way, or is reset in
- * place.  Not available (MOOG_E_UNSUPPORTED): programs of the plain kernels (their resets are cheap), programs with a
+ * place.  The pool is two episodes deep (records for the next episode and the one after it: an episode shorter than a fill
+ * does not stall the call it ends in).  An env whose record is not ready when its episode ends waits for a fill that is
+ * under way, or is reset in place.  Not available (MOOG_E_UNSUPPORTED): programs of the plain kernels (their resets are cheap), programs with a
  * MOOG_CELL_PSTATE op (the reset depends on the episode that has just ended), a runtime that serialises kernels.
- * Calls with injected uniforms never use the pool.  Costs 2 records per env of device memory.
+ * Calls with injected uniforms never use the pool.  Costs 4 records per env of device memory.
  * moog_engine_get_reset_pool: whether it is on, and (synchronising the device) stats[5] = fill launches so far, episodes
  * opened from the pool, episodes opened by a reset in place, pool records rejected, take-overs that had to wait for a fill. */
 int moog_engine_set_reset_pool(moog_engine_t* e, int32_t enabled);

@@ -98,10 +98,12 @@ struct moog_engine {
   static constexpr int POOL_STREAMS = 8;
   int pool_streams = 2;   // the ones in use: hardware queues the runtime has (GPU_MAX_HW_QUEUES, default 4) minus the caller's and the sort's
   bool pool_on = false, pool_ready = false;
-  int32_t* pool_state = nullptr;   // [n_envs] 0 empty / 1 being filled / 2 ready
-  int32_t* pool_tag = nullptr;     // [n_envs] episode of the pool record
+  int pool_depth = 2;              // records per env: the next episode and the one after (an episode shorter than a fill does not stall its call)
+  int32_t* pool_state = nullptr;   // [pool_depth][n_envs] 0 empty / 3 claimed / 1 being filled / 2 ready
+  int32_t* pool_tag = nullptr;     // [pool_depth][n_envs] episode of the pool record
+  int32_t* pool_lock = nullptr;    // [n_envs] 4 while the step kernel opens an episode of the env
   unsigned long long* pool_stats = nullptr;   // [4] KArgs::pool_stats
-  double* pool_f64[2] = {nullptr, nullptr};   // [n_envs][f64_per_env]: the fill's inputs, the record after its reset
+  double* pool_f64[2] = {nullptr, nullptr};   // [pool_depth][n_envs][f64_per_env]: the fill's inputs, the record after its reset
   int32_t* pool_i32[2] = {nullptr, nullptr};
   hipStream_t pool_stream[POOL_STREAMS] = {};   // fills run here, call k's on stream k % pool_streams
   hipEvent_t ev_pool = nullptr;    // the call a fill follows
@@ -164,6 +166,7 @@ static void free_engine(moog_engine* e) {
   if (e->pe_min) hipHostFree(e->pe_min);
   if (e->pool_state) hipFree(e->pool_state);
   if (e->pool_tag) hipFree(e->pool_tag);
+  if (e->pool_lock) hipFree(e->pool_lock);
   if (e->pool_stats) hipFree(e->pool_stats);
   for (int k = 0; k < 2; ++k) { if (e->pool_f64[k]) hipFree(e->pool_f64[k]); if (e->pool_i32[k]) hipFree(e->pool_i32[k]); }
   if (e->watch) hipFree(e->watch);
@@ -752,6 +755,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.fops = e->d_fops; a.n_fops = e->n_fops;
   const bool pool = e->pool_on && mode == MODE_STEP && !(inj && inj->uniforms);
   a.pool_state = pool ? e->pool_state : nullptr; a.pool_tag = e->pool_tag; a.pool_stats = e->pool_stats;
+  a.pool_lock = e->pool_lock; a.pool_depth = e->pool_depth;
   for (int k = 0; k < 2; ++k) { a.pool_f64[k] = e->pool_f64[k]; a.pool_i32[k] = e->pool_i32[k]; }
   a.live_f64 = nullptr; a.live_i32 = nullptr;
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
@@ -895,7 +899,7 @@ static int pool_kick(moog_engine* e, hipStream_t s) {
   a.pool_state = e->pool_state;
   a.fault_flag = nullptr;   // (a fault of the pool's record reaches the host when the record is adopted and stored)
   a.dbg = 0;
-  moog_launch_reset_full(e->n_envs, e->step_lds, ps, a);
+  moog_launch_reset_full(e->n_envs * e->pool_depth, e->step_lds, ps, a);   // one workgroup per (record, env)
   HIPCHK(hipGetLastError());
   ++e->pool_fills;
   return MOOG_OK;
@@ -904,7 +908,8 @@ static int pool_kick(moog_engine* e, hipStream_t s) {
 // every pool record is dropped (the host reset the envs, or handed other records over): fills under way finish first
 static int pool_drop(moog_engine* e, hipStream_t s) {
   for (int k = 0; k < e->pool_streams; ++k) HIPCHK(hipStreamSynchronize(e->pool_stream[k]));
-  HIPCHK(hipMemsetAsync(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs, s));
+  HIPCHK(hipMemsetAsync(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs * e->pool_depth, s));
+  HIPCHK(hipMemsetAsync(e->pool_lock, 0, sizeof(int32_t) * (size_t)e->n_envs, s));
   return MOOG_OK;
 }
 
@@ -1084,9 +1089,11 @@ int moog_engine_set_reset_pool(moog_engine_t* e, int32_t enabled) {
       return fail(MOOG_E_UNSUPPORTED, "the reset pool needs kernels to run beside each other (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING / GPU_MAX_HW_QUEUES=1 / counter collection serialise them)");
   }
   if (!e->pool_ready) {
-    const size_t n = (size_t)e->n_envs;
+    { const char* pd = getenv("MOOG_POOL_DEPTH"); if (pd && atoi(pd) >= 1 && atoi(pd) <= 4) e->pool_depth = atoi(pd); }   // experiments
+    const size_t n = (size_t)e->n_envs * e->pool_depth;
     if (!e->pool_state) HIPCHK(hipMalloc(&e->pool_state, sizeof(int32_t) * n));
     if (!e->pool_tag) HIPCHK(hipMalloc(&e->pool_tag, sizeof(int32_t) * n));
+    if (!e->pool_lock) HIPCHK(hipMalloc(&e->pool_lock, sizeof(int32_t) * (size_t)e->n_envs));
     if (!e->pool_stats) { HIPCHK(hipMalloc(&e->pool_stats, 4 * sizeof(unsigned long long))); HIPCHK(hipMemset(e->pool_stats, 0, 4 * sizeof(unsigned long long))); }
     for (int k = 0; k < 2; ++k) {
       if (!e->pool_f64[k]) HIPCHK(hipMalloc(&e->pool_f64[k], sizeof(double) * n * (size_t)e->L.f64_per_env));
@@ -1104,8 +1111,9 @@ int moog_engine_set_reset_pool(moog_engine_t* e, int32_t enabled) {
     if (!e->ev_pool) HIPCHK(hipEventCreateWithFlags(&e->ev_pool, hipEventDisableTiming));
     e->pool_ready = true;
   }
-  HIPCHK(hipMemset(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs));
-  HIPCHK(hipMemset(e->pool_tag, 0, sizeof(int32_t) * (size_t)e->n_envs));
+  HIPCHK(hipMemset(e->pool_state, 0, sizeof(int32_t) * (size_t)e->n_envs * e->pool_depth));
+  HIPCHK(hipMemset(e->pool_tag, 0, sizeof(int32_t) * (size_t)e->n_envs * e->pool_depth));
+  HIPCHK(hipMemset(e->pool_lock, 0, sizeof(int32_t) * (size_t)e->n_envs));
   e->pool_on = true;
   return MOOG_OK;
 }

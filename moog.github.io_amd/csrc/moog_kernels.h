@@ -173,8 +173,11 @@ struct KArgs {
   int32_t watch_off;     // byte offset of the watcher's words in the workgroup's LDS
   // reset pool (moog_engine_set_reset_pool; the kernels that carry every component only): per env one record of the NEXT
   // episode, built by a fill launch (MODE_FILL) beside the step kernels and adopted by the step kernel when the episode ends
-  int32_t* pool_state;   // [n_envs] 0 empty, 1 being filled, 2 ready; null: no pool
-  int32_t* pool_tag;     // [n_envs] the episode (high word of the draw counter) the pool record opens
+  // pool_depth records per env, record (d, env) at index d * n_envs + env of every pool array
+  int32_t* pool_state;   // 0 empty, 3 claimed (no tag yet), 1 being filled, 2 ready; null: no pool
+  int32_t* pool_tag;     // the episode (high word of the draw counter) the record opens
+  int32_t* pool_lock;    // [n_envs] 4 while the step kernel is opening an episode of the env (fills keep off), else 0
+  int32_t pool_depth;
   double* pool_f64[2];   // [0] the record as the fill read it (the reset's inputs are validated against it), [1] the record after
   int32_t* pool_i32[2];  //     the reset; same layout and strides as the live records
   unsigned long long* pool_stats;   // [4] episodes opened from the pool / by a reset in place / pool records rejected / adoptions that waited for a fill
@@ -299,49 +302,61 @@ __device__ inline void pool_copy_record(const moog_layout_t& G, int lane, const 
   for (int i = lane; i < G.i32_per_env / 4; i += 64) d[i] = c[i];
 }
 
-// Step kernel, an env whose episode has ended, its live record staged in LDS: takes the pool's record over when it is
-// ready (waiting for a fill that is under way: its wave is resident and shorter than a reset from scratch), opens the
-// episode the live record expects and was built from the inputs the live record holds now.  true: the record in LDS (and
-// the fields that live in HBM only) are the new episode's; false: the caller resets in place.
-// *held: the env's flag is 4 now -- no fill may claim the env before the new episode's record is in memory (a fill that
-// copied the old episode's record would build the episode that is just starting once more, for the next take-over to
-// reject); the caller hands the flag back with pool_release after store_record.
+// Step kernel, an env whose episode has ended, its live record staged in LDS: takes over the pool record that opens the
+// episode the live record expects, when there is one (waiting for a fill of it that is under way: its wave is resident and
+// shorter than a reset from scratch) and it was built from the inputs the live record holds now.  true: the record in LDS
+// (and the fields that live in HBM only) are the new episode's; false: the caller resets in place.
+// The env's lock is taken first (*held) and handed back by pool_release once the new episode's record is in memory: a fill
+// that copied the record in between would read the episode that has just ended.
 __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, int32_t* gq, int* held) {
   *held = 0;
   if (!a.pool_state || e.inj) return false;
-  int st = 0, waited = 0;
+  *held = 1;
+  const unsigned episode = (unsigned)e.q[e.L.o_rng + 1] + 1u;
+  int pick = -1, waited = 0;
   if (e.lane == 0) {
-    for (int spins = 0; spins < 400000; ++spins) {   // (a bound, not a protocol: a few tenths of a second)
-      st = __hip_atomic_load(&a.pool_state[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (st == 1) { waited = 1; __builtin_amdgcn_s_sleep(32); continue; }
-      if (st == 0) {   // nothing built, nothing under way: keep the fills out and reset in place
-        int expect = 0;
-        if (__hip_atomic_compare_exchange_strong(&a.pool_state[env], &expect, 4, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT)) { st = 4; break; }
-        continue;   // (a fill claimed the env this instant: wait for it)
+    __hip_atomic_store(&a.pool_lock[env], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int d = 0; d < a.pool_depth; ++d) {
+      int32_t* sp = &a.pool_state[(size_t)d * a.n_envs + env];
+      int st = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; st == 3 && spins < 100000; ++spins) {   // (claimed this instant: its tag is a few stores away)
+        __builtin_amdgcn_s_sleep(2);
+        st = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      break;
+      if (st != 1 && st != 2) continue;
+      const unsigned tag = (unsigned)__hip_atomic_load(&a.pool_tag[(size_t)d * a.n_envs + env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tag == episode) { if (pick < 0) pick = d; }
+      else if (st == 2 && (int)(tag - episode) < 0)   // an episode that has passed (the host reset the env, or a late fill)
+        __hip_atomic_store(sp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (pick >= 0) {
+      int32_t* sp = &a.pool_state[(size_t)pick * a.n_envs + env];
+      int st = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spins = 0; st == 1 && spins < 400000; ++spins) {   // (a bound, not a protocol: a few tenths of a second)
+        waited = 1;
+        __builtin_amdgcn_s_sleep(32);
+        st = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (st != 2) pick = -1;   // (it will raise its flag later, for an episode that will have passed by then)
     }
   }
-  st = __shfl(st, 0);
+  pick = __shfl(pick, 0);
   waited = __shfl(waited, 0);
-  if (st != 2) {   // 4: ours, empty.  1: a fill that did not finish in time -- its record, for an episode that will have passed, gets rejected later
-    *held = st == 4;
+  if (pick < 0) {
     if (e.lane == 0) atomicAdd(&a.pool_stats[1], 1ull);
     return false;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  const size_t fo = (size_t)env * a.L.f64_per_env, qo = (size_t)env * a.L.i32_per_env;
-  const double* pre_f = a.pool_f64[0] + fo; const int32_t* pre_q = a.pool_i32[0] + qo;
-  const double* post_f = a.pool_f64[1] + fo; const int32_t* post_q = a.pool_i32[1] + qo;
-  const unsigned episode = (unsigned)e.q[e.L.o_rng + 1] + 1u;
-  bool ok = (unsigned)a.pool_tag[env] == episode;
-  ok = ok && pool_inputs_equal(e, a.L, pre_f, pre_q, gf, gq);
+  const size_t rec = (size_t)pick * a.n_envs + env;
+  const double* pre_f = a.pool_f64[0] + rec * a.L.f64_per_env; const int32_t* pre_q = a.pool_i32[0] + rec * a.L.i32_per_env;
+  const double* post_f = a.pool_f64[1] + rec * a.L.f64_per_env; const int32_t* post_q = a.pool_i32[1] + rec * a.L.i32_per_env;
+  const bool ok = pool_inputs_equal(e, a.L, pre_f, pre_q, gf, gq);
   wsync();
-  if (e.lane == 0) __hip_atomic_store(&a.pool_state[env], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  *held = 1;
-  if (!ok) {   // stale: the host edited the records, or something changed a kept sprite after the fill read it
-    if (e.lane == 0) { atomicAdd(&a.pool_stats[1], 1ull); atomicAdd(&a.pool_stats[2], 1ull); }
+  if (!ok) {   // stale: something changed a kept sprite after the fill read it
+    if (e.lane == 0) {
+      __hip_atomic_store(&a.pool_state[rec], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&a.pool_stats[1], 1ull); atomicAdd(&a.pool_stats[2], 1ull);
+    }
     return false;
   }
   // what outlives a reset: sticky fault bits, the state slots (never reset; a reset that reads one is not eligible)
@@ -359,20 +374,22 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
     e.f[e.L.o_rule + e.lane] = keep;
     if (e.L.o_rule2 >= 0) e.f[e.L.o_rule2 + e.lane] = keep2;
   }
+  wave_global_fence();
+  wsync();
   if (e.lane == 0) {
     e.q[e.L.o_fault] |= fault;
+    __hip_atomic_store(&a.pool_state[rec], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the lock keeps the fills off the env)
     atomicAdd(&a.pool_stats[0], 1ull);
     if (waited) atomicAdd(&a.pool_stats[3], 1ull);
   }
-  wave_global_fence();
   wsync();
   return true;
 }
 
-// the new episode's record is stored: fills may claim the env again (they read the record from memory: this XCD's L2 first)
+// the new episode's record is stored: fills may read the env again (from memory: this XCD's L2 first)
 __device__ inline void pool_release(const KArgs& a, int env, int lane) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(&a.pool_state[env], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(&a.pool_lock[env], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #else
 __device__ __forceinline__ bool pool_adopt(Env&, const KArgs&, int, double*, int32_t*, int* held) { *held = 0; return false; }
@@ -385,34 +402,78 @@ __device__ __forceinline__ void pool_release(const KArgs&, int, int) {}
 template <int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
 __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   int env = blockIdx.x;
-  if (env >= a.n_envs) return;
-  int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  if (a.mask != nullptr && a.mask[env] == 0) return;
-  double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
 #if MOOG_WITH_MAZE
-  if (a.mode == MODE_FILL) {   // reset pool: a.f64 / a.i32 are the pool's records; claim the env, copy its live record, reset the copy
+  const int pool_d = a.mode == MODE_FILL ? env / a.n_envs : 0;   // reset pool: one workgroup per (record, env)
+  if (a.mode == MODE_FILL) env -= pool_d * a.n_envs;
+  const size_t rec = (size_t)pool_d * a.n_envs + env;
+#else
+  const size_t rec = (size_t)env;
+#endif
+  if (env >= a.n_envs) return;
+  int32_t* gq = a.i32 + rec * a.L.i32_per_env;
+  if (a.mask != nullptr && a.mask[env] == 0) return;
+  double* gf = a.f64 + rec * a.L.f64_per_env;
+#if MOOG_WITH_MAZE
+  if (a.mode == MODE_FILL) {   // a.f64 / a.i32 are the pool's records: claim record pool_d of the env, copy the live record, reset the copy
+    if (pool_d >= a.pool_depth) return;
+    const int32_t* lq = a.live_i32 + (size_t)env * a.L.i32_per_env;
     int won = 0;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && __hip_atomic_load(&a.pool_lock[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      bool lower_busy = true;   // the records of an env fill in order: a later one waits for the earlier ones to have been claimed
+      for (int d = 0; d < pool_d; ++d)
+        lower_busy = lower_busy && __hip_atomic_load(&a.pool_state[(size_t)d * a.n_envs + env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
       int expect = 0;
-      won = __hip_atomic_compare_exchange_strong(&a.pool_state[env], &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+      won = lower_busy && __hip_atomic_compare_exchange_strong(&a.pool_state[rec], &expect, 3, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
     }
     if (!__shfl(won, 0)) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double* lf = a.live_f64 + (size_t)env * a.L.f64_per_env;
-    const int32_t* lq = a.live_i32 + (size_t)env * a.L.i32_per_env;
     // (the step kernels may be storing this record right now: what the reset reads of it is validated when the record is
     //  adopted, pool_adopt; the rest it overwrites)
-    pool_copy_record(a.L, (int)threadIdx.x, lf, lq, a.pool_f64[0] + (size_t)env * a.L.f64_per_env,
-                     a.pool_i32[0] + (size_t)env * a.L.i32_per_env);
-    pool_copy_record(a.L, (int)threadIdx.x, a.pool_f64[0] + (size_t)env * a.L.f64_per_env,
-                     a.pool_i32[0] + (size_t)env * a.L.i32_per_env, gf, gq);
+    pool_copy_record(a.L, (int)threadIdx.x, lf, lq, a.pool_f64[0] + rec * a.L.f64_per_env, a.pool_i32[0] + rec * a.L.i32_per_env);
+    pool_copy_record(a.L, (int)threadIdx.x, a.pool_f64[0] + rec * a.L.f64_per_env, a.pool_i32[0] + rec * a.L.i32_per_env, gf, gq);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int go = 0;
+    if (threadIdx.x == 0) {
+      // the episode this record opens: the next one the live record expects that no other record of the env holds or is being
+      // filled for (a later record waits for an earlier one's tag; an earlier one does not wait for a later one)
+      const unsigned ep_live = (unsigned)gq[a.L.o_rng + 1];
+      unsigned target = ep_live + 1u;
+      for (int round = 0; round < a.pool_depth; ++round)
+        for (int d = 0; d < a.pool_depth; ++d) {
+          if (d == pool_d) continue;
+          const size_t o = (size_t)d * a.n_envs + env;
+          int st = __hip_atomic_load(&a.pool_state[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int spins = 0; st == 3 && d < pool_d && spins < 100000; ++spins) {
+            __builtin_amdgcn_s_sleep(2);
+            st = __hip_atomic_load(&a.pool_state[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if ((st == 1 || st == 2) &&
+              (unsigned)__hip_atomic_load(&a.pool_tag[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == target) ++target;
+        }
+      __hip_atomic_store(&a.pool_tag[rec], (int32_t)target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.pool_state[rec], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // the copy is of a record that was not being replaced: the lock is free and the live record still says the same episode
+      const bool stable = __hip_atomic_load(&a.pool_lock[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+                          (unsigned)__hip_atomic_load(&lq[a.L.o_rng + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ep_live;
+      if (stable) { gq[a.L.o_rng + 1] = (int32_t)(target - 1u); go = 1; }   // (env_reset opens the next segment)
+      else __hip_atomic_store(&a.pool_state[rec], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!__shfl(go, 0)) return;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
 #endif
   Env e;
   bind_env(e, a, env);
+#if MOOG_WITH_MAZE
+  if (a.mode == MODE_FILL) {   // (the fields the kernels keep in HBM: this record's, not record 0's)
+    if (a.H.f_cut1 > a.H.f_cut0) e.gcol = gf + a.L.o_color;
+    if (a.H.i_cut1 > a.H.i_cut0) { e.gopa = gq + a.L.o_opacity; e.gshape = gq + a.L.o_shape; e.gtele = gq + a.L.o_tele; }
+  }
+#endif
   load_record(e, a.H, a.L, gf, gq);
   if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
   wsync();
@@ -421,13 +482,9 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
 #if MOOG_WITH_MAZE
   if (a.mode == MODE_FILL) {
     if (e.lane == 0) e.q[e.L.o_reset_next] = 0;
-    const int32_t tag = e.q[e.L.o_rng + 1];
     store_record(e, a.H, a.L, gf, gq, nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record (and what the reset wrote straight to HBM) before the flag
-    if (e.lane == 0) {
-      a.pool_tag[env] = tag;
-      __hip_atomic_store(&a.pool_state[env], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (e.lane == 0) __hip_atomic_store(&a.pool_state[rec], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
 #endif
