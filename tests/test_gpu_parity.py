@@ -709,6 +709,25 @@ def test_reset_pool_is_result_neutral(name, n, steps, min_episodes):
         assert np.array_equal(gobs[key], wobs[key], equal_nan=True), (key, gstats)
 
 
+def test_reset_pool_refusals():
+    """The reset pool is refused where it cannot keep its promise (moog_engine_set_reset_pool): programs of the plain kernels,
+    and programs whose initializer keeps a number across episodes (predators_arena's curriculum: the reset depends on the
+    episode that has just ended).  'auto' only asks for it where an initializer plays physics forward."""
+    from moog import _engine
+    for name in ('colliding_predators', 'predators_arena_l2'):
+        with pytest.raises(_engine.EngineError):
+            make_env(name, 8, reset_pool=True)
+        env = make_env(name, 8)   # 'auto'
+        assert not env.reset_pool['on'] and env.reset_pool_refusal is None
+        env.close()
+    env = make_env('bounce_box_contact_prediction', 8)
+    assert env.reset_pool['on']
+    env.close()
+    env = make_env('bounce_box_contact_prediction', 8, reset_pool=False)
+    assert not env.reset_pool['on']
+    env.close()
+
+
 @pytest.mark.parametrize('name,n,steps,walls,edit', [('pacman', 48, 70, 136, 100), ('maze_zoo', 96, 60, None, 20),
                                                      ('pacman_l1', 32, 40, None, 3)])
 def test_env_prefix_frames_equal(name, n, steps, walls, edit, monkeypatch):

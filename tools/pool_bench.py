@@ -26,6 +26,9 @@ def run(name, n, pool, steps, warm):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'only':   # only <config> <envs>: the pooled run alone (tools/prof_pool.sh)
+        run(sys.argv[2], int(sys.argv[3]), 'auto', 600, 100)
+        sys.exit(0)
     sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096]
     for name in ('bounce_box_contact_prediction', 'red_green_l1'):
         for n in sizes:
