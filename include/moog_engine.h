@@ -819,6 +819,14 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
  * environment turns it off, =1 on for any frame size.  Returns the number of slots it covers now (0: unused). */
 int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots);
 
+/* PILRenderer(color_to_rgb=<any callable>) (pil_renderer.py:72-76,108: the renderer calls it on every sprite's colour
+ * triple when it draws): the callable is Python and stays on the host.  The binding evaluates it once per DISTINCT colour
+ * triple (colours rarely change after a reset), keeps r | g << 8 | b << 16 per (env, sprite slot) in a device array
+ * [n_envs][n_slots] and hands the array over here; the rasteriser then takes a live sprite's colour from it instead of
+ * applying render.cmap (opacity still comes from the record).  NULL: back to render.cmap.  While set, the engine draws
+ * every sprite every frame (no cached prefix pictures) and frames do not follow their env's step. */
+int moog_engine_set_color_override(moog_engine_t* e, const uint32_t* rgb_dev);
+
 /* Profiling aids, both 0 in production (they make results wrong: timing only).  `step_debug`: bit
  * mask that switches parts of the step kernel off / writes cycle counters instead of outputs;
  * `raster_stop` = k truncates the raster kernel after phase k.  The initial values come from the

@@ -119,6 +119,7 @@ struct moog_engine {
   double* s_f64 = nullptr;
   int32_t* s_i32 = nullptr;
   uint8_t* s_bg = nullptr;
+  const uint32_t* rgb_override = nullptr;   // moog_engine_set_color_override
   // per-env prefix (RArgs::sbg_env_stride): leading sprites that stay put within an episode but differ between envs
   int pe_ns = 0, pe_nsv = 0;        // slots / vertex slots of the prefix (0: off); shrinks to the slots that really stay put
   double* pe_f64 = nullptr;         // [n_envs] snapshot of the record each env's picture was drawn from
@@ -785,7 +786,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_nv = e->s_i32 ? e->s_i32 + e->L.o_nverts : nullptr;
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
-  r.sbg_env_stride = 0; r.env_build = nullptr;
+  r.sbg_env_stride = 0; r.env_build = nullptr; r.rgb_override = e->rgb_override;
   r.dl = nullptr; r.dl_stride = e->dl_stride; r.nsl = 0; r.sref_dl = e->s_dl;
   return r;
 }
@@ -1141,6 +1142,7 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1 || e->pad_w != e->canvas_w)
     return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing, of a width that is a multiple of 16");
   if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
+  if (e->rgb_override) return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while the host supplies the sprites' colours (moog_engine_set_color_override)");
   {   // tools that run one kernel at a time (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) would leave the frames' grid
       // waiting for a step kernel that cannot start beside it; MOOG_NO_FUSED=1 is the manual switch
     const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
@@ -1218,6 +1220,16 @@ int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled) {
   if (!e || !enabled) return fail(MOOG_E_INVALID, "null argument");
   // (a call's frames that gave up waiting switch the mode off at the next call; report that already)
   *enabled = (e->fused && !(e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u)) ? 1 : 0;
+  return MOOG_OK;
+}
+
+int moog_engine_set_color_override(moog_engine_t* e, const uint32_t* rgb_dev) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  e->rgb_override = rgb_dev;
+  if (rgb_dev) {   // the cached pictures hold the colour map's colours; frames that follow their env's step would be drawn
+                   // before the host has seen the step's colours; the draw-list rasterisers have their own colour code
+    e->n_static = 0; e->pe_ns = 0; e->fused = false; e->dlist = false; e->wave = false;
+  }
   return MOOG_OK;
 }
 

@@ -90,6 +90,7 @@ struct RArgs {
   // drawn and names the envs whose picture a `build` launch has to draw again (env_build).  The frame launch then skips
   // the prefix of every env without comparing anything.
   size_t sbg_env_stride;    // bytes between the envs' pictures; 0: one picture for all (the comparison is the frame kernel's)
+  const uint32_t* rgb_override;   // [n_envs][S] r | g << 8 | b << 16 per sprite slot instead of the colour map (moog_engine_set_color_override), or null
   const int32_t* env_build; // build launches: [n_envs] 1 = draw this env's picture, 0 = the workgroup has nothing to do; null: every env
   // draw lists (moog_drawlist.h): when set, the vertices come from the env's list instead of the f64 record
   const uint32_t* dl;

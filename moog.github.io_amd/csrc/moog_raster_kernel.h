@@ -629,7 +629,10 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
     unsigned rgba = 0u;
     if (alive) {
       unsigned r8, g8, b8;
-      if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(c0, c1, c2, r8, g8, b8);
+      if (a.rgb_override) {   // the host evaluated PILRenderer(color_to_rgb=<a callable>) for this sprite's colour
+        const unsigned o = a.rgb_override[(size_t)env * S + s];
+        r8 = o & 255u; g8 = (o >> 8) & 255u; b8 = (o >> 16) & 255u;
+      } else if (P->render.cmap == MOOG_CMAP_HSV) hsv_to_rgb_u8(c0, c1, c2, r8, g8, b8);
       else { r8 = (unsigned)(int)c0 & 255u; g8 = (unsigned)(int)c1 & 255u; b8 = (unsigned)(int)c2 & 255u; }
       rgba = r8 | (g8 << 8) | (b8 << 16) | (((unsigned)opa & 255u) << 24);
     }

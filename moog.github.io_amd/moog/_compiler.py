@@ -26,7 +26,7 @@ from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
     'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index',
-                 'pstate_slots', 'dynamic_meta'])
+                 'pstate_slots', 'dynamic_meta', 'color_fn'])
 
 
 class _ShapeTable(object):
@@ -1382,7 +1382,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                  # (slot, metadata key, cell that holds the look-ahead's exit, {exit: value}) of the metadata values
                  # an initializer's look-ahead decides
                  [(slot_of[id(sp)], key, cell, table) for sp, key, cell, table in getattr(tr, 'dynamic_meta', [])
-                  if id(sp) in slot_of])
+                  if id(sp) in slot_of],
+                 # PILRenderer(color_to_rgb=<a callable>): evaluated on the host (environment.py _refresh_colors)
+                 ren.color_to_rgb if ren._cmap == 'callable' else None)
     # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
     c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
     return c

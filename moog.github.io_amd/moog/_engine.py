@@ -19,7 +19,7 @@ SYMBOLS = (
     'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
     'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
     'moog_engine_read_watch', 'moog_engine_set_reset_pool', 'moog_engine_get_reset_pool',
-    'moog_engine_env_prefix',
+    'moog_engine_env_prefix', 'moog_engine_set_color_override',
 )
 
 _LIB = None
@@ -72,6 +72,7 @@ def load_library(path=None):
     lib.moog_engine_get_fused.argtypes = [vp, ctypes.POINTER(i32)]
     lib.moog_engine_set_reset_pool.argtypes = [vp, i32]
     lib.moog_engine_env_prefix.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.moog_engine_set_color_override.argtypes = [vp, vp]
     lib.moog_engine_get_reset_pool.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
     lib.moog_engine_set_action_dtype.argtypes = [vp, i32]
     lib.moog_engine_layer_usage.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]

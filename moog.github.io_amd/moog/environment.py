@@ -129,6 +129,75 @@ class BatchedEnvironment(object):
         self._fused = False
         self._action_f32 = False
         self._apply_reset_pool()
+        self._setup_color_fn()
+
+    def _setup_color_fn(self):
+        """PILRenderer(color_to_rgb=<a callable>): the callable is evaluated here, on the host, once per distinct colour
+        triple; the rasteriser takes the results per (env, sprite slot) from `self._rgb` (moog_engine_set_color_override).
+        The engine's calls are then split -- step without frames, colours, frames -- and one small device-to-host read per
+        call asks whether any colour changed: convenient, not fast (like the host-side ModifyMetaState rules)."""
+        from .observers import pil_renderer
+        ren = [o for o in self.observers.values() if isinstance(o, pil_renderer.PILRenderer)]
+        self._color_fn = ren[0].color_to_rgb if ren and ren[0]._cmap == 'callable' else None
+        if self._color_fn is None:
+            return
+        torch = self._torch
+        S = self.layout.S
+        self._rgb = torch.zeros((self.num_envs, S), dtype=torch.int32, device=self.device)
+        self._rgb_seen = None          # colour bit patterns the entries of _rgb were computed from
+        self._rgb_done = torch.zeros((self.num_envs, S), dtype=torch.bool, device=self.device)
+        self._rgb_cache = {}
+        _engine.check(self._lib, self._lib.moog_engine_set_color_override(self._handle, ctypes.c_void_p(self._rgb.data_ptr())))
+        self._out_noimg = _abi.StepOut()
+        self._out_noimg.reward, self._out_noimg.discount = self._out.reward, self._out.discount
+        self._out_noimg.step_type = self._out.step_type
+
+    @staticmethod
+    def _call_color_fn(fn, triple):
+        """color_to_rgb on one colour triple, the way pil_renderer.py:108-110 and Pillow's ink conversion treat the result:
+        three integers, clipped to 0 .. 255.  Components that hold an integral value are passed as Python ints (a Sprite
+        keeps the numbers it was given; the engine's records hold float64)."""
+        import numbers
+        args = tuple(int(v) if float(v).is_integer() else float(v) for v in triple)
+        out = list(fn(args))
+        if len(out) != 3:
+            raise ValueError('color_to_rgb must return three components, got %r' % (out,))
+        rgb = 0
+        for k, v in enumerate(out):
+            if not isinstance(v, (numbers.Integral, np.integer)):
+                raise TypeError('color_to_rgb returned %r: Pillow takes integer colour components' % (v,))
+            rgb |= min(255, max(0, int(v))) << (8 * k)
+        return rgb
+
+    def _refresh_colors(self):
+        torch = self._torch
+        L, S = self.layout, self.layout.S
+        col = self.state_f64[:, L.o_color:L.o_color + 3 * S].view(torch.int64).view(self.num_envs, S, 3)
+        alive = (self.state_i32[:, L.o_flags:L.o_flags + S] & _abi.MOOG_F_ALIVE) != 0
+        if self._rgb_seen is None:
+            need = alive
+        else:
+            need = alive & ((col != self._rgb_seen).any(-1) | ~self._rgb_done)
+        idx = need.nonzero()            # (the one synchronising read of the call)
+        if idx.shape[0]:
+            bits = col[idx[:, 0], idx[:, 1]].cpu().numpy()
+            vals = bits.view(np.float64)
+            out = np.empty(len(bits), np.int32)
+            for i in range(len(bits)):
+                key = bits[i].tobytes()
+                rgb = self._rgb_cache.get(key)
+                if rgb is None:
+                    rgb = self._rgb_cache[key] = self._call_color_fn(self._color_fn, vals[i])
+                out[i] = rgb
+            self._rgb[idx[:, 0], idx[:, 1]] = torch.as_tensor(out, device=self.device)
+            self._rgb_done[idx[:, 0], idx[:, 1]] = True
+        self._rgb_seen = col.clone()
+
+    def _render_with_colors(self):
+        self._refresh_colors()
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_render(
+                self._handle, ctypes.c_void_p(self.image.data_ptr()), self._stream()))
 
     def _apply_reset_pool(self):
         want = self._reset_pool_arg
@@ -389,6 +458,7 @@ class BatchedEnvironment(object):
         if had_schedule:
             self.enable_cost_schedule(True, fused=had_fused)
         self._apply_reset_pool()
+        self._setup_color_fn()
         self.capacity_growths = getattr(self, 'capacity_growths', []) + [dict(caps)]
 
     def raise_faults(self):
@@ -431,7 +501,9 @@ class BatchedEnvironment(object):
         with self._torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_reset(
                 self._handle, mask_ptr, ctypes.byref(inj) if inj else None,
-                ctypes.byref(self._out), self._stream()))
+                ctypes.byref(self._out if self._color_fn is None else self._out_noimg), self._stream()))
+        if self._color_fn is not None:
+            self._render_with_colors()
         if self.check_faults:
             self.raise_faults()   # (a reset is rare and its sampler is where most faults come from: check at once)
         del keep, mask_t
@@ -478,7 +550,9 @@ class BatchedEnvironment(object):
         with torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_step(
                 self._handle, ctypes.c_void_p(a.data_ptr()), ctypes.byref(inj) if inj else None,
-                ctypes.byref(self._out), self._stream()))
+                ctypes.byref(self._out if self._color_fn is None else self._out_noimg), self._stream()))
+        if self._color_fn is not None:
+            self._render_with_colors()
         self._last_action = a
         # Programs whose rules append to layers can overflow a layer's capacity at any step:
         # surface that (one host sync per step; set check_faults = False to opt out).
@@ -565,6 +639,9 @@ class BatchedEnvironment(object):
     def observation(self):
         """Renders the current state (environment.py:128-131)."""
         self._poll_faults()
+        if self._color_fn is not None:
+            self._render_with_colors()
+            return self._observation()
         with self._torch.cuda.device(self.device):
             _engine.check(self._lib, self._lib.moog_engine_render(
                 self._handle, ctypes.c_void_p(self.image.data_ptr()), self._stream()))

@@ -26,8 +26,16 @@ class PILRenderer(object):
             self._cmap = 'identity'
         elif color_to_rgb == 'hsv_to_rgb' or color_to_rgb is color_maps.hsv_to_rgb:
             self._cmap = 'hsv'
+        elif isinstance(color_to_rgb, str):
+            color_to_rgb = getattr(color_maps, color_to_rgb)   # pil_renderer.py:74-75
+            self._cmap = 'hsv' if color_to_rgb is color_maps.hsv_to_rgb else 'callable'
+        elif callable(color_to_rgb):
+            # any Python function of the colour triple (pil_renderer.py:72-76,108): it stays on the host -- the environment
+            # evaluates it once per distinct colour triple and hands the rasteriser the results per sprite
+            # (moog_engine_set_color_override)
+            self._cmap = 'callable'
         else:
-            raise NotImplementedError('color_to_rgb must be None or hsv_to_rgb')
+            raise TypeError('color_to_rgb must be None, the name of a function of color_maps, or a callable')
         self.color_to_rgb = color_to_rgb
         self._bg_color = (0, 0, 0) if bg_color is None else tuple(bg_color)
         self._observation_spec = dm_env.specs.Array(

@@ -8,6 +8,8 @@
     expressions must be selected for the reward alone
   * level 1: Reset(condition = <sprites named by position>) while the state's FIRST layer is empty: the condition is
     anchored to slots, not to a layer's first live sprite
+  * level 2: PILRenderer(color_to_rgb=<a Python function>) (pil_renderer.py:72-76,108): branches, int(), components that
+    Pillow clips to 0 .. 255 -- evaluated on the host per distinct colour (moog_engine_set_color_override)
 """
 import collections
 
@@ -28,6 +30,15 @@ def _pull(distance):
     if distance < 0.45:
         return 0.0006 / (distance * distance + 0.02)
     return 0.
+
+
+def _palette(color):
+    h, s, v = color
+    if h > 0.8:   # the tinted sprites
+        return (300, int(64 * s), -20)   # (Pillow clips: 255, 64, 0)
+    if s == 0.:
+        return (int(90 * v), int(90 * v), int(90 * v) + 100)
+    return (int(255 * v * (1 - s * h)), int(200 * h) + 20, 255 - int(255 * h))
 
 
 def get_config(level=0):
@@ -86,7 +97,8 @@ def get_config(level=0):
         'physics': physics,
         'task': task,
         'action_space': action_spaces.Joystick(scaling_factor=0.03, action_layers='agent'),
-        'observers': {'image': observers.PILRenderer(image_size=(64, 64), color_to_rgb='hsv_to_rgb')},
+        'observers': {'image': observers.PILRenderer(image_size=(64, 64),
+                                                     color_to_rgb=_palette if level == 2 else 'hsv_to_rgb')},
         'game_rules': rules,
         'meta_state_initializer': lambda: {'phase': ''},
     }

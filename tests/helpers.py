@@ -58,6 +58,19 @@ class OracleEnv(object):
         self.step_type = np.zeros(n_envs, np.int32)
         self.image = np.zeros((n_envs, self.P.render.height, self.P.render.width, 3), np.uint8)
         self.lib = oracle()
+        # PILRenderer(color_to_rgb=<a callable>): Python, evaluated here per live sprite and handed to the oracle's renderer
+        # per (env, slot) -- the oracle's counterpart of moog_engine_set_color_override
+        self.color_fn = getattr(compiled, 'color_fn', None)
+
+    def _color_override(self):
+        from moog import environment
+        S = self.L.S
+        rgb = np.zeros((self.n, S), np.uint32)
+        alive = (self.i32[:, self.L.o_flags:self.L.o_flags + S] & _abi.MOOG_F_ALIVE) != 0
+        col = self.f64[:, self.L.o_color:self.L.o_color + 3 * S].reshape(self.n, S, 3)
+        for i, s_ in zip(*np.nonzero(alive)):
+            rgb[i, s_] = environment.BatchedEnvironment._call_color_fn(self.color_fn, col[i, s_])
+        return rgb
 
     def _inj(self, u):
         if u is None:
@@ -66,6 +79,10 @@ class OracleEnv(object):
         return u, u.shape[1]
 
     def reset(self, uniforms=None, mask=None, render=True):
+        if self.color_fn is not None and render:   # (the colours exist once the state does: draw afterwards)
+            self.reset(uniforms, mask, render=False)
+            self.render()
+            return
         u, nu = self._inj(uniforms)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         self.lib.oracle_reset(ctypes.byref(self.P), _ptr(self.f64, _dp), _ptr(self.i32, _ip),
@@ -75,6 +92,10 @@ class OracleEnv(object):
                               _ptr(self.step_type, _ip), _ptr(self.image, _bp) if render else None)
 
     def step(self, actions, uniforms=None, render=True):
+        if self.color_fn is not None and render:
+            self.step(actions, uniforms, render=False)
+            self.render()
+            return
         u, nu = self._inj(uniforms)
         # float32 actions (the reference's Joystick spec): the scaling is a float32 product
         self.lib.oracle_set_action_f32(1 if getattr(actions, 'dtype', None) == np.float32 else 0)
@@ -100,6 +121,17 @@ class OracleEnv(object):
            _ptr(u, _dp), nu, ctypes.c_uint64(self.seed), ctypes.c_int64(self.env_index0))
 
     def render(self):
+        rgb = None
+        if self.color_fn is not None:
+            rgb = self._color_override()
+            self.lib.oracle_set_color_override(rgb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(0))
+        try:
+            return self._render()
+        finally:
+            if rgb is not None:
+                self.lib.oracle_set_color_override(None, ctypes.c_int64(0))
+
+    def _render(self):
         self.lib.oracle_render(ctypes.byref(self.P), _ptr(self.f64, _dp), _ptr(self.i32, _ip),
                                self.n, _ptr(self.image, _bp))
         return self.image

@@ -111,13 +111,20 @@ def test_unsupported_components_raise():
     tasks.ContactReward(1., 'a', 'b', condition=lambda a, b, meta_state: meta_state['phase'] == 'go')
     assert physics.DistanceForce(lambda d: 0.1 * d if d < 1 else 0.)._force_node is not None
     assert game_rules.DelayedRule(lambda: np.random.randint(2, 5), ())._random == (1, 2.0, np.inf, 5.0)
+    # any Python colour function: evaluated on the host per distinct colour (tests/golden/callables_zoo_l2_s0.npz)
+    assert observers.PILRenderer(image_size=(8, 8), color_to_rgb=lambda c: (int(c[0]), 0, 0))._cmap == 'callable'
+    assert observers.PILRenderer(image_size=(8, 8), color_to_rgb='hsv_to_rgb')._cmap == 'hsv'
+    from moog import environment
+    call = environment.BatchedEnvironment._call_color_fn
+    assert call(lambda c: (300, int(64 * c[1]), -20), (0.9, 1.0, 1.0)) == 255 | (64 << 8)   # Pillow clips the ink
+    assert call(lambda c: c, (255.0, 128.0, 0.0)) == 255 | (128 << 8)                       # integral components arrive as ints
+    with pytest.raises(TypeError):
+        call(lambda c: (0.5, 0, 0), (0.1, 0.2, 0.3))                                        # Pillow takes integers only
     # still refused, with a message: what the tracer cannot follow
     with pytest.raises(NotImplementedError):
         physics.DistanceForce(lambda d: float(d) ** 2)            # float() of a traced value
     with pytest.raises(NotImplementedError):
         game_rules.TimedRule(lambda: (np.random.randint(0, 3), np.random.randint(5, 9)), ())   # two draws
-    with pytest.raises(NotImplementedError):
-        observers.PILRenderer(image_size=(8, 8), color_to_rgb=lambda c: c)   # the rasteriser has no expression evaluator
     with pytest.raises(NotImplementedError):
         tasks.Reset(condition=lambda state: len(state['x']) > 3).classify(['x', 'y'])
 
