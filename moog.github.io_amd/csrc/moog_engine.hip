@@ -625,6 +625,12 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET) e->maze_kernel = true;
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
   if (prog->maze.random) e->maze_kernel = true;
+  {   // MOOG_STEP_VARIANT=t|m (experiments): run a program on a kernel variant that carries more than it needs (what the variant
+      // itself costs: profiles/r04_variant_tax.txt)
+    const char* v = getenv("MOOG_STEP_VARIANT");
+    if (v && (v[0] == 't' || v[0] == 'm')) e->dynamic_rules = true;
+    if (v && v[0] == 'm') e->maze_kernel = true;
+  }
   if (err == hipSuccess)
     err = (hipError_t)moog_configure_reset_plain(e->step_lds);
     if (err == hipSuccess) err = (hipError_t)moog_configure_reset_full(e->step_lds);
