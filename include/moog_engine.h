@@ -819,6 +819,16 @@ int moog_engine_static_prefix(moog_engine_t* e, int32_t* n_slots, uint8_t* image
  * environment turns it off, =1 on for any frame size.  Returns the number of slots it covers now (0: unused). */
 int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots);
 
+/* Which step kernel a program runs on: variant 0 = plain, 1 = + expression evaluator, run-time sampler, dynamic layers,
+ * 2 = + the rare components (maze physics and walks, reset-time expressions, computed shapes, look-aheads).  The same program
+ * steps 1.4 - 2.7 times slower on variant 2 (profiles/r04_variant_tax.txt), so a program that needs the rare components only
+ * to BUILD an episode (everything but maze physics / maze walks / modifiers that assign sprite.angle / run-time generators with
+ * computed factors) is stepped by variant 1 with a LATE RESET: a step kernel that cannot open an env's next episode -- from
+ * the reset pool, if that is on -- marks the env, and the full reset kernel, launched behind every step launch, opens it
+ * before the frames are drawn: the same time steps and records as a reset inside the step kernel (late_reset = 1).
+ * MOOG_NO_LATE_RESET=1 in the environment: such programs are stepped by variant 2 as before. */
+int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late_reset);
+
 /* PILRenderer(color_to_rgb=<any callable>) (pil_renderer.py:72-76,108: the renderer calls it on every sprite's colour
  * triple when it draws): the callable is Python and stays on the host.  The binding evaluates it once per DISTINCT colour
  * triple (colours rarely change after a reset), keeps r | g << 8 | b << 16 per (env, sprite slot) in a device array

@@ -2396,9 +2396,10 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
     if (op == MOOG_X_SLOT_CONST) { v(n) = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
     if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_ARG) { v(n) = e.xarg; XSETTAG(n, 2); ++n; continue; }   // (np.linalg.norm gives a float64)
-    if constexpr (MOOG_WITH_MAZE != 0) {
-      if (op == MOOG_X_HDRAW_T) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
-    }
+    // (values an initializer left in the record, read by rules and tasks while stepping: in every kernel, so that a program
+    //  whose INITIALIZER needs the kernels that carry every component can still be stepped by the others, moog_kernels.h
+    //  "late reset")
+    if (op == MOOG_X_HDRAW_T) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
     if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
       const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
       int t; v(n) = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
@@ -2413,9 +2414,9 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
       XSETTAG(n - 1, any2 ? 2 : (any1 ? 1 : 0));
       continue;
     }
-    if constexpr (MOOG_WITH_MAZE != 0) {   // reset-time expressions: only in the kernels that carry every component
-      if (op == MOOG_X_HDRAW) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
-      if (op == MOOG_X_SLOT_ATTR) { int t; v(n) = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
+    if (op == MOOG_X_HDRAW) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
+    if (op == MOOG_X_SLOT_ATTR) { int t; v(n) = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
+    if constexpr (MOOG_WITH_MAZE != 0) {   // expressions about the sprite being created: only in the kernels that carry every component
       if (op == MOOG_X_STORE_VERT) {   // raw shape coordinate -> the vertex area of the slot being created
         --n;
         if (e.lane == 0) VERT(e.cur_slot)[I->a] = v(n);

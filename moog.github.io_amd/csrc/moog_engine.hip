@@ -61,6 +61,9 @@ struct moog_engine {
   int32_t watch_off = 0;
   bool dynamic_rules = false;
   bool maze_kernel = false;   // the program uses MazePhysics / a maze walk / a per-reset maze
+  bool late_reset = false;    // ... but only to build an episode: it is stepped by the kernels without the rare components, and
+                              // the full reset kernel behind every step launch opens the episodes those could not (step_env)
+  uint8_t* late_mask = nullptr;   // [n_envs]
   RPlan raster_plan_{};
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
@@ -168,6 +171,7 @@ static void free_engine(moog_engine* e) {
   if (e->pool_state) hipFree(e->pool_state);
   if (e->pool_tag) hipFree(e->pool_tag);
   if (e->pool_lock) hipFree(e->pool_lock);
+  if (e->late_mask) hipFree(e->late_mask);
   if (e->pool_stats) hipFree(e->pool_stats);
   for (int k = 0; k < 2; ++k) { if (e->pool_f64[k]) hipFree(e->pool_f64[k]); if (e->pool_i32[k]) hipFree(e->pool_i32[k]); }
   if (e->watch) hipFree(e->watch);
@@ -625,11 +629,39 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET) e->maze_kernel = true;
   for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
   if (prog->maze.random) e->maze_kernel = true;
+  if (e->maze_kernel) {
+    // What the program needs WHILE STEPPING of the components only the every-component kernels carry: maze walks and
+    // MazePhysics, modifiers that assign sprite.angle, run-time generators with maze cells / computed factors.  Everything else
+    // that selects those kernels (reset-time draws and expressions, maze generation, shuffles, choices, look-aheads, values an
+    // initializer keeps across episodes) happens when an episode is built.
+    bool stepping = false;
+    for (int f = 0; f < prog->n_forces; ++f)
+      stepping = stepping || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET;
+    for (int c = 0; c < prog->n_corrective; ++c) stepping = stepping || prog->corrective[c].kind == MOOG_CORR_MAZE;
+    for (int k = 0; k < prog->n_dcode; ++k) stepping = stepping || (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE);
+    for (int o = 0; o < prog->n_ops; ++o) {
+      const moog_genop_t& op = prog->ops[o];
+      if (!op.runtime) continue;
+      bool full = op.cell_sel != MOOG_CELL_NONE || op.code_off >= 0;
+      for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
+        full = full || op.factors[k].kind == MOOG_DIST_EXPR || op.factors[k].kind == MOOG_DIST_EXPR_SHAPE;
+      stepping = stepping || full;
+    }
+    const char* off = getenv("MOOG_NO_LATE_RESET");
+    e->late_reset = !stepping && !(off && atoi(off));
+    if (e->late_reset) e->dynamic_rules = true;   // (the variant with the expression evaluator)
+  }
   {   // MOOG_STEP_VARIANT=t|m (experiments): run a program on a kernel variant that carries more than it needs (what the variant
       // itself costs: profiles/r04_variant_tax.txt)
     const char* v = getenv("MOOG_STEP_VARIANT");
     if (v && (v[0] == 't' || v[0] == 'm')) e->dynamic_rules = true;
-    if (v && v[0] == 'm') e->maze_kernel = true;
+    if (v && v[0] == 'm') { e->maze_kernel = true; e->late_reset = false; }
+  }
+  if (e->late_reset) {
+    if (hipMalloc(&e->late_mask, (size_t)n_envs) != hipSuccess || hipMemset(e->late_mask, 0, (size_t)n_envs) != hipSuccess) {
+      free_engine(e);
+      return fail(MOOG_E_NOMEM, "hipMalloc(late reset mask) failed");
+    }
   }
   if (err == hipSuccess)
     err = (hipError_t)moog_configure_reset_plain(e->step_lds);
@@ -765,6 +797,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.pool_lock = e->pool_lock; a.pool_depth = e->pool_depth;
   for (int k = 0; k < 2; ++k) { a.pool_f64[k] = e->pool_f64[k]; a.pool_i32[k] = e->pool_i32[k]; }
   a.live_f64 = nullptr; a.live_i32 = nullptr;
+  a.late_mask = (mode == MODE_STEP && e->late_reset) ? e->late_mask : nullptr;
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
   return a;
 }
@@ -772,8 +805,9 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   static const moog_step_launch_fn launch[6] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
                                                 moog_launch_step_t4, moog_launch_step_m3, moog_launch_step_m4};
-  if (e->step_wps == 2 && !e->maze_kernel && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
-  launch[(e->maze_kernel ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
+  const bool full = e->maze_kernel && !e->late_reset;
+  if (e->step_wps == 2 && !full && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
+  launch[(full ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
 }
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
@@ -912,6 +946,17 @@ static int pool_kick(moog_engine* e, hipStream_t s) {
   return MOOG_OK;
 }
 
+// Late reset (step_env): behind the step kernel of a program stepped by the kernels without the rare components, the full
+// reset kernel opens the episodes of the envs that kernel marked (a grid of early exits when there are none).
+static int late_reset_launch(moog_engine* e, const moog_inject_t* inject, const moog_step_out_t* out, hipStream_t s) {
+  KArgs b = make_args(e, nullptr, inject, out, MODE_RESET_MASK, nullptr);
+  b.late_mask = e->late_mask;
+  b.pool_state = (e->pool_on && !(inject && inject->uniforms)) ? e->pool_state : nullptr;   // (the step kernel took the env's lock then)
+  moog_launch_reset_full(e->n_envs, e->step_lds, s, b);
+  HIPCHK(hipGetLastError());
+  return MOOG_OK;
+}
+
 // every pool record is dropped (the host reset the envs, or handed other records over): fills under way finish first
 static int pool_drop(moog_engine* e, hipStream_t s) {
   for (int k = 0; k < e->pool_streams; ++k) HIPCHK(hipStreamSynchronize(e->pool_stream[k]));
@@ -1017,11 +1062,12 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     return MOOG_OK;
   }
 
-  const bool emit = e->dlist && out && out->image;
+  const bool emit = e->dlist && out && out->image && !e->late_reset;   // (a late reset's record has no draw list yet)
   if (emit) a.dl = e->d_dl;
   {
     Bracket br(e, MOOG_K_STEP, s);
     launch_step(e, s, a);
+    if (e->late_reset && (rc = late_reset_launch(e, inject, out, s)) != MOOG_OK) return rc;
   }
   HIPCHK(hipGetLastError());
   if (a.pool_state && (rc = pool_kick(e, s)) != MOOG_OK) return rc;
@@ -1148,6 +1194,7 @@ int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
   if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1 || e->pad_w != e->canvas_w)
     return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing, of a width that is a multiple of 16");
   if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
+  if (e->late_reset) return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps of a program whose episodes are opened by the reset kernel behind the step kernel (late reset)");
   if (e->rgb_override) return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while the host supplies the sprites' colours (moog_engine_set_color_override)");
   {   // tools that run one kernel at a time (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) would leave the frames' grid
       // waiting for a step kernel that cannot start beside it; MOOG_NO_FUSED=1 is the manual switch
@@ -1226,6 +1273,14 @@ int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled) {
   if (!e || !enabled) return fail(MOOG_E_INVALID, "null argument");
   // (a call's frames that gave up waiting switch the mode off at the next call; report that already)
   *enabled = (e->fused && !(e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u)) ? 1 : 0;
+  return MOOG_OK;
+}
+
+int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late_reset) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  const bool full = e->maze_kernel && !e->late_reset;
+  if (variant) *variant = full ? 2 : (e->dynamic_rules ? 1 : 0);
+  if (late_reset) *late_reset = e->late_reset ? 1 : 0;
   return MOOG_OK;
 }
 

@@ -180,6 +180,8 @@ struct KArgs {
   int32_t pool_depth;
   double* pool_f64[2];   // [0] the record as the fill read it (the reset's inputs are validated against it), [1] the record after
   int32_t* pool_i32[2];  //     the reset; same layout and strides as the live records
+  uint8_t* late_mask;    // [n_envs] late reset (see step_env): the step kernel marks the envs it could not open an episode for,
+                         // the full reset kernel behind it serves and clears them; null: the step kernel resets in place
   unsigned long long* pool_stats;   // [4] episodes opened from the pool / by a reset in place / pool records rejected / adoptions that waited for a fill
   const double* live_f64;    // MODE_FILL: the live records (a.f64 / a.i32 are pool_f64[1] / pool_i32[1] then)
   const int32_t* live_i32;
@@ -261,6 +263,13 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
 // (otherwise it resets in place, as without a pool).  Programs whose reset reads a state scalar (MOOG_CELL_PSTATE)
 // are not eligible (moog_engine_set_reset_pool refuses them).
 #if MOOG_WITH_MAZE
+#define MOOG_WITH_POOL 1
+#elif defined(MOOG_STEP_DYN)
+#define MOOG_WITH_POOL (MOOG_STEP_DYN >= 1)   // (the step kernels with the expression evaluator step late-reset programs)
+#else
+#define MOOG_WITH_POOL 0
+#endif
+#if MOOG_WITH_POOL
 // the per-slot words of two records (HBM layout) agree, for every slot the reset keeps
 __device__ inline bool pool_inputs_equal(const Env& e, const moog_layout_t& G, const double* af, const int32_t* aq,
                                          const double* bf, const int32_t* bq) {
@@ -412,6 +421,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   if (env >= a.n_envs) return;
   int32_t* gq = a.i32 + rec * a.L.i32_per_env;
   if (a.mask != nullptr && a.mask[env] == 0) return;
+  if (a.late_mask != nullptr && a.mode != MODE_FILL && a.late_mask[env] == 0) return;   // late reset: the envs the step kernel marked
   double* gf = a.f64 + rec * a.L.f64_per_env;
 #if MOOG_WITH_MAZE
   if (a.mode == MODE_FILL) {   // a.f64 / a.i32 are the pool's records: claim record pool_d of the env, copy the live record, reset the copy
@@ -495,6 +505,12 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
     if (a.step_type) a.step_type[env] = 0;
   }
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+#if MOOG_WITH_MAZE
+  if (a.late_mask != nullptr) {   // late reset: served; the step kernel took the pool's lock for this env when the episode ended
+    if (a.pool_state) pool_release(a, env, e.lane);
+    if (e.lane == 0) a.late_mask[env] = 0;
+  }
+#endif
 }
 
 #if !MOOG_RESET_FULL   // (the sort kernel lives in the first of the two reset translation units)
@@ -573,7 +589,17 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
 #ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
   if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
     int held = 0;
-    if (!(DYN && pool_adopt(e, a, env, gf, gq, &held))) env_reset<DYN>(e);   // (the next episode may be waiting in the reset pool)
+    if (!(DYN && pool_adopt(e, a, env, gf, gq, &held))) {   // (the next episode may be waiting in the reset pool)
+      if (DYN && a.late_mask) {
+        // Late reset: this kernel does not carry the program's initializer (it is one of the kernels that leave the rare
+        // components out, chosen because the program needs them only to build an episode: the same program on the kernel
+        // that carries everything steps 1.4 - 2.7 times slower, profiles/r04_variant_tax.txt).  The env is marked and left
+        // as it is; the full reset kernel, launched behind this one, opens its episode and releases the pool's lock.
+        if (e.lane == 0) a.late_mask[env] = 1;
+        return false;
+      }
+      env_reset<DYN>(e);
+    }
     wsync();
     if (e.lane == 0) {
       e.q[e.L.o_reset_next] = 0;

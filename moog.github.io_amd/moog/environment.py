@@ -228,6 +228,13 @@ class BatchedEnvironment(object):
                     waited=int(st[4]))
 
     @property
+    def kernel_variant(self):
+        """(step-kernel variant 0 / 1 / 2, late reset) -- include/moog_engine.h moog_engine_kernel_variant."""
+        v, late = ctypes.c_int32(), ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_kernel_variant(self._handle, ctypes.byref(v), ctypes.byref(late)))
+        return int(v.value), bool(late.value)
+
+    @property
     def env_prefix_slots(self):
         """Leading sprite slots the rasteriser keeps in a cached picture per env (moog_engine_env_prefix); 0: unused."""
         v = ctypes.c_int32()

@@ -709,6 +709,55 @@ def test_reset_pool_is_result_neutral(name, n, steps, min_episodes):
         assert np.array_equal(gobs[key], wobs[key], equal_nan=True), (key, gstats)
 
 
+@pytest.mark.parametrize('name,n,steps', [('predators_arena_l2', 96, 130), ('parallelogram_catch', 96, 80), ('match_to_sample_l3', 64, 80),
+                                          ('callables_zoo', 64, 80)])
+def test_late_reset_is_result_neutral(name, n, steps, monkeypatch):
+    """Late reset (moog_engine_kernel_variant): a program that needs the rare components only to BUILD an episode is stepped
+    by the kernel without them; the full reset kernel behind every step launch opens the episodes that kernel could not.
+    Time steps, every frame and the final records equal those of the same program stepped by the kernel that carries
+    everything (MOOG_NO_LATE_RESET=1), episode boundaries included."""
+    import torch
+
+    def digest(ts):
+        img = ts.observation['image']
+        ww = (torch.arange(img[0].numel(), device=img.device, dtype=torch.int64) % 8191) + 1
+        return ((img.reshape(img.shape[0], -1).to(torch.int64) * ww).sum(1).cpu().numpy(), ts.step_type.cpu().numpy(),
+                np.nan_to_num(ts.reward.cpu().numpy(), nan=-7.0), np.nan_to_num(ts.discount.cpu().numpy(), nan=-7.0))
+
+    def run(late):
+        if late:
+            monkeypatch.delenv('MOOG_NO_LATE_RESET', raising=False)
+        else:
+            monkeypatch.setenv('MOOG_NO_LATE_RESET', '1')
+        env = make_env(name, n, seed=17, reset_pool=False)
+        variant = env.kernel_variant
+        env.check_faults = False
+        g = torch.Generator(device='cpu').manual_seed(4)
+        grid = env._is_grid
+        out = [digest(env.reset())]
+        for k in range(steps):
+            a = (torch.randint(0, 5, (n,), generator=g, dtype=torch.int32) if grid
+                 else torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1)
+            if k % 10 == 5:   # (episodes of some of these configs outlast the run: end a rotating quarter of them by hand)
+                env.state_i32[(k // 10) % 4::4, env.layout.o_reset_next] = 1
+            out.append(digest(env.step(a)))
+        f, q = download(env)
+        obs = observable_state(env, f, q)
+        env.close()
+        return out, obs, variant
+
+    want, wobs, wv = run(False)
+    got, gobs, gv = run(True)
+    assert wv == (2, False) and gv == (1, True), (wv, gv)
+    assert sum(int((d[1] == 0).sum()) for d in want[1:]) >= n // 4, 'too few episode boundaries in the run'
+    for k in range(len(want)):
+        for part in range(4):
+            assert np.array_equal(got[k][part], want[k][part]), 'call %d, output %d differs in envs %s' % (
+                k, part, np.nonzero(got[k][part] != want[k][part])[0][:8])
+    for key in wobs:
+        assert np.array_equal(gobs[key], wobs[key], equal_nan=True), key
+
+
 def test_reset_pool_refusals():
     """The reset pool is refused where it cannot keep its promise (moog_engine_set_reset_pool): programs of the plain kernels,
     and programs whose initializer keeps a number across episodes (predators_arena's curriculum: the reset depends on the
