@@ -1,5 +1,8 @@
 # Round-4 evidence, one gpurun call on the final build: bench lines, launch-structure and batch-size sweeps, per-config table,
 # rank hook, tails, rocprofv3 trace + PMC passes, watcher section profiles, function costs round 3 vs round 4, unit latencies.
+# (The -DMOOG_WATCH library and the fn_bench libraries under tools/ubench/build are built per ABI version -- tools/build_variant.sh,
+#  tools/fn_bench.sh: rebuild them before re-running this after include/moog_engine.h changed; tools/r04_collect2.sh is the part that
+#  needs no extra builds and was re-run on the final build of the round.)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04; rm -rf $O; mkdir -p $O
 W=$GRAFT_REPO_ROOT/tools/ubench/build
