@@ -496,6 +496,13 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_tile_w = tw;
     e->raster_tiles_x = e->pad_w / tw;
     e->raster_band_h = e->canvas_h <= 128 ? e->canvas_h : 64;
+    {   // frames that will use the per-env prefix (setup_env_prefix): few sprites are left to draw per tile and the per-tile fixed
+        // cost dominates -- whole-height tiles measured 1.65 against 1.73 ms per 4096 pacman frames (profiles/r04_env_prefix.txt)
+      int nsv_ = 0;
+      const char* sw = getenv("MOOG_RASTER_ENV_BG");
+      if (e->canvas_h > 128 && e->canvas_h <= 256 && e->aa <= 1 && !(sw && atoi(sw) == 0) && env_prefix_slots(prog, &nsv_) >= 32)
+        e->raster_band_h = e->canvas_h;
+    }
     { const char* bh = getenv("MOOG_RASTER_BAND_H"); if (bh && atoi(bh) >= 16 && atoi(bh) <= e->canvas_h) e->raster_band_h = atoi(bh); }   // experiments
     e->raster_bands = (e->canvas_h + e->raster_band_h - 1) / e->raster_band_h;
     int W = e->raster_tile_w, H = e->raster_band_h;   // (the LDS plan is per tile)
