@@ -65,6 +65,7 @@ struct moog_engine {
                               // the full reset kernel behind every step launch opens the episodes those could not (step_env)
   uint8_t* late_mask = nullptr;   // [n_envs]
   RPlan raster_plan_{};
+  RmSetup mask_setup{};   // the mask rasteriser (moog_raster_mask_core.h): ok = this program's ordinary frames are drawn by it
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
   int aa = 1, canvas_w = 0, canvas_h = 0, aa_chunk = 0;
@@ -547,6 +548,35 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_lds = pl.total;
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
+  {   // mask rasteriser (moog_raster_mask_core.h): one-tile frames, polygons of <= 32 vertices, no copying polygon modifier
+    RmSetup& ms = e->mask_setup;
+    memset(&ms, 0, sizeof ms);
+    int maxv = 1;
+    for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
+    const char* sw = getenv("MOOG_RASTER_MASK");   // 0: the push / sort / span kernel for every frame (A/B runs, tests)
+    ms.ok = !(sw && atoi(sw) == 0) && e->raster_tiles_x * e->raster_bands == 1 && e->pad_w <= 128 && e->canvas_h <= 128 &&
+            maxv <= RM_MAX_NV && prog->n_slots >= 1 && prog->n_slots <= 256 && prog->render.polymod != MOOG_POLYMOD_TORUS &&
+            e->L.TOTV >= 1;
+    if (ms.ok) {
+      ms.S = prog->n_slots;
+      ms.iwords = (ms.S + 31) / 32;
+      ms.cmap = prog->render.cmap;
+      ms.first_person = prog->render.polymod == MOOG_POLYMOD_FIRST_PERSON ? 1 : 0;
+      if (ms.first_person) { ms.fp_slot0 = prog->layer_slot0[prog->render.polymod_layer]; ms.fp_nslots = prog->layer_nslots[prog->render.polymod_layer]; }
+      ms.bg = ((uint32_t)prog->render.bg[0] & 255u) | (((uint32_t)prog->render.bg[1] & 255u) << 8) | (((uint32_t)prog->render.bg[2] & 255u) << 16);
+      // row records per pass: 224 (the headline workload's frames have ~170 rows behind the cached walls), at least a
+      // canvas height so that any one polygon fits; frames with more rows take several passes
+      int cap = 224;
+      { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) cap = atoi(rc); }   // tuning / tests of the multi-pass path
+      if (cap < e->canvas_h) cap = e->canvas_h;
+      if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
+      ms.cap_rows = cap;
+      rm_plan(ms.S, e->L.TOTV, e->pad_w, e->canvas_h, cap, ms.iwords, 2, &ms.plan);
+      ms.lds = ms.plan.total;
+      { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) ms.lds += (uint32_t)atoi(pad); }  // occupancy experiments
+      if (ms.lds > 64 * 1024) ms.ok = 0;
+    }
+  }
   {   // wave rasteriser: eligibility and LDS plan (moog_raster_wave.h)
     int maxv = 1;
     for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
@@ -675,6 +705,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err == hipSuccess) err = (hipError_t)moog_configure_reset_full(e->step_lds);
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
+  if (err == hipSuccess && e->mask_setup.ok) err = (hipError_t)moog_raster_configure_mask(e->mask_setup.lds);
   if (err == hipSuccess && e->wave) err = (hipError_t)moog_raster_wave_configure(e->wave_lds);
   if (err != hipSuccess) {
     free_engine(e);
@@ -819,6 +850,7 @@ static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
   RArgs r;
+  r.ms = e->mask_setup;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;

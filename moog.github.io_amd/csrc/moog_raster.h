@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "../../include/moog_engine.h"
+#include "moog_raster_mask_core.h"
 
 #define R_THREADS 256
 #define R_SLOW 8            // lanes that run the generic scanline concurrently (bounds its LDS scratch)
@@ -46,7 +47,19 @@ struct RPlan {   // LDS carve-up (byte offsets), computed once on the host
       o_rows, o_seg, o_queue, o_misc, total;
 };
 
+// What the mask rasteriser (moog_raster_mask_core.h) needs beyond RArgs: fixed per engine.  ok: the program's frames are
+// one tile, its polygons have <= 32 vertices and no polygon modifier copies them -- moog_raster_launch then draws
+// ordinary frames (not the prefix pictures, not draw-list or per-env-prefix frames) with that kernel.
+struct RmSetup {
+  int32_t ok;
+  int32_t S, cap_rows, iwords, cmap, first_person, fp_slot0, fp_nslots;
+  uint32_t bg;
+  RmPlan plan;
+  uint32_t lds;
+};
+
 struct RArgs {
+  RmSetup ms;
   const moog_program_t* P;
   moog_layout_t L;
   const double* f64;
@@ -247,6 +260,7 @@ struct RResize { int32_t cw, ch, ow, oh, kh, kv; const int32_t* bh; const int32_
 // Rows of `row_bytes` bytes out of rows `in_stride` bytes apart (frames whose width is not a multiple of 16 are drawn wider).
 void moog_crop_launch(const uint8_t* in, uint8_t* out, size_t rows, int in_stride, int row_bytes, hipStream_t stream);
 void moog_resize_launch(const RResize& r, const uint8_t* canvas, uint8_t* tmp, uint8_t* out, int n, hipStream_t stream);
+int moog_raster_configure_mask(size_t lds_bytes);   // the same for the mask rasteriser's kernels
 int moog_raster_configure(size_t lds_bytes);   // hipFuncSetAttribute(max dynamic LDS); returns a hipError_t
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream);
 // Per-env prefix check: one wavefront per env compares the first n_static slots of the live record (alive bit, vertex count,

@@ -2,6 +2,7 @@
 // translation unit so that it builds independently of the step / reset kernels.
 #include "moog_raster_kernel.h"
 #include "moog_raster_wave.h"
+#include "moog_raster_mask.h"
 
 template <int WORDS, bool DL>
 __global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS, DL>(a, (int)blockIdx.x, -1); }
@@ -114,6 +115,8 @@ void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups,
   else hipLaunchKernelGGL(moog_raster_follow_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
 }
 
+int moog_raster_configure_mask(size_t lds_bytes) { return moog_raster_mask_configure(lds_bytes); }
+
 int moog_raster_configure(size_t lds_bytes) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -141,7 +144,24 @@ int moog_raster_configure(size_t lds_bytes) {
   return (int)err;
 }
 
+static RmArgs mask_args(const RArgs& r) {
+  RmArgs a;
+  memset(&a, 0, sizeof a);
+  a.P = r.P; a.L = r.L; a.f64 = r.f64; a.i32 = r.i32; a.image = r.image; a.vinfo = r.vinfo;
+  a.n_envs = r.n_envs; a.S = r.ms.S; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h; a.scale_w = r.scale_w;
+  a.flip = r.flip; a.iwords = r.ms.iwords; a.cmap = r.ms.cmap; a.first_person = r.ms.first_person;
+  a.fp_slot0 = r.ms.fp_slot0; a.fp_nslots = r.ms.fp_nslots; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
+  a.n_static = r.n_static; a.nsv = r.nsv; a.sref_v = r.sref_v; a.sref_col = r.sref_col; a.sref_flags = r.sref_flags;
+  a.sref_nv = r.sref_nv; a.sref_opa = r.sref_opa; a.sbg = r.sbg; a.rgb_override = r.rgb_override;
+  a.plan = r.ms.plan;
+  return a;
+}
+
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
+  if (a.ms.ok && !a.build && !a.dl && a.sbg_env_stride == 0 && !a.env_build) {
+    moog_raster_mask_launch(mask_args(a), a.ms.lds, stream);
+    return;
+  }
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
   if (a.dl) {
     if (a.words > 1) hipLaunchKernelGGL((moog_raster_kernel<2, true>), grid, dim3(R_THREADS), lds_bytes, stream, a);

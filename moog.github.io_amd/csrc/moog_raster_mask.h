@@ -1,0 +1,68 @@
+// moog_raster_mask.h -- the mask rasteriser's kernel: one workgroup of RM_THREADS threads per frame, the phases of
+// moog_raster_mask_core.h with barriers in between.  Included by moog_raster.hip.
+#ifndef MOOG_RASTER_MASK_H_
+#define MOOG_RASTER_MASK_H_
+#include <hip/hip_runtime.h>
+
+#include "moog_raster_mask_core.h"
+
+#define RM_THREADS 128
+
+extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
+
+template <int WORDS>
+__global__ __launch_bounds__(RM_THREADS) void moog_raster_mask_kernel(RmArgs a) {
+  const int env = (int)blockIdx.x;
+  if (env >= a.n_envs) return;
+  const RmCtx c = rm_ctx(a.plan, moog_lds);
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  RmThread th;
+  rm_p0<WORDS>(a, c, env, tid, RM_THREADS, th);
+  __syncthreads();
+  if (a.debug_stop == 1) return;
+  rm_p1<WORDS>(a, c, env, tid, RM_THREADS, th);
+  __syncthreads();
+  if (a.debug_stop == 2) return;
+  // (every wave scans the items for itself: both write the same words, and a wave's LDS operations execute in order,
+  //  so each reads back what it wrote -- no barrier between the scan and the edges)
+  rm_p2_scan(a, c, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int base = 0;;) {
+    const int end = __builtin_amdgcn_readfirstlane(rm_pass_end(a, c, base));
+    const int total_rows = __builtin_amdgcn_readfirstlane(c.rowoff[end] - c.rowoff[base]);
+    rm_p2_assign(a, c, base, end, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (a.debug_stop == 3) return;
+    rm_p3<WORDS>(a, c, base, end, tid, RM_THREADS);
+    __syncthreads();
+    if (a.debug_stop == 4) return;
+    rm_p4<WORDS>(a, c, total_rows, tid, RM_THREADS, c.xx + (tid >> 6) * RM_XX);
+    __syncthreads();
+    if (a.debug_stop == 5) return;
+    rm_p5<WORDS>(a, c, env, base == 0, tid, RM_THREADS);
+    if (end >= a.S) break;
+    base = end;
+    __syncthreads();
+    rm_next_pass(a, c, tid, RM_THREADS);
+    __syncthreads();
+  }
+}
+
+static inline int moog_raster_mask_configure(size_t lds_bytes) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (err == hipSuccess)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  return (int)err;
+}
+
+static inline void moog_raster_mask_launch(const RmArgs& a, size_t lds_bytes, hipStream_t stream) {
+  const dim3 grid((unsigned)a.n_envs);
+  if (a.W > 64) hipLaunchKernelGGL(moog_raster_mask_kernel<2>, grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(moog_raster_mask_kernel<1>, grid, dim3(RM_THREADS), lds_bytes, stream, a);
+}
+
+#endif  // MOOG_RASTER_MASK_H_

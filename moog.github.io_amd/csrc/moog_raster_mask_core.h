@@ -1,0 +1,833 @@
+// moog_raster_mask_core.h -- the "mask" rasteriser: Pillow-exact polygon fill without sorting crossings.
+//
+// Replaces, for one-tile frames (<= 128 x 128 canvas, polygons of <= 32 vertices), the push / sort / span pipeline of
+// moog_raster_kernel.h.  Same contract: bit-exact with ImageDraw.polygon in RGBA blend mode as PILRenderer uses it
+// (reference moog/observers/pil_renderer.py:88-120; Pillow Draw.c ImagingDrawPolygon / polygon_generic(hasAlpha = 1) /
+// hline32rgba as restated in oracle/moog_oracle.c).
+//
+// What makes it cheap (the frames of the headline workload hold ~28 polygons that are 3-6 pixels tall):
+//  * No crossing lists.  polygon_generic sorts a row's crossings xx[] and fills [ROUND_UP(xx[2q]), ROUND_DOWN(xx[2q+1])]
+//    for every pair, left to right, never painting a pixel twice (x_pos).  The union of those spans is
+//        XOR_x low(ROUND_DOWN(x) + 1)   |   OR_x pixels[ROUND_UP(x) .. ROUND_DOWN(x)]
+//    (low(t) = pixels 0 .. t-1): pixel p is covered iff the number of crossings with ROUND_DOWN(x) < p is odd, or some
+//    crossing rounds onto p (the second term is one pixel, none for a positive half-integer).  Both terms are commutative, so a row's mask is accumulated in any order, in registers.
+//    (A closed polygon crosses a row an even number of times with Pillow's counting -- an edge's last row counts twice,
+//    a local extremum 2 or 4 times; a row with an odd count takes the generic routine.)
+//  * Census by bit mask.  Polygons have <= 32 edges, so "which edges are active on row y", "which are horizontal heads
+//    there" and "which have a corner there, leaning left / right" are four 32-bit words per (polygon, row), OR-ed
+//    together by the edges (LDS atomics without return).  The row's thread then walks the set bits: only edges that
+//    really cross the row cost anything.
+//  * polygon_generic's corner fix-up ("connect discontiguous corners") is resolved per ROW from the two corner words:
+//    fewer than two edges of one lean with a corner on the row = nothing to do (the common case, no edge is read).
+//  * Horizontal heads (draw_horizontal_lines) only need the pen position x_pos at the moments Pillow looks at it; those
+//    are the ends of the runs of the span mask, in order.
+//  * Compose works on the frame's bytes as they lie in memory (48 bytes per 16 pixels): a 16-entry table turns four
+//    coverage bits into three dwords of byte masks, one v_bfi_b32 per dword paints an opaque polygon.
+//
+// The file is host + device code: tests/test_raster_mask_model.py compiles it with g++ and runs whole frames through
+// the same functions, thread by thread, against the oracle renderer (no GPU needed to find a logic error).
+#ifndef MOOG_RASTER_MASK_CORE_H_
+#define MOOG_RASTER_MASK_CORE_H_
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/moog_engine.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RM_DEV 1
+#else
+#define RM_DEV 0
+#endif
+#if defined(__HIPCC__)
+#define RM_FN __host__ __device__ __forceinline__
+#define RM_SLOW __host__ __device__ __noinline__
+#else
+#define RM_FN static inline
+#define RM_SLOW static
+#endif
+#if RM_DEV
+#define RM_ANY(x) __any((x))
+#define RM_CONSTP(T) const __attribute__((address_space(4))) T*
+#else
+#define RM_ANY(x) (x)
+#define RM_CONSTP(T) const T*
+#endif
+
+#define RM_MAX_NV 32          // vertices per polygon (edge index = bit of a census word)
+#define RM_XX 64              // crossing-list capacity of the generic row routine (2 per edge)
+
+struct RmEdge { uint32_t w0, w1, w2, w3; };   // table edge: float x0 | float dx | y0, y1 (shorts) | 0;  head: xmin, xmax (shorts) | 0 | y, y | 1
+struct RmRow { uint32_t act, heads, tipP, tipN; };   // census of a (polygon, row); after the row phase w0.. = the coverage mask
+struct RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint32_t rgba; };   // row record of row 0 | first vertex slot, live vertices << 20 | min(ymax, H) | colour
+
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_rowoff, o_seg, o_lut, o_xx, o_misc, total; };
+
+struct RmArgs {
+  const moog_program_t* P;
+  moog_layout_t L;
+  const double* f64;
+  const int32_t* i32;
+  uint8_t* image;
+  const uint32_t* vinfo;      // per vertex slot: sprite slot | index within the sprite << 8
+  int32_t n_envs;
+  int32_t S;                  // sprite slots (= items: no polygon modifier that copies)
+  int32_t cap_rows;           // row records per pass (>= H)
+  int32_t W, H;               // the canvas in memory (width a multiple of 16, <= 128)
+  int32_t scale_w;            // the width the vertices are scaled by (pil_renderer.py:65-66)
+  int32_t flip;               // rows are written bottom-up (np.flipud, pil_renderer.py:118)
+  int32_t iwords;             // 32-bit words of a segment's item bit mask
+  int32_t cmap, first_person, fp_slot0, fp_nslots;
+  uint32_t bg;                // r | g << 8 | b << 16
+  int32_t debug_stop;
+  int32_t threads;            // threads per frame (64 * waves)
+  // static prefix (moog_raster.h): the first n_static slots are in the cached picture `sbg` when they equal the reference
+  int32_t n_static, nsv;
+  const double* sref_v;
+  const double* sref_col;
+  const int32_t* sref_flags;
+  const int32_t* sref_nv;
+  const int32_t* sref_opa;
+  const uint8_t* sbg;
+  const uint32_t* rgb_override;
+  RmPlan plan;
+};
+
+static inline uint32_t rm_align(uint32_t x) { return (x + 15u) & ~15u; }
+
+static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, RmPlan* p) {
+  uint32_t o = 0;
+  p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
+  p->o_ivert = o; o = rm_align(o + (uint32_t)TOTV * 4u);
+  p->o_rows = o; o = rm_align(o + (uint32_t)cap_rows * sizeof(RmRow));
+  p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows);
+  p->o_info = o; o = rm_align(o + (uint32_t)S * sizeof(RmItem));
+  p->o_item_y = o; o = rm_align(o + (uint32_t)S * 8u);
+  p->o_rowoff = o; o = rm_align(o + (uint32_t)(S + 1) * 4u);
+  p->o_seg = o; o = rm_align(o + (uint32_t)H * (uint32_t)(W / 16) * (uint32_t)iwords * 4u);
+  p->o_lut = o; o = rm_align(o + 16u * 16u);
+  p->o_xx = o; o = rm_align(o + (uint32_t)waves * RM_XX * 4u);
+  p->o_misc = o; o = rm_align(o + 64u);
+  p->total = o;
+}
+
+struct RmCtx {
+  RmEdge* edges; uint32_t* ivert; RmRow* rows; uint8_t* rowitem; RmItem* info; int32_t* item_y; int32_t* rowoff;
+  uint32_t* seg; uint32_t* lut; float* xx; int32_t* misc;   // misc: [5] static prefix differs
+};
+
+RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
+  RmCtx c;
+  c.edges = reinterpret_cast<RmEdge*>(lds + pl.o_edge);
+  c.ivert = reinterpret_cast<uint32_t*>(lds + pl.o_ivert);
+  c.rows = reinterpret_cast<RmRow*>(lds + pl.o_rows);
+  c.rowitem = reinterpret_cast<uint8_t*>(lds + pl.o_rowitem);
+  c.info = reinterpret_cast<RmItem*>(lds + pl.o_info);
+  c.item_y = reinterpret_cast<int32_t*>(lds + pl.o_item_y);
+  c.rowoff = reinterpret_cast<int32_t*>(lds + pl.o_rowoff);
+  c.seg = reinterpret_cast<uint32_t*>(lds + pl.o_seg);
+  c.lut = reinterpret_cast<uint32_t*>(lds + pl.o_lut);
+  c.xx = reinterpret_cast<float*>(lds + pl.o_xx);
+  c.misc = reinterpret_cast<int32_t*>(lds + pl.o_misc);
+  return c;
+}
+
+// ---- small helpers ---------------------------------------------------------------------------------------------------
+RM_FN uint32_t rm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+RM_FN float rm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+RM_FN int rm_ffs(uint32_t m) { return __builtin_ctz(m); }
+RM_FN void rm_or(uint32_t* p, uint32_t v) {
+#if RM_DEV
+  atomicOr(p, v);
+#else
+  *p |= v;
+#endif
+}
+RM_FN void rm_min(int32_t* p, int32_t v) {
+#if RM_DEV
+  atomicMin(p, v);
+#else
+  if (v < *p) *p = v;
+#endif
+}
+RM_FN void rm_max(int32_t* p, int32_t v) {
+#if RM_DEV
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
+// float -> int the way v_cvt_i32_f32 does it (saturating): the host model and the kernel then agree on far-away crossings
+RM_FN int rm_f2i(float f) {
+  if (!(f > -2147483648.0f)) return (int)0x80000000;
+  if (!(f < 2147483648.0f)) return 0x7fffffff;
+  return (int)f;
+}
+// Draw.c ROUND_UP / ROUND_DOWN
+RM_FN int rm_round_up(float f) { return rm_f2i(copysignf(floorf(fabsf(f) + 0.5f), f)); }
+RM_FN int rm_round_down(float f) { return rm_f2i(copysignf(ceilf(fabsf(f) - 0.5f), f)); }
+// Pillow's (int) cast of a coordinate as x86-64 performs it (cvttsd2si): NaN and out-of-range give INT_MIN
+RM_FN int rm_pil_int(double d) { return (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000; }
+RM_FN int rm_clamp16(int v) { return v < -32000 ? -32000 : (v > 32000 ? 32000 : v); }
+
+// color_maps.py:21-23 (colorsys.hsv_to_rgb, then uint8 truncation)
+RM_FN uint32_t rm_hsv_rgb(double h, double s, double v) {
+  double r, g, b;
+  if (s == 0.0) { r = g = b = v; }
+  else {
+    int i = (int)(h * 6.0);
+    double f = (h * 6.0) - i;
+    double p = v * (1.0 - s), q = v * (1.0 - s * f), t = v * (1.0 - s * (1.0 - f));
+    i = ((i % 6) + 6) % 6;
+    switch (i) {
+      case 0: r = v; g = t; b = p; break;
+      case 1: r = q; g = v; b = p; break;
+      case 2: r = p; g = v; b = t; break;
+      case 3: r = p; g = q; b = v; break;
+      case 4: r = t; g = p; b = v; break;
+      default: r = v; g = p; b = q; break;
+    }
+  }
+  return ((uint32_t)(int)(255 * r) & 255u) | (((uint32_t)(int)(255 * g) & 255u) << 8) | (((uint32_t)(int)(255 * b) & 255u) << 16);
+}
+
+// ---- coverage masks -----------------------------------------------------------------------------------------------
+template <int WORDS> struct RmMask { uint64_t w[WORDS]; };
+RM_FN uint64_t rm_low(int t) { return t <= 0 ? 0ull : (t >= 64 ? ~0ull : ((1ull << t) - 1ull)); }   // pixels 0 .. t-1
+template <int WORDS> RM_FN void rm_clear(RmMask<WORDS>& m) { for (int i = 0; i < WORDS; ++i) m.w[i] = 0ull; }
+template <int WORDS> RM_FN bool rm_bit(const RmMask<WORDS>& m, int p) { return (m.w[WORDS > 1 ? (p >> 6) : 0] >> (p & 63)) & 1ull; }
+// pixels [a, b] clipped to [0, 64 * WORDS); nothing when a > b
+template <int WORDS> RM_FN void rm_or_range(RmMask<WORDS>& m, int a, int b) {
+  if (a < 0) a = 0;
+  if (b > 64 * WORDS - 1) b = 64 * WORDS - 1;
+  if (a > b) return;
+  m.w[0] |= rm_low(b + 1) & ~rm_low(a);
+  if (WORDS > 1) m.w[1] |= rm_low(b + 1 - 64) & ~rm_low(a - 64);
+}
+
+// ---- edges ------------------------------------------------------------------------------------------------------------
+RM_FN int rm_y0(const RmEdge& e) { return (int)(int16_t)(e.w2 & 0xffffu); }
+RM_FN int rm_y1(const RmEdge& e) { return (int)(int32_t)e.w2 >> 16; }
+RM_FN float rm_xat(const RmEdge& e, int y) { return (float)(y - rm_y0(e)) * rm_u2f(e.w1) + rm_u2f(e.w0); }   // Draw.c: (ymin - y0) * dx + x0
+
+// ImagingDrawPolygon's edge list, the edge that leaves vertex k of a ring of nv packed points (x | y << 16, shorts):
+// 0 = no edge (the closing edge of a ring whose last point is its first, a horizontal edge merged into the run before
+// it, or -- see below -- a repeated point), 1 = table edge, 2 = horizontal head [xmin, xmax].
+RM_FN int rm_build_edge(const uint32_t* pv, int k, int nv, RmEdge* out) {
+  const int k2 = (k + 1 == nv) ? 0 : k + 1;
+  const uint32_t q0 = pv[k], q1 = pv[k2];
+  const int x0 = (int16_t)(q0 & 0xffffu), y0 = (int16_t)(q0 >> 16), x1 = (int16_t)(q1 & 0xffffu), y1 = (int16_t)(q1 >> 16);
+  const bool closing = (k == nv - 1);
+  if (y0 != y1) {
+    out->w0 = rm_f2u((float)x0);
+    out->w1 = rm_f2u(((float)(x1 - x0)) / (float)(y1 - y0));
+    out->w2 = (q0 >> 16) | (q1 & 0xffff0000u);
+    out->w3 = 0u;
+    return 1;
+  }
+  if (closing && x0 == x1) return 0;   // last == first: no closing edge
+  if (k >= 1 && !closing) {
+    const uint32_t qp = pv[k - 1];
+    const int xp = (int16_t)(qp & 0xffffu), yp = (int16_t)(qp >> 16);
+    // "horizontal line immediately following another horizontal line", same direction: the run before it grows
+    if (yp == y0 && ((x1 > x0 && x0 > xp) || (x1 < x0 && x0 < xp))) return 0;
+    // Three equal points in a row (tiny circles): this zero-length head repeats the one before it, which is visited
+    // immediately before it with the same outcome either way -- dropped.
+    if (xp == x0 && yp == y0 && x1 == x0) return 0;
+  }
+  int hx = x1;   // extend over the following merged edges (never the closing edge)
+  {
+    int q = k + 1;
+    int px = x0, cx = x1;
+    while (q <= nv - 2) {
+      const uint32_t qn = pv[q + 1];
+      const int nx = (int16_t)(qn & 0xffffu), ny = (int16_t)(qn >> 16);
+      const bool ab = (ny == y0) && ((nx > cx && cx > px) || (nx < cx && cx < px));
+      if (!ab) break;
+      hx = nx; px = cx; cx = nx; ++q;
+    }
+  }
+  const int xmin = x0 < hx ? x0 : hx, xmax = x0 < hx ? hx : x0;
+  out->w0 = (uint32_t)(uint16_t)xmin | ((uint32_t)(uint16_t)xmax << 16);
+  out->w1 = 0u;
+  out->w2 = (q0 >> 16) | (q0 & 0xffff0000u);
+  out->w3 = 1u;
+  return 2;
+}
+
+// ---- one row of one polygon ---------------------------------------------------------------------------------------------
+// polygon_generic verbatim for one row (any number of crossings, overwritten partner entries, odd counts): the rare rows.
+// xx: RM_XX floats of scratch.
+template <int WORDS>
+RM_SLOW void rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, int y, int pymax, float* xx, RmMask<WORDS>& m) {
+  rm_clear(m);
+  int j = 0;
+  for (int i = 0; i < nv; ++i) {
+    const RmEdge E = pe[i];
+    const int y0 = rm_y0(E), y1 = rm_y1(E);
+    if (y0 == y1) continue;   // (records of vertices without an edge are zero: y0 == y1)
+    const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
+    if (y < emin || y > emax) continue;
+    const float dx = rm_u2f(E.w1);
+    const float x = rm_xat(E, y);
+    if (j < RM_XX) xx[j] = x;
+    ++j;
+    if (y == emax && y < pymax) {
+      if (j < RM_XX) xx[j] = x;
+      ++j;
+    } else if (dx != 0.0f) {
+      for (int k = 0; k < i; ++k) {
+        const RmEdge K = pe[k];
+        const int ky0 = rm_y0(K), ky1 = rm_y1(K);
+        if (ky0 == ky1) continue;
+        const int kmin = ky0 < ky1 ? ky0 : ky1, kmax = ky0 < ky1 ? ky1 : ky0;
+        if (y < kmin || y > kmax) continue;
+        const float kdx = rm_u2f(K.w1);
+        if ((dx > 0 && kdx <= 0) || (dx < 0 && kdx >= 0)) continue;
+        const bool top = (y == emin && y == kmin), bot = (y == emax && y == kmax);
+        if (!(top || bot)) continue;
+        if (x != rm_xat(K, y)) continue;
+        const int off = top ? 1 : -1;
+        const float adj = rm_xat(E, y + off), adjo = rm_xat(K, y + off);
+        float vv = 0; bool have = false;
+        if (adj > x && adjo > x) {
+          const float v = (float)(rm_round_up(fminf(adj, adjo)) - 1);
+          if (v > x) { vv = v; have = true; }
+        } else if (adj < x && adjo < x) {
+          const float v = (float)(rm_round_up(fmaxf(adj, adjo)) + 1);
+          if (v < x) { vv = v; have = true; }
+        }
+        if (have) {   // the partner's (first) entry on this row is overwritten
+          int kpos = 0;
+          for (int q = 0; q < k; ++q) {
+            const RmEdge Q = pe[q];
+            const int qy0 = rm_y0(Q), qy1 = rm_y1(Q);
+            if (qy0 == qy1) continue;
+            const int qmin = qy0 < qy1 ? qy0 : qy1, qmax = qy0 < qy1 ? qy1 : qy0;
+            if (y < qmin || y > qmax) continue;
+            kpos += (y == qmax && y < pymax) ? 2 : 1;
+          }
+          if (kpos < RM_XX) xx[kpos] = vv;
+        }
+        break;
+      }
+    }
+  }
+  if (j > RM_XX) j = RM_XX;
+  for (int q = 1; q < j; ++q) {   // qsort(x_cmp)
+    const float key = xx[q];
+    int r = q - 1;
+    while (r >= 0 && xx[r] > key) { xx[r + 1] = xx[r]; --r; }
+    xx[r + 1] = key;
+  }
+  int x_pos = (j == 0) ? -1 : 0;
+  for (int i = 1; i <= j + 1; i += 2) {
+    const bool last = (i >= j);   // the call behind the loop
+    int x_end = 0;
+    if (!last) {
+      x_end = rm_round_down(xx[i]);
+      if (x_end < x_pos) continue;
+    }
+    {   // draw_horizontal_lines: every head of the row, in edge order
+      uint32_t hb = heads;
+      while (hb) {
+        const int k = rm_ffs(hb);
+        hb &= hb - 1u;
+        const RmEdge h = pe[k];
+        int xmin = (int16_t)(h.w0 & 0xffffu);
+        const int xmax = (int16_t)(h.w0 >> 16);
+        if (x_pos != -1 && x_pos < xmin) continue;
+        if (x_pos > xmin) {
+          xmin = x_pos;
+          if (xmax < xmin) continue;
+        }
+        rm_or_range(m, xmin, xmax);
+        x_pos = xmax + 1;
+      }
+    }
+    if (last) break;
+    if (x_end < x_pos) continue;
+    int x_start = rm_round_up(xx[i - 1]);
+    if (x_pos > x_start) {
+      x_start = x_pos;
+      if (x_end < x_start) continue;
+    }
+    rm_or_range(m, x_start, x_end);
+    x_pos = x_end + 1;
+  }
+}
+
+// The corner fix-up of a row, from the census word of one lean (bits = edges with a corner on this row): every edge but
+// the first looks at the earlier ones in order; the first whose crossing is the same float decides, and what it decides
+// is a new value for the PARTNER's entry (polygon_generic: xx[k] = ...).  At most two partners are kept; a third: generic.
+struct RmFix { int k0, k1; float v0, v1; bool generic; };
+RM_FN void rm_fix_put(RmFix& f, int k, float v) {
+  if (f.k0 == k) f.v0 = v;
+  else if (f.k1 == k) f.v1 = v;
+  else if (f.k0 < 0) { f.k0 = k; f.v0 = v; }
+  else if (f.k1 < 0) { f.k1 = k; f.v1 = v; }
+  else f.generic = true;
+}
+RM_FN void rm_fix_class(const RmEdge* pe, uint32_t m, int y, RmFix& f) {
+  uint32_t rest = m & (m - 1u);
+  while (rest) {
+    const int i = rm_ffs(rest);
+    rest &= rest - 1u;
+    const RmEdge E = pe[i];
+    const int y0 = rm_y0(E), y1 = rm_y1(E);
+    const bool top = (y == (y0 < y1 ? y0 : y1));
+    const float x = rm_xat(E, y);
+    uint32_t cand = m & ((1u << i) - 1u);
+    while (cand) {
+      const int k = rm_ffs(cand);
+      cand &= cand - 1u;
+      const RmEdge K = pe[k];
+      const int ky0 = rm_y0(K), ky1 = rm_y1(K);
+      if (y != (top ? (ky0 < ky1 ? ky0 : ky1) : (ky0 < ky1 ? ky1 : ky0))) continue;
+      if (x != rm_xat(K, y)) continue;
+      const int off = top ? 1 : -1;
+      const float adj = rm_xat(E, y + off), adjo = rm_xat(K, y + off);
+      if (adj > x && adjo > x) {
+        const float v = (float)(rm_round_up(fminf(adj, adjo)) - 1);
+        if (v > x) rm_fix_put(f, k, v);
+      } else if (adj < x && adjo < x) {
+        const float v = (float)(rm_round_up(fmaxf(adj, adjo)) + 1);
+        if (v < x) rm_fix_put(f, k, v);
+      }
+      break;
+    }
+  }
+}
+
+// draw_horizontal_lines with the pen at `pen`: heads that start behind the pen (or any head when the row has no
+// crossing: pen == -1) are painted from the pen on and move it; the others stay pending.  x_pos only grows, so a head
+// that was looked at with the pen at or behind its start is finished whether or not anything was painted.
+template <int WORDS>
+RM_FN void rm_heads(const RmEdge* pe, uint32_t& hb, int& pen, RmMask<WORDS>& m) {
+  uint32_t bits = hb;
+  while (bits) {
+    const int k = rm_ffs(bits);
+    bits &= bits - 1u;
+    const RmEdge h = pe[k];
+    const int xmin = (int16_t)(h.w0 & 0xffffu), xmax = (int16_t)(h.w0 >> 16);
+    if (pen != -1 && pen < xmin) continue;
+    hb &= ~(1u << k);
+    const int hs = pen > xmin ? pen : xmin;
+    if (xmax < hs) continue;
+    rm_or_range(m, hs, xmax);
+    pen = xmax + 1;
+  }
+}
+
+// The coverage mask of row y of a polygon from its census record.  Returns false when the row needs rm_row_generic.
+template <int WORDS>
+RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int W, RmMask<WORDS>& out) {
+  RmFix fix; fix.k0 = -1; fix.k1 = -1; fix.v0 = 0.0f; fix.v1 = 0.0f; fix.generic = false;
+  {
+    const bool tp = (rec.tipP & (rec.tipP - 1u)) != 0u, tn = (rec.tipN & (rec.tipN - 1u)) != 0u;
+    if (RM_ANY(tp || tn)) {
+      if (tp) rm_fix_class(pe, rec.tipP, y, fix);
+      if (tn) rm_fix_class(pe, rec.tipN, y, fix);
+    }
+  }
+  RmMask<WORDS> par, pix;
+  rm_clear(par); rm_clear(pix);
+  bool odd = false;
+  RmMask<WORDS> seen, seen2;
+  rm_clear(seen); rm_clear(seen2);
+  const bool anyheads = RM_ANY(rec.heads != 0u);
+  uint32_t m = rec.act;
+  const float wlim = (float)(W - 1);
+  while (RM_ANY(m != 0u)) {
+    if (m != 0u) {
+      const int k = rm_ffs(m);
+      m &= m - 1u;
+      const RmEdge E = pe[k];
+      const int y0 = rm_y0(E), y1 = rm_y1(E);
+      float x = rm_xat(E, y);
+      x = (k == fix.k0) ? fix.v0 : x;
+      x = (k == fix.k1) ? fix.v1 : x;
+      const int emax = y0 < y1 ? y1 : y0;
+      const bool dup = (y == emax) && (y < pymax);   // "needed to draw consistent polygons": the edge's last row counts twice
+      const float ax = fabsf(x);
+      const float fu = floorf(ax + 0.5f), fd = ceilf(ax - 0.5f);
+      const float fs = copysignf(fd, x);                 // ROUND_DOWN(x)
+      const float fc = fminf(fmaxf(fs, -1.0f), wlim);    // clipped to [-1, W - 1]
+      const int rc = (int)fc;
+      // pixels p with ROUND_UP(x) <= p <= ROUND_DOWN(x): round(x) unless x is a half-integer -- a positive one has none, a
+      // negative one two (Draw.c rounds halves away from zero going up, towards zero going down), of which only
+      // ROUND_DOWN(-0.5) = 0 can be on the canvas
+      const bool onpix = ((fu == fd) || (x < 0.0f)) && (fs == fc) && (fc >= 0.0f);
+      if (!dup) {
+        par.w[0] ^= rm_low(rc + 1);
+        if (WORDS > 1) par.w[1] ^= rm_low(rc + 1 - 64);
+        odd = !odd;
+      }
+      if (onpix) pix.w[WORDS > 1 ? (rc >> 6) : 0] |= 1ull << (rc & 63);
+      if (anyheads) {
+        // Where Pillow's pen can come to rest: the last pixels of the spans = ROUND_DOWN of the crossings of odd rank.
+        // seen: pixels some crossing rounds down onto; seen2: pixels two or more do (one of two neighbours in the sorted
+        // list has odd rank; this includes the pairs of equal half-integers, whose span [n + 1, n] paints nothing and
+        // still moves the pen).  A lone crossing has odd rank iff the parity mask covers its pixel (below).
+        const uint64_t b = ((fs == fc) && (fc >= 0.0f)) ? (1ull << (rc & 63)) : 0ull;
+        uint64_t& sw = seen.w[WORDS > 1 ? ((rc >> 6) & 1) : 0];
+        uint64_t& sw2 = seen2.w[WORDS > 1 ? ((rc >> 6) & 1) : 0];
+        sw2 |= (sw & b) | (dup ? b : 0ull);
+        sw |= b;
+      }
+    }
+  }
+  const bool any = rec.act != 0u;
+  for (int i = 0; i < WORDS; ++i) {
+    const int wbits = W - 64 * i;
+    out.w[i] = (par.w[i] | pix.w[i]) & rm_low(wbits);
+  }
+  if (anyheads) {
+    if (rec.heads != 0u) {
+      // Pillow's span loop, as far as the heads can tell: the spans' last pixels in order; a span that ends behind the
+      // pen is passed over without a look at the heads
+      RmMask<WORDS> res = out;
+      uint32_t hb = rec.heads;
+      int pen = any ? 0 : -1;
+      for (int i = 0; i < WORDS; ++i) {
+        uint64_t ends = seen2.w[i] | (seen.w[i] & par.w[i]);
+        while (ends) {
+          const int e = 64 * i + __builtin_ctzll(ends);
+          ends &= ends - 1ull;
+          if (e < pen) continue;
+          rm_heads<WORDS>(pe, hb, pen, res);
+          if (e < pen) continue;
+          pen = e + 1;
+        }
+      }
+      rm_heads<WORDS>(pe, hb, pen, res);
+      for (int i = 0; i < WORDS; ++i) out.w[i] = res.w[i] & rm_low(W - 64 * i);
+    }
+  }
+  return !(odd || fix.generic);
+}
+
+// ---- the frame, phase by phase ------------------------------------------------------------------------------------------
+// One workgroup of `T` threads (T / 64 wavefronts) renders one frame.  Barriers stand between the phases:
+//   p0  clear the tables; per-slot colour / liveness                     | p1  vertices -> integer canvas points, item row ranges
+//   p2  (every wave for itself) item rows -> row records                 | p3  edges + census
+//   p4  rows -> coverage masks, which 16-pixel segments an item touches  | p5  compose + store
+// A frame with more rows than row records takes several passes over p2 .. p5, whole items at a time.
+struct RmThread {   // what a thread carries from one phase to the next
+  uint32_t vi; double vx, vy;   // the first vertex slot's table entry and coordinates, loaded before the tables are cleared
+  bool st_bad;
+  double fpx, fpy;
+};
+
+template <int WORDS>
+RM_FN void rm_p0(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThread& th) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
+  th.vi = 0u; th.vx = 0.0; th.vy = 0.0; th.st_bad = false; th.fpx = 0.0; th.fpy = 0.0;
+  if (tid < L.TOTV) {   // phase 1's first loads go out before anything else (HBM latency under the clearing)
+    th.vi = a.vinfo[tid];
+    th.vx = gf[L.o_verts + 2 * tid]; th.vy = gf[L.o_verts + 2 * tid + 1];
+  }
+  for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
+  const int nseg = a.W >> 4;
+  for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
+  if (tid < 16) {   // four coverage bits -> byte masks of the 12 bytes of four RGB pixels
+    const uint32_t p0 = tid & 1, p1 = (tid >> 1) & 1, p2 = (tid >> 2) & 1, p3 = (tid >> 3) & 1;
+    c.lut[4 * tid + 0] = (p0 ? 0x00ffffffu : 0u) | (p1 ? 0xff000000u : 0u);
+    c.lut[4 * tid + 1] = (p1 ? 0x0000ffffu : 0u) | (p2 ? 0xffff0000u : 0u);
+    c.lut[4 * tid + 2] = (p2 ? 0x000000ffu : 0u) | (p3 ? 0xffffff00u : 0u);
+    c.lut[4 * tid + 3] = 0u;
+  }
+  if (tid < 8) c.misc[tid] = 0;
+  RM_CONSTP(moog_program_t) P = (RM_CONSTP(moog_program_t))(uintptr_t)a.P;
+  const int NS = a.n_static;
+  for (int s = tid; s < a.S; s += T) {
+    const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
+    const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
+    const bool alive = (flags & MOOG_F_ALIVE) != 0;
+    if (s < NS) {
+      const double* rc = a.sref_col + 3 * s;
+      uint64_t b0, b1, b2, r0, r1, r2;
+      memcpy(&b0, &c0, 8); memcpy(&b1, &c1, 8); memcpy(&b2, &c2, 8); memcpy(&r0, rc, 8); memcpy(&r1, rc + 1, 8); memcpy(&r2, rc + 2, 8);
+      th.st_bad = th.st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
+                  b0 != r0 || b1 != r1 || b2 != r2;
+    }
+    uint32_t rgba = 0u;
+    if (alive) {
+      uint32_t rgb;
+      if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.S + s] & 0xffffffu;
+      else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
+      else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
+      rgba = rgb | (((uint32_t)opa & 255u) << 24);
+    }
+    RmItem it;
+    it.rowbase = 0; it.pb_nv = P->slot_voff[s] | ((alive ? nvs : 0) << 20); it.pymax = 0; it.rgba = rgba;
+    c.info[s] = it;
+    c.item_y[2 * s] = 0x7fffffff; c.item_y[2 * s + 1] = -0x7fffffff;
+  }
+  if (a.first_person) {   // polygon_modifiers.py:41-64: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
+    for (int s = a.fp_slot0; s < a.fp_slot0 + a.fp_nslots; ++s)
+      if (gq[L.o_flags + s] & MOOG_F_ALIVE) { th.fpx = 0.5 - gf[L.o_pos + 2 * s]; th.fpy = 0.5 - gf[L.o_pos + 2 * s + 1]; break; }
+  }
+}
+
+template <int WORDS>
+RM_FN void rm_p1(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThread& th) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  const int NS = a.n_static;
+  uint32_t vi = th.vi; double vx = th.vx, vy = th.vy;
+  for (int idx = tid; idx < L.TOTV; idx += T) {
+    const uint32_t vi_c = vi; const double x_c = vx, y_c = vy;
+    if (idx + T < L.TOTV) {   // the next round's loads
+      vi = a.vinfo[idx + T];
+      vx = gf[L.o_verts + 2 * (idx + T)]; vy = gf[L.o_verts + 2 * (idx + T) + 1];
+    }
+    const int s = vi_c & 0xffu, k = (vi_c >> 8) & 0xffu;
+    if (k >= (c.info[s].pb_nv >> 20)) continue;
+    if (idx < a.nsv && NS > 0) {
+      uint64_t b0, b1, r0, r1;
+      memcpy(&b0, &x_c, 8); memcpy(&b1, &y_c, 8); memcpy(&r0, a.sref_v + 2 * idx, 8); memcpy(&r1, a.sref_v + 2 * idx + 1, 8);
+      th.st_bad = th.st_bad || b0 != r0 || b1 != r1;
+    }
+    double px = x_c, py = y_c;
+    if (a.first_person) { px = px + th.fpx; py = py + th.fpy; }
+    const int ix = rm_clamp16(rm_pil_int((double)a.scale_w * px)), iy = rm_clamp16(rm_pil_int((double)a.H * py));
+    c.ivert[idx] = (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
+    rm_min(&c.item_y[2 * s], iy);
+    rm_max(&c.item_y[2 * s + 1], iy);
+  }
+  if (th.st_bad) c.misc[5] = 1;   // (cleared before the previous barrier)
+}
+
+// Rows an item occupies on the canvas: [ystart, ystart + cnt)
+RM_FN int rm_item_rows(const RmArgs& a, const RmCtx& c, int g, int s_lo, int* ystart) {
+  int y0 = c.item_y[2 * g], y1 = c.item_y[2 * g + 1];
+  if (y0 < 0) y0 = 0;
+  if (y1 > a.H - 1) y1 = a.H - 1;   // rows >= H draw nothing (hline clips)
+  *ystart = y0;
+  return (y1 >= y0 && g >= s_lo) ? (y1 - y0 + 1) : 0;
+}
+
+// p2, by every wave for itself (lane = this thread's index in its wave): exclusive scan of the items' row counts.
+// Host model: called once per wave with lane = -1 and does all lanes' work in a loop.
+RM_FN void rm_p2_scan(const RmArgs& a, const RmCtx& c, int lane) {
+  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+#if RM_DEV
+  int run = 0;
+  for (int i0 = 0; i0 < a.S; i0 += 64) {
+    const int g = i0 + lane;
+    int ys = 0;
+    const int cnt = g < a.S ? rm_item_rows(a, c, g, s_lo, &ys) : 0;
+    int inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (g < a.S) c.rowoff[g] = run + inc - cnt;
+    run += __shfl(inc, 63);
+  }
+  if (lane == 0) c.rowoff[a.S] = run;
+#else
+  (void)lane;
+  int run = 0;
+  for (int g = 0; g < a.S; ++g) { int ys; c.rowoff[g] = run; run += rm_item_rows(a, c, g, s_lo, &ys); }
+  c.rowoff[a.S] = run;
+#endif
+}
+
+// The pass that starts with item `base`: as many whole items as fit in the row records.  Returns the item behind it.
+RM_FN int rm_pass_end(const RmArgs& a, const RmCtx& c, int base) {
+  const int r0 = c.rowoff[base];
+  int lo = base + 1, hi = a.S;   // largest end with rowoff[end] - r0 <= cap_rows
+  if (c.rowoff[a.S] - r0 <= a.cap_rows) return a.S;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (c.rowoff[mid] - r0 <= a.cap_rows) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// p2, second half (every wave for itself; `lane` as above): the pass's items get their row records.
+RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int lane) {
+  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+  const int r0 = c.rowoff[base];
+#if RM_DEV
+  for (int g = base + lane; g < end; g += 64) {
+#else
+  (void)lane;
+  for (int g = base; g < end; ++g) {
+#endif
+    int ys;
+    const int cnt = rm_item_rows(a, c, g, s_lo, &ys);
+    const int first = c.rowoff[g] - r0;
+    c.info[g].rowbase = first - ys;
+    const int ymax = c.item_y[2 * g + 1];
+    c.info[g].pymax = ymax > a.H ? a.H : ymax;   // polygon_generic clamps ymax to ysize
+    for (int j = 0; j < cnt; ++j) c.rowitem[first + j] = (uint8_t)g;
+  }
+}
+
+// p3: the edge that leaves every vertex, and the census of the rows it touches
+template <int WORDS>
+RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int tid, int T) {
+  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+  const int TOTV = a.L.TOTV;
+  for (int idx = tid; idx < TOTV; idx += T) {
+    const uint32_t vi = a.vinfo[idx];
+    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
+    const RmItem it = c.info[s];
+    const int nv = it.pb_nv >> 20;
+    RmEdge E = {0u, 0u, 0u, 0u};
+    int kind = 0;
+    const bool mine = k < nv && s >= s_lo && s >= base && s < end;
+    if (mine) kind = rm_build_edge(c.ivert + (idx - k), k, nv, &E);
+    if (k < nv) c.edges[idx] = E;   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
+    if (!mine || kind == 0) continue;
+    const uint32_t bit = 1u << k;
+    const int y0 = rm_y0(E), y1 = rm_y1(E);
+    RmRow* rr = c.rows + it.rowbase;
+    if (kind == 2) {
+      if (y0 >= 0 && y0 < a.H) rm_or(&rr[y0].heads, bit);
+      continue;
+    }
+    const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
+    const int ya = emin < 0 ? 0 : emin, yb = emax > a.H - 1 ? a.H - 1 : emax;
+    for (int y = ya; y <= yb; ++y) rm_or(&rr[y].act, bit);
+    const float dx = rm_u2f(E.w1);
+    if (dx != 0.0f) {   // rows on which the corner fix-up looks at this edge: its first row; its last if that is the polygon's
+      const bool pos = dx > 0.0f;
+      if (emin >= 0 && emin < a.H) rm_or(pos ? &rr[emin].tipP : &rr[emin].tipN, bit);
+      if (emax == it.pymax && emax >= 0 && emax < a.H) rm_or(pos ? &rr[emax].tipP : &rr[emax].tipN, bit);
+    }
+  }
+}
+
+#if !RM_DEV && defined(RM_STATS)
+static long long rm_stats[16];   // host model only: [1] generic rows [3] active edges [4..7] rows by number of heads [8] rows with a corner pair [9] most active edges
+#endif
+// p4: one thread per (item, row)
+template <int WORDS>
+RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T, float* xx_wave) {
+  const int nseg = a.W >> 4;
+  for (int w0 = 0; w0 < total_rows; w0 += T) {
+    const int w = w0 + tid;
+    const bool on = w < total_rows;
+    RmRow rec = {0u, 0u, 0u, 0u};
+    RmItem it = {0, 0, 0, 0u};
+    int g = 0;
+    if (on) { rec = c.rows[w]; g = c.rowitem[w]; it = c.info[g]; }
+    const int y = w - it.rowbase;
+    const RmEdge* pe = c.edges + (it.pb_nv & 0xfffff);
+    RmMask<WORDS> m;
+    const bool ok = rm_row_fast<WORDS>(pe, rec, y, it.pymax, a.W, m);
+#if !RM_DEV && defined(RM_STATS)
+    if (on) {
+      rm_stats[1] += ok ? 0 : 1;
+      rm_stats[3] += __builtin_popcount(rec.act);
+      const int nh = __builtin_popcount(rec.heads);
+      rm_stats[4 + (nh > 3 ? 3 : nh)]++;
+      rm_stats[8] += ((rec.tipP & (rec.tipP - 1u)) || (rec.tipN & (rec.tipN - 1u))) ? 1 : 0;
+      if (__builtin_popcount(rec.act) > rm_stats[9]) rm_stats[9] = __builtin_popcount(rec.act);
+    }
+#endif
+#if RM_DEV
+    unsigned long long gm = __ballot(on && !ok);
+    while (gm) {   // the rare rows, one at a time (they share the wave's scratch list)
+      const int l = __builtin_ctzll(gm);
+      gm &= gm - 1ull;
+      if ((tid & 63) == l) rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave, m);
+    }
+#else
+    if (on && !ok) rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave, m);
+#endif
+    if (on) {
+      uint64_t* mp = reinterpret_cast<uint64_t*>(c.rows + w);
+      mp[0] = m.w[0];
+      if (WORDS > 1) mp[1] = m.w[1];
+      for (int sg = 0; sg < nseg; ++sg) {
+        const uint64_t mw = m.w[WORDS > 1 ? (sg >> 2) : 0];
+        if ((mw >> ((sg & 3) * 16)) & 0xffffull) rm_or(&c.seg[(y * nseg + sg) * a.iwords + (g >> 5)], 1u << (g & 31));
+      }
+    }
+  }
+}
+
+// Draw.c BLEND8 / DIV255 on one channel
+RM_FN uint32_t rm_blend8(uint32_t bg, uint32_t fg, uint32_t al) {
+  const uint32_t t = bg * (255u - al) + fg * al + 128u;
+  return ((t >> 8) + t) >> 8;
+}
+
+// p5: compose (painter's order = item order) and store, one thread per 16-pixel segment = 48 bytes = 12 dwords.
+// first_pass: the picture starts from the background colour / the cached static prefix, else from what `image` holds.
+template <int WORDS>
+RM_FN void rm_p5(const RmArgs& a, const RmCtx& c, int env, bool first_pass, int tid, int T) {
+  const int nseg = a.W >> 4, segs = a.H * nseg;
+  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+  uint8_t* out = a.image + (size_t)env * a.H * a.W * 3;
+  const bool from_cache = first_pass && s_lo > 0;
+  const uint32_t bg0 = (a.bg & 0xffffffu) | (a.bg << 24), bg1 = ((a.bg >> 8) & 0xffffu) | (a.bg << 16), bg2 = ((a.bg >> 16) & 0xffu) | (a.bg << 8);
+  for (int seg = tid; seg < segs; seg += T) {
+    const int y = seg / nseg, sg = seg - y * nseg, x0 = sg * 16;
+    const size_t off = ((size_t)(a.flip ? a.H - 1 - y : y) * a.W + x0) * 3;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + off);
+    uint32_t d[12];
+    if (first_pass && !from_cache) {
+      for (int q = 0; q < 4; ++q) { d[3 * q] = bg0; d[3 * q + 1] = bg1; d[3 * q + 2] = bg2; }
+    } else {
+      const uint32_t* src = from_cache ? reinterpret_cast<const uint32_t*>(a.sbg + off) : dst;
+      for (int q = 0; q < 12; ++q) d[q] = src[q];
+    }
+    for (int iw = 0; iw < a.iwords; ++iw) {
+      uint32_t bitsw = c.seg[seg * a.iwords + iw];
+      while (RM_ANY(bitsw != 0u)) {
+        if (bitsw != 0u) {
+          const int g = iw * 32 + rm_ffs(bitsw);
+          bitsw &= bitsw - 1u;
+          const RmItem it = c.info[g];
+          const uint32_t* mrow = reinterpret_cast<const uint32_t*>(c.rows + (it.rowbase + y));
+          const uint32_t bits = (mrow[x0 >> 5] >> (x0 & 31)) & 0xffffu;
+          const uint32_t rgb = it.rgba, al = it.rgba >> 24;
+          const uint32_t c0 = (rgb & 0xffffffu) | (rgb << 24), c1 = ((rgb >> 8) & 0xffffu) | (rgb << 16), c2 = ((rgb >> 16) & 0xffu) | (rgb << 8);
+          if (RM_ANY(al != 255u)) {
+            if (al != 255u) {   // hline32rgba: one BLEND8 per channel of every covered pixel
+              for (int q = 0; q < 4; ++q) {
+                const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
+                const uint32_t cc[3] = {c0, c1, c2};
+                for (int j = 0; j < 3; ++j) {
+                  const uint32_t mk = lm[j], o = d[3 * q + j], f = cc[j];
+                  uint32_t r = 0u;
+                  for (int b = 0; b < 4; ++b) {
+                    const uint32_t ob = (o >> (8 * b)) & 255u, fb = (f >> (8 * b)) & 255u;
+                    r |= (((mk >> (8 * b)) & 1u) ? rm_blend8(ob, fb, al) : ob) << (8 * b);
+                  }
+                  d[3 * q + j] = r;
+                }
+              }
+              continue;
+            }
+          }
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
+            const uint32_t m0 = lm[0], m1 = lm[1], m2 = lm[2];
+            d[3 * q] = (c0 & m0) | (d[3 * q] & ~m0);
+            d[3 * q + 1] = (c1 & m1) | (d[3 * q + 1] & ~m1);
+            d[3 * q + 2] = (c2 & m2) | (d[3 * q + 2] & ~m2);
+          }
+        }
+      }
+    }
+    for (int q = 0; q < 12; ++q) dst[q] = d[q];
+  }
+}
+
+// Later passes start from clean row records / segment words
+RM_FN void rm_next_pass(const RmArgs& a, const RmCtx& c, int tid, int T) {
+  for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
+  const int nseg = a.W >> 4;
+  for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
+}
+
+#endif  // MOOG_RASTER_MASK_CORE_H_
