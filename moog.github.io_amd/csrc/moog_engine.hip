@@ -564,14 +564,15 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       ms.first_person = prog->render.polymod == MOOG_POLYMOD_FIRST_PERSON ? 1 : 0;
       if (ms.first_person) { ms.fp_slot0 = prog->layer_slot0[prog->render.polymod_layer]; ms.fp_nslots = prog->layer_nslots[prog->render.polymod_layer]; }
       ms.bg = ((uint32_t)prog->render.bg[0] & 255u) | (((uint32_t)prog->render.bg[1] & 255u) << 8) | (((uint32_t)prog->render.bg[2] & 255u) << 16);
-      // row records per pass: 224 (the headline workload's frames have ~170 rows behind the cached walls), at least a
+      // row records per pass: 192 (the headline workload's frames have ~170 rows behind the cached walls), at least a
       // canvas height so that any one polygon fits; frames with more rows take several passes
-      int cap = 224;
+      int cap = 192;
       { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) cap = atoi(rc); }   // tuning / tests of the multi-pass path
+      if (cap > RM_SORT_ROUNDS * RM_THREADS) cap = RM_SORT_ROUNDS * RM_THREADS;   // (the row sort keeps a pass's rows in registers, RM_SORT_ROUNDS per thread)
       if (cap < e->canvas_h) cap = e->canvas_h;
       if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
       ms.cap_rows = cap;
-      rm_plan(ms.S, e->L.TOTV, e->pad_w, e->canvas_h, cap, ms.iwords, 2, &ms.plan);
+      rm_plan(ms.S, e->L.TOTV, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, &ms.plan);
       ms.lds = ms.plan.total;
       { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) ms.lds += (uint32_t)atoi(pad); }  // occupancy experiments
       if (ms.lds > 64 * 1024) ms.ok = 0;

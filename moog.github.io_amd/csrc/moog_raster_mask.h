@@ -6,18 +6,18 @@
 
 #include "moog_raster_mask_core.h"
 
-#define RM_THREADS 128
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
 template <int WORDS>
-__global__ __launch_bounds__(RM_THREADS) void moog_raster_mask_kernel(RmArgs a) {
+__global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mask_kernel(RmArgs a) {
   const int env = (int)blockIdx.x;
   if (env >= a.n_envs) return;
   const RmCtx c = rm_ctx(a.plan, moog_lds);
   const int tid = (int)threadIdx.x, lane = tid & 63;
   RmThread th;
   rm_p0<WORDS>(a, c, env, tid, RM_THREADS, th);
+  if (tid < 64) rm_p0_slots(a, c, env, lane, th);
   __syncthreads();
   if (a.debug_stop == 1) return;
   rm_p1<WORDS>(a, c, env, tid, RM_THREADS, th);
@@ -25,23 +25,31 @@ __global__ __launch_bounds__(RM_THREADS) void moog_raster_mask_kernel(RmArgs a) 
   if (a.debug_stop == 2) return;
   // (every wave scans the items for itself: both write the same words, and a wave's LDS operations execute in order,
   //  so each reads back what it wrote -- no barrier between the scan and the edges)
-  rm_p2_scan(a, c, lane);
+  const int s_lo = __builtin_amdgcn_readfirstlane(rm_s_lo(a, c));
+  rm_p2_scan(a, c, s_lo, lane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   for (int base = 0;;) {
     const int end = __builtin_amdgcn_readfirstlane(rm_pass_end(a, c, base));
     const int total_rows = __builtin_amdgcn_readfirstlane(c.rowoff[end] - c.rowoff[base]);
-    rm_p2_assign(a, c, base, end, lane);
+    rm_p2_assign(a, c, base, end, s_lo, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.debug_stop == 3) return;
-    rm_p3<WORDS>(a, c, base, end, tid, RM_THREADS);
+    rm_p3<WORDS>(a, c, base, end, s_lo, tid, RM_THREADS);
     __syncthreads();
     if (a.debug_stop == 4) return;
+    {
+      RmSortKey sk;
+      rm_p4a(c, total_rows, tid, RM_THREADS, sk);
+      __syncthreads();
+      rm_p4b(c, total_rows, tid, RM_THREADS, sk);
+      __syncthreads();
+    }
     rm_p4<WORDS>(a, c, total_rows, tid, RM_THREADS, c.xx + (tid >> 6) * RM_XX);
     __syncthreads();
     if (a.debug_stop == 5) return;
-    rm_p5<WORDS>(a, c, env, base == 0, tid, RM_THREADS);
+    rm_p5<WORDS>(a, c, env, base == 0, s_lo, tid, RM_THREADS);
     if (end >= a.S) break;
     base = end;
     __syncthreads();

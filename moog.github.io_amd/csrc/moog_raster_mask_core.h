@@ -8,9 +8,9 @@
 // What makes it cheap (the frames of the headline workload hold ~28 polygons that are 3-6 pixels tall):
 //  * No crossing lists.  polygon_generic sorts a row's crossings xx[] and fills [ROUND_UP(xx[2q]), ROUND_DOWN(xx[2q+1])]
 //    for every pair, left to right, never painting a pixel twice (x_pos).  The union of those spans is
-//        XOR_x low(ROUND_DOWN(x) + 1)   |   OR_x pixels[ROUND_UP(x) .. ROUND_DOWN(x)]
-//    (low(t) = pixels 0 .. t-1): pixel p is covered iff the number of crossings with ROUND_DOWN(x) < p is odd, or some
-//    crossing rounds onto p (the second term is one pixel, none for a positive half-integer).  Both terms are commutative, so a row's mask is accumulated in any order, in registers.
+//        XOR_x high(ROUND_DOWN(x) + 1)   |   OR_x pixels[ROUND_UP(x) .. ROUND_DOWN(x)]
+//    (high(t) = pixels t, t + 1, ...): pixel p is covered iff the number of crossings with ROUND_DOWN(x) < p is odd, or
+//    some crossing rounds onto p (the second term is one pixel, none for a positive half-integer).  Both terms are commutative, so a row's mask is accumulated in any order, in registers.
 //    (A closed polygon crosses a row an even number of times with Pillow's counting -- an edge's last row counts twice,
 //    a local extremum 2 or 4 times; a row with an odd count takes the generic routine.)
 //  * Census by bit mask.  Polygons have <= 32 edges, so "which edges are active on row y", "which are horizontal heads
@@ -54,14 +54,22 @@
 #define RM_CONSTP(T) const T*
 #endif
 
+#ifndef RM_THREADS
+#define RM_THREADS 128        // threads per frame
+#endif
+#ifndef RM_WAVES_PER_SIMD
+#define RM_WAVES_PER_SIMD 5   // register budget: 96 VGPRs
+#endif
 #define RM_MAX_NV 32          // vertices per polygon (edge index = bit of a census word)
 #define RM_XX 64              // crossing-list capacity of the generic row routine (2 per edge)
 
-struct RmEdge { uint32_t w0, w1, w2, w3; };   // table edge: float x0 | float dx | y0, y1 (shorts) | 0;  head: xmin, xmax (shorts) | 0 | y, y | 1
-struct RmRow { uint32_t act, heads, tipP, tipN; };   // census of a (polygon, row); after the row phase w0.. = the coverage mask
-struct RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint32_t rgba; };   // row record of row 0 | first vertex slot, live vertices << 20 | min(ymax, H) | colour
+struct alignas(16) RmEdge { uint32_t w0, w1, w2, w3; };   // table edge: float x0 | float dx | y0, y1 (shorts) | 0;  head: xmin, xmax (shorts) | 0 | y, y | 1
+struct alignas(16) RmRow { uint32_t act, heads, tipP, tipN; };   // census of a (polygon, row); after the row phase w0.. = the coverage mask
+struct alignas(16) RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint32_t rgba; };   // row record of row 0 | first vertex slot, live vertices << 20 | min(ymax, H) | colour
 
-struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_rowoff, o_seg, o_lut, o_xx, o_misc, total; };
+struct alignas(16) RmU4 { uint32_t x, y, z, w; };
+
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, total; };
 
 struct RmArgs {
   const moog_program_t* P;
@@ -100,7 +108,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
   p->o_ivert = o; o = rm_align(o + (uint32_t)TOTV * 4u);
   p->o_rows = o; o = rm_align(o + (uint32_t)cap_rows * sizeof(RmRow));
-  p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows);
+  p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows * 2u);
   p->o_info = o; o = rm_align(o + (uint32_t)S * sizeof(RmItem));
   p->o_item_y = o; o = rm_align(o + (uint32_t)S * 8u);
   p->o_rowoff = o; o = rm_align(o + (uint32_t)(S + 1) * 4u);
@@ -108,12 +116,18 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_lut = o; o = rm_align(o + 16u * 16u);
   p->o_xx = o; o = rm_align(o + (uint32_t)waves * RM_XX * 4u);
   p->o_misc = o; o = rm_align(o + 64u);
+  p->o_owner = o; o = rm_align(o + (uint32_t)TOTV);   // the slot of every compact vertex number
+  {   // a word per thread (p3) / the sorted row list (p4)
+    const uint32_t b1 = (uint32_t)waves * 64u * 4u, b2 = (uint32_t)cap_rows * 2u;
+    p->o_spare = o; o = rm_align(o + (b1 > b2 ? b1 : b2));
+  }   // a word per thread: where atomics with nothing to add go
   p->total = o;
 }
 
 struct RmCtx {
-  RmEdge* edges; uint32_t* ivert; RmRow* rows; uint8_t* rowitem; RmItem* info; int32_t* item_y; int32_t* rowoff;
-  uint32_t* seg; uint32_t* lut; float* xx; int32_t* misc;   // misc: [5] static prefix differs
+  RmEdge* edges; uint32_t* ivert; RmRow* rows; uint16_t* rowitem;   // rowitem: the row's item | 256 when a shallow edge has a corner on the row
+  RmItem* info; int32_t* item_y; int32_t* rowoff;
+  uint32_t* seg; uint32_t* lut; float* xx; uint32_t* spare; uint16_t* sorted; uint8_t* owner; int32_t* misc;   // sorted (p4: the rows in order of their kind) shares the spare words' memory (p3)   // misc: [5] static prefix differs
 };
 
 RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
@@ -121,7 +135,7 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
   c.edges = reinterpret_cast<RmEdge*>(lds + pl.o_edge);
   c.ivert = reinterpret_cast<uint32_t*>(lds + pl.o_ivert);
   c.rows = reinterpret_cast<RmRow*>(lds + pl.o_rows);
-  c.rowitem = reinterpret_cast<uint8_t*>(lds + pl.o_rowitem);
+  c.rowitem = reinterpret_cast<uint16_t*>(lds + pl.o_rowitem);
   c.info = reinterpret_cast<RmItem*>(lds + pl.o_info);
   c.item_y = reinterpret_cast<int32_t*>(lds + pl.o_item_y);
   c.rowoff = reinterpret_cast<int32_t*>(lds + pl.o_rowoff);
@@ -129,6 +143,9 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
   c.lut = reinterpret_cast<uint32_t*>(lds + pl.o_lut);
   c.xx = reinterpret_cast<float*>(lds + pl.o_xx);
   c.misc = reinterpret_cast<int32_t*>(lds + pl.o_misc);
+  c.spare = reinterpret_cast<uint32_t*>(lds + pl.o_spare);
+  c.sorted = reinterpret_cast<uint16_t*>(lds + pl.o_spare);
+  c.owner = reinterpret_cast<uint8_t*>(lds + pl.o_owner);
   return c;
 }
 
@@ -194,6 +211,8 @@ RM_FN uint32_t rm_hsv_rgb(double h, double s, double v) {
 // ---- coverage masks -----------------------------------------------------------------------------------------------
 template <int WORDS> struct RmMask { uint64_t w[WORDS]; };
 RM_FN uint64_t rm_low(int t) { return t <= 0 ? 0ull : (t >= 64 ? ~0ull : ((1ull << t) - 1ull)); }   // pixels 0 .. t-1
+RM_FN uint64_t rm_high(int t) { return t >= 64 ? 0ull : (~0ull << (t & 63)); }                       // pixels t .. 63 (t >= 0)
+RM_FN uint64_t rm_high1(int t) { return t <= 64 ? ~0ull : rm_high(t - 64); }                           // the same of the second word
 template <int WORDS> RM_FN void rm_clear(RmMask<WORDS>& m) { for (int i = 0; i < WORDS; ++i) m.w[i] = 0ull; }
 template <int WORDS> RM_FN bool rm_bit(const RmMask<WORDS>& m, int p) { return (m.w[WORDS > 1 ? (p >> 6) : 0] >> (p & 63)) & 1ull; }
 // pixels [a, b] clipped to [0, 64 * WORDS); nothing when a > b
@@ -259,7 +278,8 @@ RM_FN int rm_build_edge(const uint32_t* pv, int k, int nv, RmEdge* out) {
 // polygon_generic verbatim for one row (any number of crossings, overwritten partner entries, odd counts): the rare rows.
 // xx: RM_XX floats of scratch.
 template <int WORDS>
-RM_SLOW void rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, int y, int pymax, float* xx, RmMask<WORDS>& m) {
+RM_SLOW RmMask<WORDS> rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, int y, int pymax, float* xx) {   // (the mask comes back in registers: a reference would put the caller's copy in scratch memory)
+  RmMask<WORDS> m;
   rm_clear(m);
   int j = 0;
   for (int i = 0; i < nv; ++i) {
@@ -355,6 +375,7 @@ RM_SLOW void rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, int y, int
     rm_or_range(m, x_start, x_end);
     x_pos = x_end + 1;
   }
+  return m;
 }
 
 // The corner fix-up of a row, from the census word of one lean (bits = edges with a corner on this row): every edge but
@@ -419,12 +440,65 @@ RM_FN void rm_heads(const RmEdge* pe, uint32_t& hb, int& pen, RmMask<WORDS>& m) 
   }
 }
 
+// The crossings of a row, accumulated (see the head of the file).  HEADS: also where the spans end (seen / seen2).
+template <int WORDS, bool HEADS>
+RM_FN void rm_crossings(const RmEdge* pe, uint32_t m, int y, int pymax, int W, const RmFix& fix, RmMask<WORDS>& par, RmMask<WORDS>& pix,
+                        RmMask<WORDS>& seen, RmMask<WORDS>& seen2, bool& odd) {
+  const float wlim = (float)(W - 1);
+  const bool anyheads = HEADS;
+  // (wave-uniform loop without a branch inside: a lane whose row has no edge left goes through the motions on edge 0 with
+  //  every effect masked off)
+  const bool ylt = y < pymax;
+  while (RM_ANY(m != 0u)) {
+    const bool valid = m != 0u;
+    const int k = valid ? rm_ffs(m) : 0;
+    m &= m - 1u;
+    const RmEdge E = pe[k];
+    const int y0 = rm_y0(E), y1 = rm_y1(E);
+    float x = rm_xat(E, y);
+    x = (k == fix.k0) ? fix.v0 : x;
+    x = (k == fix.k1) ? fix.v1 : x;
+    const int emax = y0 < y1 ? y1 : y0;
+    const bool dup = (y == emax) && ylt;   // "needed to draw consistent polygons": the edge's last row counts twice
+    const float ax = fabsf(x);
+    const float fu = floorf(ax + 0.5f), fd = ceilf(ax - 0.5f);
+    const float fs = copysignf(fd, x);                 // ROUND_DOWN(x)
+    const float fc = fminf(fmaxf(fs, -1.0f), wlim);    // clipped to [-1, W - 1]
+    const int rc = (int)fc;
+    const bool inr = valid && (fs == fc) && (fc >= 0.0f);   // ROUND_DOWN(x) is a pixel of the canvas
+    // pixels p with ROUND_UP(x) <= p <= ROUND_DOWN(x): round(x) unless x is a half-integer -- a positive one has none, a
+    // negative one two (Draw.c rounds halves away from zero going up, towards zero going down), of which only
+    // ROUND_DOWN(-0.5) = 0 can be on the canvas
+    const bool onpix = inr && ((fu == fd) || (x < 0.0f));
+    const bool tog = valid && !dup;
+    const int t = tog ? rc + 1 : 64 * WORDS;   // (nothing above 64 * WORDS - 1)
+    par.w[0] ^= rm_high(t);
+    if (WORDS > 1) par.w[1] ^= rm_high1(t);
+    odd = odd != tog;
+    const uint64_t b = (uint64_t)(inr ? 1u : 0u) << (rc & 63);
+    const bool hiw = WORDS > 1 && rc >= 64;   // (which word of the mask the pixel is in)
+    const uint64_t b0 = hiw ? 0ull : b, b1 = hiw ? b : 0ull;
+    pix.w[0] |= onpix ? b0 : 0ull;
+    if (WORDS > 1) pix.w[1] |= onpix ? b1 : 0ull;
+    if (anyheads) {
+      // Where Pillow's pen can come to rest: the last pixels of the spans = ROUND_DOWN of the crossings of odd rank.
+      // seen: pixels some crossing rounds down onto; seen2: pixels two or more do (one of two neighbours in the sorted
+      // list has odd rank; this includes the pairs of equal half-integers, whose span [n + 1, n] paints nothing and
+      // still moves the pen).  A lone crossing has odd rank iff the parity mask covers its pixel (below).
+      seen2.w[0] |= (seen.w[0] & b0) | (dup ? b0 : 0ull);
+      seen.w[0] |= b0;
+      if (WORDS > 1) { seen2.w[1] |= (seen.w[1] & b1) | (dup ? b1 : 0ull); seen.w[1] |= b1; }
+    }
+  }
+}
+
 // The coverage mask of row y of a polygon from its census record.  Returns false when the row needs rm_row_generic.
 template <int WORDS>
-RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int W, RmMask<WORDS>& out) {
+RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int W, bool shallow, RmMask<WORDS>& out) {
   RmFix fix; fix.k0 = -1; fix.k1 = -1; fix.v0 = 0.0f; fix.v1 = 0.0f; fix.generic = false;
   {
-    const bool tp = (rec.tipP & (rec.tipP - 1u)) != 0u, tn = (rec.tipN & (rec.tipN - 1u)) != 0u;
+    // (shallow: some edge with a corner on this row runs >= 1.49 pixels per row -- without one no fix-up moves anything)
+    const bool tp = shallow && (rec.tipP & (rec.tipP - 1u)) != 0u, tn = shallow && (rec.tipN & (rec.tipN - 1u)) != 0u;
     if (RM_ANY(tp || tn)) {
       if (tp) rm_fix_class(pe, rec.tipP, y, fix);
       if (tn) rm_fix_class(pe, rec.tipN, y, fix);
@@ -436,47 +510,10 @@ RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int 
   RmMask<WORDS> seen, seen2;
   rm_clear(seen); rm_clear(seen2);
   const bool anyheads = RM_ANY(rec.heads != 0u);
-  uint32_t m = rec.act;
-  const float wlim = (float)(W - 1);
-  while (RM_ANY(m != 0u)) {
-    if (m != 0u) {
-      const int k = rm_ffs(m);
-      m &= m - 1u;
-      const RmEdge E = pe[k];
-      const int y0 = rm_y0(E), y1 = rm_y1(E);
-      float x = rm_xat(E, y);
-      x = (k == fix.k0) ? fix.v0 : x;
-      x = (k == fix.k1) ? fix.v1 : x;
-      const int emax = y0 < y1 ? y1 : y0;
-      const bool dup = (y == emax) && (y < pymax);   // "needed to draw consistent polygons": the edge's last row counts twice
-      const float ax = fabsf(x);
-      const float fu = floorf(ax + 0.5f), fd = ceilf(ax - 0.5f);
-      const float fs = copysignf(fd, x);                 // ROUND_DOWN(x)
-      const float fc = fminf(fmaxf(fs, -1.0f), wlim);    // clipped to [-1, W - 1]
-      const int rc = (int)fc;
-      // pixels p with ROUND_UP(x) <= p <= ROUND_DOWN(x): round(x) unless x is a half-integer -- a positive one has none, a
-      // negative one two (Draw.c rounds halves away from zero going up, towards zero going down), of which only
-      // ROUND_DOWN(-0.5) = 0 can be on the canvas
-      const bool onpix = ((fu == fd) || (x < 0.0f)) && (fs == fc) && (fc >= 0.0f);
-      if (!dup) {
-        par.w[0] ^= rm_low(rc + 1);
-        if (WORDS > 1) par.w[1] ^= rm_low(rc + 1 - 64);
-        odd = !odd;
-      }
-      if (onpix) pix.w[WORDS > 1 ? (rc >> 6) : 0] |= 1ull << (rc & 63);
-      if (anyheads) {
-        // Where Pillow's pen can come to rest: the last pixels of the spans = ROUND_DOWN of the crossings of odd rank.
-        // seen: pixels some crossing rounds down onto; seen2: pixels two or more do (one of two neighbours in the sorted
-        // list has odd rank; this includes the pairs of equal half-integers, whose span [n + 1, n] paints nothing and
-        // still moves the pen).  A lone crossing has odd rank iff the parity mask covers its pixel (below).
-        const uint64_t b = ((fs == fc) && (fc >= 0.0f)) ? (1ull << (rc & 63)) : 0ull;
-        uint64_t& sw = seen.w[WORDS > 1 ? ((rc >> 6) & 1) : 0];
-        uint64_t& sw2 = seen2.w[WORDS > 1 ? ((rc >> 6) & 1) : 0];
-        sw2 |= (sw & b) | (dup ? b : 0ull);
-        sw |= b;
-      }
-    }
-  }
+  // (two copies of the loop: the bookkeeping for the heads is a fifth of its instructions, and after the row sort only
+  //  the first wavefuls of a pass have rows with heads)
+  if (anyheads) rm_crossings<WORDS, true>(pe, rec.act, y, pymax, W, fix, par, pix, seen, seen2, odd);
+  else rm_crossings<WORDS, false>(pe, rec.act, y, pymax, W, fix, par, pix, seen, seen2, odd);
   const bool any = rec.act != 0u;
   for (int i = 0; i < WORDS; ++i) {
     const int wbits = W - 64 * i;
@@ -506,6 +543,19 @@ RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int 
   }
   return !(odd || fix.generic);
 }
+
+// Inclusive scan over the wavefront in six DPP adds: within rows of 16 lanes, then across the rows
+#if RM_DEV
+RM_FN int rm_wave_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+#endif
 
 // ---- the frame, phase by phase ------------------------------------------------------------------------------------------
 // One workgroup of `T` threads (T / 64 wavefronts) renders one frame.  Barriers stand between the phases:
@@ -539,37 +589,73 @@ RM_FN void rm_p0(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
     c.lut[4 * tid + 2] = (p2 ? 0x000000ffu : 0u) | (p3 ? 0xffffff00u : 0u);
     c.lut[4 * tid + 3] = 0u;
   }
-  if (tid < 8) c.misc[tid] = 0;
-  RM_CONSTP(moog_program_t) P = (RM_CONSTP(moog_program_t))(uintptr_t)a.P;
-  const int NS = a.n_static;
-  for (int s = tid; s < a.S; s += T) {
-    const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
-    const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
-    const bool alive = (flags & MOOG_F_ALIVE) != 0;
-    if (s < NS) {
-      const double* rc = a.sref_col + 3 * s;
-      uint64_t b0, b1, b2, r0, r1, r2;
-      memcpy(&b0, &c0, 8); memcpy(&b1, &c1, 8); memcpy(&b2, &c2, 8); memcpy(&r0, rc, 8); memcpy(&r1, rc + 1, 8); memcpy(&r2, rc + 2, 8);
-      th.st_bad = th.st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
-                  b0 != r0 || b1 != r1 || b2 != r2;
-    }
-    uint32_t rgba = 0u;
-    if (alive) {
-      uint32_t rgb;
-      if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.S + s] & 0xffffffu;
-      else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
-      else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
-      rgba = rgb | (((uint32_t)opa & 255u) << 24);
-    }
-    RmItem it;
-    it.rowbase = 0; it.pb_nv = P->slot_voff[s] | ((alive ? nvs : 0) << 20); it.pymax = 0; it.rgba = rgba;
-    c.info[s] = it;
-    c.item_y[2 * s] = 0x7fffffff; c.item_y[2 * s + 1] = -0x7fffffff;
-  }
+  if (tid < 12) c.misc[tid] = 0;   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort)
   if (a.first_person) {   // polygon_modifiers.py:41-64: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
     for (int s = a.fp_slot0; s < a.fp_slot0 + a.fp_nslots; ++s)
       if (gq[L.o_flags + s] & MOOG_F_ALIVE) { th.fpx = 0.5 - gf[L.o_pos + 2 * s]; th.fpy = 0.5 - gf[L.o_pos + 2 * s + 1]; break; }
   }
+}
+
+// p0, the first wave only (lane = the thread's index in it; host model: lane = -1 does every lane's work): per-slot
+// colour and liveness, and where the slot's live vertices start in the COMPACT vertex numbering the later phases use
+// (live vertices only, slot after slot: 260 of the headline workload's 451 vertex slots are in use).
+RM_FN void rm_p0_slots(const RmArgs& a, const RmCtx& c, int env, int lane, RmThread& th) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
+  const int NS = a.n_static;
+  int run = 0;
+#if RM_DEV
+  for (int i0 = 0; i0 < a.S; i0 += 64) {
+    const int s = i0 + lane;
+    const bool in = s < a.S;
+#else
+  (void)lane;
+  for (int s = 0; s < a.S; ++s) {
+    const bool in = true;
+#endif
+    int nvl = 0;
+    uint32_t rgba = 0u;
+    if (in) {
+      const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
+      const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
+      const bool alive = (flags & MOOG_F_ALIVE) != 0;
+      if (s < NS) {
+        const double* rc = a.sref_col + 3 * s;
+        uint64_t b0, b1, b2, r0, r1, r2;
+        memcpy(&b0, &c0, 8); memcpy(&b1, &c1, 8); memcpy(&b2, &c2, 8); memcpy(&r0, rc, 8); memcpy(&r1, rc + 1, 8); memcpy(&r2, rc + 2, 8);
+        th.st_bad = th.st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
+                    b0 != r0 || b1 != r1 || b2 != r2;
+      }
+      if (alive) {
+        uint32_t rgb;
+        if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.S + s] & 0xffffffu;
+        else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
+        else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
+        rgba = rgb | (((uint32_t)opa & 255u) << 24);
+        nvl = nvs < 0 ? 0 : (nvs > RM_MAX_NV ? RM_MAX_NV : nvs);
+      }
+    }
+#if RM_DEV
+    const int inc = rm_wave_scan(nvl);
+    const int first = run + inc - nvl;
+    run += __builtin_amdgcn_readlane(inc, 63);
+#else
+    const int first = run;
+    run += nvl;
+#endif
+    if (in) {
+      RmItem it;
+      it.rowbase = 0; it.pb_nv = first | (nvl << 20); it.pymax = 0; it.rgba = rgba;
+      c.info[s] = it;
+      c.item_y[2 * s] = 0x7fffffff; c.item_y[2 * s + 1] = -0x7fffffff;
+    }
+  }
+#if RM_DEV
+  if (lane == 0) c.misc[0] = run;
+#else
+  c.misc[0] = run;
+#endif
 }
 
 template <int WORDS>
@@ -585,7 +671,9 @@ RM_FN void rm_p1(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
       vx = gf[L.o_verts + 2 * (idx + T)]; vy = gf[L.o_verts + 2 * (idx + T) + 1];
     }
     const int s = vi_c & 0xffu, k = (vi_c >> 8) & 0xffu;
-    if (k >= (c.info[s].pb_nv >> 20)) continue;
+    const int pbnv = c.info[s].pb_nv;
+    if (k >= (pbnv >> 20)) continue;
+    const int ci = (pbnv & 0xfffff) + k;   // the vertex's compact number
     if (idx < a.nsv && NS > 0) {
       uint64_t b0, b1, r0, r1;
       memcpy(&b0, &x_c, 8); memcpy(&b1, &y_c, 8); memcpy(&r0, a.sref_v + 2 * idx, 8); memcpy(&r1, a.sref_v + 2 * idx + 1, 8);
@@ -594,12 +682,16 @@ RM_FN void rm_p1(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
     double px = x_c, py = y_c;
     if (a.first_person) { px = px + th.fpx; py = py + th.fpy; }
     const int ix = rm_clamp16(rm_pil_int((double)a.scale_w * px)), iy = rm_clamp16(rm_pil_int((double)a.H * py));
-    c.ivert[idx] = (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
+    c.ivert[ci] = (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
+    c.owner[ci] = (uint8_t)s;
     rm_min(&c.item_y[2 * s], iy);
     rm_max(&c.item_y[2 * s + 1], iy);
   }
   if (th.st_bad) c.misc[5] = 1;   // (cleared before the previous barrier)
 }
+
+// Items below s_lo are in the cached picture of the static prefix (valid after p1's barrier)
+RM_FN int rm_s_lo(const RmArgs& a, const RmCtx& c) { return (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0; }
 
 // Rows an item occupies on the canvas: [ystart, ystart + cnt)
 RM_FN int rm_item_rows(const RmArgs& a, const RmCtx& c, int g, int s_lo, int* ystart) {
@@ -612,21 +704,23 @@ RM_FN int rm_item_rows(const RmArgs& a, const RmCtx& c, int g, int s_lo, int* ys
 
 // p2, by every wave for itself (lane = this thread's index in its wave): exclusive scan of the items' row counts.
 // Host model: called once per wave with lane = -1 and does all lanes' work in a loop.
-RM_FN void rm_p2_scan(const RmArgs& a, const RmCtx& c, int lane) {
-  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+RM_FN void rm_p2_scan(const RmArgs& a, const RmCtx& c, int s_lo, int lane) {
 #if RM_DEV
   int run = 0;
   for (int i0 = 0; i0 < a.S; i0 += 64) {
     const int g = i0 + lane;
     int ys = 0;
     const int cnt = g < a.S ? rm_item_rows(a, c, g, s_lo, &ys) : 0;
+    // inclusive scan over the wave in six DPP adds: within rows of 16 lanes, then across the rows
     int inc = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
-    }
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     if (g < a.S) c.rowoff[g] = run + inc - cnt;
-    run += __shfl(inc, 63);
+    run += __builtin_amdgcn_readlane(inc, 63);
   }
   if (lane == 0) c.rowoff[a.S] = run;
 #else
@@ -650,8 +744,7 @@ RM_FN int rm_pass_end(const RmArgs& a, const RmCtx& c, int base) {
 }
 
 // p2, second half (every wave for itself; `lane` as above): the pass's items get their row records.
-RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int lane) {
-  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
+RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, int lane) {
   const int r0 = c.rowoff[base];
 #if RM_DEV
   for (int g = base + lane; g < end; g += 64) {
@@ -665,63 +758,152 @@ RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int 
     c.info[g].rowbase = first - ys;
     const int ymax = c.item_y[2 * g + 1];
     c.info[g].pymax = ymax > a.H ? a.H : ymax;   // polygon_generic clamps ymax to ysize
-    for (int j = 0; j < cnt; ++j) c.rowitem[first + j] = (uint8_t)g;
+    for (int j = 0; j < cnt; ++j) c.rowitem[first + j] = (uint16_t)g;
   }
 }
 
-// p3: the edge that leaves every vertex, and the census of the rows it touches
+// p3: the edge that leaves every vertex, and the census of the rows it touches.  Written for the wavefront: table edges
+// (nine in ten) are built by every lane without a branch, the census is atomics whose operand is zero where a lane has
+// nothing to say (on a spare word), so that the only divergent code is the horizontal edges' run merging.
 template <int WORDS>
-RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int tid, int T) {
-  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
-  const int TOTV = a.L.TOTV;
-  for (int idx = tid; idx < TOTV; idx += T) {
-    const uint32_t vi = a.vinfo[idx];
-    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
+RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, int tid, int T) {
+  const int lo = s_lo > base ? s_lo : base;
+  const int nlive = c.misc[0];
+  uint32_t* const spare = c.spare + tid;   // (this thread's own: atomics on one address would queue up behind each other)
+  for (int idx = tid; idx < nlive; idx += T) {   // compact vertex numbers: every one is a live vertex
+    const int s = c.owner[idx];
     const RmItem it = c.info[s];
-    const int nv = it.pb_nv >> 20;
-    RmEdge E = {0u, 0u, 0u, 0u};
-    int kind = 0;
-    const bool mine = k < nv && s >= s_lo && s >= base && s < end;
-    if (mine) kind = rm_build_edge(c.ivert + (idx - k), k, nv, &E);
-    if (k < nv) c.edges[idx] = E;   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
-    if (!mine || kind == 0) continue;
-    const uint32_t bit = 1u << k;
-    const int y0 = rm_y0(E), y1 = rm_y1(E);
-    RmRow* rr = c.rows + it.rowbase;
-    if (kind == 2) {
-      if (y0 >= 0 && y0 < a.H) rm_or(&rr[y0].heads, bit);
-      continue;
+    const int nv = it.pb_nv >> 20, k = idx - (it.pb_nv & 0xfffff);
+    const bool live = true;
+    const bool mine = s >= lo && s < end;
+    const uint32_t* pv = c.ivert + (idx - k);
+    const uint32_t q0 = pv[k], q1 = pv[(k + 1 >= nv) ? 0 : k + 1];
+    const int x0 = (int16_t)(q0 & 0xffffu), y0 = (int16_t)(q0 >> 16), x1 = (int16_t)(q1 & 0xffffu), y1 = (int16_t)(q1 >> 16);
+    const bool table = mine && y0 != y1;
+    RmEdge E;
+    E.w0 = table ? rm_f2u((float)x0) : 0u;
+    const float dx = ((float)(x1 - x0)) / (float)(table ? y1 - y0 : 1);
+    E.w1 = table ? rm_f2u(dx) : 0u;
+    E.w2 = table ? ((q0 >> 16) | (q1 & 0xffff0000u)) : 0u;
+    E.w3 = 0u;
+    const bool horiz = mine && y0 == y1;
+    bool head = false;
+    if (RM_ANY(horiz)) {
+      if (horiz) head = rm_build_edge(pv, k, nv, &E) == 2;
     }
+    if (live) c.edges[idx] = E;   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
+    const uint32_t bit = 1u << k;
+    RmRow* rr = c.rows + it.rowbase;
     const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
     const int ya = emin < 0 ? 0 : emin, yb = emax > a.H - 1 ? a.H - 1 : emax;
-    for (int y = ya; y <= yb; ++y) rm_or(&rr[y].act, bit);
-    const float dx = rm_u2f(E.w1);
-    if (dx != 0.0f) {   // rows on which the corner fix-up looks at this edge: its first row; its last if that is the polygon's
-      const bool pos = dx > 0.0f;
-      if (emin >= 0 && emin < a.H) rm_or(pos ? &rr[emin].tipP : &rr[emin].tipN, bit);
-      if (emax == it.pymax && emax >= 0 && emax < a.H) rm_or(pos ? &rr[emax].tipP : &rr[emax].tipN, bit);
+    {   // the rows the edge crosses
+      const bool any = table && ya <= yb;
+      const int last = any ? yb : ya - 1;
+      for (int y = ya; RM_ANY(y <= last); ++y) {
+        const bool on = y <= last;
+        rm_or(on ? &rr[y].act : spare, on ? bit : 0u);
+      }
+    }
+    {   // a head's row
+      const bool on = head && y0 >= 0 && y0 < a.H;
+      rm_or(on ? &rr[y0].heads : spare, on ? bit : 0u);
+    }
+    {   // rows on which the corner fix-up looks at this edge: its first row; its last if that is the polygon's
+      const bool lean = table && dx != 0.0f, pos = dx > 0.0f;
+      const bool t0 = lean && emin >= 0 && emin < a.H;
+      const bool t1 = lean && emax == it.pymax && emax >= 0 && emax < a.H;
+      rm_or(t0 ? (pos ? &rr[emin].tipP : &rr[emin].tipN) : spare, t0 ? bit : 0u);
+      rm_or(t1 ? (pos ? &rr[emax].tipP : &rr[emax].tipN) : spare, t1 ? bit : 0u);
+      // A fix-up moves a crossing only when both edges of the corner run at least 1.5 pixels sideways per row (the new
+      // value is ROUND_UP of the nearer neighbour row's crossing -+ 1 and must lie beyond the corner): rows without such
+      // an edge skip the partner search.  (1.49: the crossings are float32 sums, off by far less than that.)
+      const bool shallow = fabsf(dx) >= 1.49f;
+      uint8_t* const fl = reinterpret_cast<uint8_t*>(c.rowitem);
+      uint8_t* const fspare = reinterpret_cast<uint8_t*>(spare);
+      *((t0 && shallow) ? fl + 2 * (it.rowbase + emin) + 1 : fspare) = 1;
+      *((t1 && shallow) ? fl + 2 * (it.rowbase + emax) + 1 : fspare) = 1;
     }
   }
 }
 
 #if !RM_DEV && defined(RM_STATS)
+static long long rm_hist[16];   // rows by number of active edges
 static long long rm_stats[16];   // host model only: [1] generic rows [3] active edges [4..7] rows by number of heads [8] rows with a corner pair [9] most active edges
 #endif
+// The rows of a pass differ a lot in what they cost -- two edges and nothing else (half of them), six or seven edges, a
+// horizontal head or two, a corner fix-up -- and a wavefront pays for its most expensive lane in every loop.  So the rows
+// are handed to p4's threads in order of their kind (a counting sort on four buckets): rows with heads or a possible
+// fix-up first, then by the number of crossing edges.  The order of the rows has no effect on the picture.
+//   p4a: every row's bucket, its place in the bucket (ballots; one LDS atomic per wave, round and bucket)
+//   p4b (behind a barrier): the buckets' starts are known -> the sorted list
+#define RM_SORT_ROUNDS 3   // rounds of T rows a pass may have at most (cap_rows <= RM_SORT_ROUNDS * T)
+struct RmSortKey { int key[RM_SORT_ROUNDS]; int pos[RM_SORT_ROUNDS]; };
+
+RM_FN int rm_row_bucket(const RmRow& rec, bool shallow) {
+  const bool special = rec.heads != 0u || (shallow && (((rec.tipP & (rec.tipP - 1u)) | (rec.tipN & (rec.tipN - 1u))) != 0u));
+  const int pc = __builtin_popcount(rec.act);
+  return special ? 0 : (pc >= 5 ? 1 : (pc >= 3 ? 2 : 3));
+}
+
+RM_FN void rm_p4a(const RmCtx& c, int total_rows, int tid, int T, RmSortKey& sk) {
+#if RM_DEV
+  const int lane = tid & 63;
+  for (int r = 0; r < RM_SORT_ROUNDS; ++r) {
+    if (r * T >= total_rows) break;
+    const int w = r * T + tid;
+    const bool on = w < total_rows;
+    int key = 4;
+    if (on) { const RmRow rec = c.rows[w]; key = rm_row_bucket(rec, (c.rowitem[w] >> 8) != 0); }
+    int pos = 0;
+    for (int b = 0; b < 4; ++b) {
+      const unsigned long long mb = __ballot(key == b);
+      int base = 0;
+      if (lane == 0 && mb) base = atomicAdd(&c.misc[8 + b], __builtin_popcountll(mb));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (key == b) pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+    }
+    sk.key[r] = key; sk.pos[r] = pos;
+  }
+#else
+  (void)sk; (void)T;
+  if (tid != 0) return;   // host model: thread 0 sorts the whole pass
+  int cnt[4] = {0, 0, 0, 0}, start[4];
+  for (int w = 0; w < total_rows; ++w) cnt[rm_row_bucket(c.rows[w], (c.rowitem[w] >> 8) != 0)]++;
+  start[0] = 0; for (int b = 1; b < 4; ++b) start[b] = start[b - 1] + cnt[b - 1];
+  for (int w = 0; w < total_rows; ++w) c.sorted[start[rm_row_bucket(c.rows[w], (c.rowitem[w] >> 8) != 0)]++] = (uint16_t)w;
+#endif
+}
+
+RM_FN void rm_p4b(const RmCtx& c, int total_rows, int tid, int T, const RmSortKey& sk) {
+#if RM_DEV
+  const int n0 = c.misc[8], n1 = c.misc[9], n2 = c.misc[10];
+  for (int r = 0; r < RM_SORT_ROUNDS; ++r) {
+    if (r * T >= total_rows) break;
+    const int key = sk.key[r];
+    const int start = key == 0 ? 0 : (key == 1 ? n0 : (key == 2 ? n0 + n1 : n0 + n1 + n2));
+    if (key < 4) c.sorted[start + sk.pos[r]] = (uint16_t)(r * T + tid);
+  }
+#else
+  (void)c; (void)total_rows; (void)tid; (void)T; (void)sk;
+#endif
+}
+
 // p4: one thread per (item, row)
 template <int WORDS>
 RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T, float* xx_wave) {
   const int nseg = a.W >> 4;
   for (int w0 = 0; w0 < total_rows; w0 += T) {
-    const int w = w0 + tid;
-    const bool on = w < total_rows;
+    const bool on = w0 + tid < total_rows;
+    const int w = on ? c.sorted[w0 + tid] : 0;
     RmRow rec = {0u, 0u, 0u, 0u};
     RmItem it = {0, 0, 0, 0u};
     int g = 0;
-    if (on) { rec = c.rows[w]; g = c.rowitem[w]; it = c.info[g]; }
+    bool shallow = false;
+    if (on) { rec = c.rows[w]; const int ri = c.rowitem[w]; g = ri & 255; shallow = (ri >> 8) != 0; it = c.info[g]; }
     const int y = w - it.rowbase;
     const RmEdge* pe = c.edges + (it.pb_nv & 0xfffff);
     RmMask<WORDS> m;
-    const bool ok = rm_row_fast<WORDS>(pe, rec, y, it.pymax, a.W, m);
+    const bool ok = rm_row_fast<WORDS>(pe, rec, y, it.pymax, a.W, shallow, m);
 #if !RM_DEV && defined(RM_STATS)
     if (on) {
       rm_stats[1] += ok ? 0 : 1;
@@ -729,7 +911,7 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
       const int nh = __builtin_popcount(rec.heads);
       rm_stats[4 + (nh > 3 ? 3 : nh)]++;
       rm_stats[8] += ((rec.tipP & (rec.tipP - 1u)) || (rec.tipN & (rec.tipN - 1u))) ? 1 : 0;
-      if (__builtin_popcount(rec.act) > rm_stats[9]) rm_stats[9] = __builtin_popcount(rec.act);
+      { const int pc = __builtin_popcount(rec.act); rm_hist[pc > 15 ? 15 : pc]++; }
     }
 #endif
 #if RM_DEV
@@ -737,10 +919,10 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
     while (gm) {   // the rare rows, one at a time (they share the wave's scratch list)
       const int l = __builtin_ctzll(gm);
       gm &= gm - 1ull;
-      if ((tid & 63) == l) rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave, m);
+      if ((tid & 63) == l) m = rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
     }
 #else
-    if (on && !ok) rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave, m);
+    if (on && !ok) m = rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
 #endif
     if (on) {
       uint64_t* mp = reinterpret_cast<uint64_t*>(c.rows + w);
@@ -760,71 +942,89 @@ RM_FN uint32_t rm_blend8(uint32_t bg, uint32_t fg, uint32_t al) {
   return ((t >> 8) + t) >> 8;
 }
 
-// p5: compose (painter's order = item order) and store, one thread per 16-pixel segment = 48 bytes = 12 dwords.
+// p5: compose (painter's order = item order) and store: one 16-pixel segment = 48 bytes = 12 dwords per thread.
 // first_pass: the picture starts from the background colour / the cached static prefix, else from what `image` holds.
-template <int WORDS>
-RM_FN void rm_p5(const RmArgs& a, const RmCtx& c, int env, bool first_pass, int tid, int T) {
-  const int nseg = a.W >> 4, segs = a.H * nseg;
-  const int s_lo = (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0;
-  uint8_t* out = a.image + (size_t)env * a.H * a.W * 3;
-  const bool from_cache = first_pass && s_lo > 0;
+// ITEMS = false: a segment no item touches (a copy of the background).
+template <int WORDS, bool ITEMS>
+RM_FN void rm_p5_segment(const RmArgs& a, const RmCtx& c, uint8_t* out, bool first_pass, bool from_cache, int seg, bool on) {
+  const int nseg = a.W >> 4;
   const uint32_t bg0 = (a.bg & 0xffffffu) | (a.bg << 24), bg1 = ((a.bg >> 8) & 0xffffu) | (a.bg << 16), bg2 = ((a.bg >> 16) & 0xffu) | (a.bg << 8);
-  for (int seg = tid; seg < segs; seg += T) {
-    const int y = seg / nseg, sg = seg - y * nseg, x0 = sg * 16;
-    const size_t off = ((size_t)(a.flip ? a.H - 1 - y : y) * a.W + x0) * 3;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out + off);
-    uint32_t d[12];
-    if (first_pass && !from_cache) {
-      for (int q = 0; q < 4; ++q) { d[3 * q] = bg0; d[3 * q + 1] = bg1; d[3 * q + 2] = bg2; }
-    } else {
-      const uint32_t* src = from_cache ? reinterpret_cast<const uint32_t*>(a.sbg + off) : dst;
-      for (int q = 0; q < 12; ++q) d[q] = src[q];
-    }
+  const int y = seg / nseg, sg = seg - y * nseg, x0 = sg * 16;
+  const size_t off = ((size_t)(a.flip ? a.H - 1 - y : y) * a.W + x0) * 3;   // (a multiple of 48)
+  RmU4* dst = reinterpret_cast<RmU4*>(out + off);
+  uint32_t d[12];
+  if (first_pass && !from_cache) {
+    for (int q = 0; q < 4; ++q) { d[3 * q] = bg0; d[3 * q + 1] = bg1; d[3 * q + 2] = bg2; }
+  } else if (on) {
+    const RmU4* src = from_cache ? reinterpret_cast<const RmU4*>(a.sbg + off) : dst;
+    const RmU4 u0 = src[0], u1 = src[1], u2 = src[2];
+    d[0] = u0.x; d[1] = u0.y; d[2] = u0.z; d[3] = u0.w; d[4] = u1.x; d[5] = u1.y; d[6] = u1.z; d[7] = u1.w;
+    d[8] = u2.x; d[9] = u2.y; d[10] = u2.z; d[11] = u2.w;
+  } else {
+    for (int q = 0; q < 12; ++q) d[q] = 0u;
+  }
+  if (ITEMS) {
     for (int iw = 0; iw < a.iwords; ++iw) {
-      uint32_t bitsw = c.seg[seg * a.iwords + iw];
+      uint32_t bitsw = on ? c.seg[seg * a.iwords + iw] : 0u;
+      // (wave-uniform loop, no branch inside for opaque items: a lane without an item left paints with an empty mask)
       while (RM_ANY(bitsw != 0u)) {
-        if (bitsw != 0u) {
-          const int g = iw * 32 + rm_ffs(bitsw);
-          bitsw &= bitsw - 1u;
-          const RmItem it = c.info[g];
-          const uint32_t* mrow = reinterpret_cast<const uint32_t*>(c.rows + (it.rowbase + y));
-          const uint32_t bits = (mrow[x0 >> 5] >> (x0 & 31)) & 0xffffu;
-          const uint32_t rgb = it.rgba, al = it.rgba >> 24;
-          const uint32_t c0 = (rgb & 0xffffffu) | (rgb << 24), c1 = ((rgb >> 8) & 0xffffu) | (rgb << 16), c2 = ((rgb >> 16) & 0xffu) | (rgb << 8);
-          if (RM_ANY(al != 255u)) {
-            if (al != 255u) {   // hline32rgba: one BLEND8 per channel of every covered pixel
-              for (int q = 0; q < 4; ++q) {
-                const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
-                const uint32_t cc[3] = {c0, c1, c2};
-                for (int j = 0; j < 3; ++j) {
-                  const uint32_t mk = lm[j], o = d[3 * q + j], f = cc[j];
-                  uint32_t r = 0u;
-                  for (int b = 0; b < 4; ++b) {
-                    const uint32_t ob = (o >> (8 * b)) & 255u, fb = (f >> (8 * b)) & 255u;
-                    r |= (((mk >> (8 * b)) & 1u) ? rm_blend8(ob, fb, al) : ob) << (8 * b);
-                  }
-                  d[3 * q + j] = r;
+        const bool valid = bitsw != 0u;
+        const int g = valid ? iw * 32 + rm_ffs(bitsw) : 0;
+        bitsw &= bitsw - 1u;
+        const RmItem it = c.info[g];
+        const uint32_t* mrow = reinterpret_cast<const uint32_t*>(c.rows + (valid ? it.rowbase + y : 0));
+        const uint32_t bits = valid ? (mrow[x0 >> 5] >> (x0 & 31)) & 0xffffu : 0u;
+        const uint32_t rgb = it.rgba, al = it.rgba >> 24;
+        const uint32_t c0 = (rgb & 0xffffffu) | (rgb << 24), c1 = ((rgb >> 8) & 0xffffu) | (rgb << 16), c2 = ((rgb >> 16) & 0xffu) | (rgb << 8);
+        const bool blend = valid && al != 255u;
+        for (int q = 0; q < 4; ++q) {
+          const RmU4 lm = *reinterpret_cast<const RmU4*>(c.lut + 4 * ((bits >> (4 * q)) & 15u));
+          const uint32_t m0 = blend ? 0u : lm.x, m1 = blend ? 0u : lm.y, m2 = blend ? 0u : lm.z;
+          d[3 * q] = (c0 & m0) | (d[3 * q] & ~m0);
+          d[3 * q + 1] = (c1 & m1) | (d[3 * q + 1] & ~m1);
+          d[3 * q + 2] = (c2 & m2) | (d[3 * q + 2] & ~m2);
+        }
+        if (RM_ANY(blend)) {
+          if (blend) {   // hline32rgba: one BLEND8 per channel of every covered pixel
+            const uint32_t cc[3] = {c0, c1, c2};
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
+              for (int j = 0; j < 3; ++j) {
+                const uint32_t mk = lm[j], o = d[3 * q + j], f = cc[j];
+                uint32_t r = 0u;
+                for (int b = 0; b < 4; ++b) {
+                  const uint32_t ob = (o >> (8 * b)) & 255u, fb = (f >> (8 * b)) & 255u;
+                  r |= (((mk >> (8 * b)) & 1u) ? rm_blend8(ob, fb, al) : ob) << (8 * b);
                 }
+                d[3 * q + j] = r;
               }
-              continue;
             }
-          }
-          for (int q = 0; q < 4; ++q) {
-            const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
-            const uint32_t m0 = lm[0], m1 = lm[1], m2 = lm[2];
-            d[3 * q] = (c0 & m0) | (d[3 * q] & ~m0);
-            d[3 * q + 1] = (c1 & m1) | (d[3 * q + 1] & ~m1);
-            d[3 * q + 2] = (c2 & m2) | (d[3 * q + 2] & ~m2);
           }
         }
       }
     }
-    for (int q = 0; q < 12; ++q) dst[q] = d[q];
   }
+  if (on) {
+    RmU4 v0, v1, v2;
+    v0.x = d[0]; v0.y = d[1]; v0.z = d[2]; v0.w = d[3]; v1.x = d[4]; v1.y = d[5]; v1.z = d[6]; v1.w = d[7];
+    v2.x = d[8]; v2.y = d[9]; v2.z = d[10]; v2.w = d[11];
+    dst[0] = v0; dst[1] = v1; dst[2] = v2;
+  }
+}
+
+template <int WORDS>
+RM_FN void rm_p5(const RmArgs& a, const RmCtx& c, int env, bool first_pass, int s_lo, int tid, int T) {
+  // (Listing the segments that hold a sprite -- four in ten -- and composing those with every lane busy was measured:
+  //  the copies of the empty ones and the list cost what the denser loop saves, profiles/r05_raster.txt.)
+  const int nseg = a.W >> 4, segs = a.H * nseg;
+  uint8_t* out = a.image + (size_t)env * a.H * a.W * 3;
+  const bool from_cache = first_pass && s_lo > 0;
+  for (int seg = tid; seg < segs; seg += T) rm_p5_segment<WORDS, true>(a, c, out, first_pass, from_cache, seg, true);
 }
 
 // Later passes start from clean row records / segment words
 RM_FN void rm_next_pass(const RmArgs& a, const RmCtx& c, int tid, int T) {
+  if (tid < 4) c.misc[8 + tid] = 0;
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;

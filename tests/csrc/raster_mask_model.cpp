@@ -26,6 +26,7 @@ int rm_model_polygon(const int* xy, int n, int W, int H, uint8_t* cov, int mode,
   std::vector<RmEdge> edges(n);
   std::vector<RmRow> rows(H > 0 ? H : 1);
   for (auto& r : rows) { r.act = r.heads = r.tipP = r.tipN = 0u; }
+  std::vector<char> shallow(H > 0 ? H : 1, 0);
   for (int k = 0; k < n; ++k) {
     RmEdge E = {0u, 0u, 0u, 0u};
     const int kind = rm_build_edge(pv.data(), k, n, &E);
@@ -38,16 +39,16 @@ int rm_model_polygon(const int* xy, int n, int W, int H, uint8_t* cov, int mode,
     for (int y = emin < 0 ? 0 : emin; y <= (emax > H - 1 ? H - 1 : emax); ++y) rows[y].act |= bit;
     const float dx = rm_u2f(E.w1);
     if (dx != 0.0f) {
-      if (emin >= 0 && emin < H) (dx > 0 ? rows[emin].tipP : rows[emin].tipN) |= bit;
-      if (emax == pymax && emax >= 0 && emax < H) (dx > 0 ? rows[emax].tipP : rows[emax].tipN) |= bit;
+      if (emin >= 0 && emin < H) { (dx > 0 ? rows[emin].tipP : rows[emin].tipN) |= bit; if (fabsf(dx) >= 1.49f) shallow[emin] = 1; }
+      if (emax == pymax && emax >= 0 && emax < H) { (dx > 0 ? rows[emax].tipP : rows[emax].tipN) |= bit; if (fabsf(dx) >= 1.49f) shallow[emax] = 1; }
     }
   }
   float xx[RM_XX];
   for (int y = (ymin < 0 ? 0 : ymin); y <= (ymax > H - 1 ? H - 1 : ymax); ++y) {
     RmMask<2> m;
     bool ok = false;
-    if (mode == 0) ok = rm_row_fast<2>(edges.data(), rows[y], y, pymax, W, m);
-    if (!ok) { rm_row_generic<2>(edges.data(), n, rows[y].heads, y, pymax, xx, m); if (stats) stats[1]++; }
+    if (mode == 0) ok = rm_row_fast<2>(edges.data(), rows[y], y, pymax, W, shallow[y] != 0, m);
+    if (!ok) { m = rm_row_generic<2>(edges.data(), n, rows[y].heads, y, pymax, xx); if (stats) stats[1]++; }
     if (stats) stats[0]++;
     for (int x = 0; x < W; ++x) cov[(size_t)y * W + x] = rm_bit(m, x) ? 1 : 0;
   }
@@ -96,20 +97,24 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   for (int env = 0; env < n_envs; ++env) {
     memset(lds.data(), 0xA5, lds.size());   // LDS is not zero when a workgroup starts
     for (int t = 0; t < T; ++t) rm_p0<2>(a, c, env, t, T, th[t]);
+    rm_p0_slots(a, c, env, -1, th[0]);
     for (int t = 0; t < T; ++t) rm_p1<2>(a, c, env, t, T, th[t]);
-    for (int w = 0; w < waves; ++w) rm_p2_scan(a, c, -1);
+    const int s_lo = rm_s_lo(a, c);
+    for (int w = 0; w < waves; ++w) rm_p2_scan(a, c, s_lo, -1);
     for (int base = 0;;) {
       const int end = rm_pass_end(a, c, base);
       const int total_rows = c.rowoff[end] - c.rowoff[base];
-      for (int w = 0; w < waves; ++w) rm_p2_assign(a, c, base, end, -1);
+      for (int w = 0; w < waves; ++w) rm_p2_assign(a, c, base, end, s_lo, -1);
       if (a.W > 64) {
-        for (int t = 0; t < T; ++t) rm_p3<2>(a, c, base, end, t, T);
+        for (int t = 0; t < T; ++t) rm_p3<2>(a, c, base, end, s_lo, t, T);
+        { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
         for (int t = 0; t < T; ++t) rm_p4<2>(a, c, total_rows, t, T, c.xx + (t / 64) * RM_XX);
-        for (int t = 0; t < T; ++t) rm_p5<2>(a, c, env, base == 0, t, T);
+        for (int t = 0; t < T; ++t) rm_p5<2>(a, c, env, base == 0, s_lo, t, T);
       } else {
-        for (int t = 0; t < T; ++t) rm_p3<1>(a, c, base, end, t, T);
+        for (int t = 0; t < T; ++t) rm_p3<1>(a, c, base, end, s_lo, t, T);
+        { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
         for (int t = 0; t < T; ++t) rm_p4<1>(a, c, total_rows, t, T, c.xx + (t / 64) * RM_XX);
-        for (int t = 0; t < T; ++t) rm_p5<1>(a, c, env, base == 0, t, T);
+        for (int t = 0; t < T; ++t) rm_p5<1>(a, c, env, base == 0, s_lo, t, T);
       }
       if (stats) { stats[0] += total_rows; stats[2]++; for (int q = 1; q < 16; ++q) if (q != 2) { if (q == 9) { if (rm_stats[q] > stats[q]) stats[q] = rm_stats[q]; } else stats[q] += rm_stats[q]; rm_stats[q] = 0; } }
       if (end >= a.S) break;
@@ -119,5 +124,7 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   }
   return 0;
 }
+
+void rm_model_hist(long long* out) { for (int i = 0; i < 16; ++i) { out[i] = rm_hist[i]; rm_hist[i] = 0; } }
 
 }  // extern "C"
