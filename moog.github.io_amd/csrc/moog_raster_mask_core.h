@@ -55,7 +55,7 @@
 #endif
 
 #ifndef RM_THREADS
-#define RM_THREADS 128        // threads per frame
+#define RM_THREADS 128        // threads per frame (256 and 64 were measured: slower, profiles/r05_raster.txt)
 #endif
 #ifndef RM_WAVES_PER_SIMD
 #define RM_WAVES_PER_SIMD 5   // register budget: 96 VGPRs
@@ -449,7 +449,8 @@ RM_FN void rm_crossings(const RmEdge* pe, uint32_t m, int y, int pymax, int W, c
   // (wave-uniform loop without a branch inside: a lane whose row has no edge left goes through the motions on edge 0 with
   //  every effect masked off)
   const bool ylt = y < pymax;
-  while (RM_ANY(m != 0u)) {
+  // (do-while: the plain while loop makes the compiler copy every loop-carried mask register once per iteration)
+  if (RM_ANY(m != 0u)) do {
     const bool valid = m != 0u;
     const int k = valid ? rm_ffs(m) : 0;
     m &= m - 1u;
@@ -489,7 +490,7 @@ RM_FN void rm_crossings(const RmEdge* pe, uint32_t m, int y, int pymax, int W, c
       seen.w[0] |= b0;
       if (WORDS > 1) { seen2.w[1] |= (seen.w[1] & b1) | (dup ? b1 : 0ull); seen.w[1] |= b1; }
     }
-  }
+  } while (RM_ANY(m != 0u));
 }
 
 // The coverage mask of row y of a polygon from its census record.  Returns false when the row needs rm_row_generic.
@@ -942,6 +943,17 @@ RM_FN uint32_t rm_blend8(uint32_t bg, uint32_t fg, uint32_t al) {
   return ((t >> 8) + t) >> 8;
 }
 
+// BLEND8 on the four bytes of a dword at once (bytes 0 and 2, then 1 and 3, in 16-bit lanes: bg * (255 - a) + fg * a + 128
+// <= 65153 and the DIV255 sum stay below 65536, so nothing carries from one lane into the next)
+RM_FN uint32_t rm_blend_dword(uint32_t o, uint32_t f, uint32_t al) {
+  const uint32_t na = 255u - al, k = 0x00ff00ffu;
+  uint32_t e = (o & k) * na + (f & k) * al + 0x00800080u;
+  e = ((((e >> 8) & k) + e) >> 8) & k;
+  uint32_t h = ((o >> 8) & k) * na + ((f >> 8) & k) * al + 0x00800080u;
+  h = ((((h >> 8) & k) + h) >> 8) & k;
+  return e | (h << 8);
+}
+
 // p5: compose (painter's order = item order) and store: one 16-pixel segment = 48 bytes = 12 dwords per thread.
 // first_pass: the picture starts from the background colour / the cached static prefix, else from what `image` holds.
 // ITEMS = false: a segment no item touches (a copy of the background).
@@ -967,7 +979,8 @@ RM_FN void rm_p5_segment(const RmArgs& a, const RmCtx& c, uint8_t* out, bool fir
     for (int iw = 0; iw < a.iwords; ++iw) {
       uint32_t bitsw = on ? c.seg[seg * a.iwords + iw] : 0u;
       // (wave-uniform loop, no branch inside for opaque items: a lane without an item left paints with an empty mask)
-      while (RM_ANY(bitsw != 0u)) {
+      // (do-while: with a plain while loop the compiler copies all twelve dwords of the segment once per iteration)
+      if (RM_ANY(bitsw != 0u)) do {
         const bool valid = bitsw != 0u;
         const int g = valid ? iw * 32 + rm_ffs(bitsw) : 0;
         bitsw &= bitsw - 1u;
@@ -977,31 +990,24 @@ RM_FN void rm_p5_segment(const RmArgs& a, const RmCtx& c, uint8_t* out, bool fir
         const uint32_t rgb = it.rgba, al = it.rgba >> 24;
         const uint32_t c0 = (rgb & 0xffffffu) | (rgb << 24), c1 = ((rgb >> 8) & 0xffffu) | (rgb << 16), c2 = ((rgb >> 16) & 0xffu) | (rgb << 8);
         const bool blend = valid && al != 255u;
-        for (int q = 0; q < 4; ++q) {
-          const RmU4 lm = *reinterpret_cast<const RmU4*>(c.lut + 4 * ((bits >> (4 * q)) & 15u));
-          const uint32_t m0 = blend ? 0u : lm.x, m1 = blend ? 0u : lm.y, m2 = blend ? 0u : lm.z;
-          d[3 * q] = (c0 & m0) | (d[3 * q] & ~m0);
-          d[3 * q + 1] = (c1 & m1) | (d[3 * q + 1] & ~m1);
-          d[3 * q + 2] = (c2 & m2) | (d[3 * q + 2] & ~m2);
-        }
-        if (RM_ANY(blend)) {
-          if (blend) {   // hline32rgba: one BLEND8 per channel of every covered pixel
-            const uint32_t cc[3] = {c0, c1, c2};
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t* lm = c.lut + 4 * ((bits >> (4 * q)) & 15u);
-              for (int j = 0; j < 3; ++j) {
-                const uint32_t mk = lm[j], o = d[3 * q + j], f = cc[j];
-                uint32_t r = 0u;
-                for (int b = 0; b < 4; ++b) {
-                  const uint32_t ob = (o >> (8 * b)) & 255u, fb = (f >> (8 * b)) & 255u;
-                  r |= (((mk >> (8 * b)) & 1u) ? rm_blend8(ob, fb, al) : ob) << (8 * b);
-                }
-                d[3 * q + j] = r;
-              }
-            }
+        if (RM_ANY(blend)) {   // a translucent sprite in this wavefront: hline32rgba, one BLEND8 per channel of every covered pixel
+          for (int q = 0; q < 4; ++q) {
+            const RmU4 lm = *reinterpret_cast<const RmU4*>(c.lut + 4 * ((bits >> (4 * q)) & 15u));
+            const uint32_t s0 = blend ? rm_blend_dword(d[3 * q], c0, al) : c0, s1 = blend ? rm_blend_dword(d[3 * q + 1], c1, al) : c1,
+                           s2 = blend ? rm_blend_dword(d[3 * q + 2], c2, al) : c2;
+            d[3 * q] = (s0 & lm.x) | (d[3 * q] & ~lm.x);
+            d[3 * q + 1] = (s1 & lm.y) | (d[3 * q + 1] & ~lm.y);
+            d[3 * q + 2] = (s2 & lm.z) | (d[3 * q + 2] & ~lm.z);
+          }
+        } else {
+          for (int q = 0; q < 4; ++q) {
+            const RmU4 lm = *reinterpret_cast<const RmU4*>(c.lut + 4 * ((bits >> (4 * q)) & 15u));
+            d[3 * q] = (c0 & lm.x) | (d[3 * q] & ~lm.x);
+            d[3 * q + 1] = (c1 & lm.y) | (d[3 * q + 1] & ~lm.y);
+            d[3 * q + 2] = (c2 & lm.z) | (d[3 * q + 2] & ~lm.z);
           }
         }
-      }
+      } while (RM_ANY(bitsw != 0u));
     }
   }
   if (on) {
