@@ -61,15 +61,13 @@ def raster_bytes_per_env(env):
     return float(P.render.height * P.render.width * 3 + per_env.mean().item())
 
 
-def raster_kernel_name():
-    """Which rasteriser the engine runs (moog_engine.hip): the workgroup rasteriser reading the f64 records (default), the
-    same from the draw lists the step kernel emits (MOOG_RASTER_DL=1), or the wave rasteriser from the lists' edge records
-    (MOOG_RASTER_WAVE=1) -- the two opt-in paths cost the step kernel more than they save."""
-    if os.environ.get('MOOG_RASTER_WAVE') == '1':
-        return 'moog_raster_wave_kernel<1> (two wavefronts per frame, edge records from the draw lists)'
-    if os.environ.get('MOOG_RASTER_DL') == '1':
-        return 'moog_raster_kernel<1, true> (points from the draw lists the step kernel emits)'
-    return 'moog_raster_kernel<1, false> (vertices from the f64 records)'
+def raster_kernel_name(env):
+    """Which rasteriser draws the frames (moog_engine_raster_path): the name a rocprofv3 trace of this run shows."""
+    part = env.parts[0] if hasattr(env, 'parts') else env
+    words = 2 if part.compiled.program.render.width > 64 else 1
+    if part.raster_path() == 'mask':
+        return 'moog_raster_mask_kernel<%d> (csrc/moog_raster_mask_core.h)' % words
+    return 'moog_raster_kernel<%d> (csrc/moog_raster_kernel.h)' % words
 
 
 def raster_traffic(workload, n_envs):
@@ -244,9 +242,7 @@ def main():
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
-    ap.add_argument('--no-fused', action='store_true',
-                    help='separate step / raster launches in every call (default: frames follow their env\'s step, '
-                         'moog_engine_set_fused)')
+    ap.add_argument('--no-fused', action='store_true', help='(accepted and ignored: the launch structure it switched off was retired with ABI 30)')
     ap.add_argument('--lockstep', action='store_true', help='keep the episodes of the batch synchronous')
     ap.add_argument('--no-extras', action='store_true', help='skip the strict-fault-check comparison window')
     ap.add_argument('--sub-batches', type=int, default=1,
@@ -262,6 +258,11 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         sys.exit(2)
 
+    # Hardware queues of this process (read by the HIP runtime when it initialises; its default is 4): the asynchronous
+    # sub-batches run beside each other only on queues of their own, two per sub-batch.  Set here, by the benchmark, and
+    # reported in the JSON line -- the engine library leaves the variable alone.
+    if args.sub_batches > 1:
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', str(max(4, 2 * args.sub_batches)))
     import torch
     import torch.distributed as dist
     from moog import _abi, environment, sharding
@@ -298,7 +299,7 @@ def main():
             num_envs=n, sub_batches=G, device=dev, seed=2024, env_index0=index0,
             layer_capacity=example_configs.capacity(args.workload),
             **example_configs.load(args.workload))
-        args.no_fused = args.no_extras = True
+        args.no_extras = True
     else:
         env = environment.BatchedEnvironment(
             num_envs=n, device=dev, seed=2024, env_index0=index0,
@@ -306,7 +307,6 @@ def main():
             **example_configs.load(args.workload))
     if not args.no_schedule:
         env.enable_cost_schedule()
-    fused = False
     env.reset()
     is_grid = env._is_grid
     P = env.compiled.program
@@ -345,27 +345,13 @@ def main():
         burn_in = int(timeout) + 1
         for _ in range(burn_in):
             one_step()
-    # Launch structure (setup, before the warm-up): frames following their env's step pays when the step kernel is long
-    # and heavy-tailed next to the raster work; the engine's host side times both on the stationary mix and keeps the faster.
-    tuned = None
-    if not args.no_schedule and not args.no_fused:
-        fused = env.tune_launch(one_step)
-        tuned = 'timed against the separate launches before the warm-up (2 x 24 calls each, alternating)'
-        if use_dist:   # one launch structure for the whole node: the mode is kept only if every rank kept it
-            agree = -sharding.max_over_ranks(-(1.0 if fused else 0.0), device=dev if backend == 'nccl' else None)
-            if fused and agree < 1.0:
-                fused = env.set_fused(False)
-            tuned += '; kept only if every rank keeps it'
     for _ in range(args.warmup):
         one_step()
     # Kernels of the timed region are bracketed by HIP events on the launch stream, so the per-kernel
     # averages (and the roofline figure of the raster kernel) are measurements of the timed steps
     # themselves.  Every 8th launch of each kernel is bracketed (25 samples per kernel in the default window,
     # never fewer than 10): bracketing every launch costs the timed region 20 us per step (2 %), measured.
-    # When frames follow their env's step (moog_engine_set_fused) the raster work of a call runs beside its step
-    # kernel and has no duration of its own: the sampled calls (every 16th then, 12 in the default window) take the
-    # separate launches, so the kernels are timed alone, by the same events, inside the timed region.
-    every = max(1, min(16 if fused else 8, args.steps // 10))
+    every = max(1, min(8, args.steps // 10))
     env.set_timing(True, every=every)
     for k in range(_abi.MOOG_K_COUNT):
         env.kernel_time(k)   # clear
@@ -425,13 +411,9 @@ def main():
                        'parallelism': 'env-sharded x%d, no collective' % world,
                        'launch': (('%d asynchronous sub-batches of %d envs, one HIP stream each: step -> frames -> next step '
                                    'chained per sub-batch, no whole-batch barrier between calls (SubBatchedEnvironment.step_async)'
-                                   % (G, m)) if G > 1 else
-                                  ('frames follow their env\'s step (raster grid beside the step kernel); every %dth call takes the '
-                                   'separate launches and is the one whose kernels are timed' % every) if fused
-                                  else 'separate step and raster launches') + ((' -- ' + tuned) if tuned else ''),
+                                   % (G, m)) if G > 1 else 'step launch, then raster launch, on one stream'),
                        'sub_batches': G,
-                       'launch_tuning_ms_per_step': ({k.replace('_s_per_call', ''): round(v * 1e3, 4) for k, v in env.last_tune.items()}
-                                                     if getattr(env, 'last_tune', None) else None),
+                       'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
                        'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)
                                    if staggered else 'lockstep'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
@@ -440,12 +422,10 @@ def main():
                          'traffic_source': (tr.get('source', 'profiles/raster_traffic.json') + ' (offline rocprofv3 PMC passes, '
                                             'not this run)') if tr else None,
                          'algorithmic_bytes_per_launch': n * rb,
-                         'kernel': raster_kernel_name(), 'avg_kernel_us': r_avg_s * 1e6, 'kernel_samples': int(r_n),
+                         'kernel': raster_kernel_name(env), 'avg_kernel_us': r_avg_s * 1e6, 'kernel_samples': int(r_n),
                          'algorithmic_bytes_per_env': rb},
             'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items() if v[1] > 0},
-            'kernels_avg_us_note': ('HIP-event brackets inside the timed region; with frames following steps the sampled calls '
-                                    '(every %dth) take the separate launches, so these are separate-launch samples' % every) if fused
-                                   else ('HIP-event brackets around every %dth launch inside the timed region' % every),
+            'kernels_avg_us_note': 'HIP-event brackets around every %dth launch inside the timed region' % every,
             'faulted_envs': faults,
         }
         line.update(extras)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOOG_ABI_VERSION 29
+#define MOOG_ABI_VERSION 30
 
 /* ---- capacity limits of the program blob -------------------------------- */
 #define MOOG_MAX_LAYERS 16
@@ -76,9 +76,7 @@ extern "C" {
 #define MOOG_FAULT_PHASE_END 128
 /* MazePhysics: an avatar is on no grid line of the maze (maze_physics.py:87-97 raises ValueError) */
 #define MOOG_FAULT_OFF_GRID 256
-/* moog_engine_set_fused: a frame's workgroup gave up waiting for its env's step (engine error) */
-#define MOOG_FAULT_FRAME_TIMEOUT 512   /* (no longer raised: a frame that gives up waiting is drawn by the fallback launch) */
-#define MOOG_FAULT_FRAME_MISMATCH 1024 /* MOOG_FUSED_SELFCHECK: a call's frames differ from the ordinary launch's */
+/* (512, 1024: the fault bits of the "frames follow their env's step" launch structure, retired with ABI 30) */
 #define MOOG_MAX_MAZE 32
 #define MOOG_MAX_MAZE_POINTS 8 /* cells of one sample_distinct_open_points() call */
 #define MOOG_MAX_MAZE_GEN 16   /* size of a maze drawn on the device (its frontier list holds size^2 one-byte cells) */
@@ -738,26 +736,10 @@ int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
  * landing in the under-filled tail of the launch.  NULLs disable. */
 int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_dev);
 
-/* Frames follow their env's step (pure performance setting, results do not depend on it; needs a schedule).
- * The step kernel lasts as long as its slowest env while the mean env is done in about a third of that time.  With
- * `enabled`, a moog_engine_step call with an image output launches, beside the step kernel and on an engine-owned
- * stream, a small persistent raster grid whose workgroups take the envs in the order they are expected to finish,
- * wait for each env's step to be stored (a per-env flag in HBM) and draw its frame: most frames are drawn on the
- * compute units the finished envs have left idle, and only the slowest env's frame follows the step kernel.  The
- * caller's stream waits for the frames before the call's outputs may be read.  One-tile frames without
- * anti-aliasing only (MOOG_E_UNSUPPORTED otherwise, and while a tool runs one kernel at a time: the environment
- * variable ROCPROF_COUNTER_COLLECTION that rocprofv3 --pmc sets, or MOOG_NO_FUSED=1); calls with injected uniforms,
- * debug settings, or whose raster launch is being timed (moog_engine_set_timing) take the separate launches.
- * Whether the mode pays depends on the workload (a long, heavy-tailed step kernel next to the raster work): the
- * Python host measures it (BatchedEnvironment.tune_launch).
- * The mode needs the step kernel to run BESIDE the frames' grid, which HIP does not promise.  It is refused while the
- * runtime is told to serialise kernels (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, GPU_MAX_HW_QUEUES=1); if kernels are
- * serialised by something the engine cannot see, the grid gives up after about half a second WITHOUT drawing anything
- * it is not sure of, a fallback launch behind the step kernel draws that call's whole batch, and the engine leaves the
- * mode at the next call (one line on stderr): a degraded call is slow, never wrong, never an error.
- * moog_engine_get_fused reports whether the mode is (still) in use. */
-int moog_engine_set_fused(moog_engine_t* e, int32_t enabled);
-int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled);
+/* (ABI <= 29 had moog_engine_set_fused / moog_engine_get_fused here: a raster grid beside the step kernel that drew each
+ * frame as soon as its env's step was stored.  It paid 3 % when the step kernel took 750 us and the rasteriser 95; with the
+ * step kernel at 650 us and the rasteriser at 57 it measured slower than the two plain launches and was removed --
+ * profiles/HISTORY.md 3.4.) */
 
 /* Reset pool (programs whose initializer is expensive: bounce_box_contact_prediction.py:88-119 and red_green.py:120-203
  * play the episode forward inside state_initializer -- MOOG_CELL_SIMULATE -- which on one wavefront takes as long as a
@@ -828,6 +810,12 @@ int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots);
  * before the frames are drawn: the same time steps and records as a reset inside the step kernel (late_reset = 1).
  * MOOG_NO_LATE_RESET=1 in the environment: such programs are stepped by variant 2 as before. */
 int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late_reset);
+
+/* Which rasteriser draws this engine's ordinary frames (what a profile of the run names): MOOG_RASTER_MASK = the mask
+ * rasteriser (csrc/moog_raster_mask_core.h: one-tile frames, polygons of <= 32 vertices, no copying polygon modifier),
+ * MOOG_RASTER_SPANS = the push / sort / span kernel (csrc/moog_raster_kernel.h: everything else, and every prefix picture). */
+enum { MOOG_RASTER_SPANS = 0, MOOG_RASTER_MASK = 1 };
+int moog_engine_raster_path(moog_engine_t* e, int32_t* path);
 
 /* PILRenderer(color_to_rgb=<any callable>) (pil_renderer.py:72-76,108: the renderer calls it on every sprite's colour
  * triple when it draws): the callable is Python and stays on the host.  The binding evaluates it once per DISTINCT colour

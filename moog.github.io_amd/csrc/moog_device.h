@@ -115,8 +115,6 @@ struct Env {
   int32_t* layer_hw;       // global [2 * MOOG_MAX_LAYERS] or null: per dynamic layer, the most sprites an append ever wanted
                            // room for (over all envs and calls), then the number of appends dropped because the layer was full
   double xarg;             // the argument of the function being evaluated (MOOG_X_ARG)
-  int wrote_direct;        // sticky, per lane: this call stored a colour / opacity / shape id / Portal bit (fields that may
-                           // live in HBM, written with ordinary stores): the frame's hand-over needs an L2 write-back
 };
 
 #define PX(s) (e.f[e.L.o_pos + 2 * (s)])
@@ -126,13 +124,13 @@ struct Env {
 #define ANG(s) (e.f[e.L.o_angle + (s)])
 #define ANGV(s) (e.f[e.L.o_angvel + (s)])
 #define MASS(s) (e.f[e.L.o_mass + (s)])
-// Colours, opacities, shape ids and Portal bits are READ through COL / OPAC / SHAPEID / TELE and WRITTEN through the
-// *_SET forms only: a writer that bypassed them would not be seen by the frames-follow-steps hand-over (moog_kernels.h).
+// Colours, opacities, shape ids and Portal bits may live in HBM (fields the step path hardly ever touches): they are READ
+// through COL / OPAC / SHAPEID / TELE and WRITTEN through the *_SET forms.
 #define COL(s, c) (static_cast<const double*>(e.gcol)[3 * (s) + (c)])
-#define COL_SET(s, c, v) (const_cast<Env&>(e).wrote_direct = 1, e.gcol[3 * (s) + (c)] = (v))
-#define OPAC_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gopa[(s)] = (v))
-#define SHAPEID_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gshape[(s)] = (v))
-#define TELE_SET(s, v) (const_cast<Env&>(e).wrote_direct = 1, e.gtele[(s)] = (v))
+#define COL_SET(s, c, v) (e.gcol[3 * (s) + (c)] = (v))
+#define OPAC_SET(s, v) (e.gopa[(s)] = (v))
+#define SHAPEID_SET(s, v) (e.gshape[(s)] = (v))
+#define TELE_SET(s, v) (e.gtele[(s)] = (v))
 #define INER(s, c) (e.f[e.L.o_inertia + 2 * (s) + (c)])
 #define MAXR(s) (e.f[e.L.o_maxr + (s)])
 #define FLAGS(s) (e.q[e.L.o_flags + (s)])

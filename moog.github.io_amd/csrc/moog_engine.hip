@@ -83,21 +83,6 @@ struct moog_engine {
   hipEvent_t ev_step_done = nullptr, ev_sched_done = nullptr;
   bool sched_pending = false;
   float* cost = nullptr;
-  // moog_engine_set_fused: frames follow their env's step on a second stream (RFollow in moog_raster.h)
-  bool fused = false;
-  int32_t* fused_done = nullptr;   // per-env call numbers
-  uint32_t* fused_ticket = nullptr;
-  int32_t* perm_buf[2] = {nullptr, nullptr};   // the caller's order buffer and the engine's own: the sort alternates while frames read
-  int perm_cur = 0;
-  int32_t fused_epoch = 0;
-  int fused_resident = 0, fused_groups = 0;
-  bool fused_ready = false;   // every allocation / stream / event of the fused mode exists
-  hipStream_t fused_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_frames = nullptr;
-  uint32_t* fused_abort = nullptr;   // pinned host word: number of the call whose frames gave up waiting (0: none)
-  bool fused_force_serial = false;   // MOOG_FUSED_FORCE_SERIAL=1 (test aid): the frames' grid runs in front of the step kernel
-  int fused_selfcheck = 0, fused_calls = 0;   // MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again and compared
-  uint8_t* fused_check_img = nullptr;
   // moog_engine_set_reset_pool: the next episode of every env is built beside the step kernels (moog_kernels.h "reset pool")
   static constexpr int POOL_STREAMS = 8;
   int pool_streams = 2;   // the ones in use: hardware queues the runtime has (GPU_MAX_HW_QUEUES, default 4) minus the caller's and the sort's
@@ -124,6 +109,7 @@ struct moog_engine {
   int32_t* s_i32 = nullptr;
   uint8_t* s_bg = nullptr;
   const uint32_t* rgb_override = nullptr;   // moog_engine_set_color_override
+  int kept_n_static = 0, kept_pe_ns = 0, kept_pe_nsv = 0;   // the prefixes' sizes while a colour override has them switched off
   // per-env prefix (RArgs::sbg_env_stride): leading sprites that stay put within an episode but differ between envs
   int pe_ns = 0, pe_nsv = 0;        // slots / vertex slots of the prefix (0: off); shrinks to the slots that really stay put
   double* pe_f64 = nullptr;         // [n_envs] snapshot of the record each env's picture was drawn from
@@ -132,15 +118,6 @@ struct moog_engine {
   int32_t* pe_valid = nullptr;      // [n_envs] the env has a picture
   int32_t* pe_build = nullptr;      // [n_envs] this call's build launch draws the env's picture
   int32_t* pe_min = nullptr;        // pinned host word: first slot of the prefix seen changing in the middle of an episode
-  // wave rasteriser (moog_raster_wave.h): one wavefront per frame from the env's draw list (moog_drawlist.h)
-  bool wave = false;          // the wave rasteriser is on (MOOG_RASTER_WAVE=1; needs draw lists)
-  bool dlist = false;         // the program's frames can be drawn from draw lists (the step kernel emits them)
-  RWPlan wave_plan{};
-  size_t wave_lds = 0;
-  uint32_t* d_dl = nullptr;   // [n_envs][dl_stride] draw lists
-  int dl_stride = 0;
-  uint32_t* s_dl = nullptr;   // reference draw list of the static prefix's scratch env
-  int wave_nsl = 0;           // entries of round 0 the prefix occupies (0: the wave path does not use the cached picture)
 };
 
 static void free_engine(moog_engine* e) {
@@ -150,15 +127,11 @@ static void free_engine(moog_engine* e) {
   if (e->s_f64) hipFree(e->s_f64);
   if (e->s_i32) hipFree(e->s_i32);
   if (e->s_bg) hipFree(e->s_bg);
-  if (e->d_dl) hipFree(e->d_dl);
-  if (e->s_dl) hipFree(e->s_dl);
   if (e->aa_canvas) hipFree(e->aa_canvas);
   if (e->pad_img) hipFree(e->pad_img);
   if (e->aa_tmp) hipFree(e->aa_tmp);
   if (e->aa_tables) hipFree(e->aa_tables);
   if (e->fault_flag) hipHostFree(e->fault_flag);
-  if (e->fused_abort) hipHostFree(e->fused_abort);
-  if (e->fused_check_img) hipFree(e->fused_check_img);
   if (e->layer_hw) hipFree(e->layer_hw);
   for (int k = 0; k < moog_engine::POOL_STREAMS; ++k)
     if (e->pool_stream[k]) { hipStreamSynchronize(e->pool_stream[k]); hipStreamDestroy(e->pool_stream[k]); }
@@ -268,7 +241,6 @@ static int validate(const moog_program_t* p) {
 static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t* inj,
                        const moog_step_out_t* out, int mode, const uint8_t* mask);
 static RArgs raster_args(moog_engine* e, uint8_t* image);
-static DLArgs drawlist_args(moog_engine* e);
 
 // Pillow Resample.c precompute_coeffs + normalize_coeffs_8bpc for the LANCZOS filter (support 3): the window of
 // output sample xx is centred on (xx + 0.5) * scale, weights are normalised in double and rounded to fixed
@@ -364,28 +336,10 @@ static int build_static_prefix(moog_engine* e) {
   RArgs r = raster_args(e, e->s_bg);
   r.n_static = ns; r.nsv = nsv; r.build = 1; r.debug_stop = 0;
   moog_raster_launch(r, e->raster_lds, 0);
-  if (e->dlist) {   // the draw-list paths compare a frame's prefix with the reference's draw-list entries
-    if (hipMalloc(&e->s_dl, (size_t)e->dl_stride * 4) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(reference draw list) failed");
-    DLArgs d = drawlist_args(e);
-    d.dl = e->s_dl; d.n_envs = 1;
-    moog_drawlist_launch(d, 0);
-  }
   e->view = keep; e->n_envs = keep_n;
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(0));
   e->n_static = ns; e->nsv = nsv;
-  if (e->dlist) {   // the prefix's sprites must be alive in the reference and fill the front of round 0
-    std::vector<int32_t> q((size_t)e->L.i32_per_env);
-    HIPCHK(hipMemcpy(q.data(), e->s_i32, ib, hipMemcpyDeviceToHost));
-    int lanes = 0;
-    bool ok = true;
-    for (int sl = 0; sl < ns; ++sl) {
-      const int nv = q[e->L.o_nverts + sl];
-      ok = ok && (q[e->L.o_flags + sl] & MOOG_F_ALIVE) && nv > 0 && nv <= DL_MAX_NV;
-      lanes += nv;
-    }
-    e->wave_nsl = (ok && lanes <= 64) ? lanes : 0;
-  }
   return MOOG_OK;
 }
 
@@ -396,7 +350,7 @@ static int build_static_prefix(moog_engine* e) {
 // MOOG_RASTER_ENV_BG=0 turns it off, =1 turns it on whatever the frame size (A/B runs, tests).
 static int setup_env_prefix(moog_engine* e) {
   const char* sw = getenv("MOOG_RASTER_ENV_BG");
-  if ((sw && atoi(sw) == 0) || e->aa > 1 || e->wave) return MOOG_OK;
+  if ((sw && atoi(sw) == 0) || e->aa > 1) return MOOG_OK;
   const bool forced = sw && atoi(sw) == 1;
   int nsv = 0;
   const int ns = env_prefix_slots(&e->prog, &nsv);
@@ -462,7 +416,6 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
                 (size_t)e->L.S * 4 * 8 +
                 (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
-  if ((size_t)HL.o_verts * 8 < (size_t)DL_SCRATCH_A) e->step_lds += DL_SCRATCH_A + 16;   // the draw-list emission's scratch (moog_kernels.h emit_drawlist)
   if (prog->xstack_depth > 0) {   // per-lane value stacks of the lane-parallel filter evaluator (moog_device.h eval_expr_t<true>)
     e->step_lds = (e->step_lds + 15) & ~(size_t)15;
     e->xstack_off = (int32_t)e->step_lds;
@@ -578,36 +531,6 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       if (ms.lds > 64 * 1024) ms.ok = 0;
     }
   }
-  {   // wave rasteriser: eligibility and LDS plan (moog_raster_wave.h)
-    int maxv = 1;
-    for (int sl = 0; sl < prog->n_slots; ++sl) if (prog->slot_vcap[sl] > maxv) maxv = prog->slot_vcap[sl];
-    const int max_rounds = dl_max_rounds(e->L.TOTV, maxv);
-    // Draw lists are OPT-IN (MOOG_RASTER_DL=1: the workgroup rasteriser reads the points from the list; MOOG_RASTER_WAVE=1:
-    // the wave rasteriser reads the edge records).  Measured on the headline workload (profiles/r03_raster_experiments.txt):
-    // the emission runs at the end of every env's step, i.e. on the critical path of the step kernel's slowest wavefront,
-    // and costs it more (+15 us for the points, +30 us with the edge records) than the rasterisers save (-2.5 / -19 us).
-    const char* on = getenv("MOOG_RASTER_DL");
-    const char* wv = getenv("MOOG_RASTER_WAVE");
-    const bool want = (on && atoi(on) == 1) || (wv && atoi(wv) == 1);
-    e->dlist = want && prog->render.polymod == MOOG_POLYMOD_NONE && e->aa == 1 &&
-               e->raster_tiles_x * e->raster_bands == 1 && e->canvas_w <= 128 && e->canvas_h <= 128 && e->pad_w == e->canvas_w &&
-               prog->n_slots >= 1 && prog->n_slots <= RW_MAX_ITEMS && maxv <= DL_MAX_NV && max_rounds <= DL_MAX_ROUNDS && e->L.TOTV >= 1;
-    e->wave = e->dlist && wv && atoi(wv) == 1;
-    if (e->dlist) {
-      e->dl_stride = dl_stride_words(max_rounds);
-      int e_rounds = max_rounds < 5 ? max_rounds : 5;   // edge records for five rounds per pass (the headline workload's frames need 4-5)
-      int r_cap = 192;                                  // row records per pass
-      { const char* ec = getenv("MOOG_WAVE_EDGE_ROUNDS"); if (ec && atoi(ec) >= 1) e_rounds = atoi(ec); }   // tuning / tests of the multi-pass path
-      { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) r_cap = atoi(rc); }
-      if (r_cap < e->canvas_h) r_cap = e->canvas_h;   // any one polygon fits
-      if (r_cap > 8000) r_cap = 8000;                 // (row indices travel as 16 bits, 14 bits of item id share the row word)
-      raster_wave_plan(e->canvas_w, e->canvas_h, 64 * e_rounds, r_cap, e->raster_xxcap, &e->wave_plan);
-      e->wave_lds = e->wave_plan.total;
-      { const char* pad = getenv("MOOG_WAVE_LDS_PAD"); if (pad) e->wave_lds += (size_t)atoi(pad); }   // occupancy experiments
-      if (e->wave_lds > 64 * 1024) e->wave = false;
-      if (hipMalloc(&e->d_dl, (size_t)n_envs * e->dl_stride * 4) != hipSuccess) e->dlist = e->wave = false;
-    }
-  }
   {
     int (*const configure[6])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
                                          moog_configure_step_t4, moog_configure_step_m3, moog_configure_step_m4};
@@ -707,7 +630,6 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
   if (err == hipSuccess && e->mask_setup.ok) err = (hipError_t)moog_raster_configure_mask(e->mask_setup.lds);
-  if (err == hipSuccess && e->wave) err = (hipError_t)moog_raster_wave_configure(e->wave_lds);
   if (err != hipSuccess) {
     free_engine(e);
     return fail(MOOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(err));
@@ -753,12 +675,6 @@ static void drain(TimedKernel& t) {
 int moog_engine_destroy(moog_engine_t* e) {
   if (!e) return MOOG_OK;
   for (int k = 0; k < MOOG_K_COUNT; ++k) drain(e->timed[k]);
-  if (e->fused_stream) { hipStreamSynchronize(e->fused_stream); hipStreamDestroy(e->fused_stream); }
-  if (e->ev_fork) hipEventDestroy(e->ev_fork);
-  if (e->ev_frames) hipEventDestroy(e->ev_frames);
-  if (e->fused_done) hipFree(e->fused_done);
-  if (e->fused_ticket) hipFree(e->fused_ticket);
-  if (e->perm_buf[1]) hipFree(e->perm_buf[1]);
   if (e->sched_stream) {
     hipStreamSynchronize(e->sched_stream);
     hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
@@ -820,12 +736,10 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.step_type = out ? out->step_type : nullptr;
   a.mode = mode;
   a.vslot = e->d_vslot;
-  a.perm = (mode == MODE_STEP && e->perm) ? (e->perm_buf[1] ? e->perm_buf[e->perm_cur] : e->perm) : nullptr;
+  a.perm = (mode == MODE_STEP && e->perm) ? e->perm : nullptr;
   a.cost = (mode == MODE_STEP) ? e->cost : nullptr;
   a.dbg = e->step_dbg;
   a.fault_flag = e->fault_flag;
-  a.done = nullptr; a.epoch = 0; a.done_wb = 0;
-  a.dl = nullptr; a.dl_stride = e->dl_stride; a.dl_cw = e->canvas_w; a.dl_ch = e->canvas_h; a.dl_deep = e->wave ? 1 : 0;
   a.layer_hw = e->layer_hw;
   a.act_f32 = e->act_f32;
   a.xstack_off = e->xstack_off;
@@ -867,12 +781,11 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
   r.sbg_env_stride = 0; r.env_build = nullptr; r.rgb_override = e->rgb_override;
-  r.dl = nullptr; r.dl_stride = e->dl_stride; r.nsl = 0; r.sref_dl = e->s_dl;
   return r;
 }
 
 // Per-env prefix: validates every env's picture against its live record, draws the stale ones again, and points the frame
-// launch's arguments at the pictures.  (The launches that do not pass through here -- frames that follow their env's step,
+// launch's arguments at the pictures.  (The launches that do not pass through here --
 // anti-aliased canvases -- draw every sprite; the next launch that does re-validates, so nothing goes stale unseen.)
 static int use_env_prefix(moog_engine* e, RArgs& r, hipStream_t s) {
   if (e->pe_ns <= 0) return MOOG_OK;
@@ -890,57 +803,17 @@ static int use_env_prefix(moog_engine* e, RArgs& r, hipStream_t s) {
   moog_prefix_check_launch(c, s);
   RArgs b = r;
   b.image = e->pe_bg; b.n_static = e->pe_ns; b.nsv = e->pe_nsv; b.build = 1; b.env_build = e->pe_build; b.debug_stop = 0;
-  b.sbg = nullptr; b.sbg_env_stride = 0; b.dl = nullptr; b.nsl = 0;
+  b.sbg = nullptr; b.sbg_env_stride = 0;
   moog_raster_launch(b, e->raster_lds, s);
   r.n_static = e->pe_ns; r.nsv = e->pe_nsv; r.sbg = e->pe_bg;
   r.sbg_env_stride = (size_t)e->canvas_h * e->pad_w * 3;
-  r.nsl = 0;
   return MOOG_OK;
 }
 
-static DLArgs drawlist_args(moog_engine* e) {
-  DLArgs d;
-  d.P = e->d_prog; d.L = e->L; d.f64 = e->view.f64; d.i32 = e->view.i32; d.vslot = e->d_vslot;
-  d.dl = e->d_dl; d.dl_stride = e->dl_stride; d.n_envs = e->n_envs; d.cw = e->canvas_w; d.ch = e->canvas_h; d.deep = e->wave ? 1 : 0;
-  return d;
-}
-
-static RWArgs raster_wave_args(moog_engine* e, uint8_t* image) {
-  RWArgs r;
-  r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
-  r.dl = e->d_dl; r.dl_stride = e->dl_stride; r.n_envs = e->n_envs; r.W = e->canvas_w; r.H = e->canvas_h;
-  r.debug_stop = e->raster_stop; r.xxcap = e->raster_xxcap; r.plan = e->wave_plan;
-  const bool pre = e->n_static > 0 && e->wave_nsl > 0 && e->s_dl;
-  r.n_static = pre ? e->n_static : 0; r.nsl = pre ? e->wave_nsl : 0;
-  r.sref_dl = e->s_dl;
-  r.sref_col = e->s_f64 ? e->s_f64 + e->L.o_color : nullptr;
-  r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
-  r.sbg = e->s_bg;
-  r.perm = nullptr;
-  return r;
-}
-
-// have_dl: the step kernel of this call emitted the draw lists; otherwise they are built from the records first
-static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1, bool have_dl = false) {
-  if (e->wave) {
-    if (!have_dl) moog_drawlist_launch(drawlist_args(e), s);
-    {
-      Bracket br(e, MOOG_K_RASTER, s, timed);
-      moog_raster_wave_launch(raster_wave_args(e, image), e->wave_lds, s);
-    }
-    HIPCHK(hipGetLastError());
-    return MOOG_OK;
-  }
+static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1) {
   RArgs r = raster_args(e, image);
-  if (e->dlist) {   // the workgroup rasteriser from the draw lists
-    if (!have_dl) moog_drawlist_launch(drawlist_args(e), s);
-    r.dl = e->d_dl;
-    const bool pre = e->n_static > 0 && e->wave_nsl > 0 && e->s_dl;
-    r.nsl = pre ? e->wave_nsl : 0;
-    if (!pre) r.n_static = 0;
-  }
   Bracket br(e, MOOG_K_RASTER, s, timed);
-  if (e->aa <= 1 && !r.dl) { const int rc = use_env_prefix(e, r, s); if (rc) return rc; }
+  if (e->aa <= 1) { const int rc = use_env_prefix(e, r, s); if (rc) return rc; }
   if (e->aa <= 1 && e->pad_w != e->canvas_w) {   // drawn 16-aligned, cropped into the caller's frames
     r.image = e->pad_img;
     moog_raster_launch(r, e->raster_lds, s);
@@ -1041,69 +914,6 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
     e->sched_pending = false;
   }
-  if (e->fused && e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u) {
-    // An earlier call's frames gave up waiting for a step kernel that was not running beside them (its frames were drawn
-    // by the fallback launch): something serialises the kernels -- the separate launches are the right structure then.
-    e->fused = false;
-    fprintf(stderr, "moog: frames could not follow their env's step (kernels are being serialised); the engine uses the separate step / raster launches from now on\n");
-  }
-  int time_raster = -1;
-  const bool follow = e->fused && e->perm && e->cost && out && out->image && !(inject && inject->uniforms) && !e->step_dbg &&
-                      !e->raster_stop;
-  // (a call whose raster launch is to be timed takes the separate launches below: the kernel is then measured alone)
-  if (follow) time_raster = sampled(e, MOOG_K_RASTER) ? 1 : 0;
-  if (follow && !time_raster) {
-    if (++e->fused_epoch == INT32_MAX) e->fused_epoch = 1;
-    a.done = e->fused_done;
-    a.epoch = e->fused_epoch;
-    { const char* wb = getenv("MOOG_FUSED_ALWAYS_WB"); a.done_wb = (wb && atoi(wb)) ? 1 : 0; }   // (experiments; the kernel derives the need itself)
-    RArgs r = raster_args(e, out->image);
-    RFollow f;
-    f.done = e->fused_done; f.epoch = e->fused_epoch; f.perm = a.perm; f.resident = e->fused_resident;
-    f.ticket = e->fused_ticket; f.spin_cap = 2000000;   // a few seconds
-    f.abort_host = e->fused_abort;
-    if (e->fused_force_serial) {   // test aid: the grid cannot see a finished env, gives up, and the fallback draws the batch
-      f.spin_cap = 4000;
-      moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, s);
-    } else {
-      HIPCHK(hipEventRecord(e->ev_fork, s));
-      HIPCHK(hipStreamWaitEvent(e->fused_stream, e->ev_fork, 0));
-    }
-    {
-      Bracket br(e, MOOG_K_STEP, s);
-      launch_step(e, s, a);
-    }
-    if (a.pool_state && (rc = pool_kick(e, s)) != MOOG_OK) return rc;
-    if (!e->fused_force_serial) {
-      moog_raster_follow_launch(r, f, e->fused_groups, e->raster_lds, e->fused_stream);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(e->ev_frames, e->fused_stream));
-    }
-    HIPCHK(hipEventRecord(e->ev_step_done, s));
-    HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
-    // (the last frames are still reading this call's order: the sort writes the other buffer, beside them)
-    e->perm_cur ^= 1;
-    moog_launch_sched(e->sched_stream, e->cost, e->perm_buf[e->perm_cur], e->n_envs, e->view.i32 + e->L.o_reset_next,
-                      e->L.i32_per_env);
-    HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
-    e->sched_pending = true;
-    if (!e->fused_force_serial) HIPCHK(hipStreamWaitEvent(s, e->ev_frames, 0));
-    // behind the step kernel and the frames: draws the batch if (and only if) this call's grid gave up
-    moog_raster_fallback_launch(r, e->fused_ticket, e->fused_epoch, e->fused_groups, e->raster_lds, s);
-    if (e->fused_selfcheck > 0 && (++e->fused_calls % e->fused_selfcheck) == 0) {   // the same frames by the ordinary launch
-      const size_t bytes = (size_t)e->n_envs * e->prog.render.width * e->prog.render.height * 3;
-      if (!e->fused_check_img && hipMalloc(&e->fused_check_img, bytes) != hipSuccess) return fail(MOOG_E_NOMEM, "hipMalloc(self-check frames) failed");
-      RArgs c = raster_args(e, e->fused_check_img);
-      moog_raster_launch(c, e->raster_lds, s);
-      moog_frames_compare_launch(out->image, e->fused_check_img, bytes, e->fault_flag, e->view.i32 + e->L.o_fault,
-                                 MOOG_FAULT_FRAME_MISMATCH, s);
-    }
-    HIPCHK(hipGetLastError());
-    return MOOG_OK;
-  }
-
-  const bool emit = e->dlist && out && out->image && !e->late_reset;   // (a late reset's record has no draw list yet)
-  if (emit) a.dl = e->d_dl;
   {
     Bracket br(e, MOOG_K_STEP, s);
     launch_step(e, s, a);
@@ -1114,12 +924,12 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   if (e->perm && e->cost) {
     HIPCHK(hipEventRecord(e->ev_step_done, s));
     HIPCHK(hipStreamWaitEvent(e->sched_stream, e->ev_step_done, 0));
-    moog_launch_sched(e->sched_stream, e->cost, e->perm_buf[1] ? e->perm_buf[e->perm_cur] : e->perm, e->n_envs,
+    moog_launch_sched(e->sched_stream, e->cost, e->perm, e->n_envs,
                       e->view.i32 + e->L.o_reset_next, e->L.i32_per_env);
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
   }
-  if (out && out->image) return launch_raster(e, out->image, s, time_raster, emit);
+  if (out && out->image) return launch_raster(e, out->image, s);
   return MOOG_OK;
 }
 
@@ -1148,9 +958,6 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
   if (e->sched_pending) { hipEventSynchronize(e->ev_sched_done); e->sched_pending = false; }
   e->perm = perm_dev;
   e->cost = cost_dev;
-  e->perm_buf[0] = perm_dev;
-  e->perm_cur = 0;
-  if (!perm_dev) e->fused = false;
   if (perm_dev && cost_dev && !e->sched_stream) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->sched_stream, hipStreamNonBlocking));
@@ -1228,70 +1035,6 @@ int moog_engine_get_reset_pool(moog_engine_t* e, int32_t* enabled, int64_t* stat
   return MOOG_OK;
 }
 
-int moog_engine_set_fused(moog_engine_t* e, int32_t enabled) {
-  if (!e) return fail(MOOG_E_INVALID, "null engine");
-  if (!enabled) { e->fused = false; return MOOG_OK; }
-  if (e->aa > 1 || e->raster_tiles_x * e->raster_bands != 1 || e->pad_w != e->canvas_w)
-    return fail(MOOG_E_UNSUPPORTED, "frames follow their env's step only for one-tile frames without anti-aliasing, of a width that is a multiple of 16");
-  if (!(e->perm && e->cost)) return fail(MOOG_E_INVALID, "moog_engine_set_fused needs a schedule (moog_engine_set_schedule)");
-  if (e->late_reset) return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps of a program whose episodes are opened by the reset kernel behind the step kernel (late reset)");
-  if (e->rgb_override) return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while the host supplies the sprites' colours (moog_engine_set_color_override)");
-  {   // tools that run one kernel at a time (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION) would leave the frames' grid
-      // waiting for a step kernel that cannot start beside it; MOOG_NO_FUSED=1 is the manual switch
-    const char* cc = getenv("ROCPROF_COUNTER_COLLECTION");
-    const char* att = getenv("ROCPROF_ATT_PARAM_SERIALIZE_ALL");
-    const char* off = getenv("MOOG_NO_FUSED");
-    const char* ser = getenv("AMD_SERIALIZE_KERNEL");
-    const char* blk = getenv("HIP_LAUNCH_BLOCKING");
-    const char* hwq = getenv("GPU_MAX_HW_QUEUES");
-    if ((ser && atoi(ser)) || (blk && atoi(blk)) || (hwq && atoi(hwq) == 1))
-      return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while the runtime serialises kernels (AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING / GPU_MAX_HW_QUEUES=1)");
-    if ((cc && atoi(cc)) || (att && atoi(att)) || (off && atoi(off)))
-      return fail(MOOG_E_UNSUPPORTED, "frames cannot follow steps while kernels are serialised (counter collection) or MOOG_NO_FUSED is set");
-  }
-  HIPCHK(hipSetDevice(e->device));
-  if (!e->fused_ready) {   // (keyed on a flag set at the END of the block: a failed allocation half way is retried, not dereferenced)
-    if (!e->fused_done) HIPCHK(hipMalloc(&e->fused_done, sizeof(int32_t) * (size_t)e->n_envs));
-    HIPCHK(hipMemset(e->fused_done, 0, sizeof(int32_t) * (size_t)e->n_envs));
-    if (!e->perm_buf[1]) HIPCHK(hipMalloc(&e->perm_buf[1], sizeof(int32_t) * (size_t)e->n_envs));
-    if (!e->fused_ticket) HIPCHK(hipMalloc(&e->fused_ticket, 2 * sizeof(uint32_t)));
-    HIPCHK(hipMemset(e->fused_ticket, 0, 2 * sizeof(uint32_t)));
-    if (!e->fused_abort)
-      HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&e->fused_abort), sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    *e->fused_abort = 0u;
-    { const char* fs = getenv("MOOG_FUSED_FORCE_SERIAL"); e->fused_force_serial = fs && atoi(fs) == 1; }
-    { const char* sc = getenv("MOOG_FUSED_SELFCHECK"); e->fused_selfcheck = sc ? atoi(sc) : 0; }
-    {   // MOOG_FUSED_CU_STRIDE=k (experiment): the frames' grid only runs on every k-th compute unit, the others keep
-        // their whole LDS for stepping envs
-      const char* cs = getenv("MOOG_FUSED_CU_STRIDE");
-      const int stride = cs ? atoi(cs) : 0;
-      if (stride > 1) {
-        hipDeviceProp_t pr;
-        HIPCHK(hipGetDeviceProperties(&pr, e->device));
-        std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0u);
-        for (int cu = 0; cu < pr.multiProcessorCount; cu += stride) mask[cu >> 5] |= 1u << (cu & 31);
-        if (!e->fused_stream) HIPCHK(hipExtStreamCreateWithCUMask(&e->fused_stream, (uint32_t)mask.size(), mask.data()));
-      } else {
-        if (!e->fused_stream) HIPCHK(hipStreamCreateWithFlags(&e->fused_stream, hipStreamNonBlocking));
-      }
-    }
-    if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    if (!e->ev_frames) HIPCHK(hipEventCreateWithFlags(&e->ev_frames, hipEventDisableTiming));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, e->device));
-    const int per_cu = (int)(160 * 1024 / (e->step_lds ? e->step_lds : 1));
-    e->fused_resident = (per_cu < 4 * e->step_wps ? per_cu : 4 * e->step_wps) * prop.multiProcessorCount;
-    e->fused_groups = prop.multiProcessorCount;   // one per compute unit: two measured 1 % slower (more contention with the steps)
-    { const char* g = getenv("MOOG_FUSED_GROUPS"); if (g && atoi(g) > 0) e->fused_groups = atoi(g); }   // experiments
-    if (e->fused_groups > e->n_envs) e->fused_groups = e->n_envs;
-    e->fused_ready = true;
-  }
-  e->perm_buf[0] = e->perm;
-  __atomic_store_n(e->fused_abort, 0u, __ATOMIC_RELAXED);
-  e->fused = true;
-  return MOOG_OK;
-}
-
 int moog_engine_set_action_dtype(moog_engine_t* e, int32_t float32) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
   e->act_f32 = float32 ? 1 : 0;
@@ -1309,10 +1052,9 @@ int moog_engine_layer_usage(moog_engine_t* e, int32_t* high_water, int32_t* drop
   return MOOG_OK;
 }
 
-int moog_engine_get_fused(moog_engine_t* e, int32_t* enabled) {
-  if (!e || !enabled) return fail(MOOG_E_INVALID, "null argument");
-  // (a call's frames that gave up waiting switch the mode off at the next call; report that already)
-  *enabled = (e->fused && !(e->fused_abort && __atomic_load_n(e->fused_abort, __ATOMIC_RELAXED) != 0u)) ? 1 : 0;
+int moog_engine_raster_path(moog_engine_t* e, int32_t* path) {
+  if (!e || !path) return fail(MOOG_E_INVALID, "null argument");
+  *path = (e->mask_setup.ok && e->pe_ns <= 0) ? MOOG_RASTER_MASK : MOOG_RASTER_SPANS;
   return MOOG_OK;
 }
 
@@ -1326,11 +1068,14 @@ int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late
 
 int moog_engine_set_color_override(moog_engine_t* e, const uint32_t* rgb_dev) {
   if (!e) return fail(MOOG_E_INVALID, "null engine");
-  e->rgb_override = rgb_dev;
-  if (rgb_dev) {   // the cached pictures hold the colour map's colours; frames that follow their env's step would be drawn
-                   // before the host has seen the step's colours; the draw-list rasterisers have their own colour code
-    e->n_static = 0; e->pe_ns = 0; e->fused = false; e->dlist = false; e->wave = false;
+  if (rgb_dev && !e->rgb_override) {   // the cached pictures hold the colour map's colours: off while the host supplies them
+    e->kept_n_static = e->n_static; e->kept_pe_ns = e->pe_ns; e->kept_pe_nsv = e->pe_nsv;
+    e->n_static = 0; e->pe_ns = 0; e->pe_nsv = 0;
+  } else if (!rgb_dev && e->rgb_override) {   // back to render.cmap: the prefixes as they were (the per-env pictures are drawn again)
+    e->n_static = e->kept_n_static; e->pe_ns = e->kept_pe_ns; e->pe_nsv = e->kept_pe_nsv;
+    if (e->pe_ns > 0 && e->pe_valid) HIPCHK(hipMemset(e->pe_valid, 0, sizeof(int32_t) * (size_t)e->n_envs));
   }
+  e->rgb_override = rgb_dev;
   return MOOG_OK;
 }
 

@@ -3,7 +3,6 @@
 // the host side (moog_engine.hip), which only sees the launch functions declared at the bottom.
 #pragma once
 #include "moog_device.h"
-#include "moog_drawlist.h"
 
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
@@ -71,10 +70,8 @@ __device__ inline void load_record(const Env& e, const HotLayout& h, const moog_
   wsync();
 }
 
-// through: the record is about to be read by another kernel that is running now (moog_engine_set_fused) -- agent-scope
-// stores (sc1: written through this XCD's L2), so that no L2 write-back is needed before the env's flag is raised
 __device__ inline void store_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
-                                    double* gf, int32_t* gq, int32_t* fault_flag = nullptr, bool through = false) {
+                                    double* gf, int32_t* gq, int32_t* fault_flag = nullptr) {
   wsync();
   if (fault_flag && e.lane == 0) {   // rare: tell the host without waiting for it to look at every record
     const int32_t fw = e.q[e.L.o_fault];
@@ -86,24 +83,6 @@ __device__ inline void store_record(const Env& e, const HotLayout& h, const moog
   int4* dsti = reinterpret_cast<int4*>(gq);
   const int4* srci = reinterpret_cast<const int4*>(e.q);
   const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
-  if (through) {
-    for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
-      if (i >= fa && i < fb) continue;
-      const double2 v = src[i < fa ? i : i - (fb - fa)];
-      __hip_atomic_store(&gf[2 * i], v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gf[2 * i + 1], v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    unsigned long long* gq64 = reinterpret_cast<unsigned long long*>(gq);
-    for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
-      if (i >= ia && i < ib) continue;
-      const int4 v = srci[i < ia ? i : i - (ib - ia)];
-      __hip_atomic_store(&gq64[2 * i], (unsigned long long)(unsigned)v.x | ((unsigned long long)(unsigned)v.y << 32), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&gq64[2 * i + 1], (unsigned long long)(unsigned)v.z | ((unsigned long long)(unsigned)v.w << 32), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
   for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
     if (i < fa) dst[i] = src[i];
     else if (i >= fb) dst[i] = src[i - (fb - fa)];
@@ -157,13 +136,6 @@ struct KArgs {
   const int32_t* perm;   // launch order (or null)
   float* cost;           // per-env cycles of this step (or null)
   int32_t* fault_flag;   // host-visible word: OR of every fault bit raised by any env (deferred fault surfacing)
-  int32_t* done;         // moog_engine_set_fused: per env, the number of the last call whose step has been stored (or null)
-  int32_t epoch;         // this call's number
-  int32_t done_wb;       // 1: rules may write record fields straight to HBM -- always write this XCD's L2 back before the flag
-  uint32_t* dl;          // draw lists for the wave rasteriser (moog_drawlist.h), emitted when the record is stored (or null)
-  int32_t dl_stride;     // words per env
-  int32_t dl_cw, dl_ch;  // canvas size
-  int32_t dl_deep;       // 1: with the edge records (the wave rasteriser's input); 0: packed points only
   int32_t* layer_hw;     // usage of the dynamic layers (Env::layer_hw) or null
   int32_t act_f32;       // 1: `actions` holds float32 values (moog_engine_set_action_dtype)
   int32_t xstack_off;    // byte offset of the per-lane expression stacks in a wave's LDS area (Env::xstack), 0: none
@@ -191,23 +163,9 @@ struct KArgs {
 
 enum { MODE_STEP = 0, MODE_PHYSICS = 1, MODE_RESET_MASK = 2, MODE_FILL = 3 };
 
-// The env's draw list (moog_drawlist.h), from the record in LDS, once the step / reset is complete and the record is
-// stored.  Scratch: the broad-phase candidate list, the edge-index scratch and the candidate bit matrix (contiguous, 896
-// bytes) are dead by then, and so is the head of the f64 record (positions, velocities, ... -- everything in front of the
-// vertices); records too small for that get DL_SCRATCH_A extra bytes behind the bit matrix (moog_engine.hip step_lds).
-__device__ __forceinline__ void emit_drawlist(const Env& e, const KArgs& a, int env) {
-  if (!a.dl) return;
-  wsync();
-  unsigned char* sa = ((size_t)e.L.o_verts * 8 >= (size_t)DL_SCRATCH_A)
-                          ? reinterpret_cast<unsigned char*>(e.f)
-                          : reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(e.rowm + 64) + 15) & ~(uintptr_t)15);
-  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, e.L.S, e.q + e.L.o_flags, e.q + e.L.o_nverts, e.f + e.L.o_verts,
-                       e.voff, a.dl_cw, a.dl_ch, e.lane, sa, reinterpret_cast<unsigned char*>(e.cand), a.dl_deep != 0);
-}
-
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
-// lds: this wave's record area (the whole dynamic LDS of a one-wave workgroup; the fused launch runs four envs per workgroup)
+// lds: this wave's record area (the whole dynamic LDS of a one-wave workgroup)
 __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* lds = moog_lds, int lane = (int)threadIdx.x) {
   e.P = as_const_prog(a.P);
   e.fops = (PFOp)(unsigned long long)a.fops;
@@ -239,7 +197,6 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.vslot = a.vslot;
   e.dbg = a.dbg;
   e.n_path = 0; e.n_resp = 0; e.n_disj = 0;
-  e.wrote_direct = 0;
   e.layer_hw = a.layer_hw;
   e.cell_tab_n = 0; e.cell_nw = 0;
 #ifdef MOOG_PROFILE
@@ -576,7 +533,7 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
 // One env's step (or auto-reset), one wavefront.
 // Returns true when the call reset the env (the reset path writes colours / opacities / shapes straight to HBM).
 template <bool DYN>
-__device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned char* lds, const int lane) {
+__device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned char* lds, const int lane) {
   const long long t_sched = a.cost ? clock64() : 0;
   int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
   Env e;
@@ -596,7 +553,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
         // that carries everything steps 1.4 - 2.7 times slower, profiles/r04_variant_tax.txt).  The env is marked and left
         // as it is; the full reset kernel, launched behind this one, opens its episode and releases the pool's lock.
         if (e.lane == 0) a.late_mask[env] = 1;
-        return false;
+        return;
       }
       env_reset<DYN>(e);
     }
@@ -613,11 +570,10 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
       }
 #endif
     }
-    store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     if (DYN && held) pool_release(a, env, e.lane);
-    emit_drawlist(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
-    return true;   // (the reset path writes colours / opacities / shapes straight to HBM)
+    return;
   }
 #endif
   { PROF_T0; bbox_build_all(e); PROF_ADD(e, 9); }
@@ -625,8 +581,8 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
   const int K = uni(P->updates_per_env_step);
   if (a.mode == MODE_PHYSICS) {
     for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
-    store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
-    return false;
+    store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+    return;
   }
   {
   PROF_T0;
@@ -676,8 +632,7 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
   SEC(e, SEC_STORE);
-  store_record(e, a.H, a.L, gf, gq, a.fault_flag, a.done != nullptr);
-  emit_drawlist(e, a, env);
+  store_record(e, a.H, a.L, gf, gq, a.fault_flag);
   if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);
@@ -686,9 +641,6 @@ __device__ __forceinline__ bool step_env(const KArgs& a, const int env, unsigned
     if (a.reward && (a.dbg >> 8)) a.reward[env] = (double)e.prof[((a.dbg >> 8) & 31) - 1];
 #endif
   }
-  // a rule / modifier / run-time sprite creation stored a colour, opacity, shape id or Portal bit (ordinary stores, possibly
-  // to HBM): derived from the writers themselves (COL_SET ... in moog_device.h), not from a host-side list of components
-  return a.done != nullptr && __any(e.wrote_direct != 0);
 }
 
 template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiation (one per translation unit)
@@ -733,23 +685,10 @@ __global__ __launch_bounds__(MOOG_STEP_THREADS, WPS) void moog_step_kernel(KArgs
     else if (b < a.prio_t[2]) __builtin_amdgcn_s_setprio(1);
   }
   if (a.perm) env = a.perm[env];
-  const bool direct = step_env<DYN>(a, env, moog_lds, (int)threadIdx.x);
+  step_env<DYN>(a, env, moog_lds, (int)threadIdx.x);
 #ifdef MOOG_WATCH
   if (a.watch && threadIdx.x == 0) { int32_t* w = reinterpret_cast<int32_t*>(__builtin_assume_aligned(moog_lds + a.watch_off, 16)); __hip_atomic_store(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
-  if (a.done) {   // the frame of this env may be drawn now (moog_raster_follow_kernel): record first, then the flag
-    // The record went out with agent-scope stores; whatever the call wrote straight to HBM with ordinary stores (a reset's
-    // colours / opacities / shapes; rules that modify them: done_wb) needs this XCD's L2 written back first.  That
-    // write-back is kept off the common path: 4096 of them per launch cost the step kernel 30 us.
-    if (direct || a.done_wb) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    else {
-      // every store of the record acknowledged before the flag goes out (a workgroup-scope fence alone emits no wait
-      // here: the flag overtook the record about once in 10^5 frames)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(&a.done[env], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 

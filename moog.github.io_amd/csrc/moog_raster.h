@@ -105,11 +105,6 @@ struct RArgs {
   size_t sbg_env_stride;    // bytes between the envs' pictures; 0: one picture for all (the comparison is the frame kernel's)
   const uint32_t* rgb_override;   // [n_envs][S] r | g << 8 | b << 16 per sprite slot instead of the colour map (moog_engine_set_color_override), or null
   const int32_t* env_build; // build launches: [n_envs] 1 = draw this env's picture, 0 = the workgroup has nothing to do; null: every env
-  // draw lists (moog_drawlist.h): when set, the vertices come from the env's list instead of the f64 record
-  const uint32_t* dl;
-  int32_t dl_stride;        // words per env
-  int32_t nsl;              // entries of the reference list that the static prefix occupies (0: the list path does not use the cached picture)
-  const uint32_t* sref_dl;  // reference draw list of the static prefix's scratch env
 };
 
 // Edge record, 16 bytes, one per vertex slot (the edge from vertex k to k + 1).
@@ -148,109 +143,6 @@ __host__ __device__ inline void raster_plan(int S, int TOTV, int ncopy, int W, i
   p->o_misc = o; o = r_align(o + 64);
   p->total = o;
 }
-
-// moog_engine_set_fused: frames follow their env's step.  A small persistent grid (one workgroup per compute unit) runs
-// on a second stream BESIDE the step kernel; a workgroup takes the next position of the expected finish order, waits
-// until that env's step has been stored (done[env] == epoch: the step wave writes its record with agent-scope stores,
-// then raises the flag), and renders it.  It cannot starve the step kernel: 27 KB of LDS and four waves of <= 80 VGPRs
-// per compute unit leave room for ten stepping envs there, and the grid is too small to fill the compute units by itself.
-struct RFollow {
-  const int32_t* done;     // per env: number of the last call whose step has been stored
-  int32_t epoch;           // this call's number
-  const int32_t* perm;     // the step kernel's launch order (descending expected cost)
-  int32_t resident;        // positions of the launch order that start with the launch (the others start as those finish)
-  uint32_t* ticket;        // [0] frames handed out in this call (zeroed by the gate kernel),
-                           // [1] the number of the call the gate gave up on (no step kernel beside it: kernels serialised by a tool)
-  int32_t spin_cap;        // polls (about a microsecond each) before a workgroup gives up
-  uint32_t* abort_host;    // host-visible word: the number of the call that gave up (the engine then leaves the mode)
-};
-// A call whose gate or a frame gave up waiting (no step kernel beside the grid: kernels serialised by something the engine
-// cannot see) is NOT lost: ticket[1] holds the call's number, the remaining workgroups leave at once, and the fallback
-// launch, which the engine enqueues behind the step kernel of every call, draws the whole batch when (and only when) it
-// finds that number -- otherwise its workgroups return after one load.
-void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream);
-void moog_raster_fallback_launch(const RArgs& a, const uint32_t* ticket, int epoch, int workgroups, size_t lds_bytes, hipStream_t stream);
-// self-check of the mode: the fault bit is raised (summary word + one env's fault word) when the two frame batches differ anywhere
-void moog_frames_compare_launch(const uint8_t* a, const uint8_t* b, size_t bytes, int32_t* fault_flag, int32_t* env_fault, int32_t bit, hipStream_t stream);
-
-// ---- the wave rasteriser (moog_raster_wave.h): one wavefront per frame, input = the env's draw list (moog_drawlist.h)
-#define RW_SLOW 1   // lanes of a wave that run the generic scanline (the crossing list aliases the wave's long-edge list)
-#define RW_LONG 64   // long edges (5 to 12 rows) a wave lists per pass for its lane groups; the others push their rows themselves
-#define RW_VLONG 16  // very long edges (walls) a wave lists per pass
-#define RW_PEND 256  // rare rows a wave sets aside (uint16): [0, 128) several heads, [128, 256) generic scanline
-#define RW_MAX_ITEMS 64
-
-#define RW_WAVES 2            // wavefronts per frame
-#define RW_THREADS (64 * RW_WAVES)
-
-struct RWPlan {   // LDS carve-up (byte offsets), computed once on the host
-  unsigned o_edge, o_rows, o_item_y, o_rgba, o_rowbase, o_iinfo, o_rowitems, o_rowitem, o_long, o_pend, o_dummy, o_misc, total;
-  int32_t e_cap;   // edge records (a multiple of 64: rounds per pass)
-  int32_t r_cap;   // row records per pass (>= canvas height)
-};
-
-struct RWArgs {
-  const moog_program_t* P;
-  moog_layout_t L;
-  const double* f64;
-  const int32_t* i32;
-  uint8_t* image;
-  const uint32_t* dl;        // draw lists
-  int32_t dl_stride;         // words per env
-  int32_t n_envs;
-  int32_t W, H;              // canvas = observation size
-  int32_t debug_stop;        // >0: leave out the stages behind that one (profiling aid): 2 no edges, 3 no pushes, 5 no compose
-  int32_t xxcap;             // crossing-list capacity of the generic scanline = 2 * max vertices per sprite
-  RWPlan plan;
-  // static prefix (above): the first n_static slots, when alive and equal to the reference, are in the cached picture
-  int32_t n_static;
-  int32_t nsl;               // entries of round 0 that the prefix occupies in the reference draw list
-  const uint32_t* sref_dl;   // reference draw list (of the scratch env)
-  const double* sref_col;    // reference colours [n_static][3]
-  const int32_t* sref_opa;
-  const uint8_t* sbg;        // background + prefix, [H][W][3] in output (flipped) order
-  const int32_t* perm;       // optional: workgroup b renders env perm[b]
-};
-
-__host__ __device__ inline void raster_wave_plan(int W, int H, int e_cap, int r_cap, int xxcap, RWPlan* p) {
-  size_t o = 0;
-  p->e_cap = e_cap; p->r_cap = r_cap;
-  {   // edge records; at compose time the same words hold the waves' lists of 16-pixel segments to compose (uint16 each)
-    const size_t l1 = (size_t)e_cap * sizeof(REdge), l2 = (size_t)H * (W / 16) * 2 * 2;
-    p->o_edge = o; o = r_align(o + (l1 > l2 ? l1 : l2));
-  }
-  p->o_rows = o; o = r_align(o + (size_t)r_cap * sizeof(RRow));
-  p->o_item_y = o; o = r_align(o + RW_MAX_ITEMS * 8);         // ymin, ymax (ints, atomics)
-  p->o_rgba = o; o = r_align(o + RW_MAX_ITEMS * 4);
-  p->o_rowbase = o; o = r_align(o + RW_MAX_ITEMS * 4);        // first row record - first row
-  p->o_iinfo = o; o = r_align(o + RW_MAX_ITEMS * 4);          // first edge record | vertices << 16
-  p->o_rowitems = o; o = r_align(o + (size_t)H * 8);          // per canvas row: the items with a covered pixel there
-  p->o_rowitem = o; o = r_align(o + (size_t)r_cap);           // item of every row record
-  {   // per wave: long-edge list (push stage) / generic crossing list (row stage)
-    const size_t l1 = (size_t)(RW_LONG + RW_VLONG) * 4, l2 = (size_t)xxcap * RW_SLOW * 4;
-    p->o_long = o; o = r_align(o + (l1 > l2 ? l1 : l2) * RW_WAVES);
-  }
-  p->o_pend = o; o = r_align(o + RW_PEND * 2 * RW_WAVES);
-  p->o_dummy = o; o = r_align(o + 64 * RW_WAVES * 2);         // where the key stores of masked-off pushes go
-  p->o_misc = o; o = r_align(o + (8 + 8 * RW_WAVES) * 4);
-  p->total = (unsigned)o;
-}
-
-struct DLArgs {   // moog_drawlist_kernel: draw lists from state records in HBM
-  const moog_program_t* P;
-  moog_layout_t L;
-  const double* f64;
-  const int32_t* i32;
-  const int16_t* vslot;
-  uint32_t* dl;
-  int32_t dl_stride;
-  int32_t n_envs;
-  int32_t cw, ch;
-  int32_t deep;   // 1: with the edge records (moog_drawlist.h)
-};
-void moog_drawlist_launch(const DLArgs& a, hipStream_t stream);
-int moog_raster_wave_configure(size_t lds_bytes);
-void moog_raster_wave_launch(const RWArgs& a, size_t lds_bytes, hipStream_t stream);
 
 // moog_raster.hip: the kernel's own translation unit
 // Image.resize(LANCZOS) of a batch of canvases [n][ch][cw][3] -> observations [n][oh][ow][3], flipped; tmp: [n][ch][ow][3]

@@ -1,145 +1,18 @@
 // moog_raster.hip -- the rasteriser kernel (see moog_raster.h for the design), its own
 // translation unit so that it builds independently of the step / reset kernels.
 #include "moog_raster_kernel.h"
-#include "moog_raster_wave.h"
 #include "moog_raster_mask.h"
 
-template <int WORDS, bool DL>
-__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS, DL>(a, (int)blockIdx.x, -1); }
-
-
-// Frames follow their env's step (RFollow in moog_raster.h).
-__device__ __forceinline__ void follow_give_up(const RFollow& f) {
-  __hip_atomic_store(&f.ticket[1], (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (f.abort_host) __hip_atomic_store(f.abort_host, (unsigned)f.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 template <int WORDS>
-__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_follow_kernel(RArgs a, RFollow f) {
-  // (the frame's env goes from the polling thread to the workgroup through a spare word of the plan's misc area: the
-  //  kernel has no static LDS, so that the frames of the largest programs still fit)
-  int* const s_env = reinterpret_cast<int*>(moog_lds + a.plan.o_misc) + 15;
-  const int n = a.n_envs;
-  for (;;) {
-    if (threadIdx.x == 0) {
-      const unsigned b = atomicAdd(f.ticket, 1u);
-      int env = -1;
-      if (b < (unsigned)n && __hip_atomic_load(&f.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)f.epoch) {
-        // Positions of the launch order (descending cost) in the order they are expected to finish: the first `resident`
-        // start at once and finish lightest first, the ones behind them start as those finish (about as late as two
-        // light envs take), and the heaviest quarter of the first round finishes last.
-        const int r1 = f.resident < n ? f.resident : n, x = r1 / 4, bi = (int)b;
-        const int pos = bi < r1 - x ? r1 - 1 - bi : (bi < n - x ? r1 + (bi - (r1 - x)) : n - 1 - bi);
-        env = f.perm[pos];
-        int spins = 0;
-        while (__hip_atomic_load(&f.done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.epoch) {
-          __builtin_amdgcn_s_sleep(16);
-          ++spins;
-          // another workgroup (or the gate) gave up: the fallback launch draws every frame of this call
-          if ((spins & 255) == 0 && __hip_atomic_load(&f.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)f.epoch) { env = -1; break; }
-          if (spins > f.spin_cap) {   // never draw a record that may still be in flight
-            follow_give_up(f);
-            env = -1;
-            break;
-          }
-        }
-      }
-      *s_env = env;
-    }
-    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (after the poll: same wave)
-    __syncthreads();
-    const int env = *s_env;
-    if (env < 0) return;
-    raster_block<WORDS>(a, 0, env);
-    __syncthreads();   // the next frame reuses the tables and s_env
-  }
-}
-
-// Holds the follow grid back until the step kernel's first round is resident: launched at the same moment, the frames'
-// workgroups would take LDS and wave slots before the step kernel's workgroups and push a quarter of the envs into a
-// third round.  One wavefront polls 64 envs from the light end of the first round and returns when any of them is done
-// (by then every workgroup of the first round started long ago); the follow grid is the next launch on its stream.
-__global__ __launch_bounds__(64) void moog_raster_gate_kernel(RFollow f, int n) {
-  // (this call's frame counter starts at zero: done here, not by a memset -- a fill kernel needs a wave slot with more
-  //  registers than the step kernel leaves free and would sit in the queue for 300 us)
-  if (threadIdx.x == 0) __hip_atomic_store(&f.ticket[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int r1 = f.resident < n ? f.resident : n;
-  const int stride = r1 >= 64 * 8 ? 8 : 1;
-  int pos = r1 - 1 - (int)threadIdx.x * stride;
-  if (pos < 0) pos = 0;
-  const int env = f.perm[pos];
-  for (int spins = 0; spins < f.spin_cap / 8; ++spins) {
-    const bool mine = __hip_atomic_load(&f.done[env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f.epoch;
-    if (__ballot(mine) != 0ull) return;
-    __builtin_amdgcn_s_sleep(64);
-  }
-  // No env finished in about half a second: the step kernel is not running beside this stream (something serialises the
-  // kernels).  The follow grid leaves without drawing; the fallback launch behind the step kernel draws the batch.
-  if (threadIdx.x == 0) follow_give_up(f);
-}
-
-template <int WORDS>
-__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_fallback_kernel(RArgs a, const uint32_t* ticket, int epoch) {
-  if (__hip_atomic_load(&ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)epoch) return;
-  for (int env = (int)blockIdx.x; env < a.n_envs; env += (int)gridDim.x) {
-    raster_block<WORDS>(a, 0, env);
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256) void moog_frames_compare_kernel(const uint4* a, const uint4* b, size_t n16, int32_t* fault_flag, int32_t* env_fault, int32_t bit) {
-  bool bad = false;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-    const uint4 x = a[i], y = b[i];
-    bad = bad || x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
-  }
-  if (__any(bad) && (threadIdx.x & 63) == 0) {
-    __hip_atomic_fetch_or(env_fault, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_or(fault_flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-void moog_frames_compare_launch(const uint8_t* a, const uint8_t* b, size_t bytes, int32_t* fault_flag, int32_t* env_fault, int32_t bit, hipStream_t stream) {
-  hipLaunchKernelGGL(moog_frames_compare_kernel, dim3(512), dim3(256), 0, stream, reinterpret_cast<const uint4*>(a),
-                     reinterpret_cast<const uint4*>(b), bytes / 16, fault_flag, env_fault, bit);
-}
-
-void moog_raster_fallback_launch(const RArgs& a, const uint32_t* ticket, int epoch, int workgroups, size_t lds_bytes, hipStream_t stream) {
-  if (a.words > 1) hipLaunchKernelGGL(moog_raster_fallback_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, ticket, epoch);
-  else hipLaunchKernelGGL(moog_raster_fallback_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, ticket, epoch);
-}
-
-void moog_raster_follow_launch(const RArgs& a, const RFollow& f, int workgroups, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(moog_raster_gate_kernel, dim3(1), dim3(64), 0, stream, f, a.n_envs);
-  if (a.words > 1) hipLaunchKernelGGL(moog_raster_follow_kernel<2>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
-  else hipLaunchKernelGGL(moog_raster_follow_kernel<1>, dim3(workgroups), dim3(R_THREADS), lds_bytes, stream, a, f);
-}
+__global__ __launch_bounds__(R_THREADS, 6) void moog_raster_kernel(RArgs a) { raster_block<WORDS>(a, (int)blockIdx.x, -1); }
 
 int moog_raster_configure_mask(size_t lds_bytes) { return moog_raster_mask_configure(lds_bytes); }
 
 int moog_raster_configure(size_t lds_bytes) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1, false>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_follow_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_follow_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_fallback_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_fallback_kernel<2>),
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return (int)err;
 }
@@ -157,64 +30,16 @@ static RmArgs mask_args(const RArgs& r) {
   return a;
 }
 
+// Ordinary frames of programs the mask rasteriser takes (RmSetup::ok) are drawn by it; the pictures of the static / per-env
+// prefix, frames on top of a per-env prefix and every other program's frames by the push / sort / span kernel.
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
-  if (a.ms.ok && !a.build && !a.dl && a.sbg_env_stride == 0 && !a.env_build) {
+  if (a.ms.ok && !a.build && a.sbg_env_stride == 0 && !a.env_build) {
     moog_raster_mask_launch(mask_args(a), a.ms.lds, stream);
     return;
   }
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));
-  if (a.dl) {
-    if (a.words > 1) hipLaunchKernelGGL((moog_raster_kernel<2, true>), grid, dim3(R_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((moog_raster_kernel<1, true>), grid, dim3(R_THREADS), lds_bytes, stream, a);
-    return;
-  }
-  if (a.words > 1) hipLaunchKernelGGL((moog_raster_kernel<2, false>), grid, dim3(R_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL((moog_raster_kernel<1, false>), grid, dim3(R_THREADS), lds_bytes, stream, a);
-}
-
-// ---- the wave rasteriser: one wavefront per frame (moog_raster_wave.h) ---------------------------------------------
-template <int WORDS>
-__global__ __launch_bounds__(RW_THREADS, 5) void moog_raster_wave_kernel(RWArgs a) {
-  int env = (int)blockIdx.x;
-  if (env >= a.n_envs) return;
-  if (a.perm) env = a.perm[env];
-  raster_wave<WORDS>(a, env);
-}
-
-// Draw lists from state records in HBM (frames of states the step kernel did not produce): one wavefront per env.
-__global__ __launch_bounds__(64) void moog_drawlist_kernel(DLArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char sa[DL_SCRATCH_A];
-  __shared__ __attribute__((aligned(16))) unsigned char sb[DL_SCRATCH_B];
-  __shared__ int32_t voff[RW_MAX_ITEMS];
-  const int env = (int)blockIdx.x;
-  if (env >= a.n_envs) return;
-  PProg P = as_const_prog(a.P);
-  const int lane = (int)threadIdx.x;
-  if (lane < a.L.S) voff[lane] = P->slot_voff[lane];
-  __syncthreads();
-  const double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
-  const int32_t* gq = a.i32 + (size_t)env * a.L.i32_per_env;
-  drawlist_emit<false>(a.dl + (size_t)env * a.dl_stride, a.L.S, gq + a.L.o_flags, gq + a.L.o_nverts, gf + a.L.o_verts, voff,
-                       a.cw, a.ch, lane, sa, sb, a.deep != 0);
-}
-
-void moog_drawlist_launch(const DLArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(moog_drawlist_kernel, dim3((unsigned)a.n_envs), dim3(64), 0, stream, a);
-}
-
-int moog_raster_wave_configure(size_t lds_bytes) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_wave_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_wave_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  return (int)err;
-}
-
-void moog_raster_wave_launch(const RWArgs& a, size_t lds_bytes, hipStream_t stream) {
-  const dim3 grid((unsigned)a.n_envs);
-  if (a.W > 64) hipLaunchKernelGGL(moog_raster_wave_kernel<2>, grid, dim3(RW_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(moog_raster_wave_kernel<1>, grid, dim3(RW_THREADS), lds_bytes, stream, a);
+  if (a.words > 1) hipLaunchKernelGGL(moog_raster_kernel<2>, grid, dim3(R_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(moog_raster_kernel<1>, grid, dim3(R_THREADS), lds_bytes, stream, a);
 }
 
 // ---- Image.resize(size, resample=LANCZOS) (pil_renderer.py:112; Pillow Resample.c, 8 bits per channel): a horizontal

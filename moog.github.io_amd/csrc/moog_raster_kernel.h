@@ -4,7 +4,6 @@
 #define MOOG_RASTER_KERNEL_H_
 #include "moog_device.h"
 #include "moog_raster.h"
-#include "moog_drawlist.h"
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
@@ -497,9 +496,7 @@ __device__ __noinline__ void r_next_pass(RRow* rows, int cap_rows, int* misc, in
 
 // block = index of the workgroup among the launch's raster workgroups; env_of_block >= 0 names the env of a
 // one-tile frame directly (the fused launch renders envs in its own order)
-// DL: the vertices come from the env's draw list (moog_drawlist.h: live vertices only, already integer canvas points)
-// instead of the f64 record -- one-tile frames without a polygon modifier, <= 64 slots (moog_engine.hip decides).
-template <int WORDS, bool DL = false>
+template <int WORDS>
 __device__ __forceinline__ void raster_block(const RArgs& a, const int block, const int env_of_block) {
   // one workgroup = one tile (<= 128 columns x band_h rows) of one env's frame; frames up to 128 x 128 are one tile
   const int tiles = a.tiles_x * a.bands;
@@ -552,28 +549,15 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   // phase 1's first loads go out before the tables are cleared (HBM latency under the clearing)
   unsigned vi_next = 0u;
   double2 v_next = make_double2(0.0, 0.0);
-  const uint32_t* dl = DL ? a.dl + (size_t)env * a.dl_stride : nullptr;
-  const int n_entries = DL ? 64 * uni((int)dl[0]) : 0;   // rounds of 64 entries; a round's byte at dl + 4 says how many are used
-  uint2 en_next = make_uint2(0u, 0u);
-  auto entry_of = [&](const uint32_t* list, int ie) -> uint2 {   // {packed point, info word} of entry ie (moog_drawlist.h)
-    const uint32_t* rnd = list + DL_HDR + DL_ROUND_WORDS * (ie >> 6);
-    return make_uint2(rnd[4 * (ie & 63)], rnd[256 + (ie & 63)] & ~DL_INFO_HEAD);
-  };
-  auto load_entry = [&](int ie) -> uint2 {
-    uint2 en = make_uint2(0u, 0u);   // (w1 == 0 never occurs for a used entry: nv >= 1)
-    if (ie < n_entries && (ie & 63) < (int)reinterpret_cast<const uint8_t*>(dl + 4)[ie >> 6]) en = entry_of(dl, ie);
-    return en;
-  };
   // static prefix: this thread's share of the comparison with the reference record
   const bool per_env = a.sbg_env_stride != 0;   // the env's own picture, validated by the check launch: nothing to compare here
   const int NS = (a.build || per_env) ? 0 : a.n_static;
   const int NSE = (per_env && !a.build) ? a.n_static : 0;   // slots that are in the env's picture: dead as far as this frame goes
   // ... and whole rounds of them are left out of the per-slot and per-vertex loops (their vertex slots are the record's first)
-  const int S0 = DL ? 0 : (NSE & ~63), V0 = (DL || NSE == 0) ? 0 : ((int)a.nsv / R_THREADS) * R_THREADS;
+  const int S0 = NSE & ~63, V0 = NSE == 0 ? 0 : ((int)a.nsv / R_THREADS) * R_THREADS;
   const uint8_t* sbg = a.sbg + (size_t)env * a.sbg_env_stride;
   bool st_bad = false;
-  if (DL) en_next = load_entry(tid);
-  else if (V0 + tid < TOTV) {
+  if (V0 + tid < TOTV) {
     vi_next = a.vinfo[V0 + tid];
     v_next = *reinterpret_cast<const double2*>(gf + a.L.o_verts + 2 * (V0 + tid));
   }
@@ -593,20 +577,12 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   }
   for (int s = S0 + tid - (R_THREADS - 64); s >= S0 && s < S; s += 64) {
     // (every load of the slot goes out at once: one trip to HBM, not one per dependent step)
-    // (DL: a slot is alive when the draw list has an item for it; its vertex count comes with its first entry)
-    const unsigned s2i = DL ? (unsigned)reinterpret_cast<const uint8_t*>(dl + 12)[s] : 0u;
-    const int flags = DL ? (s2i != 255u ? MOOG_F_ALIVE : 0) : gq[a.L.o_flags + s];
-    const int nvs = DL ? 0 : gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
+    const int flags = gq[a.L.o_flags + s];
+    const int nvs = gq[a.L.o_nverts + s], opa = gq[a.L.o_opacity + s];
     const double* col = gf + a.L.o_color + 3 * s;
     const double c0 = col[0], c1 = col[1], c2 = col[2];
     const bool alive = (flags & MOOG_F_ALIVE) != 0 && !(a.build && s >= a.n_static) && s >= NSE;
-    if (DL && s < NS) {
-      const double* rc = a.sref_col + 3 * s;
-      st_bad = st_bad || s2i != (unsigned)s || opa != a.sref_opa[s] ||
-               __double_as_longlong(c0) != __double_as_longlong(rc[0]) ||
-               __double_as_longlong(c1) != __double_as_longlong(rc[1]) ||
-               __double_as_longlong(c2) != __double_as_longlong(rc[2]);
-    } else if (s < NS) {
+    if (s < NS) {
       const double* rc = a.sref_col + 3 * s;
       st_bad = st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
                __double_as_longlong(c0) != __double_as_longlong(rc[0]) ||
@@ -655,25 +631,6 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
 
   // ---- 1: vertices -> integer canvas coordinates; item row ranges ----------------------
   unsigned vi_keep0 = 0u, vi_keep1 = 0u;   // the first two rounds' table entries, reused by phase 2
-  if (DL) {   // entries of the draw list: packed points into the slot's vertex area, item row ranges, vertex counts
-    for (int ie = tid; ie < n_entries; ie += R_THREADS) {
-      const uint2 en = en_next;
-      en_next = load_entry(ie + R_THREADS);
-      const unsigned vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u;   // slot | k << 8 | used
-      if (ie == tid) vi_keep0 = vi; else if (ie == tid + R_THREADS) vi_keep1 = vi;
-      if (NS > 0 && ie < a.nsl) {   // the prefix's entries against the reference's
-        const uint2 ref = entry_of(a.sref_dl, ie);
-        st_bad = st_bad || ref.x != en.x || ref.y != en.y;
-      }
-      if (!en.y) continue;
-      const int s = (int)(en.y >> 24), k = (int)((en.y >> 8) & 255u);
-      const int y = (short)(en.x >> 16);
-      reinterpret_cast<unsigned*>(ivert)[(pbase[s] & 0xfffff) + k] = en.x;
-      atomicMin(&item_y[2 * s], y);
-      atomicMax(&item_y[2 * s + 1], y);
-      if (k == 0) atomicOr(reinterpret_cast<unsigned*>(&pbase[s]), ((en.y >> 16) & 255u) << 20);
-    }
-  } else
   for (int idx = V0 + tid; idx < TOTV; idx += R_THREADS) {
     const unsigned vi = vi_next;
     const double2 v = v_next;
@@ -710,15 +667,11 @@ __device__ __forceinline__ void raster_block(const RArgs& a, const int block, co
   // ---- 2b: the edge leaving every vertex (ImagingDrawPolygon: add_edge + merge of
   //          horizontal runs); table edges and horizontal heads join the compact list
   for (int c = 0; c < ncopy; ++c) {
-    for (int base0 = V0; base0 < (DL ? n_entries : TOTV); base0 += R_THREADS) {
+    for (int base0 = V0; base0 < TOTV; base0 += R_THREADS) {
       int idx = base0 + tid;
       int kind = 0;   // 1 table edge, 2 horizontal head
       unsigned vi = 0u;
-      if (DL) {
-        vi = base0 == 0 ? vi_keep0 : (base0 == R_THREADS ? vi_keep1 : 0u);
-        if (base0 >= 2 * R_THREADS) { const uint2 en = load_entry(idx); vi = en.y ? ((en.y >> 24) | (en.y & 0xff00u) | 0x80000000u) : 0u; }
-        idx = (vi >> 31) ? (pbase[vi & 0xffu] & 0xfffff) + (int)((vi >> 8) & 0xffu) : TOTV;   // the vertex slot of the entry
-      } else if (idx < TOTV) vi = base0 == V0 ? vi_keep0 : (base0 == V0 + R_THREADS ? vi_keep1 : a.vinfo[idx]);
+      if (idx < TOTV) vi = base0 == V0 ? vi_keep0 : (base0 == V0 + R_THREADS ? vi_keep1 : a.vinfo[idx]);
       if (idx < TOTV) {
         int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
         int nv = pbase[s] >> 20;

@@ -17,10 +17,10 @@ SYMBOLS = (
     'moog_engine_step', 'moog_engine_physics_only', 'moog_engine_render',
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
     'moog_engine_set_debug', 'moog_engine_static_prefix', 'moog_engine_poll_faults',
-    'moog_engine_set_fused', 'moog_engine_get_fused', 'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
+    'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
     'moog_engine_read_watch', 'moog_engine_set_reset_pool', 'moog_engine_get_reset_pool',
     'moog_engine_env_prefix', 'moog_engine_set_color_override',
-    'moog_engine_kernel_variant',
+    'moog_engine_kernel_variant', 'moog_engine_raster_path',
 )
 
 _LIB = None
@@ -40,12 +40,10 @@ def load_library(path=None):
     # one already resident when the engine library resolves libamdhip64, so that
     # both share one runtime (streams, device pointers).
     import torch  # noqa: F401
-    # Kernels of different streams run beside each other only on different hardware queues, and the runtime's default is 4
-    # for the whole process: the sub-batches (SubBatchedEnvironment) and the reset pool's fills need more.  The HIP runtime
-    # reads the variable when it initialises, so this only takes effect in a process that has not touched the GPU yet (and
-    # never overrides the caller's own setting).
-    if 'GPU_MAX_HW_QUEUES' not in os.environ and not torch.cuda.is_initialized():
-        os.environ['GPU_MAX_HW_QUEUES'] = '16'
+    # (Kernels of different streams run beside each other only on different hardware queues, and the HIP runtime's default is
+    #  4 for the whole process -- GPU_MAX_HW_QUEUES, read when the runtime initialises.  The asynchronous sub-batches want 2
+    #  per sub-batch, the reset pool's fills use what is there (queues - 2, at most 8).  The library does not touch the
+    #  variable: a process that wants more sets it before anything initialises HIP, as bench.py and the tools do.)
     if not os.path.exists(path):
         raise EngineError(
             'HIP engine library not found at %s -- build it with '
@@ -69,12 +67,11 @@ def load_library(path=None):
     lib.moog_engine_render.argtypes = [vp, vp, vp]
     lib.moog_engine_set_schedule.argtypes = [vp, vp, vp]
     lib.moog_engine_set_timing.argtypes = [vp, i32]
-    lib.moog_engine_set_fused.argtypes = [vp, i32]
-    lib.moog_engine_get_fused.argtypes = [vp, ctypes.POINTER(i32)]
     lib.moog_engine_set_reset_pool.argtypes = [vp, i32]
     lib.moog_engine_env_prefix.argtypes = [vp, ctypes.POINTER(i32)]
     lib.moog_engine_set_color_override.argtypes = [vp, vp]
     lib.moog_engine_kernel_variant.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.moog_engine_raster_path.argtypes = [vp, ctypes.POINTER(i32)]
     lib.moog_engine_get_reset_pool.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]
     lib.moog_engine_set_action_dtype.argtypes = [vp, i32]
     lib.moog_engine_layer_usage.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]

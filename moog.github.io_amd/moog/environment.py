@@ -34,9 +34,6 @@ _FAULT_EXC = (
     (_abi.MOOG_FAULT_TETHER_ZIP, ValueError,
      'All layers fed into TetherAcrossLayers must have the same number of sprites.'),
     (_abi.MOOG_FAULT_OFF_GRID, ValueError, 'Object is not on the maze grid.'),
-    (_abi.MOOG_FAULT_FRAME_TIMEOUT, RuntimeError, 'fused launch: a frame gave up waiting for its env\'s step.'),
-    (_abi.MOOG_FAULT_FRAME_MISMATCH, RuntimeError,
-     'frames that followed their env\'s step differ from the ordinary raster launch (MOOG_FUSED_SELFCHECK).'),
 )
 
 
@@ -126,7 +123,6 @@ class BatchedEnvironment(object):
         # False = never check.  Runs with injected uniforms / run-time sprite creation check at once.
         self.check_faults = True
         self._cost = self._perm = None
-        self._fused = False
         self._action_f32 = False
         self._apply_reset_pool()
         self._setup_color_fn()
@@ -251,20 +247,13 @@ class BatchedEnvironment(object):
                 torch.zeros((n,), dtype=torch.int32, device=device),
                 torch.zeros((n, P.render.height, P.render.width, 3), dtype=torch.uint8, device=device))
 
-    def enable_cost_schedule(self, enabled=True, fused=False):
+    def enable_cost_schedule(self, enabled=True):
         """Launch the step kernel's workgroups in order of descending per-env cost of the
         previous step (longest-processing-time first): the envs with clustered contacts
         start first instead of landing in the under-filled tail of the launch.  The engine
         re-sorts the order after every step on a side stream.  A pure scheduling hint --
-        results are identical.
-
-        fused=True also asks for ONE launch per step() call (moog_engine_set_fused): each frame is rasterised as
-        soon as its env's step is stored, beside the slower envs' steps.  Returns whether the fused launch is in
-        use (programs it does not cover keep the separate launches)."""
+        results are identical."""
         torch = self._torch
-        self._fused = False
-        if not (enabled and fused):
-            _engine.check(self._lib, self._lib.moog_engine_set_fused(self._handle, 0))
         if enabled:
             self._cost = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
             self._perm = torch.arange(self.num_envs, dtype=torch.int32, device=self.device)
@@ -272,55 +261,16 @@ class BatchedEnvironment(object):
                 _engine.check(self._lib, self._lib.moog_engine_set_schedule(
                     self._handle, ctypes.c_void_p(self._perm.data_ptr()),
                     ctypes.c_void_p(self._cost.data_ptr())))
-                if fused:
-                    self._fused = self._lib.moog_engine_set_fused(self._handle, 1) == 0
         else:
             self._cost = self._perm = None
             _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
-        return self._fused
 
-    def set_fused(self, enabled):
-        """Frames follow their env's step (moog_engine_set_fused) on / off; needs the cost schedule.  Returns whether
-        the mode is in use afterwards (False when the program or the environment -- counter collection -- rules it out)."""
-        if self._perm is None:
-            enabled = False
-        with self._torch.cuda.device(self.device):
-            self._fused = self._lib.moog_engine_set_fused(self._handle, 1 if enabled else 0) == 0 and bool(enabled)
-        return self._fused
-
-    @property
-    def fused(self):
-        """Whether frames (still) follow their env's step: the engine leaves the mode by itself when a call's frames had
-        to be drawn by the fallback launch (kernels serialised by something it cannot see)."""
+    def raster_path(self):
+        """Which rasteriser draws this engine's frames: 'mask' (csrc/moog_raster_mask_core.h) or 'spans'
+        (csrc/moog_raster_kernel.h) -- moog_engine_raster_path."""
         v = ctypes.c_int32()
-        _engine.check(self._lib, self._lib.moog_engine_get_fused(self._handle, ctypes.byref(v)))
-        self._fused = bool(v.value)
-        return self._fused
-
-    def tune_launch(self, step_fn, steps=24, settle=4):
-        """Launch-structure autotuning, to be run once the episode mix is stationary: times 2 x `steps` calls of
-        `step_fn()` (which must call self.step) with separate step / raster launches and with frames following
-        their env's step, and keeps the faster.  Whether the second pays depends on the workload: it needs a step
-        kernel that is long and heavy-tailed next to the raster work (colliding_predators_32: +4 %; a 100 us step
-        kernel or a program whose rules write record fields straight to HBM: slower).  Returns the mode kept."""
-        import time
-        torch = self._torch
-        took = {False: 0.0, True: 0.0}
-        for rnd in range(2):                       # A B A B: a drift of the box's clocks hits both modes alike
-            for fused in (False, True):
-                if self.set_fused(fused) != fused:
-                    return self.set_fused(False)
-                for _ in range(settle):
-                    step_fn()
-                torch.cuda.synchronize(self.device)
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    step_fn()
-                torch.cuda.synchronize(self.device)
-                took[fused] += time.perf_counter() - t0
-        # (what was measured, for the caller's records: seconds per call in each mode)
-        self.last_tune = {'separate_s_per_call': took[False] / (2 * steps), 'fused_s_per_call': took[True] / (2 * steps)}
-        return self.set_fused(took[True] < 0.995 * took[False])
+        _engine.check(self._lib, self._lib.moog_engine_raster_path(self._handle, ctypes.byref(v)))
+        return 'mask' if v.value == _abi.MOOG_RASTER_MASK else 'spans'
 
     # -- plumbing ---------------------------------------------------------------------
     def _stream(self):
@@ -448,7 +398,7 @@ class BatchedEnvironment(object):
             new_f = move(self.state_f64, src_f, torch.float64)
             new_q = move(self.state_i32, src_q, torch.int32)
             # the new engine, over the new records (outputs stay where they are)
-            had_schedule, had_fused, f32 = self._perm is not None, self._fused, self._action_f32
+            had_schedule, f32 = self._perm is not None, self._action_f32
             self._lib.moog_engine_destroy(self._handle)
             self._handle = ctypes.c_void_p()
             self.compiled, self.layout = new_c, L
@@ -463,7 +413,7 @@ class BatchedEnvironment(object):
             if f32:
                 _engine.check(self._lib, self._lib.moog_engine_set_action_dtype(self._handle, 1))
         if had_schedule:
-            self.enable_cost_schedule(True, fused=had_fused)
+            self.enable_cost_schedule(True)
         self._apply_reset_pool()
         self._setup_color_fn()
         self.capacity_growths = getattr(self, 'capacity_growths', []) + [dict(caps)]
@@ -473,8 +423,7 @@ class BatchedEnvironment(object):
 
         Faults are STICKY, like a broken environment in the reference: the per-env fault words (and the engine's summary
         word that _poll_faults reads) stay set, so every later reset() / step() / observation() raises again until
-        clear_faults() -- after which the faulted envs should be reset.  The one engine-origin condition,
-        MOOG_FAULT_FRAME_MISMATCH of the fused mode's self-check, is reported once and cleared."""
+        clear_faults() -- after which the faulted envs should be reset."""
         faults = self.state_i32[:, self.layout.o_fault]
         if not bool((faults != 0).any().item()):
             return
@@ -484,12 +433,6 @@ class BatchedEnvironment(object):
         for bit, exc, msg in _FAULT_EXC:
             if allbits & bit:
                 env = int((faults & bit).nonzero()[0].item())
-                if bit == _abi.MOOG_FAULT_FRAME_MISMATCH:   # engine-origin: report once
-                    self.state_i32[:, self.layout.o_fault] &= ~bit
-                    got = ctypes.c_int32()
-                    _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 0, ctypes.byref(got)))
-                    if got.value == bit:   # (other faults keep the summary word set: they are sticky)
-                        _engine.check(self._lib, self._lib.moog_engine_poll_faults(self._handle, 1, ctypes.byref(got)))
                 if bit == _abi.MOOG_FAULT_LAYER_FULL:   # which layer, and how much room it asked for
                     full = {k: v for k, v in self.layer_usage().items() if v['dropped'] > 0}
                     msg += ' Overflowing layers: %s -- pass layer_capacity={layer: slots} with more than high_water ' \
@@ -865,8 +808,7 @@ class SubBatchedEnvironment(object):
         return slice(g * self.part_envs, (g + 1) * self.part_envs)
 
     def enable_cost_schedule(self, enabled=True):
-        """Cost-ordered launch inside every sub-batch (BatchedEnvironment.enable_cost_schedule; the frames-follow-steps
-        launch is not used here: overlap comes from the streams)."""
+        """Cost-ordered launch inside every sub-batch (BatchedEnvironment.enable_cost_schedule)."""
         for g, p in enumerate(self.parts):
             with self._torch.cuda.stream(self._streams[g]):
                 p.enable_cost_schedule(enabled)

@@ -486,53 +486,6 @@ def test_cost_schedule_is_result_neutral():
     assert np.array_equal(outs[0][3], outs[1][3], equal_nan=True)
 
 
-@pytest.mark.parametrize('name,n,steps', [
-    ('colliding_predators_32', 4096, 40),   # no rules: records go out with agent-scope stores, L2 write-back only after a reset
-    ('colliding_predators_32', 333, 60),    # fewer envs than the follow grid has workgroups per round
-    ('chase_avoid_torus', 1024, 130),       # rules (torus wrap, vanish) + nine-copy frames + auto-resets
-    ('functional_maze', 512, 60),           # 128-column frames (two mask words), Booster writes colours straight to HBM
-    ('falling_balls', 1024, 80),
-])
-def test_frames_follow_steps_is_result_neutral(name, n, steps):
-    """moog_engine_set_fused: every frame is drawn beside the step kernel as soon as its env's step is stored.  States,
-    time steps and EVERY frame of every call equal the separate launches' (each call's frames are compared, so a frame
-    drawn from a stale or half-written record cannot hide), with per-kernel timing sampled in between (those calls
-    take the separate launches) and with episodes ending at different steps."""
-    import torch
-    outs = []
-    for fused in (False, True):
-        env = make_env(name, n, seed=12)
-        assert env.enable_cost_schedule(fused=fused) == fused
-        env.reset()
-        if fused:
-            env.set_timing(True, every=5)
-        grid = env._is_grid
-        g = torch.Generator(device='cpu').manual_seed(2)
-        sums, last = [], None
-        for k in range(steps):
-            if grid:
-                a = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32)
-            else:
-                a = torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1
-            out = env.step(a)
-            img = out.observation['image']
-            # a position-weighted checksum of every env's frame (exact integer arithmetic) + the step types / rewards
-            w = (torch.arange(img[0].numel(), device=img.device, dtype=torch.int64) % 8191) + 1
-            sums.append(((img.reshape(n, -1).to(torch.int64) * w).sum(1).cpu().numpy(), out.step_type.cpu().numpy(),
-                         np.nan_to_num(out.reward.cpu().numpy(), nan=-7.0)))
-            last = img
-        f, q = download(env)
-        env.raise_faults()
-        outs.append((f, q, last.cpu().numpy(), sums))
-        env.close()
-    assert np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
-    assert np.array_equal(outs[0][2], outs[1][2])
-    for k, (x, y) in enumerate(zip(outs[0][3], outs[1][3])):
-        assert np.array_equal(x[0], y[0]), 'frames of call %d differ in envs %s' % (k, np.nonzero(x[0] != y[0])[0][:8])
-        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
-
-
 @pytest.mark.parametrize('name,n,G,steps', [('colliding_predators_32', 768, 4, 30), ('chase_avoid_torus', 512, 2, 25),
                                              ('functional_maze', 256, 8, 25), ('falling_balls_64', 256, 2, 12)])
 def test_sub_batches_are_result_neutral(name, n, G, steps):
@@ -853,95 +806,6 @@ def test_layer_capacity_auto_grows_transparently():
                 assert p['x'] == q['x'] and p['y'] == q['y'] and np.array_equal(p['vertices'], q['vertices'])
     big.close()
     auto.close()
-
-
-def test_tune_launch_keeps_a_working_mode():
-    """BatchedEnvironment.tune_launch times both launch structures and keeps one; without a schedule it keeps the separate launches."""
-    env = make_env('colliding_predators_32', 512, seed=2)
-    env.reset()
-    assert env.tune_launch(lambda: env.step(env.random_action()), steps=3, settle=1) is False
-    env.enable_cost_schedule()
-    kept = env.tune_launch(lambda: env.step(env.random_action()), steps=3, settle=1)
-    assert kept in (True, False) and kept == env._fused
-    out = env.step(env.random_action())
-    assert out.observation['image'].shape == (512, 64, 64, 3)
-    env.raise_faults()
-    env.close()
-
-
-def test_frames_follow_steps_refuses_what_it_does_not_cover(monkeypatch):
-    env = make_env('aa_zoo', 8, seed=1)          # anti-aliased renderer
-    assert env.enable_cost_schedule(fused=True) is False
-    env.reset()
-    env.step(env.random_action())
-    env.close()
-    # a tool that runs one kernel at a time (rocprofv3 --pmc) would leave the frames' grid waiting for a step kernel that
-    # cannot start beside it: the engine keeps the separate launches there
-    for var in ('ROCPROF_COUNTER_COLLECTION', 'MOOG_NO_FUSED'):
-        monkeypatch.setenv(var, '1')
-        env = make_env('colliding_predators_32', 64, seed=1)
-        assert env.enable_cost_schedule(fused=True) is False
-        env.reset()
-        env.step(env.random_action())
-        env.close()
-        monkeypatch.delenv(var)
-
-
-def test_frames_follow_steps_degrades_instead_of_faulting(monkeypatch):
-    """The mode needs the step kernel to run beside the frames' grid.  MOOG_FUSED_FORCE_SERIAL=1 puts the grid IN FRONT of
-    the step kernel on the same stream -- what a tool that serialises kernels does: the grid cannot see a finished env, gives
-    up without drawing, the fallback launch behind the step kernel draws the batch, and the engine leaves the mode at the
-    next call.  Frames and states equal the separate launches' in every call, nothing raises, the runtime's own
-    serialisation switches are refused up front."""
-    import torch
-    n = 256
-    ref = make_env('colliding_predators_32', n, seed=9)
-    ref.reset()
-    monkeypatch.setenv('MOOG_FUSED_FORCE_SERIAL', '1')
-    env = make_env('colliding_predators_32', n, seed=9)
-    assert env.enable_cost_schedule(fused=True) is True
-    env.reset()
-    assert env.fused is True
-    rs = np.random.RandomState(1)
-    for k in range(6):
-        a = rs.uniform(-1, 1, size=(n, 2))
-        i0 = ref.step(a).observation['image'].cpu().numpy()
-        i1 = env.step(a).observation['image'].cpu().numpy()
-        assert np.array_equal(i0, i1), 'frames of call %d differ' % k
-        if k >= 1:
-            assert env.fused is False   # (the first call's grid gave up: seen by the next call at the latest)
-    f0, q0 = download(ref)
-    f1, q1 = download(env)
-    assert np.array_equal(q0, q1) and np.array_equal(f0, f1, equal_nan=True)
-    env.raise_faults()
-    env.close()
-    monkeypatch.delenv('MOOG_FUSED_FORCE_SERIAL')
-    for var, val in (('AMD_SERIALIZE_KERNEL', '3'), ('HIP_LAUNCH_BLOCKING', '1'), ('GPU_MAX_HW_QUEUES', '1')):
-        monkeypatch.setenv(var, val)
-        e2 = make_env('colliding_predators_32', 64, seed=1)
-        assert e2.enable_cost_schedule(fused=True) is False
-        e2.close()
-        monkeypatch.delenv(var)
-
-
-@pytest.mark.parametrize('name', ['colliding_predators_32', 'functional_maze', 'chase_avoid_torus'])
-def test_frames_follow_steps_self_check(name, monkeypatch):
-    """MOOG_FUSED_SELFCHECK=N: every N-th call's frames are drawn again by the ordinary launch and compared on the device; a
-    difference raises MOOG_FAULT_FRAME_MISMATCH.  Programs whose rules write colours / Portal bits straight to HBM take part:
-    the step kernel derives the L2 write-back from the writers themselves (COL_SET ... in moog_device.h)."""
-    monkeypatch.setenv('MOOG_FUSED_SELFCHECK', '2')
-    n = 1024
-    env = make_env(name, n, seed=4)
-    if env.enable_cost_schedule(fused=True) is not True:
-        pytest.skip('the program does not take the mode')
-    env.reset()
-    for k in range(40):
-        env.step(env.random_action())
-    import torch
-    torch.cuda.synchronize()
-    env.raise_faults()
-    env._poll_faults()
-    env.close()
 
 
 def _simulation_env():
@@ -1743,36 +1607,32 @@ def test_anti_aliasing_sweep(size, aa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['list', 'wave'])
-@pytest.mark.parametrize('name,rows,edge_rounds', [
-    ('colliding_predators_32', None, None), ('colliding_predators_32', 64, None), ('colliding_predators_32', None, 1),
-    ('colliding_predators_32', 64, 1), ('pong', None, None), ('colliding_predators', None, None),
-    ('falling_balls', None, 1), ('rules_zoo', 64, None), ('lambda_zoo', None, None)])
-def test_draw_list_rasterisers_match_the_record_rasteriser(name, rows, edge_rounds, mode, monkeypatch):
-    """Programs with one-tile frames, no polygon modifier, <= 64 slots and <= 32 vertices per sprite are drawn from DRAW
-    LISTS (live vertices as packed integer canvas points, emitted by the step kernel when it stores the record; built by
-    moog_drawlist_kernel for frames of uploaded state / after a reset): by the workgroup rasteriser ('list', the default)
-    or by the wave rasteriser ('wave', MOOG_RASTER_WAVE=1: two wavefronts per frame).  MOOG_RASTER_DL=0 selects the
-    rasteriser that reads the f64 records.  All three must give the same frames, bit for bit -- frames that come with a
-    step, frames of uploaded state, frames after resets -- also when the row / edge records are capped so that frames
-    take several passes."""
-    import torch
+@pytest.mark.parametrize('name,rows', [
+    ('colliding_predators_32', None), ('colliding_predators_32', 64), ('pong', None), ('colliding_predators', None),
+    ('falling_balls', 40), ('falling_balls_64', None), ('rules_zoo', 64), ('lambda_zoo', None), ('functional_maze', None),
+    ('functional_maze', 128), ('cleanup', None), ('match_to_sample_l3', None), ('predators_arena_l2', None),
+    ('parallelogram_catch', None), ('multi_tracking_with_feature_l1', None)])
+def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
+    """One-tile frames of polygons with <= 32 vertices are drawn by the mask rasteriser (csrc/moog_raster_mask_core.h: no
+    crossing lists, census by bit mask); MOOG_RASTER_MASK=0 selects the push / sort / span kernel for every frame.  Both
+    must give the same frames, bit for bit -- frames that come with a step, frames of uploaded state, frames after resets
+    -- also when the row records are capped so that frames take several passes."""
     n = 192
-    monkeypatch.setenv('MOOG_RASTER_DL', '0')
+    monkeypatch.setenv('MOOG_RASTER_MASK', '0')
     ref = make_env(name, n, seed=31, env_index0=17)
-    monkeypatch.setenv('MOOG_RASTER_DL', '1')
-    monkeypatch.setenv('MOOG_RASTER_WAVE', '1' if mode == 'wave' else '0')
+    assert ref.raster_path() == 'spans'
+    monkeypatch.setenv('MOOG_RASTER_MASK', '1')
     if rows is not None:
         monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
-    if edge_rounds is not None:
-        monkeypatch.setenv('MOOG_WAVE_EDGE_ROUNDS', str(edge_rounds))
     env = make_env(name, n, seed=31, env_index0=17)
+    if env.raster_path() != 'mask':
+        pytest.skip('the program keeps the span kernel (multi-tile frames, polygons with more than 32 vertices)')
     a0 = ref.reset().observation['image'].cpu().numpy()
     a1 = env.reset().observation['image'].cpu().numpy()
     assert np.array_equal(a0, a1), 'frames of the reset differ'
     rs = np.random.RandomState(4)
     for k in range(14):
-        a = rs.randint(0, 5, size=n) if env._is_grid else rs.uniform(-1, 1, size=(n, 2))
+        a = env.random_action()
         i0 = ref.step(a).observation['image'].cpu().numpy()
         i1 = env.step(a).observation['image'].cpu().numpy()
         bad = np.nonzero((i0 != i1).reshape(n, -1).any(axis=1))[0]
@@ -1782,6 +1642,17 @@ def test_draw_list_rasterisers_match_the_record_rasteriser(name, rows, edge_roun
         assert np.array_equal(q0, q1) and np.array_equal(f0, f1, equal_nan=True)
         o1 = env.observation()['image'].cpu().numpy()   # the same frame from the records
         assert np.array_equal(o1, i1), 'frame from the records differs from the frame of the step'
+
+
+def test_raster_path_by_program():
+    """Which rasteriser a program's frames take (moog_engine_raster_path): the mask rasteriser for one-tile frames of
+    polygons with <= 32 vertices; multi-tile frames (pacman 256 x 256), nine-copy frames (torus) and polygons with more
+    vertices keep the span kernel."""
+    for name, want in (('colliding_predators_32', 'mask'), ('functional_maze', 'mask'), ('falling_balls_64', 'mask'),
+                       ('pacman', 'spans'), ('chase_avoid_torus', 'spans'), ('first_person_predators_prey', 'spans')):
+        env = make_env(name, 4, seed=1)
+        assert env.raster_path() == want, name
+        env.close()
 
 
 @pytest.mark.gpu
