@@ -1072,7 +1072,10 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
         elif isinstance(r, rules_lib.VanishByFilter):
             R.kind = _abi.MOOG_RULE_VANISH_BY_FILTER
             R.l0 = layer_index(r._layer)
-            R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
+            if getattr(r, '_traced_filter', None) is not None:   # (a config-local Vanish subclass: expand_local_rule)
+                R.filter, fnode = _abi.MOOG_FILTER_EXPR, r._traced_filter
+            else:
+                R.filter, fnode = rules_lib._classify_filter(r._filter_fn)
             if fnode is not None:
                 R.xfilter, R.filter = put_filter(fnode, [r._layer])
         elif isinstance(r, rules_lib.ChangeLayer):

@@ -894,6 +894,55 @@ def trace_state_fixed(fn, with_meta=False):
         forced = [v for _, v in trail[:k]] + [False]
 
 
+def trace_index_filter(fn, layer):
+    """The per-sprite predicate of `fn(state) -> indices into state[layer]` when that is a filter over the layer's own
+    sprites, `[i for i, s in enumerate(state[layer]) if pred(s)]` (a config-local subclass of game_rules.Vanish,
+    vanish.py:9-39).  Traced over two representative sprites: sprite 0 is in the result exactly where the predicate holds
+    for it, and sprite 1's membership must be the same expression with the sprites exchanged (checked on random values
+    of the leaves) -- indices that depend on the other sprites, on other layers or on the list's order are refused."""
+    global _TRACER
+    paths, forced, uses = [], [], []
+    while True:
+        tr = _Tracer()
+        tr.forced = list(forced)
+        st = _SymState(2)
+        prev, _TRACER = _TRACER, tr
+        try:
+            ret = fn(st)
+            ret = [int(i) for i in ret]
+        finally:
+            _TRACER = prev
+        for u in st.uses:
+            if u not in uses:
+                uses.append(u)
+        if any(i not in (0, 1) for i in ret) or sorted(set(ret)) != ret:
+            raise Unsupported('_get_vanish_inds must return increasing indices of the layer\'s sprites')
+        paths.append((list(tr.trail), ret, []))
+        if len(paths) > MAX_PATHS:
+            raise Unsupported('too many execution paths in _get_vanish_inds')
+        trail = tr.trail
+        k = len(trail) - 1
+        while k >= 0 and trail[k][1] is False:
+            k -= 1
+        if k < 0:
+            break
+        forced = [v for _, v in trail[:k]] + [False]
+    if uses != [('quant', layer)]:
+        raise Unsupported('_get_vanish_inds must iterate over its own layer and nothing else (it used %s)' % (uses,))
+    n0 = _merge(paths, lambda p: lift(float(0 in p[1])))
+    n1 = _merge(paths, lambda p: lift(float(1 in p[1])))
+    rs = np.random.RandomState(0)
+    for _ in range(256):
+        env = _RandomLeaves(rs)
+        if _evaluate(n1, env) != _evaluate(_substitute(_substitute(_substitute(n0, 0, 2), 1, 0), 2, 1), env):
+            raise Unsupported('_get_vanish_inds is not a per-sprite filter of its layer')
+    seen = set()
+    _sprites_of(n0, seen)
+    if 1 in seen:
+        raise Unsupported('_get_vanish_inds: whether a sprite vanishes depends on another sprite of the layer')
+    return n0
+
+
 def _substitute(node, old, new):
     if node.op == 'attr':
         return Node('attr', new if node.args[0] == old else node.args[0], node.args[1])

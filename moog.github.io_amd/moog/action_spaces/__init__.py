@@ -92,3 +92,18 @@ class Composite(AbstractActionSpace):
     @property
     def action_keys(self):
         return list(self._action_keys)
+
+def _submodules(**modules):
+    """The reference keeps one class per file (`from moog.physics import collisions`, `moog.game_rules.vanish.Vanish`);
+    here a package is one file, and those module paths are aliases that hold the same objects."""
+    import sys
+    import types
+    for name, names in modules.items():
+        m = types.ModuleType(__name__ + '.' + name)
+        m.__doc__ = 'Alias module: the reference\'s moog/%s/%s.py (names defined in %s).' % (__name__.split('.')[-1], name, __name__)
+        for n in names:
+            setattr(m, n, globals()[n])
+        sys.modules[m.__name__] = m
+        globals()[name] = m
+
+_submodules(abstract_action_space=('AbstractActionSpace',), composite=('Composite',), grid=('Grid',), joystick=('Joystick',), set_position=('SetPosition',))

@@ -44,6 +44,21 @@ class ModifyMetaState(AbstractRule):
         self._meta_state_modifier(meta_state)
 
 
+class UpdateMetaStateValue(AbstractRule):
+    """modify_meta_state.py:28-48: meta_state[key] = value every step it runs (typically a one-time rule of a Phase).
+    Host side, like ModifyMetaState."""
+
+    host_side = True
+
+    def __init__(self, key, value):
+        self._key = key
+        self._value = value
+
+    def step(self, state, meta_state):
+        del state
+        meta_state[self._key] = self._value
+
+
 class _ProbeSprite(object):
     def __init__(self, pos):
         self.position = np.array(pos, dtype=float)
@@ -123,6 +138,18 @@ def expand_local_rule(r):
              Phase, PhaseSequence, TimedRule, ConditionalRule, ModifySprites, Portal, _RuleDraws, _ModifyTraced)
     if isinstance(r, known) or lookup_lowering(r) is not None or getattr(r, 'host_side', False):
         return [r]
+    if isinstance(r, Vanish) and type(r).step is Vanish.step:
+        # a config-local vanishing rule (vanish.py:9-39): its index function, traced, is a filter over the layer
+        if getattr(r, '_moog_expanded', None) is None:
+            from .. import _symbolic
+            try:
+                node = _symbolic.trace_index_filter(r._get_vanish_inds, r._layer)
+            except _symbolic.Unsupported as e:
+                raise NotImplementedError('rule %s: %s' % (type(r).__name__, e))
+            low = VanishByFilter(r._layer)
+            low._traced_filter = node
+            r._moog_expanded = [low]
+        return r._moog_expanded
     if getattr(r, '_moog_expanded', None) is not None:
         return r._moog_expanded
     r._moog_expanded = _expand(r)
@@ -182,6 +209,24 @@ def _classify_filter(filter_fn):
         pass
     from .. import _symbolic
     return _abi.MOOG_FILTER_EXPR, _symbolic.trace_value(filter_fn, 1)
+
+
+class Vanish(AbstractRule):
+    """vanish.py:9-39, the base of the vanishing rules: a subclass names the sprites of `layer` to remove through
+    `_get_vanish_inds(state)`.  On the device sprites are named by a filter over their own attributes, so a config-local
+    subclass is lowered when its `_get_vanish_inds` is the reference's own pattern -- the indices of the sprites of the
+    layer that pass a test (`[i for i, s in enumerate(state[layer]) if test(s)]`): it is traced once over a probe layer
+    (game_rules.expand_local_rule) into a VanishByFilter.  Anything else (indices that depend on other layers, on the
+    order of the list) is refused at construction of the environment with the reason."""
+
+    def __init__(self, layer):
+        self._layer = layer
+
+    def _get_vanish_inds(self, state):
+        raise NotImplementedError
+
+    def step(self, state, meta_state):
+        raise RuntimeError('game rules are stepped by the engine, not on the host')
 
 
 class VanishByFilter(AbstractRule):
@@ -388,6 +433,16 @@ def get_contact_counter(layer_0, layer_1):
     return _ContactCounter(layer_0, layer_1)
 
 
+class _ContactIndices(_ContactCounter):
+    """contact_rules.get_contact_indices (:15-37): `state -> [(i_0, i_1), ...]`.  As a ConditionalRule condition only its
+    truth value matters (an empty list is false), which is the contact counter's: lowered the same way.  The list
+    itself exists on the device only (RawState observers read sprites, not index pairs)."""
+
+
+def get_contact_indices(layer_0, layer_1):
+    return _ContactIndices(layer_0, layer_1)
+
+
 class _BinomialProbe(object):
     def __init__(self, n, p):
         self.n, self.p = n, p
@@ -462,3 +517,18 @@ def _lower_booster(rule, layer_index):
 
 
 register_lowering('Booster', _lower_booster)
+
+def _submodules(**modules):
+    """The reference keeps one class per file (`from moog.physics import collisions`, `moog.game_rules.vanish.Vanish`);
+    here a package is one file, and those module paths are aliases that hold the same objects."""
+    import sys
+    import types
+    for name, names in modules.items():
+        m = types.ModuleType(__name__ + '.' + name)
+        m.__doc__ = 'Alias module: the reference\'s moog/%s/%s.py (names defined in %s).' % (__name__.split('.')[-1], name, __name__)
+        for n in names:
+            setattr(m, n, globals()[n])
+        sys.modules[m.__name__] = m
+        globals()[name] = m
+
+_submodules(abstract_rule=('AbstractRule',), change_layer=('ChangeLayer',), conditional=('ConditionalRule',), contact_rules=('get_contact_counter', 'get_contact_indices', 'ModifyOnContact'), create_sprites=('CreateSprites',), fixation=('Fixation',), modify_meta_state=('ModifyMetaState', 'UpdateMetaStateValue'), modify_sprites=('ModifySprites',), portal=('Portal',), re_center=('KeepNearCenter',), task_phases=('Phase', 'PhaseSequence'), timing=('DelayedRule', 'TemporaryRule', 'TimedRule'), vanish=('Vanish', 'VanishByFilter', 'VanishOnContact'))

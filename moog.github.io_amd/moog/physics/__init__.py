@@ -213,3 +213,18 @@ class Physics(AbstractPhysics):
         if not isinstance(corrective_physics, (list, tuple)):
             corrective_physics = [corrective_physics]
         self._corrective_physics = list(corrective_physics)
+
+def _submodules(**modules):
+    """The reference keeps one class per file (`from moog.physics import collisions`, `moog.game_rules.vanish.Vanish`);
+    here a package is one file, and those module paths are aliases that hold the same objects."""
+    import sys
+    import types
+    for name, names in modules.items():
+        m = types.ModuleType(__name__ + '.' + name)
+        m.__doc__ = 'Alias module: the reference\'s moog/%s/%s.py (names defined in %s).' % (__name__.split('.')[-1], name, __name__)
+        for n in names:
+            setattr(m, n, globals()[n])
+        sys.modules[m.__name__] = m
+        globals()[name] = m
+
+_submodules(abstract_force=('AbstractForce', 'AbstractNewtonianForce'), abstract_physics=('AbstractPhysics',), collisions=('Collision',), constant_speed=('ConstantSpeed',), distance_fn_force=('DistanceForce', 'linear_force_fn', 'spring_force_fn'), friction=('Drag', 'KineticFriction'), gravity=('DownGravity', 'Gravity'), maze_walk=('DeterministicMazeWalk', 'RandomMazeWalk'), maze_physics=('MazePhysics',), physics=('Physics',), random_force=('RandomForce',), tether_physics=('Tether', 'TetherZippedLayers'))

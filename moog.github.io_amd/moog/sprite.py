@@ -221,3 +221,57 @@ def shape_record(raw):
                         (0.0 * path[:, 0] + 1.0 * path[:, 1]) + neg[1]], axis=1)
     inertia -= area * np.square(centroid)
     return centred, centroid, inertia / area
+
+
+# ---- module functions of the reference's sprite.py (config-time, host side) ------------------------------------------
+_EPSILON_INTERPOLATION = 1e-8   # sprite.py:35
+
+
+def update_sprite(sprite, **factors):
+    """sprite.update_sprite (sprite.py:51-105) for a sprite RECIPE: the new factors replace the recipe's (the engine
+    builds the live sprite from them, so "without resetting the shape unless necessary" has nothing to save here).
+    What a recipe cannot carry (a factor of a sprite that is already live on the device) is refused by
+    Sprite.__setattr__ with the reason."""
+    unknown = set(factors) - set(FACTOR_NAMES)
+    if unknown:
+        raise TypeError('unknown sprite factors: %s' % sorted(unknown))
+    for k, v in factors.items():
+        if k == 'shape':
+            sprite.factors['shape'] = sprite._adopt({'shape': v})['shape']
+        else:
+            setattr(sprite, k, v)
+
+
+def _cross_2d(a, b):
+    return a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+
+
+def segment_crossing_coefficients(start_0, end_0, start_1, end_1):
+    """sprite.py:108-164: for every pair of a segment of set 0 ([N, 2] starts / ends) and one of set 1 ([M, 2]) the
+    coefficients A, B of start_0 + A * delta_0 = start_1 + B * delta_1 (both [N, M]); the denominator carries the
+    reference's 1e-8 so that parallel segments do not divide by zero.  Host numpy (the engine's collision code has its
+    own restatement in csrc/moog_device.h)."""
+    start_0, end_0 = np.asarray(start_0, float), np.asarray(end_0, float)
+    start_1, end_1 = np.asarray(start_1, float), np.asarray(end_1, float)
+    d0 = (end_0 - start_0)[:, None]
+    d1 = (end_1 - start_1)[None]
+    rel = start_1[None] - start_0[:, None]
+    den = _cross_2d(d0, d1) + _EPSILON_INTERPOLATION
+    return _cross_2d(rel, d1) / den, _cross_2d(rel, d0) / den
+
+
+def segment_crossings(start_0, end_0, start_1, end_1):
+    """sprite.py:166-199: the crossing points ([K, 2]) of all pairs of segments whose A and B lie strictly inside
+    (0, 1), and their segment indices ([K, 2])."""
+    start_0, end_0 = np.asarray(start_0, float), np.asarray(end_0, float)
+    A, B = segment_crossing_coefficients(start_0, end_0, start_1, end_1)
+    inds = np.argwhere((A > 0) & (A < 1) & (B > 0) & (B < 1))
+    pts = np.array([start_0[i] + A[i, j] * (end_0[i] - start_0[i]) for i, j in inds])
+    return pts, inds
+
+
+def sprite_edge_crossings(sprite_0, sprite_1):
+    """sprite.py:202-224, for anything with closed `path.vertices` (first vertex repeated at the end) -- the reference's
+    live sprites; a recipe has no path (Sprite.__getattr__ says so)."""
+    v0, v1 = np.asarray(sprite_0.path.vertices, float), np.asarray(sprite_1.path.vertices, float)
+    return segment_crossings(v0[:-1], v0[1:], v1[:-1], v1[1:])

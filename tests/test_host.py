@@ -476,3 +476,114 @@ def test_a_generator_called_twice_is_not_a_restart():
         return collections.OrderedDict([('a', got)])
     tr, state = _compiler._trace_initializer(init_again)
     assert len(tr.ops) == 1 and tr.ops[0].restart_if_short
+
+
+REFERENCE_EXPORTS = {   # the `from .x import Y` lists of the reference's five component packages (moog/*/__init__.py)
+    'game_rules': ['AbstractRule', 'ChangeLayer', 'ConditionalRule', 'get_contact_counter', 'get_contact_indices',
+                   'ModifyOnContact', 'CreateSprites', 'Fixation', 'ModifyMetaState', 'UpdateMetaStateValue', 'ModifySprites',
+                   'Portal', 'KeepNearCenter', 'Phase', 'PhaseSequence', 'DelayedRule', 'TemporaryRule', 'TimedRule', 'Vanish',
+                   'VanishByFilter', 'VanishOnContact'],
+    'physics': ['AbstractForce', 'AbstractNewtonianForce', 'AbstractPhysics', 'Collision', 'ConstantSpeed', 'DistanceForce',
+                'linear_force_fn', 'spring_force_fn', 'Drag', 'KineticFriction', 'DownGravity', 'Gravity',
+                'DeterministicMazeWalk', 'RandomMazeWalk', 'MazePhysics', 'Physics', 'RandomForce', 'Tether',
+                'TetherZippedLayers'],
+    'observers': ['AbstractObserver', 'PILRenderer', 'RawState', 'polygon_modifiers'],
+    'action_spaces': ['AbstractActionSpace', 'Composite', 'Grid', 'Joystick', 'SetPosition'],
+    'tasks': ['AbstractTask', 'CompositeTask', 'ContactReward', 'Reset', 'StayAlive'],
+    'env_wrappers': ['AbstractEnvironmentWrapper', 'LoggingEnvironment', 'MultiAgentEnvironment', 'SimulationEnvironment'],
+    'maze_lib': ['Maze', 'generate_random_maze_matrix', 'get_connected_open_blob'],
+}
+
+
+def test_reference_import_surface():
+    """Every name the reference's packages export exists under the same name, and so do the module paths its own tests
+    and configs import (tests/moog/**: `from moog.physics import collisions`, `from moog.observers import pil_renderer`,
+    `from moog.env_wrappers import simulation / gym_wrapper`, `moog.game_rules.vanish.Vanish`, the sprite module's
+    functions).  When /root/reference is there the lists are read from its __init__ files instead of the table above."""
+    import importlib
+    import re
+    exports = {k: list(v) for k, v in REFERENCE_EXPORTS.items()}
+    ref = '/root/reference/moog'
+    if os.path.isdir(ref):
+        for pkg in exports:
+            with open(os.path.join(ref, pkg, '__init__.py')) as f:
+                found = re.findall(r'^from \.\S* import (\w+)', f.read(), flags=re.M)
+            assert sorted(found) == sorted(exports[pkg]), pkg
+    for pkg, names in exports.items():
+        m = importlib.import_module('moog.' + pkg)
+        for n in names:
+            assert hasattr(m, n), 'moog.%s.%s' % (pkg, n)
+    for path, attr in (('moog.physics.collisions', 'Collision'), ('moog.observers.pil_renderer', 'PILRenderer'),
+                       ('moog.observers.polygon_modifiers', 'TorusGeometry'), ('moog.observers.color_maps', 'hsv_to_rgb'),
+                       ('moog.env_wrappers.simulation', 'SimulationEnvironment'), ('moog.env_wrappers.gym_wrapper', 'GymWrapper'),
+                       ('moog.game_rules.vanish', 'Vanish'), ('moog.game_rules.contact_rules', 'get_contact_indices'),
+                       ('moog.game_rules.modify_meta_state', 'UpdateMetaStateValue'), ('moog.game_rules.timing', 'TimedRule'),
+                       ('moog.physics.tether_physics', 'Tether'), ('moog.tasks.contact_reward', 'ContactReward'),
+                       ('moog.action_spaces.joystick', 'Joystick'), ('moog.observers.abstract_observer', 'AbstractObserver'),
+                       ('moog.state_initialization.distributions', 'Continuous'),
+                       ('moog.state_initialization.sprite_generators', 'generate_sprites'),
+                       ('moog.sprite', 'update_sprite'), ('moog.sprite', 'segment_crossing_coefficients'),
+                       ('moog.sprite', 'segment_crossings'), ('moog.sprite', 'sprite_edge_crossings'), ('moog.shapes', 'border_walls')):
+        assert hasattr(importlib.import_module(path), attr), '%s.%s' % (path, attr)
+    from moog.physics import collisions   # noqa: F401  (the statement itself, as tests/moog/physics/test_collisions.py:28 has it)
+    from moog import game_rules
+    assert game_rules.vanish.Vanish is game_rules.Vanish
+
+
+def test_segment_helpers_and_update_sprite():
+    """The sprite module's functions (sprite.py:51-224), host numpy: crossing coefficients of two segment sets with the
+    reference's 1e-8 in the denominator; update_sprite replaces factors of a recipe."""
+    from moog import sprite
+    s0, e0 = np.array([[0., 0.], [0., 1.]]), np.array([[1., 1.], [1., 1.]])
+    s1, e1 = np.array([[0., 1.], [5., 5.]]), np.array([[1., 0.], [6., 5.]])
+    A, B = sprite.segment_crossing_coefficients(s0, e0, s1, e1)
+    assert A.shape == (2, 2) and abs(A[0, 0] - 0.5) < 1e-7 and abs(B[0, 0] - 0.5) < 1e-7
+    pts, inds = sprite.segment_crossings(s0, e0, s1, e1)
+    assert inds.tolist() == [[0, 0]] and np.allclose(pts, [[0.5, 0.5]], atol=1e-7)
+
+    class Live(object):   # what the reference passes: anything with a closed path
+        def __init__(self, v):
+            self.path = type('P', (), {'vertices': np.concatenate([v, v[:1]])})
+    sq = np.array([[0., 0.], [1., 0.], [1., 1.], [0., 1.]])
+    pts, inds = sprite.sprite_edge_crossings(Live(sq), Live(sq + 0.5))
+    assert sorted(map(tuple, np.round(pts, 6).tolist())) == [(0.5, 1.0), (1.0, 0.5)]
+    sp = sprite.Sprite(x=0.2, y=0.3, c0=10)
+    sprite.update_sprite(sp, x=0.7, c0=99, shape='triangle')
+    assert sp.factors['x'] == 0.7 and sp.factors['c0'] == 99 and sp.factors['shape'] == 'triangle'
+    with pytest.raises(TypeError):
+        sprite.update_sprite(sp, colour=1)
+
+
+def test_config_local_vanish_and_meta_state_value():
+    """A config that subclasses game_rules.Vanish (vanish.py:9-39) with the reference's own pattern -- the indices of the
+    layer's sprites that pass a test -- lowers to the device's filtered vanish; index functions that are not a per-sprite
+    filter are refused with the reason.  UpdateMetaStateValue (modify_meta_state.py:28-48) is a host-side rule."""
+    import collections
+    from moog import action_spaces, game_rules, observers, physics as physics_lib, sprite, tasks
+
+    class VanishLeft(game_rules.Vanish):
+        def _get_vanish_inds(self, state):
+            return [i for i, s in enumerate(state[self._layer]) if s.x < 0.25]
+
+    class VanishFirstTwo(game_rules.Vanish):
+        def _get_vanish_inds(self, state):
+            return [i for i, _ in enumerate(state[self._layer])][:1]
+
+    def config(rule):
+        return dict(
+            state_initializer=lambda: collections.OrderedDict(
+                [('prey', [sprite.Sprite(x=0.1 + 0.2 * k, y=0.5, scale=0.05, c0=128) for k in range(4)]),
+                 ('agent', [sprite.Sprite(x=0.5, y=0.2, scale=0.1)])]),
+            physics=physics_lib.Physics(), task=tasks.ContactReward(1., 'agent', 'prey'),
+            action_space=action_spaces.Grid(0.1, action_layers='agent', control_velocity=True),
+            observers={'image': observers.PILRenderer(image_size=(64, 64))},
+            game_rules=(rule, game_rules.UpdateMetaStateValue('phase', 'go')), meta_state_initializer=lambda: {'phase': ''})
+
+    c = _compiler.compile_config(**config(VanishLeft('prey')))
+    P = c.program
+    assert P.n_rules == 1 and P.rules[0].kind == _abi.MOOG_RULE_VANISH_BY_FILTER and P.rules[0].filter == _abi.MOOG_FILTER_EXPR
+    m = {'phase': ''}
+    game_rules.UpdateMetaStateValue('phase', 'go').step(None, m)
+    assert m == {'phase': 'go'}
+    with pytest.raises(NotImplementedError):
+        _compiler.compile_config(**config(VanishFirstTwo('prey')))
