@@ -239,6 +239,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
+    ap.add_argument('--total-envs', type=int, default=0,
+                    help='strong scaling: this many envs in all, split over the ranks (shard_range); overrides --envs-per-gpu')
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
@@ -290,8 +292,11 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    n = args.envs_per_gpu
-    index0 = sharding.shard_range(n * world, rank, world)[0]
+    if args.total_envs > 0:   # strong scaling: a fixed batch, split as evenly as the env axis allows
+        index0, n = sharding.shard_range(args.total_envs, rank, world)
+    else:
+        n = args.envs_per_gpu
+        index0 = sharding.shard_range(n * world, rank, world)[0]
 
     G = max(1, args.sub_batches)
     if G > 1:
@@ -363,7 +368,12 @@ def main():
     dt = time.perf_counter() - t0
     env.set_timing(False)
     # MAX over ranks, off the timed path (RCCL needs the tensor on the GPU, gloo on the host)
-    dt_max = sharding.max_over_ranks(dt, device=dev if backend == 'nccl' else None)
+    rdev = dev if backend == 'nccl' else None
+    dt_max = sharding.max_over_ranks(dt, device=rdev)
+    # what the collective itself saw: ranks that took part, envs they stepped, the slowest and the fastest rank's own rate
+    ranks_seen, envs_seen = sharding.reduce_over_ranks([1.0, float(n)], 'sum', device=rdev)
+    rate_min = sharding.reduce_over_ranks([n * args.steps / dt], 'min', device=rdev)[0]
+    rate_max = sharding.reduce_over_ranks([n * args.steps / dt], 'max', device=rdev)[0]
     env.raise_faults()   # faults of the timed steps (deferred surfacing: none were skipped silently)
 
     k_ms = {'raster': env.kernel_time(_abi.MOOG_K_RASTER), 'step': env.kernel_time(_abi.MOOG_K_STEP),
@@ -383,7 +393,7 @@ def main():
         env.check_faults = True
     faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
     if rank == 0:
-        total_steps = n * world * args.steps
+        total_steps = int(envs_seen) * args.steps
         rb = raster_bytes_per_env(env)
         r_ms, r_n = k_ms['raster']
         r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
@@ -395,11 +405,13 @@ def main():
             'value': total_steps / dt_max,
             'unit': 'env steps/sec',
             'n_gpus': world,
+            'ranks_seen': int(ranks_seen),
+            'per_rank_value': {'min': rate_min, 'max': rate_max},
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': dt_max / args.steps * 1e3,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if args.total_envs > 0 else 'weak',
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
@@ -407,7 +419,7 @@ def main():
                                    'random joystick actions, auto-reset on' % (
                                        args.workload, n, P.n_slots, P.updates_per_env_step,
                                        P.render.height, P.render.width),
-                       'envs_per_gpu': n, 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
+                       'envs_per_gpu': n, 'total_envs': int(envs_seen), 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
                        'parallelism': 'env-sharded x%d, no collective' % world,
                        'launch': (('%d asynchronous sub-batches of %d envs, one HIP stream each: step -> frames -> next step '
                                    'chained per sub-batch, no whole-batch barrier between calls (SubBatchedEnvironment.step_async)'
@@ -431,6 +443,9 @@ def main():
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.workload)
+        elif world > 1:
+            line['cpu_baseline'] = None
+            line['cpu_baseline_note'] = 'timed by the --gpus 1 run only (rank 0, N = 1)'
         print(json.dumps(line))
         sys.stdout.flush()
     if use_dist:

@@ -187,6 +187,9 @@ class BatchedEnvironment(object):
                 out[i] = rgb
             self._rgb[idx[:, 0], idx[:, 1]] = torch.as_tensor(out, device=self.device)
             self._rgb_done[idx[:, 0], idx[:, 1]] = True
+        # (a slot without a live sprite forgets what it held: the sprite that comes to life there is evaluated again even if a
+        #  host-side edit gave it the colour bits the snapshot already has)
+        self._rgb_done &= alive
         self._rgb_seen = col.clone()
 
     def _render_with_colors(self):
@@ -768,9 +771,13 @@ class SubBatchedEnvironment(object):
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
                  meta_state_initializer=None, num_envs=1, sub_batches=2, device=None, seed=0, env_index0=0,
-                 layer_capacity=None, keep_sprite_factors=False):
+                 layer_capacity=None, keep_sprite_factors=False, reset_pool='auto'):
         import torch
         self._torch = torch
+        if layer_capacity == 'auto' or (isinstance(layer_capacity, dict) and layer_capacity.get('auto')):
+            # (growing a layer re-creates the engine over new records: the sub-batches are views of ONE set of tensors)
+            raise NotImplementedError("SubBatchedEnvironment: layer_capacity='auto' is not available; pass {layer: slots} "
+                                      "(BatchedEnvironment(layer_capacity='auto').layer_usage() reports the demand)")
         if meta_state_initializer is not None or any(getattr(r, 'host_side', False) for r in game_rules):
             raise NotImplementedError('SubBatchedEnvironment: host-side meta-state rules step the whole batch on the host')
         G = int(sub_batches)
@@ -795,7 +802,7 @@ class SubBatchedEnvironment(object):
             self.parts.append(BatchedEnvironment(
                 state_initializer, physics, task, action_space, observers, game_rules, None,
                 num_envs=m, device=self.device, seed=seed, env_index0=int(env_index0) + g * m,
-                _compiled=self.compiled, _buffers=views))
+                reset_pool=reset_pool, _compiled=self.compiled, _buffers=views))
         self.physics, self.task, self.action_space = physics, task, action_space
         self.observers, self.game_rules = observers, game_rules
         self._is_grid = self.parts[0]._is_grid

@@ -260,27 +260,63 @@ class CreateSprites(AbstractRule):
 
 def _probe_randint(fn):
     """Calls fn() twice with np.random.randint replaced -- once returning its low bound, once its highest value -- and
-    returns ([(low, high) of every draw], value at the low bounds, value at the high bounds)."""
-    real = np.random.randint
-    out = []
-    for pick_high in (False, True):
-        seen = []
+    returns ([(low, high) of every draw], value at the low bounds, value at the high bounds).
 
-        def probe(low, high=None, size=None, dtype=int, _seen=seen, _hi=pick_high):
-            if high is None:
-                low, high = 0, low
-            if size is not None:
-                raise NotImplementedError('np.random.randint with a size in a rule\'s interval')
-            _seen.append((int(low), int(high)))
-            return int(high) - 1 if _hi else int(low)
-        np.random.randint = probe
-        try:
-            value = fn()
-        finally:
-            np.random.randint = real
-        out.append((seen, value))
+    The reference calls fn() at every reset (timing.py:47): a callable may only be lowered when everything random in it
+    is seen here.  So every other entry point of np.random and of the `random` module raises while fn runs, and a
+    callable that got at a generator behind the probe's back (`from numpy.random import randint`, a RandomState of its
+    own is fine only if it is deterministic) is caught by the global generators' state having moved, or by the two
+    calls disagreeing without a probed draw.  The host generators are left exactly as they were."""
+    import random as py_random
+    real = np.random.randint
+    np_state, py_state = np.random.get_state(), py_random.getstate()
+
+    def refuse(name):
+        def _refuse(*args, **kwargs):
+            raise NotImplementedError('a rule interval that draws from %s is not lowered (np.random.randint is)' % name)
+        return _refuse
+    np_names = [n for n in ('rand', 'randn', 'random', 'random_sample', 'ranf', 'sample', 'uniform', 'normal', 'choice',
+                            'permutation', 'shuffle', 'random_integers', 'binomial', 'poisson', 'exponential', 'beta',
+                            'gamma', 'geometric', 'triangular', 'standard_normal', 'bytes') if hasattr(np.random, n)]
+    py_names = [n for n in ('random', 'uniform', 'randint', 'randrange', 'choice', 'choices', 'sample', 'shuffle', 'gauss',
+                            'normalvariate', 'triangular', 'betavariate', 'expovariate', 'getrandbits') if hasattr(py_random, n)]
+    saved = [(np.random, n, getattr(np.random, n)) for n in np_names] + [(py_random, n, getattr(py_random, n)) for n in py_names]
+    out = []
+    try:
+        for mod, n, _ in saved:
+            setattr(mod, n, refuse(('np.random.' if mod is np.random else 'random.') + n))
+        for pick_high in (False, True):
+            seen = []
+
+            def probe(low, high=None, size=None, dtype=int, _seen=seen, _hi=pick_high):
+                if high is None:
+                    low, high = 0, low
+                if size is not None:
+                    raise NotImplementedError('np.random.randint with a size in a rule\'s interval')
+                _seen.append((int(low), int(high)))
+                return int(high) - 1 if _hi else int(low)
+            np.random.randint = probe
+            try:
+                value = fn()
+            finally:
+                np.random.randint = real
+            out.append((seen, value))
+    finally:
+        for mod, n, f in saved:
+            setattr(mod, n, f)
+        moved = (not all(np.array_equal(a, b) for a, b in zip(np_state, np.random.get_state()))) or py_state != py_random.getstate()
+        np.random.set_state(np_state)
+        py_random.setstate(py_state)
+    if moved:
+        raise NotImplementedError('a rule interval that draws from the host\'s random generators other than through '
+                                  'np.random.randint is not lowered')
     if out[0][0] != out[1][0]:
         raise NotImplementedError('a rule interval whose draws depend on each other')
+    if not out[0][0]:
+        v0, v1 = np.asarray(out[0][1], float), np.asarray(out[1][1], float)
+        if v0.shape != v1.shape or not np.array_equal(v0, v1):
+            raise NotImplementedError('a rule interval that changes from call to call without an np.random.randint draw '
+                                      'is not lowered')
     return out[0][0], out[0][1], out[1][1]
 
 

@@ -29,6 +29,19 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def reduce_over_ranks(values, op='sum', device=None):
+    """SUM / MIN / MAX all-reduce of a list of Python floats over the default process group; identity when there is
+    none.  The benchmark's bookkeeping (ranks that really took part, slowest / fastest rank) -- never the data path."""
+    import torch
+    import torch.distributed as dist
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return vals
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op={'sum': dist.ReduceOp.SUM, 'min': dist.ReduceOp.MIN, 'max': dist.ReduceOp.MAX}[op])
+    return [float(x) for x in t.tolist()]
+
+
 class MultiDeviceEnvironment(object):
     """One process driving several GPUs: one engine handle + stream per device,
     each owning a contiguous env block.  Outputs stay device-local (lists of

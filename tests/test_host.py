@@ -587,3 +587,24 @@ def test_config_local_vanish_and_meta_state_value():
     assert m == {'phase': 'go'}
     with pytest.raises(NotImplementedError):
         _compiler.compile_config(**config(VanishFirstTwo('prey')))
+
+
+def test_rule_interval_probe_sees_every_draw():
+    """A callable interval of a TimedRule family rule is redrawn at every reset by the reference (timing.py:47): it is
+    lowered when its randomness is ONE np.random.randint draw, kept when it is a constant, and refused when it draws any
+    other way (np.random.uniform / choice, the `random` module, a randint imported by name) -- never frozen at the value
+    of the probe call.  The host's generators are left untouched by the probe."""
+    import random as py_random
+    from numpy.random import randint as captured
+    from moog import game_rules as gr
+    np.random.seed(3)
+    py_random.seed(3)
+    before = (np.random.get_state()[1].copy(), py_random.getstate())
+    assert gr.DelayedRule(lambda: np.random.randint(10, 100), [])._random == (1, 10.0, np.inf, 100.0)
+    assert gr.TemporaryRule(lambda: np.random.randint(5, 9), [])._random == (2, 0.0, 5.0, 9.0)
+    assert gr.DelayedRule(lambda: 7, [])._step_interval == (7.0, np.inf)
+    for fn in (lambda: int(np.random.uniform(10, 100)), lambda: np.random.choice([3, 5]), lambda: py_random.randint(1, 5),
+               lambda: captured(10, 100), lambda: np.random.randint(0, 3) + np.random.randint(0, 3)):
+        with pytest.raises(NotImplementedError):
+            gr.DelayedRule(fn, [])
+    assert np.array_equal(before[0], np.random.get_state()[1]) and before[1] == py_random.getstate()
