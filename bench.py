@@ -247,6 +247,8 @@ def main():
     ap.add_argument('--no-fused', action='store_true', help='(accepted and ignored: the launch structure it switched off was retired with ABI 30)')
     ap.add_argument('--lockstep', action='store_true', help='keep the episodes of the batch synchronous')
     ap.add_argument('--no-extras', action='store_true', help='skip the strict-fault-check comparison window')
+    ap.add_argument('--no-spec', action='store_true',
+                    help='step with the generic kernels even if one specialised for the program exists (moog/_spec.py)')
     ap.add_argument('--sub-batches', type=int, default=1,
                     help='G > 1: the batch is stepped as G asynchronous sub-batches, one HIP stream each '
                          '(moog.environment.SubBatchedEnvironment): an ADDITIONAL line, the synchronous whole-batch '
@@ -265,6 +267,8 @@ def main():
     # reported in the JSON line -- the engine library leaves the variable alone.
     if args.sub_batches > 1:
         os.environ.setdefault('GPU_MAX_HW_QUEUES', str(max(4, 2 * args.sub_batches)))
+    if args.no_spec:
+        os.environ['MOOG_STEP_SPEC'] = '0'
     import torch
     import torch.distributed as dist
     from moog import _abi, environment, sharding
@@ -306,6 +310,17 @@ def main():
             **example_configs.load(args.workload))
         args.no_extras = True
     else:
+        # (the step kernel specialised for this program is built by __graft_entry__.build(); if it is not there -- another
+        #  workload, a fresh checkout -- it is compiled here, before anything is timed: ~20 s of hipcc, no GPU work)
+        spec = False
+        if not args.no_spec:
+            try:
+                from moog import _compiler, _spec
+                _spec.build(_compiler.compile_config(layer_capacity=example_configs.capacity(args.workload),
+                                                     **example_configs.load(args.workload)).program)
+                spec = True
+            except Exception as exc:   # pylint: disable=broad-except  (no hipcc on the box: the generic kernels do)
+                sys.stderr.write('bench.py: no specialised step kernel (%s)\n' % (exc,))
         env = environment.BatchedEnvironment(
             num_envs=n, device=dev, seed=2024, env_index0=index0,
             layer_capacity=example_configs.capacity(args.workload),
@@ -426,6 +441,10 @@ def main():
                                    % (G, m)) if G > 1 else 'step launch, then raster launch, on one stream'),
                        'sub_batches': G,
                        'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'runtime default (4)'),
+                       'step_kernel': ((env.parts[0] if hasattr(env, 'parts') else env).step_kernel() +
+                                       ' (moog_step_kernel compiled with the program as a constant, moog/_spec.py)'
+                                       if (env.parts[0] if hasattr(env, 'parts') else env).step_kernel() == 'specialised'
+                                       else 'generic (moog_step_kernel reading the program at run time)'),
                        'episodes': ('staggered (step_count offsets + %d burn-in steps before the warm-up)' % burn_in)
                                    if staggered else 'lockstep'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',

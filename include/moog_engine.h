@@ -624,9 +624,14 @@ typedef struct {
                        * [MOOG_MAX_MAZE_POINTS] sampled cells (i << 8 | j); -1 unless maze.random */
 } moog_layout_t;
 
-static inline int32_t moog_align_(int32_t x, int32_t a) { return (x + a - 1) / a * a; }
+#if defined(__HIPCC__)
+#define MOOG_HD __host__ __device__   /* (a program-specialised kernel computes its layout at compile time) */
+#else
+#define MOOG_HD
+#endif
+MOOG_HD static inline int32_t moog_align_(int32_t x, int32_t a) { return (x + a - 1) / a * a; }
 
-static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
+MOOG_HD static inline void moog_layout(const moog_program_t* p, moog_layout_t* L) {
   int32_t S = p->n_slots, o = 0;
   L->S = S; L->TOTV = p->n_total_verts; L->T = p->n_tasks; L->R = p->n_rules;
   L->o_pos = o; o += 2 * S;
@@ -810,6 +815,19 @@ int moog_engine_env_prefix(moog_engine_t* e, int32_t* n_slots);
  * before the frames are drawn: the same time steps and records as a reset inside the step kernel (late_reset = 1).
  * MOOG_NO_LATE_RESET=1 in the environment: such programs are stepped by variant 2 as before. */
 int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late_reset);
+
+/* Program-specialised step kernels.  The generic step kernels read the lowered config through the scalar cache and carry
+ * every component of their variant; the same source compiled with the program as a compile-time constant
+ * (csrc/moog_step_spec.hip, built ahead of time by moog/_spec.py -- `python -m moog._spec <config>` or
+ * BatchedEnvironment(specialize=True)) drops what the program does not use and folds its parameters: same arithmetic, bit-identical
+ * results, 7 % faster on the headline workload.  moog_engine_create looks for
+ *     <MOOG_SPEC_DIR, default: the directory of the engine library + "/spec">/step_<hash>_d<variant>w<wps>.so
+ * and uses it after checking ABI, variant and the embedded program byte for byte (MOOG_STEP_SPEC=0: never).
+ * moog_program_step_kernel (no device needed): the variant (0 plain, 1 + evaluator / sampler / dynamic layers, 2 + the rare
+ * components), the register-allocation variant (waves per SIMD) and the hash the file name carries (FNV-1a 64 of the
+ * program's bytes).  moog_engine_step_kernel: whether this engine steps with a specialised kernel. */
+int moog_program_step_kernel(const moog_program_t* program, int32_t* variant, int32_t* wps, uint64_t* hash);
+int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised);
 
 /* Which rasteriser draws this engine's ordinary frames (what a profile of the run names): MOOG_RASTER_MASK = the mask
  * rasteriser (csrc/moog_raster_mask_core.h: one-tile frames, polygons of <= 32 vertices, no copying polygon modifier),

@@ -20,6 +20,8 @@
 #include "moog_kernels.h"
 
 #include "moog_raster.h"
+#include <dlfcn.h>
+#include <unistd.h>
 
 // =====================================================================================
 // host side: engine object + C ABI
@@ -53,6 +55,8 @@ struct moog_engine {
   moog_state_view_t view{nullptr, nullptr};
   size_t step_lds = 0, raster_lds = 0;
   int step_wps = 4;   // register-allocation variant of the step kernel (waves per SIMD)
+  void* spec_handle = nullptr;   // a step kernel compiled for this very program (load_spec_kernel), or null
+  void (*spec_launch)(int, size_t, hipStream_t, const KArgs*) = nullptr;
   int prio_pm[3] = {0, 0, 0};   // wave priorities by launch rank, per mille of the batch (KArgs::prio_t)
   int32_t xstack_off = 0;
   FOp* d_fops = nullptr;        // flattened force list (moog_flatten_forces)
@@ -201,6 +205,113 @@ static int env_prefix_slots(const moog_program_t* p, int* nsv) {
   *nsv = nv;
   return ns;
 }
+
+// Which step kernel a program takes, from the program alone (no device): the variant (plain / + expression evaluator,
+// run-time sampler, dynamic layers / + the rare components), whether its episodes are opened by the reset kernel behind the
+// step kernel (late reset), the LDS of one env and the register-allocation variant that follows from it.  Used by
+// moog_engine_create and, through moog_program_step_kernel, by the builder of program-specialised kernels (moog/_spec.py).
+struct StepVariant { bool dynamic_rules = false, maze_kernel = false, late_reset = false; int wps = 4; size_t step_lds = 0; int32_t xstack_off = 0; };
+
+static StepVariant step_variant_of(const moog_program_t* prog) {
+  StepVariant v;
+  moog_layout_t GL;
+  moog_layout(prog, &GL);
+  const moog_layout_t HL = hot_layout(GL).L;   // the records as staged in LDS
+  v.step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 + (size_t)GL.S * 4 * 8 +
+               (size_t)((GL.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
+  if (prog->xstack_depth > 0) {   // per-lane value stacks of the lane-parallel filter evaluator (moog_device.h eval_expr_t<true>)
+    v.step_lds = (v.step_lds + 15) & ~(size_t)15;
+    v.xstack_off = (int32_t)v.step_lds;
+    v.step_lds += (size_t)prog->xstack_depth * 64 * 8;
+  }
+  { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) v.step_lds += (size_t)atoi(pad); }  // occupancy experiments
+  for (int r = 0; r < prog->n_rules; ++r) {
+    int k = prog->rules[r].kind;
+    if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES ||
+        k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT || k == MOOG_RULE_DRAWS)
+      v.dynamic_rules = true;
+  }
+  for (int t = 0; t < prog->n_tasks; ++t) {
+    if (prog->tasks[t].kind == MOOG_TASK_CONTACT_REWARD && (prog->tasks[t].xcond >= 0 || prog->tasks[t].xreward >= 0))
+      v.dynamic_rules = true;
+    if (prog->tasks[t].kind == MOOG_TASK_RESET && (prog->tasks[t].cond >= MOOG_COND_ALL_EXPR || prog->tasks[t].xreward >= 0))
+      v.dynamic_rules = true;   // (a reward_fn that reads the state is an expression too: task_reward<DYN> evaluates it)
+  }
+  for (int r = 0; r < prog->n_rules; ++r)
+    if ((prog->rules[r].kind == MOOG_RULE_CONDITIONAL || prog->rules[r].kind == MOOG_RULE_PHASE) &&
+        prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
+      v.dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
+  for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) v.dynamic_rules = true;
+  for (int f = 0; f < prog->n_forces; ++f)   // a traced force_fn runs in the expression evaluator
+    if (prog->forces[f].kind == MOOG_FORCE_DISTANCE_EXPR) v.dynamic_rules = true;
+  for (int r = 0; r < prog->n_rules; ++r)
+    if (prog->rules[r].kind == MOOG_RULE_FIXATION || (prog->rules[r].kind == MOOG_RULE_PHASE && prog->rules[r].op == 1))
+      v.dynamic_rules = true;
+  for (int k = 0; k < prog->n_dcode; ++k) {   // assigning sprite.angle turns the path: in the kernels that carry every component
+    if (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE) v.maze_kernel = true;
+    // expressions that name sprites by slot (state-level task functions: Reset(condition / reward_fn), and the reset-time
+    // code) use opcodes only those kernels' evaluator carries (moog_device.h eval_expr_t: MOOG_WITH_MAZE)
+    const int op = prog->dcode[k].op;
+    if (op == MOOG_X_SLOT_ATTR || op == MOOG_X_HDRAW || op == MOOG_X_HDRAW_T || op == MOOG_X_STORE_VERT || op == MOOG_X_FACTOR)
+      v.maze_kernel = true;
+  }
+  for (int o = 0; o < prog->n_ops; ++o) if (prog->ops[o].cell_sel != MOOG_CELL_NONE) v.maze_kernel = true;   // maze / draw / shuffle ops
+  if (prog->n_hdraws > 0) v.maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
+  for (int o = 0; o < prog->n_ops; ++o)
+    for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
+      if (prog->ops[o].factors[k].kind == MOOG_DIST_EXPR || prog->ops[o].factors[k].kind == MOOG_DIST_EXPR_SHAPE)
+        v.maze_kernel = true;
+  // the maze components live in a kernel variant of their own (m3 / m4): their code would only enlarge the others
+  for (int f = 0; f < prog->n_forces; ++f)
+    if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET) v.maze_kernel = true;
+  for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) v.maze_kernel = true;
+  if (prog->maze.random) v.maze_kernel = true;
+  if (v.maze_kernel) {
+    // What the program needs WHILE STEPPING of the components only the every-component kernels carry: maze walks and
+    // MazePhysics, modifiers that assign sprite.angle, run-time generators with maze cells / computed factors.  Everything else
+    // that selects those kernels (reset-time draws and expressions, maze generation, shuffles, choices, look-aheads, values an
+    // initializer keeps across episodes) happens when an episode is built.
+    bool stepping = false;
+    for (int f = 0; f < prog->n_forces; ++f)
+      stepping = stepping || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET;
+    for (int c = 0; c < prog->n_corrective; ++c) stepping = stepping || prog->corrective[c].kind == MOOG_CORR_MAZE;
+    for (int k = 0; k < prog->n_dcode; ++k) stepping = stepping || (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE);
+    for (int o = 0; o < prog->n_ops; ++o) {
+      const moog_genop_t& op = prog->ops[o];
+      if (!op.runtime) continue;
+      bool full = op.cell_sel != MOOG_CELL_NONE || op.code_off >= 0;
+      for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
+        full = full || op.factors[k].kind == MOOG_DIST_EXPR || op.factors[k].kind == MOOG_DIST_EXPR_SHAPE;
+      stepping = stepping || full;
+    }
+    const char* off = getenv("MOOG_NO_LATE_RESET");
+    v.late_reset = !stepping && !(off && atoi(off));
+    if (v.late_reset) v.dynamic_rules = true;   // (the variant with the expression evaluator)
+  }
+  {   // MOOG_STEP_VARIANT=t|m (experiments): run a program on a kernel variant that carries more than it needs (what the variant
+      // itself costs: profiles/r04_variant_tax.txt)
+    const char* sv = getenv("MOOG_STEP_VARIANT");
+    if (sv && (sv[0] == 't' || sv[0] == 'm')) v.dynamic_rules = true;
+    if (sv && sv[0] == 'm') { v.maze_kernel = true; v.late_reset = false; }
+  }
+  // register allocation: three waves per SIMD (168 VGPRs) when the LDS of an env allows no more than 14 envs per CU anyway
+  v.wps = (160 * 1024 / (v.step_lds ? v.step_lds : 1)) <= 14 ? 3 : 4;
+  { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) v.wps = atoi(w); }   // experiments
+  { const char* w = getenv("MOOG_STEP_WPS"); if (w && atoi(w) == 2 && !v.dynamic_rules && !(v.maze_kernel && !v.late_reset)) v.wps = 2; }   // (plain programs only)
+  return v;
+}
+
+static uint64_t program_hash(const moog_program_t* prog) {   // FNV-1a 64 over the program's bytes (moog/_spec.py computes the same)
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(prog);
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < sizeof(moog_program_t); ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+// A step kernel compiled for exactly this program (csrc/moog_step_spec.hip), if one has been built: looked for as
+// <MOOG_SPEC_DIR or the directory of this library + "/spec">/step_<hash>_d<variant>w<wps>.so.  Everything about it is
+// checked -- ABI, argument struct, variant, and the embedded program byte for byte -- before it replaces the generic kernel.
+static void load_spec_kernel(moog_engine* e, const moog_program_t* prog);
 
 extern "C" {
 
@@ -412,16 +523,10 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err == hipSuccess && !fops.empty()) err = hipMemcpy(e->d_fops, fops.data(), fops.size() * sizeof(FOp), hipMemcpyHostToDevice);
     if (err != hipSuccess) { free_engine(e); return fail(MOOG_E_NOMEM, "force list"); }
   }
-  const moog_layout_t HL = hot_layout(e->L).L;   // the records as staged in LDS
-  e->step_lds = (size_t)HL.f64_per_env * 8 + (size_t)HL.i32_per_env * 4 +
-                (size_t)e->L.S * 4 * 8 +
-                (size_t)((e->L.S + 3) & ~3) * 4 + CAND_CAP * 2 + 128 + 64 * 8 + 16;
-  if (prog->xstack_depth > 0) {   // per-lane value stacks of the lane-parallel filter evaluator (moog_device.h eval_expr_t<true>)
-    e->step_lds = (e->step_lds + 15) & ~(size_t)15;
-    e->xstack_off = (int32_t)e->step_lds;
-    e->step_lds += (size_t)prog->xstack_depth * 64 * 8;
+  {
+    const StepVariant sv = step_variant_of(prog);
+    e->step_lds = sv.step_lds; e->xstack_off = sv.xstack_off;
   }
-  { const char* pad = getenv("MOOG_LDS_PAD"); if (pad) e->step_lds += (size_t)atoi(pad); }  // occupancy experiments
   { const char* w = getenv("MOOG_WATCH");   // section sampling (moog_engine_read_watch): two words of LDS for the watcher
     if (w && atoi(w) == 1) {
       e->step_lds = (e->step_lds + 15) & ~(size_t)15;
@@ -535,10 +640,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     int (*const configure[6])(size_t) = {moog_configure_step_f3, moog_configure_step_f4, moog_configure_step_t3,
                                          moog_configure_step_t4, moog_configure_step_m3, moog_configure_step_m4};
     for (int v = 0; v < 6 && err == hipSuccess; ++v) err = (hipError_t)configure[v](e->step_lds);
-    e->step_wps = (160 * 1024 / (e->step_lds ? e->step_lds : 1)) <= 14 ? 3 : 4;
-    { const char* w = getenv("MOOG_STEP_WPS"); if (w && (atoi(w) == 3 || atoi(w) == 4)) e->step_wps = atoi(w); }   // experiments
     if (err == hipSuccess) err = (hipError_t)moog_configure_step_f2(e->step_lds);
-    { const char* w = getenv("MOOG_STEP_WPS"); if (w && atoi(w) == 2) e->step_wps = 2; }   // (plain programs only: launch_step)
     {   // MOOG_STEP_PRIO="a,b,c": per mille of the launch order that runs at wave priority 3 / >= 2 / >= 1 ("0": off)
       const char* pr = getenv("MOOG_STEP_PRIO");
       int a = 0, b = 0, c = 0;
@@ -549,75 +651,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       }
     }
   }
-  for (int r = 0; r < prog->n_rules; ++r) {
-    int k = prog->rules[r].kind;
-    if (k == MOOG_RULE_VANISH_BY_FILTER || k == MOOG_RULE_CHANGE_LAYER || k == MOOG_RULE_CREATE_SPRITES ||
-        k == MOOG_RULE_MODIFY_SPRITES || k == MOOG_RULE_MODIFY_ON_CONTACT || k == MOOG_RULE_DRAWS)
-      e->dynamic_rules = true;
+  {
+    const StepVariant sv = step_variant_of(prog);
+    e->dynamic_rules = sv.dynamic_rules; e->maze_kernel = sv.maze_kernel; e->late_reset = sv.late_reset; e->step_wps = sv.wps;
   }
-  for (int t = 0; t < prog->n_tasks; ++t) {
-    if (prog->tasks[t].kind == MOOG_TASK_CONTACT_REWARD && (prog->tasks[t].xcond >= 0 || prog->tasks[t].xreward >= 0))
-      e->dynamic_rules = true;
-    if (prog->tasks[t].kind == MOOG_TASK_RESET && (prog->tasks[t].cond >= MOOG_COND_ALL_EXPR || prog->tasks[t].xreward >= 0))
-      e->dynamic_rules = true;   // (a reward_fn that reads the state is an expression too: task_reward<DYN> evaluates it)
-  }
-  for (int r = 0; r < prog->n_rules; ++r)
-    if ((prog->rules[r].kind == MOOG_RULE_CONDITIONAL || prog->rules[r].kind == MOOG_RULE_PHASE) &&
-        prog->rules[r].cond >= MOOG_RCOND_CONTACT_COUNT)
-      e->dynamic_rules = true;   // (rule_gate is compiled into both variants; keep them together anyway)
-  for (int l = 0; l < prog->n_layers; ++l) if (prog->layer_dynamic[l]) e->dynamic_rules = true;
-  for (int f = 0; f < prog->n_forces; ++f)   // a traced force_fn runs in the expression evaluator
-    if (prog->forces[f].kind == MOOG_FORCE_DISTANCE_EXPR) e->dynamic_rules = true;
-  for (int r = 0; r < prog->n_rules; ++r)
-    if (prog->rules[r].kind == MOOG_RULE_FIXATION || (prog->rules[r].kind == MOOG_RULE_PHASE && prog->rules[r].op == 1))
-      e->dynamic_rules = true;
-  for (int k = 0; k < prog->n_dcode; ++k) {   // assigning sprite.angle turns the path: in the kernels that carry every component
-    if (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE) e->maze_kernel = true;
-    // expressions that name sprites by slot (state-level task functions: Reset(condition / reward_fn), and the reset-time
-    // code) use opcodes only those kernels' evaluator carries (moog_device.h eval_expr_t: MOOG_WITH_MAZE)
-    const int op = prog->dcode[k].op;
-    if (op == MOOG_X_SLOT_ATTR || op == MOOG_X_HDRAW || op == MOOG_X_HDRAW_T || op == MOOG_X_STORE_VERT || op == MOOG_X_FACTOR)
-      e->maze_kernel = true;
-  }
-  for (int o = 0; o < prog->n_ops; ++o) if (prog->ops[o].cell_sel != MOOG_CELL_NONE) e->maze_kernel = true;   // maze / draw / shuffle ops
-  if (prog->n_hdraws > 0) e->maze_kernel = true;   // reset-time expressions: in the kernels that carry every component (m3 / m4)
-  for (int o = 0; o < prog->n_ops; ++o)
-    for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
-      if (prog->ops[o].factors[k].kind == MOOG_DIST_EXPR || prog->ops[o].factors[k].kind == MOOG_DIST_EXPR_SHAPE)
-        e->maze_kernel = true;
-  // the maze components live in a kernel variant of their own (m3 / m4): their code would only enlarge the others
-  for (int f = 0; f < prog->n_forces; ++f)
-    if (prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET) e->maze_kernel = true;
-  for (int c = 0; c < prog->n_corrective; ++c) if (prog->corrective[c].kind == MOOG_CORR_MAZE) e->maze_kernel = true;
-  if (prog->maze.random) e->maze_kernel = true;
-  if (e->maze_kernel) {
-    // What the program needs WHILE STEPPING of the components only the every-component kernels carry: maze walks and
-    // MazePhysics, modifiers that assign sprite.angle, run-time generators with maze cells / computed factors.  Everything else
-    // that selects those kernels (reset-time draws and expressions, maze generation, shuffles, choices, look-aheads, values an
-    // initializer keeps across episodes) happens when an episode is built.
-    bool stepping = false;
-    for (int f = 0; f < prog->n_forces; ++f)
-      stepping = stepping || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK || prog->forces[f].kind == MOOG_FORCE_MAZE_WALK_DET;
-    for (int c = 0; c < prog->n_corrective; ++c) stepping = stepping || prog->corrective[c].kind == MOOG_CORR_MAZE;
-    for (int k = 0; k < prog->n_dcode; ++k) stepping = stepping || (prog->dcode[k].op == MOOG_X_STORE && prog->dcode[k].a == MOOG_XA_ANGLE);
-    for (int o = 0; o < prog->n_ops; ++o) {
-      const moog_genop_t& op = prog->ops[o];
-      if (!op.runtime) continue;
-      bool full = op.cell_sel != MOOG_CELL_NONE || op.code_off >= 0;
-      for (int k = 0; k < MOOG_NUM_FACTORS; ++k)
-        full = full || op.factors[k].kind == MOOG_DIST_EXPR || op.factors[k].kind == MOOG_DIST_EXPR_SHAPE;
-      stepping = stepping || full;
-    }
-    const char* off = getenv("MOOG_NO_LATE_RESET");
-    e->late_reset = !stepping && !(off && atoi(off));
-    if (e->late_reset) e->dynamic_rules = true;   // (the variant with the expression evaluator)
-  }
-  {   // MOOG_STEP_VARIANT=t|m (experiments): run a program on a kernel variant that carries more than it needs (what the variant
-      // itself costs: profiles/r04_variant_tax.txt)
-    const char* v = getenv("MOOG_STEP_VARIANT");
-    if (v && (v[0] == 't' || v[0] == 'm')) e->dynamic_rules = true;
-    if (v && v[0] == 'm') { e->maze_kernel = true; e->late_reset = false; }
-  }
+  if (!e->watch) load_spec_kernel(e, prog);
   if (e->late_reset) {
     if (hipMalloc(&e->late_mask, (size_t)n_envs) != hipSuccess || hipMemset(e->late_mask, 0, (size_t)n_envs) != hipSuccess) {
       free_engine(e);
@@ -680,7 +718,9 @@ int moog_engine_destroy(moog_engine_t* e) {
     hipEventDestroy(e->ev_step_done); hipEventDestroy(e->ev_sched_done);
     hipStreamDestroy(e->sched_stream);
   }
+  void* spec = e->spec_handle;
   free_engine(e);
+  (void)spec;   // (the object stays mapped: unloading a code object that a stream may still reference is not worth the risk)
   return MOOG_OK;
 }
 
@@ -758,6 +798,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   static const moog_step_launch_fn launch[6] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
                                                 moog_launch_step_t4, moog_launch_step_m3, moog_launch_step_m4};
+  if (e->spec_launch) { e->spec_launch(e->n_envs, e->step_lds, s, &a); return; }
   const bool full = e->maze_kernel && !e->late_reset;
   if (e->step_wps == 2 && !full && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
   launch[(full ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
@@ -1052,6 +1093,21 @@ int moog_engine_layer_usage(moog_engine_t* e, int32_t* high_water, int32_t* drop
   return MOOG_OK;
 }
 
+int moog_program_step_kernel(const moog_program_t* prog, int32_t* variant, int32_t* wps, uint64_t* hash) {
+  if (!prog) return fail(MOOG_E_INVALID, "null program");
+  const StepVariant v = step_variant_of(prog);
+  if (variant) *variant = (v.maze_kernel && !v.late_reset) ? 2 : (v.dynamic_rules ? 1 : 0);
+  if (wps) *wps = v.wps;
+  if (hash) *hash = program_hash(prog);
+  return MOOG_OK;
+}
+
+int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised) {
+  if (!e || !specialised) return fail(MOOG_E_INVALID, "null argument");
+  *specialised = e->spec_launch ? 1 : 0;
+  return MOOG_OK;
+}
+
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path) {
   if (!e || !path) return fail(MOOG_E_INVALID, "null argument");
   *path = (e->mask_setup.ok && e->pe_ns <= 0) ? MOOG_RASTER_MASK : MOOG_RASTER_SPANS;
@@ -1144,3 +1200,42 @@ int moog_engine_kernel_time(moog_engine_t* e, int32_t kernel_id, double* total_m
 }
 
 }  // extern "C"
+
+static void load_spec_kernel(moog_engine* e, const moog_program_t* prog) {
+  { const char* sw = getenv("MOOG_STEP_SPEC"); if (sw && atoi(sw) == 0) return; }   // 0: the generic kernels (A/B runs, tests)
+  std::string dir;
+  if (const char* d = getenv("MOOG_SPEC_DIR")) dir = d;
+  else {
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&moog_abi_version), &info) || !info.dli_fname) return;
+    dir = info.dli_fname;
+    const size_t cut = dir.find_last_of('/');
+    dir = (cut == std::string::npos ? std::string(".") : dir.substr(0, cut)) + "/spec";
+  }
+  const bool full = e->maze_kernel && !e->late_reset;
+  char name[96];
+  snprintf(name, sizeof name, "/step_%016llx_d%dw%d.so", (unsigned long long)program_hash(prog), full ? 2 : (e->dynamic_rules ? 1 : 0), e->step_wps);
+  const std::string path = dir + name;
+  if (access(path.c_str(), R_OK) != 0) return;
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) { fprintf(stderr, "moog: %s does not load (%s); the generic step kernel is used\n", path.c_str(), dlerror()); return; }
+  typedef int (*fn_i)(void);
+  typedef unsigned long long (*fn_u)(void);
+  typedef const void* (*fn_p)(void);
+  typedef int (*fn_cfg)(size_t);
+  fn_i abi = reinterpret_cast<fn_i>(dlsym(h, "moog_spec_abi")), var = reinterpret_cast<fn_i>(dlsym(h, "moog_spec_variant"));
+  fn_u hash = reinterpret_cast<fn_u>(dlsym(h, "moog_spec_hash")), ksz = reinterpret_cast<fn_u>(dlsym(h, "moog_spec_kargs_size"));
+  fn_p pr = reinterpret_cast<fn_p>(dlsym(h, "moog_spec_program"));
+  fn_cfg cfg = reinterpret_cast<fn_cfg>(dlsym(h, "moog_spec_configure"));
+  void* launch = dlsym(h, "moog_spec_launch");
+  const bool ok = abi && var && hash && ksz && pr && cfg && launch && abi() == MOOG_ABI_VERSION && ksz() == sizeof(KArgs) &&
+                  var() == ((full ? 2 : (e->dynamic_rules ? 1 : 0)) | (e->step_wps << 8)) && hash() == program_hash(prog) &&
+                  memcmp(pr(), prog, sizeof(moog_program_t)) == 0 && cfg(e->step_lds) == (int)hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "moog: %s was built for another program, variant or ABI; the generic step kernel is used\n", path.c_str());
+    dlclose(h);
+    return;
+  }
+  e->spec_handle = h;
+  e->spec_launch = reinterpret_cast<void (*)(int, size_t, hipStream_t, const KArgs*)>(launch);
+}

@@ -685,6 +685,14 @@ __global__ __launch_bounds__(MOOG_STEP_THREADS, WPS) void moog_step_kernel(KArgs
     else if (b < a.prio_t[2]) __builtin_amdgcn_s_setprio(1);
   }
   if (a.perm) env = a.perm[env];
+#ifdef MOOG_SPEC_PROGRAM_INC
+  {   // a program-specialised build (moog_step_spec.hip): the layout is a compile-time constant like the program itself
+    moog_layout_t L;
+    moog_layout(&MOOG_SPEC_PROGRAM, &L);
+    a.L = L;
+    a.H = hot_layout(L);
+  }
+#endif
   step_env<DYN>(a, env, moog_lds, (int)threadIdx.x);
 #ifdef MOOG_WATCH
   if (a.watch && threadIdx.x == 0) { int32_t* w = reinterpret_cast<int32_t*>(__builtin_assume_aligned(moog_lds + a.watch_off, 16)); __hip_atomic_store(w + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

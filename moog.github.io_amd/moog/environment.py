@@ -42,10 +42,15 @@ class BatchedEnvironment(object):
 
     def __init__(self, state_initializer, physics, task, action_space, observers, game_rules=(),
                  meta_state_initializer=None, num_envs=1, device=None, seed=0, env_index0=0,
-                 layer_capacity=None, keep_sprite_factors=False, reset_pool='auto', _compiled=None, _buffers=None):
+                 layer_capacity=None, keep_sprite_factors=False, reset_pool='auto', specialize=False, _compiled=None,
+                 _buffers=None):
         import torch
         self._torch = torch
         self._lib = _engine.load_library()  # raises when the HIP extension is missing
+        # specialize: True compiles (once; needs hipcc, not a GPU; ~20 s) a step kernel for this very program -- same source, the
+        # program a compile-time constant, bit-identical results, faster (moog/_spec.py).  Whatever the argument, an engine uses
+        # such a kernel when one has been built for its program (moog_engine_step_kernel; MOOG_STEP_SPEC=0 turns that off).
+        self._specialize = bool(specialize)
         # reset_pool: build every env's NEXT episode beside the step kernels and take it over when the episode ends
         # (moog_engine_set_reset_pool; same results, bit for bit).  'auto': on for configs whose state_initializer plays
         # physics forward (bounce_box_contact_prediction, red_green: a reset there costs as much as a hundred steps of the
@@ -98,6 +103,9 @@ class BatchedEnvironment(object):
                 (self.state_f64, self.state_i32, self.reward, self.discount, self.step_type,
                  self.image) = self.allocate_buffers(torch, L, P, n, self.device)
         self._handle = ctypes.c_void_p()
+        if self._specialize:
+            from . import _spec
+            _spec.build(P)
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(self.device):   # (the engine calls hipSetDevice: keep torch's current device)
             _engine.check(self._lib, self._lib.moog_engine_create(
@@ -267,6 +275,12 @@ class BatchedEnvironment(object):
         else:
             self._cost = self._perm = None
             _engine.check(self._lib, self._lib.moog_engine_set_schedule(self._handle, None, None))
+
+    def step_kernel(self):
+        """'specialised' when the engine steps with a kernel compiled for this program (moog/_spec.py), else 'generic'."""
+        v = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_step_kernel(self._handle, ctypes.byref(v)))
+        return 'specialised' if v.value else 'generic'
 
     def raster_path(self):
         """Which rasteriser draws this engine's frames: 'mask' (csrc/moog_raster_mask_core.h) or 'spans'

@@ -1,5 +1,7 @@
 """HIP engine vs the CPU oracle / the reference golden vectors (needs an MI355X).
 Everything goes through the C ABI (moog.environment.BatchedEnvironment -> ctypes)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1768,3 +1770,37 @@ def test_filters_over_big_layers_lane_parallel():
     assert np.array_equal(out.observation['image'].cpu().numpy(), o.render())
     env.raise_faults()
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,n,steps', [('colliding_predators_32', 512, 30), ('falling_balls_64', 128, 20), ('functional_maze', 256, 30),
+                                          ('cleanup', 128, 40), ('pacman', 32, 30)])
+def test_specialised_step_kernel_is_result_neutral(name, n, steps, monkeypatch, tmp_path):
+    """moog/_spec.py compiles the step kernel with the program as a compile-time constant (csrc/moog_step_spec.hip): same
+    source, same arithmetic -- records, time steps and frames of every call equal the generic kernel's bit for bit, across
+    auto-resets, for a plain program, a program of the variant with the expression evaluator and one of the variant with
+    every component.  The engine says which kernel it uses; a kernel built for another program is not picked up."""
+    from moog import _spec
+    monkeypatch.setenv('MOOG_SPEC_DIR', str(tmp_path))
+    ref = make_env(name, n, seed=6, env_index0=3)
+    assert ref.step_kernel() == 'generic'
+    path = _spec.build(ref.compiled.program)
+    assert os.path.dirname(path) == str(tmp_path)
+    env = make_env(name, n, seed=6, env_index0=3)
+    assert env.step_kernel() == 'specialised'
+    other = make_env('pong', 8, seed=1)
+    assert other.step_kernel() == 'generic'
+    other.close()
+    t0, t1 = ref.reset(), env.reset()
+    assert np.array_equal(t0.observation['image'].cpu().numpy(), t1.observation['image'].cpu().numpy())
+    for k in range(steps):
+        a = ref.random_action()
+        t0, t1 = ref.step(a), env.step(a)
+        f0, q0 = download(ref)
+        f1, q1 = download(env)
+        assert np.array_equal(q0, q1), 'integer records differ at call %d' % k
+        assert np.array_equal(f0, f1, equal_nan=True), 'float records differ at call %d' % k
+        assert np.array_equal(t0.step_type.cpu().numpy(), t1.step_type.cpu().numpy())
+        assert np.array_equal(t0.reward.cpu().numpy(), t1.reward.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(t0.observation['image'].cpu().numpy(), t1.observation['image'].cpu().numpy())
+    env.raise_faults()

@@ -608,3 +608,24 @@ def test_rule_interval_probe_sees_every_draw():
         with pytest.raises(NotImplementedError):
             gr.DelayedRule(fn, [])
     assert np.array_equal(before[0], np.random.get_state()[1]) and before[1] == py_random.getstate()
+
+
+def test_program_step_kernel_and_spec_source():
+    """moog_program_step_kernel needs no device: variant, register-allocation variant and the FNV-1a hash the specialised
+    kernel's file name carries (computed here in Python as a check); the generated include reproduces the program's doubles
+    exactly (hexadecimal literals)."""
+    from moog import _spec
+    for name, variant in (('colliding_predators_32', 0), ('cleanup', 1), ('pacman', 2)):
+        P = helpers.compiled(name).program
+        v, w, h = _spec.kernel_of(P)
+        assert v == variant and w in (2, 3, 4), (name, v, w)
+        raw = bytes(P)
+        assert len(raw) == ctypes.sizeof(_abi.Program)
+        fnv = 1469598103934665603
+        for b in raw[::1]:
+            fnv = ((fnv ^ b) * 1099511628211) & 0xffffffffffffffff
+        assert fnv == h, name
+        assert os.path.basename(_spec.path_of(P)) == 'step_%016x_d%dw%d.so' % (h, v, w)
+    src = _spec.source_of(helpers.compiled('colliding_predators_32').program)
+    assert 'MOOG_SPEC_HASH' in src and 'static const moog_program_t MOOG_SPEC_PROGRAM = {' in src
+    assert float.fromhex(float.hex(0.1)) == 0.1 and '0x1.' in src

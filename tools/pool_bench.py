@@ -2,6 +2,7 @@
 (wall-clock env-steps/s of `steps` calls with random actions after a warm-up, frames drawn; the pool's own counters)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'moog.github.io_amd'))
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')   # (the reset pool's fills and nothing else here want more than the runtime's four; set before HIP initialises)
 import torch
 from moog import environment
 from moog_demos import example_configs
