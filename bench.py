@@ -313,7 +313,9 @@ def main():
         # (the step kernel specialised for this program is built by __graft_entry__.build(); if it is not there -- another
         #  workload, a fresh checkout -- it is compiled here, before anything is timed: ~20 s of hipcc, no GPU work)
         spec = False
-        if not args.no_spec:
+        if os.environ.get('MOOG_SPEC_PREBUILT'):   # (A/B runs: kernels built by hand in MOOG_SPEC_DIR are used as they are)
+            spec = True
+        elif not args.no_spec:
             try:
                 from moog import _compiler, _spec
                 _spec.build(_compiler.compile_config(layer_capacity=example_configs.capacity(args.workload),

@@ -613,9 +613,22 @@ __device__ __forceinline__ int nth_set_bit16(unsigned m, int k) {
   return pos;
 }
 
+// k-th set bit of a 32-bit mask, k < popcount
+__device__ __forceinline__ int nth_set_bit32(unsigned m, int k) {
+  const int c = __popc(m & 0xffffu);
+  const bool hi = k >= c;
+  return nth_set_bit16(hi ? m >> 16 : m & 0xffffu, hi ? k - c : k) + (hi ? 16 : 0);
+}
+
 #define CAND_SKIP 0xFFFF   // a candidate entry struck from the list (collision_same_layer): counts as rejected
-__device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
-  const int grp = e.lane >> 4, gl = e.lane & 15;
+// G lanes per candidate: 16 (four candidates a batch), or -- with -DMOOG_WIDE_BATCH -- 32 (two) for polygons of 17 - 32
+// vertices: falling_balls_64's 30-gons never fit sixteen lanes and each of its candidates takes the whole wave's path test.
+// Exact either way (the parity suite passes with it); not faster, see narrow_reject_prefix below.
+template <int G>
+__device__ inline int narrow_reject_prefix_g(const Env& e, int c, int n) {
+  constexpr int SH = G == 16 ? 4 : 5;
+  constexpr unsigned long long GM = G == 16 ? 0xffffull : 0xffffffffull;
+  const int grp = e.lane >> SH, gl = e.lane & (G - 1);
   const int pr0 = grp < n ? (int)e.cand[c + grp] : CAND_SKIP;
   const bool active = pr0 != CAND_SKIP;
   const int pr = active ? pr0 : 0;
@@ -635,28 +648,34 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   const int gb1 = (gl < nb) ? gl : 0, gb2 = (gl + 1 >= nb) ? 0 : gl + 1;
   const double2 a1 = *reinterpret_cast<const double2*>(va + 2 * ga1), a2 = *reinterpret_cast<const double2*>(va + 2 * ga2);
   const double2 b1 = *reinterpret_cast<const double2*>(vb + 2 * gb1), b2 = *reinterpret_cast<const double2*>(vb + 2 * gb2);
-  bool slow = (na > 16) | (nb > 16);
+  const bool big = (na > G) | (nb > G);
   // the "all vertices of one inside the other" tests would run (box within box): not here
-  slow |= (na + 1 >= 3) & (nb > 0) &
-          !((bl.x < al.x - BB_MARGIN) | (bl.y < al.y - BB_MARGIN) | (bh.x > ah.x + BB_MARGIN) | (bh.y > ah.y + BB_MARGIN));
+  bool slow = (na + 1 >= 3) & (nb > 0) &
+              !((bl.x < al.x - BB_MARGIN) | (bl.y < al.y - BB_MARGIN) | (bh.x > ah.x + BB_MARGIN) | (bh.y > ah.y + BB_MARGIN));
   slow |= (nb + 1 >= 3) & (na > 0) &
           !((al.x < bl.x - BB_MARGIN) | (al.y < bl.y - BB_MARGIN) | (ah.x > bh.x + BB_MARGIN) | (ah.y > bh.y + BB_MARGIN));
   slow &= active;
-  if (__ballot(slow) & 0xffffull) return 0;   // the first candidate takes the ordinary path anyway
+  if (__ballot(slow) & GM) return 0;   // the first candidate takes the ordinary path anyway
+  if (G == 16) {   // the first candidate is too long for sixteen lanes (and for nothing else): thirty-two, if they do
+    const unsigned long long bg = __ballot(big & active), b32 = __ballot(active & ((na > 32) | (nb > 32)));
+    if (bg & GM) return (b32 & GM) ? 0 : -1;
+  } else if (__ballot(big & active) & GM) return 0;
+  slow |= big & active;
   bool ka = false, kb = false;
   if (active && !slow) {
     if (gl < na) ka = !seg_outside_dop_r(a1.x, a1.y, a2.x, a2.y, bl, bh);
     if (gl < nb) kb = !seg_outside_dop_r(b1.x, b1.y, b2.x, b2.y, al, ah);
   }
   const unsigned long long ma = __ballot(ka), mb = __ballot(kb);
-  const unsigned ga = (unsigned)(ma >> (16 * grp)) & 0xffffu, gb = (unsigned)(mb >> (16 * grp)) & 0xffffu;
+  const unsigned ga = (unsigned)((ma >> (G * grp)) & GM), gb = (unsigned)((mb >> (G * grp)) & GM);
   const int ca = __popc(ga), cb = __popc(gb), total = ca * cb;
-  slow = slow || total > 16;
+  slow = slow || total > G;
   int hit = 0;
   if (active && !slow && gl < total) {
-    // gl / cb for gl < 16, 1 <= cb <= 16 (the quotient of a half-integer is never near an integer)
+    // gl / cb for gl < G, 1 <= cb <= G (the quotient of a half-integer is never near an integer)
     const int ia = (int)(((float)gl + 0.5f) / (float)cb), ib = gl - ia * cb;
-    const int i = nth_set_bit16(ga, ia), j = nth_set_bit16(gb, ib);   // the surviving edges, in order
+    const int i = G == 16 ? nth_set_bit16(ga, ia) : nth_set_bit32(ga, ia);   // the surviving edges, in order
+    const int j = G == 16 ? nth_set_bit16(gb, ib) : nth_set_bit32(gb, ib);
     const int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
     const double2 p11 = *reinterpret_cast<const double2*>(va + 2 * i), p12 = *reinterpret_cast<const double2*>(va + 2 * i2);
     const double2 p21 = *reinterpret_cast<const double2*>(vb + 2 * j), p22 = *reinterpret_cast<const double2*>(vb + 2 * j2);
@@ -671,13 +690,22 @@ __device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
   }
   const unsigned long long stop = __ballot((hit & 3) != 0 || slow), slows = __ballot(slow), props = __ballot(hit == 2);
   int r = 0;
-  while (r < n && ((stop >> (16 * r)) & 0xffffull) == 0ull) ++r;
+  while (r < n && ((stop >> (G * r)) & GM) == 0ull) ++r;
   // bit 8: the candidate that ended the prefix is a proven overlap (its edges cross); bit 9: two non-parallel edges do
-  if (r < n && ((slows >> (16 * r)) & 0xffffull) == 0ull) {
-    if ((props >> (16 * r)) & 0xffffull) r |= 512;
+  if (r == n) return r | 1024;   // bit 10: every candidate looked at is rejected (n of them: four, or two of the long ones)
+  if (((slows >> (G * r)) & GM) == 0ull) {
+    if ((props >> (G * r)) & GM) r |= 512;
     r |= 256;
   }
   return r;
+}
+
+__device__ inline int narrow_reject_prefix(const Env& e, int c, int n) {
+  const int r = narrow_reject_prefix_g<16>(e, c, n);
+#ifdef MOOG_WIDE_BATCH   // measured (profiles/r05_step_experiments.txt): falling_balls_64 +0.7 %, colliding_predators_32 -2 %: off
+  if (r < 0) return narrow_reject_prefix_g<32>(e, c, n < 2 ? n : 2);
+#endif
+  return r < 0 ? 0 : r;
 }
 
 // sprite.py:442-460 (one point, one lane)
@@ -2110,7 +2138,7 @@ __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int 
         SEC(e, SEC_PAIR_CONSUME);
         known_hit = (rr & 256) != 0;
         c += r;
-        if (r == n) { --c; continue; }   // all of them: on to the next batch
+        if (rr & 1024) { --c; continue; }   // all of them: on to the next batch
       }
       int pr = uni((int)e.cand[c]);
       int s0 = pr >> 8, t = pr & 255;
@@ -2234,7 +2262,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
         known_hit = (rr & 256) != 0;
         proper_hit = (rr & 512) != 0;
         c += r;
-        if (r == nn) { --c; continue; }   // all of them: on to the next batch
+        if (rr & 1024) { --c; continue; }   // all of them: on to the next batch
       }
       const int pr = uni((int)e.cand[c]);
       if (pr == CAND_SKIP) continue;

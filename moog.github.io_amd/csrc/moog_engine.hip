@@ -792,13 +792,17 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.live_f64 = nullptr; a.live_i32 = nullptr;
   a.late_mask = (mode == MODE_STEP && e->late_reset) ? e->late_mask : nullptr;
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
+  a.rank0 = 0;
   return a;
 }
 
 static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   static const moog_step_launch_fn launch[6] = {moog_launch_step_f3, moog_launch_step_f4, moog_launch_step_t3,
                                                 moog_launch_step_t4, moog_launch_step_m3, moog_launch_step_m4};
-  if (e->spec_launch) { e->spec_launch(e->n_envs, e->step_lds, s, &a); return; }
+  if (e->spec_launch) {
+    e->spec_launch(e->n_envs, e->step_lds, s, &a);
+    return;
+  }
   const bool full = e->maze_kernel && !e->late_reset;
   if (e->step_wps == 2 && !full && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
   launch[(full ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);

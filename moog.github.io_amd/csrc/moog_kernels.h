@@ -157,6 +157,7 @@ struct KArgs {
   unsigned long long* pool_stats;   // [4] episodes opened from the pool / by a reset in place / pool records rejected / adoptions that waited for a fill
   const double* live_f64;    // MODE_FILL: the live records (a.f64 / a.i32 are pool_f64[1] / pool_i32[1] then)
   const int32_t* live_i32;
+  int32_t rank0;         // launch rank of workgroup 0 (0; a launch split by rank was measured in round 5, profiles/r05_step_experiments.txt)
   int32_t prio_t[3];     // wave priorities by launch rank (with `perm`: descending cost of the previous step): workgroups
                          // [0, t0) issue at priority 3, [t0, t1) at 2, [t1, t2) at 1, the rest at 0; all zero: off
 };
@@ -654,7 +655,7 @@ template <bool DYN, int WPS, int VARIANT>   // VARIANT only names the instantiat
 #define MOOG_STEP_THREADS 64
 #endif
 __global__ __launch_bounds__(MOOG_STEP_THREADS, WPS) void moog_step_kernel(KArgs a) {
-  int env = blockIdx.x;
+  int env = (int)blockIdx.x + a.rank0;
   if (env >= a.n_envs) return;
 #ifdef MOOG_WATCH
   if (a.watch) {
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(MOOG_STEP_THREADS, WPS) void moog_step_kernel(KArgs
   // instruction every ~9 cycles instead of every ~5: the envs that were expensive in the previous step (they come first in
   // the launch order) get the SIMD's issue slots ahead of their neighbours.  A scheduling hint: no result depends on it.
   if (a.perm && a.prio_t[2] > 0) {
-    const int b = (int)blockIdx.x;
+    const int b = env;
     if (b < a.prio_t[0]) __builtin_amdgcn_s_setprio(3);
     else if (b < a.prio_t[1]) __builtin_amdgcn_s_setprio(2);
     else if (b < a.prio_t[2]) __builtin_amdgcn_s_setprio(1);

@@ -346,7 +346,7 @@ def test_full_size_properties():
 @pytest.mark.parametrize('name,n,steps,size', [('chase_avoid_torus', 4096, 8, None),
                                                ('colliding_predators_32', 4096, 8, None),
                                                ('functional_maze', 8192, 6, 128),
-                                               ('falling_balls_64', 8192, 2, None)])
+                                               ('falling_balls_64', 8192, 6, None)])
 def test_full_size_vs_oracle(name, n, steps, size):
     """BASELINE.json's configs at their full per-GPU sizes against the oracle itself (OpenMP over envs
     makes it affordable): reset + a few steps in lock step -- integer records bit-exact, floats <= 1e-9,
