@@ -17,11 +17,23 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   const int tid = (int)threadIdx.x, lane = tid & 63;
   RmThread th;
   rm_p0<WORDS>(a, c, env, tid, RM_THREADS, th);
-  if (tid < 64) rm_p0_slots(a, c, env, lane, th);
-  __syncthreads();
-  if (a.debug_stop == 1) return;
-  rm_p1<WORDS>(a, c, env, tid, RM_THREADS, th);
-  __syncthreads();
+  if (a.ncopy > 1) {   // torus frames: nine copies per sprite, the visible ones become items
+    if (tid < 64) rm_t0_slots(a, c, env, lane);
+    __syncthreads();
+    if (a.debug_stop == 1) return;
+    rm_t1_bounds(a, c, env, tid, RM_THREADS);
+    __syncthreads();
+    if (tid < 64) rm_t2_items(a, c, lane);
+    __syncthreads();
+    rm_t3_points(a, c, env, tid, RM_THREADS);
+    __syncthreads();
+  } else {
+    if (tid < 64) rm_p0_slots(a, c, env, lane, th);
+    __syncthreads();
+    if (a.debug_stop == 1) return;
+    rm_p1<WORDS>(a, c, env, tid, RM_THREADS, th);
+    __syncthreads();
+  }
   if (a.debug_stop == 2) return;
   // (every wave scans the items for itself: both write the same words, and a wave's LDS operations execute in order,
   //  so each reads back what it wrote -- no barrier between the scan and the edges)

@@ -1,7 +1,7 @@
 // moog_raster_mask_core.h -- the "mask" rasteriser: Pillow-exact polygon fill without sorting crossings.
 //
-// Replaces, for one-tile frames (<= 128 x 128 canvas, polygons of <= 32 vertices), the push / sort / span pipeline of
-// moog_raster_kernel.h.  Same contract: bit-exact with ImageDraw.polygon in RGBA blend mode as PILRenderer uses it
+// Replaces, for one-tile frames (<= 128 x 128 canvas, polygons of <= 32 vertices; plain frames, first-person frames and the
+// nine copies per sprite of a torus), the push / sort / span pipeline of moog_raster_kernel.h.  Same contract: bit-exact with ImageDraw.polygon in RGBA blend mode as PILRenderer uses it
 // (reference moog/observers/pil_renderer.py:88-120; Pillow Draw.c ImagingDrawPolygon / polygon_generic(hasAlpha = 1) /
 // hline32rgba as restated in oracle/moog_oracle.c).
 //
@@ -69,7 +69,7 @@ struct alignas(16) RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint3
 
 struct alignas(16) RmU4 { uint32_t x, y, z, w; };
 
-struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, total; };
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, total; };
 
 struct RmArgs {
   const moog_program_t* P;
@@ -79,7 +79,9 @@ struct RmArgs {
   uint8_t* image;
   const uint32_t* vinfo;      // per vertex slot: sprite slot | index within the sprite << 8
   int32_t n_envs;
-  int32_t S;                  // sprite slots (= items: no polygon modifier that copies)
+  int32_t S;                  // items (polygons a frame may hold): slots * ncopy
+  int32_t slots;              // sprite slots
+  int32_t ncopy;              // 1, or 9: polygon_modifiers.py TorusGeometry draws every sprite at the 3 x 3 offsets -1, 0, 1
   int32_t cap_rows;           // row records per pass (>= H)
   int32_t W, H;               // the canvas in memory (width a multiple of 16, <= 128)
   int32_t scale_w;            // the width the vertices are scaled by (pil_renderer.py:65-66)
@@ -103,6 +105,7 @@ struct RmArgs {
 
 static inline uint32_t rm_align(uint32_t x) { return (x + 15u) & ~15u; }
 
+// S: items; TOTV: vertex slots of all items (the program's vertex slots x copies)
 static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, RmPlan* p) {
   uint32_t o = 0;
   p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
@@ -111,6 +114,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows * 2u);
   p->o_info = o; o = rm_align(o + (uint32_t)S * sizeof(RmItem));
   p->o_item_y = o; o = rm_align(o + (uint32_t)S * 8u);
+  p->o_item_x = o; o = rm_align(o + (uint32_t)S * 8u);   // (torus frames: the sprites' coordinate bounds, 36 of its 72 bytes per sprite)
   p->o_rowoff = o; o = rm_align(o + (uint32_t)(S + 1) * 4u);
   p->o_seg = o; o = rm_align(o + (uint32_t)H * (uint32_t)(W / 16) * (uint32_t)iwords * 4u);
   p->o_lut = o; o = rm_align(o + 16u * 16u);
@@ -126,7 +130,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
 
 struct RmCtx {
   RmEdge* edges; uint32_t* ivert; RmRow* rows; uint16_t* rowitem;   // rowitem: the row's item | 256 when a shallow edge has a corner on the row
-  RmItem* info; int32_t* item_y; int32_t* rowoff;
+  RmItem* info; int32_t* item_y; int32_t* item_x; int32_t* rowoff;
   uint32_t* seg; uint32_t* lut; float* xx; uint32_t* spare; uint16_t* sorted; uint8_t* owner; int32_t* misc;   // sorted (p4: the rows in order of their kind) shares the spare words' memory (p3)   // misc: [5] static prefix differs
 };
 
@@ -138,6 +142,7 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
   c.rowitem = reinterpret_cast<uint16_t*>(lds + pl.o_rowitem);
   c.info = reinterpret_cast<RmItem*>(lds + pl.o_info);
   c.item_y = reinterpret_cast<int32_t*>(lds + pl.o_item_y);
+  c.item_x = reinterpret_cast<int32_t*>(lds + pl.o_item_x);
   c.rowoff = reinterpret_cast<int32_t*>(lds + pl.o_rowoff);
   c.seg = reinterpret_cast<uint32_t*>(lds + pl.o_seg);
   c.lut = reinterpret_cast<uint32_t*>(lds + pl.o_lut);
@@ -630,7 +635,7 @@ RM_FN void rm_p0_slots(const RmArgs& a, const RmCtx& c, int env, int lane, RmThr
       }
       if (alive) {
         uint32_t rgb;
-        if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.S + s] & 0xffffffu;
+        if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.slots + s] & 0xffffffu;
         else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
         else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
         rgba = rgb | (((uint32_t)opa & 255u) << 24);
@@ -689,6 +694,176 @@ RM_FN void rm_p1(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
     rm_max(&c.item_y[2 * s + 1], iy);
   }
   if (th.st_bad) c.misc[5] = 1;   // (cleared before the previous barrier)
+}
+
+// ---- torus frames: item = (slot, copy), copy c drawn at the offset (c / 3 - 1, c % 3 - 1) (polygon_modifiers.py:88-97) ----
+// Of a sprite's nine copies one is on the canvas, two or four when it straddles an edge or a corner; the others must cost
+// next to nothing.  Pillow truncates the scaled coordinates towards zero, so a copy's integer points are not the
+// sprite's shifted by a canvas: they come from the doubles, copy by copy.  But x -> (int)(W * (x + o)) is monotone, so a
+// copy's integer bounds are those of the sprite's smallest and largest coordinates: the vertices leave four 64-bit
+// atomics per sprite behind (t1), the items work out which copies can touch the canvas and number their vertices (t2),
+// and only those copies' points are computed and stored (t3).  A sprite with a coordinate that is not an ordinary number
+// (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN, which is not monotone) takes per-copy atomics instead.
+//   t0 (first wave): per-slot colour and liveness into the nine items      | t1: vertices -> the sprites' bounds
+//   t2 (first wave): visible items get their compact vertex ranges        | t3: the visible copies' integer points
+struct alignas(16) RmBounds { long long kx0, kx1, ky0, ky1; };   // order-preserving keys of the smallest / largest x and y
+RM_FN long long rm_key(double d) { long long b; memcpy(&b, &d, 8); return b ^ ((b >> 63) & 0x7fffffffffffffffll); }
+RM_FN double rm_unkey(long long k) { const long long b = k ^ ((k >> 63) & 0x7fffffffffffffffll); double d; memcpy(&d, &b, 8); return d; }
+RM_FN void rm_min64(long long* p, long long v) {
+#if RM_DEV
+  atomicMin(p, v);
+#else
+  if (v < *p) *p = v;
+#endif
+}
+RM_FN void rm_max64(long long* p, long long v) {
+#if RM_DEV
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
+// slots * 32 bytes of bounds live where the items' x ranges would (S * 8 = slots * 72 bytes); [slots * 4 ...): irregular flags
+RM_FN RmBounds* rm_bounds(const RmCtx& c) { return reinterpret_cast<RmBounds*>(c.item_x); }
+RM_FN int32_t* rm_irregular(const RmArgs& a, const RmCtx& c) { return c.item_x + 8 * a.slots; }
+
+RM_FN void rm_t0_slots(const RmArgs& a, const RmCtx& c, int env, int lane) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
+#if RM_DEV
+  for (int s = lane; s < a.slots; s += 64) {
+#else
+  (void)lane;
+  for (int s = 0; s < a.slots; ++s) {
+#endif
+    const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
+    const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
+    int nvl = 0;
+    uint32_t rgba = 0u;
+    if (flags & MOOG_F_ALIVE) {
+      uint32_t rgb;
+      if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.slots + s] & 0xffffffu;
+      else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
+      else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
+      rgba = rgb | (((uint32_t)opa & 255u) << 24);
+      nvl = nvs < 0 ? 0 : (nvs > RM_MAX_NV ? RM_MAX_NV : nvs);
+    }
+    for (int cp = 0; cp < a.ncopy; ++cp) {
+      const int g = s * a.ncopy + cp;
+      RmItem it;
+      it.rowbase = 0; it.pb_nv = nvl << 20; it.pymax = 0; it.rgba = rgba;
+      c.info[g] = it;
+      c.item_y[2 * g] = 0x7fffffff; c.item_y[2 * g + 1] = -0x7fffffff;
+    }
+    RmBounds bz;
+    bz.kx0 = 0x7fffffffffffffffll; bz.kx1 = -0x7fffffffffffffffll - 1; bz.ky0 = bz.kx0; bz.ky1 = bz.kx1;
+    rm_bounds(c)[s] = bz;
+    rm_irregular(a, c)[s] = 0;
+  }
+}
+
+// The integer canvas point of copy cp of a vertex (pil_renderer.py:104-108: the scaled doubles through Pillow's (int))
+RM_FN uint32_t rm_copy_point(const RmArgs& a, double x, double y, int cp, int* ix_out, int* iy_out) {
+  const double px = x + (double)(cp / 3 - 1), py = y + (double)(cp % 3 - 1);
+  const int ix = rm_clamp16(rm_pil_int((double)a.scale_w * px)), iy = rm_clamp16(rm_pil_int((double)a.H * py));
+  *ix_out = ix; *iy_out = iy;
+  return (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
+}
+
+RM_FN void rm_t1_bounds(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  for (int idx = tid; idx < L.TOTV; idx += T) {
+    const uint32_t vi = a.vinfo[idx];
+    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
+    if (k >= (c.info[s * a.ncopy].pb_nv >> 20)) continue;
+    const double x = gf[L.o_verts + 2 * idx], y = gf[L.o_verts + 2 * idx + 1];
+    // ordinary: every copy's scaled coordinate is far inside what (int) holds (NaN fails the comparisons)
+    const bool ordinary = fabs(x) < 1.0e6 && fabs(y) < 1.0e6;
+    if (ordinary) {
+      RmBounds* bd = rm_bounds(c) + s;
+      rm_min64(&bd->kx0, rm_key(x)); rm_max64(&bd->kx1, rm_key(x));
+      rm_min64(&bd->ky0, rm_key(y)); rm_max64(&bd->ky1, rm_key(y));
+    } else {
+      rm_irregular(a, c)[s] = 1;
+      for (int cp = 0; cp < a.ncopy; ++cp) {   // (the bounds of such a sprite's copies are OR-ed in below, point by point)
+        int ix, iy;
+        rm_copy_point(a, x, y, cp, &ix, &iy);
+        const int g = s * a.ncopy + cp;
+        rm_min(&c.item_y[2 * g], iy); rm_max(&c.item_y[2 * g + 1], iy);
+      }
+    }
+  }
+}
+
+// A polygon whose points all lie two or more pixels beside the canvas paints nothing: its crossings are float32
+// interpolations between such points (off by far less than a pixel at these magnitudes), its heads lie between them.
+RM_FN void rm_t2_items(const RmArgs& a, const RmCtx& c, int lane) {
+  int run = 0;
+#if RM_DEV
+  for (int i0 = 0; i0 < a.S; i0 += 64) {
+    const int g = i0 + lane;
+    const bool in = g < a.S;
+#else
+  (void)lane;
+  for (int g = 0; g < a.S; ++g) {
+    const bool in = true;
+#endif
+    int nvl = 0;
+    if (in) {
+      nvl = c.info[g].pb_nv >> 20;
+      const int s = g / a.ncopy, cp = g - s * a.ncopy;
+      const RmBounds bd = rm_bounds(c)[s];
+      const bool irregular = rm_irregular(a, c)[s] != 0;
+      int y0 = c.item_y[2 * g], y1 = c.item_y[2 * g + 1];   // (what the sprite's irregular vertices left, or nothing)
+      int x0 = 0x7fffffff, x1 = -0x7fffffff;
+      if (bd.kx0 <= bd.kx1) {   // the ordinary vertices: the copy's bounds from the sprite's extreme coordinates
+        int ixa, iya, ixb, iyb;
+        rm_copy_point(a, rm_unkey(bd.kx0), rm_unkey(bd.ky0), cp, &ixa, &iya);
+        rm_copy_point(a, rm_unkey(bd.kx1), rm_unkey(bd.ky1), cp, &ixb, &iyb);
+        x0 = ixa; x1 = ixb;
+        y0 = iya < y0 ? iya : y0; y1 = iyb > y1 ? iyb : y1;
+      }
+      // (an irregular sprite keeps every copy its rows put on the canvas: its x range is not tracked)
+      const bool vis = nvl > 0 && y1 >= 0 && y0 <= a.H - 1 && (irregular || (x1 >= -1 && x0 <= a.W));
+      if (vis) { c.item_y[2 * g] = y0; c.item_y[2 * g + 1] = y1; }
+      else { nvl = 0; c.item_y[2 * g] = 0x7fffffff; c.item_y[2 * g + 1] = -0x7fffffff; }
+    }
+#if RM_DEV
+    const int inc = rm_wave_scan(nvl);
+    const int first = run + inc - nvl;
+    run += __builtin_amdgcn_readlane(inc, 63);
+#else
+    const int first = run;
+    run += nvl;
+#endif
+    if (in) c.info[g].pb_nv = first | (nvl << 20);
+  }
+#if RM_DEV
+  if (lane == 0) c.misc[0] = run;
+#else
+  c.misc[0] = run;
+#endif
+}
+
+RM_FN void rm_t3_points(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
+  const moog_layout_t& L = a.L;
+  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
+  for (int idx = tid; idx < L.TOTV; idx += T) {
+    const uint32_t vi = a.vinfo[idx];
+    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
+    const double x = gf[L.o_verts + 2 * idx], y = gf[L.o_verts + 2 * idx + 1];
+    for (int cp = 0; cp < a.ncopy; ++cp) {
+      const int g = s * a.ncopy + cp;
+      const int pbnv = c.info[g].pb_nv;
+      if (k >= (pbnv >> 20)) continue;
+      int ix, iy;
+      const int ci = (pbnv & 0xfffff) + k;
+      c.ivert[ci] = rm_copy_point(a, x, y, cp, &ix, &iy);
+      c.owner[ci] = (uint8_t)g;
+    }
+  }
 }
 
 // Items below s_lo are in the cached picture of the static prefix (valid after p1's barrier)

@@ -71,10 +71,12 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
     for (int k = 0; k < P->slot_vcap[sl]; ++k) vi[P->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
   }
   a.vinfo = vi.data();
-  a.n_envs = n_envs; a.S = P->n_slots;
+  a.ncopy = P->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
+  a.n_envs = n_envs; a.slots = P->n_slots; a.S = P->n_slots * a.ncopy;
+  if (a.S > 256) return -4;
   const int cw = P->render.width, ch = P->render.height;
   a.W = (cw + 15) & ~15; a.H = ch; a.scale_w = cw; a.flip = 1;
-  if (a.W > 128 || a.H > 128 || P->render.aa > 1 || P->render.polymod == MOOG_POLYMOD_TORUS) return -3;
+  if (a.W > 128 || a.H > 128 || P->render.aa > 1) return -3;
   a.cap_rows = cap_rows < a.H ? a.H : cap_rows;
   a.iwords = (a.S + 31) / 32; if (a.iwords < 1) a.iwords = 1;
   a.cmap = P->render.cmap;
@@ -82,23 +84,30 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   if (a.first_person) { a.fp_slot0 = P->layer_slot0[P->render.polymod_layer]; a.fp_nslots = P->layer_nslots[P->render.polymod_layer]; }
   a.bg = ((uint32_t)P->render.bg[0] & 255u) | (((uint32_t)P->render.bg[1] & 255u) << 8) | (((uint32_t)P->render.bg[2] & 255u) << 16);
   a.threads = threads;
-  a.n_static = n_static; a.nsv = nsv;
-  if (n_static > 0) {
+  a.n_static = a.ncopy > 1 ? 0 : n_static; a.nsv = nsv;
+  if (a.n_static > 0) {
     a.sref_v = sref_f64 + L.o_verts; a.sref_col = sref_f64 + L.o_color;
     a.sref_flags = sref_i32 + L.o_flags; a.sref_nv = sref_i32 + L.o_nverts; a.sref_opa = sref_i32 + L.o_opacity;
     a.sbg = sbg;
   }
   a.rgb_override = rgb_override;
   const int T = threads, waves = T / 64;
-  rm_plan(a.S, L.TOTV, a.W, a.H, a.cap_rows, a.iwords, waves, &a.plan);
+  rm_plan(a.S, L.TOTV * a.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, &a.plan);
   std::vector<unsigned char> lds(a.plan.total + 64);
   const RmCtx c = rm_ctx(a.plan, lds.data());
   std::vector<RmThread> th(T);
   for (int env = 0; env < n_envs; ++env) {
     memset(lds.data(), 0xA5, lds.size());   // LDS is not zero when a workgroup starts
     for (int t = 0; t < T; ++t) rm_p0<2>(a, c, env, t, T, th[t]);
-    rm_p0_slots(a, c, env, -1, th[0]);
-    for (int t = 0; t < T; ++t) rm_p1<2>(a, c, env, t, T, th[t]);
+    if (a.ncopy > 1) {
+      rm_t0_slots(a, c, env, -1);
+      for (int t = 0; t < T; ++t) rm_t1_bounds(a, c, env, t, T);
+      rm_t2_items(a, c, -1);
+      for (int t = 0; t < T; ++t) rm_t3_points(a, c, env, t, T);
+    } else {
+      rm_p0_slots(a, c, env, -1, th[0]);
+      for (int t = 0; t < T; ++t) rm_p1<2>(a, c, env, t, T, th[t]);
+    }
     const int s_lo = rm_s_lo(a, c);
     for (int w = 0; w < waves; ++w) rm_p2_scan(a, c, s_lo, -1);
     for (int base = 0;;) {

@@ -1613,7 +1613,8 @@ def test_anti_aliasing_sweep(size, aa):
     ('colliding_predators_32', None), ('colliding_predators_32', 64), ('pong', None), ('colliding_predators', None),
     ('falling_balls', 40), ('falling_balls_64', None), ('rules_zoo', 64), ('lambda_zoo', None), ('functional_maze', None),
     ('functional_maze', 128), ('cleanup', None), ('match_to_sample_l3', None), ('predators_arena_l2', None),
-    ('parallelogram_catch', None), ('multi_tracking_with_feature_l1', None)])
+    ('parallelogram_catch', None), ('multi_tracking_with_feature_l1', None), ('chase_avoid_torus', None),
+    ('chase_avoid_torus', 64), ('aa_zoo', None)])
 def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
     """One-tile frames of polygons with <= 32 vertices are drawn by the mask rasteriser (csrc/moog_raster_mask_core.h: no
     crossing lists, census by bit mask); MOOG_RASTER_MASK=0 selects the push / sort / span kernel for every frame.  Both
@@ -1648,10 +1649,10 @@ def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
 
 def test_raster_path_by_program():
     """Which rasteriser a program's frames take (moog_engine_raster_path): the mask rasteriser for one-tile frames of
-    polygons with <= 32 vertices; multi-tile frames (pacman 256 x 256), nine-copy frames (torus) and polygons with more
-    vertices keep the span kernel."""
+    polygons with <= 32 vertices, the nine copies per sprite of a torus included; multi-tile frames (pacman 256 x 256) and
+    polygons with more vertices keep the span kernel."""
     for name, want in (('colliding_predators_32', 'mask'), ('functional_maze', 'mask'), ('falling_balls_64', 'mask'),
-                       ('pacman', 'spans'), ('chase_avoid_torus', 'spans'), ('first_person_predators_prey', 'spans')):
+                       ('pacman', 'spans'), ('chase_avoid_torus', 'mask'), ('first_person_predators_prey', 'spans')):
         env = make_env(name, 4, seed=1)
         assert env.raster_path() == want, name
         env.close()
