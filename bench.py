@@ -66,7 +66,9 @@ def raster_kernel_name(env):
     part = env.parts[0] if hasattr(env, 'parts') else env
     words = 2 if part.compiled.program.render.width > 64 else 1
     if part.raster_path() == 'mask':
-        return 'moog_raster_mask_kernel<%d> (csrc/moog_raster_mask_core.h)' % words
+        P = part.compiled.program
+        big = any(P.slot_vcap[s] > 32 for s in range(P.n_slots))   # (the instantiation with the long-polygon row routine)
+        return 'moog_raster_mask_kernel<%d, %s> (csrc/moog_raster_mask_core.h)' % (words, 'true' if big else 'false')
     return 'moog_raster_kernel<%d> (csrc/moog_raster_kernel.h)' % words
 
 

@@ -606,7 +606,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_lds = pl.total;
     { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) e->raster_lds += (size_t)atoi(pad); }  // occupancy experiments
   }
-  {   // mask rasteriser (moog_raster_mask_core.h): one-tile frames, polygons of <= 32 vertices, at most 256 polygons (a torus has nine per sprite)
+  {   // mask rasteriser (moog_raster_mask_core.h): one-tile frames, polygons of <= 128 vertices, at most 256 polygons (a torus has nine per sprite)
     RmSetup& ms = e->mask_setup;
     memset(&ms, 0, sizeof ms);
     int maxv = 1;
@@ -614,9 +614,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     const int ncopy = prog->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
     const char* sw = getenv("MOOG_RASTER_MASK");   // 0: the push / sort / span kernel for every frame (A/B runs, tests)
     ms.ok = !(sw && atoi(sw) == 0) && e->raster_tiles_x * e->raster_bands == 1 && e->pad_w <= 128 && e->canvas_h <= 128 &&
-            maxv <= RM_MAX_NV && prog->n_slots >= 1 && prog->n_slots * ncopy <= 256 && e->L.TOTV >= 1;
+            maxv <= RM_BIG_NV && prog->n_slots >= 1 && prog->n_slots * ncopy <= 256 && e->L.TOTV >= 1;
     if (ms.ok) {
-      ms.slots = prog->n_slots; ms.ncopy = ncopy;
+      ms.slots = prog->n_slots; ms.ncopy = ncopy; ms.big = maxv > RM_MAX_NV ? 1 : 0;
       ms.S = prog->n_slots * ncopy;
       ms.iwords = (ms.S + 31) / 32;
       ms.cmap = prog->render.cmap;
@@ -631,7 +631,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       if (cap < e->canvas_h) cap = e->canvas_h;
       if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
       ms.cap_rows = cap;
-      rm_plan(ms.S, e->L.TOTV * ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, &ms.plan);
+      rm_plan(ms.S, e->L.TOTV * ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, ms.big, &ms.plan);
       ms.lds = ms.plan.total;
       { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) ms.lds += (uint32_t)atoi(pad); }  // occupancy experiments
       if (ms.lds > 64 * 1024) ms.ok = 0;

@@ -52,7 +52,7 @@ struct RPlan {   // LDS carve-up (byte offsets), computed once on the host
 // ordinary frames (not the prefix pictures, not draw-list or per-env-prefix frames) with that kernel.
 struct RmSetup {
   int32_t ok;
-  int32_t S, slots, ncopy, cap_rows, iwords, cmap, first_person, fp_slot0, fp_nslots;
+  int32_t S, slots, ncopy, big, cap_rows, iwords, cmap, first_person, fp_slot0, fp_nslots;
   uint32_t bg;
   RmPlan plan;
   uint32_t lds;

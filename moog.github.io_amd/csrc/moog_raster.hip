@@ -21,7 +21,7 @@ static RmArgs mask_args(const RArgs& r) {
   RmArgs a;
   memset(&a, 0, sizeof a);
   a.P = r.P; a.L = r.L; a.f64 = r.f64; a.i32 = r.i32; a.image = r.image; a.vinfo = r.vinfo;
-  a.n_envs = r.n_envs; a.S = r.ms.S; a.slots = r.ms.slots; a.ncopy = r.ms.ncopy; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h; a.scale_w = r.scale_w;
+  a.n_envs = r.n_envs; a.S = r.ms.S; a.slots = r.ms.slots; a.ncopy = r.ms.ncopy; a.big = r.ms.big; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h; a.scale_w = r.scale_w;
   a.flip = r.flip; a.iwords = r.ms.iwords; a.cmap = r.ms.cmap; a.first_person = r.ms.first_person;
   a.fp_slot0 = r.ms.fp_slot0; a.fp_nslots = r.ms.fp_nslots; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
   a.n_static = r.n_static; a.nsv = r.nsv; a.sref_v = r.sref_v; a.sref_col = r.sref_col; a.sref_flags = r.sref_flags;

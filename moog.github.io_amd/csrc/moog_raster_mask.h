@@ -9,7 +9,9 @@
 
 extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
-template <int WORDS>
+// BIG: the program has slots for polygons of more than RM_MAX_NV vertices (rm_p4_big); a kernel of its own so that everybody
+// else's keeps its registers
+template <int WORDS, bool BIG>
 __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mask_kernel(RmArgs a) {
   const int env = (int)blockIdx.x;
   if (env >= a.n_envs) return;
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
       rm_p4b(c, total_rows, tid, RM_THREADS, sk);
       __syncthreads();
     }
-    rm_p4<WORDS>(a, c, total_rows, tid, RM_THREADS, c.xx + (tid >> 6) * RM_XX);
+    rm_p4<WORDS>(a, c, total_rows, tid, RM_THREADS, c.xx + (tid >> 6) * a.plan.xx_stride);
+    if (BIG) rm_p4_big<WORDS>(a, c, tid, RM_THREADS, c.xx + (tid >> 6) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + (RM_THREADS / 64) * a.plan.xx_stride));
     __syncthreads();
     if (a.debug_stop == 5) return;
     rm_p5<WORDS>(a, c, env, base == 0, s_lo, tid, RM_THREADS);
@@ -71,18 +74,20 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
 }
 
 static inline int moog_raster_mask_configure(size_t lds_bytes) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (err == hipSuccess)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  const void* const kernels[4] = {reinterpret_cast<const void*>(moog_raster_mask_kernel<1, false>), reinterpret_cast<const void*>(moog_raster_mask_kernel<2, false>),
+                                  reinterpret_cast<const void*>(moog_raster_mask_kernel<1, true>), reinterpret_cast<const void*>(moog_raster_mask_kernel<2, true>)};
+  hipError_t err = hipSuccess;
+  for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return (int)err;
 }
 
 static inline void moog_raster_mask_launch(const RmArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs);
-  if (a.W > 64) hipLaunchKernelGGL(moog_raster_mask_kernel<2>, grid, dim3(RM_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL(moog_raster_mask_kernel<1>, grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  if (a.big) {
+    if (a.W > 64) hipLaunchKernelGGL((moog_raster_mask_kernel<2, true>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL((moog_raster_mask_kernel<1, true>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  } else if (a.W > 64) hipLaunchKernelGGL((moog_raster_mask_kernel<2, false>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL((moog_raster_mask_kernel<1, false>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
 }
 
 #endif  // MOOG_RASTER_MASK_H_

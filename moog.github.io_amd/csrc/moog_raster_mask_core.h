@@ -41,9 +41,11 @@
 #endif
 #if defined(__HIPCC__)
 #define RM_FN __host__ __device__ __forceinline__
+#define RM_MEMBER __host__ __device__ __forceinline__
 #define RM_SLOW __host__ __device__ __noinline__
 #else
 #define RM_FN static inline
+#define RM_MEMBER inline
 #define RM_SLOW static
 #endif
 #if RM_DEV
@@ -60,8 +62,9 @@
 #ifndef RM_WAVES_PER_SIMD
 #define RM_WAVES_PER_SIMD 5   // register budget: 96 VGPRs
 #endif
-#define RM_MAX_NV 32          // vertices per polygon (edge index = bit of a census word)
-#define RM_XX 64              // crossing-list capacity of the generic row routine (2 per edge)
+#define RM_MAX_NV 32          // vertices per polygon whose rows go by census words (edge index = bit of a word)
+#define RM_BIG_NV 128         // vertices per polygon at most: longer ones (the 102-vertex annuli) take the cooperative row routine
+#define RM_XX (2 * RM_BIG_NV)  // crossing-list capacity of the generic row routine (2 per edge)
 
 struct alignas(16) RmEdge { uint32_t w0, w1, w2, w3; };   // table edge: float x0 | float dx | y0, y1 (shorts) | 0;  head: xmin, xmax (shorts) | 0 | y, y | 1
 struct alignas(16) RmRow { uint32_t act, heads, tipP, tipN; };   // census of a (polygon, row); after the row phase w0.. = the coverage mask
@@ -69,7 +72,7 @@ struct alignas(16) RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint3
 
 struct alignas(16) RmU4 { uint32_t x, y, z, w; };
 
-struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, total; };
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, xx_stride, total; };   // xx_stride: floats of scratch per wavefront
 
 struct RmArgs {
   const moog_program_t* P;
@@ -81,6 +84,7 @@ struct RmArgs {
   int32_t n_envs;
   int32_t S;                  // items (polygons a frame may hold): slots * ncopy
   int32_t slots;              // sprite slots
+  int32_t big;                // some slot may hold a polygon of more than RM_MAX_NV vertices (rm_p4_big)
   int32_t ncopy;              // 1, or 9: polygon_modifiers.py TorusGeometry draws every sprite at the 3 x 3 offsets -1, 0, 1
   int32_t cap_rows;           // row records per pass (>= H)
   int32_t W, H;               // the canvas in memory (width a multiple of 16, <= 128)
@@ -106,7 +110,7 @@ struct RmArgs {
 static inline uint32_t rm_align(uint32_t x) { return (x + 15u) & ~15u; }
 
 // S: items; TOTV: vertex slots of all items (the program's vertex slots x copies)
-static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, RmPlan* p) {
+static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, int big, RmPlan* p) {
   uint32_t o = 0;
   p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
   p->o_ivert = o; o = rm_align(o + (uint32_t)TOTV * 4u);
@@ -118,7 +122,8 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_rowoff = o; o = rm_align(o + (uint32_t)(S + 1) * 4u);
   p->o_seg = o; o = rm_align(o + (uint32_t)H * (uint32_t)(W / 16) * (uint32_t)iwords * 4u);
   p->o_lut = o; o = rm_align(o + 16u * 16u);
-  p->o_xx = o; o = rm_align(o + (uint32_t)waves * RM_XX * 4u);
+  p->xx_stride = big ? (uint32_t)RM_XX : 2u * RM_MAX_NV;   // per wave: the generic routine's crossing list (two entries per edge); for long polygons also rm_big_row's edge list and census words
+  p->o_xx = o; o = rm_align(o + (uint32_t)waves * p->xx_stride * 4u + (big ? (uint32_t)waves * 64u * RM_MAX_NV : 0u));   // + a list of edge numbers per thread (rm_p4_big)
   p->o_misc = o; o = rm_align(o + 64u);
   p->o_owner = o; o = rm_align(o + (uint32_t)TOTV);   // the slot of every compact vertex number
   {   // a word per thread (p3) / the sorted row list (p4)
@@ -282,8 +287,8 @@ RM_FN int rm_build_edge(const uint32_t* pv, int k, int nv, RmEdge* out) {
 // ---- one row of one polygon ---------------------------------------------------------------------------------------------
 // polygon_generic verbatim for one row (any number of crossings, overwritten partner entries, odd counts): the rare rows.
 // xx: RM_XX floats of scratch.
-template <int WORDS>
-RM_SLOW RmMask<WORDS> rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, int y, int pymax, float* xx) {   // (the mask comes back in registers: a reference would put the caller's copy in scratch memory)
+template <int WORDS, class PE>
+RM_SLOW RmMask<WORDS> rm_row_generic(const PE pe, int nv, uint32_t heads, int y, int pymax, float* xx) {   // nv > RM_MAX_NV: `heads` is ignored, the heads of the row are found by looking   // (the mask comes back in registers: a reference would put the caller's copy in scratch memory)
   RmMask<WORDS> m;
   rm_clear(m);
   int j = 0;
@@ -355,9 +360,12 @@ RM_SLOW RmMask<WORDS> rm_row_generic(const RmEdge* pe, int nv, uint32_t heads, i
     }
     {   // draw_horizontal_lines: every head of the row, in edge order
       uint32_t hb = heads;
-      while (hb) {
-        const int k = rm_ffs(hb);
-        hb &= hb - 1u;
+      const bool scan = nv > RM_MAX_NV;
+      int ks = 0;
+      while (scan ? ks < nv : hb != 0u) {
+        int k;
+        if (scan) { k = ks++; if (pe[k].w3 != 1u || rm_y0(pe[k]) != y) continue; }
+        else { k = rm_ffs(hb); hb &= hb - 1u; }
         const RmEdge h = pe[k];
         int xmin = (int16_t)(h.w0 & 0xffffu);
         const int xmax = (int16_t)(h.w0 >> 16);
@@ -394,7 +402,8 @@ RM_FN void rm_fix_put(RmFix& f, int k, float v) {
   else if (f.k1 < 0) { f.k1 = k; f.v1 = v; }
   else f.generic = true;
 }
-RM_FN void rm_fix_class(const RmEdge* pe, uint32_t m, int y, RmFix& f) {
+template <class PE>
+RM_FN void rm_fix_class(const PE pe, uint32_t m, int y, RmFix& f) {
   uint32_t rest = m & (m - 1u);
   while (rest) {
     const int i = rm_ffs(rest);
@@ -428,8 +437,8 @@ RM_FN void rm_fix_class(const RmEdge* pe, uint32_t m, int y, RmFix& f) {
 // draw_horizontal_lines with the pen at `pen`: heads that start behind the pen (or any head when the row has no
 // crossing: pen == -1) are painted from the pen on and move it; the others stay pending.  x_pos only grows, so a head
 // that was looked at with the pen at or behind its start is finished whether or not anything was painted.
-template <int WORDS>
-RM_FN void rm_heads(const RmEdge* pe, uint32_t& hb, int& pen, RmMask<WORDS>& m) {
+template <int WORDS, class PE>
+RM_FN void rm_heads(const PE pe, uint32_t& hb, int& pen, RmMask<WORDS>& m) {
   uint32_t bits = hb;
   while (bits) {
     const int k = rm_ffs(bits);
@@ -446,8 +455,8 @@ RM_FN void rm_heads(const RmEdge* pe, uint32_t& hb, int& pen, RmMask<WORDS>& m) 
 }
 
 // The crossings of a row, accumulated (see the head of the file).  HEADS: also where the spans end (seen / seen2).
-template <int WORDS, bool HEADS>
-RM_FN void rm_crossings(const RmEdge* pe, uint32_t m, int y, int pymax, int W, const RmFix& fix, RmMask<WORDS>& par, RmMask<WORDS>& pix,
+template <int WORDS, bool HEADS, class PE>
+RM_FN void rm_crossings(const PE pe, uint32_t m, int y, int pymax, int W, const RmFix& fix, RmMask<WORDS>& par, RmMask<WORDS>& pix,
                         RmMask<WORDS>& seen, RmMask<WORDS>& seen2, bool& odd) {
   const float wlim = (float)(W - 1);
   const bool anyheads = HEADS;
@@ -499,8 +508,8 @@ RM_FN void rm_crossings(const RmEdge* pe, uint32_t m, int y, int pymax, int W, c
 }
 
 // The coverage mask of row y of a polygon from its census record.  Returns false when the row needs rm_row_generic.
-template <int WORDS>
-RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int W, bool shallow, RmMask<WORDS>& out) {
+template <int WORDS, class PE>
+RM_FN bool rm_row_fast(const PE pe, const RmRow rec, int y, int pymax, int W, bool shallow, RmMask<WORDS>& out) {
   RmFix fix; fix.k0 = -1; fix.k1 = -1; fix.v0 = 0.0f; fix.v1 = 0.0f; fix.generic = false;
   {
     // (shallow: some edge with a corner on this row runs >= 1.49 pixels per row -- without one no fix-up moves anything)
@@ -538,12 +547,12 @@ RM_FN bool rm_row_fast(const RmEdge* pe, const RmRow rec, int y, int pymax, int 
           const int e = 64 * i + __builtin_ctzll(ends);
           ends &= ends - 1ull;
           if (e < pen) continue;
-          rm_heads<WORDS>(pe, hb, pen, res);
+          rm_heads<WORDS, PE>(pe, hb, pen, res);
           if (e < pen) continue;
           pen = e + 1;
         }
       }
-      rm_heads<WORDS>(pe, hb, pen, res);
+      rm_heads<WORDS, PE>(pe, hb, pen, res);
       for (int i = 0; i < WORDS; ++i) out.w[i] = res.w[i] & rm_low(W - 64 * i);
     }
   }
@@ -595,7 +604,7 @@ RM_FN void rm_p0(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
     c.lut[4 * tid + 2] = (p2 ? 0x000000ffu : 0u) | (p3 ? 0xffffff00u : 0u);
     c.lut[4 * tid + 3] = 0u;
   }
-  if (tid < 12) c.misc[tid] = 0;   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort)
+  if (tid < 13) c.misc[tid] = 0;   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort, [12] rows of long polygons)
   if (a.first_person) {   // polygon_modifiers.py:41-64: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
     for (int s = a.fp_slot0; s < a.fp_slot0 + a.fp_nslots; ++s)
       if (gq[L.o_flags + s] & MOOG_F_ALIVE) { th.fpx = 0.5 - gf[L.o_pos + 2 * s]; th.fpy = 0.5 - gf[L.o_pos + 2 * s + 1]; break; }
@@ -639,7 +648,7 @@ RM_FN void rm_p0_slots(const RmArgs& a, const RmCtx& c, int env, int lane, RmThr
         else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
         else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
         rgba = rgb | (((uint32_t)opa & 255u) << 24);
-        nvl = nvs < 0 ? 0 : (nvs > RM_MAX_NV ? RM_MAX_NV : nvs);
+        nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
       }
     }
 #if RM_DEV
@@ -747,7 +756,7 @@ RM_FN void rm_t0_slots(const RmArgs& a, const RmCtx& c, int env, int lane) {
       else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
       else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
       rgba = rgb | (((uint32_t)opa & 255u) << 24);
-      nvl = nvs < 0 ? 0 : (nvs > RM_MAX_NV ? RM_MAX_NV : nvs);
+      nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
     }
     for (int cp = 0; cp < a.ncopy; ++cp) {
       const int g = s * a.ncopy + cp;
@@ -952,6 +961,11 @@ RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, i
     const int nv = it.pb_nv >> 20, k = idx - (it.pb_nv & 0xfffff);
     const bool live = true;
     const bool mine = s >= lo && s < end;
+    // A long polygon's row record is ONE 128-bit word: which of its edges cross the row or are heads on it (what kind, the row's
+    // thread reads off the edge records: rm_p4_big).  A short polygon's is four 32-bit words, one per kind.
+    const bool lng = mine && nv > RM_MAX_NV;
+    const bool census = mine && !lng;
+    const int wsel = lng ? (k >> 5) : 0;
     const uint32_t* pv = c.ivert + (idx - k);
     const uint32_t q0 = pv[k], q1 = pv[(k + 1 >= nv) ? 0 : k + 1];
     const int x0 = (int16_t)(q0 & 0xffffu), y0 = (int16_t)(q0 >> 16), x1 = (int16_t)(q1 & 0xffffu), y1 = (int16_t)(q1 >> 16);
@@ -968,7 +982,7 @@ RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, i
       if (horiz) head = rm_build_edge(pv, k, nv, &E) == 2;
     }
     if (live) c.edges[idx] = E;   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
-    const uint32_t bit = 1u << k;
+    const uint32_t bit = 1u << (k & 31);
     RmRow* rr = c.rows + it.rowbase;
     const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
     const int ya = emin < 0 ? 0 : emin, yb = emax > a.H - 1 ? a.H - 1 : emax;
@@ -977,15 +991,15 @@ RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, i
       const int last = any ? yb : ya - 1;
       for (int y = ya; RM_ANY(y <= last); ++y) {
         const bool on = y <= last;
-        rm_or(on ? &rr[y].act : spare, on ? bit : 0u);
+        rm_or(on ? &rr[y].act + wsel : spare, on ? bit : 0u);   // (RmRow = four consecutive words)
       }
     }
     {   // a head's row
       const bool on = head && y0 >= 0 && y0 < a.H;
-      rm_or(on ? &rr[y0].heads : spare, on ? bit : 0u);
+      rm_or(on ? (lng ? &rr[y0].act + wsel : &rr[y0].heads) : spare, on ? bit : 0u);
     }
     {   // rows on which the corner fix-up looks at this edge: its first row; its last if that is the polygon's
-      const bool lean = table && dx != 0.0f, pos = dx > 0.0f;
+      const bool lean = census && table && dx != 0.0f, pos = dx > 0.0f;
       const bool t0 = lean && emin >= 0 && emin < a.H;
       const bool t1 = lean && emax == it.pymax && emax >= 0 && emax < a.H;
       rm_or(t0 ? (pos ? &rr[emin].tipP : &rr[emin].tipN) : spare, t0 ? bit : 0u);
@@ -1028,10 +1042,14 @@ RM_FN void rm_p4a(const RmCtx& c, int total_rows, int tid, int T, RmSortKey& sk)
     if (r * T >= total_rows) break;
     const int w = r * T + tid;
     const bool on = w < total_rows;
-    int key = 4;
-    if (on) { const RmRow rec = c.rows[w]; key = rm_row_bucket(rec, (c.rowitem[w] >> 8) != 0); }
+    int key = 5;
+    if (on) {
+      const RmRow rec = c.rows[w];
+      const int ri = c.rowitem[w];
+      key = (c.info[ri & 255].pb_nv >> 20) > RM_MAX_NV ? 4 : rm_row_bucket(rec, (ri >> 8) != 0);   // 4: a long polygon's row (rm_p4_big)
+    }
     int pos = 0;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 5; ++b) {
       const unsigned long long mb = __ballot(key == b);
       int base = 0;
       if (lane == 0 && mb) base = atomicAdd(&c.misc[8 + b], __builtin_popcountll(mb));
@@ -1044,9 +1062,14 @@ RM_FN void rm_p4a(const RmCtx& c, int total_rows, int tid, int T, RmSortKey& sk)
   (void)sk; (void)T;
   if (tid != 0) return;   // host model: thread 0 sorts the whole pass
   int cnt[4] = {0, 0, 0, 0}, start[4];
-  for (int w = 0; w < total_rows; ++w) cnt[rm_row_bucket(c.rows[w], (c.rowitem[w] >> 8) != 0)]++;
+  auto bucket = [&](int w) { return (c.info[c.rowitem[w] & 255].pb_nv >> 20) > RM_MAX_NV ? 4 : rm_row_bucket(c.rows[w], (c.rowitem[w] >> 8) != 0); };
+  for (int w = 0; w < total_rows; ++w) if (bucket(w) < 4) cnt[bucket(w)]++;
   start[0] = 0; for (int b = 1; b < 4; ++b) start[b] = start[b - 1] + cnt[b - 1];
-  for (int w = 0; w < total_rows; ++w) c.sorted[start[rm_row_bucket(c.rows[w], (c.rowitem[w] >> 8) != 0)]++] = (uint16_t)w;
+  for (int w = 0; w < total_rows; ++w) if (bucket(w) < 4) c.sorted[start[bucket(w)]++] = (uint16_t)w;
+  for (int b = 0; b < 4; ++b) c.misc[8 + b] = cnt[b];
+  int nb = 0;
+  for (int w = 0; w < total_rows; ++w) if (bucket(w) == 4) c.sorted[cnt[0] + cnt[1] + cnt[2] + cnt[3] + nb++] = (uint16_t)w;
+  c.misc[12] = nb;
 #endif
 }
 
@@ -1056,8 +1079,8 @@ RM_FN void rm_p4b(const RmCtx& c, int total_rows, int tid, int T, const RmSortKe
   for (int r = 0; r < RM_SORT_ROUNDS; ++r) {
     if (r * T >= total_rows) break;
     const int key = sk.key[r];
-    const int start = key == 0 ? 0 : (key == 1 ? n0 : (key == 2 ? n0 + n1 : n0 + n1 + n2));
-    if (key < 4) c.sorted[start + sk.pos[r]] = (uint16_t)(r * T + tid);
+    const int start = key == 0 ? 0 : (key == 1 ? n0 : (key == 2 ? n0 + n1 : (key == 3 ? n0 + n1 + n2 : n0 + n1 + n2 + c.misc[11])));
+    if (key < 5) c.sorted[start + sk.pos[r]] = (uint16_t)(r * T + tid);
   }
 #else
   (void)c; (void)total_rows; (void)tid; (void)T; (void)sk;
@@ -1068,8 +1091,10 @@ RM_FN void rm_p4b(const RmCtx& c, int total_rows, int tid, int T, const RmSortKe
 template <int WORDS>
 RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T, float* xx_wave) {
   const int nseg = a.W >> 4;
-  for (int w0 = 0; w0 < total_rows; w0 += T) {
-    const bool on = w0 + tid < total_rows;
+  (void)total_rows;
+  const int sorted_rows = c.misc[8] + c.misc[9] + c.misc[10] + c.misc[11];   // (the pass's rows but those of long polygons)
+  for (int w0 = 0; w0 < sorted_rows; w0 += T) {
+    const bool on = w0 + tid < sorted_rows;
     const int w = on ? c.sorted[w0 + tid] : 0;
     RmRow rec = {0u, 0u, 0u, 0u};
     RmItem it = {0, 0, 0, 0u};
@@ -1099,6 +1124,105 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
     }
 #else
     if (on && !ok) m = rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
+#endif
+    if (on) {
+      uint64_t* mp = reinterpret_cast<uint64_t*>(c.rows + w);
+      mp[0] = m.w[0];
+      if (WORDS > 1) mp[1] = m.w[1];
+      for (int sg = 0; sg < nseg; ++sg) {
+        const uint64_t mw = m.w[WORDS > 1 ? (sg >> 2) : 0];
+        if ((mw >> ((sg & 3) * 16)) & 0xffffull) rm_or(&c.seg[(y * nseg + sg) * a.iwords + (g >> 5)], 1u << (g & 31));
+      }
+    }
+  }
+}
+
+// ---- long polygons (RM_MAX_NV < nv <= RM_BIG_NV: the 102-vertex annuli of the reference's fixation screens) ----------------
+// A census word has 32 bits, so p3 leaves ONE 128-bit word per row of such a polygon: the edges that cross the row and the heads
+// that lie on it.  Their rows come behind the others in the sorted list (bucket 4) and take a thread each like them: the thread
+// walks the set bits, reads off every such edge's record what it is on this row (crossing, head, corner of which lean) and
+// notes it in a list of edge numbers of its own (32 bytes of LDS), with the four census words over the list's positions.  polygon_generic only ever looks at a
+// row's active edges and heads, in order, so the row routines of the short polygons run on the list unchanged (RmIndexed).
+// A row with more than RM_MAX_NV such edges (a comb) goes to rm_row_generic over the whole polygon.
+struct RmIndexed {
+  const RmEdge* pe; const uint8_t* idx;
+  RM_MEMBER RmEdge operator[](int k) const { return pe[idx[k]]; }
+};
+// what an edge record says about row y without any arithmetic: a crossing, a head on the row, a corner the fix-up looks at
+RM_FN void rm_big_classify(const RmEdge& E, int y, int pymax, bool& cross, bool& head, bool& tip_p, bool& tip_n, bool& shallow) {
+  cross = false; head = false; tip_p = false; tip_n = false; shallow = false;
+  const int y0 = rm_y0(E), y1 = rm_y1(E);
+  if (E.w3 == 1u) { head = (y0 == y); return; }
+  if (y0 == y1) return;
+  const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
+  if (y < emin || y > emax) return;
+  cross = true;
+  const float dx = rm_u2f(E.w1);
+  const bool corner = (y == emin) || (y == emax && emax == pymax);
+  if (dx != 0.0f && corner) { tip_p = dx > 0.0f; tip_n = !tip_p; shallow = fabsf(dx) >= 1.49f; }
+}
+
+// idx_all: 32 bytes per thread of the frame (behind the waves' crossing lists)
+template <int WORDS>
+RM_FN void rm_p4_big(const RmArgs& a, const RmCtx& c, int tid, int T, float* xx_wave, uint8_t* idx_all) {
+  const int nseg = a.W >> 4;
+  const int first = c.misc[8] + c.misc[9] + c.misc[10] + c.misc[11], nbig = c.misc[12];
+  uint8_t* const idx = idx_all + 32 * tid;
+  for (int w0 = 0; w0 < nbig; w0 += T) {
+    const bool on = w0 + tid < nbig;
+    const int w = on ? c.sorted[first + w0 + tid] : 0;
+    RmItem it = {0, 0, 0, 0u};
+    int g = 0;
+    if (on) { g = c.rowitem[w] & 255; it = c.info[g]; }
+    const int y = w - it.rowbase, nv = on ? (it.pb_nv >> 20) : 0;
+    const RmEdge* pe = c.edges + (it.pb_nv & 0xfffff);
+    RmRow rec = {0u, 0u, 0u, 0u};
+    bool shallow = false;
+    int n_rel = 0;
+    uint32_t bw[4] = {0u, 0u, 0u, 0u};
+    if (on) { const RmRow r = c.rows[w]; bw[0] = r.act; bw[1] = r.heads; bw[2] = r.tipP; bw[3] = r.tipN; }   // the row's 128-bit word
+    const int n_all = __builtin_popcount(bw[0]) + __builtin_popcount(bw[1]) + __builtin_popcount(bw[2]) + __builtin_popcount(bw[3]);
+    if (n_all <= RM_MAX_NV) {
+      for (int q = 0; q < 4; ++q) {
+        uint32_t mq = q * 32 < nv ? bw[q] : 0u;
+        if (RM_ANY(mq != 0u)) do {   // (wave-uniform loop: a lane without a bit left goes through the motions on edge 0)
+          const bool valid = mq != 0u;
+          const int k = valid ? q * 32 + rm_ffs(mq) : 0;
+          mq &= mq - 1u;
+          bool cr, hd, tp, tn, sh;
+          rm_big_classify(pe[k], y, it.pymax, cr, hd, tp, tn, sh);
+          if (valid) {
+            idx[n_rel] = (uint8_t)k;
+            const uint32_t bit = 1u << n_rel;
+            rec.act |= cr ? bit : 0u; rec.heads |= hd ? bit : 0u; rec.tipP |= tp ? bit : 0u; rec.tipN |= tn ? bit : 0u;
+            shallow = shallow || sh;
+            ++n_rel;
+          }
+        } while (RM_ANY(mq != 0u));
+      }
+    } else n_rel = n_all;
+    RmIndexed list; list.pe = pe; list.idx = idx;
+    RmMask<WORDS> m;
+    rm_clear(m);
+    const bool all = on && n_rel > RM_MAX_NV;
+    if (all) { rec.act = 0u; rec.heads = 0u; rec.tipP = 0u; rec.tipN = 0u; }
+    const bool ok = rm_row_fast<WORDS, RmIndexed>(list, rec, y, it.pymax, a.W, shallow, m);
+#if RM_DEV
+    unsigned long long gm = __ballot(on && (all || !ok));
+    while (gm) {   // the rare rows, one at a time (they share the wave's scratch list)
+      const int l = __builtin_ctzll(gm);
+      gm &= gm - 1ull;
+      if ((tid & 63) == l) {
+        if (all) m = rm_row_generic<WORDS, const RmEdge*>(pe, nv, 0u, y, it.pymax, xx_wave);
+        else m = rm_row_generic<WORDS, RmIndexed>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
+      }
+    }
+#else
+    if (on && all) m = rm_row_generic<WORDS, const RmEdge*>(pe, nv, 0u, y, it.pymax, xx_wave);
+    else if (on && !ok) m = rm_row_generic<WORDS, RmIndexed>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
+#if defined(RM_STATS)
+    if (on) { rm_stats[1] += (all || !ok) ? 1 : 0; rm_stats[10] += 1; rm_stats[11] += all ? 1 : 0; }
+#endif
 #endif
     if (on) {
       uint64_t* mp = reinterpret_cast<uint64_t*>(c.rows + w);
@@ -1205,7 +1329,7 @@ RM_FN void rm_p5(const RmArgs& a, const RmCtx& c, int env, bool first_pass, int 
 
 // Later passes start from clean row records / segment words
 RM_FN void rm_next_pass(const RmArgs& a, const RmCtx& c, int tid, int T) {
-  if (tid < 4) c.misc[8 + tid] = 0;
+  if (tid < 5) c.misc[8 + tid] = 0;
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;

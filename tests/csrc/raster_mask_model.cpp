@@ -13,7 +13,7 @@ extern "C" {
 // One polygon of n integer canvas points on a W x H canvas -> cov[H][W] (0 / 1).  mode 0: the fast row routine with the
 // generic one as its fallback (the kernel's behaviour), 1: generic only.  stats[0] += rows, stats[1] += generic rows.
 int rm_model_polygon(const int* xy, int n, int W, int H, uint8_t* cov, int mode, long long* stats) {
-  if (n < 1 || n > RM_MAX_NV || W > 128) return -1;
+  if (n < 1 || n > RM_MAX_NV || W > 128) return -1;   // (long polygons: rm_model_frames)
   std::vector<uint32_t> pv(n);
   int ymin = 0x7fffffff, ymax = -0x7fffffff;
   for (int k = 0; k < n; ++k) {
@@ -67,7 +67,8 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   a.P = P; a.L = L; a.f64 = f64; a.i32 = i32; a.image = image;
   std::vector<uint32_t> vi((size_t)(L.TOTV > 0 ? L.TOTV : 1), 0u);
   for (int sl = 0; sl < P->n_slots; ++sl) {
-    if (P->slot_vcap[sl] > RM_MAX_NV) return -2;
+    if (P->slot_vcap[sl] > RM_BIG_NV) return -2;
+    if (P->slot_vcap[sl] > RM_MAX_NV) a.big = 1;
     for (int k = 0; k < P->slot_vcap[sl]; ++k) vi[P->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
   }
   a.vinfo = vi.data();
@@ -92,7 +93,7 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   }
   a.rgb_override = rgb_override;
   const int T = threads, waves = T / 64;
-  rm_plan(a.S, L.TOTV * a.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, &a.plan);
+  rm_plan(a.S, L.TOTV * a.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan);
   std::vector<unsigned char> lds(a.plan.total + 64);
   const RmCtx c = rm_ctx(a.plan, lds.data());
   std::vector<RmThread> th(T);
@@ -117,12 +118,14 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
       if (a.W > 64) {
         for (int t = 0; t < T; ++t) rm_p3<2>(a, c, base, end, s_lo, t, T);
         { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
-        for (int t = 0; t < T; ++t) rm_p4<2>(a, c, total_rows, t, T, c.xx + (t / 64) * RM_XX);
+        for (int t = 0; t < T; ++t) rm_p4<2>(a, c, total_rows, t, T, c.xx + (t / 64) * a.plan.xx_stride);
+        if (a.big) for (int t = 0; t < T; ++t) rm_p4_big<2>(a, c, t, T, c.xx + (t / 64) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + waves * a.plan.xx_stride));
         for (int t = 0; t < T; ++t) rm_p5<2>(a, c, env, base == 0, s_lo, t, T);
       } else {
         for (int t = 0; t < T; ++t) rm_p3<1>(a, c, base, end, s_lo, t, T);
         { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
-        for (int t = 0; t < T; ++t) rm_p4<1>(a, c, total_rows, t, T, c.xx + (t / 64) * RM_XX);
+        for (int t = 0; t < T; ++t) rm_p4<1>(a, c, total_rows, t, T, c.xx + (t / 64) * a.plan.xx_stride);
+        if (a.big) for (int t = 0; t < T; ++t) rm_p4_big<1>(a, c, t, T, c.xx + (t / 64) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + waves * a.plan.xx_stride));
         for (int t = 0; t < T; ++t) rm_p5<1>(a, c, env, base == 0, s_lo, t, T);
       }
       if (stats) { stats[0] += total_rows; stats[2]++; for (int q = 1; q < 16; ++q) if (q != 2) { if (q == 9) { if (rm_stats[q] > stats[q]) stats[q] = rm_stats[q]; } else stats[q] += rm_stats[q]; rm_stats[q] = 0; } }

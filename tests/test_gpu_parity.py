@@ -1616,7 +1616,7 @@ def test_anti_aliasing_sweep(size, aa):
     ('parallelogram_catch', None), ('multi_tracking_with_feature_l1', None), ('chase_avoid_torus', None),
     ('chase_avoid_torus', 64), ('aa_zoo', None)])
 def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
-    """One-tile frames of polygons with <= 32 vertices are drawn by the mask rasteriser (csrc/moog_raster_mask_core.h: no
+    """One-tile frames of polygons with <= 128 vertices are drawn by the mask rasteriser (csrc/moog_raster_mask_core.h: no
     crossing lists, census by bit mask); MOOG_RASTER_MASK=0 selects the push / sort / span kernel for every frame.  Both
     must give the same frames, bit for bit -- frames that come with a step, frames of uploaded state, frames after resets
     -- also when the row records are capped so that frames take several passes."""
@@ -1629,7 +1629,7 @@ def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
         monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
     env = make_env(name, n, seed=31, env_index0=17)
     if env.raster_path() != 'mask':
-        pytest.skip('the program keeps the span kernel (multi-tile frames, polygons with more than 32 vertices)')
+        pytest.skip('the program keeps the span kernel (multi-tile frames)')
     a0 = ref.reset().observation['image'].cpu().numpy()
     a1 = env.reset().observation['image'].cpu().numpy()
     assert np.array_equal(a0, a1), 'frames of the reset differ'
@@ -1649,10 +1649,11 @@ def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
 
 def test_raster_path_by_program():
     """Which rasteriser a program's frames take (moog_engine_raster_path): the mask rasteriser for one-tile frames of
-    polygons with <= 32 vertices, the nine copies per sprite of a torus included; multi-tile frames (pacman 256 x 256) and
-    polygons with more vertices keep the span kernel."""
+    polygons with <= 128 vertices (the 102-vertex annuli take its cooperative row routine), the nine copies per sprite of a
+    torus included; multi-tile frames (pacman 256 x 256) and frames whose tables outgrow 64 KB of LDS keep the span kernel."""
     for name, want in (('colliding_predators_32', 'mask'), ('functional_maze', 'mask'), ('falling_balls_64', 'mask'),
-                       ('pacman', 'spans'), ('chase_avoid_torus', 'mask'), ('first_person_predators_prey', 'spans')):
+                       ('pacman', 'spans'), ('chase_avoid_torus', 'mask'), ('match_to_sample_l3', 'mask'),
+                       ('first_person_predators_prey', 'mask')):
         env = make_env(name, 4, seed=1)
         assert env.raster_path() == want, name
         env.close()

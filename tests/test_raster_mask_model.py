@@ -134,7 +134,8 @@ def model_frames(m, c, f64, i32, cap_rows, static=None, threads=128):
 
 @pytest.mark.parametrize('name,cap_rows', [('colliding_predators_32', 192), ('colliding_predators_32', 64), ('functional_maze', 128),
                                            ('falling_balls_64', 100), ('pong', 192), ('cleanup', 128),
-                                           ('chase_avoid_torus', 192), ('chase_avoid_torus', 64)])
+                                           ('chase_avoid_torus', 192), ('chase_avoid_torus', 64), ('match_to_sample_l3', 192),
+                                           ('parallelogram_catch', 96), ('multi_tracking_with_feature_l3', 192)])
 def test_model_frames_vs_oracle(model, name, cap_rows):
     """Whole frames through the kernel's phases (the row records capped so that frames take several passes),
     against the oracle renderer: states of a few steps of the oracle's own simulation.  chase_avoid_torus: nine copies per
@@ -155,7 +156,7 @@ def test_model_frames_vs_oracle(model, name, cap_rows):
         passes += int(st[2])
         bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
         assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist())
-    if cap_rows < 192 and name != 'chase_avoid_torus':
+    if cap_rows < 192 and name not in ('chase_avoid_torus', 'parallelogram_catch'):
         assert passes > 4 * n, 'the capped records were meant to force several passes per frame'
 
 
@@ -223,3 +224,64 @@ def test_model_torus_copies(model):
     bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
     assert bad.size == 0, ('frames differ (capped rows)', bad[:8].tolist())
     assert st[2] > n
+
+
+def long_polygon(rs, W, nv, kind):
+    """Integer canvas points of a polygon with nv > 32 vertices."""
+    if kind == 0:      # lattice: repeated points, spikes, runs of horizontal edges, corners sharing rows
+        step = int(rs.randint(1, 4))
+        ox, oy = rs.randint(-4, W - 4, size=2)
+        xy = np.stack([ox + step * rs.randint(0, 9, size=nv), oy + step * rs.randint(0, 9, size=nv)], 1)
+    elif kind == 1:    # comb: dozens of crossings per row
+        t = np.arange(nv)
+        xy = np.stack([rs.randint(-3, 4) + (W * t) // nv, np.where(t % 2 == 0, rs.randint(0, W // 2), rs.randint(W // 2, W)) + rs.randint(-2, 3, size=nv)], 1)
+    elif kind == 2:    # annulus: outer ring one way, inner ring back, joined by a seam (shapes.annulus_vertices)
+        n0 = nv // 2
+        n1 = nv - n0
+        c = rs.uniform(0.2 * W, 0.8 * W, size=2)
+        r0, r1 = rs.uniform(0.2 * W, 0.7 * W), rs.uniform(0.02 * W, 0.18 * W)
+        th0, th1 = np.linspace(0, 2 * np.pi, n0), np.linspace(2 * np.pi, 0, n1)
+        xy = np.concatenate([np.stack([c[0] + r0 * np.cos(th0), c[1] + r0 * np.sin(th0)], 1),
+                             np.stack([c[0] + r1 * np.cos(th1), c[1] + r1 * np.sin(th1)], 1)])
+    elif kind == 3:    # star
+        th = rs.uniform(0, 2 * np.pi) + 2 * np.pi * np.arange(nv) / nv
+        rad = np.where(np.arange(nv) % 2 == 0, rs.uniform(0.3, 0.6) * W, rs.uniform(0.05, 0.3) * W)
+        c = rs.uniform(0.3 * W, 0.7 * W, size=2)
+        xy = np.stack([c[0] + rad * np.cos(th), c[1] + rad * np.sin(th)], 1)
+    elif kind == 4:    # random scatter straddling the canvas
+        xy = rs.randint(-10, W + 10, size=(nv, 2))
+    else:              # all on two rows: heads only
+        xy = np.stack([rs.randint(-5, W + 5, size=nv), rs.randint(0, W) + rs.randint(0, 2, size=nv)], 1)
+    return np.trunc(xy).astype(np.int64)
+
+
+def test_model_long_polygons(model):
+    """Polygons of 33 .. 102 vertices (the reference's 102-vertex annuli and worse) take the cooperative row routine
+    (rm_p4_big): planted in the big slots of match_to_sample's frames beside the ordinary sprites, against the oracle."""
+    c = helpers.compiled('match_to_sample_l3')
+    P, L = c.program, c.layout
+    n = 240
+    o = helpers.OracleEnv(c, n_envs=n, seed=9)
+    o.reset()
+    W = P.render.width
+    big = [s for s in range(P.n_slots) if P.slot_vcap[s] > 32]
+    assert big
+    rs = np.random.RandomState(77)
+    for e in range(n):
+        for s in big:
+            nv = int(rs.randint(33, P.slot_vcap[s] + 1))
+            pts = long_polygon(rs, W, nv, (e + s) % 6)
+            # world coordinates whose scaled (int) is the wanted point: (p + 0.5) / W for p >= 0, (p - 0.5) / W below zero
+            wv = (pts + np.where(pts >= 0, 0.5, -0.5)) / float(W)
+            v0 = L.o_verts + 2 * int(P.slot_voff[s])
+            o.f64[e, v0:v0 + 2 * nv] = wv.reshape(-1)
+            o.i32[e, L.o_nverts + s] = nv
+            o.i32[e, L.o_flags + s] |= 1
+            o.i32[e, L.o_opacity + s] = (255, 128)[e % 2]
+    ref = o.render().copy()
+    img, st = model_frames(model, c, o.f64, o.i32, 192)
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
+    img, st = model_frames(model, c, o.f64, o.i32, 64)
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ (capped rows)', bad[:8].tolist(), int(bad.size))
