@@ -105,6 +105,9 @@ struct moog_engine {
   int32_t* layer_hw = nullptr;   // [2 * MOOG_MAX_LAYERS]: high-water mark / dropped appends of the dynamic layers
   TimedKernel timed[MOOG_K_COUNT];
   int32_t* fault_flag = nullptr;   // pinned host word the kernels OR fault bits into
+  int32_t* rows_seen = nullptr;    // two pinned host words: the most polygon rows a frame wanted when that was more than the mask rasteriser's row records; how many frames did
+  int raster_rows_fixed = 0;       // MOOG_RASTER_ROWS pins the records (tests of the multi-pass path)
+  int mask_free_cap = 0;           // the most row records that cost no resident frame per CU (mask_free_rows)
   int step_dbg = 0, raster_stop = 0;   // profiling aids (MOOG_STEP_DEBUG / MOOG_RASTER_STOP at create, moog_engine_set_debug)
   // static prefix of the rasteriser (moog_raster.h): a scratch env record that holds the reference
   // sprites (what a reset makes of the constant generation ops) and their picture
@@ -136,6 +139,7 @@ static void free_engine(moog_engine* e) {
   if (e->aa_tmp) hipFree(e->aa_tmp);
   if (e->aa_tables) hipFree(e->aa_tables);
   if (e->fault_flag) hipHostFree(e->fault_flag);
+  if (e->rows_seen) hipHostFree(e->rows_seen);
   if (e->layer_hw) hipFree(e->layer_hw);
   for (int k = 0; k < moog_engine::POOL_STREAMS; ++k)
     if (e->pool_stream[k]) { hipStreamSynchronize(e->pool_stream[k]); hipStreamDestroy(e->pool_stream[k]); }
@@ -459,6 +463,59 @@ static int build_static_prefix(moog_engine* e) {
 // pacman's 256 x 256 frames (136 walls, 8 tiles) 2.51 -> 1.73 ms per 4096; one-tile frames (maze_zoo, functional_maze)
 // lose 0.09 ms to the check and the build launch and gain nothing, their workgroups being bound by fixed costs.
 // MOOG_RASTER_ENV_BG=0 turns it off, =1 turns it on whatever the frame size (A/B runs, tests).
+// The mask rasteriser's row records per pass (moog_raster_mask_core.h): `cap` of them, at least a canvas height so that any one
+// polygon fits, at most one per (polygon, canvas row) and 4096 (the row sort's 12-bit places), and no more than 64 KB of LDS
+// leave room for.  ok = 0 when even the smallest plan does not fit.
+static void mask_plan_rows(moog_engine* e, int cap) {
+  RmSetup& ms = e->mask_setup;
+  if (cap > 4096) cap = 4096;
+  if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
+  if (cap < e->canvas_h) cap = e->canvas_h;
+  for (;;) {
+    rm_plan(ms.S, e->L.TOTV * ms.ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, ms.big, &ms.plan);
+    if (ms.plan.total <= 64u * 1024u || cap <= e->canvas_h) break;
+    cap = cap - 64 > e->canvas_h ? cap - 64 : e->canvas_h;
+  }
+  ms.cap_rows = cap;
+  ms.lds = ms.plan.total;
+  { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad && ms.lds + (uint32_t)atoi(pad) <= 64u * 1024u) ms.lds += (uint32_t)atoi(pad); }  // occupancy experiments
+  if (ms.plan.total > 64u * 1024u) ms.ok = 0;
+}
+
+// A frame with more polygon rows than row records is drawn in several passes, each a full sweep over the frame: correct, and
+// cheaper than it sounds -- what costs is a resident frame less per CU (profiles/r05_raster.txt 5: cleanup's raster launch takes 97 us
+// with 192 or 384 records and 1390 us with the 1500 its busiest frames would like).  So frames that want more records say so
+// through a host-mapped word and before a later launch the records grow AS FAR AS THAT IS FREE: the same number of frames per
+// CU (LDS; registers hold ten, and a plan within 1 KB of losing one counts as losing it).  falling_balls_64's launch 628 -> 471 us.
+// They never shrink; the picture does not depend on their number.  Once they are as many as is free the frames stop reporting
+// (an atomic on host memory per frame and launch: 8.6 ms per launch when every frame of a batch of 4096 keeps doing it).
+static int mask_frames_per_cu(uint32_t lds) { const int n = (int)(160u * 1024u / (lds + 1024u)); return n > 10 ? 10 : n; }
+// the most row records that cost no resident frame per CU against the plan in hand (called once, at create)
+static int mask_free_rows(moog_engine* e) {
+  RmSetup& ms = e->mask_setup;
+  const RmSetup first = ms;
+  int best = first.cap_rows;
+  for (int cap = first.cap_rows + 32; cap <= 4096; cap += 32) {
+    ms = first;
+    mask_plan_rows(e, cap);
+    if (!ms.ok || ms.cap_rows < cap || mask_frames_per_cu(ms.lds) < mask_frames_per_cu(first.lds)) break;
+    best = cap;
+  }
+  ms = first;
+  return best;
+}
+static void mask_rows_grow(moog_engine* e) {
+  if (!e->rows_seen || e->raster_rows_fixed || e->mask_setup.cap_rows >= e->mask_free_cap) return;
+  const int want = __atomic_load_n(&e->rows_seen[0], __ATOMIC_RELAXED);
+  RmSetup& ms = e->mask_setup;
+  if (want <= ms.cap_rows) return;
+  const RmSetup before = ms;
+  int cap = (want + want / 8 + 31) & ~31;
+  if (cap > e->mask_free_cap) cap = e->mask_free_cap;
+  mask_plan_rows(e, cap);
+  if (!ms.ok || ms.cap_rows <= before.cap_rows) ms = before;
+}
+
 static int setup_env_prefix(moog_engine* e) {
   const char* sw = getenv("MOOG_RASTER_ENV_BG");
   if ((sw && atoi(sw) == 0) || e->aa > 1) return MOOG_OK;
@@ -625,16 +682,11 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       ms.bg = ((uint32_t)prog->render.bg[0] & 255u) | (((uint32_t)prog->render.bg[1] & 255u) << 8) | (((uint32_t)prog->render.bg[2] & 255u) << 16);
       // row records per pass: 192 (the headline workload's frames have ~170 rows behind the cached walls), at least a
       // canvas height so that any one polygon fits; frames with more rows take several passes
+      // (frames that want more keep the records growing: mask_rows_grow, before a launch)
       int cap = 192;
-      { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) cap = atoi(rc); }   // tuning / tests of the multi-pass path
-      if (cap > RM_SORT_ROUNDS * RM_THREADS) cap = RM_SORT_ROUNDS * RM_THREADS;   // (the row sort keeps a pass's rows in registers, RM_SORT_ROUNDS per thread)
-      if (cap < e->canvas_h) cap = e->canvas_h;
-      if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
-      ms.cap_rows = cap;
-      rm_plan(ms.S, e->L.TOTV * ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, ms.big, &ms.plan);
-      ms.lds = ms.plan.total;
-      { const char* pad = getenv("MOOG_RASTER_LDS_PAD"); if (pad) ms.lds += (uint32_t)atoi(pad); }  // occupancy experiments
-      if (ms.lds > 64 * 1024) ms.ok = 0;
+      { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) { cap = atoi(rc); e->raster_rows_fixed = 1; } }   // tuning / tests of the multi-pass path
+      mask_plan_rows(e, cap);
+      e->mask_free_cap = (ms.ok && !e->raster_rows_fixed) ? mask_free_rows(e) : ms.cap_rows;
     }
   }
   {
@@ -668,7 +720,7 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     if (err == hipSuccess) err = (hipError_t)moog_configure_reset_full(e->step_lds);
   if (err == hipSuccess)
     err = (hipError_t)moog_raster_configure(e->raster_lds);
-  if (err == hipSuccess && e->mask_setup.ok) err = (hipError_t)moog_raster_configure_mask(e->mask_setup.lds);
+  if (err == hipSuccess && e->mask_setup.ok) err = (hipError_t)moog_raster_configure_mask(64 * 1024);   // (the records may grow: mask_rows_grow)
   if (err != hipSuccess) {
     free_engine(e);
     return fail(MOOG_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(err));
@@ -676,6 +728,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
   { const char* ds = getenv("MOOG_STEP_DEBUG"); e->step_dbg = ds ? atoi(ds) : 0; }
   { const char* ds = getenv("MOOG_RASTER_STOP"); e->raster_stop = ds ? atoi(ds) : 0; }
   // (coherent = fine-grained: the kernels' system-scope atomics and the host's atomic read / clear meet in the same memory)
+  if (hipHostMalloc(reinterpret_cast<void**>(&e->rows_seen), 2 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { e->rows_seen[0] = 0; e->rows_seen[1] = 0; }   // ([1]: how many frames wanted more: for tools)
+  else e->rows_seen = nullptr;   // (without it the records keep their first size)
   if (hipHostMalloc(reinterpret_cast<void**>(&e->fault_flag), sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
     free_engine(e);
     return fail(MOOG_E_NOMEM, "hipHostMalloc(fault flag) failed");
@@ -811,7 +865,10 @@ static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
   RArgs r;
+  if (e->mask_setup.ok) mask_rows_grow(e);
   r.ms = e->mask_setup;
+  // (frames report only while the records can still grow: every report is an atomic on host memory)
+  r.rows_seen = (e->raster_rows_fixed || e->mask_setup.cap_rows >= e->mask_free_cap) ? nullptr : e->rows_seen;
   r.P = e->d_prog; r.L = e->L; r.f64 = e->view.f64; r.i32 = e->view.i32; r.image = image;
   r.vinfo = e->d_vinfo; r.plan = e->raster_plan_;
   r.n_envs = e->n_envs; r.chunk = e->raster_chunk; r.words = e->raster_words;

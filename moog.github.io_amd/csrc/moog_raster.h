@@ -60,6 +60,7 @@ struct RmSetup {
 
 struct RArgs {
   RmSetup ms;
+  int32_t* rows_seen;     // (mask rasteriser) host-mapped word for frames that want more row records, or null
   const moog_program_t* P;
   moog_layout_t L;
   const double* f64;

@@ -25,7 +25,7 @@ static RmArgs mask_args(const RArgs& r) {
   a.flip = r.flip; a.iwords = r.ms.iwords; a.cmap = r.ms.cmap; a.first_person = r.ms.first_person;
   a.fp_slot0 = r.ms.fp_slot0; a.fp_nslots = r.ms.fp_nslots; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
   a.n_static = r.n_static; a.nsv = r.nsv; a.sref_v = r.sref_v; a.sref_col = r.sref_col; a.sref_flags = r.sref_flags;
-  a.sref_nv = r.sref_nv; a.sref_opa = r.sref_opa; a.sbg = r.sbg; a.rgb_override = r.rgb_override;
+  a.sref_nv = r.sref_nv; a.sref_opa = r.sref_opa; a.sbg = r.sbg; a.rgb_override = r.rgb_override; a.rows_seen = r.rows_seen;
   if (a.ncopy > 1) a.n_static = 0;   // (torus frames are drawn whole: no cached picture under copies)
   a.plan = r.ms.plan;
   return a;

@@ -43,6 +43,10 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   rm_p2_scan(a, c, s_lo, lane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  if (a.rows_seen && tid == 0 && c.rowoff[a.S] > a.cap_rows) {   // several passes: the engine may grow the records (mask_rows_grow)
+    atomicMax(a.rows_seen, c.rowoff[a.S]);
+    atomicAdd(a.rows_seen + 1, 1);
+  }
   for (int base = 0;;) {
     const int end = __builtin_amdgcn_readfirstlane(rm_pass_end(a, c, base));
     const int total_rows = __builtin_amdgcn_readfirstlane(c.rowoff[end] - c.rowoff[base]);
@@ -53,11 +57,16 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
     rm_p3<WORDS>(a, c, base, end, s_lo, tid, RM_THREADS);
     __syncthreads();
     if (a.debug_stop == 4) return;
-    {
+    if (a.cap_rows <= RM_SORT_ROUNDS * RM_THREADS) {
       RmSortKey sk;
       rm_p4a(c, total_rows, tid, RM_THREADS, sk);
       __syncthreads();
       rm_p4b(c, total_rows, tid, RM_THREADS, sk);
+      __syncthreads();
+    } else {
+      rm_p4a_lds(c, total_rows, tid, RM_THREADS);
+      __syncthreads();
+      rm_p4b_lds(c, total_rows, tid, RM_THREADS);
       __syncthreads();
     }
     rm_p4<WORDS>(a, c, total_rows, tid, RM_THREADS, c.xx + (tid >> 6) * a.plan.xx_stride);

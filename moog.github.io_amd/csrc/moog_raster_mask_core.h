@@ -64,6 +64,7 @@
 #endif
 #define RM_MAX_NV 32          // vertices per polygon whose rows go by census words (edge index = bit of a word)
 #define RM_BIG_NV 128         // vertices per polygon at most: longer ones (the 102-vertex annuli) take the cooperative row routine
+#define RM_SORT_ROUNDS_T (3 * RM_THREADS)   // = RM_SORT_ROUNDS * RM_THREADS (defined with the sort, below)
 #define RM_XX (2 * RM_BIG_NV)  // crossing-list capacity of the generic row routine (2 per edge)
 
 struct alignas(16) RmEdge { uint32_t w0, w1, w2, w3; };   // table edge: float x0 | float dx | y0, y1 (shorts) | 0;  head: xmin, xmax (shorts) | 0 | y, y | 1
@@ -72,7 +73,7 @@ struct alignas(16) RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint3
 
 struct alignas(16) RmU4 { uint32_t x, y, z, w; };
 
-struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, xx_stride, total; };   // xx_stride: floats of scratch per wavefront
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, o_skey, xx_stride, total; };   // xx_stride: floats of scratch per wavefront
 
 struct RmArgs {
   const moog_program_t* P;
@@ -104,6 +105,7 @@ struct RmArgs {
   const int32_t* sref_opa;
   const uint8_t* sbg;
   const uint32_t* rgb_override;
+  int32_t* rows_seen;         // two host-mapped words (or null): the most rows a frame wanted when that was more than cap_rows, and how many frames did (the engine may grow the records)
   RmPlan plan;
 };
 
@@ -126,6 +128,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_xx = o; o = rm_align(o + (uint32_t)waves * p->xx_stride * 4u + (big ? (uint32_t)waves * 64u * RM_MAX_NV : 0u));   // + a list of edge numbers per thread (rm_p4_big)
   p->o_misc = o; o = rm_align(o + 64u);
   p->o_owner = o; o = rm_align(o + (uint32_t)TOTV);   // the slot of every compact vertex number
+  p->o_skey = o; o = rm_align(o + (cap_rows > RM_SORT_ROUNDS_T ? (uint32_t)cap_rows * 2u : 0u));   // the row sort of a long pass: bucket << 12 | place in the bucket
   {   // a word per thread (p3) / the sorted row list (p4)
     const uint32_t b1 = (uint32_t)waves * 64u * 4u, b2 = (uint32_t)cap_rows * 2u;
     p->o_spare = o; o = rm_align(o + (b1 > b2 ? b1 : b2));
@@ -136,7 +139,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
 struct RmCtx {
   RmEdge* edges; uint32_t* ivert; RmRow* rows; uint16_t* rowitem;   // rowitem: the row's item | 256 when a shallow edge has a corner on the row
   RmItem* info; int32_t* item_y; int32_t* item_x; int32_t* rowoff;
-  uint32_t* seg; uint32_t* lut; float* xx; uint32_t* spare; uint16_t* sorted; uint8_t* owner; int32_t* misc;   // sorted (p4: the rows in order of their kind) shares the spare words' memory (p3)   // misc: [5] static prefix differs
+  uint32_t* seg; uint32_t* lut; float* xx; uint32_t* spare; uint16_t* sorted; uint16_t* skey; uint8_t* owner; int32_t* misc;   // sorted (p4: the rows in order of their kind) shares the spare words' memory (p3)   // misc: [5] static prefix differs
 };
 
 RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
@@ -156,6 +159,7 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
   c.spare = reinterpret_cast<uint32_t*>(lds + pl.o_spare);
   c.sorted = reinterpret_cast<uint16_t*>(lds + pl.o_spare);
   c.owner = reinterpret_cast<uint8_t*>(lds + pl.o_owner);
+  c.skey = reinterpret_cast<uint16_t*>(lds + pl.o_skey);
   return c;
 }
 
@@ -1026,7 +1030,7 @@ static long long rm_stats[16];   // host model only: [1] generic rows [3] active
 // fix-up first, then by the number of crossing edges.  The order of the rows has no effect on the picture.
 //   p4a: every row's bucket, its place in the bucket (ballots; one LDS atomic per wave, round and bucket)
 //   p4b (behind a barrier): the buckets' starts are known -> the sorted list
-#define RM_SORT_ROUNDS 3   // rounds of T rows a pass may have at most (cap_rows <= RM_SORT_ROUNDS * T)
+#define RM_SORT_ROUNDS 3   // rounds of T rows whose sort keys a thread keeps in registers (passes of more rows: rm_p4a_lds)
 struct RmSortKey { int key[RM_SORT_ROUNDS]; int pos[RM_SORT_ROUNDS]; };
 
 RM_FN int rm_row_bucket(const RmRow& rec, bool shallow) {
@@ -1084,6 +1088,48 @@ RM_FN void rm_p4b(const RmCtx& c, int total_rows, int tid, int T, const RmSortKe
   }
 #else
   (void)c; (void)total_rows; (void)tid; (void)T; (void)sk;
+#endif
+}
+
+// The same with the keys in LDS instead of registers: passes of more than RM_SORT_ROUNDS * T rows (device only: the host model's
+// rm_p4a sorts any number)
+RM_FN void rm_p4a_lds(const RmCtx& c, int total_rows, int tid, int T) {
+#if RM_DEV
+  const int lane = tid & 63;
+  for (int w0 = 0; w0 < total_rows; w0 += T) {
+    const int w = w0 + tid;
+    const bool on = w < total_rows;
+    int key = 5;
+    if (on) {
+      const RmRow rec = c.rows[w];
+      const int ri = c.rowitem[w];
+      key = (c.info[ri & 255].pb_nv >> 20) > RM_MAX_NV ? 4 : rm_row_bucket(rec, (ri >> 8) != 0);   // 4: a long polygon's row (rm_p4_big)
+    }
+    int pos = 0;
+    for (int b = 0; b < 5; ++b) {
+      const unsigned long long mb = __ballot(key == b);
+      int base = 0;
+      if (lane == 0 && mb) base = atomicAdd(&c.misc[8 + b], __builtin_popcountll(mb));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (key == b) pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+    }
+    if (on) c.skey[w] = (uint16_t)((key << 12) | pos);   // (a pass has at most 4096 rows: rm_plan's callers)
+  }
+#else
+  (void)c; (void)total_rows; (void)tid; (void)T;
+#endif
+}
+
+RM_FN void rm_p4b_lds(const RmCtx& c, int total_rows, int tid, int T) {
+#if RM_DEV
+  const int n0 = c.misc[8], n1 = c.misc[9], n2 = c.misc[10], n3 = c.misc[11];
+  for (int w = tid; w < total_rows; w += T) {
+    const int sk = c.skey[w], key = sk >> 12, pos = sk & 4095;
+    const int start = key == 0 ? 0 : (key == 1 ? n0 : (key == 2 ? n0 + n1 : (key == 3 ? n0 + n1 + n2 : n0 + n1 + n2 + n3)));
+    c.sorted[start + pos] = (uint16_t)w;
+  }
+#else
+  (void)c; (void)total_rows; (void)tid; (void)T;
 #endif
 }
 
