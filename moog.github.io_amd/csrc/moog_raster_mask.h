@@ -11,7 +11,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
 // BIG: the program has slots for polygons of more than RM_MAX_NV vertices (rm_p4_big); a kernel of its own so that everybody
 // else's keeps its registers
-template <int WORDS, bool BIG>
+template <int WORDS, bool BIG, bool TORUS>
 __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mask_kernel(RmArgs a) {
   const int env = (int)blockIdx.x;
   if (env >= a.n_envs) return;
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   const int tid = (int)threadIdx.x, lane = tid & 63;
   RmThread th;
   rm_p0<WORDS>(a, c, env, tid, RM_THREADS, th);
-  if (a.ncopy > 1) {   // torus frames: nine copies per sprite, the visible ones become items
+  if (TORUS) {   // torus frames (a.ncopy = 9): nine copies per sprite, the visible ones become items
     if (tid < 64) rm_t0_slots(a, c, env, lane);
     __syncthreads();
     if (a.debug_stop == 1) return;
@@ -82,21 +82,28 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   }
 }
 
+typedef void (*moog_raster_mask_fn)(RmArgs);
+// [WORDS - 1][BIG][TORUS]: a kernel per combination, so that frames that need neither keep their registers
+static inline moog_raster_mask_fn moog_raster_mask_pick(int words, bool big, bool torus) {
+  static const moog_raster_mask_fn table[2][2][2] = {
+      {{moog_raster_mask_kernel<1, false, false>, moog_raster_mask_kernel<1, false, true>},
+       {moog_raster_mask_kernel<1, true, false>, moog_raster_mask_kernel<1, true, true>}},
+      {{moog_raster_mask_kernel<2, false, false>, moog_raster_mask_kernel<2, false, true>},
+       {moog_raster_mask_kernel<2, true, false>, moog_raster_mask_kernel<2, true, true>}}};
+  return table[words - 1][big ? 1 : 0][torus ? 1 : 0];
+}
+
 static inline int moog_raster_mask_configure(size_t lds_bytes) {
-  const void* const kernels[4] = {reinterpret_cast<const void*>(moog_raster_mask_kernel<1, false>), reinterpret_cast<const void*>(moog_raster_mask_kernel<2, false>),
-                                  reinterpret_cast<const void*>(moog_raster_mask_kernel<1, true>), reinterpret_cast<const void*>(moog_raster_mask_kernel<2, true>)};
   hipError_t err = hipSuccess;
-  for (int k = 0; k < 4 && err == hipSuccess; ++k) err = hipFuncSetAttribute(kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  for (int k = 0; k < 8 && err == hipSuccess; ++k)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_pick(1 + (k & 1), (k & 2) != 0, (k & 4) != 0)),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return (int)err;
 }
 
 static inline void moog_raster_mask_launch(const RmArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs);
-  if (a.big) {
-    if (a.W > 64) hipLaunchKernelGGL((moog_raster_mask_kernel<2, true>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL((moog_raster_mask_kernel<1, true>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
-  } else if (a.W > 64) hipLaunchKernelGGL((moog_raster_mask_kernel<2, false>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
-  else hipLaunchKernelGGL((moog_raster_mask_kernel<1, false>), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL(moog_raster_mask_pick(a.W > 64 ? 2 : 1, a.big != 0, a.ncopy > 1), grid, dim3(RM_THREADS), lds_bytes, stream, a);
 }
 
 #endif  // MOOG_RASTER_MASK_H_

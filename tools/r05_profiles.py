@@ -15,7 +15,7 @@ def clean(txt):
 out = ['# Round 5, final build: bench lines, rocprofv3 kernel trace and PMC passes of `python bench.py --no-cpu-baseline --no-extras`',
        '# (tools/r05_collect.sh -> tools/prof.sh, one MI355X box).  Counters are per launch, summed over the device; SQ_* cycle',
        '# counters are in units of four cycles.  moog_step_kernel<false, 3, 0> is the program-specialised kernel here (same mangled name',
-       '# as the generic one: lib/spec/step_417c47560f31861d_d0w3.so); moog_raster_mask_kernel<1, false> is the roofline-graded kernel.', '']
+       '# as the generic one: lib/spec/step_417c47560f31861d_d0w3.so); moog_raster_mask_kernel<1, false, false> is the roofline-graded kernel.', '']
 for l in rd('bench.txt').splitlines():
     if l.startswith('=='):
         out.append(l)
@@ -30,12 +30,12 @@ def counter(kernel, name):
         if kernel in l and (' ' + name + ' ') in l:
             return float(l.split()[-1]), int(l.split()[-2])
     raise KeyError((kernel, name))
-fetch, nl = counter('moog_raster_mask_kernel<1, false>', 'FETCH_SIZE')
-write, _ = counter('moog_raster_mask_kernel<1, false>', 'WRITE_SIZE')
+fetch, nl = counter('moog_raster_mask_kernel<1, false, false>', 'FETCH_SIZE')
+write, _ = counter('moog_raster_mask_kernel<1, false, false>', 'WRITE_SIZE')
 traffic = int(round((2 * fetch + write) * 1024))
 head = json.loads([l for l in rd('bench.txt').splitlines() if l.startswith('{')][0])
 alg = head['roofline']['algorithmic_bytes_per_launch']
-trace_avg = [float(l.split()[-4]) for l in ps.splitlines() if 'moog_raster_mask_kernel<1, false>' in l and '%' in l][0]
+trace_avg = [float(l.split()[-4]) for l in ps.splitlines() if 'moog_raster_mask_kernel<1, false, false>' in l and '%' in l][0]
 out += ['', '## the roofline line of the headline bench',
         'algorithmic bytes per launch %d; HIP-event average %.2f us (bench.py, inside the timed region) -> %.1f GB/s = %.4f of 8 TB/s' % (
             alg, head['roofline']['avg_kernel_us'], head['roofline']['achieved'], head['roofline']['frac']),
@@ -45,7 +45,7 @@ out += ['', '## the roofline line of the headline bench',
 open(os.path.join(P, 'r05_current.txt'), 'w').write('\n'.join(out) + '\n')
 json.dump({'_comment': 'HBM traffic of the roofline-graded raster kernel per launch from rocprofv3 PMC passes: 2*FETCH_SIZE (gfx950 correction '
                        'for wide coalesced reads) + WRITE_SIZE, KB -> bytes',
-           'colliding_predators_32': {'n_envs': 4096, 'traffic_bytes': traffic, 'kernel': 'moog_raster_mask_kernel<1, false>',
+           'colliding_predators_32': {'n_envs': 4096, 'traffic_bytes': traffic, 'kernel': 'moog_raster_mask_kernel<1, false, false>',
                                       'source': 'profiles/r05_current.txt (FETCH_SIZE x 2 + WRITE_SIZE, %d launches, end-of-round-5 build)' % nl,
                                       'fetch_kb': fetch, 'write_kb': write}},
           open(os.path.join(P, 'raster_traffic.json'), 'w'), indent=1)

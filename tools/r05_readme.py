@@ -41,7 +41,7 @@ s = re.sub(r'\| this engine \| one MI355X \| [^|]* \|', '| this engine | one MI3
 s = re.sub(r'\| the reference itself \(Python \+ numpy \+ matplotlib \+ Pillow, `BASELINE.md` §2\) \| [^|]* \| [^|]* \|',
            '| the reference itself (Python + numpy + matplotlib + Pillow; `tools/ref_cpu_timing.py`, `profiles/r05_ref_cpu.txt`) | 1 core of an 8-vCPU Xeon @ 2.1 GHz (build container) | 23.0 |', s)
 # per-config table
-a = s.index('| config (level) | envs | env-steps/s | step kernel | raster kernel |')
+a = s.index('| config (level) | envs | env-steps/s')
 b = s.index('`bounce_box_contact_prediction` and `red_green` play the whole episode forward')
 order = ['chase_avoid_torus', 'functional_maze', 'pong', 'colliding_predators', 'falling_balls', 'first_person_predators_prey', 'cleanup', 'pacman@4096',
          'parallelogram_catch', 'multi_tracking_with_feature_l3', 'match_to_sample_l3', 'predators_arena_l2', 'bounce_box_contact_prediction', 'red_green_l1']
