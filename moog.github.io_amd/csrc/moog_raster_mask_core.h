@@ -599,6 +599,7 @@ RM_FN void rm_p0(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThr
     th.vx = gf[L.o_verts + 2 * tid]; th.vy = gf[L.o_verts + 2 * tid + 1];
   }
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
+  for (int i = tid; i < (a.cap_rows + 1) / 2; i += T) reinterpret_cast<uint32_t*>(c.rowitem)[i] = 0u;   // (the rows' flag bytes)
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
   if (tid < 16) {   // four coverage bits -> byte masks of the 12 bytes of four RGB pixels
@@ -947,7 +948,9 @@ RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int 
     c.info[g].rowbase = first - ys;
     const int ymax = c.item_y[2 * g + 1];
     c.info[g].pymax = ymax > a.H ? a.H : ymax;   // polygon_generic clamps ymax to ysize
-    for (int j = 0; j < cnt; ++j) c.rowitem[first + j] = (uint16_t)g;
+    // (the low byte only: the high byte is the "shallow corner" flag p3 sets, and the other wavefront may already be in p3 when
+    //  this one gets here -- a 16-bit store would wipe its flags; the flags are cleared with the row records)
+    for (int j = 0; j < cnt; ++j) reinterpret_cast<uint8_t*>(c.rowitem)[2 * (first + j)] = (uint8_t)g;
   }
 }
 
@@ -1377,6 +1380,7 @@ RM_FN void rm_p5(const RmArgs& a, const RmCtx& c, int env, bool first_pass, int 
 RM_FN void rm_next_pass(const RmArgs& a, const RmCtx& c, int tid, int T) {
   if (tid < 5) c.misc[8 + tid] = 0;
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
+  for (int i = tid; i < (a.cap_rows + 1) / 2; i += T) reinterpret_cast<uint32_t*>(c.rowitem)[i] = 0u;   // (the rows' flag bytes)
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
 }
