@@ -1806,3 +1806,79 @@ def test_specialised_step_kernel_is_result_neutral(name, n, steps, monkeypatch, 
         assert np.array_equal(t0.reward.cpu().numpy(), t1.reward.cpu().numpy(), equal_nan=True)
         assert np.array_equal(t0.observation['image'].cpu().numpy(), t1.observation['image'].cpu().numpy())
     env.raise_faults()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', [None, 64])
+def test_long_polygons_planted_vs_oracle(rows, monkeypatch):
+    """Polygons of 33 .. 102 vertices (annuli, combs, lattices, stars, scatter, heads only: tests/test_raster_mask_model.py
+    long_polygon) planted in the long slots of match_to_sample's records on the device, drawn by the mask rasteriser's long-polygon
+    rows (rm_p4_big: 128-bit edge words, indexed edge lists, LDS atomics) and compared with the oracle renderer; also with the row
+    records capped (several passes, the LDS-free sort)."""
+    import torch
+    from test_raster_mask_model import long_polygon
+    if rows is not None:
+        monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
+    name, n = 'match_to_sample_l3', 480
+    env = make_env(name, n, seed=9)
+    assert env.raster_path() == 'mask'
+    env.reset()
+    f, q = download(env)
+    P, L = env.compiled.program, env.compiled.layout
+    W = P.render.width
+    big = [s for s in range(P.n_slots) if P.slot_vcap[s] > 32]
+    assert big
+    rs = np.random.RandomState(177)
+    for e in range(n):
+        for s in big:
+            nv = int(rs.randint(33, P.slot_vcap[s] + 1))
+            pts = long_polygon(rs, W, nv, (e + s) % 6)
+            wv = (pts + np.where(pts >= 0, 0.5, -0.5)) / float(W)   # world coordinates whose scaled (int) is the wanted point
+            v0 = L.o_verts + 2 * int(P.slot_voff[s])
+            f[e, v0:v0 + 2 * nv] = wv.reshape(-1)
+            q[e, L.o_nverts + s] = nv
+            q[e, L.o_flags + s] |= 1
+            q[e, L.o_opacity + s] = (255, 128)[e % 2]
+    upload(env, f, q)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=9)
+    o.f64[:], o.i32[:] = f, q
+    img = env.observation()['image'].cpu().numpy()
+    ref = o.render()
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
+
+
+@pytest.mark.gpu
+def test_torus_copies_planted_vs_oracle():
+    """Torus frames with the sprites moved to where the nine copies matter (across edges and corners, far outside, blown up beyond
+    the canvas so that copies overlap; every vertex of some sprites NaN / infinite / beyond int): the mask rasteriser's torus phases
+    (64-bit LDS atomics on order-preserving keys, visible copies only) against the oracle renderer."""
+    name, n = 'chase_avoid_torus', 512
+    env = make_env(name, n, seed=3)
+    assert env.raster_path() == 'mask'
+    env.reset()
+    env.step(env.random_action())
+    f, q = download(env)
+    P, L = env.compiled.program, env.compiled.layout
+    rs = np.random.RandomState(8)
+    for e in range(n):
+        for s in range(P.n_slots):
+            v0, nv = L.o_verts + 2 * int(P.slot_voff[s]), int(q[e, L.o_nverts + s])
+            if nv <= 0:
+                continue
+            v = f[e, v0:v0 + 2 * nv].reshape(nv, 2)
+            ctr = v.mean(axis=0)
+            kind = (e + s) % 8
+            scale = (1.0, 1.0, 2.5, 1.0, 9.0, 30.0, 0.3, 1.0)[kind]
+            target = ((0.0, rs.rand()), (0.0, 0.0), (rs.rand(), 1.0), (1.0, 1.0), rs.rand(2), rs.rand(2), (0.999, 0.001),
+                      rs.uniform(-1.3, 2.3, size=2))[kind]
+            v[:] = (v - ctr) * scale + np.asarray(target, np.float64)
+            if e % 9 == 4 and s % 2 == 0:
+                v[:, rs.randint(2)] = (np.nan, 3.0e9, -7.0e11, np.inf)[(e // 9 + s) % 4]
+    upload(env, f, q)
+    o = helpers.OracleEnv(env.compiled, n_envs=n, seed=3)
+    o.f64[:], o.i32[:] = f, q
+    img = env.observation()['image'].cpu().numpy()
+    ref = o.render()
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
