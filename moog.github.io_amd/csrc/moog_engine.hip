@@ -614,6 +614,9 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
     e->raster_band_h = e->canvas_h <= 128 ? e->canvas_h : 64;
     {   // frames that will use the per-env prefix (setup_env_prefix): few sprites are left to draw per tile and the per-tile fixed
         // cost dominates -- whole-height tiles measured 1.65 against 1.73 ms per 4096 pacman frames (profiles/r04_env_prefix.txt)
+        // (decided here, from what the PROGRAM allows: the tile plan sizes every LDS table.  A handle that later runs without the prefix --
+        //  allocation failure, a prefix that shrank to nothing, a colour override -- keeps the whole-height tiles: 1.65 ms against 1.73 ms
+        //  with 64-row bands WITH the prefix, 2.45 against 2.51 ms WITHOUT it in the same file: not a loss either way)
       int nsv_ = 0;
       const char* sw = getenv("MOOG_RASTER_ENV_BG");
       if (e->canvas_h > 128 && e->canvas_h <= 256 && e->aa <= 1 && !(sw && atoi(sw) == 0) && env_prefix_slots(prog, &nsv_) >= 32)
