@@ -319,13 +319,17 @@ def main():
         if os.environ.get('MOOG_SPEC_PREBUILT'):   # (A/B runs: kernels built by hand in MOOG_SPEC_DIR are used as they are)
             spec = True
         elif not args.no_spec:
-            try:
-                from moog import _compiler, _spec
-                _spec.build(_compiler.compile_config(layer_capacity=example_configs.capacity(args.workload),
-                                                     **example_configs.load(args.workload)).program)
-                spec = True
-            except Exception as exc:   # pylint: disable=broad-except  (no hipcc on the box: the generic kernels do)
-                sys.stderr.write('bench.py: no specialised step kernel (%s)\n' % (exc,))
+            # (rank 0 builds, the others wait for it: eight hipcc runs at once would only slow each other down)
+            if rank == 0:
+                try:
+                    from moog import _compiler, _spec
+                    _spec.build(_compiler.compile_config(layer_capacity=example_configs.capacity(args.workload),
+                                                         **example_configs.load(args.workload)).program)
+                    spec = True
+                except Exception as exc:   # pylint: disable=broad-except  (no hipcc on the box: the generic kernels do)
+                    sys.stderr.write('bench.py: no specialised step kernel (%s)\n' % (exc,))
+            if use_dist:
+                dist.barrier()
         env = environment.BatchedEnvironment(
             num_envs=n, device=dev, seed=2024, env_index0=index0,
             layer_capacity=example_configs.capacity(args.workload),
