@@ -347,17 +347,52 @@ class BatchedEnvironment(object):
                 for li, name in enumerate(self.compiled.layer_names) if P.layer_dynamic[li]}
 
     def _grow_if_close(self):
-        """layer_capacity='auto': doubles the layers whose high-water mark has come within a quarter of their capacity.
+        """layer_capacity='auto': grows the layers whose high-water mark has come close to their capacity -- within a quarter of
+        it: the layer is doubled; after fit_layer_capacity(headroom=h), within h / 2 of it: the layer grows by the factor 1 + h.
         Nothing has been dropped at that point (a dropped append raises, as ever), so the state moves over intact."""
+        import math
+        m = getattr(self, '_grow_margin', 0.25)
+        factor = 2.0 if m >= 0.25 else 1.0 + 2.0 * m
         use = self.layer_usage()
-        grow = {name: max(2 * u['capacity'], u['high_water'] + 4) for name, u in use.items()
-                if u['dropped'] == 0 and 4 * u['high_water'] >= 3 * u['capacity']}
+        grow = {name: max(int(math.ceil(factor * u['capacity'])), u['high_water'] + 4) for name, u in use.items()
+                if u['dropped'] == 0 and u['capacity'] - u['high_water'] <= max(2.0 if m < 0.25 else 0.0, m * u['capacity'])}
         if grow:
             self._grow_layers(grow)
 
+    def fit_layer_capacity(self, headroom=0.25, min_room=4):
+        """Sizes the layers that rules append to by what the batch has needed so far instead of by their capacity: every such
+        layer gets `high-water mark x (1 + headroom)` slots (at least `min_room` more than the mark, never fewer than the last
+        slot in use in any env), the engine is re-created and the records move over as in _grow_layers.  From then on the
+        layers grow on demand (layer_capacity='auto').  A state record holds every slot's vertices, so its size -- and with it
+        how many envs share a CU's LDS in the step kernel -- follows the capacities: first_person_predators_prey at
+        {'prey': 32, 'predators': 96} is one env per CU, fitted to a 4096-env batch's needs it is two or three.
+        Returns the new capacities ({} when nothing shrinks).  Results do not depend on capacities (a sprite keeps its layer
+        and its place in the layer's list)."""
+        import math
+        torch = self._torch
+        P, L = self.compiled.program, self.layout
+        use = self.layer_usage()
+        flags = self.state_i32[:, L.o_flags:L.o_flags + L.S] & 1
+        caps = {}
+        for li, name in enumerate(self.compiled.layer_names):
+            if name not in use:
+                continue
+            s0, n_old = int(P.layer_slot0[li]), int(P.layer_nslots[li])
+            alive = flags[:, s0:s0 + n_old].any(dim=0).nonzero()
+            in_use = int(alive.max().item()) + 1 if alive.numel() else 0
+            mark = max(use[name]['high_water'], in_use)
+            want = max(mark + int(min_room), int(math.ceil(mark * (1.0 + headroom))), 1)
+            if want < n_old:
+                caps[name] = want
+        if caps:
+            self._grow_layers(caps)
+            self._auto_capacity = True
+            self._grow_margin = min(0.25, 0.5 * float(headroom))
+        return caps
+
     def _grow_layers(self, new_caps):
-        """Re-creates the engine with larger capacities for the given layers ({layer: slots}) and moves every env's state
-        records to the new layout: a sprite keeps its layer and its position in the layer's list, everything that is not per
+        """Re-creates the engine with other capacities for the given layers ({layer: slots}; fewer slots only when the
+        slots given up hold no sprite: fit_layer_capacity) and moves every env's state records to the new layout: a sprite keeps its layer and its position in the layer's list, everything that is not per
         slot (task / rule / action state, counters, the random streams' positions) is copied as is."""
         torch = self._torch
         old_c, old_L = self.compiled, self.layout
@@ -373,8 +408,7 @@ class BatchedEnvironment(object):
         slot_map = []   # (old slot, new slot)
         for li in range(P.n_layers):
             o0, n_old, n0 = int(old_P.layer_slot0[li]), int(old_P.layer_nslots[li]), int(P.layer_slot0[li])
-            assert int(P.layer_nslots[li]) >= n_old
-            slot_map += [(o0 + k, n0 + k) for k in range(n_old)]
+            slot_map += [(o0 + k, n0 + k) for k in range(min(n_old, int(P.layer_nslots[li])))]
         for name, width in (('o_pos', 2), ('o_vel', 2), ('o_angle', 1), ('o_angvel', 1), ('o_mass', 1), ('o_color', 3),
                             ('o_inertia', 2), ('o_maxr', 1), ('o_scale', 1), ('o_aspect', 1)):
             a, b = getattr(old_L, name), getattr(L, name)

@@ -1882,3 +1882,41 @@ def test_torus_copies_planted_vs_oracle():
     ref = o.render()
     bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
     assert bad.size == 0, ('frames differ', bad[:8].tolist(), int(bad.size))
+
+
+@pytest.mark.gpu
+def test_fit_layer_capacity_is_result_neutral():
+    """fit_layer_capacity() re-creates the engine with the appendable layers sized by their high-water marks (a smaller record:
+    more envs per CU): time steps and frames of every later call equal those of the engine that keeps its roomy layers, the
+    layers still grow on demand afterwards, and the sprites are the same layer by layer."""
+    import torch
+    from moog import environment
+    from moog_demos import example_configs
+    name, n = 'first_person_predators_prey', 256
+    cfg = example_configs.load(name)
+    big = environment.BatchedEnvironment(num_envs=n, seed=5, layer_capacity={'prey': 32, 'predators': 96}, **cfg)
+    fit = environment.BatchedEnvironment(num_envs=n, seed=5, layer_capacity={'prey': 32, 'predators': 96}, **cfg)
+    big.reset()
+    fit.reset()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for k in range(90):   # (the roomy layers themselves overflow after ~150 calls of a random policy)
+        if k == 30:
+            before = fit.layout.f64_per_env
+            caps = fit.fit_layer_capacity(headroom=0.1, min_room=1)   # tight: the layers have to grow again later in the run
+            assert caps and fit.layout.f64_per_env < before, (caps, before, fit.layout.f64_per_env)
+        a = torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1
+        x, y = big.step(a), fit.step(a)
+        assert torch.equal(x.step_type, y.step_type), k
+        assert torch.equal(torch.nan_to_num(x.reward, nan=-7.), torch.nan_to_num(y.reward, nan=-7.)), k
+        assert torch.equal(x.observation['image'], y.observation['image']), 'frames differ at call %d' % k
+    assert len(fit.capacity_growths) >= 2, fit.capacity_growths   # the fit, then at least one growth on demand
+    use = fit.layer_usage()
+    assert all(u['dropped'] == 0 for u in use.values()), use
+    for env_i in (0, n // 2, n - 1):
+        sa, sb = big.sprites(env_i), fit.sprites(env_i)
+        for layer in sa:
+            assert len(sa[layer]) == len(sb[layer]), layer
+            for p, q in zip(sa[layer], sb[layer]):
+                assert p['x'] == q['x'] and p['y'] == q['y'] and np.array_equal(p['vertices'], q['vertices'])
+    big.close()
+    fit.close()
