@@ -4,6 +4,19 @@
 #pragma once
 #include "moog_device.h"
 
+// What the launch order of the next call sorts by (moog_sched_kernel): 0.6 x this call's cycles + 0.4 x the previous value.  An
+// env that was expensive lately tends to be expensive again (a pile of sprites in contact) even when one call in between was
+// cheap; with the bare cycle count such an env starts late in the next launch and the launch lasts as long as it does.
+// Measured (profiles/r05_step_experiments.txt 4): headline step launch 610 -> 595 us, config 5 unchanged; fmaxf(now, 0.9 x
+// before) gains as much on the headline and loses 2 % on config 5.  -DMOOG_COST_DECAY=d [-DMOOG_COST_EMA] are the experiment's knobs.
+#if defined(MOOG_COST_DECAY) && defined(MOOG_COST_EMA)
+#define MOOG_COST_OF(now, before) (MOOG_COST_DECAY * (before) + (1.0f - MOOG_COST_DECAY) * (now))
+#elif defined(MOOG_COST_DECAY)
+#define MOOG_COST_OF(now, before) fmaxf((now), MOOG_COST_DECAY * (before))
+#else
+#define MOOG_COST_OF(now, before) (0.4f * (before) + 0.6f * (now))
+#endif
+
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
 // =====================================================================================
@@ -573,7 +586,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
     }
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     if (DYN && held) pool_release(a, env, e.lane);
-    if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
+    if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
     return;
   }
 #endif
@@ -634,7 +647,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   }
   SEC(e, SEC_STORE);
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
-  if (a.cost && e.lane == 0) a.cost[env] = (float)(clock64() - t_sched);
+  if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);
     if (a.reward) a.reward[env] = (double)(e.n_path + 100000 * e.n_resp) + 1e10 * (double)e.n_disj;
