@@ -120,7 +120,7 @@ def cpu_model():
     return 'unknown'
 
 
-def _time_oracle(workload, n, threads, seconds_target, max_steps):
+def _time_oracle(workload, n, threads, seconds_target, max_steps, phase='full'):
     import ctypes
     import numpy as np
     import helpers
@@ -136,16 +136,18 @@ def _time_oracle(workload, n, threads, seconds_target, max_steps):
     act = (lambda: rs.randint(0, 5, size=n)) if grid else (lambda: rs.uniform(-1, 1, size=(n, 2)))
     for _ in range(2):
         o.step(act())
+    # (the phases without frames: the oracle's step with rendering off; its physics-only entry point is not timed apart)
+    one = {'full': lambda: o.step(act()), 'render': o.render}.get(phase, lambda: o.step(act(), render=False))
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < seconds_target and steps < max_steps:
-        o.step(act())
+        one()
         steps += 1
     dt = time.perf_counter() - t0
     return n * steps / dt, steps, dt
 
 
-def cpu_baseline(workload, seconds_target=10.0):
+def cpu_baseline(workload, seconds_target=10.0, phase='full'):
     """Times the CPU oracle (oracle/moog_oracle.c, a C restatement of the reference
     algorithm) on a bounded sample of the same workload: first one thread (the
     reference's own single-threaded design), then one OpenMP thread per host core over
@@ -153,14 +155,15 @@ def cpu_baseline(workload, seconds_target=10.0):
     sys.path.insert(0, os.path.join(REPO, 'tests'))
     cores = host_cores()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))
-    v1, s1, d1 = _time_oracle(workload, 32, 1, seconds_target * 0.5, 200)
-    vn, sn, dn = _time_oracle(workload, 64 * cores, cores, seconds_target, 400)
+    v1, s1, d1 = _time_oracle(workload, 32, 1, seconds_target * 0.5, 200, phase)
+    vn, sn, dn = _time_oracle(workload, 64 * cores, cores, seconds_target, 400, phase)
     return {'value': vn, 'unit': 'env steps/sec', 'cores': cores, 'kind': 'port',
             'cpu_model': cpu_model(),
             'single_thread': {'value': v1, 'unit': 'env steps/sec', 'cores': 1,
                               'sample': '%s, 32 envs x %d steps, 1 thread, %.1f s' % (workload, s1, d1)},
-            'sample': '%s, %d envs x %d steps (physics + raster), %d OpenMP threads, %.1f s'
-                      % (workload, 64 * cores, sn, cores, dn)}
+            'sample': '%s, %d envs x %d steps (%s), %d OpenMP threads, %.1f s'
+                      % (workload, 64 * cores, sn, {'full': 'physics + raster', 'render': 'raster only'}.get(phase, 'step without raster'),
+                         cores, dn)}
 
 
 def free_port():
@@ -244,7 +247,15 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--total-envs', type=int, default=0,
                     help='strong scaling: this many envs in all, split over the ranks (shard_range); overrides --envs-per-gpu')
-    ap.add_argument('--workload', default=WORKLOAD)
+    ap.add_argument('--workload', default=WORKLOAD,
+                    help='a recipe of moog_demos.example_configs; name@size = the recipe with a size x size renderer '
+                         '(functional_maze@128 --envs-per-gpu 8192 is BASELINE.json configs[3])')
+    ap.add_argument('--phase', default='full', choices=('full', 'step', 'physics', 'render'),
+                    help="what a timed step is (the phases of the reference's tests/runtime_benchmark.py:64-157): full = step + frames "
+                         '(the headline); step = the full step with the observers disabled (:75-84; BASELINE.json configs[1], '
+                         '"physics-only (no observer)", is --workload chase_avoid_torus --phase step); physics = '
+                         'env.physics.step alone (:101-107, moog_engine_physics_only); render = env.observation() alone (:113-130, '
+                         'moog_engine_render)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-schedule', action='store_true', help='disable cost-ordered launch')
     ap.add_argument('--no-fused', action='store_true', help='(accepted and ignored: the launch structure it switched off was retired with ABI 30)')
@@ -353,11 +364,17 @@ def main():
 
     m = n // G
 
+    phase = ['full']   # (burn-in and warm-up of the physics / render phases are full steps: the timed phase starts from the stationary mix)
+
     def one_step():
         a = acts[step_no[0] % ring]
         if G > 1:   # every sub-batch queues its step behind its own previous call only: no whole-batch barrier
             for g in range(G):
                 env.step_async(g, a[g * m:(g + 1) * m])
+        elif phase[0] == 'physics':
+            env.physics_step()
+        elif phase[0] == 'render':
+            env.observation()
         else:
             env.step(a)
         step_no[0] += 1
@@ -374,6 +391,15 @@ def main():
         burn_in = int(timeout) + 1
         for _ in range(burn_in):
             one_step()
+    if args.phase != 'full' and G > 1:
+        sys.stderr.write('bench.py: --phase %s needs --sub-batches 1\n' % args.phase)
+        sys.exit(2)
+    if args.phase == 'step':   # observers disabled: the engine is handed no image pointer (moog_demos/runtime_benchmark.py phase 1)
+        env._out.image = None
+        args.no_extras = True
+    phase[0] = args.phase
+    if args.phase in ('physics', 'render'):
+        args.no_extras = True
     for _ in range(args.warmup):
         one_step()
     # Kernels of the timed region are bracketed by HIP events on the launch stream, so the per-kernel
@@ -418,14 +444,26 @@ def main():
     faults = int((env.state_i32[:, env.layout.o_fault] != 0).sum().item())
     if rank == 0:
         total_steps = int(envs_seen) * args.steps
-        rb = raster_bytes_per_env(env)
-        r_ms, r_n = k_ms['raster']
+        frames = args.phase in ('full', 'render')
+        if frames:
+            rb = raster_bytes_per_env(env)
+            r_ms, r_n = k_ms['raster']
+            roof_kernel = raster_kernel_name(env)
+            tr = raster_traffic(args.workload, n)
+        else:
+            # No frames in this phase: the launch that dominates is the step kernel.  Its algorithmic bytes (SURVEY 8d B_phys: the
+            # mutable sprite state read and written once, the per-sprite parameters read, the action; sub-steps stay on chip):
+            # S x (6 x 8 + 6 x 8 + 1) + S x 56 + 16 bytes per env-step.  It is a latency-bound O(S^2) geometry kernel: the HBM
+            # fraction is reported because the contract asks for one, not because HBM bounds it.
+            rb = float(P.n_slots * 153 + 16)
+            r_ms, r_n = k_ms['step']
+            roof_kernel = 'moog_step_kernel (csrc/moog_kernels.h; not HBM-bound: one wavefront per env, dependent fp64 chain)'
+            tr = None
         r_avg_s = (r_ms / max(r_n, 1)) * 1e-3
         achieved = (n * rb / r_avg_s) / 1e9 if r_avg_s > 0 else 0.0
-        tr = raster_traffic(args.workload, n)
         line = {
             'metric': 'env steps/sec (whole node), %d envs x %d sprites, %dx%d obs' % (
-                n, P.n_slots, P.render.height, P.render.width),
+                n, P.n_slots, P.render.height, P.render.width) + ('' if args.phase == 'full' else ' [phase: %s]' % args.phase),
             'value': total_steps / dt_max,
             'unit': 'env steps/sec',
             'n_gpus': world,
@@ -443,6 +481,9 @@ def main():
                                    'random joystick actions, auto-reset on' % (
                                        args.workload, n, P.n_slots, P.updates_per_env_step,
                                        P.render.height, P.render.width),
+                       'phase': {'full': 'step + frames', 'step': 'full step, observers disabled (no frames)',
+                                 'physics': 'physics.step only (moog_engine_physics_only)',
+                                 'render': 'env.observation() only (moog_engine_render)'}[args.phase],
                        'envs_per_gpu': n, 'total_envs': int(envs_seen), 'sprites': P.n_slots, 'obs': [P.render.height, P.render.width],
                        'parallelism': 'env-sharded x%d, no collective' % world,
                        'launch': (('%d asynchronous sub-batches of %d envs, one HIP stream each: step -> frames -> next step '
@@ -462,7 +503,7 @@ def main():
                          'traffic_source': (tr.get('source', 'profiles/raster_traffic.json') + ' (offline rocprofv3 PMC passes, '
                                             'not this run)') if tr else None,
                          'algorithmic_bytes_per_launch': n * rb,
-                         'kernel': raster_kernel_name(env), 'avg_kernel_us': r_avg_s * 1e6, 'kernel_samples': int(r_n),
+                         'kernel': roof_kernel, 'avg_kernel_us': r_avg_s * 1e6, 'kernel_samples': int(r_n),
                          'algorithmic_bytes_per_env': rb},
             'kernels_avg_us': {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in k_ms.items() if v[1] > 0},
             'kernels_avg_us_note': 'HIP-event brackets around every %dth launch inside the timed region' % every,
@@ -470,7 +511,7 @@ def main():
         }
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args.workload)
+            line['cpu_baseline'] = cpu_baseline(args.workload, phase=args.phase)
         elif world > 1:
             line['cpu_baseline'] = None
             line['cpu_baseline_note'] = 'timed by the --gpus 1 run only (rank 0, N = 1)'

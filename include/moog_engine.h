@@ -696,6 +696,10 @@ typedef struct moog_engine moog_engine_t;
 enum { MOOG_K_STEP = 0, MOOG_K_RASTER = 1, MOOG_K_RESET = 2, MOOG_K_COUNT = 3 };
 
 int moog_abi_version(void);
+/* The digest of the kernel sources and hipcc flags the library was built from (moog/_digest.py: 64 bits of SHA-256 over
+ * csrc/ and this header, passed to the build as -DMOOG_SRC_DIGEST).  A program-specialised step kernel is used only when
+ * it carries the same digest (the symbol `moog_spec_source_digest` of the object); 0 = built without one. */
+unsigned long long moog_source_digest(void);
 const char* moog_last_error(void);
 /* sizeof(moog_program_t) as compiled, for binding self-checks */
 int64_t moog_program_sizeof(void);
@@ -733,8 +737,8 @@ int moog_engine_physics_only(moog_engine_t* e, const moog_inject_t* inject,
 int moog_engine_render(moog_engine_t* e, uint8_t* image_dev, void* hip_stream);
 
 /* Optional launch-order schedule for the step kernel (pure performance hint, results do
- * not depend on it).  `cost_dev` (float[n_envs], borrowed) receives every env's shader-clock
- * cycles of the last step; `perm_dev` (int32[n_envs], borrowed, initialised by the caller to a
+ * not depend on it).  `cost_dev` (float[n_envs], borrowed; zeroed by this call) holds a moving average of every env's
+ * shader-clock cycles per step (0.6 x the last step + 0.4 x the value before: the step kernel reads and writes it); `perm_dev` (int32[n_envs], borrowed, initialised by the caller to a
  * permutation, e.g. the identity) is the order in which workgroups pick envs.  After every
  * step the engine re-sorts it by descending cost (counting sort on a side stream, overlapped
  * with the rasteriser) so that the expensive envs (clustered contacts) start first instead of
@@ -822,7 +826,8 @@ int moog_engine_kernel_variant(moog_engine_t* e, int32_t* variant, int32_t* late
  * BatchedEnvironment(specialize=True)) drops what the program does not use and folds its parameters: same arithmetic, bit-identical
  * results, 7 % faster on the headline workload.  moog_engine_create looks for
  *     <MOOG_SPEC_DIR, default: the directory of the engine library + "/spec">/step_<hash>_d<variant>w<wps>.so
- * and uses it after checking ABI, variant and the embedded program byte for byte (MOOG_STEP_SPEC=0: never).
+ * and uses it after checking the digest of the sources it was built from (moog_source_digest), ABI, variant and the embedded
+ * program byte for byte (MOOG_STEP_SPEC=0: never).  An object that fails a check is reported on stderr and left alone.
  * moog_program_step_kernel (no device needed): the variant (0 plain, 1 + evaluator / sampler / dynamic layers, 2 + the rare
  * components), the register-allocation variant (waves per SIMD) and the hash the file name carries (FNV-1a 64 of the
  * program's bytes).  moog_engine_step_kernel: whether this engine steps with a specialised kernel. */
@@ -830,8 +835,10 @@ int moog_program_step_kernel(const moog_program_t* program, int32_t* variant, in
 int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised);
 
 /* Which rasteriser draws this engine's ordinary frames (what a profile of the run names): MOOG_RASTER_MASK = the mask
- * rasteriser (csrc/moog_raster_mask_core.h: one-tile frames, polygons of <= 32 vertices, no copying polygon modifier),
- * MOOG_RASTER_SPANS = the push / sort / span kernel (csrc/moog_raster_kernel.h: everything else, and every prefix picture). */
+ * rasteriser (csrc/moog_raster_mask_core.h: one-tile frames -- padded width and height <= 128 --, polygons of <= 128
+ * vertices, slots x copies <= 256, tables within 64 KB of LDS; plain, first-person and torus frames),
+ * MOOG_RASTER_SPANS = the push / sort / span kernel (csrc/moog_raster_kernel.h: everything else, every prefix picture, and
+ * every frame while a per-env prefix is active). */
 enum { MOOG_RASTER_SPANS = 0, MOOG_RASTER_MASK = 1 };
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path);
 

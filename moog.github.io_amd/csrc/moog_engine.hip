@@ -314,12 +314,23 @@ static uint64_t program_hash(const moog_program_t* prog) {   // FNV-1a 64 over t
 
 // A step kernel compiled for exactly this program (csrc/moog_step_spec.hip), if one has been built: looked for as
 // <MOOG_SPEC_DIR or the directory of this library + "/spec">/step_<hash>_d<variant>w<wps>.so.  Everything about it is
-// checked -- ABI, argument struct, variant, and the embedded program byte for byte -- before it replaces the generic kernel.
+// checked -- the digest of the kernel sources and flags it was built from, ABI, argument struct, variant, and the embedded
+// program byte for byte -- before it replaces the generic kernel.
 static void load_spec_kernel(moog_engine* e, const moog_program_t* prog);
+
+// The digest of the kernel sources and flags this library was built from (moog/_digest.py; -DMOOG_SRC_DIGEST=0x...ull on the
+// command line of this unit and of every program-specialised step kernel).  0: built without one -- no specialised kernel loads.
+#ifndef MOOG_SRC_DIGEST
+#define MOOG_SRC_DIGEST 0ull
+#endif
+#define MOOG_STR2(x) #x
+#define MOOG_STR(x) MOOG_STR2(x)
+extern "C" const char moog_src_digest_marker[] = "MOOG_SRC_DIGEST=" MOOG_STR(MOOG_SRC_DIGEST);   // (read as text by moog/_digest.py)
 
 extern "C" {
 
 int moog_abi_version(void) { return MOOG_ABI_VERSION; }
+unsigned long long moog_source_digest(void) { return MOOG_SRC_DIGEST; }
 const char* moog_last_error(void) { return g_err.c_str(); }
 int64_t moog_program_sizeof(void) { return (int64_t)sizeof(moog_program_t); }
 
@@ -1064,6 +1075,10 @@ int moog_engine_set_schedule(moog_engine_t* e, int32_t* perm_dev, float* cost_de
   if (e->sched_pending) { hipEventSynchronize(e->ev_sched_done); e->sched_pending = false; }
   e->perm = perm_dev;
   e->cost = cost_dev;
+  if (perm_dev && cost_dev) {   // the step kernel reads the costs (a moving average): they start from zero, whatever the caller's memory held
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemset(cost_dev, 0, (size_t)e->n_envs * sizeof(float)));
+  }
   if (perm_dev && cost_dev && !e->sched_stream) {
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamCreateWithFlags(&e->sched_stream, hipStreamNonBlocking));
@@ -1290,6 +1305,15 @@ static void load_spec_kernel(moog_engine* e, const moog_program_t* prog) {
   typedef int (*fn_cfg)(size_t);
   fn_i abi = reinterpret_cast<fn_i>(dlsym(h, "moog_spec_abi")), var = reinterpret_cast<fn_i>(dlsym(h, "moog_spec_variant"));
   fn_u hash = reinterpret_cast<fn_u>(dlsym(h, "moog_spec_hash")), ksz = reinterpret_cast<fn_u>(dlsym(h, "moog_spec_kargs_size"));
+  fn_u dig = reinterpret_cast<fn_u>(dlsym(h, "moog_spec_source_digest"));
+  // (the sources first: an object of another build of the same ABI number may differ in anything)
+  if (!dig || dig() != MOOG_SRC_DIGEST || MOOG_SRC_DIGEST == 0ull) {
+    fprintf(stderr, "moog: %s was built from other kernel sources or flags (digest %016llx, this library %016llx); the generic step "
+            "kernel is used -- rebuild it (python -m moog._spec ..., __graft_entry__.build())\n", path.c_str(),
+            dig ? dig() : 0ull, (unsigned long long)MOOG_SRC_DIGEST);
+    dlclose(h);
+    return;
+  }
   fn_p pr = reinterpret_cast<fn_p>(dlsym(h, "moog_spec_program"));
   fn_cfg cfg = reinterpret_cast<fn_cfg>(dlsym(h, "moog_spec_configure"));
   void* launch = dlsym(h, "moog_spec_launch");

@@ -14,8 +14,12 @@
 #elif defined(MOOG_COST_DECAY)
 #define MOOG_COST_OF(now, before) fmaxf((now), MOOG_COST_DECAY * (before))
 #else
-#define MOOG_COST_OF(now, before) (0.4f * (before) + 0.6f * (now))
+#define MOOG_COST_OF(now, before) moog_cost_ema((now), (before))
 #endif
+// (a `before` that is not a finite number -- a caller's cost array that was never initialised -- would stay in the average for good)
+static __device__ __forceinline__ float moog_cost_ema(float now, float before) {
+  return (before >= 0.f && before < 3.0e38f) ? 0.4f * before + 0.6f * now : now;
+}
 
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
@@ -489,14 +493,38 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
 // took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
 // counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
 // The order inside a bin is arbitrary -- the schedule never changes a result.
+// Round 6 (33.6 us -> a handful): a thread keeps its envs' bins in registers (one pass over the costs
+// instead of three), the prefix sum over the bins is a DPP scan per wavefront + one over the sixteen wave totals (three
+// barriers instead of twenty-two), a cost that is not a finite number (a caller's uninitialised array) counts as zero.
 #define SCHED_BINS 1024
+#define SCHED_KEEP 8   // bins a thread keeps in registers: batches of up to 8192 envs make one pass over the costs
+__device__ __forceinline__ int sched_wave_scan(int v) {   // inclusive, within a wavefront (the rasteriser's rm_wave_scan)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ float sched_cost(const float* cost, int i) { const float c = cost[i]; return (c >= 0.f && c < 3.0e38f) ? c : 0.f; }
 __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int32_t* perm, int n,
                                                            const int32_t* reset_next, int stride) {
   __shared__ int hist[SCHED_BINS];
   __shared__ float red[16];
+  __shared__ int wsum[16];
   const int t = threadIdx.x;
+  float c[SCHED_KEEP];
+  int rn[SCHED_KEEP];
   float m = 0.f;
-  for (int i = t; i < n; i += 1024) m = fmaxf(m, cost[i]);
+#pragma unroll
+  for (int q = 0; q < SCHED_KEEP; ++q) {
+    const int i = t + 1024 * q;
+    c[q] = i < n ? sched_cost(cost, i) : 0.f;
+    rn[q] = i < n ? reset_next[(size_t)i * stride] : 0;
+    m = fmaxf(m, c[q]);
+  }
+  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024) m = fmaxf(m, sched_cost(cost, i));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((t & 63) == 0) red[t >> 6] = m;
   hist[t] = 0;
@@ -507,32 +535,35 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
   // bin 0 = most expensive
   // (an env whose episode just ended is reset inside the next step kernel: the sampler's rejection loop is
   //  as long as the heaviest step, so it starts first)
-  for (int i = t; i < n; i += 1024) {
-    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
+  auto bin_of = [&](float cv, int r) {
+    int b = SCHED_BINS - 1 - (int)(cv * scale);
     b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
-    if (reset_next[(size_t)i * stride] == 1) b = 0;
-    atomicAdd(&hist[b], 1);
+    return r == 1 ? 0 : b;
+  };
+  int bq[SCHED_KEEP];
+#pragma unroll
+  for (int q = 0; q < SCHED_KEEP; ++q) {
+    bq[q] = bin_of(c[q], rn[q]);
+    if (t + 1024 * q < n) atomicAdd(&hist[bq[q]], 1);
   }
+  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024) atomicAdd(&hist[bin_of(sched_cost(cost, i), reset_next[(size_t)i * stride])], 1);
   __syncthreads();
-  // exclusive prefix sum over the 1024 bins (one bin per thread, Hillis-Steele in LDS)
-  int v = hist[t];
+  // exclusive prefix sum over the 1024 bins, one bin per thread
+  const int v = hist[t];
+  const int inc = sched_wave_scan(v);
+  if ((t & 63) == 63) wsum[t >> 6] = inc;
   __syncthreads();
-  for (int o = 1; o < SCHED_BINS; o <<= 1) {
-    int add = (t >= o) ? hist[t - o] : 0;
-    __syncthreads();
-    hist[t] += add;
-    __syncthreads();
+  int before = 0;
+  for (int w = 0; w < (t >> 6); ++w) before += wsum[w];
+  hist[t] = before + inc - v;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SCHED_KEEP; ++q) {
+    const int i = t + 1024 * q;
+    if (i < n) perm[atomicAdd(&hist[bq[q]], 1)] = i;
   }
-  const int start = hist[t] - v;
-  __syncthreads();
-  hist[t] = start;
-  __syncthreads();
-  for (int i = t; i < n; i += 1024) {
-    int b = SCHED_BINS - 1 - (int)(cost[i] * scale);
-    b = b < 0 ? 0 : (b > SCHED_BINS - 1 ? SCHED_BINS - 1 : b);
-    if (reset_next[(size_t)i * stride] == 1) b = 0;
-    perm[atomicAdd(&hist[b], 1)] = i;
-  }
+  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024)
+    perm[atomicAdd(&hist[bin_of(sched_cost(cost, i), reset_next[(size_t)i * stride])], 1)] = i;
 }
 #endif
 

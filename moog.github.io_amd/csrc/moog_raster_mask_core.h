@@ -1,7 +1,8 @@
 // moog_raster_mask_core.h -- the "mask" rasteriser: Pillow-exact polygon fill without sorting crossings.
 //
-// Replaces, for one-tile frames (<= 128 x 128 canvas, polygons of <= 32 vertices; plain frames, first-person frames and the
-// nine copies per sprite of a torus), the push / sort / span pipeline of moog_raster_kernel.h.  Same contract: bit-exact with ImageDraw.polygon in RGBA blend mode as PILRenderer uses it
+// Replaces, for one-tile frames (<= 128 x 128 canvas, polygons of <= 128 vertices -- census words up to 32, an indexed edge list
+// beyond --, <= 256 items; plain frames, first-person frames and the nine copies per sprite of a torus), the push / sort / span
+// pipeline of moog_raster_kernel.h.  Same contract: bit-exact with ImageDraw.polygon in RGBA blend mode as PILRenderer uses it
 // (reference moog/observers/pil_renderer.py:88-120; Pillow Draw.c ImagingDrawPolygon / polygon_generic(hasAlpha = 1) /
 // hline32rgba as restated in oracle/moog_oracle.c).
 //

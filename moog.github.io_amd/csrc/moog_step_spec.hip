@@ -8,8 +8,17 @@
 #define MOOG_WITH_MAZE (MOOG_STEP_DYN == 2)
 #include "moog_kernels.h"
 
+#ifndef MOOG_SRC_DIGEST
+#define MOOG_SRC_DIGEST 0ull
+#endif
+#define MOOG_STR2(x) #x
+#define MOOG_STR(x) MOOG_STR2(x)
+extern "C" const char moog_src_digest_marker[] = "MOOG_SRC_DIGEST=" MOOG_STR(MOOG_SRC_DIGEST);   // (read as text by moog/_digest.py)
+
 extern "C" {
 
+// (moog/_digest.py: the kernel sources and flags this object was built from; the engine library refuses another build's)
+unsigned long long moog_spec_source_digest(void) { return MOOG_SRC_DIGEST; }
 int moog_spec_abi(void) { return MOOG_ABI_VERSION; }
 unsigned long long moog_spec_hash(void) { return MOOG_SPEC_HASH; }
 int moog_spec_variant(void) { return MOOG_STEP_DYN | (MOOG_STEP_WPS << 8); }

@@ -26,7 +26,7 @@ from .state_initialization import distributions as distribs
 
 Compiled = collections.namedtuple(
     'Compiled', ['program', 'layer_names', 'layer_slots', 'observer_key', 'layout', 'shape_names', 'rule_ref_index',
-                 'pstate_slots', 'dynamic_meta', 'color_fn'])
+                 'pstate_slots', 'dynamic_meta', 'color_fn', 'layer_n_init'])
 
 
 class _ShapeTable(object):
@@ -417,6 +417,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
     # slots: layer order, list order
     slot_of = {}
     slot_sprite = []
+    layer_n_init = {}
     P.n_layers = len(layer_names)
     for li, name in enumerate(layer_names):
         P.layer_slot0[li] = len(slot_sprite)
@@ -427,6 +428,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             P.slot_layer[len(slot_sprite)] = li
             slot_sprite.append(s)
         n_init = len(slot_sprite) - P.layer_slot0[li]
+        layer_n_init[name] = n_init   # (slots of the layer that have a recipe: the floor of any later re-sizing)
         cap = n_init
         if name in dynamic:
             P.layer_dynamic[li] = 1
@@ -1387,7 +1389,7 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
                  [(slot_of[id(sp)], key, cell, table) for sp, key, cell, table in getattr(tr, 'dynamic_meta', [])
                   if id(sp) in slot_of],
                  # PILRenderer(color_to_rgb=<a callable>): evaluated on the host (environment.py _refresh_colors)
-                 ren.color_to_rgb if ren._cmap == 'callable' else None)
+                 ren.color_to_rgb if ren._cmap == 'callable' else None, layer_n_init)
     # shape id -> Sprite.shape value (sprite.py:517-523): the name, or 'custom' for raw vertices
     c.shape_names.extend(k[1] if k[0] == 'name' else 'custom' for k, _ in shapes.entries)
     return c

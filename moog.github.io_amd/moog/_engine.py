@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', 'lib', 'libmoog_hip.so'))
 
 SYMBOLS = (
-    'moog_abi_version', 'moog_last_error', 'moog_program_sizeof', 'moog_engine_create',
+    'moog_abi_version', 'moog_source_digest', 'moog_last_error', 'moog_program_sizeof', 'moog_engine_create',
     'moog_engine_destroy', 'moog_engine_layout', 'moog_engine_load_state', 'moog_engine_reset',
     'moog_engine_step', 'moog_engine_physics_only', 'moog_engine_render',
     'moog_engine_set_timing', 'moog_engine_kernel_time', 'moog_engine_set_schedule',
@@ -52,6 +52,7 @@ def load_library(path=None):
     lib = ctypes.CDLL(path)
     vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
     lib.moog_abi_version.restype = ctypes.c_int
+    lib.moog_source_digest.restype = ctypes.c_uint64
     lib.moog_last_error.restype = ctypes.c_char_p
     lib.moog_program_sizeof.restype = i64
     lib.moog_engine_create.argtypes = [ctypes.POINTER(_abi.Program), i32, i32, u64, i64,
@@ -84,7 +85,7 @@ def load_library(path=None):
                                             ctypes.POINTER(i64)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ('moog_last_error', 'moog_program_sizeof', 'moog_abi_version'):
+        if name not in ('moog_last_error', 'moog_program_sizeof', 'moog_abi_version', 'moog_source_digest'):
             fn.restype = ctypes.c_int
     if lib.moog_abi_version() != _abi.MOOG_ABI_VERSION:
         raise EngineError('ABI mismatch: library %d, header %d'

@@ -381,7 +381,9 @@ class BatchedEnvironment(object):
             alive = flags[:, s0:s0 + n_old].any(dim=0).nonzero()
             in_use = int(alive.max().item()) + 1 if alive.numel() else 0
             mark = max(use[name]['high_water'], in_use)
-            want = max(mark + int(min_room), int(math.ceil(mark * (1.0 + headroom))), 1)
+            # (never below the slots the initializer fills: a layer whose sprites have all vanished is re-made whole by the
+            #  next reset, and compile_config refuses fewer slots than that)
+            want = max(mark + int(min_room), int(math.ceil(mark * (1.0 + headroom))), 1, int(self.compiled.layer_n_init.get(name, 0)))
             if want < n_old:
                 caps[name] = want
         if caps:
@@ -402,6 +404,13 @@ class BatchedEnvironment(object):
         new_c = _compiler.compile_config(*self._config_args, layer_capacity=caps, keep_sprite_factors=self._keep_sprite_factors)
         P, L = new_c.program, new_c.layout
         assert list(new_c.layer_names) == list(old_c.layer_names)
+        # Other capacities = another program = another hash: the specialised step kernel of the old program does not fit.
+        # specialize=True builds the new program's (~20 s of hipcc, once per capacity set; kept in the spec directory); otherwise the
+        # engine falls back to the generic kernels -- said once, so that a slower run is not a mystery (step_kernel() tells).
+        was_specialised = self.step_kernel() == 'specialised'
+        if self._specialize:
+            from . import _spec
+            _spec.build(P)
         # index maps: for every word of a new record, the word of the old record it comes from (-1: zero)
         src_f = np.full(L.f64_per_env, -1, np.int64)
         src_q = np.full(L.i32_per_env, -1, np.int64)
@@ -468,6 +477,12 @@ class BatchedEnvironment(object):
         self._apply_reset_pool()
         self._setup_color_fn()
         self.capacity_growths = getattr(self, 'capacity_growths', []) + [dict(caps)]
+        if was_specialised and self.step_kernel() != 'specialised' and not getattr(self, '_warned_generic', False):
+            self._warned_generic = True
+            import warnings
+            warnings.warn('layer capacities changed to %s: the program-specialised step kernel was built for the old capacities, '
+                          'the generic step kernel is in use from here on (BatchedEnvironment(specialize=True) or '
+                          '`moog._spec.build(env.compiled.program)` builds one for the new program)' % (dict(caps),), RuntimeWarning)
 
     def raise_faults(self):
         """Re-raises device-side per-env faults with the reference's exception types.

@@ -19,6 +19,7 @@ NAMES = ('pong', 'chase_avoid_torus', 'colliding_predators', 'functional_maze', 
 def capacity(name):
     """layer_capacity for BatchedEnvironment / compile_config: run-time sprite capacity of the
     layers a recipe's rules append to (module attribute LAYER_CAPACITY), or None."""
+    name = name.partition('@')[0]
     m = re.match(r'(.*)_l(\d+)$', name)
     if m:
         name = m.group(1)
@@ -26,7 +27,13 @@ def capacity(name):
 
 
 def load(name, level=0):
+    """`name`: a recipe module; `<name>_l<k>`: its level k; `<name>@<size>`: the recipe with a size x size renderer
+    (functional_maze@128 = BASELINE.json configs[3]; the recipe's get_config must take `image_size`)."""
+    name, _, size = name.partition('@')
     m = re.match(r'(.*)_l(\d+)$', name)   # e.g. chase_avoid_torus_l1 = level 1 of chase_avoid_torus
     if m:
         name, level = m.group(1), int(m.group(2))
-    return importlib.import_module(__name__ + '.' + name).get_config(level)
+    get_config = importlib.import_module(__name__ + '.' + name).get_config
+    if size:
+        return get_config(level, image_size=(int(size), int(size)))
+    return get_config(level)

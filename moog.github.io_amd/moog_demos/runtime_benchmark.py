@@ -31,7 +31,9 @@ def _timed(fn, reps, sync):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def main():
+def main(argv=None):
+    """Runs the benchmark and prints its table; returns {'phases': {name: ms per batch}, 'render': {(size, anti_aliasing): ms per
+    batch}} (what tests/test_gpu_parity.py::test_runtime_benchmark_reports_every_phase checks)."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', default='colliding_predators_32')
     ap.add_argument('--level', type=int, default=0)
@@ -39,9 +41,9 @@ def main():
     ap.add_argument('--reps', type=int, default=50)
     ap.add_argument('--render_sizes', action='store_true', help='time the six (size, anti_aliasing) renderer settings')
     ap.add_argument('--render_envs', type=int, default=256, help='batch of the renderer-size sweep')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     env = environment.BatchedEnvironment(
-        num_envs=args.num_envs, **example_configs.load(args.config, args.level))
+        num_envs=args.num_envs, layer_capacity=example_configs.capacity(args.config), **example_configs.load(args.config, args.level))
     env.check_faults = False
     sync = torch.cuda.synchronize
     env.reset()
@@ -68,6 +70,7 @@ def main():
                                                      P.render.width))
     for name, ms in rows:
         print('  %-16s %9.3f ms / batch   %12.0f env-calls/s' % (name, ms, n / ms * 1e3))
+    result = {'phases': dict(rows), 'render': {}}
     if args.render_sizes:   # _IMAGE_SIZE_ANTI_ALIASING of the reference's benchmark
         from moog import observers
         env.close()
@@ -86,7 +89,11 @@ def main():
             ms = _timed(e2.observation, max(args.reps // 5, 3), sync)
             print('  render only, %4d x %-4d anti_aliasing %d: %9.3f ms / batch of %d   %10.0f frames/s' % (
                 size, size, aa, ms, m, m / ms * 1e3))
+            result['render'][(size, aa)] = ms
             e2.close()
+    else:
+        env.close()
+    return result
 
 
 if __name__ == '__main__':

@@ -343,23 +343,36 @@ def test_full_size_properties():
     assert np.array_equal(q2, q[128:192]) and np.array_equal(f2, f[128:192], equal_nan=True)
 
 
-@pytest.mark.parametrize('name,n,steps,size', [('chase_avoid_torus', 4096, 8, None),
-                                               ('colliding_predators_32', 4096, 8, None),
-                                               ('functional_maze', 8192, 6, 128),
-                                               ('falling_balls_64', 8192, 6, None)])
-def test_full_size_vs_oracle(name, n, steps, size):
+@pytest.mark.parametrize('name,n,steps,size,kernel', [('chase_avoid_torus', 4096, 8, None, 'specialised'),
+                                                      ('colliding_predators_32', 4096, 8, None, 'specialised'),
+                                                      ('functional_maze', 8192, 6, 128, 'specialised'),
+                                                      ('falling_balls_64', 8192, 6, None, 'specialised'),
+                                                      ('colliding_predators_32', 4096, 4, None, 'generic'),
+                                                      ('falling_balls_64', 8192, 3, None, 'generic')])
+def test_full_size_vs_oracle(name, n, steps, size, kernel, monkeypatch):
     """BASELINE.json's configs at their full per-GPU sizes against the oracle itself (OpenMP over envs
     makes it affordable): reset + a few steps in lock step -- integer records bit-exact, floats <= 1e-9,
-    rewards / step types exact, and every one of the final frames bit-exact."""
+    rewards / step types exact, and every one of the final frames bit-exact.  `kernel`: the binary that steps -- the
+    program-specialised kernels bench.py times (lib/spec/step_<hash>.so, built by __graft_entry__.build(); the test FAILS
+    when the engine did not pick one up, so the parity claim is about that binary) and, for two of the workloads, the generic
+    kernels (MOOG_STEP_SPEC=0)."""
     import torch  # noqa: F401
-    from moog import environment
+    from moog import _spec, environment
     from moog_demos import example_configs
+    if kernel == 'generic':
+        monkeypatch.setenv('MOOG_STEP_SPEC', '0')
+    else:
+        monkeypatch.delenv('MOOG_STEP_SPEC', raising=False)
+        monkeypatch.delenv('MOOG_SPEC_DIR', raising=False)
     if size is None:
         env = make_env(name, n, seed=17, env_index0=0)
     else:
         cfg = __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, image_size=(size, size))
         env = environment.BatchedEnvironment(num_envs=n, seed=17, env_index0=0,
                                              layer_capacity=example_configs.capacity(name), **cfg)
+    assert env.step_kernel() == kernel, (env.step_kernel(), _spec.path_of(env.compiled.program))
+    print('%s steps with the %s kernel%s' % (name, kernel, ': ' + os.path.basename(_spec.path_of(env.compiled.program))
+                                              if kernel == 'specialised' else ''))
     o = helpers.OracleEnv(env.compiled, n_envs=n, seed=17, env_index0=0)
     env.reset()
     o.reset(render=False)
@@ -414,15 +427,30 @@ def test_gym_wrapper_contract():
     assert np.array_equal(env.render(), obs['image'])
 
 
-def test_multi_device_sharding_matches_single_engine():
-    """Two engine handles (here on the same GPU) over a split env axis reproduce the
+def _shard_devices():
+    """Device lists for the sharding test: two handles on one GPU always; distinct GPUs when the box has them."""
+    import torch
+    lists = [['cuda:0', 'cuda:0']]
+    k = torch.cuda.device_count()
+    if k >= 2:
+        lists.append(['cuda:%d' % i for i in range(min(k, 8))])
+    return lists
+
+
+@pytest.mark.parametrize('which', ['one_gpu_two_handles', 'distinct_gpus'])
+def test_multi_device_sharding_matches_single_engine(which):
+    """Two (or, on a multi-GPU box, one per GPU) engine handles over a split env axis reproduce the
     single-engine batch: global-index RNG keys, no exchange between shards."""
     import torch
     from moog import sharding
     from moog_demos import example_configs
+    devices = _shard_devices()
+    if which == 'distinct_gpus' and len(devices) < 2:
+        pytest.skip('one GPU visible: distinct devices cannot be exercised here (bench.py --gpus N / tools/bench_ranks.sh are the N > 1 path)')
+    devices = devices[-1] if which == 'distinct_gpus' else devices[0]
     n = 96
     cfg = example_configs.load('chase_avoid_torus')
-    multi = sharding.MultiDeviceEnvironment(n, ['cuda:0', 'cuda:0'], seed=4, **cfg)
+    multi = sharding.MultiDeviceEnvironment(n, devices, seed=4, **cfg)
     single = make_env('chase_avoid_torus', n, seed=4)
     a = multi.gather(multi.reset())
     b = single.reset()
@@ -435,7 +463,7 @@ def test_multi_device_sharding_matches_single_engine():
     assert np.array_equal(a.step_type.numpy(), b.step_type.cpu().numpy())
     assert helpers.same_or_nan(a.reward.numpy(), b.reward.cpu().numpy())
     assert np.array_equal(a.observation['image'].numpy(), b.observation['image'].cpu().numpy())
-    f = torch.cat([s.state_f64 for s in multi.shards]).cpu().numpy()
+    f = torch.cat([s.state_f64.cpu() for s in multi.shards]).numpy()
     assert np.array_equal(f, single.state_f64.cpu().numpy(), equal_nan=True)
 
 
@@ -1806,6 +1834,48 @@ def test_specialised_step_kernel_is_result_neutral(name, n, steps, monkeypatch, 
         assert np.array_equal(t0.reward.cpu().numpy(), t1.reward.cpu().numpy(), equal_nan=True)
         assert np.array_equal(t0.observation['image'].cpu().numpy(), t1.observation['image'].cpu().numpy())
     env.raise_faults()
+
+
+@pytest.mark.gpu
+def test_runtime_benchmark_reports_every_phase(capsys):
+    """the batched counterpart of the reference's tests/runtime_benchmark.py:64-157 runs -- pong with one env and
+    with a batch -- and reports its five phases (step + render, step without render, reset, physics only, render only) and the
+    six renderer settings of runtime_benchmark.py:31-38 (64 .. 1024 pixels, anti_aliasing 1 / 2), every figure a positive time."""
+    from moog_demos import runtime_benchmark
+    phases = ('step + render', 'step, no render', 'reset only', 'physics only', 'render only')
+    r1 = runtime_benchmark.main(['--config', 'pong', '--num_envs', '1', '--reps', '5'])
+    assert tuple(r1['phases']) == phases and all(v > 0 for v in r1['phases'].values()) and r1['render'] == {}
+    r2 = runtime_benchmark.main(['--config', 'pong', '--num_envs', '4096', '--reps', '5', '--render_sizes', '--render_envs', '16'])
+    assert tuple(r2['phases']) == phases and all(v > 0 for v in r2['phases'].values())
+    assert sorted(r2['render']) == [(64, 1), (128, 1), (256, 1), (512, 1), (512, 2), (1024, 1)]
+    assert all(v > 0 for v in r2['render'].values())
+    out = capsys.readouterr().out
+    assert out.count('render only,') == 6 and 'pong: 4096 envs' in out and 'pong: 1 envs' in out
+    # a batch amortises the launches: 4096 envs per call cost far less than 4096 calls of one env
+    assert r2['phases']['step + render'] < 200 * r1['phases']['step + render']
+
+
+@pytest.mark.gpu
+def test_specialised_kernel_of_another_build_is_refused(monkeypatch, tmp_path, capfd):
+    """A specialised step kernel is tied to the kernel sources and flags it was built from (moog/_digest.py): an object that
+    carries another digest -- same ABI number, same program, same file name -- is reported and left alone, the engine steps
+    with the generic kernels; moog._spec.build() replaces it and remove_stale() deletes it."""
+    from moog import _digest, _engine, _spec
+    monkeypatch.setenv('MOOG_SPEC_DIR', str(tmp_path))
+    assert '%016x' % _engine.load_library().moog_source_digest() == _digest.source_digest() == _digest.digest_of(_engine.LIB_PATH)
+    probe = make_env('pong', 8, seed=1)
+    path = _spec.build(probe.compiled.program, digest='00000000deadbeef')
+    assert _digest.digest_of(path) == '00000000deadbeef' and not _spec.is_current(path)
+    env = make_env('pong', 8, seed=1)
+    assert env.step_kernel() == 'generic'
+    assert 'built from other kernel sources' in capfd.readouterr().err
+    env.close()
+    assert _spec.build(probe.compiled.program) == path and _spec.is_current(path)
+    env = make_env('pong', 8, seed=1)
+    assert env.step_kernel() == 'specialised'
+    env.close()
+    _spec.build(probe.compiled.program, force=True, digest='00000000deadbeef')
+    assert _spec.remove_stale() == [os.path.basename(path)] and not os.path.exists(path)
 
 
 @pytest.mark.gpu

@@ -38,6 +38,22 @@ def test_hip_library_exports_abi():
     assert declared == set(_engine.SYMBOLS), declared ^ set(_engine.SYMBOLS)
 
 
+def test_built_objects_carry_the_source_digest():
+    """moog/_digest.py: libmoog_hip.so and every specialised step kernel in lib/spec carry the digest of the kernel sources
+    and flags they were built from; __graft_entry__.build() leaves no object of another build behind (the engine would refuse
+    it one by one: csrc/moog_engine.hip load_spec_kernel, tests/test_gpu_parity.py::test_specialised_kernel_of_another_build_is_refused)."""
+    import glob
+    from moog import _digest, _spec
+    d = _digest.source_digest()
+    assert len(d) == 16 and _digest.digest_of(_engine.LIB_PATH) == d, 'libmoog_hip.so is not the build of these sources: run __graft_entry__.build()'
+    assert '%016x' % _engine.load_library().moog_source_digest() == d
+    objs = sorted(glob.glob(os.path.join(_spec.SPEC_DIR, 'step_*.so')))
+    assert len(objs) >= 4, 'the BASELINE workloads\' specialised kernels are built by __graft_entry__.build()'
+    stale = [os.path.basename(o) for o in objs if not _spec.is_current(o, d)]
+    assert not stale, stale
+    assert _digest.digest_of(os.path.join(_spec.SPEC_DIR, 'no_such_object.so')) is None
+
+
 def test_step_kernels_have_no_calls(tmp_path):
     """Every device function is inlined into the step / reset kernels: the env's descriptor (`Env`, moog_device.h) lives in
     registers only then.  One function left out of line takes it by reference through scratch memory (round 4: the step
