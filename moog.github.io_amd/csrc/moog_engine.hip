@@ -70,6 +70,9 @@ struct moog_engine {
   uint8_t* late_mask = nullptr;   // [n_envs]
   RPlan raster_plan_{};
   RmSetup mask_setup{};   // the mask rasteriser (moog_raster_mask_core.h): ok = this program's ordinary frames are drawn by it
+  uint8_t* draw = nullptr;        // its input: a draw record per env (moog_draw_record.h), written by the step kernel or derived before the launch
+  RmDrawLayout draw_lay{};
+  bool draw_in_step = true;       // MOOG_DRAW_IN_STEP=0: never by the step kernel (A/B runs, tests: the derive kernel for every launch)
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
   int aa = 1, canvas_w = 0, canvas_h = 0, aa_chunk = 0;
@@ -131,6 +134,7 @@ static void free_engine(moog_engine* e) {
   if (e->d_prog) hipFree(e->d_prog);
   if (e->d_vslot) hipFree(e->d_vslot);
   if (e->d_vinfo) hipFree(e->d_vinfo);
+  if (e->draw) hipFree(e->draw);
   if (e->s_f64) hipFree(e->s_f64);
   if (e->s_i32) hipFree(e->s_i32);
   if (e->s_bg) hipFree(e->s_bg);
@@ -701,6 +705,15 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) { cap = atoi(rc); e->raster_rows_fixed = 1; } }   // tuning / tests of the multi-pass path
       mask_plan_rows(e, cap);
       e->mask_free_cap = (ms.ok && !e->raster_rows_fixed) ? mask_free_rows(e) : ms.cap_rows;
+      if (ms.ok) {   // a draw record per env (moog_draw_record.h): header + an item per slot and copy + every vertex slot's point and owner byte
+        e->draw_lay = rm_draw_layout(ms.S, e->L.TOTV * ms.ncopy);
+        if (hipMalloc(&e->draw, (size_t)e->n_envs * e->draw_lay.stride) != hipSuccess) {
+          free_engine(e);
+          return fail(MOOG_E_NOMEM, "out of device memory (draw records)");
+        }
+        const char* ds = getenv("MOOG_DRAW_IN_STEP");
+        e->draw_in_step = !(ds && atoi(ds) == 0);
+      }
     }
   }
   {
@@ -862,6 +875,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   a.late_mask = (mode == MODE_STEP && e->late_reset) ? e->late_mask : nullptr;
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
   a.rank0 = 0;
+  memset(&a.draw, 0, sizeof a.draw);   // (moog_engine_step turns the draw records on)
   return a;
 }
 
@@ -875,6 +889,32 @@ static void launch_step(moog_engine* e, hipStream_t s, const KArgs& a) {
   const bool full = e->maze_kernel && !e->late_reset;
   if (e->step_wps == 2 && !full && !e->dynamic_rules) { moog_launch_step_f2(e->n_envs, e->step_lds, s, a); return; }
   launch[(full ? 4 : (e->dynamic_rules ? 2 : 0)) + (e->step_wps == 4 ? 1 : 0)](e->n_envs, e->step_lds, s, a);
+}
+
+// What the draw-record emitter needs (moog_draw_record.h): by value in the step kernel's and the derive kernel's arguments.
+// out = null when this engine's frames are not the mask rasteriser's.
+static RmEmit emit_args(moog_engine* e) {
+  RmEmit m;
+  memset(&m, 0, sizeof m);
+  const RmSetup& ms = e->mask_setup;
+  if (!ms.ok || !e->draw) return m;
+  m.out = e->draw; m.lay = e->draw_lay;
+  m.S = ms.S; m.slots = ms.slots; m.ncopy = ms.ncopy; m.W = e->pad_w; m.H = e->canvas_h; m.scale_w = e->canvas_w;
+  m.cmap = ms.cmap; m.first_person = ms.first_person; m.fp_slot0 = ms.fp_slot0; m.fp_nslots = ms.fp_nslots;
+  m.n_static = (e->s_f64 && ms.ncopy == 1) ? e->n_static : 0;
+  m.sref_v = e->s_f64 ? e->s_f64 + e->L.o_verts : nullptr;
+  m.sref_col = e->s_f64 ? e->s_f64 + e->L.o_color : nullptr;
+  m.sref_flags = e->s_i32 ? e->s_i32 + e->L.o_flags : nullptr;
+  m.sref_nv = e->s_i32 ? e->s_i32 + e->L.o_nverts : nullptr;
+  m.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
+  m.rgb_override = e->rgb_override;
+  return m;
+}
+// The step kernel writes the draw records of the frames the raster launch behind it draws (moog_engine_step with an image):
+// when those frames are the mask rasteriser's, drawn in one launch over every env, and the step kernel is the one that leaves
+// every env's record final (a late-reset program's episodes are opened by the reset kernel behind it: derived instead).
+static bool step_emits_draw(moog_engine* e) {
+  return e->draw_in_step && e->mask_setup.ok && e->draw && e->pe_ns <= 0 && e->aa <= 1 && !e->late_reset;
 }
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
@@ -898,6 +938,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
   r.sbg_env_stride = 0; r.env_build = nullptr; r.rgb_override = e->rgb_override;
+  r.em = emit_args(e); r.draw_ready = 0; r.env0 = 0;
   return r;
 }
 
@@ -927,8 +968,9 @@ static int use_env_prefix(moog_engine* e, RArgs& r, hipStream_t s) {
   return MOOG_OK;
 }
 
-static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1) {
+static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int timed = -1, bool draw_ready = false) {
   RArgs r = raster_args(e, image);
+  r.draw_ready = draw_ready ? 1 : 0;
   Bracket br(e, MOOG_K_RASTER, s, timed);
   if (e->aa <= 1) { const int rc = use_env_prefix(e, r, s); if (rc) return rc; }
   if (e->aa <= 1 && e->pad_w != e->canvas_w) {   // drawn 16-aligned, cropped into the caller's frames
@@ -946,6 +988,7 @@ static int launch_raster(moog_engine* e, uint8_t* image, hipStream_t s, int time
       c.i32 = r.i32 + (size_t)e0 * e->L.i32_per_env;
       c.image = e->aa_canvas;
       c.n_envs = n;
+      c.env0 = e0; c.draw_ready = 0;
       moog_raster_launch(c, e->raster_lds, s);
       moog_resize_launch(e->aa_resize, e->aa_canvas, e->aa_tmp, image + (size_t)e0 * frame, n, s);
     }
@@ -1027,6 +1070,8 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   hipStream_t s = (hipStream_t)hip_stream;
   // (envs whose episode ended in the previous call are reset inside the step kernel, environment.py:100-101)
   KArgs a = make_args(e, actions_dev, inject, out, MODE_STEP, nullptr);
+  const bool emit = out && out->image && step_emits_draw(e);
+  if (emit) a.draw = emit_args(e);
   if (e->sched_pending) {   // the order computed from the previous step's costs
     HIPCHK(hipStreamWaitEvent(s, e->ev_sched_done, 0));
     e->sched_pending = false;
@@ -1046,7 +1091,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
     HIPCHK(hipEventRecord(e->ev_sched_done, e->sched_stream));
     e->sched_pending = true;
   }
-  if (out && out->image) return launch_raster(e, out->image, s);
+  if (out && out->image) return launch_raster(e, out->image, s, -1, emit);
   return MOOG_OK;
 }
 

@@ -3,6 +3,7 @@
 // the host side (moog_engine.hip), which only sees the launch functions declared at the bottom.
 #pragma once
 #include "moog_device.h"
+#include "moog_draw_record.h"   // the rasteriser's input, written where the record is on chip (step_env's epilogue)
 
 // What the launch order of the next call sorts by (moog_sched_kernel): 0.6 x this call's cycles + 0.4 x the previous value.  An
 // env that was expensive lately tends to be expensive again (a pile of sprites in contact) even when one call in between was
@@ -175,6 +176,7 @@ struct KArgs {
   const double* live_f64;    // MODE_FILL: the live records (a.f64 / a.i32 are pool_f64[1] / pool_i32[1] then)
   const int32_t* live_i32;
   int32_t rank0;         // launch rank of workgroup 0 (0; a launch split by rank was measured in round 5, profiles/r05_step_experiments.txt)
+  RmEmit draw;           // draw.out != null: a step (MODE_STEP) also writes the env's draw record (moog_draw_record.h) for the raster launch behind it
   int32_t prio_t[3];     // wave priorities by launch rank (with `perm`: descending cost of the previous step): workgroups
                          // [0, t0) issue at priority 3, [t0, t1) at 2, [t1, t2) at 1, the rest at 0; all zero: off
 };
@@ -225,6 +227,28 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.seed = a.seed;
   e.env_index = a.env_index0 + env;
   e.lane = lane;
+}
+
+// The env's record as the step kernel holds it (LDS; colours and opacities where bind_env says) for the draw-record emitter
+struct RmSrcEnv {
+  const Env* e;
+  __device__ __forceinline__ int flags(int s) const { return e->q[e->L.o_flags + s]; }
+  __device__ __forceinline__ int nv(int s) const { return e->q[e->L.o_nverts + s]; }
+  __device__ __forceinline__ int opa(int s) const { return static_cast<const int32_t*>(e->gopa)[s]; }
+  __device__ __forceinline__ int voff(int s) const { return e->voff[s]; }
+  __device__ __forceinline__ int vcap(int s) const { return e->P->slot_vcap[s]; }
+  __device__ __forceinline__ double col(int s, int c) const { return static_cast<const double*>(e->gcol)[3 * s + c]; }
+  __device__ __forceinline__ const double* vert(int s) const { return &e->f[e->L.o_verts + 2 * e->voff[s]]; }
+  __device__ __forceinline__ const double* pos(int s) const { return &e->f[e->L.o_pos + 2 * s]; }
+};
+// After store_record: the frame the rasteriser is about to draw, from the record still in LDS (what the reset path wrote
+// straight to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
+__device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, int env) {
+  if (!a.draw.out) return;
+  wsync();
+  RmSrcEnv src;
+  src.e = &e;
+  rm_emit(a.draw, src, env, e.lane);
 }
 
 // =====================================================================================
@@ -617,6 +641,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
     }
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     if (DYN && held) pool_release(a, env, e.lane);
+    emit_draw_record(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
     return;
   }
@@ -678,6 +703,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   }
   SEC(e, SEC_STORE);
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
+  emit_draw_record(e, a, env);
   if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);

@@ -60,6 +60,11 @@ struct RmSetup {
 
 struct RArgs {
   RmSetup ms;
+  // (mask rasteriser) the draw records it reads (moog_draw_record.h).  draw_ready: the step kernel wrote them for exactly these
+  // records (moog_engine_step); else moog_raster_launch derives them from f64 / i32 first.  env0: the engine's index of env 0
+  // of this launch (launches over a chunk of the envs).
+  RmEmit em;
+  int32_t draw_ready, env0;
   int32_t* rows_seen;     // (mask rasteriser) host-mapped word for frames that want more row records, or null
   const moog_program_t* P;
   moog_layout_t L;

@@ -20,13 +20,11 @@ int moog_raster_configure(size_t lds_bytes) {
 static RmArgs mask_args(const RArgs& r) {
   RmArgs a;
   memset(&a, 0, sizeof a);
-  a.P = r.P; a.L = r.L; a.f64 = r.f64; a.i32 = r.i32; a.image = r.image; a.vinfo = r.vinfo;
-  a.n_envs = r.n_envs; a.S = r.ms.S; a.slots = r.ms.slots; a.ncopy = r.ms.ncopy; a.big = r.ms.big; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h; a.scale_w = r.scale_w;
-  a.flip = r.flip; a.iwords = r.ms.iwords; a.cmap = r.ms.cmap; a.first_person = r.ms.first_person;
-  a.fp_slot0 = r.ms.fp_slot0; a.fp_nslots = r.ms.fp_nslots; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
-  a.n_static = r.n_static; a.nsv = r.nsv; a.sref_v = r.sref_v; a.sref_col = r.sref_col; a.sref_flags = r.sref_flags;
-  a.sref_nv = r.sref_nv; a.sref_opa = r.sref_opa; a.sbg = r.sbg; a.rgb_override = r.rgb_override; a.rows_seen = r.rows_seen;
-  if (a.ncopy > 1) a.n_static = 0;   // (torus frames are drawn whole: no cached picture under copies)
+  a.draw = r.em.out; a.lay = r.em.lay; a.image = r.image;
+  a.n_envs = r.n_envs; a.S = r.ms.S; a.big = r.ms.big; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h;
+  a.flip = r.flip; a.iwords = r.ms.iwords; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
+  a.n_static = r.em.ncopy > 1 ? 0 : r.em.n_static;   // (torus frames are drawn whole: no cached picture under copies)
+  a.sbg = r.sbg; a.rows_seen = r.rows_seen;
   a.plan = r.ms.plan;
   return a;
 }
@@ -35,6 +33,11 @@ static RmArgs mask_args(const RArgs& r) {
 // prefix, frames on top of a per-env prefix and every other program's frames by the push / sort / span kernel.
 void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   if (a.ms.ok && !a.build && a.sbg_env_stride == 0 && !a.env_build) {
+    if (!a.draw_ready) {   // records the engine did not step itself: the emitter on the records in HBM
+      RmDeriveArgs d;
+      d.em = a.em; d.P = a.P; d.L = a.L; d.f64 = a.f64; d.i32 = a.i32; d.n_envs = a.n_envs; d.env0 = a.env0;
+      moog_draw_derive_launch(d, stream);
+    }
     moog_raster_mask_launch(mask_args(a), a.ms.lds, stream);
     return;
   }

@@ -11,38 +11,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 
 // BIG: the program has slots for polygons of more than RM_MAX_NV vertices (rm_p4_big); a kernel of its own so that everybody
 // else's keeps its registers
-template <int WORDS, bool BIG, bool TORUS>
+template <int WORDS, bool BIG>
 __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mask_kernel(RmArgs a) {
   const int env = (int)blockIdx.x;
   if (env >= a.n_envs) return;
   const RmCtx c = rm_ctx(a.plan, moog_lds);
   const int tid = (int)threadIdx.x, lane = tid & 63;
-  RmThread th;
-  rm_p0<WORDS>(a, c, env, tid, RM_THREADS, th);
-  if (TORUS) {   // torus frames (a.ncopy = 9): nine copies per sprite, the visible ones become items
-    if (tid < 64) rm_t0_slots(a, c, env, lane);
-    __syncthreads();
-    if (a.debug_stop == 1) return;
-    rm_t1_bounds(a, c, env, tid, RM_THREADS);
-    __syncthreads();
-    if (tid < 64) rm_t2_items(a, c, lane);
-    __syncthreads();
-    rm_t3_points(a, c, env, tid, RM_THREADS);
-    __syncthreads();
-  } else {
-    if (tid < 64) rm_p0_slots(a, c, env, lane, th);
-    __syncthreads();
-    if (a.debug_stop == 1) return;
-    rm_p1<WORDS>(a, c, env, tid, RM_THREADS, th);
-    __syncthreads();
-  }
-  if (a.debug_stop == 2) return;
-  // (every wave scans the items for itself: both write the same words, and a wave's LDS operations execute in order,
-  //  so each reads back what it wrote -- no barrier between the scan and the edges)
+  rm_load(a, c, env, tid, RM_THREADS);
+  __syncthreads();
+  if (a.debug_stop == 1 || a.debug_stop == 2) return;
   const int s_lo = __builtin_amdgcn_readfirstlane(rm_s_lo(a, c));
-  rm_p2_scan(a, c, s_lo, lane);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   if (a.rows_seen && tid == 0 && c.rowoff[a.S] > a.cap_rows) {   // several passes: the engine may grow the records (mask_rows_grow)
     atomicMax(a.rows_seen, c.rowoff[a.S]);
     atomicAdd(a.rows_seen + 1, 1);
@@ -50,6 +28,8 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   for (int base = 0;;) {
     const int end = __builtin_amdgcn_readfirstlane(rm_pass_end(a, c, base));
     const int total_rows = __builtin_amdgcn_readfirstlane(c.rowoff[end] - c.rowoff[base]);
+    // (every wave assigns the pass's row records for itself: both write the same words, and a wave's LDS operations execute in
+    //  order, so each reads back what it wrote -- no barrier between the assignment and the edges)
     rm_p2_assign(a, c, base, end, s_lo, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -82,28 +62,43 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
   }
 }
 
+// The draw records of frames the engine did not step itself (moog_engine_render after load_state or an edit of the state
+// tensors, resets, programs whose step kernels do not emit): one wavefront per env runs the emitter on the record in HBM.
+struct RmDeriveArgs { RmEmit em; const moog_program_t* P; moog_layout_t L; const double* f64; const int32_t* i32; int32_t n_envs; int32_t env0; };
+__global__ __launch_bounds__(64) void moog_draw_derive_kernel(RmDeriveArgs d) {
+  const int env = (int)blockIdx.x;
+  if (env >= d.n_envs) return;
+  RmSrcRecord src;
+  src.P = d.P; src.L = &d.L; src.f = d.f64 + (size_t)env * d.L.f64_per_env; src.q = d.i32 + (size_t)env * d.L.i32_per_env;
+  RmEmit em = d.em;
+  if (em.rgb_override) em.rgb_override += (size_t)d.env0 * em.slots;   // (the override array is indexed by the engine's env; a chunk of envs starts at env0)
+  rm_emit(em, src, env, (int)threadIdx.x);
+}
+
 typedef void (*moog_raster_mask_fn)(RmArgs);
-// [WORDS - 1][BIG][TORUS]: a kernel per combination, so that frames that need neither keep their registers
-static inline moog_raster_mask_fn moog_raster_mask_pick(int words, bool big, bool torus) {
-  static const moog_raster_mask_fn table[2][2][2] = {
-      {{moog_raster_mask_kernel<1, false, false>, moog_raster_mask_kernel<1, false, true>},
-       {moog_raster_mask_kernel<1, true, false>, moog_raster_mask_kernel<1, true, true>}},
-      {{moog_raster_mask_kernel<2, false, false>, moog_raster_mask_kernel<2, false, true>},
-       {moog_raster_mask_kernel<2, true, false>, moog_raster_mask_kernel<2, true, true>}}};
-  return table[words - 1][big ? 1 : 0][torus ? 1 : 0];
+// [WORDS - 1][BIG]: a kernel per combination, so that frames that need neither keep their registers
+static inline moog_raster_mask_fn moog_raster_mask_pick(int words, bool big) {
+  static const moog_raster_mask_fn table[2][2] = {
+      {moog_raster_mask_kernel<1, false>, moog_raster_mask_kernel<1, true>},
+      {moog_raster_mask_kernel<2, false>, moog_raster_mask_kernel<2, true>}};
+  return table[words - 1][big ? 1 : 0];
 }
 
 static inline int moog_raster_mask_configure(size_t lds_bytes) {
   hipError_t err = hipSuccess;
-  for (int k = 0; k < 8 && err == hipSuccess; ++k)
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_pick(1 + (k & 1), (k & 2) != 0, (k & 4) != 0)),
+  for (int k = 0; k < 4 && err == hipSuccess; ++k)
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(moog_raster_mask_pick(1 + (k & 1), (k & 2) != 0)),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return (int)err;
 }
 
 static inline void moog_raster_mask_launch(const RmArgs& a, size_t lds_bytes, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_envs);
-  hipLaunchKernelGGL(moog_raster_mask_pick(a.W > 64 ? 2 : 1, a.big != 0, a.ncopy > 1), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+  hipLaunchKernelGGL(moog_raster_mask_pick(a.W > 64 ? 2 : 1, a.big != 0), grid, dim3(RM_THREADS), lds_bytes, stream, a);
+}
+
+static inline void moog_draw_derive_launch(const RmDeriveArgs& d, hipStream_t stream) {
+  hipLaunchKernelGGL(moog_draw_derive_kernel, dim3((unsigned)d.n_envs), dim3(64), 0, stream, d);
 }
 
 #endif  // MOOG_RASTER_MASK_H_

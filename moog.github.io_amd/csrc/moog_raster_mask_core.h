@@ -29,33 +29,7 @@
 // the same functions, thread by thread, against the oracle renderer (no GPU needed to find a logic error).
 #ifndef MOOG_RASTER_MASK_CORE_H_
 #define MOOG_RASTER_MASK_CORE_H_
-#include <math.h>
-#include <stdint.h>
-#include <string.h>
-
-#include "../../include/moog_engine.h"
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RM_DEV 1
-#else
-#define RM_DEV 0
-#endif
-#if defined(__HIPCC__)
-#define RM_FN __host__ __device__ __forceinline__
-#define RM_MEMBER __host__ __device__ __forceinline__
-#define RM_SLOW __host__ __device__ __noinline__
-#else
-#define RM_FN static inline
-#define RM_MEMBER inline
-#define RM_SLOW static
-#endif
-#if RM_DEV
-#define RM_ANY(x) __any((x))
-#define RM_CONSTP(T) const __attribute__((address_space(4))) T*
-#else
-#define RM_ANY(x) (x)
-#define RM_CONSTP(T) const T*
-#endif
+#include "moog_draw_record.h"   // the frame's input: integer points, colours, row ranges (written by the step / reset / derive kernels)
 
 #ifndef RM_THREADS
 #define RM_THREADS 128        // threads per frame (256 and 64 were measured: slower, profiles/r05_raster.txt)
@@ -63,8 +37,6 @@
 #ifndef RM_WAVES_PER_SIMD
 #define RM_WAVES_PER_SIMD 5   // register budget: 96 VGPRs
 #endif
-#define RM_MAX_NV 32          // vertices per polygon whose rows go by census words (edge index = bit of a word)
-#define RM_BIG_NV 128         // vertices per polygon at most: longer ones (the 102-vertex annuli) take the cooperative row routine
 #define RM_SORT_ROUNDS_T (3 * RM_THREADS)   // = RM_SORT_ROUNDS * RM_THREADS (defined with the sort, below)
 #define RM_XX (2 * RM_BIG_NV)  // crossing-list capacity of the generic row routine (2 per edge)
 
@@ -74,45 +46,32 @@ struct alignas(16) RmItem { int32_t rowbase; int32_t pb_nv; int32_t pymax; uint3
 
 struct alignas(16) RmU4 { uint32_t x, y, z, w; };
 
-struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_item_x, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, o_skey, xx_stride, total; };   // xx_stride: floats of scratch per wavefront
+struct RmPlan { uint32_t o_edge, o_ivert, o_rows, o_rowitem, o_info, o_item_y, o_rowoff, o_seg, o_lut, o_xx, o_misc, o_spare, o_owner, o_skey, xx_stride, total; };   // xx_stride: floats of scratch per wavefront
 
 struct RmArgs {
-  const moog_program_t* P;
-  moog_layout_t L;
-  const double* f64;
-  const int32_t* i32;
+  const uint8_t* draw;        // the frames' draw records (moog_draw_record.h), [n_envs][lay.stride]
+  RmDrawLayout lay;
   uint8_t* image;
-  const uint32_t* vinfo;      // per vertex slot: sprite slot | index within the sprite << 8
   int32_t n_envs;
   int32_t S;                  // items (polygons a frame may hold): slots * ncopy
-  int32_t slots;              // sprite slots
   int32_t big;                // some slot may hold a polygon of more than RM_MAX_NV vertices (rm_p4_big)
-  int32_t ncopy;              // 1, or 9: polygon_modifiers.py TorusGeometry draws every sprite at the 3 x 3 offsets -1, 0, 1
   int32_t cap_rows;           // row records per pass (>= H)
   int32_t W, H;               // the canvas in memory (width a multiple of 16, <= 128)
-  int32_t scale_w;            // the width the vertices are scaled by (pil_renderer.py:65-66)
   int32_t flip;               // rows are written bottom-up (np.flipud, pil_renderer.py:118)
   int32_t iwords;             // 32-bit words of a segment's item bit mask
-  int32_t cmap, first_person, fp_slot0, fp_nslots;
   uint32_t bg;                // r | g << 8 | b << 16
   int32_t debug_stop;
   int32_t threads;            // threads per frame (64 * waves)
-  // static prefix (moog_raster.h): the first n_static slots are in the cached picture `sbg` when they equal the reference
-  int32_t n_static, nsv;
-  const double* sref_v;
-  const double* sref_col;
-  const int32_t* sref_flags;
-  const int32_t* sref_nv;
-  const int32_t* sref_opa;
+  // static prefix (moog_raster.h): a frame whose record says RM_DRAW_PREFIX_OK starts from the cached picture `sbg` (its prefix items are empty)
+  int32_t n_static;
   const uint8_t* sbg;
-  const uint32_t* rgb_override;
   int32_t* rows_seen;         // two host-mapped words (or null): the most rows a frame wanted when that was more than cap_rows, and how many frames did (the engine may grow the records)
   RmPlan plan;
 };
 
 static inline uint32_t rm_align(uint32_t x) { return (x + 15u) & ~15u; }
 
-// S: items; TOTV: vertex slots of all items (the program's vertex slots x copies)
+// S: items; TOTV: points a frame may hold (the program's vertex slots x copies)
 static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, int big, RmPlan* p) {
   uint32_t o = 0;
   p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
@@ -121,7 +80,6 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
   p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows * 2u);
   p->o_info = o; o = rm_align(o + (uint32_t)S * sizeof(RmItem));
   p->o_item_y = o; o = rm_align(o + (uint32_t)S * 8u);
-  p->o_item_x = o; o = rm_align(o + (uint32_t)S * 8u);   // (torus frames: the sprites' coordinate bounds, 36 of its 72 bytes per sprite)
   p->o_rowoff = o; o = rm_align(o + (uint32_t)(S + 1) * 4u);
   p->o_seg = o; o = rm_align(o + (uint32_t)H * (uint32_t)(W / 16) * (uint32_t)iwords * 4u);
   p->o_lut = o; o = rm_align(o + 16u * 16u);
@@ -139,7 +97,7 @@ static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwor
 
 struct RmCtx {
   RmEdge* edges; uint32_t* ivert; RmRow* rows; uint16_t* rowitem;   // rowitem: the row's item | 256 when a shallow edge has a corner on the row
-  RmItem* info; int32_t* item_y; int32_t* item_x; int32_t* rowoff;
+  RmItem* info; int32_t* item_y; int32_t* rowoff;
   uint32_t* seg; uint32_t* lut; float* xx; uint32_t* spare; uint16_t* sorted; uint16_t* skey; uint8_t* owner; int32_t* misc;   // sorted (p4: the rows in order of their kind) shares the spare words' memory (p3)   // misc: [5] static prefix differs
 };
 
@@ -151,7 +109,6 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
   c.rowitem = reinterpret_cast<uint16_t*>(lds + pl.o_rowitem);
   c.info = reinterpret_cast<RmItem*>(lds + pl.o_info);
   c.item_y = reinterpret_cast<int32_t*>(lds + pl.o_item_y);
-  c.item_x = reinterpret_cast<int32_t*>(lds + pl.o_item_x);
   c.rowoff = reinterpret_cast<int32_t*>(lds + pl.o_rowoff);
   c.seg = reinterpret_cast<uint32_t*>(lds + pl.o_seg);
   c.lut = reinterpret_cast<uint32_t*>(lds + pl.o_lut);
@@ -165,8 +122,6 @@ RM_FN RmCtx rm_ctx(const RmPlan& pl, unsigned char* lds) {
 }
 
 // ---- small helpers ---------------------------------------------------------------------------------------------------
-RM_FN uint32_t rm_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-RM_FN float rm_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 RM_FN int rm_ffs(uint32_t m) { return __builtin_ctz(m); }
 RM_FN void rm_or(uint32_t* p, uint32_t v) {
 #if RM_DEV
@@ -198,31 +153,6 @@ RM_FN int rm_f2i(float f) {
 // Draw.c ROUND_UP / ROUND_DOWN
 RM_FN int rm_round_up(float f) { return rm_f2i(copysignf(floorf(fabsf(f) + 0.5f), f)); }
 RM_FN int rm_round_down(float f) { return rm_f2i(copysignf(ceilf(fabsf(f) - 0.5f), f)); }
-// Pillow's (int) cast of a coordinate as x86-64 performs it (cvttsd2si): NaN and out-of-range give INT_MIN
-RM_FN int rm_pil_int(double d) { return (d >= -2147483648.0 && d < 2147483648.0) ? (int)d : (int)0x80000000; }
-RM_FN int rm_clamp16(int v) { return v < -32000 ? -32000 : (v > 32000 ? 32000 : v); }
-
-// color_maps.py:21-23 (colorsys.hsv_to_rgb, then uint8 truncation)
-RM_FN uint32_t rm_hsv_rgb(double h, double s, double v) {
-  double r, g, b;
-  if (s == 0.0) { r = g = b = v; }
-  else {
-    int i = (int)(h * 6.0);
-    double f = (h * 6.0) - i;
-    double p = v * (1.0 - s), q = v * (1.0 - s * f), t = v * (1.0 - s * (1.0 - f));
-    i = ((i % 6) + 6) % 6;
-    switch (i) {
-      case 0: r = v; g = t; b = p; break;
-      case 1: r = q; g = v; b = p; break;
-      case 2: r = p; g = v; b = t; break;
-      case 3: r = p; g = q; b = v; break;
-      case 4: r = t; g = p; b = v; break;
-      default: r = v; g = p; b = q; break;
-    }
-  }
-  return ((uint32_t)(int)(255 * r) & 255u) | (((uint32_t)(int)(255 * g) & 255u) << 8) | (((uint32_t)(int)(255 * b) & 255u) << 16);
-}
-
 // ---- coverage masks -----------------------------------------------------------------------------------------------
 template <int WORDS> struct RmMask { uint64_t w[WORDS]; };
 RM_FN uint64_t rm_low(int t) { return t <= 0 ? 0ull : (t >= 64 ? ~0ull : ((1ull << t) - 1ull)); }   // pixels 0 .. t-1
@@ -564,324 +494,54 @@ RM_FN bool rm_row_fast(const PE pe, const RmRow rec, int y, int pymax, int W, bo
   return !(odd || fix.generic);
 }
 
-// Inclusive scan over the wavefront in six DPP adds: within rows of 16 lanes, then across the rows
-#if RM_DEV
-RM_FN int rm_wave_scan(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-  return v;
-}
-#endif
-
 // ---- the frame, phase by phase ------------------------------------------------------------------------------------------
 // One workgroup of `T` threads (T / 64 wavefronts) renders one frame.  Barriers stand between the phases:
-//   p0  clear the tables; per-slot colour / liveness                     | p1  vertices -> integer canvas points, item row ranges
+//   load  clear the tables; the frame's draw record (moog_draw_record.h) -> items, integer points, row offsets
 //   p2  (every wave for itself) item rows -> row records                 | p3  edges + census
 //   p4  rows -> coverage masks, which 16-pixel segments an item touches  | p5  compose + store
 // A frame with more rows than row records takes several passes over p2 .. p5, whole items at a time.
-struct RmThread {   // what a thread carries from one phase to the next
-  uint32_t vi; double vx, vy;   // the first vertex slot's table entry and coordinates, loaded before the tables are cleared
-  bool st_bad;
-  double fpx, fpy;
-};
-
-template <int WORDS>
-RM_FN void rm_p0(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThread& th) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
-  th.vi = 0u; th.vx = 0.0; th.vy = 0.0; th.st_bad = false; th.fpx = 0.0; th.fpy = 0.0;
-  if (tid < L.TOTV) {   // phase 1's first loads go out before anything else (HBM latency under the clearing)
-    th.vi = a.vinfo[tid];
-    th.vx = gf[L.o_verts + 2 * tid]; th.vy = gf[L.o_verts + 2 * tid + 1];
-  }
+// (Rounds 1-5 read the state record here -- liveness, colour map, float64 vertices -> canvas points, per-item row ranges, the nine
+//  copies of a torus: a fifth of the kernel and four fifths of its reads.  That work is the emitter's now, done where the
+//  record is already on chip.)
+RM_FN void rm_load(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
+  const uint8_t* rec = a.draw + (size_t)env * a.lay.stride;
+  const RmDrawHdr hdr = *reinterpret_cast<const RmDrawHdr*>(rec);
+  const RmDrawItem* items = reinterpret_cast<const RmDrawItem*>(rec + a.lay.o_items);
+  const uint32_t* pts = reinterpret_cast<const uint32_t*>(rec + a.lay.o_pts);
+  const uint32_t* own = reinterpret_cast<const uint32_t*>(rec + a.lay.o_owner);
+  // the loads go out first (HBM latency under the clearing)
+  const int n_pts = hdr.n_pts;
+  RmDrawItem it = {0, 0u, RM_Y01_EMPTY, 0u};
+  if (tid < a.S) it = items[tid];
+  uint32_t p0 = 0u, o0 = 0u;
+  if (tid < n_pts) p0 = pts[tid];
+  if (4 * tid < n_pts) o0 = own[tid];
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
   for (int i = tid; i < (a.cap_rows + 1) / 2; i += T) reinterpret_cast<uint32_t*>(c.rowitem)[i] = 0u;   // (the rows' flag bytes)
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
   if (tid < 16) {   // four coverage bits -> byte masks of the 12 bytes of four RGB pixels
-    const uint32_t p0 = tid & 1, p1 = (tid >> 1) & 1, p2 = (tid >> 2) & 1, p3 = (tid >> 3) & 1;
-    c.lut[4 * tid + 0] = (p0 ? 0x00ffffffu : 0u) | (p1 ? 0xff000000u : 0u);
-    c.lut[4 * tid + 1] = (p1 ? 0x0000ffffu : 0u) | (p2 ? 0xffff0000u : 0u);
-    c.lut[4 * tid + 2] = (p2 ? 0x000000ffu : 0u) | (p3 ? 0xffffff00u : 0u);
+    const uint32_t b0 = tid & 1, b1 = (tid >> 1) & 1, b2 = (tid >> 2) & 1, b3 = (tid >> 3) & 1;
+    c.lut[4 * tid + 0] = (b0 ? 0x00ffffffu : 0u) | (b1 ? 0xff000000u : 0u);
+    c.lut[4 * tid + 1] = (b1 ? 0x0000ffffu : 0u) | (b2 ? 0xffff0000u : 0u);
+    c.lut[4 * tid + 2] = (b2 ? 0x000000ffu : 0u) | (b3 ? 0xffffff00u : 0u);
     c.lut[4 * tid + 3] = 0u;
   }
-  if (tid < 13) c.misc[tid] = 0;   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort, [12] rows of long polygons)
-  if (a.first_person) {   // polygon_modifiers.py:41-64: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
-    for (int s = a.fp_slot0; s < a.fp_slot0 + a.fp_nslots; ++s)
-      if (gq[L.o_flags + s] & MOOG_F_ALIVE) { th.fpx = 0.5 - gf[L.o_pos + 2 * s]; th.fpy = 0.5 - gf[L.o_pos + 2 * s + 1]; break; }
+  if (tid < 13) c.misc[tid] = tid == 0 ? n_pts : ((tid == 5 && !(hdr.flags & RM_DRAW_PREFIX_OK)) ? 1 : 0);   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort, [12] rows of long polygons)
+  if (tid == 0) c.rowoff[a.S] = hdr.total_rows;
+  for (int g = tid; g < a.S; g += T) {
+    if (g != tid) it = items[g];
+    RmItem o;
+    o.rowbase = 0; o.pb_nv = (int32_t)it.pb_nv; o.pymax = 0; o.rgba = it.rgba;
+    c.info[g] = o;
+    c.item_y[2 * g] = (int)(int16_t)((uint32_t)it.y01 & 0xffffu); c.item_y[2 * g + 1] = (int)it.y01 >> 16;
+    c.rowoff[g] = it.rowoff;
   }
+  for (int i = tid; i < n_pts; i += T) c.ivert[i] = (i == tid) ? p0 : pts[i];
+  for (int i = tid; 4 * i < n_pts; i += T) reinterpret_cast<uint32_t*>(c.owner)[i] = (i == tid) ? o0 : own[i];
 }
 
-// p0, the first wave only (lane = the thread's index in it; host model: lane = -1 does every lane's work): per-slot
-// colour and liveness, and where the slot's live vertices start in the COMPACT vertex numbering the later phases use
-// (live vertices only, slot after slot: 260 of the headline workload's 451 vertex slots are in use).
-RM_FN void rm_p0_slots(const RmArgs& a, const RmCtx& c, int env, int lane, RmThread& th) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
-  const int NS = a.n_static;
-  int run = 0;
-#if RM_DEV
-  for (int i0 = 0; i0 < a.S; i0 += 64) {
-    const int s = i0 + lane;
-    const bool in = s < a.S;
-#else
-  (void)lane;
-  for (int s = 0; s < a.S; ++s) {
-    const bool in = true;
-#endif
-    int nvl = 0;
-    uint32_t rgba = 0u;
-    if (in) {
-      const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
-      const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
-      const bool alive = (flags & MOOG_F_ALIVE) != 0;
-      if (s < NS) {
-        const double* rc = a.sref_col + 3 * s;
-        uint64_t b0, b1, b2, r0, r1, r2;
-        memcpy(&b0, &c0, 8); memcpy(&b1, &c1, 8); memcpy(&b2, &c2, 8); memcpy(&r0, rc, 8); memcpy(&r1, rc + 1, 8); memcpy(&r2, rc + 2, 8);
-        th.st_bad = th.st_bad || ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s] ||
-                    b0 != r0 || b1 != r1 || b2 != r2;
-      }
-      if (alive) {
-        uint32_t rgb;
-        if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.slots + s] & 0xffffffu;
-        else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
-        else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
-        rgba = rgb | (((uint32_t)opa & 255u) << 24);
-        nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
-      }
-    }
-#if RM_DEV
-    const int inc = rm_wave_scan(nvl);
-    const int first = run + inc - nvl;
-    run += __builtin_amdgcn_readlane(inc, 63);
-#else
-    const int first = run;
-    run += nvl;
-#endif
-    if (in) {
-      RmItem it;
-      it.rowbase = 0; it.pb_nv = first | (nvl << 20); it.pymax = 0; it.rgba = rgba;
-      c.info[s] = it;
-      c.item_y[2 * s] = 0x7fffffff; c.item_y[2 * s + 1] = -0x7fffffff;
-    }
-  }
-#if RM_DEV
-  if (lane == 0) c.misc[0] = run;
-#else
-  c.misc[0] = run;
-#endif
-}
-
-template <int WORDS>
-RM_FN void rm_p1(const RmArgs& a, const RmCtx& c, int env, int tid, int T, RmThread& th) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  const int NS = a.n_static;
-  uint32_t vi = th.vi; double vx = th.vx, vy = th.vy;
-  for (int idx = tid; idx < L.TOTV; idx += T) {
-    const uint32_t vi_c = vi; const double x_c = vx, y_c = vy;
-    if (idx + T < L.TOTV) {   // the next round's loads
-      vi = a.vinfo[idx + T];
-      vx = gf[L.o_verts + 2 * (idx + T)]; vy = gf[L.o_verts + 2 * (idx + T) + 1];
-    }
-    const int s = vi_c & 0xffu, k = (vi_c >> 8) & 0xffu;
-    const int pbnv = c.info[s].pb_nv;
-    if (k >= (pbnv >> 20)) continue;
-    const int ci = (pbnv & 0xfffff) + k;   // the vertex's compact number
-    if (idx < a.nsv && NS > 0) {
-      uint64_t b0, b1, r0, r1;
-      memcpy(&b0, &x_c, 8); memcpy(&b1, &y_c, 8); memcpy(&r0, a.sref_v + 2 * idx, 8); memcpy(&r1, a.sref_v + 2 * idx + 1, 8);
-      th.st_bad = th.st_bad || b0 != r0 || b1 != r1;
-    }
-    double px = x_c, py = y_c;
-    if (a.first_person) { px = px + th.fpx; py = py + th.fpy; }
-    const int ix = rm_clamp16(rm_pil_int((double)a.scale_w * px)), iy = rm_clamp16(rm_pil_int((double)a.H * py));
-    c.ivert[ci] = (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
-    c.owner[ci] = (uint8_t)s;
-    rm_min(&c.item_y[2 * s], iy);
-    rm_max(&c.item_y[2 * s + 1], iy);
-  }
-  if (th.st_bad) c.misc[5] = 1;   // (cleared before the previous barrier)
-}
-
-// ---- torus frames: item = (slot, copy), copy c drawn at the offset (c / 3 - 1, c % 3 - 1) (polygon_modifiers.py:88-97) ----
-// Of a sprite's nine copies one is on the canvas, two or four when it straddles an edge or a corner; the others must cost
-// next to nothing.  Pillow truncates the scaled coordinates towards zero, so a copy's integer points are not the
-// sprite's shifted by a canvas: they come from the doubles, copy by copy.  But x -> (int)(W * (x + o)) is monotone, so a
-// copy's integer bounds are those of the sprite's smallest and largest coordinates: the vertices leave four 64-bit
-// atomics per sprite behind (t1), the items work out which copies can touch the canvas and number their vertices (t2),
-// and only those copies' points are computed and stored (t3).  A sprite with a coordinate that is not an ordinary number
-// (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN, which is not monotone) takes per-copy atomics instead.
-//   t0 (first wave): per-slot colour and liveness into the nine items      | t1: vertices -> the sprites' bounds
-//   t2 (first wave): visible items get their compact vertex ranges        | t3: the visible copies' integer points
-struct alignas(16) RmBounds { long long kx0, kx1, ky0, ky1; };   // order-preserving keys of the smallest / largest x and y
-RM_FN long long rm_key(double d) { long long b; memcpy(&b, &d, 8); return b ^ ((b >> 63) & 0x7fffffffffffffffll); }
-RM_FN double rm_unkey(long long k) { const long long b = k ^ ((k >> 63) & 0x7fffffffffffffffll); double d; memcpy(&d, &b, 8); return d; }
-RM_FN void rm_min64(long long* p, long long v) {
-#if RM_DEV
-  atomicMin(p, v);
-#else
-  if (v < *p) *p = v;
-#endif
-}
-RM_FN void rm_max64(long long* p, long long v) {
-#if RM_DEV
-  atomicMax(p, v);
-#else
-  if (v > *p) *p = v;
-#endif
-}
-// slots * 32 bytes of bounds live where the items' x ranges would (S * 8 = slots * 72 bytes); [slots * 4 ...): irregular flags
-RM_FN RmBounds* rm_bounds(const RmCtx& c) { return reinterpret_cast<RmBounds*>(c.item_x); }
-RM_FN int32_t* rm_irregular(const RmArgs& a, const RmCtx& c) { return c.item_x + 8 * a.slots; }
-
-RM_FN void rm_t0_slots(const RmArgs& a, const RmCtx& c, int env, int lane) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  const int32_t* gq = a.i32 + (size_t)env * L.i32_per_env;
-#if RM_DEV
-  for (int s = lane; s < a.slots; s += 64) {
-#else
-  (void)lane;
-  for (int s = 0; s < a.slots; ++s) {
-#endif
-    const int flags = gq[L.o_flags + s], nvs = gq[L.o_nverts + s], opa = gq[L.o_opacity + s];
-    const double c0 = gf[L.o_color + 3 * s], c1 = gf[L.o_color + 3 * s + 1], c2 = gf[L.o_color + 3 * s + 2];
-    int nvl = 0;
-    uint32_t rgba = 0u;
-    if (flags & MOOG_F_ALIVE) {
-      uint32_t rgb;
-      if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.slots + s] & 0xffffffu;
-      else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
-      else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
-      rgba = rgb | (((uint32_t)opa & 255u) << 24);
-      nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
-    }
-    for (int cp = 0; cp < a.ncopy; ++cp) {
-      const int g = s * a.ncopy + cp;
-      RmItem it;
-      it.rowbase = 0; it.pb_nv = nvl << 20; it.pymax = 0; it.rgba = rgba;
-      c.info[g] = it;
-      c.item_y[2 * g] = 0x7fffffff; c.item_y[2 * g + 1] = -0x7fffffff;
-    }
-    RmBounds bz;
-    bz.kx0 = 0x7fffffffffffffffll; bz.kx1 = -0x7fffffffffffffffll - 1; bz.ky0 = bz.kx0; bz.ky1 = bz.kx1;
-    rm_bounds(c)[s] = bz;
-    rm_irregular(a, c)[s] = 0;
-  }
-}
-
-// The integer canvas point of copy cp of a vertex (pil_renderer.py:104-108: the scaled doubles through Pillow's (int))
-RM_FN uint32_t rm_copy_point(const RmArgs& a, double x, double y, int cp, int* ix_out, int* iy_out) {
-  const double px = x + (double)(cp / 3 - 1), py = y + (double)(cp % 3 - 1);
-  const int ix = rm_clamp16(rm_pil_int((double)a.scale_w * px)), iy = rm_clamp16(rm_pil_int((double)a.H * py));
-  *ix_out = ix; *iy_out = iy;
-  return (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
-}
-
-RM_FN void rm_t1_bounds(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  for (int idx = tid; idx < L.TOTV; idx += T) {
-    const uint32_t vi = a.vinfo[idx];
-    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
-    if (k >= (c.info[s * a.ncopy].pb_nv >> 20)) continue;
-    const double x = gf[L.o_verts + 2 * idx], y = gf[L.o_verts + 2 * idx + 1];
-    // ordinary: every copy's scaled coordinate is far inside what (int) holds (NaN fails the comparisons)
-    const bool ordinary = fabs(x) < 1.0e6 && fabs(y) < 1.0e6;
-    if (ordinary) {
-      RmBounds* bd = rm_bounds(c) + s;
-      rm_min64(&bd->kx0, rm_key(x)); rm_max64(&bd->kx1, rm_key(x));
-      rm_min64(&bd->ky0, rm_key(y)); rm_max64(&bd->ky1, rm_key(y));
-    } else {
-      rm_irregular(a, c)[s] = 1;
-      for (int cp = 0; cp < a.ncopy; ++cp) {   // (the bounds of such a sprite's copies are OR-ed in below, point by point)
-        int ix, iy;
-        rm_copy_point(a, x, y, cp, &ix, &iy);
-        const int g = s * a.ncopy + cp;
-        rm_min(&c.item_y[2 * g], iy); rm_max(&c.item_y[2 * g + 1], iy);
-      }
-    }
-  }
-}
-
-// A polygon whose points all lie two or more pixels beside the canvas paints nothing: its crossings are float32
-// interpolations between such points (off by far less than a pixel at these magnitudes), its heads lie between them.
-RM_FN void rm_t2_items(const RmArgs& a, const RmCtx& c, int lane) {
-  int run = 0;
-#if RM_DEV
-  for (int i0 = 0; i0 < a.S; i0 += 64) {
-    const int g = i0 + lane;
-    const bool in = g < a.S;
-#else
-  (void)lane;
-  for (int g = 0; g < a.S; ++g) {
-    const bool in = true;
-#endif
-    int nvl = 0;
-    if (in) {
-      nvl = c.info[g].pb_nv >> 20;
-      const int s = g / a.ncopy, cp = g - s * a.ncopy;
-      const RmBounds bd = rm_bounds(c)[s];
-      const bool irregular = rm_irregular(a, c)[s] != 0;
-      int y0 = c.item_y[2 * g], y1 = c.item_y[2 * g + 1];   // (what the sprite's irregular vertices left, or nothing)
-      int x0 = 0x7fffffff, x1 = -0x7fffffff;
-      if (bd.kx0 <= bd.kx1) {   // the ordinary vertices: the copy's bounds from the sprite's extreme coordinates
-        int ixa, iya, ixb, iyb;
-        rm_copy_point(a, rm_unkey(bd.kx0), rm_unkey(bd.ky0), cp, &ixa, &iya);
-        rm_copy_point(a, rm_unkey(bd.kx1), rm_unkey(bd.ky1), cp, &ixb, &iyb);
-        x0 = ixa; x1 = ixb;
-        y0 = iya < y0 ? iya : y0; y1 = iyb > y1 ? iyb : y1;
-      }
-      // (an irregular sprite keeps every copy its rows put on the canvas: its x range is not tracked)
-      const bool vis = nvl > 0 && y1 >= 0 && y0 <= a.H - 1 && (irregular || (x1 >= -1 && x0 <= a.W));
-      if (vis) { c.item_y[2 * g] = y0; c.item_y[2 * g + 1] = y1; }
-      else { nvl = 0; c.item_y[2 * g] = 0x7fffffff; c.item_y[2 * g + 1] = -0x7fffffff; }
-    }
-#if RM_DEV
-    const int inc = rm_wave_scan(nvl);
-    const int first = run + inc - nvl;
-    run += __builtin_amdgcn_readlane(inc, 63);
-#else
-    const int first = run;
-    run += nvl;
-#endif
-    if (in) c.info[g].pb_nv = first | (nvl << 20);
-  }
-#if RM_DEV
-  if (lane == 0) c.misc[0] = run;
-#else
-  c.misc[0] = run;
-#endif
-}
-
-RM_FN void rm_t3_points(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
-  const moog_layout_t& L = a.L;
-  const double* gf = a.f64 + (size_t)env * L.f64_per_env;
-  for (int idx = tid; idx < L.TOTV; idx += T) {
-    const uint32_t vi = a.vinfo[idx];
-    const int s = vi & 0xffu, k = (vi >> 8) & 0xffu;
-    const double x = gf[L.o_verts + 2 * idx], y = gf[L.o_verts + 2 * idx + 1];
-    for (int cp = 0; cp < a.ncopy; ++cp) {
-      const int g = s * a.ncopy + cp;
-      const int pbnv = c.info[g].pb_nv;
-      if (k >= (pbnv >> 20)) continue;
-      int ix, iy;
-      const int ci = (pbnv & 0xfffff) + k;
-      c.ivert[ci] = rm_copy_point(a, x, y, cp, &ix, &iy);
-      c.owner[ci] = (uint8_t)g;
-    }
-  }
-}
-
-// Items below s_lo are in the cached picture of the static prefix (valid after p1's barrier)
+// Items below s_lo are in the cached picture of the static prefix (valid after the load's barrier; the emitter left them empty)
 RM_FN int rm_s_lo(const RmArgs& a, const RmCtx& c) { return (a.n_static > 0 && c.misc[5] == 0) ? a.n_static : 0; }
 
 // Rows an item occupies on the canvas: [ystart, ystart + cnt)
@@ -891,35 +551,6 @@ RM_FN int rm_item_rows(const RmArgs& a, const RmCtx& c, int g, int s_lo, int* ys
   if (y1 > a.H - 1) y1 = a.H - 1;   // rows >= H draw nothing (hline clips)
   *ystart = y0;
   return (y1 >= y0 && g >= s_lo) ? (y1 - y0 + 1) : 0;
-}
-
-// p2, by every wave for itself (lane = this thread's index in its wave): exclusive scan of the items' row counts.
-// Host model: called once per wave with lane = -1 and does all lanes' work in a loop.
-RM_FN void rm_p2_scan(const RmArgs& a, const RmCtx& c, int s_lo, int lane) {
-#if RM_DEV
-  int run = 0;
-  for (int i0 = 0; i0 < a.S; i0 += 64) {
-    const int g = i0 + lane;
-    int ys = 0;
-    const int cnt = g < a.S ? rm_item_rows(a, c, g, s_lo, &ys) : 0;
-    // inclusive scan over the wave in six DPP adds: within rows of 16 lanes, then across the rows
-    int inc = cnt;
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    if (g < a.S) c.rowoff[g] = run + inc - cnt;
-    run += __builtin_amdgcn_readlane(inc, 63);
-  }
-  if (lane == 0) c.rowoff[a.S] = run;
-#else
-  (void)lane;
-  int run = 0;
-  for (int g = 0; g < a.S; ++g) { int ys; c.rowoff[g] = run; run += rm_item_rows(a, c, g, s_lo, &ys); }
-  c.rowoff[a.S] = run;
-#endif
 }
 
 // The pass that starts with item `base`: as many whole items as fit in the row records.  Returns the item behind it.
@@ -934,7 +565,8 @@ RM_FN int rm_pass_end(const RmArgs& a, const RmCtx& c, int base) {
   return lo;
 }
 
-// p2, second half (every wave for itself; `lane` as above): the pass's items get their row records.
+// p2 (every wave for itself; device: `lane` = the thread's index in its wave; host model: lane = -1 does every lane's work): the
+// pass's items get their row records (the row offsets come with the draw record).
 RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, int lane) {
   const int r0 = c.rowoff[base];
 #if RM_DEV

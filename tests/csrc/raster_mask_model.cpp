@@ -56,61 +56,61 @@ int rm_model_polygon(const int* xy, int n, int W, int H, uint8_t* cov, int mode,
 }
 
 // Whole frames of n_envs state records; image: [n_envs][H][Wpad][3].  sref_*: the reference record of the static prefix
-// (or n_static = 0).  stats: [0] rows, [1] generic rows, [2] passes.
+// (or n_static = 0).  stats: [0] rows, [1] generic rows, [2] passes.  The records go through the emitter (rm_emit on the
+// records as the ABI lays them out: what the derive kernel runs, and -- on the record in LDS -- the step kernel) into draw
+// records, and the frame's phases read those.  draw_out (or null): the draw records, [n_envs][*draw_stride] bytes.
 int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i32, int n_envs, uint8_t* image,
                     int threads, int cap_rows, int n_static, int nsv, const double* sref_f64, const int32_t* sref_i32,
                     const uint8_t* sbg, const uint32_t* rgb_override, long long* stats) {
+  (void)nsv;
   moog_layout_t L;
   moog_layout(P, &L);
   RmArgs a;
   memset(&a, 0, sizeof a);
-  a.P = P; a.L = L; a.f64 = f64; a.i32 = i32; a.image = image;
-  std::vector<uint32_t> vi((size_t)(L.TOTV > 0 ? L.TOTV : 1), 0u);
+  RmEmit em;
+  memset(&em, 0, sizeof em);
+  a.image = image;
   for (int sl = 0; sl < P->n_slots; ++sl) {
     if (P->slot_vcap[sl] > RM_BIG_NV) return -2;
     if (P->slot_vcap[sl] > RM_MAX_NV) a.big = 1;
-    for (int k = 0; k < P->slot_vcap[sl]; ++k) vi[P->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
   }
-  a.vinfo = vi.data();
-  a.ncopy = P->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
-  a.n_envs = n_envs; a.slots = P->n_slots; a.S = P->n_slots * a.ncopy;
+  em.ncopy = P->render.polymod == MOOG_POLYMOD_TORUS ? 9 : 1;
+  a.n_envs = n_envs; em.slots = P->n_slots; em.S = a.S = P->n_slots * em.ncopy;
   if (a.S > 256) return -4;
   const int cw = P->render.width, ch = P->render.height;
-  a.W = (cw + 15) & ~15; a.H = ch; a.scale_w = cw; a.flip = 1;
+  a.W = (cw + 15) & ~15; a.H = ch; a.flip = 1;
+  em.W = a.W; em.H = a.H; em.scale_w = cw;
   if (a.W > 128 || a.H > 128 || P->render.aa > 1) return -3;
   a.cap_rows = cap_rows < a.H ? a.H : cap_rows;
   a.iwords = (a.S + 31) / 32; if (a.iwords < 1) a.iwords = 1;
-  a.cmap = P->render.cmap;
-  a.first_person = P->render.polymod == MOOG_POLYMOD_FIRST_PERSON;
-  if (a.first_person) { a.fp_slot0 = P->layer_slot0[P->render.polymod_layer]; a.fp_nslots = P->layer_nslots[P->render.polymod_layer]; }
+  em.cmap = P->render.cmap;
+  em.first_person = P->render.polymod == MOOG_POLYMOD_FIRST_PERSON;
+  if (em.first_person) { em.fp_slot0 = P->layer_slot0[P->render.polymod_layer]; em.fp_nslots = P->layer_nslots[P->render.polymod_layer]; }
   a.bg = ((uint32_t)P->render.bg[0] & 255u) | (((uint32_t)P->render.bg[1] & 255u) << 8) | (((uint32_t)P->render.bg[2] & 255u) << 16);
   a.threads = threads;
-  a.n_static = a.ncopy > 1 ? 0 : n_static; a.nsv = nsv;
-  if (a.n_static > 0) {
-    a.sref_v = sref_f64 + L.o_verts; a.sref_col = sref_f64 + L.o_color;
-    a.sref_flags = sref_i32 + L.o_flags; a.sref_nv = sref_i32 + L.o_nverts; a.sref_opa = sref_i32 + L.o_opacity;
+  em.n_static = em.ncopy > 1 ? 0 : n_static;
+  a.n_static = em.n_static;
+  if (em.n_static > 0) {
+    em.sref_v = sref_f64 + L.o_verts; em.sref_col = sref_f64 + L.o_color;
+    em.sref_flags = sref_i32 + L.o_flags; em.sref_nv = sref_i32 + L.o_nverts; em.sref_opa = sref_i32 + L.o_opacity;
     a.sbg = sbg;
   }
-  a.rgb_override = rgb_override;
+  em.rgb_override = rgb_override;
+  em.lay = rm_draw_layout(em.S, L.TOTV * em.ncopy);
+  std::vector<uint8_t> draw((size_t)n_envs * em.lay.stride, 0xCD);   // (whatever the buffer held before: the record says how much of it counts)
+  em.out = draw.data();
+  a.draw = draw.data(); a.lay = em.lay;
   const int T = threads, waves = T / 64;
-  rm_plan(a.S, L.TOTV * a.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan);
+  rm_plan(a.S, L.TOTV * em.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan);
   std::vector<unsigned char> lds(a.plan.total + 64);
   const RmCtx c = rm_ctx(a.plan, lds.data());
-  std::vector<RmThread> th(T);
   for (int env = 0; env < n_envs; ++env) {
+    RmSrcRecord src;
+    src.P = P; src.L = &L; src.f = f64 + (size_t)env * L.f64_per_env; src.q = i32 + (size_t)env * L.i32_per_env;
+    rm_emit(em, src, env, -1);
     memset(lds.data(), 0xA5, lds.size());   // LDS is not zero when a workgroup starts
-    for (int t = 0; t < T; ++t) rm_p0<2>(a, c, env, t, T, th[t]);
-    if (a.ncopy > 1) {
-      rm_t0_slots(a, c, env, -1);
-      for (int t = 0; t < T; ++t) rm_t1_bounds(a, c, env, t, T);
-      rm_t2_items(a, c, -1);
-      for (int t = 0; t < T; ++t) rm_t3_points(a, c, env, t, T);
-    } else {
-      rm_p0_slots(a, c, env, -1, th[0]);
-      for (int t = 0; t < T; ++t) rm_p1<2>(a, c, env, t, T, th[t]);
-    }
+    for (int t = 0; t < T; ++t) rm_load(a, c, env, t, T);
     const int s_lo = rm_s_lo(a, c);
-    for (int w = 0; w < waves; ++w) rm_p2_scan(a, c, s_lo, -1);
     for (int base = 0;;) {
       const int end = rm_pass_end(a, c, base);
       const int total_rows = c.rowoff[end] - c.rowoff[base];

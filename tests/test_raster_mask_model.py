@@ -24,7 +24,8 @@ _P = ctypes.POINTER
 def model():
     os.makedirs(BUILD, exist_ok=True)
     hdr = os.path.join(helpers.REPO, 'include', 'moog_engine.h')
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(p) for p in (SRC, CORE, hdr)):
+    draw = os.path.join(os.path.dirname(CORE), 'moog_draw_record.h')
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(p) for p in (SRC, CORE, draw, hdr)):
         tmp = SO + '.%d.tmp' % os.getpid()   # (xdist workers may build at the same time)
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-Wall',
                                '-Wno-unused-function', SRC, '-o', tmp])
@@ -135,7 +136,7 @@ def model_frames(m, c, f64, i32, cap_rows, static=None, threads=128):
 @pytest.mark.parametrize('name,cap_rows', [('colliding_predators_32', 192), ('colliding_predators_32', 64), ('functional_maze', 128),
                                            ('falling_balls_64', 100), ('pong', 192), ('cleanup', 128),
                                            ('chase_avoid_torus', 192), ('chase_avoid_torus', 64), ('match_to_sample_l3', 192),
-                                           ('parallelogram_catch', 96), ('multi_tracking_with_feature_l3', 192)])
+                                           ('parallelogram_catch', 96), ('multi_tracking_with_feature_l3', 192), ('first_person_predators_prey', 192)])
 def test_model_frames_vs_oracle(model, name, cap_rows):
     """Whole frames through the kernel's phases (the row records capped so that frames take several passes),
     against the oracle renderer: states of a few steps of the oracle's own simulation.  chase_avoid_torus: nine copies per
