@@ -129,9 +129,80 @@ RM_FN int rm_wave_scan(int v) {
 }
 #endif
 
+RM_FN void rm_min(int32_t* p, int32_t v) {
+#if RM_DEV
+  atomicMin(p, v);
+#else
+  if (v < *p) *p = v;
+#endif
+}
+RM_FN void rm_max(int32_t* p, int32_t v) {
+#if RM_DEV
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
+RM_FN void rm_or32(int32_t* p, int32_t v) {
+#if RM_DEV
+  atomicOr(p, v);
+#else
+  *p |= v;
+#endif
+}
+// what one wavefront's LDS writes need before its other lanes read them (device); nothing on the host, where a phase is a loop
+RM_FN void rm_wave_sync() {
+#if RM_DEV
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+// a loop over i = 0 .. n-1 shared out to the lanes of a wavefront (host model: lane < 0, one call does every lane's work)
+#if RM_DEV
+#define RM_LANES(i, n, lane) for (int i = (lane); i < (n); i += 64)
+#else
+#define RM_LANES(i, n, lane) for (int i = 0; i < (n); ++i)
+#endif
+
 // ---- the emitter ------------------------------------------------------------------------------------------------------------
-// SRC: where the env's record lies (HBM, or the step kernel's LDS copy with the colours left in HBM):
-//   int flags(s), nv(s), opa(s), voff(s), vcap(s);  double col(s, c);  const double* vert(s)  (x, y pairs of the slot's vertices)
+// One wavefront per env.  SRC says where the env's record lies (HBM, or the step kernel's LDS copy with the colours in HBM):
+//   int flags(s), nv(s), opa(s), voff(s), vcap(s), vslot(idx);  double col(s, c);  const double* vbase()  (x, y of vertex slot 0),
+//   const double* pos(s)
+// Lanes are sprites where the work is per sprite (liveness, colour, item records) and VERTEX SLOTS where it is per vertex
+// (the integer points, their bounds): every vertex slot of the record is looked at once, 64 at a time, its loads coalesced.
+// `sc` is scratch in LDS: 2 words per sprite slot, 4 per item (RM_EMIT_SCRATCH_WORDS).
+//   P  the static prefix against its reference record (slot words by slot, vertices by vertex slot)         -> s_lo
+//   A  per slot: live vertices, colour; ONE copy per sprite: the items' first points (scan)
+//   B  per vertex slot: its point(s) -> the items' bounds (LDS atomics); one copy per sprite: stored straight away
+//   C  per item: (copies: does it touch the canvas? first point by scan) rows on the canvas (scan) -> the item record
+//   D  (copies only) per vertex slot: the visible copies' points
+#define RM_EMIT_SCRATCH_WORDS(slots, items, copies) (((copies) > 1 ? 8 * (slots) : 0) + 2 * (slots) + 4 * (items))
+// key (copies only): per slot the order-preserving keys of its smallest / largest x and y among the ordinary vertices (four 64-bit words);
+// slot: [2s] nvl | irregular << 16, [2s + 1] rgba;  item: [4g] first point, [4g + 1] nvl, [4g + 2] ymin, [4g + 3] ymax (copies, until C:
+// the bounds the sprite's irregular vertices left, [4g] xmin [4g + 1] xmax)
+struct RmEmitScratch { long long* key; int32_t* slot; int32_t* item; };
+RM_FN void rm_emit_scratch(int32_t* base, int slots, int copies, RmEmitScratch* sc) {   // (base: 8-byte aligned)
+  sc->key = reinterpret_cast<long long*>(base);
+  sc->slot = base + (copies > 1 ? 8 * slots : 0);
+  sc->item = sc->slot + 2 * slots;
+}
+RM_FN long long rm_key(double d) { long long b; memcpy(&b, &d, 8); return b ^ ((b >> 63) & 0x7fffffffffffffffll); }
+RM_FN double rm_unkey(long long k) { const long long b = k ^ ((k >> 63) & 0x7fffffffffffffffll); double d; memcpy(&d, &b, 8); return d; }
+RM_FN void rm_min64(long long* p, long long v) {
+#if RM_DEV
+  atomicMin(p, v);
+#else
+  if (v < *p) *p = v;
+#endif
+}
+RM_FN void rm_max64(long long* p, long long v) {
+#if RM_DEV
+  atomicMax(p, v);
+#else
+  if (v > *p) *p = v;
+#endif
+}
+
 // The integer canvas point of copy cp of a vertex (pil_renderer.py:104-108: the scaled doubles through Pillow's (int));
 // copy c of a torus is drawn at the offset (c / 3 - 1, c % 3 - 1) (polygon_modifiers.py:88-97), the first-person modifier
 // translates everything by (fpx, fpy) (polygon_modifiers.py:41-64); one of the two at most.
@@ -144,73 +215,30 @@ RM_FN uint32_t rm_emit_point(const RmEmit& a, double x, double y, int cp, double
   return (uint32_t)(uint16_t)ix | ((uint32_t)(uint16_t)iy << 16);
 }
 
-// A prefix slot against the reference record: alive bit, vertex count, opacity, colour bits, and its live vertices bit for bit
-template <class SRC>
-RM_FN bool rm_emit_prefix_differs(const RmEmit& a, const SRC& src, int s) {
-  const int flags = src.flags(s), nvs = src.nv(s), opa = src.opa(s);
-  bool bad = ((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0 || nvs != a.sref_nv[s] || opa != a.sref_opa[s];
-  for (int c = 0; c < 3; ++c) {
-    const double v = src.col(s, c), r = a.sref_col[3 * s + c];
-    uint64_t b0, r0;
-    memcpy(&b0, &v, 8); memcpy(&r0, &r, 8);
-    bad = bad || b0 != r0;
-  }
-  if (flags & MOOG_F_ALIVE) {
-    int nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
-    if (nvl > src.vcap(s)) nvl = src.vcap(s);
-    const double* v = src.vert(s);
-    const double* r = a.sref_v + 2 * src.voff(s);
-    for (int k = 0; k < 2 * nvl; ++k) {
-      const double x = v[k], y = r[k];
-      uint64_t b0, r0;
-      memcpy(&b0, &x, 8); memcpy(&r0, &y, 8);
-      bad = bad || b0 != r0;
-    }
-  }
-  return bad;
-}
-
-// item g = slot s, copy cp: live vertices (0: dead or inside the valid prefix) and colour
-template <class SRC>
-RM_FN int rm_emit_item_live(const RmEmit& a, const SRC& src, int env, int s, int s_lo, uint32_t* rgba_out) {
-  const int flags = src.flags(s), nvs = src.nv(s), opa = src.opa(s);
-  *rgba_out = 0u;
-  if (!(flags & MOOG_F_ALIVE)) return 0;
-  const double c0 = src.col(s, 0), c1 = src.col(s, 1), c2 = src.col(s, 2);
-  uint32_t rgb;
-  if (a.rgb_override) rgb = a.rgb_override[(size_t)env * a.slots + s] & 0xffffffu;
-  else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
-  else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
-  *rgba_out = rgb | (((uint32_t)opa & 255u) << 24);
+RM_FN int rm_emit_nvl(int nvs, int vcap) {
   int nvl = nvs < 0 ? 0 : (nvs > RM_BIG_NV ? RM_BIG_NV : nvs);
-  if (nvl > src.vcap(s)) nvl = src.vcap(s);
-  return s < s_lo ? 0 : nvl;
+  return nvl > vcap ? vcap : nvl;
 }
 
-// The item's integer points: their bounds, and -- out != null -- the points themselves (+ the owner bytes).
-// A torus copy whose points all lie two or more pixels beside the canvas paints nothing (its crossings are float32
-// interpolations between such points, its heads lie between them): *visible = false.  A sprite with a coordinate that is not an
-// ordinary number (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN) keeps every copy its rows put on the canvas.
+// P: a prefix slot's words / a prefix vertex slot's coordinates against the reference record, bit for bit
 template <class SRC>
-RM_FN void rm_emit_item_points(const RmEmit& a, const SRC& src, int s, int cp, int g, int nvl, double fpx, double fpy,
-                               uint32_t* pts_out, uint8_t* owner_out, int* ymin, int* ymax, bool* visible) {
-  const double* v = src.vert(s);
-  int y0 = 0x7fffffff, y1 = -0x7fffffff, x0 = 0x7fffffff, x1 = -0x7fffffff;
-  bool irregular = false;
-  for (int k = 0; k < nvl; ++k) {
-    const double x = v[2 * k], y = v[2 * k + 1];
-    int ix, iy;
-    const uint32_t p = rm_emit_point(a, x, y, cp, fpx, fpy, &ix, &iy);
-    if (pts_out) { pts_out[k] = p; owner_out[k] = (uint8_t)g; }
-    y0 = iy < y0 ? iy : y0; y1 = iy > y1 ? iy : y1;
-    // ordinary: every copy's scaled coordinate is far inside what (int) holds (NaN fails the comparisons)
-    const bool ordinary = fabs(x) < 1.0e6 && fabs(y) < 1.0e6;
-    if (ordinary) { x0 = ix < x0 ? ix : x0; x1 = ix > x1 ? ix : x1; }
-    else irregular = true;
-  }
-  *ymin = y0; *ymax = y1;
-  // (an irregular sprite's x range is not tracked: every copy its rows put on the canvas is kept)
-  *visible = nvl > 0 && (a.ncopy == 1 || (y1 >= 0 && y0 <= a.H - 1 && (irregular || (x1 >= -1 && x0 <= a.W))));
+RM_FN bool rm_emit_prefix_slot_differs(const RmEmit& a, const SRC& src, int s) {
+  const int flags = src.flags(s), nvs = src.nv(s), opa = src.opa(s);
+  const double c0 = src.col(s, 0), c1 = src.col(s, 1), c2 = src.col(s, 2);
+  const double r0 = a.sref_col[3 * s], r1 = a.sref_col[3 * s + 1], r2 = a.sref_col[3 * s + 2];
+  uint64_t b0, b1, b2, q0, q1, q2;
+  memcpy(&b0, &c0, 8); memcpy(&b1, &c1, 8); memcpy(&b2, &c2, 8); memcpy(&q0, &r0, 8); memcpy(&q1, &r1, 8); memcpy(&q2, &r2, 8);
+  return (((flags ^ a.sref_flags[s]) & MOOG_F_ALIVE) != 0) | (nvs != a.sref_nv[s]) | (opa != a.sref_opa[s]) | (b0 != q0) | (b1 != q1) | (b2 != q2);
+}
+template <class SRC>
+RM_FN bool rm_emit_prefix_vertex_differs(const RmEmit& a, const SRC& src, int idx) {
+  const int s = src.vslot(idx);
+  const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
+  const double rx = a.sref_v[2 * idx], ry = a.sref_v[2 * idx + 1];
+  const bool live = (src.flags(s) & MOOG_F_ALIVE) != 0 && idx - src.voff(s) < rm_emit_nvl(src.nv(s), src.vcap(s));
+  uint64_t b0, b1, q0, q1;
+  memcpy(&b0, &x, 8); memcpy(&b1, &y, 8); memcpy(&q0, &rx, 8); memcpy(&q1, &ry, 8);
+  return live & ((b0 != q0) | (b1 != q1));
 }
 
 RM_FN int rm_rows_on_canvas(int y0, int y1, int H) {
@@ -219,31 +247,134 @@ RM_FN int rm_rows_on_canvas(int y0, int y1, int H) {
   return y1 >= y0 ? y1 - y0 + 1 : 0;
 }
 
-// One wavefront (device: `lane` = the thread's index in it; host model: lane = -1 does every lane's work) writes env's record.
+#define RM_EMIT_PF 8   // rounds of vertex slots whose slot numbers a lane fetches ahead (device)
 template <class SRC>
-RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane) {
+RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmEmitScratch& sc, int totv) {
   uint8_t* const rec = a.out + (size_t)env * a.lay.stride;
   RmDrawItem* const items = reinterpret_cast<RmDrawItem*>(rec + a.lay.o_items);
   uint32_t* const pts = reinterpret_cast<uint32_t*>(rec + a.lay.o_pts);
   uint8_t* const owner = rec + a.lay.o_owner;
+  const bool copies = a.ncopy > 1;
+#if RM_DEV
+  // Everything this wavefront reads from global memory without knowing anything yet goes out first, in one go: the emitter sits
+  // on the step kernel's critical path, and a load it waits for costs as much as a hundred instructions.  vertex slot -> sprite slot:
+  int vsl[RM_EMIT_PF];
+#pragma unroll
+  for (int r = 0; r < RM_EMIT_PF; ++r) vsl[r] = (lane + 64 * r < totv) ? src.vslot(lane + 64 * r) : 0;
+#endif
   // first-person frames: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
   double fpx = 0.0, fpy = 0.0;
   if (a.first_person) {
     for (int s = a.fp_slot0; s < a.fp_slot0 + a.fp_nslots; ++s)
       if (src.flags(s) & MOOG_F_ALIVE) { const double* p = src.pos(s); fpx = 0.5 - p[0]; fpy = 0.5 - p[1]; break; }
   }
-  // the static prefix (never under copies: torus frames are drawn whole)
-  const int NS = a.ncopy > 1 ? 0 : a.n_static;
+  // P: the static prefix (never under copies: torus frames are drawn whole)
+  const int NS = copies ? 0 : a.n_static;
   bool bad = false;
+  if (NS > 0) {
+    RM_LANES(s, NS, lane) bad = bad | rm_emit_prefix_slot_differs(a, src, s);
+    const int nsv = src.voff(NS - 1) + src.vcap(NS - 1);   // (the prefix's vertex slots are the first of the record)
+    RM_LANES(idx, nsv, lane) bad = bad | rm_emit_prefix_vertex_differs(a, src, idx);
+  }
+  // A, first half: the slots' colours (in HBM for the step kernel: loaded before the vote on the prefix is waited for)
+  int run_pts = 0;
 #if RM_DEV
-  for (int s = lane; s < NS; s += 64) bad = bad || rm_emit_prefix_differs(a, src, s);
-  bad = RM_ANY(bad);
+  for (int i0 = 0; i0 < a.slots; i0 += 64) {
+    const int s = i0 + lane;
+    const bool in = s < a.slots;
 #else
-  (void)lane;
-  for (int s = 0; s < NS; ++s) bad = bad || rm_emit_prefix_differs(a, src, s);
+  bad = RM_ANY(bad);
+  for (int s = 0; s < a.slots; ++s) {
+    const bool in = true;
 #endif
-  const int s_lo = bad ? 0 : NS;
-  int run_pts = 0, run_rows = 0;
+    int nvl = 0;
+    uint32_t rgba = 0u;
+    if (in) {
+      const int flags = src.flags(s), opa = src.opa(s);
+      const double c0 = src.col(s, 0), c1 = src.col(s, 1), c2 = src.col(s, 2);
+      const uint32_t ov = a.rgb_override ? a.rgb_override[(size_t)env * a.slots + s] : 0u;
+      if (flags & MOOG_F_ALIVE) {
+        uint32_t rgb;
+        if (a.rgb_override) rgb = ov & 0xffffffu;
+        else if (a.cmap == MOOG_CMAP_HSV) rgb = rm_hsv_rgb(c0, c1, c2);
+        else rgb = ((uint32_t)(int)c0 & 255u) | (((uint32_t)(int)c1 & 255u) << 8) | (((uint32_t)(int)c2 & 255u) << 16);
+        rgba = rgb | (((uint32_t)opa & 255u) << 24);
+        nvl = rm_emit_nvl(src.nv(s), src.vcap(s));
+      }
+    }
+#if RM_DEV
+    if (i0 == 0) bad = RM_ANY(bad);   // (the vote, behind the first round's loads)
+#endif
+    const int s_lo = bad ? 0 : NS;
+    if (s < s_lo) nvl = 0;
+    int first = 0;
+    if (!copies) {
+#if RM_DEV
+      const int inc = rm_wave_scan(nvl);
+      first = run_pts + inc - nvl;
+      run_pts += __builtin_amdgcn_readlane(inc, 63);
+#else
+      first = run_pts;
+      run_pts += nvl;
+#endif
+    }
+    if (in) {
+      sc.slot[2 * s] = nvl; sc.slot[2 * s + 1] = (int32_t)rgba;
+      if (copies) {
+        long long* kk = sc.key + 4 * s;
+        kk[0] = 0x7fffffffffffffffll; kk[1] = -0x7fffffffffffffffll - 1; kk[2] = kk[0]; kk[3] = kk[1];
+      }
+      for (int cp = 0; cp < a.ncopy; ++cp) {
+        int32_t* it = sc.item + 4 * (s * a.ncopy + cp);
+        it[0] = copies ? 0x7fffffff : first; it[1] = copies ? -0x7fffffff : nvl; it[2] = 0x7fffffff; it[3] = -0x7fffffff;
+      }
+    }
+  }
+  rm_wave_sync();
+  // B: per vertex slot.  One copy per sprite: the point, stored where the item's points go, and the item's y range.  Copies:
+  // Pillow truncates the scaled coordinates towards zero, so a copy's integer points are not the sprite's shifted by a canvas --
+  // but x -> (int)(W * (x + o)) is monotone, so a copy's integer bounds are those of the sprite's smallest and largest
+  // coordinates: four 64-bit atomics per vertex on order-preserving keys.  A vertex with a coordinate that is not an ordinary number
+  // (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN, which is not monotone) leaves its nine points' y behind instead.
+  auto vertex_b = [&](int idx, int s) {
+    const int k = idx - src.voff(s);
+    const int nvl = sc.slot[2 * s] & 0xffff;
+    if (k >= nvl) return;
+    const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
+    if (!copies) {
+      int ix, iy;
+      const uint32_t p = rm_emit_point(a, x, y, 0, fpx, fpy, &ix, &iy);
+      int32_t* it = sc.item + 4 * s;
+      pts[it[0] + k] = p; owner[it[0] + k] = (uint8_t)s;
+      rm_min(it + 2, iy); rm_max(it + 3, iy);
+    } else {
+      // ordinary: every copy's scaled coordinate is far inside what (int) holds (NaN fails the comparisons)
+      const bool ordinary = fabs(x) < 1.0e6 && fabs(y) < 1.0e6;
+      if (ordinary) {
+        long long* kk = sc.key + 4 * s;
+        rm_min64(kk + 0, rm_key(x)); rm_max64(kk + 1, rm_key(x));
+        rm_min64(kk + 2, rm_key(y)); rm_max64(kk + 3, rm_key(y));
+      } else {
+        rm_or32(sc.slot + 2 * s, 1 << 16);
+        for (int cp = 0; cp < a.ncopy; ++cp) {   // (the bounds of such a sprite's copies: point by point; its x range is not tracked)
+          int ix, iy;
+          rm_emit_point(a, x, y, cp, fpx, fpy, &ix, &iy);
+          int32_t* it = sc.item + 4 * (s * a.ncopy + cp);
+          rm_min(it + 2, iy); rm_max(it + 3, iy);
+        }
+      }
+    }
+  };
+#if RM_DEV
+#pragma unroll
+  for (int r = 0; r < RM_EMIT_PF; ++r) if (lane + 64 * r < totv) vertex_b(lane + 64 * r, vsl[r]);
+  for (int idx = lane + 64 * RM_EMIT_PF; idx < totv; idx += 64) vertex_b(idx, src.vslot(idx));
+#else
+  for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vslot(idx));
+#endif
+  rm_wave_sync();
+  // C: per item
+  int run_rows = 0;
 #if RM_DEV
   for (int i0 = 0; i0 < a.S; i0 += 64) {
     const int g = i0 + lane;
@@ -253,23 +384,36 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane) {
     const bool in = true;
 #endif
     const int s = in ? g / a.ncopy : 0, cp = in ? g - s * a.ncopy : 0;
-    uint32_t rgba = 0u;
-    int nvl = in ? rm_emit_item_live(a, src, env, s, s_lo, &rgba) : 0;
-    int y0 = 0x7fffffff, y1 = -0x7fffffff;
-    bool vis = false;
-    if (a.ncopy > 1) {   // copies: which of them touch the canvas decides where the points go
-      rm_emit_item_points(a, src, s, cp, g, nvl, fpx, fpy, nullptr, nullptr, &y0, &y1, &vis);
+    int32_t* it = sc.item + 4 * (in ? g : 0);
+    int y0 = in ? it[2] : 0x7fffffff, y1 = in ? it[3] : -0x7fffffff;
+    int nvl = in ? (sc.slot[2 * s] & 0xffff) : 0;
+    int first = in ? it[0] : 0;
+    if (copies) {
+      // A copy whose points all lie two or more pixels beside the canvas paints nothing: its crossings are float32
+      // interpolations between such points (off by far less than a pixel at these magnitudes), its heads lie between them.
+      const bool irregular = in && (sc.slot[2 * s] >> 16) != 0;
+      int x0 = 0x7fffffff, x1 = -0x7fffffff;
+      const long long* kk = sc.key + 4 * s;
+      if (in && kk[0] <= kk[1]) {   // the ordinary vertices: the copy's bounds from the sprite's extreme coordinates
+        int ixa, iya, ixb, iyb;
+        rm_emit_point(a, rm_unkey(kk[0]), rm_unkey(kk[2]), cp, fpx, fpy, &ixa, &iya);
+        rm_emit_point(a, rm_unkey(kk[1]), rm_unkey(kk[3]), cp, fpx, fpy, &ixb, &iyb);
+        x0 = ixa; x1 = ixb;
+        y0 = iya < y0 ? iya : y0; y1 = iyb > y1 ? iyb : y1;
+      }
+      // (an irregular sprite keeps every copy its rows put on the canvas: its x range is not tracked)
+      const bool vis = nvl > 0 && y1 >= 0 && y0 <= a.H - 1 && (irregular || (x1 >= -1 && x0 <= a.W));
       if (!vis) nvl = 0;
-    }
 #if RM_DEV
-    const int inc = rm_wave_scan(nvl);
-    const int first = run_pts + inc - nvl;
-    run_pts += __builtin_amdgcn_readlane(inc, 63);
+      const int inc = rm_wave_scan(nvl);
+      first = run_pts + inc - nvl;
+      run_pts += __builtin_amdgcn_readlane(inc, 63);
 #else
-    const int first = run_pts;
-    run_pts += nvl;
+      first = run_pts;
+      run_pts += nvl;
 #endif
-    rm_emit_item_points(a, src, s, cp, g, nvl, fpx, fpy, pts + first, owner + first, &y0, &y1, &vis);
+      if (in) { it[0] = first; it[1] = nvl; }
+    }
     const int cnt = nvl > 0 ? rm_rows_on_canvas(y0, y1, a.H) : 0;
 #if RM_DEV
     const int rinc = rm_wave_scan(cnt);
@@ -280,13 +424,36 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane) {
     run_rows += cnt;
 #endif
     if (in) {
-      RmDrawItem it;
-      it.rowoff = rowoff;
-      it.pb_nv = (uint32_t)first | ((uint32_t)nvl << 20);
-      it.y01 = nvl > 0 ? (int32_t)((uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16)) : RM_Y01_EMPTY;
-      it.rgba = rgba;
-      items[g] = it;
+      RmDrawItem o;
+      o.rowoff = rowoff;
+      o.pb_nv = (uint32_t)first | ((uint32_t)nvl << 20);
+      o.y01 = nvl > 0 ? (int32_t)((uint32_t)(uint16_t)y0 | ((uint32_t)(uint16_t)y1 << 16)) : RM_Y01_EMPTY;
+      o.rgba = nvl > 0 ? (uint32_t)sc.slot[2 * s + 1] : 0u;
+      items[g] = o;
     }
+  }
+  if (copies) {   // D: the visible copies' points
+    rm_wave_sync();
+    auto vertex_d = [&](int idx, int s) {
+      const int k = idx - src.voff(s);
+      if (k >= (sc.slot[2 * s] & 0xffff)) return;
+      const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
+      for (int cp = 0; cp < a.ncopy; ++cp) {
+        const int g = s * a.ncopy + cp;
+        const int32_t* it = sc.item + 4 * g;
+        if (k >= it[1]) continue;
+        int ix, iy;
+        pts[it[0] + k] = rm_emit_point(a, x, y, cp, fpx, fpy, &ix, &iy);
+        owner[it[0] + k] = (uint8_t)g;
+      }
+    };
+#if RM_DEV
+#pragma unroll
+    for (int r = 0; r < RM_EMIT_PF; ++r) if (lane + 64 * r < totv) vertex_d(lane + 64 * r, vsl[r]);
+    for (int idx = lane + 64 * RM_EMIT_PF; idx < totv; idx += 64) vertex_d(idx, src.vslot(idx));
+#else
+    for (int idx = 0; idx < totv; ++idx) vertex_d(idx, src.vslot(idx));
+#endif
   }
 #if RM_DEV
   if (lane == 0)
@@ -300,14 +467,15 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane) {
 
 // The record in HBM as the ABI lays it out (the derive kernel, the host model)
 struct RmSrcRecord {
-  const moog_program_t* P; const moog_layout_t* L; const double* f; const int32_t* q;
+  const moog_program_t* P; const moog_layout_t* L; const double* f; const int32_t* q; const int16_t* vs;   // vs: vertex slot -> sprite slot
   RM_MEMBER int flags(int s) const { return q[L->o_flags + s]; }
   RM_MEMBER int nv(int s) const { return q[L->o_nverts + s]; }
   RM_MEMBER int opa(int s) const { return q[L->o_opacity + s]; }
   RM_MEMBER int voff(int s) const { return P->slot_voff[s]; }
   RM_MEMBER int vcap(int s) const { return P->slot_vcap[s]; }
   RM_MEMBER double col(int s, int c) const { return f[L->o_color + 3 * s + c]; }
-  RM_MEMBER const double* vert(int s) const { return f + L->o_verts + 2 * P->slot_voff[s]; }
+  RM_MEMBER int vslot(int idx) const { return vs[idx]; }
+  RM_MEMBER const double* vbase() const { return f + L->o_verts; }
   RM_MEMBER const double* pos(int s) const { return f + L->o_pos + 2 * s; }
 };
 

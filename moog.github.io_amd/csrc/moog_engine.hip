@@ -72,6 +72,8 @@ struct moog_engine {
   RmSetup mask_setup{};   // the mask rasteriser (moog_raster_mask_core.h): ok = this program's ordinary frames are drawn by it
   uint8_t* draw = nullptr;        // its input: a draw record per env (moog_draw_record.h), written by the step kernel or derived before the launch
   RmDrawLayout draw_lay{};
+  int raster_persist = 0;         // MOOG_RASTER_PERSIST=k: frames per CU the mask rasteriser's launch keeps resident (one round of workgroups that draw several frames each); 0: a workgroup per frame
+  int n_cus = 256;
   bool draw_in_step = true;       // MOOG_DRAW_IN_STEP=0: never by the step kernel (A/B runs, tests: the derive kernel for every launch)
   int raster_tile_w = 0, raster_band_h = 0, raster_tiles_x = 1, raster_bands = 1;   // one workgroup per tile of the canvas
   // anti_aliasing > 1: frames are drawn on a canvas aa x the observation (a chunk of envs at a time) and down-sampled
@@ -487,7 +489,7 @@ static void mask_plan_rows(moog_engine* e, int cap) {
   if (cap > ms.S * e->canvas_h) cap = ms.S * e->canvas_h;
   if (cap < e->canvas_h) cap = e->canvas_h;
   for (;;) {
-    rm_plan(ms.S, e->L.TOTV * ms.ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, ms.big, &ms.plan);
+    rm_plan(ms.S, e->L.TOTV * ms.ncopy, e->pad_w, e->canvas_h, cap, ms.iwords, RM_THREADS / 64, ms.big, &ms.plan, ms.compact);
     if (ms.plan.total <= 64u * 1024u || cap <= e->canvas_h) break;
     cap = cap - 64 > e->canvas_h ? cap - 64 : e->canvas_h;
   }
@@ -504,7 +506,10 @@ static void mask_plan_rows(moog_engine* e, int cap) {
 // CU (LDS; registers hold ten, and a plan within 1 KB of losing one counts as losing it).  falling_balls_64's launch 628 -> 471 us.
 // They never shrink; the picture does not depend on their number.  Once they are as many as is free the frames stop reporting
 // (an atomic on host memory per frame and launch: 8.6 ms per launch when every frame of a batch of 4096 keeps doing it).
-static int mask_frames_per_cu(uint32_t lds) { const int n = (int)(160u * 1024u / (lds + 1024u)); return n > 10 ? 10 : n; }
+static int mask_frames_per_cu(uint32_t lds) {   // by LDS, and by registers: RM_WAVES_PER_SIMD waves on each of four SIMDs, RM_THREADS / 64 waves a frame
+  const int n = (int)(160u * 1024u / (lds + 1024u)), by_regs = RM_WAVES_PER_SIMD * 4 / (RM_THREADS / 64);
+  return n > by_regs ? by_regs : n;
+}
 // the most row records that cost no resident frame per CU against the plan in hand (called once, at create)
 static int mask_free_rows(moog_engine* e) {
   RmSetup& ms = e->mask_setup;
@@ -704,6 +709,14 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
       int cap = 192;
       { const char* rc = getenv("MOOG_RASTER_ROWS"); if (rc && atoi(rc) >= 1) { cap = atoi(rc); e->raster_rows_fixed = 1; } }   // tuning / tests of the multi-pass path
       mask_plan_rows(e, cap);
+      {   // 4-byte edge records when the 16-byte ones keep frames off a CU (or do not fit at all): MOOG_RASTER_COMPACT=0 / 1 forces
+        const char* cs = getenv("MOOG_RASTER_COMPACT");
+        const RmSetup full = ms;
+        ms.compact = 1; ms.ok = 1;
+        mask_plan_rows(e, cap);
+        const bool better = ms.ok && (!full.ok || mask_frames_per_cu(ms.lds) > mask_frames_per_cu(full.lds));
+        if (cs ? atoi(cs) == 0 : !better) ms = full;
+      }
       e->mask_free_cap = (ms.ok && !e->raster_rows_fixed) ? mask_free_rows(e) : ms.cap_rows;
       if (ms.ok) {   // a draw record per env (moog_draw_record.h): header + an item per slot and copy + every vertex slot's point and owner byte
         e->draw_lay = rm_draw_layout(ms.S, e->L.TOTV * ms.ncopy);
@@ -713,6 +726,8 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         }
         const char* ds = getenv("MOOG_DRAW_IN_STEP");
         e->draw_in_step = !(ds && atoi(ds) == 0);
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && cus > 0) e->n_cus = cus; }
+        { const char* ps = getenv("MOOG_RASTER_PERSIST"); if (ps) e->raster_persist = atoi(ps); }
       }
     }
   }
@@ -911,10 +926,13 @@ static RmEmit emit_args(moog_engine* e) {
   return m;
 }
 // The step kernel writes the draw records of the frames the raster launch behind it draws (moog_engine_step with an image):
-// when those frames are the mask rasteriser's, drawn in one launch over every env, and the step kernel is the one that leaves
-// every env's record final (a late-reset program's episodes are opened by the reset kernel behind it: derived instead).
+// when those frames are the mask rasteriser's, drawn in one launch over every env (a late-reset program's episodes are opened by
+// the reset kernel behind the step kernel: that launch writes the draw records of the envs it resets).
 static bool step_emits_draw(moog_engine* e) {
-  return e->draw_in_step && e->mask_setup.ok && e->draw && e->pe_ns <= 0 && e->aa <= 1 && !e->late_reset;
+  // (the emitter's scratch in the step kernel's LDS, emit_draw_record: a torus's nine items per slot must fit behind the vertex offsets)
+  const bool scratch_fits = e->mask_setup.ncopy == 1 ||
+      4u * (size_t)RM_EMIT_SCRATCH_WORDS(e->mask_setup.slots, e->mask_setup.S, e->mask_setup.ncopy) <= (size_t)CAND_CAP * 2 + 128 + 64 * 8;
+  return e->draw_in_step && e->mask_setup.ok && e->draw && e->pe_ns <= 0 && e->aa <= 1 && scratch_fits;
 }
 
 static RArgs raster_args(moog_engine* e, uint8_t* image) {
@@ -938,7 +956,11 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
   r.sbg_env_stride = 0; r.env_build = nullptr; r.rgb_override = e->rgb_override;
-  r.em = emit_args(e); r.draw_ready = 0; r.env0 = 0;
+  r.em = emit_args(e); r.vslot = e->d_vslot; r.draw_ready = 0; r.env0 = 0;
+  {   // (one resident round: the frames a CU holds at once by LDS and registers, or fewer when asked)
+    const int fit = mask_frames_per_cu(r.ms.lds);
+    r.ms.persist_slots = e->raster_persist > 0 ? e->n_cus * (e->raster_persist < fit ? e->raster_persist : fit) : 0;
+  }
   return r;
 }
 
@@ -1021,8 +1043,9 @@ static int pool_kick(moog_engine* e, hipStream_t s) {
 
 // Late reset (step_env): behind the step kernel of a program stepped by the kernels without the rare components, the full
 // reset kernel opens the episodes of the envs that kernel marked (a grid of early exits when there are none).
-static int late_reset_launch(moog_engine* e, const moog_inject_t* inject, const moog_step_out_t* out, hipStream_t s) {
+static int late_reset_launch(moog_engine* e, const moog_inject_t* inject, const moog_step_out_t* out, hipStream_t s, const RmEmit* draw) {
   KArgs b = make_args(e, nullptr, inject, out, MODE_RESET_MASK, nullptr);
+  if (draw) b.draw = *draw;   // (the step launch wrote draw records: the envs this launch resets get theirs from it)
   b.late_mask = e->late_mask;
   b.pool_state = (e->pool_on && !(inject && inject->uniforms)) ? e->pool_state : nullptr;   // (the step kernel took the env's lock then)
   moog_launch_reset_full(e->n_envs, e->step_lds, s, b);
@@ -1079,7 +1102,7 @@ int moog_engine_step(moog_engine_t* e, const void* actions_dev, const moog_injec
   {
     Bracket br(e, MOOG_K_STEP, s);
     launch_step(e, s, a);
-    if (e->late_reset && (rc = late_reset_launch(e, inject, out, s)) != MOOG_OK) return rc;
+    if (e->late_reset && (rc = late_reset_launch(e, inject, out, s, emit ? &a.draw : nullptr)) != MOOG_OK) return rc;
   }
   HIPCHK(hipGetLastError());
   if (a.pool_state && (rc = pool_kick(e, s)) != MOOG_OK) return rc;

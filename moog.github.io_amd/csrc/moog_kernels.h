@@ -238,17 +238,23 @@ struct RmSrcEnv {
   __device__ __forceinline__ int voff(int s) const { return e->voff[s]; }
   __device__ __forceinline__ int vcap(int s) const { return e->P->slot_vcap[s]; }
   __device__ __forceinline__ double col(int s, int c) const { return static_cast<const double*>(e->gcol)[3 * s + c]; }
-  __device__ __forceinline__ const double* vert(int s) const { return &e->f[e->L.o_verts + 2 * e->voff[s]]; }
+  __device__ __forceinline__ int vslot(int idx) const { return e->vslot[idx]; }
+  __device__ __forceinline__ const double* vbase() const { return &e->f[e->L.o_verts]; }
   __device__ __forceinline__ const double* pos(int s) const { return &e->f[e->L.o_pos + 2 * s]; }
 };
-// After store_record: the frame the rasteriser is about to draw, from the record still in LDS (what the reset path wrote
-// straight to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
+// Beside store_record: the frame the rasteriser is about to draw, from the record in LDS (what the reset path wrote straight
+// to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
 __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, int env) {
   if (!a.draw.out) return;
   wsync();
   RmSrcEnv src;
   src.e = &e;
-  rm_emit(a.draw, src, env, e.lane);
+  // scratch: one copy per sprite -- six words per slot -- in the bounding volumes (eight per slot; nothing reads them after the
+  // last sub-step); the nine copies of a torus -- 46 words per slot -- in the candidate list / list / row mask area behind the
+  // vertex offsets (CAND_CAP * 2 + 128 + 64 * 8 bytes: the engine checks that they fit, step_emits_draw)
+  RmEmitScratch sc;
+  rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(e.cand) : reinterpret_cast<int32_t*>(e.bb), a.draw.slots, a.draw.ncopy, &sc);
+  rm_emit(a.draw, src, env, e.lane, sc, e.L.TOTV);
 }
 
 // =====================================================================================
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
     if (a.discount) a.discount[env] = __builtin_nan("");
     if (a.step_type) a.step_type[env] = 0;
   }
+  emit_draw_record(e, a, env);   // (a late reset behind a step launch that wrote draw records: this env's is the new episode's)
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
 #if MOOG_WITH_MAZE
   if (a.late_mask != nullptr) {   // late reset: served; the step kernel took the pool's lock for this env when the episode ended
@@ -639,9 +646,9 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
       }
 #endif
     }
+    emit_draw_record(e, a, env);   // (before the record's stores: a wave waits once for its stores to drain, at its end)
     store_record(e, a.H, a.L, gf, gq, a.fault_flag);
     if (DYN && held) pool_release(a, env, e.lane);
-    emit_draw_record(e, a, env);
     if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
     return;
   }
@@ -702,8 +709,8 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
   }
   SEC(e, SEC_STORE);
+  emit_draw_record(e, a, env);   // (before the record's stores: a wave waits once for its stores to drain, at its end)
   store_record(e, a.H, a.L, gf, gq, a.fault_flag);
-  emit_draw_record(e, a, env);
   if (a.cost && e.lane == 0) a.cost[env] = MOOG_COST_OF((float)(clock64() - t_sched), a.cost[env]);
   if ((a.dbg & 128) && e.lane == 0 && a.discount) {   // profiling aid: cycles and work counters instead of outputs
     a.discount[env] = (double)(clock64() - t_begin);

@@ -52,10 +52,11 @@ struct RPlan {   // LDS carve-up (byte offsets), computed once on the host
 // ordinary frames (not the prefix pictures, not draw-list or per-env-prefix frames) with that kernel.
 struct RmSetup {
   int32_t ok;
-  int32_t S, slots, ncopy, big, cap_rows, iwords, cmap, first_person, fp_slot0, fp_nslots;
+  int32_t S, slots, ncopy, big, compact, cap_rows, iwords, cmap, first_person, fp_slot0, fp_nslots;   // compact: 4-byte edge records (RmEdgesCompact)
   uint32_t bg;
   RmPlan plan;
   uint32_t lds;
+  int32_t persist_slots;   // > 0: workgroups resident on the device at once; a launch of more frames is one round of workgroups that draw several frames each
 };
 
 struct RArgs {
@@ -64,6 +65,7 @@ struct RArgs {
   // records (moog_engine_step); else moog_raster_launch derives them from f64 / i32 first.  env0: the engine's index of env 0
   // of this launch (launches over a chunk of the envs).
   RmEmit em;
+  const int16_t* vslot;   // vertex slot -> sprite slot (the emitter's)
   int32_t draw_ready, env0;
   int32_t* rows_seen;     // (mask rasteriser) host-mapped word for frames that want more row records, or null
   const moog_program_t* P;

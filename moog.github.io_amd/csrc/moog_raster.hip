@@ -21,7 +21,7 @@ static RmArgs mask_args(const RArgs& r) {
   RmArgs a;
   memset(&a, 0, sizeof a);
   a.draw = r.em.out; a.lay = r.em.lay; a.image = r.image;
-  a.n_envs = r.n_envs; a.S = r.ms.S; a.big = r.ms.big; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h;
+  a.n_envs = r.n_envs; a.S = r.ms.S; a.big = r.ms.big; a.compact = r.ms.compact; a.cap_rows = r.ms.cap_rows; a.W = r.canvas_w; a.H = r.canvas_h;
   a.flip = r.flip; a.iwords = r.ms.iwords; a.bg = r.ms.bg; a.debug_stop = r.debug_stop; a.threads = RM_THREADS;
   a.n_static = r.em.ncopy > 1 ? 0 : r.em.n_static;   // (torus frames are drawn whole: no cached picture under copies)
   a.sbg = r.sbg; a.rows_seen = r.rows_seen;
@@ -35,10 +35,10 @@ void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   if (a.ms.ok && !a.build && a.sbg_env_stride == 0 && !a.env_build) {
     if (!a.draw_ready) {   // records the engine did not step itself: the emitter on the records in HBM
       RmDeriveArgs d;
-      d.em = a.em; d.P = a.P; d.L = a.L; d.f64 = a.f64; d.i32 = a.i32; d.n_envs = a.n_envs; d.env0 = a.env0;
+      d.em = a.em; d.P = a.P; d.L = a.L; d.f64 = a.f64; d.i32 = a.i32; d.vslot = a.vslot; d.n_envs = a.n_envs; d.env0 = a.env0;
       moog_draw_derive_launch(d, stream);
     }
-    moog_raster_mask_launch(mask_args(a), a.ms.lds, stream);
+    moog_raster_mask_launch(mask_args(a), a.ms.lds, stream, a.ms.persist_slots);
     return;
   }
   const dim3 grid((unsigned)a.n_envs * (unsigned)(a.tiles_x * a.bands));

@@ -55,6 +55,7 @@ struct RmArgs {
   int32_t n_envs;
   int32_t S;                  // items (polygons a frame may hold): slots * ncopy
   int32_t big;                // some slot may hold a polygon of more than RM_MAX_NV vertices (rm_p4_big)
+  int32_t compact;            // the edge table holds 4-byte records (RmEdgesCompact; the plan was made for them)
   int32_t cap_rows;           // row records per pass (>= H)
   int32_t W, H;               // the canvas in memory (width a multiple of 16, <= 128)
   int32_t flip;               // rows are written bottom-up (np.flipud, pil_renderer.py:118)
@@ -72,9 +73,9 @@ struct RmArgs {
 static inline uint32_t rm_align(uint32_t x) { return (x + 15u) & ~15u; }
 
 // S: items; TOTV: points a frame may hold (the program's vertex slots x copies)
-static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, int big, RmPlan* p) {
+static inline void rm_plan(int S, int TOTV, int W, int H, int cap_rows, int iwords, int waves, int big, RmPlan* p, int compact = 0) {
   uint32_t o = 0;
-  p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * sizeof(RmEdge));
+  p->o_edge = o; o = rm_align(o + (uint32_t)TOTV * (compact ? 4u : (uint32_t)sizeof(RmEdge)));   // (compact: RmEdgesCompact)
   p->o_ivert = o; o = rm_align(o + (uint32_t)TOTV * 4u);
   p->o_rows = o; o = rm_align(o + (uint32_t)cap_rows * sizeof(RmRow));
   p->o_rowitem = o; o = rm_align(o + (uint32_t)cap_rows * 2u);
@@ -130,20 +131,6 @@ RM_FN void rm_or(uint32_t* p, uint32_t v) {
   *p |= v;
 #endif
 }
-RM_FN void rm_min(int32_t* p, int32_t v) {
-#if RM_DEV
-  atomicMin(p, v);
-#else
-  if (v < *p) *p = v;
-#endif
-}
-RM_FN void rm_max(int32_t* p, int32_t v) {
-#if RM_DEV
-  atomicMax(p, v);
-#else
-  if (v > *p) *p = v;
-#endif
-}
 // float -> int the way v_cvt_i32_f32 does it (saturating): the host model and the kernel then agree on far-away crossings
 RM_FN int rm_f2i(float f) {
   if (!(f > -2147483648.0f)) return (int)0x80000000;
@@ -173,6 +160,45 @@ template <int WORDS> RM_FN void rm_or_range(RmMask<WORDS>& m, int a, int b) {
 RM_FN int rm_y0(const RmEdge& e) { return (int)(int16_t)(e.w2 & 0xffffu); }
 RM_FN int rm_y1(const RmEdge& e) { return (int)(int32_t)e.w2 >> 16; }
 RM_FN float rm_xat(const RmEdge& e, int y) { return (float)(y - rm_y0(e)) * rm_u2f(e.w1) + rm_u2f(e.w0); }   // Draw.c: (ymin - y0) * dx + x0
+
+// The polygons' edge records in LDS, two ways:
+//   RmEdgesFull     16 bytes per vertex: the record as rm_build_edge / rm_p3 leave it, one 128-bit read per look.
+//   RmEdgesCompact   4 bytes per vertex beside the integer points the frame holds anyway: dx of a table edge (x0, y0, y1 are the
+//                    two points), xmin | xmax << 16 of a horizontal head, RM_NO_EDGE for a horizontal edge that is no head.  Three
+//                    32-bit reads and a conversion per look -- a tenth more instructions in the rows phase -- for a quarter of the
+//                    memory: the engine picks it for programs whose edge records are what keeps frames off a CU (falling_balls_64:
+//                    1816 vertex slots, 29 of 47 KB; three resident frames per CU become six).
+#define RM_NO_EDGE 0x7fff8000u   // (no head has xmin = -32768, xmax = 32767: points are clamped to +-32000)
+struct RmEdgesFull {
+  const RmEdge* pe;
+  RM_MEMBER RmEdge operator[](int k) const { return pe[k]; }
+};
+struct RmEdgesCompact {
+  const uint32_t* pv; const uint32_t* dx; int nv;
+  RM_MEMBER RmEdge operator[](int k) const {
+    const uint32_t q0 = pv[k], q1 = pv[(k + 1 >= nv) ? 0 : k + 1], w = dx[k];
+    const bool table = (q0 >> 16) != (q1 >> 16), head = !table && w != RM_NO_EDGE;
+    RmEdge E;
+    E.w0 = table ? rm_f2u((float)(int)(int16_t)(q0 & 0xffffu)) : (head ? w : 0u);
+    E.w1 = table ? w : 0u;
+    E.w2 = table ? ((q0 >> 16) | (q1 & 0xffff0000u)) : (head ? ((q0 >> 16) | (q0 & 0xffff0000u)) : 0u);
+    E.w3 = head ? 1u : 0u;
+    return E;
+  }
+};
+template <bool COMPACT> struct RmEdgeTab;
+template <> struct RmEdgeTab<false> {
+  typedef RmEdgesFull View;
+  template <class C> static RM_MEMBER View view(const C& c, int first, int nv) { (void)nv; View v; v.pe = c.edges + first; return v; }
+  template <class C> static RM_MEMBER void put(const C& c, int idx, const RmEdge& E, bool table, bool head) { (void)table; (void)head; c.edges[idx] = E; }
+};
+template <> struct RmEdgeTab<true> {
+  typedef RmEdgesCompact View;
+  template <class C> static RM_MEMBER View view(const C& c, int first, int nv) { View v; v.pv = c.ivert + first; v.dx = reinterpret_cast<const uint32_t*>(c.edges) + first; v.nv = nv; return v; }
+  template <class C> static RM_MEMBER void put(const C& c, int idx, const RmEdge& E, bool table, bool head) {
+    reinterpret_cast<uint32_t*>(c.edges)[idx] = table ? E.w1 : (head ? E.w0 : RM_NO_EDGE);
+  }
+};
 
 // ImagingDrawPolygon's edge list, the edge that leaves vertex k of a ring of nv packed points (x | y << 16, shorts):
 // 0 = no edge (the closing edge of a ring whose last point is its first, a horizontal edge merged into the run before
@@ -516,8 +542,14 @@ RM_FN void rm_load(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
   uint32_t p0 = 0u, o0 = 0u;
   if (tid < n_pts) p0 = pts[tid];
   if (4 * tid < n_pts) o0 = own[tid];
+  // A frame whose rows all fit in the row records (total_rows <= cap_rows: the usual case) is ONE pass over every item, and what
+  // rm_p2_assign would do for that pass -- the item's first row record, its clamped ymax, the owner of its rows -- follows from
+  // the item's own record: done below, by the thread that loaded it (the kernel then skips rm_p2_assign for the first pass).
+  const bool single = hdr.total_rows <= a.cap_rows;
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
-  for (int i = tid; i < (a.cap_rows + 1) / 2; i += T) reinterpret_cast<uint32_t*>(c.rowitem)[i] = 0u;   // (the rows' flag bytes)
+  // (the rows' flag bytes: a single-pass frame's are written with the owner bytes, 16 bits at a time, by the items' threads --
+  //  clearing them here, from other threads, could land on top of that)
+  if (!single) for (int i = tid; i < (a.cap_rows + 1) / 2; i += T) reinterpret_cast<uint32_t*>(c.rowitem)[i] = 0u;
   const int nseg = a.W >> 4;
   for (int i = tid; i < a.H * nseg * a.iwords; i += T) c.seg[i] = 0u;
   if (tid < 16) {   // four coverage bits -> byte masks of the 12 bytes of four RGB pixels
@@ -527,14 +559,22 @@ RM_FN void rm_load(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
     c.lut[4 * tid + 2] = (b2 ? 0x000000ffu : 0u) | (b3 ? 0xffffff00u : 0u);
     c.lut[4 * tid + 3] = 0u;
   }
-  if (tid < 13) c.misc[tid] = tid == 0 ? n_pts : ((tid == 5 && !(hdr.flags & RM_DRAW_PREFIX_OK)) ? 1 : 0);   // ([0] live vertices, [5] static prefix differs, [8..11] rows per bucket of the sort, [12] rows of long polygons)
+  if (tid < 13) c.misc[tid] = tid == 0 ? n_pts : ((tid == 5 && !(hdr.flags & RM_DRAW_PREFIX_OK)) ? 1 : ((tid == 6 && single) ? 1 : 0));   // ([0] live vertices, [5] static prefix differs, [6] one pass: its row records are assigned, [8..11] rows per bucket of the sort, [12] rows of long polygons)
   if (tid == 0) c.rowoff[a.S] = hdr.total_rows;
   for (int g = tid; g < a.S; g += T) {
     if (g != tid) it = items[g];
+    const int ymin = (int)(int16_t)((uint32_t)it.y01 & 0xffffu), ymax = (int)it.y01 >> 16;
     RmItem o;
     o.rowbase = 0; o.pb_nv = (int32_t)it.pb_nv; o.pymax = 0; o.rgba = it.rgba;
+    if (single) {
+      const int ys = ymin < 0 ? 0 : ymin;
+      const int cnt = rm_rows_on_canvas(ymin, ymax, a.H);
+      o.rowbase = it.rowoff - ys;
+      o.pymax = ymax > a.H ? a.H : ymax;   // polygon_generic clamps ymax to ysize
+      for (int j = 0; j < cnt; ++j) c.rowitem[it.rowoff + j] = (uint16_t)g;   // (owner | flags = 0)
+    }
     c.info[g] = o;
-    c.item_y[2 * g] = (int)(int16_t)((uint32_t)it.y01 & 0xffffu); c.item_y[2 * g + 1] = (int)it.y01 >> 16;
+    c.item_y[2 * g] = ymin; c.item_y[2 * g + 1] = ymax;
     c.rowoff[g] = it.rowoff;
   }
   for (int i = tid; i < n_pts; i += T) c.ivert[i] = (i == tid) ? p0 : pts[i];
@@ -590,7 +630,7 @@ RM_FN void rm_p2_assign(const RmArgs& a, const RmCtx& c, int base, int end, int 
 // p3: the edge that leaves every vertex, and the census of the rows it touches.  Written for the wavefront: table edges
 // (nine in ten) are built by every lane without a branch, the census is atomics whose operand is zero where a lane has
 // nothing to say (on a spare word), so that the only divergent code is the horizontal edges' run merging.
-template <int WORDS>
+template <int WORDS, bool COMPACT>
 RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, int tid, int T) {
   const int lo = s_lo > base ? s_lo : base;
   const int nlive = c.misc[0];
@@ -621,7 +661,7 @@ RM_FN void rm_p3(const RmArgs& a, const RmCtx& c, int base, int end, int s_lo, i
     if (RM_ANY(horiz)) {
       if (horiz) head = rm_build_edge(pv, k, nv, &E) == 2;
     }
-    if (live) c.edges[idx] = E;   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
+    if (live) RmEdgeTab<COMPACT>::put(c, idx, E, table, head);   // (a vertex without an edge keeps a zero record: y0 == y1, skipped by everyone)
     const uint32_t bit = 1u << (k & 31);
     RmRow* rr = c.rows + it.rowbase;
     const int emin = y0 < y1 ? y0 : y1, emax = y0 < y1 ? y1 : y0;
@@ -770,8 +810,9 @@ RM_FN void rm_p4b_lds(const RmCtx& c, int total_rows, int tid, int T) {
 }
 
 // p4: one thread per (item, row)
-template <int WORDS>
+template <int WORDS, bool COMPACT>
 RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T, float* xx_wave) {
+  typedef typename RmEdgeTab<COMPACT>::View EV;
   const int nseg = a.W >> 4;
   (void)total_rows;
   const int sorted_rows = c.misc[8] + c.misc[9] + c.misc[10] + c.misc[11];   // (the pass's rows but those of long polygons)
@@ -784,9 +825,9 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
     bool shallow = false;
     if (on) { rec = c.rows[w]; const int ri = c.rowitem[w]; g = ri & 255; shallow = (ri >> 8) != 0; it = c.info[g]; }
     const int y = w - it.rowbase;
-    const RmEdge* pe = c.edges + (it.pb_nv & 0xfffff);
+    const EV pe = RmEdgeTab<COMPACT>::view(c, it.pb_nv & 0xfffff, it.pb_nv >> 20);
     RmMask<WORDS> m;
-    const bool ok = rm_row_fast<WORDS>(pe, rec, y, it.pymax, a.W, shallow, m);
+    const bool ok = rm_row_fast<WORDS, EV>(pe, rec, y, it.pymax, a.W, shallow, m);
 #if !RM_DEV && defined(RM_STATS)
     if (on) {
       rm_stats[1] += ok ? 0 : 1;
@@ -802,10 +843,10 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
     while (gm) {   // the rare rows, one at a time (they share the wave's scratch list)
       const int l = __builtin_ctzll(gm);
       gm &= gm - 1ull;
-      if ((tid & 63) == l) m = rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
+      if ((tid & 63) == l) m = rm_row_generic<WORDS, EV>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
     }
 #else
-    if (on && !ok) m = rm_row_generic<WORDS>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
+    if (on && !ok) m = rm_row_generic<WORDS, EV>(pe, it.pb_nv >> 20, rec.heads, y, it.pymax, xx_wave);
 #endif
     if (on) {
       uint64_t* mp = reinterpret_cast<uint64_t*>(c.rows + w);
@@ -826,8 +867,8 @@ RM_FN void rm_p4(const RmArgs& a, const RmCtx& c, int total_rows, int tid, int T
 // notes it in a list of edge numbers of its own (32 bytes of LDS), with the four census words over the list's positions.  polygon_generic only ever looks at a
 // row's active edges and heads, in order, so the row routines of the short polygons run on the list unchanged (RmIndexed).
 // A row with more than RM_MAX_NV such edges (a comb) goes to rm_row_generic over the whole polygon.
-struct RmIndexed {
-  const RmEdge* pe; const uint8_t* idx;
+template <class EV> struct RmIndexed {
+  EV pe; const uint8_t* idx;
   RM_MEMBER RmEdge operator[](int k) const { return pe[idx[k]]; }
 };
 // what an edge record says about row y without any arithmetic: a crossing, a head on the row, a corner the fix-up looks at
@@ -845,8 +886,10 @@ RM_FN void rm_big_classify(const RmEdge& E, int y, int pymax, bool& cross, bool&
 }
 
 // idx_all: 32 bytes per thread of the frame (behind the waves' crossing lists)
-template <int WORDS>
+template <int WORDS, bool COMPACT>
 RM_FN void rm_p4_big(const RmArgs& a, const RmCtx& c, int tid, int T, float* xx_wave, uint8_t* idx_all) {
+  typedef typename RmEdgeTab<COMPACT>::View EV;
+  typedef RmIndexed<EV> IX;
   const int nseg = a.W >> 4;
   const int first = c.misc[8] + c.misc[9] + c.misc[10] + c.misc[11], nbig = c.misc[12];
   uint8_t* const idx = idx_all + 32 * tid;
@@ -857,7 +900,7 @@ RM_FN void rm_p4_big(const RmArgs& a, const RmCtx& c, int tid, int T, float* xx_
     int g = 0;
     if (on) { g = c.rowitem[w] & 255; it = c.info[g]; }
     const int y = w - it.rowbase, nv = on ? (it.pb_nv >> 20) : 0;
-    const RmEdge* pe = c.edges + (it.pb_nv & 0xfffff);
+    const EV pe = RmEdgeTab<COMPACT>::view(c, it.pb_nv & 0xfffff, it.pb_nv >> 20);
     RmRow rec = {0u, 0u, 0u, 0u};
     bool shallow = false;
     int n_rel = 0;
@@ -883,25 +926,25 @@ RM_FN void rm_p4_big(const RmArgs& a, const RmCtx& c, int tid, int T, float* xx_
         } while (RM_ANY(mq != 0u));
       }
     } else n_rel = n_all;
-    RmIndexed list; list.pe = pe; list.idx = idx;
+    IX list; list.pe = pe; list.idx = idx;
     RmMask<WORDS> m;
     rm_clear(m);
     const bool all = on && n_rel > RM_MAX_NV;
     if (all) { rec.act = 0u; rec.heads = 0u; rec.tipP = 0u; rec.tipN = 0u; }
-    const bool ok = rm_row_fast<WORDS, RmIndexed>(list, rec, y, it.pymax, a.W, shallow, m);
+    const bool ok = rm_row_fast<WORDS, IX>(list, rec, y, it.pymax, a.W, shallow, m);
 #if RM_DEV
     unsigned long long gm = __ballot(on && (all || !ok));
     while (gm) {   // the rare rows, one at a time (they share the wave's scratch list)
       const int l = __builtin_ctzll(gm);
       gm &= gm - 1ull;
       if ((tid & 63) == l) {
-        if (all) m = rm_row_generic<WORDS, const RmEdge*>(pe, nv, 0u, y, it.pymax, xx_wave);
-        else m = rm_row_generic<WORDS, RmIndexed>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
+        if (all) m = rm_row_generic<WORDS, EV>(pe, nv, 0u, y, it.pymax, xx_wave);
+        else m = rm_row_generic<WORDS, IX>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
       }
     }
 #else
-    if (on && all) m = rm_row_generic<WORDS, const RmEdge*>(pe, nv, 0u, y, it.pymax, xx_wave);
-    else if (on && !ok) m = rm_row_generic<WORDS, RmIndexed>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
+    if (on && all) m = rm_row_generic<WORDS, EV>(pe, nv, 0u, y, it.pymax, xx_wave);
+    else if (on && !ok) m = rm_row_generic<WORDS, IX>(list, n_rel, rec.heads, y, it.pymax, xx_wave);
 #if defined(RM_STATS)
     if (on) { rm_stats[1] += (all || !ok) ? 1 : 0; rm_stats[10] += 1; rm_stats[11] += all ? 1 : 0; }
 #endif

@@ -8,6 +8,16 @@
 
 #include "../../moog.github.io_amd/csrc/moog_raster_mask_core.h"
 
+// p3 .. p5 of one pass, thread by thread
+template <int WORDS, bool COMPACT>
+static void model_pass(const RmArgs& a, const RmCtx& c, int env, int base, int end, int total_rows, int s_lo, int T, int waves) {
+  for (int t = 0; t < T; ++t) rm_p3<WORDS, COMPACT>(a, c, base, end, s_lo, t, T);
+  { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
+  for (int t = 0; t < T; ++t) rm_p4<WORDS, COMPACT>(a, c, total_rows, t, T, c.xx + (t / 64) * a.plan.xx_stride);
+  if (a.big) for (int t = 0; t < T; ++t) rm_p4_big<WORDS, COMPACT>(a, c, t, T, c.xx + (t / 64) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + waves * a.plan.xx_stride));
+  for (int t = 0; t < T; ++t) rm_p5<WORDS>(a, c, env, base == 0, s_lo, t, T);
+}
+
 extern "C" {
 
 // One polygon of n integer canvas points on a W x H canvas -> cov[H][W] (0 / 1).  mode 0: the fast row routine with the
@@ -61,7 +71,7 @@ int rm_model_polygon(const int* xy, int n, int W, int H, uint8_t* cov, int mode,
 // records, and the frame's phases read those.  draw_out (or null): the draw records, [n_envs][*draw_stride] bytes.
 int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i32, int n_envs, uint8_t* image,
                     int threads, int cap_rows, int n_static, int nsv, const double* sref_f64, const int32_t* sref_i32,
-                    const uint8_t* sbg, const uint32_t* rgb_override, long long* stats) {
+                    const uint8_t* sbg, const uint32_t* rgb_override, long long* stats, int compact) {
   (void)nsv;
   moog_layout_t L;
   moog_layout(P, &L);
@@ -101,33 +111,30 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   em.out = draw.data();
   a.draw = draw.data(); a.lay = em.lay;
   const int T = threads, waves = T / 64;
-  rm_plan(a.S, L.TOTV * em.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan);
+  a.compact = compact;
+  rm_plan(a.S, L.TOTV * em.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan, compact);
   std::vector<unsigned char> lds(a.plan.total + 64);
   const RmCtx c = rm_ctx(a.plan, lds.data());
+  std::vector<int16_t> vslot((size_t)(L.TOTV > 0 ? L.TOTV : 1), 0);
+  for (int sl = 0; sl < P->n_slots; ++sl)
+    for (int k = 0; k < P->slot_vcap[sl]; ++k) vslot[P->slot_voff[sl] + k] = (int16_t)sl;
+  std::vector<long long> scratch((RM_EMIT_SCRATCH_WORDS(em.slots, em.S, em.ncopy) + 1) / 2);
   for (int env = 0; env < n_envs; ++env) {
     RmSrcRecord src;
-    src.P = P; src.L = &L; src.f = f64 + (size_t)env * L.f64_per_env; src.q = i32 + (size_t)env * L.i32_per_env;
-    rm_emit(em, src, env, -1);
+    src.P = P; src.L = &L; src.f = f64 + (size_t)env * L.f64_per_env; src.q = i32 + (size_t)env * L.i32_per_env; src.vs = vslot.data();
+    for (auto& w : scratch) w = (long long)0xA5A5A5A5A5A5A5A5ull;   // (whatever the LDS held)
+    RmEmitScratch sc;
+    rm_emit_scratch(reinterpret_cast<int32_t*>(scratch.data()), em.slots, em.ncopy, &sc);
+    rm_emit(em, src, env, -1, sc, L.TOTV);
     memset(lds.data(), 0xA5, lds.size());   // LDS is not zero when a workgroup starts
     for (int t = 0; t < T; ++t) rm_load(a, c, env, t, T);
     const int s_lo = rm_s_lo(a, c);
     for (int base = 0;;) {
       const int end = rm_pass_end(a, c, base);
       const int total_rows = c.rowoff[end] - c.rowoff[base];
-      for (int w = 0; w < waves; ++w) rm_p2_assign(a, c, base, end, s_lo, -1);
-      if (a.W > 64) {
-        for (int t = 0; t < T; ++t) rm_p3<2>(a, c, base, end, s_lo, t, T);
-        { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
-        for (int t = 0; t < T; ++t) rm_p4<2>(a, c, total_rows, t, T, c.xx + (t / 64) * a.plan.xx_stride);
-        if (a.big) for (int t = 0; t < T; ++t) rm_p4_big<2>(a, c, t, T, c.xx + (t / 64) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + waves * a.plan.xx_stride));
-        for (int t = 0; t < T; ++t) rm_p5<2>(a, c, env, base == 0, s_lo, t, T);
-      } else {
-        for (int t = 0; t < T; ++t) rm_p3<1>(a, c, base, end, s_lo, t, T);
-        { RmSortKey sk; for (int t = 0; t < T; ++t) rm_p4a(c, total_rows, t, T, sk); for (int t = 0; t < T; ++t) rm_p4b(c, total_rows, t, T, sk); }
-        for (int t = 0; t < T; ++t) rm_p4<1>(a, c, total_rows, t, T, c.xx + (t / 64) * a.plan.xx_stride);
-        if (a.big) for (int t = 0; t < T; ++t) rm_p4_big<1>(a, c, t, T, c.xx + (t / 64) * a.plan.xx_stride, reinterpret_cast<uint8_t*>(c.xx + waves * a.plan.xx_stride));
-        for (int t = 0; t < T; ++t) rm_p5<1>(a, c, env, base == 0, s_lo, t, T);
-      }
+      if (!c.misc[6]) for (int w = 0; w < waves; ++w) rm_p2_assign(a, c, base, end, s_lo, -1);
+      if (a.W > 64) { if (compact) model_pass<2, true>(a, c, env, base, end, total_rows, s_lo, T, waves); else model_pass<2, false>(a, c, env, base, end, total_rows, s_lo, T, waves); }
+      else { if (compact) model_pass<1, true>(a, c, env, base, end, total_rows, s_lo, T, waves); else model_pass<1, false>(a, c, env, base, end, total_rows, s_lo, T, waves); }
       if (stats) { stats[0] += total_rows; stats[2]++; for (int q = 1; q < 16; ++q) if (q != 2) { if (q == 9) { if (rm_stats[q] > stats[q]) stats[q] = rm_stats[q]; } else stats[q] += rm_stats[q]; rm_stats[q] = 0; } }
       if (end >= a.S) break;
       base = end;

@@ -1637,13 +1637,17 @@ def test_anti_aliasing_sweep(size, aa):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name,rows', [
-    ('colliding_predators_32', None), ('colliding_predators_32', 64), ('pong', None), ('colliding_predators', None),
-    ('falling_balls', 40), ('falling_balls_64', None), ('rules_zoo', 64), ('lambda_zoo', None), ('functional_maze', None),
-    ('functional_maze', 128), ('cleanup', None), ('match_to_sample_l3', None), ('predators_arena_l2', None),
-    ('parallelogram_catch', None), ('multi_tracking_with_feature_l1', None), ('chase_avoid_torus', None),
-    ('chase_avoid_torus', 64), ('aa_zoo', None)])
-def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
+@pytest.mark.parametrize('name,rows,compact', [
+    ('colliding_predators_32', None, None), ('colliding_predators_32', 64, None), ('pong', None, None), ('colliding_predators', None, None),
+    ('falling_balls', 40, None), ('falling_balls_64', None, None), ('rules_zoo', 64, None), ('lambda_zoo', None, None), ('functional_maze', None, None),
+    ('functional_maze', 128, None), ('cleanup', None, None), ('match_to_sample_l3', None, None), ('predators_arena_l2', None, None),
+    ('parallelogram_catch', None, None), ('multi_tracking_with_feature_l1', None, None), ('chase_avoid_torus', None, None),
+    ('chase_avoid_torus', 64, None), ('aa_zoo', None, None),
+    # the edge records in their 4-byte form (RmEdgesCompact: what the engine picks by itself when the 16-byte records keep frames
+    # off a CU -- falling_balls_64, first_person_predators_prey) and in their 16-byte form where it would pick the other
+    ('colliding_predators_32', None, 1), ('colliding_predators_32', 64, 1), ('falling_balls_64', None, 0), ('match_to_sample_l3', None, 1),
+    ('chase_avoid_torus', 64, 1), ('functional_maze', 128, 1), ('cleanup', None, 1), ('first_person_predators_prey', None, 0)])
+def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, compact, monkeypatch):
     """One-tile frames of polygons with <= 128 vertices are drawn by the mask rasteriser (csrc/moog_raster_mask_core.h: no
     crossing lists, census by bit mask); MOOG_RASTER_MASK=0 selects the push / sort / span kernel for every frame.  Both
     must give the same frames, bit for bit -- frames that come with a step, frames of uploaded state, frames after resets
@@ -1655,6 +1659,8 @@ def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, monkeypatch):
     monkeypatch.setenv('MOOG_RASTER_MASK', '1')
     if rows is not None:
         monkeypatch.setenv('MOOG_RASTER_ROWS', str(rows))
+    if compact is not None:
+        monkeypatch.setenv('MOOG_RASTER_COMPACT', str(compact))
     env = make_env(name, n, seed=31, env_index0=17)
     if env.raster_path() != 'mask':
         pytest.skip('the program keeps the span kernel (multi-tile frames)')
@@ -1990,3 +1996,30 @@ def test_fit_layer_capacity_is_result_neutral():
                 assert p['x'] == q['x'] and p['y'] == q['y'] and np.array_equal(p['vertices'], q['vertices'])
     big.close()
     fit.close()
+
+
+def test_auto_capacity_fits_by_itself():
+    """layer_capacity={'auto': True, ...}: the layers are fitted to the batch's high-water marks after `fit_after` calls without
+    anybody asking (a smaller record from then on), keep growing on demand, and nothing observable changes: time steps and
+    frames equal those of the engine with fixed roomy layers."""
+    import torch
+    from moog import environment
+    from moog_demos import example_configs
+    name, n = 'first_person_predators_prey', 128
+    cfg = example_configs.load(name)
+    big = environment.BatchedEnvironment(num_envs=n, seed=7, layer_capacity={'prey': 32, 'predators': 96}, **cfg)
+    auto = environment.BatchedEnvironment(num_envs=n, seed=7, layer_capacity={'auto': True, 'fit_after': 25, 'prey': 32, 'predators': 96}, **cfg)
+    big.reset()
+    auto.reset()
+    before = auto.layout.f64_per_env
+    g = torch.Generator(device='cpu').manual_seed(4)
+    for k in range(60):
+        a = torch.rand((n, 2), generator=g, dtype=torch.float64) * 2 - 1
+        x, y = big.step(a), auto.step(a)
+        assert torch.equal(x.step_type, y.step_type), k
+        assert torch.equal(x.observation['image'], y.observation['image']), 'frames differ at call %d' % k
+        assert (auto.layout.f64_per_env < before) == (k >= 24), (k, auto.layout.f64_per_env, before)
+    assert auto.capacity_growths, 'the automatic fit did not happen'
+    assert all(u['dropped'] == 0 for u in auto.layer_usage().values())
+    big.close()
+    auto.close()

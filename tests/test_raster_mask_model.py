@@ -117,7 +117,7 @@ def test_model_vs_oracle_fuzz(model, seed):
     assert st[1] < 0.01 * st[0], ('rows sent to the generic routine', int(st[1]), int(st[0]))
 
 
-def model_frames(m, c, f64, i32, cap_rows, static=None, threads=128):
+def model_frames(m, c, f64, i32, cap_rows, static=None, threads=128, compact=0):
     P = c.program
     n = f64.shape[0]
     W, H = (P.render.width + 15) & ~15, P.render.height
@@ -128,7 +128,7 @@ def model_frames(m, c, f64, i32, cap_rows, static=None, threads=128):
     rc = m.rm_model_frames(ctypes.byref(P), f64.ctypes.data_as(dp), i32.ctypes.data_as(ip), n, img.ctypes.data_as(bp), threads,
                            cap_rows, ns, nsv, None if sf is None else sf.ctypes.data_as(dp),
                            None if sq is None else sq.ctypes.data_as(ip), None if sbg is None else sbg.ctypes.data_as(bp),
-                           None, st.ctypes.data_as(_P(ctypes.c_longlong)))
+                           None, st.ctypes.data_as(_P(ctypes.c_longlong)), compact)
     assert rc == 0, rc
     return img[:, :, :P.render.width], st
 
@@ -157,6 +157,9 @@ def test_model_frames_vs_oracle(model, name, cap_rows):
         passes += int(st[2])
         bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
         assert bad.size == 0, ('frames differ at step %d' % k, bad[:8].tolist())
+        img, st = model_frames(model, c, o.f64, o.i32, cap_rows, compact=1)   # 4-byte edge records (RmEdgesCompact)
+        bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+        assert bad.size == 0, ('frames differ at step %d with compact edge records' % k, bad[:8].tolist())
     if cap_rows < 192 and name not in ('chase_avoid_torus', 'parallelogram_catch'):
         assert passes > 4 * n, 'the capped records were meant to force several passes per frame'
 
@@ -286,3 +289,6 @@ def test_model_long_polygons(model):
     img, st = model_frames(model, c, o.f64, o.i32, 64)
     bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
     assert bad.size == 0, ('frames differ (capped rows)', bad[:8].tolist(), int(bad.size))
+    img, st = model_frames(model, c, o.f64, o.i32, 192, compact=1)
+    bad = np.nonzero((img != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, ('frames differ (compact edge records)', bad[:8].tolist(), int(bad.size))

@@ -10,7 +10,7 @@ from moog_demos import example_configs
 BENCH_CAPACITY = {'first_person_predators_prey': {'prey': 32, 'predators': 96}, 'rules_zoo_l1': {'prey': 24, 'predators': 24}}
 
 def config_of(name, kw):
-    kw = {k: v for k, v in kw.items() if k not in ('steps', 'capacity', 'fit')}
+    kw = {k: v for k, v in kw.items() if k not in ('steps', 'capacity', 'fit', 'warm')}
     return example_configs.load(name) if not kw else __import__('moog_demos.example_configs.' + name, fromlist=['x']).get_config(0, **kw)
 
 
@@ -30,8 +30,9 @@ def run(name, n, steps=30, observers=True, **kw):
             env.step(env.random_action())
         print('    fit_layer_capacity:', env.fit_layer_capacity(), flush=True)
         env.check_faults = False
-    for _ in range(5):
+    for _ in range(int(kw.get('warm', 5))):
         env.step(env.random_action())
+    env.check_faults = False
     env.set_timing(True)
     for k in range(3): env.kernel_time(k)
     torch.cuda.synchronize(); t = time.perf_counter()
@@ -58,6 +59,8 @@ CASES = [
     # (the same with the layers sized to their high-water marks -- 26 prey, 41 predators at 4096 envs: the record shrinks from 85 to
     #  55 KB and two envs share a CU's LDS instead of one)
     ('first_person_predators_prey', 4096, dict(steps=60, capacity={'prey': 32, 'predators': 48})),
+    # (and as a user gets it by default: layer_capacity 'auto' fits the layers by itself after 128 calls and grows them on demand)
+    ('first_person_predators_prey', 4096, dict(steps=60, warm=140, capacity={'auto': True, 'prey': 32, 'predators': 96})),
     # (fit=<calls>: the same sized by the engine itself after a warm-up, BatchedEnvironment.fit_layer_capacity(); not in the table: with a
     #  random policy this config's prey pile up, the layers keep growing and a 60-call window mostly times engine re-creations)
     ('lambda_zoo', 4096, dict()),
