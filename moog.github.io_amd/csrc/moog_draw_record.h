@@ -159,15 +159,15 @@ RM_FN void rm_wave_sync() {
 }
 // a loop over i = 0 .. n-1 shared out to the lanes of a wavefront (host model: lane < 0, one call does every lane's work)
 #if RM_DEV
-#define RM_LANES(i, n, lane) for (int i = (lane); i < (n); i += 64)
+#define RM_LANES(i, n, lane) _Pragma("unroll 1") for (int i = (lane); i < (n); i += 64)
 #else
 #define RM_LANES(i, n, lane) for (int i = 0; i < (n); ++i)
 #endif
 
 // ---- the emitter ------------------------------------------------------------------------------------------------------------
 // One wavefront per env.  SRC says where the env's record lies (HBM, or the step kernel's LDS copy with the colours in HBM):
-//   int flags(s), nv(s), opa(s), voff(s), vcap(s), vslot(idx);  double col(s, c);  const double* vbase()  (x, y of vertex slot 0),
-//   const double* pos(s)
+//   int flags(s), nv(s), opa(s), voff(s), vcap(s);  uint32_t vinfo(idx)  (vertex slot -> sprite slot | index within the sprite << 8);
+//   double col(s, c);  const double* vbase()  (x, y of vertex slot 0);  const double* pos(s)
 // Lanes are sprites where the work is per sprite (liveness, colour, item records) and VERTEX SLOTS where it is per vertex
 // (the integer points, their bounds): every vertex slot of the record is looked at once, 64 at a time, its loads coalesced.
 // `sc` is scratch in LDS: 2 words per sprite slot, 4 per item (RM_EMIT_SCRATCH_WORDS).
@@ -232,10 +232,11 @@ RM_FN bool rm_emit_prefix_slot_differs(const RmEmit& a, const SRC& src, int s) {
 }
 template <class SRC>
 RM_FN bool rm_emit_prefix_vertex_differs(const RmEmit& a, const SRC& src, int idx) {
-  const int s = src.vslot(idx);
+  const uint32_t vi = src.vinfo(idx);
+  const int s = (int)(vi & 0xffu), k = (int)(vi >> 8);
   const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
   const double rx = a.sref_v[2 * idx], ry = a.sref_v[2 * idx + 1];
-  const bool live = (src.flags(s) & MOOG_F_ALIVE) != 0 && idx - src.voff(s) < rm_emit_nvl(src.nv(s), src.vcap(s));
+  const bool live = (src.flags(s) & MOOG_F_ALIVE) != 0 && k < rm_emit_nvl(src.nv(s), src.vcap(s));
   uint64_t b0, b1, q0, q1;
   memcpy(&b0, &x, 8); memcpy(&b1, &y, 8); memcpy(&q0, &rx, 8); memcpy(&q1, &ry, 8);
   return live & ((b0 != q0) | (b1 != q1));
@@ -247,7 +248,6 @@ RM_FN int rm_rows_on_canvas(int y0, int y1, int H) {
   return y1 >= y0 ? y1 - y0 + 1 : 0;
 }
 
-#define RM_EMIT_PF 8   // rounds of vertex slots whose slot numbers a lane fetches ahead (device)
 template <class SRC>
 RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmEmitScratch& sc, int totv) {
   uint8_t* const rec = a.out + (size_t)env * a.lay.stride;
@@ -255,13 +255,9 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   uint32_t* const pts = reinterpret_cast<uint32_t*>(rec + a.lay.o_pts);
   uint8_t* const owner = rec + a.lay.o_owner;
   const bool copies = a.ncopy > 1;
-#if RM_DEV
-  // Everything this wavefront reads from global memory without knowing anything yet goes out first, in one go: the emitter sits
-  // on the step kernel's critical path, and a load it waits for costs as much as a hundred instructions.  vertex slot -> sprite slot:
-  int vsl[RM_EMIT_PF];
-#pragma unroll
-  for (int r = 0; r < RM_EMIT_PF; ++r) vsl[r] = (lane + 64 * r < totv) ? src.vslot(lane + 64 * r) : 0;
-#endif
+  // (Code size matters here as much as instruction count: in the step kernel this runs once per env, at the very end, behind
+  //  a quarter of a megabyte of hotter code -- every 64-byte line of it is an instruction-cache miss.  The loops over the
+  //  vertex slots are kept rolled (one copy of their body), with the next round's slot number fetched a round ahead.)
   // first-person frames: everything is translated so that the agent layer's first sprite sits at (0.5, 0.5)
   double fpx = 0.0, fpy = 0.0;
   if (a.first_person) {
@@ -336,8 +332,8 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   // but x -> (int)(W * (x + o)) is monotone, so a copy's integer bounds are those of the sprite's smallest and largest
   // coordinates: four 64-bit atomics per vertex on order-preserving keys.  A vertex with a coordinate that is not an ordinary number
   // (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN, which is not monotone) leaves its nine points' y behind instead.
-  auto vertex_b = [&](int idx, int s) {
-    const int k = idx - src.voff(s);
+  auto vertex_b = [&](int idx, uint32_t vi) {
+    const int s = (int)(vi & 0xffu), k = (int)(vi >> 8);
     const int nvl = sc.slot[2 * s] & 0xffff;
     if (k >= nvl) return;
     const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
@@ -366,11 +362,17 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
     }
   };
 #if RM_DEV
-#pragma unroll
-  for (int r = 0; r < RM_EMIT_PF; ++r) if (lane + 64 * r < totv) vertex_b(lane + 64 * r, vsl[r]);
-  for (int idx = lane + 64 * RM_EMIT_PF; idx < totv; idx += 64) vertex_b(idx, src.vslot(idx));
+  {
+    uint32_t v_next = lane < totv ? src.vinfo(lane) : 0u;
+#pragma unroll 1
+    for (int idx = lane; idx < totv; idx += 64) {
+      const uint32_t v_now = v_next;
+      if (idx + 64 < totv) v_next = src.vinfo(idx + 64);
+      vertex_b(idx, v_now);
+    }
+  }
 #else
-  for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vslot(idx));
+  for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vinfo(idx));
 #endif
   rm_wave_sync();
   // C: per item
@@ -434,8 +436,8 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   }
   if (copies) {   // D: the visible copies' points
     rm_wave_sync();
-    auto vertex_d = [&](int idx, int s) {
-      const int k = idx - src.voff(s);
+    auto vertex_d = [&](int idx, uint32_t vi) {
+      const int s = (int)(vi & 0xffu), k = (int)(vi >> 8);
       if (k >= (sc.slot[2 * s] & 0xffff)) return;
       const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
       for (int cp = 0; cp < a.ncopy; ++cp) {
@@ -448,11 +450,15 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
       }
     };
 #if RM_DEV
-#pragma unroll
-    for (int r = 0; r < RM_EMIT_PF; ++r) if (lane + 64 * r < totv) vertex_d(lane + 64 * r, vsl[r]);
-    for (int idx = lane + 64 * RM_EMIT_PF; idx < totv; idx += 64) vertex_d(idx, src.vslot(idx));
+    uint32_t v_next = lane < totv ? src.vinfo(lane) : 0u;
+#pragma unroll 1
+    for (int idx = lane; idx < totv; idx += 64) {
+      const uint32_t v_now = v_next;
+      if (idx + 64 < totv) v_next = src.vinfo(idx + 64);
+      vertex_d(idx, v_now);
+    }
 #else
-    for (int idx = 0; idx < totv; ++idx) vertex_d(idx, src.vslot(idx));
+    for (int idx = 0; idx < totv; ++idx) vertex_d(idx, src.vinfo(idx));
 #endif
   }
 #if RM_DEV
@@ -467,14 +473,14 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
 
 // The record in HBM as the ABI lays it out (the derive kernel, the host model)
 struct RmSrcRecord {
-  const moog_program_t* P; const moog_layout_t* L; const double* f; const int32_t* q; const int16_t* vs;   // vs: vertex slot -> sprite slot
+  const moog_program_t* P; const moog_layout_t* L; const double* f; const int32_t* q; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8
   RM_MEMBER int flags(int s) const { return q[L->o_flags + s]; }
   RM_MEMBER int nv(int s) const { return q[L->o_nverts + s]; }
   RM_MEMBER int opa(int s) const { return q[L->o_opacity + s]; }
   RM_MEMBER int voff(int s) const { return P->slot_voff[s]; }
   RM_MEMBER int vcap(int s) const { return P->slot_vcap[s]; }
   RM_MEMBER double col(int s, int c) const { return f[L->o_color + 3 * s + c]; }
-  RM_MEMBER int vslot(int idx) const { return vs[idx]; }
+  RM_MEMBER uint32_t vinfo(int idx) const { return vi[idx]; }
   RM_MEMBER const double* vbase() const { return f + L->o_verts; }
   RM_MEMBER const double* pos(int s) const { return f + L->o_pos + 2 * s; }
 };

@@ -891,6 +891,7 @@ static KArgs make_args(moog_engine* e, const void* actions, const moog_inject_t*
   for (int k = 0; k < 3; ++k) a.prio_t[k] = (int32_t)(((int64_t)e->prio_pm[k] * e->n_envs + 999) / 1000);
   a.rank0 = 0;
   memset(&a.draw, 0, sizeof a.draw);   // (moog_engine_step turns the draw records on)
+  a.draw_vinfo = e->d_vinfo;
   return a;
 }
 
@@ -956,7 +957,7 @@ static RArgs raster_args(moog_engine* e, uint8_t* image) {
   r.sref_opa = e->s_i32 ? e->s_i32 + e->L.o_opacity : nullptr;
   r.sbg = e->s_bg;
   r.sbg_env_stride = 0; r.env_build = nullptr; r.rgb_override = e->rgb_override;
-  r.em = emit_args(e); r.vslot = e->d_vslot; r.draw_ready = 0; r.env0 = 0;
+  r.em = emit_args(e); r.draw_ready = 0; r.env0 = 0;
   {   // (one resident round: the frames a CU holds at once by LDS and registers, or fewer when asked)
     const int fit = mask_frames_per_cu(r.ms.lds);
     r.ms.persist_slots = e->raster_persist > 0 ? e->n_cus * (e->raster_persist < fit ? e->raster_persist : fit) : 0;

@@ -176,6 +176,7 @@ struct KArgs {
   const double* live_f64;    // MODE_FILL: the live records (a.f64 / a.i32 are pool_f64[1] / pool_i32[1] then)
   const int32_t* live_i32;
   int32_t rank0;         // launch rank of workgroup 0 (0; a launch split by rank was measured in round 5, profiles/r05_step_experiments.txt)
+  const uint32_t* draw_vinfo;   // vertex slot -> sprite slot | index within the sprite << 8 (the emitter's)
   RmEmit draw;           // draw.out != null: a step (MODE_STEP) also writes the env's draw record (moog_draw_record.h) for the raster launch behind it
   int32_t prio_t[3];     // wave priorities by launch rank (with `perm`: descending cost of the previous step): workgroups
                          // [0, t0) issue at priority 3, [t0, t1) at 2, [t1, t2) at 1, the rest at 0; all zero: off
@@ -231,14 +232,14 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
 
 // The env's record as the step kernel holds it (LDS; colours and opacities where bind_env says) for the draw-record emitter
 struct RmSrcEnv {
-  const Env* e;
+  const Env* e; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8 (KArgs::draw_vinfo)
   __device__ __forceinline__ int flags(int s) const { return e->q[e->L.o_flags + s]; }
   __device__ __forceinline__ int nv(int s) const { return e->q[e->L.o_nverts + s]; }
   __device__ __forceinline__ int opa(int s) const { return static_cast<const int32_t*>(e->gopa)[s]; }
   __device__ __forceinline__ int voff(int s) const { return e->voff[s]; }
   __device__ __forceinline__ int vcap(int s) const { return e->P->slot_vcap[s]; }
   __device__ __forceinline__ double col(int s, int c) const { return static_cast<const double*>(e->gcol)[3 * s + c]; }
-  __device__ __forceinline__ int vslot(int idx) const { return e->vslot[idx]; }
+  __device__ __forceinline__ uint32_t vinfo(int idx) const { return vi[idx]; }
   __device__ __forceinline__ const double* vbase() const { return &e->f[e->L.o_verts]; }
   __device__ __forceinline__ const double* pos(int s) const { return &e->f[e->L.o_pos + 2 * s]; }
 };
@@ -246,15 +247,17 @@ struct RmSrcEnv {
 // to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
 __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, int env) {
   if (!a.draw.out) return;
+  const long long t_emit = (a.dbg & 256) ? clock64() : 0;   // (profiling aid: the emitter's cycles instead of the step type, tools/emit_cycles.py)
   wsync();
   RmSrcEnv src;
-  src.e = &e;
+  src.e = &e; src.vi = a.draw_vinfo;
   // scratch: one copy per sprite -- six words per slot -- in the bounding volumes (eight per slot; nothing reads them after the
   // last sub-step); the nine copies of a torus -- 46 words per slot -- in the candidate list / list / row mask area behind the
   // vertex offsets (CAND_CAP * 2 + 128 + 64 * 8 bytes: the engine checks that they fit, step_emits_draw)
   RmEmitScratch sc;
   rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(e.cand) : reinterpret_cast<int32_t*>(e.bb), a.draw.slots, a.draw.ncopy, &sc);
   rm_emit(a.draw, src, env, e.lane, sc, e.L.TOTV);
+  if ((a.dbg & 256) && e.lane == 0 && a.step_type) a.step_type[env] = (int32_t)(clock64() - t_emit);
 }
 
 // =====================================================================================

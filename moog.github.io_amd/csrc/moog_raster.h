@@ -65,7 +65,6 @@ struct RArgs {
   // records (moog_engine_step); else moog_raster_launch derives them from f64 / i32 first.  env0: the engine's index of env 0
   // of this launch (launches over a chunk of the envs).
   RmEmit em;
-  const int16_t* vslot;   // vertex slot -> sprite slot (the emitter's)
   int32_t draw_ready, env0;
   int32_t* rows_seen;     // (mask rasteriser) host-mapped word for frames that want more row records, or null
   const moog_program_t* P;

@@ -35,7 +35,7 @@ void moog_raster_launch(const RArgs& a, size_t lds_bytes, hipStream_t stream) {
   if (a.ms.ok && !a.build && a.sbg_env_stride == 0 && !a.env_build) {
     if (!a.draw_ready) {   // records the engine did not step itself: the emitter on the records in HBM
       RmDeriveArgs d;
-      d.em = a.em; d.P = a.P; d.L = a.L; d.f64 = a.f64; d.i32 = a.i32; d.vslot = a.vslot; d.n_envs = a.n_envs; d.env0 = a.env0;
+      d.em = a.em; d.P = a.P; d.L = a.L; d.f64 = a.f64; d.i32 = a.i32; d.vinfo = a.vinfo; d.n_envs = a.n_envs; d.env0 = a.env0;
       moog_draw_derive_launch(d, stream);
     }
     moog_raster_mask_launch(mask_args(a), a.ms.lds, stream, a.ms.persist_slots);

@@ -81,12 +81,12 @@ __global__ __launch_bounds__(RM_THREADS, RM_WAVES_PER_SIMD) void moog_raster_mas
 
 // The draw records of frames the engine did not step itself (moog_engine_render after load_state or an edit of the state
 // tensors, resets, programs whose step kernels do not emit): one wavefront per env runs the emitter on the record in HBM.
-struct RmDeriveArgs { RmEmit em; const moog_program_t* P; moog_layout_t L; const double* f64; const int32_t* i32; const int16_t* vslot; int32_t n_envs; int32_t env0; };
+struct RmDeriveArgs { RmEmit em; const moog_program_t* P; moog_layout_t L; const double* f64; const int32_t* i32; const uint32_t* vinfo; int32_t n_envs; int32_t env0; };
 __global__ __launch_bounds__(64) void moog_draw_derive_kernel(RmDeriveArgs d) {
   const int env = (int)blockIdx.x;
   if (env >= d.n_envs) return;
   RmSrcRecord src;
-  src.P = d.P; src.L = &d.L; src.f = d.f64 + (size_t)env * d.L.f64_per_env; src.q = d.i32 + (size_t)env * d.L.i32_per_env; src.vs = d.vslot;
+  src.P = d.P; src.L = &d.L; src.f = d.f64 + (size_t)env * d.L.f64_per_env; src.q = d.i32 + (size_t)env * d.L.i32_per_env; src.vi = d.vinfo;
   RmEmit em = d.em;
   if (em.rgb_override) em.rgb_override += (size_t)d.env0 * em.slots;   // (the override array is indexed by the engine's env; a chunk of envs starts at env0)
   RmEmitScratch sc;

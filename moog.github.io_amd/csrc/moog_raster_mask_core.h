@@ -31,6 +31,9 @@
 #define MOOG_RASTER_MASK_CORE_H_
 #include "moog_draw_record.h"   // the frame's input: integer points, colours, row ranges (written by the step / reset / derive kernels)
 
+#ifndef RM_LOAD_ASSIGN
+#define RM_LOAD_ASSIGN 1      // 0: rm_p2_assign for every pass (A/B builds)
+#endif
 #ifndef RM_THREADS
 #define RM_THREADS 128        // threads per frame (256 and 64 were measured: slower, profiles/r05_raster.txt)
 #endif
@@ -545,7 +548,7 @@ RM_FN void rm_load(const RmArgs& a, const RmCtx& c, int env, int tid, int T) {
   // A frame whose rows all fit in the row records (total_rows <= cap_rows: the usual case) is ONE pass over every item, and what
   // rm_p2_assign would do for that pass -- the item's first row record, its clamped ymax, the owner of its rows -- follows from
   // the item's own record: done below, by the thread that loaded it (the kernel then skips rm_p2_assign for the first pass).
-  const bool single = hdr.total_rows <= a.cap_rows;
+  const bool single = RM_LOAD_ASSIGN && hdr.total_rows <= a.cap_rows;
   for (int i = tid; i < a.cap_rows; i += T) { RmRow z = {0u, 0u, 0u, 0u}; c.rows[i] = z; }
   // (the rows' flag bytes: a single-pass frame's are written with the owner bytes, 16 bits at a time, by the items' threads --
   //  clearing them here, from other threads, could land on top of that)

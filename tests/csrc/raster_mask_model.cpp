@@ -115,13 +115,13 @@ int rm_model_frames(const moog_program_t* P, const double* f64, const int32_t* i
   rm_plan(a.S, L.TOTV * em.ncopy, a.W, a.H, a.cap_rows, a.iwords, waves, a.big, &a.plan, compact);
   std::vector<unsigned char> lds(a.plan.total + 64);
   const RmCtx c = rm_ctx(a.plan, lds.data());
-  std::vector<int16_t> vslot((size_t)(L.TOTV > 0 ? L.TOTV : 1), 0);
+  std::vector<uint32_t> vinfo((size_t)(L.TOTV > 0 ? L.TOTV : 1), 0u);
   for (int sl = 0; sl < P->n_slots; ++sl)
-    for (int k = 0; k < P->slot_vcap[sl]; ++k) vslot[P->slot_voff[sl] + k] = (int16_t)sl;
+    for (int k = 0; k < P->slot_vcap[sl]; ++k) vinfo[P->slot_voff[sl] + k] = (uint32_t)sl | ((uint32_t)k << 8);
   std::vector<long long> scratch((RM_EMIT_SCRATCH_WORDS(em.slots, em.S, em.ncopy) + 1) / 2);
   for (int env = 0; env < n_envs; ++env) {
     RmSrcRecord src;
-    src.P = P; src.L = &L; src.f = f64 + (size_t)env * L.f64_per_env; src.q = i32 + (size_t)env * L.i32_per_env; src.vs = vslot.data();
+    src.P = P; src.L = &L; src.f = f64 + (size_t)env * L.f64_per_env; src.q = i32 + (size_t)env * L.i32_per_env; src.vi = vinfo.data();
     for (auto& w : scratch) w = (long long)0xA5A5A5A5A5A5A5A5ull;   // (whatever the LDS held)
     RmEmitScratch sc;
     rm_emit_scratch(reinterpret_cast<int32_t*>(scratch.data()), em.slots, em.ncopy, &sc);
