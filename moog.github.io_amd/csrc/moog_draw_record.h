@@ -249,7 +249,13 @@ RM_FN int rm_rows_on_canvas(int y0, int y1, int H) {
 }
 
 template <class SRC>
-RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmEmitScratch& sc, int totv) {
+RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmEmitScratch& sc, int totv, long long* clk = nullptr) {
+#if RM_DEV
+#define RM_CLK(i) do { if (clk) clk[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define RM_CLK(i) do { (void)clk; } while (0)
+#endif
+  RM_CLK(0);
   uint8_t* const rec = a.out + (size_t)env * a.lay.stride;
   RmDrawItem* const items = reinterpret_cast<RmDrawItem*>(rec + a.lay.o_items);
   uint32_t* const pts = reinterpret_cast<uint32_t*>(rec + a.lay.o_pts);
@@ -272,6 +278,7 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
     const int nsv = src.voff(NS - 1) + src.vcap(NS - 1);   // (the prefix's vertex slots are the first of the record)
     RM_LANES(idx, nsv, lane) bad = bad | rm_emit_prefix_vertex_differs(a, src, idx);
   }
+  RM_CLK(1);
   // A, first half: the slots' colours (in HBM for the step kernel: loaded before the vote on the prefix is waited for)
   int run_pts = 0;
 #if RM_DEV
@@ -327,6 +334,7 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
     }
   }
   rm_wave_sync();
+  RM_CLK(2);
   // B: per vertex slot.  One copy per sprite: the point, stored where the item's points go, and the item's y range.  Copies:
   // Pillow truncates the scaled coordinates towards zero, so a copy's integer points are not the sprite's shifted by a canvas --
   // but x -> (int)(W * (x + o)) is monotone, so a copy's integer bounds are those of the sprite's smallest and largest
@@ -375,6 +383,7 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vinfo(idx));
 #endif
   rm_wave_sync();
+  RM_CLK(3);
   // C: per item
   int run_rows = 0;
 #if RM_DEV
@@ -461,6 +470,7 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
     for (int idx = 0; idx < totv; ++idx) vertex_d(idx, src.vinfo(idx));
 #endif
   }
+  RM_CLK(4);
 #if RM_DEV
   if (lane == 0)
 #endif

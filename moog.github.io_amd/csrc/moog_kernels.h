@@ -256,8 +256,13 @@ __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, i
   // vertex offsets (CAND_CAP * 2 + 128 + 64 * 8 bytes: the engine checks that they fit, step_emits_draw)
   RmEmitScratch sc;
   rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(e.cand) : reinterpret_cast<int32_t*>(e.bb), a.draw.slots, a.draw.ncopy, &sc);
-  rm_emit(a.draw, src, env, e.lane, sc, e.L.TOTV);
-  if ((a.dbg & 256) && e.lane == 0 && a.step_type) a.step_type[env] = (int32_t)(clock64() - t_emit);
+  long long clk[5];
+  rm_emit(a.draw, src, env, e.lane, sc, e.L.TOTV, (a.dbg & 256) ? clk : nullptr);
+  if ((a.dbg & 256) && e.lane == 0 && a.step_type) {   // (the emitter's cycles, and phase by phase: prefix | slots | vertex slots | items)
+    a.step_type[env] = (int32_t)(clock64() - t_emit);
+    if (a.discount) a.discount[env] = (double)(clk[1] - clk[0]) + 65536.0 * (double)(clk[2] - clk[1]);
+    if (a.reward) a.reward[env] = (double)(clk[3] - clk[2]) + 65536.0 * (double)(clk[4] - clk[3]);
+  }
 }
 
 // =====================================================================================

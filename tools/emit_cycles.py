@@ -14,16 +14,18 @@ env.enable_cost_schedule()
 env.reset()
 for _ in range(30):
     env.step(env.random_action())
-env.set_debug(step_debug=128 | 256)
+env.set_debug(step_debug=256)
 emit, total = [], []
 for _ in range(10):
     ts = env.step(env.random_action())
     torch.cuda.synchronize()
     emit.append(env.step_type.cpu().numpy().astype(np.float64))
-    total.append(env.discount.cpu().numpy().copy())
+    d, r = env.discount.cpu().numpy(), env.reward.cpu().numpy()
+    total.append(np.stack([np.mod(d, 65536.0), np.floor(d / 65536.0), np.mod(r, 65536.0), np.floor(r / 65536.0)]))
 env.set_debug(step_debug=0)
-emit, total = np.stack(emit), np.stack(total)
-print('%s, %d envs, step kernel %s: emitter cycles per env-step  mean %.0f  p50 %.0f  p99 %.0f  max %.0f   |  whole step  mean %.0f  p50 %.0f  max %.0f' % (
-    name, n, env.step_kernel(), emit.mean(), np.percentile(emit, 50), np.percentile(emit, 99), emit.max(), total.mean(), np.percentile(total, 50), total.max()))
-heavy = total.argmax(axis=1)
-print('the slowest env of each call: its emitter cycles', [int(emit[k, heavy[k]]) for k in range(len(heavy))], 'of', [int(total[k, heavy[k]]) for k in range(len(heavy))])
+emit, ph = np.stack(emit), np.stack(total)
+ok = np.isfinite(ph).all(axis=1)
+print('%s, %d envs, step kernel %s: emitter cycles per env-step  mean %.0f  p50 %.0f  p99 %.0f  max %.0f' % (
+    name, n, env.step_kernel(), emit.mean(), np.percentile(emit, 50), np.percentile(emit, 99), emit.max()))
+print('   by phase (mean cycles; shader clock):  prefix check %.0f | slots: colours, liveness, scan %.0f | vertex slots: points, bounds %.0f | items: rows, records %.0f' % tuple(
+    float(np.nanmean(np.where(ok, ph[:, k], np.nan))) for k in range(4)))
