@@ -68,8 +68,8 @@ def raster_kernel_name(env):
     if part.raster_path() == 'mask':
         P = part.compiled.program
         big = any(P.slot_vcap[s] > 32 for s in range(P.n_slots))   # (the instantiation with the long-polygon row routine)
-        torus = P.render.polymod == 1   # MOOG_POLYMOD_TORUS
-        return 'moog_raster_mask_kernel<%d, %s, %s> (csrc/moog_raster_mask_core.h)' % (words, 'true' if big else 'false', 'true' if torus else 'false')
+        compact = part.raster_compact_edges()                      # (4-byte edge records: programs whose 16-byte ones keep frames off a CU)
+        return 'moog_raster_mask_kernel<%d, %s, %s> (csrc/moog_raster_mask_core.h)' % (words, 'true' if big else 'false', 'true' if compact else 'false')
     return 'moog_raster_kernel<%d> (csrc/moog_raster_kernel.h)' % words
 
 

@@ -839,7 +839,7 @@ int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised);
  * vertices, slots x copies <= 256, tables within 64 KB of LDS; plain, first-person and torus frames),
  * MOOG_RASTER_SPANS = the push / sort / span kernel (csrc/moog_raster_kernel.h: everything else, every prefix picture, and
  * every frame while a per-env prefix is active). */
-enum { MOOG_RASTER_SPANS = 0, MOOG_RASTER_MASK = 1 };
+enum { MOOG_RASTER_SPANS = 0, MOOG_RASTER_MASK = 1, MOOG_RASTER_MASK_COMPACT = 3 };   /* 3: the mask rasteriser with 4-byte edge records (programs whose 16-byte records keep frames off a CU) */
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path);
 
 /* PILRenderer(color_to_rgb=<any callable>) (pil_renderer.py:72-76,108: the renderer calls it on every sprite's colour

@@ -371,11 +371,14 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   };
 #if RM_DEV
   {
-    uint32_t v_next = lane < totv ? src.vinfo(lane) : 0u;
+    // (the table entries come from global memory, ~700 cycles each, a round's work is ~250: three rounds are in flight)
+    uint32_t v0 = lane < totv ? src.vinfo(lane) : 0u, v1 = lane + 64 < totv ? src.vinfo(lane + 64) : 0u,
+             v2 = lane + 128 < totv ? src.vinfo(lane + 128) : 0u;
 #pragma unroll 1
     for (int idx = lane; idx < totv; idx += 64) {
-      const uint32_t v_now = v_next;
-      if (idx + 64 < totv) v_next = src.vinfo(idx + 64);
+      const uint32_t v_now = v0;
+      v0 = v1; v1 = v2;
+      if (idx + 192 < totv) v2 = src.vinfo(idx + 192);
       vertex_b(idx, v_now);
     }
   }

@@ -714,7 +714,10 @@ int moog_engine_create(const moog_program_t* prog, int32_t n_envs, int32_t devic
         const RmSetup full = ms;
         ms.compact = 1; ms.ok = 1;
         mask_plan_rows(e, cap);
-        const bool better = ms.ok && (!full.ok || mask_frames_per_cu(ms.lds) > mask_frames_per_cu(full.lds));
+        // (the 4-byte records cost the rows phase a tenth more instructions -- headline workload 49.5 -> 53 us when they were picked for
+        //  it by mistake -- so they are for programs whose 16-byte records leave a CU clearly short of the frames its registers allow)
+        const int by_regs = RM_WAVES_PER_SIMD * 4 / (RM_THREADS / 64);
+        const bool better = ms.ok && (!full.ok || ((int)(160u * 1024u / full.lds) < by_regs - 1 && mask_frames_per_cu(ms.lds) > mask_frames_per_cu(full.lds)));
         if (cs ? atoi(cs) == 0 : !better) ms = full;
       }
       e->mask_free_cap = (ms.ok && !e->raster_rows_fixed) ? mask_free_rows(e) : ms.cap_rows;
@@ -1259,7 +1262,7 @@ int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised) {
 
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path) {
   if (!e || !path) return fail(MOOG_E_INVALID, "null argument");
-  *path = (e->mask_setup.ok && e->pe_ns <= 0) ? MOOG_RASTER_MASK : MOOG_RASTER_SPANS;
+  *path = (e->mask_setup.ok && e->pe_ns <= 0) ? (e->mask_setup.compact ? MOOG_RASTER_MASK_COMPACT : MOOG_RASTER_MASK) : MOOG_RASTER_SPANS;
   return MOOG_OK;
 }
 

@@ -293,7 +293,14 @@ class BatchedEnvironment(object):
         (csrc/moog_raster_kernel.h) -- moog_engine_raster_path."""
         v = ctypes.c_int32()
         _engine.check(self._lib, self._lib.moog_engine_raster_path(self._handle, ctypes.byref(v)))
-        return 'mask' if v.value == _abi.MOOG_RASTER_MASK else 'spans'
+        return 'mask' if (v.value & 1) else 'spans'
+
+    def raster_compact_edges(self):
+        """Whether the mask rasteriser keeps this program's edge records in their 4-byte form (csrc/moog_raster_mask_core.h
+        RmEdgesCompact: picked when the 16-byte records would keep frames off a CU; MOOG_RASTER_COMPACT=0 / 1 forces)."""
+        v = ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_raster_path(self._handle, ctypes.byref(v)))
+        return v.value == 3
 
     # -- plumbing ---------------------------------------------------------------------
     def _stream(self):
