@@ -529,14 +529,16 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
 
 #if !MOOG_RESET_FULL   // (the sort kernel lives in the first of the two reset translation units)
 // Launch order for the next step: envs in (approximately) descending order of the cycles they
-// took in this step (longest-processing-time first).  One 1024-thread workgroup: 1024-bin
+// took in this step (longest-processing-time first).  One workgroup of SCHED_THREADS threads: 1024-bin
 // counting sort on cost / max(cost).  Runs on a side stream concurrently with the rasteriser.
 // The order inside a bin is arbitrary -- the schedule never changes a result.
-// Round 6 (33.6 us -> a handful): a thread keeps its envs' bins in registers (one pass over the costs
-// instead of three), the prefix sum over the bins is a DPP scan per wavefront + one over the sixteen wave totals (three
-// barriers instead of twenty-two), a cost that is not a finite number (a caller's uninitialised array) counts as zero.
+// Round 6: a thread keeps its envs' bins in registers (one pass over the costs instead of three), the prefix
+// sum over the bins is a DPP scan per wavefront + one over the wave totals (three barriers instead of twenty-two), a cost that
+// is not a finite number (a caller's uninitialised array) counts as zero, and the workgroup is four wavefronts instead of sixteen
+// (it runs beside the rasteriser, whose workgroups leave a CU no room for sixteen until they drain).
 #define SCHED_BINS 1024
-#define SCHED_KEEP 8   // bins a thread keeps in registers: batches of up to 8192 envs make one pass over the costs
+#define SCHED_THREADS 256   // four wavefronts: a workgroup that finds room on a CU beside the rasteriser's (sixteen waited for a CU to drain)
+#define SCHED_KEEP 16       // bins a thread keeps in registers: batches of up to 4096 envs make one pass over the costs
 __device__ __forceinline__ int sched_wave_scan(int v) {   // inclusive, within a wavefront (the rasteriser's rm_wave_scan)
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
@@ -547,29 +549,29 @@ __device__ __forceinline__ int sched_wave_scan(int v) {   // inclusive, within a
   return v;
 }
 __device__ __forceinline__ float sched_cost(const float* cost, int i) { const float c = cost[i]; return (c >= 0.f && c < 3.0e38f) ? c : 0.f; }
-__global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int32_t* perm, int n,
-                                                           const int32_t* reset_next, int stride) {
+__global__ __launch_bounds__(SCHED_THREADS) void moog_sched_kernel(const float* cost, int32_t* perm, int n,
+                                                                    const int32_t* reset_next, int stride) {
   __shared__ int hist[SCHED_BINS];
-  __shared__ float red[16];
-  __shared__ int wsum[16];
+  __shared__ float red[SCHED_THREADS / 64];
+  __shared__ int wsum[SCHED_THREADS / 64];
   const int t = threadIdx.x;
   float c[SCHED_KEEP];
   int rn[SCHED_KEEP];
   float m = 0.f;
 #pragma unroll
   for (int q = 0; q < SCHED_KEEP; ++q) {
-    const int i = t + 1024 * q;
+    const int i = t + SCHED_THREADS * q;
     c[q] = i < n ? sched_cost(cost, i) : 0.f;
     rn[q] = i < n ? reset_next[(size_t)i * stride] : 0;
     m = fmaxf(m, c[q]);
   }
-  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024) m = fmaxf(m, sched_cost(cost, i));
+  for (int i = t + SCHED_THREADS * SCHED_KEEP; i < n; i += SCHED_THREADS) m = fmaxf(m, sched_cost(cost, i));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((t & 63) == 0) red[t >> 6] = m;
-  hist[t] = 0;
+  for (int b = t; b < SCHED_BINS; b += SCHED_THREADS) hist[b] = 0;
   __syncthreads();
   m = red[0];
-  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  for (int w = 1; w < SCHED_THREADS / 64; ++w) m = fmaxf(m, red[w]);
   const float scale = m > 0.f ? (float)(SCHED_BINS - 1) / m : 0.f;
   // bin 0 = most expensive
   // (an env whose episode just ended is reset inside the next step kernel: the sampler's rejection loop is
@@ -583,25 +585,29 @@ __global__ __launch_bounds__(1024) void moog_sched_kernel(const float* cost, int
 #pragma unroll
   for (int q = 0; q < SCHED_KEEP; ++q) {
     bq[q] = bin_of(c[q], rn[q]);
-    if (t + 1024 * q < n) atomicAdd(&hist[bq[q]], 1);
+    if (t + SCHED_THREADS * q < n) atomicAdd(&hist[bq[q]], 1);
   }
-  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024) atomicAdd(&hist[bin_of(sched_cost(cost, i), reset_next[(size_t)i * stride])], 1);
+  for (int i = t + SCHED_THREADS * SCHED_KEEP; i < n; i += SCHED_THREADS) atomicAdd(&hist[bin_of(sched_cost(cost, i), reset_next[(size_t)i * stride])], 1);
   __syncthreads();
-  // exclusive prefix sum over the 1024 bins, one bin per thread
-  const int v = hist[t];
+  // exclusive prefix sum over the 1024 bins: a thread owns SCHED_BINS / SCHED_THREADS consecutive bins
+  constexpr int PER = SCHED_BINS / SCHED_THREADS;
+  int own[PER], v = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { own[k] = hist[PER * t + k]; v += own[k]; }
   const int inc = sched_wave_scan(v);
   if ((t & 63) == 63) wsum[t >> 6] = inc;
   __syncthreads();
-  int before = 0;
+  int before = inc - v;
   for (int w = 0; w < (t >> 6); ++w) before += wsum[w];
-  hist[t] = before + inc - v;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { hist[PER * t + k] = before; before += own[k]; }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < SCHED_KEEP; ++q) {
-    const int i = t + 1024 * q;
+    const int i = t + SCHED_THREADS * q;
     if (i < n) perm[atomicAdd(&hist[bq[q]], 1)] = i;
   }
-  for (int i = t + 1024 * SCHED_KEEP; i < n; i += 1024)
+  for (int i = t + SCHED_THREADS * SCHED_KEEP; i < n; i += SCHED_THREADS)
     perm[atomicAdd(&hist[bin_of(sched_cost(cost, i), reset_next[(size_t)i * stride])], 1)] = i;
 }
 #endif

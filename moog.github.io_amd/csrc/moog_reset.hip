@@ -24,6 +24,6 @@ int RESET_FN(moog_configure_reset)(size_t lds) {
 
 #if !MOOG_RESET_FULL
 void moog_launch_sched(hipStream_t s, const float* cost, int32_t* perm, int n, const int32_t* reset_next, int stride) {
-  hipLaunchKernelGGL(moog_sched_kernel, dim3(1), dim3(1024), 0, s, cost, perm, n, reset_next, stride);
+  hipLaunchKernelGGL(moog_sched_kernel, dim3(1), dim3(SCHED_THREADS), 0, s, cost, perm, n, reset_next, stride);
 }
 #endif
