@@ -85,7 +85,9 @@ if __name__ == '__main__':
     if '--build-spec' in sys.argv:   # no GPU: the specialised step kernel of every case's program (moog/_spec.py), in parallel
         import concurrent.futures
         from moog import _compiler, _spec
-        progs = [(name, _compiler.compile_config(layer_capacity=capacity_of(name, kw),
+        def plain(cap):   # ('auto' / 'fit_after' are BatchedEnvironment's: the program is the one of the initial capacities)
+            return {k: v for k, v in cap.items() if k not in ('auto', 'fit_after')} if isinstance(cap, dict) else cap
+        progs = [(name, _compiler.compile_config(layer_capacity=plain(capacity_of(name, kw)),
                                                  **config_of(name, kw)).program) for name, _, kw in CASES]
         with concurrent.futures.ThreadPoolExecutor(max_workers=7) as ex:
             for (name, _), path in zip(progs, ex.map(lambda p: _spec.build(p[1]), progs)):
