@@ -340,11 +340,10 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   // but x -> (int)(W * (x + o)) is monotone, so a copy's integer bounds are those of the sprite's smallest and largest
   // coordinates: four 64-bit atomics per vertex on order-preserving keys.  A vertex with a coordinate that is not an ordinary number
   // (NaN, or beyond what (int) holds: Pillow's cast then gives INT_MIN, which is not monotone) leaves its nine points' y behind instead.
-  auto vertex_b = [&](int idx, uint32_t vi) {
+  auto vertex_b = [&](int idx, uint32_t vi, double x, double y) {
     const int s = (int)(vi & 0xffu), k = (int)(vi >> 8);
     const int nvl = sc.slot[2 * s] & 0xffff;
     if (k >= nvl) return;
-    const double x = src.vbase()[2 * idx], y = src.vbase()[2 * idx + 1];
     if (!copies) {
       int ix, iy;
       const uint32_t p = rm_emit_point(a, x, y, 0, fpx, fpy, &ix, &iy);
@@ -371,19 +370,27 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
   };
 #if RM_DEV
   {
-    // (the table entries come from global memory, ~700 cycles each, a round's work is ~250: three rounds are in flight)
+    // (the table entries come from global memory, ~700 cycles each, a round's work is ~250: three rounds are in flight; the
+    //  coordinates too when the record lies in global memory -- the derive kernel: SRC::kGlobalRecord -- one round ahead)
     uint32_t v0 = lane < totv ? src.vinfo(lane) : 0u, v1 = lane + 64 < totv ? src.vinfo(lane + 64) : 0u,
              v2 = lane + 128 < totv ? src.vinfo(lane + 128) : 0u;
+    double xn = 0.0, yn = 0.0;
+    if (SRC::kGlobalRecord && lane < totv) { xn = src.vbase()[2 * lane]; yn = src.vbase()[2 * lane + 1]; }
 #pragma unroll 1
     for (int idx = lane; idx < totv; idx += 64) {
       const uint32_t v_now = v0;
       v0 = v1; v1 = v2;
       if (idx + 192 < totv) v2 = src.vinfo(idx + 192);
-      vertex_b(idx, v_now);
+      double x, y;
+      if (SRC::kGlobalRecord) {
+        x = xn; y = yn;
+        if (idx + 64 < totv) { xn = src.vbase()[2 * (idx + 64)]; yn = src.vbase()[2 * (idx + 64) + 1]; }
+      } else { x = src.vbase()[2 * idx]; y = src.vbase()[2 * idx + 1]; }
+      vertex_b(idx, v_now, x, y);
     }
   }
 #else
-  for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vinfo(idx));
+  for (int idx = 0; idx < totv; ++idx) vertex_b(idx, src.vinfo(idx), src.vbase()[2 * idx], src.vbase()[2 * idx + 1]);
 #endif
   rm_wave_sync();
   RM_CLK(3);
@@ -486,6 +493,7 @@ RM_FN void rm_emit(const RmEmit& a, const SRC& src, int env, int lane, const RmE
 
 // The record in HBM as the ABI lays it out (the derive kernel, the host model)
 struct RmSrcRecord {
+  static constexpr bool kGlobalRecord = true;   // (every read is a global load: the emitter fetches the coordinates a round ahead)
   const moog_program_t* P; const moog_layout_t* L; const double* f; const int32_t* q; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8
   RM_MEMBER int flags(int s) const { return q[L->o_flags + s]; }
   RM_MEMBER int nv(int s) const { return q[L->o_nverts + s]; }

@@ -232,6 +232,7 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
 
 // The env's record as the step kernel holds it (LDS; colours and opacities where bind_env says) for the draw-record emitter
 struct RmSrcEnv {
+  static constexpr bool kGlobalRecord = false;   // (the record is in LDS)
   const Env* e; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8 (KArgs::draw_vinfo)
   __device__ __forceinline__ int flags(int s) const { return e->q[e->L.o_flags + s]; }
   __device__ __forceinline__ int nv(int s) const { return e->q[e->L.o_nverts + s]; }
