@@ -842,6 +842,14 @@ int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised);
 enum { MOOG_RASTER_SPANS = 0, MOOG_RASTER_MASK = 1, MOOG_RASTER_MASK_COMPACT = 3 };   /* 3: the mask rasteriser with 4-byte edge records (programs whose 16-byte records keep frames off a CU) */
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path);
 
+/* The frames' draw records (csrc/moog_draw_record.h: what the mask rasteriser reads -- per env a header, an item per sprite slot
+ * and copy, the live vertices as integer canvas points) as the last launch left them, copied to the host (synchronises the
+ * device).  *stride: bytes per env; *in_step: 1 when moog_engine_step's step kernel writes them (else the derive kernel in
+ * front of every raster launch does).  host_out may be NULL (sizes only); bytes = the room at host_out, at least
+ * n_envs x *stride.  MOOG_E_UNSUPPORTED when the program's frames are not the mask rasteriser's.  For tests: the record
+ * the step kernel writes from LDS and the one derived from the stored state must be equal byte for byte. */
+int moog_engine_read_draw_records(moog_engine_t* e, uint8_t* host_out, int64_t bytes, int64_t* stride, int32_t* in_step);
+
 /* PILRenderer(color_to_rgb=<any callable>) (pil_renderer.py:72-76,108: the renderer calls it on every sprite's colour
  * triple when it draws): the callable is Python and stays on the host.  The binding evaluates it once per DISTINCT colour
  * triple (colours rarely change after a reset), keeps r | g << 8 | b << 16 per (env, sprite slot) in a device array

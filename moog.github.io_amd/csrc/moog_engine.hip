@@ -1260,6 +1260,20 @@ int moog_engine_step_kernel(moog_engine_t* e, int32_t* specialised) {
   return MOOG_OK;
 }
 
+int moog_engine_read_draw_records(moog_engine_t* e, uint8_t* host_out, int64_t bytes, int64_t* stride, int32_t* in_step) {
+  if (!e) return fail(MOOG_E_INVALID, "null engine");
+  if (!e->mask_setup.ok || !e->draw) return fail(MOOG_E_UNSUPPORTED, "this program's frames are not the mask rasteriser's: no draw records");
+  if (stride) *stride = (int64_t)e->draw_lay.stride;
+  if (in_step) *in_step = step_emits_draw(e) ? 1 : 0;
+  if (!host_out) return MOOG_OK;
+  const int64_t need = (int64_t)e->n_envs * (int64_t)e->draw_lay.stride;
+  if (bytes < need) return fail(MOOG_E_INVALID, "host buffer too small for the draw records");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host_out, e->draw, (size_t)need, hipMemcpyDeviceToHost));
+  return MOOG_OK;
+}
+
 int moog_engine_raster_path(moog_engine_t* e, int32_t* path) {
   if (!e || !path) return fail(MOOG_E_INVALID, "null argument");
   *path = (e->mask_setup.ok && e->pe_ns <= 0) ? (e->mask_setup.compact ? MOOG_RASTER_MASK_COMPACT : MOOG_RASTER_MASK) : MOOG_RASTER_SPANS;

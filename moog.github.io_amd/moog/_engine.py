@@ -20,7 +20,7 @@ SYMBOLS = (
     'moog_engine_layer_usage', 'moog_engine_set_action_dtype',
     'moog_engine_read_watch', 'moog_engine_set_reset_pool', 'moog_engine_get_reset_pool',
     'moog_engine_env_prefix', 'moog_engine_set_color_override',
-    'moog_engine_kernel_variant', 'moog_engine_raster_path', 'moog_program_step_kernel', 'moog_engine_step_kernel',
+    'moog_engine_kernel_variant', 'moog_engine_raster_path', 'moog_engine_read_draw_records', 'moog_program_step_kernel', 'moog_engine_step_kernel',
 )
 
 _LIB = None
@@ -73,6 +73,7 @@ def load_library(path=None):
     lib.moog_engine_set_color_override.argtypes = [vp, vp]
     lib.moog_engine_kernel_variant.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.moog_engine_raster_path.argtypes = [vp, ctypes.POINTER(i32)]
+    lib.moog_engine_read_draw_records.argtypes = [vp, vp, i64, ctypes.POINTER(i64), ctypes.POINTER(i32)]
     lib.moog_program_step_kernel.argtypes = [ctypes.POINTER(_abi.Program), ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(u64)]
     lib.moog_engine_step_kernel.argtypes = [vp, ctypes.POINTER(i32)]
     lib.moog_engine_get_reset_pool.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i64)]

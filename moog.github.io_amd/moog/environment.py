@@ -295,6 +295,18 @@ class BatchedEnvironment(object):
         _engine.check(self._lib, self._lib.moog_engine_raster_path(self._handle, ctypes.byref(v)))
         return 'mask' if (v.value & 1) else 'spans'
 
+    def draw_records(self):
+        """The frames' draw records as the last launch left them (include/moog_engine.h moog_engine_read_draw_records;
+        csrc/moog_draw_record.h): (uint8 array [num_envs, stride], written_by_the_step_kernel).  Synchronises; for tests."""
+        import numpy as np
+        stride, in_step = ctypes.c_int64(), ctypes.c_int32()
+        _engine.check(self._lib, self._lib.moog_engine_read_draw_records(self._handle, None, 0, ctypes.byref(stride), ctypes.byref(in_step)))
+        out = np.zeros((self.num_envs, stride.value), np.uint8)
+        with self._torch.cuda.device(self.device):
+            _engine.check(self._lib, self._lib.moog_engine_read_draw_records(
+                self._handle, ctypes.c_void_p(out.ctypes.data), out.nbytes, ctypes.byref(stride), ctypes.byref(in_step)))
+        return out, bool(in_step.value)
+
     def raster_compact_edges(self):
         """Whether the mask rasteriser keeps this program's edge records in their 4-byte form (csrc/moog_raster_mask_core.h
         RmEdgesCompact: picked when the 16-byte records would keep frames off a CU; MOOG_RASTER_COMPACT=0 / 1 forces)."""

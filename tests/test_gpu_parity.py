@@ -1681,6 +1681,52 @@ def test_mask_rasteriser_matches_the_span_rasteriser(name, rows, compact, monkey
         assert np.array_equal(o1, i1), 'frame from the records differs from the frame of the step'
 
 
+def _draw_record_parts(rec, S):
+    """The bytes of a draw record that count (csrc/moog_draw_record.h): header, the S items, the n_pts points and owner bytes."""
+    hdr = rec[:16].view(np.int32)
+    n_pts = int(hdr[0])
+    items = rec[16:16 + 16 * S]
+    o_pts = 16 + 16 * S
+    # (o_owner = o_pts + 4 x point capacity: the capacity follows from the stride)
+    return hdr.copy(), items.copy(), n_pts, o_pts
+
+
+@pytest.mark.parametrize('name', ['colliding_predators_32', 'chase_avoid_torus', 'functional_maze', 'falling_balls_64', 'parallelogram_catch',
+                                  'first_person_predators_prey'])
+def test_draw_records_of_the_step_kernel_equal_the_derived_ones(name):
+    """The frame's draw record (csrc/moog_draw_record.h) is written twice over: by the step kernel, from the record it holds in
+    LDS (moog_engine_step; for late-reset programs also by the reset kernel behind it), and by the derive kernel from the stored
+    state (moog_engine_render).  Same function, two homes: header, items, points and owners must be equal byte for byte, call
+    after call, across auto-resets -- and the host model (tests/test_raster_mask_model.py) runs that function on the CPU."""
+    n = 256
+    env = make_env(name, n, seed=12)
+    if env.raster_path() != 'mask':
+        pytest.skip('no draw records: the span kernel draws this program')
+    P = env.compiled.program
+    ncopy = 9 if P.render.polymod == 1 else 1
+    S = int(P.n_slots) * ncopy
+    cap = int(env.layout.TOTV) * ncopy
+    env.reset()
+    compared = 0
+    for k in range(24):
+        env.step(env.random_action())
+        a, in_step = env.draw_records()
+        if not in_step:
+            pytest.skip('the step kernel does not write this program\'s draw records')
+        env.observation()                      # the derive kernel, over the state the step launch stored
+        b, _ = env.draw_records()
+        for i in range(n):
+            ha, ia, na, o_pts = _draw_record_parts(a[i], S)
+            hb, ib, nb, _ = _draw_record_parts(b[i], S)
+            assert np.array_equal(ha, hb), (k, i, ha, hb)
+            assert np.array_equal(ia, ib), ('items differ', k, i)
+            assert np.array_equal(a[i, o_pts:o_pts + 4 * na], b[i, o_pts:o_pts + 4 * nb]), ('points differ', k, i)
+            o_own = o_pts + 4 * cap
+            assert np.array_equal(a[i, o_own:o_own + na], b[i, o_own:o_own + nb]), ('owner bytes differ', k, i)
+            compared += na
+    assert compared > 0
+
+
 def test_raster_path_by_program():
     """Which rasteriser a program's frames take (moog_engine_raster_path): the mask rasteriser for one-tile frames of
     polygons with <= 128 vertices (the 102-vertex annuli take its cooperative row routine), the nine copies per sprite of a
