@@ -3100,13 +3100,20 @@ __device__ inline void rule_reset(Env& e, int ri) {
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
   if (R->kind == MOOG_RULE_TIMED && R->op != 0) {   // a callable interval: drawn here, before the children are reset (timing.py:47)
-    const int lo = (int)(R->op == 1 ? R->p0 : R->p1), hi = (int)R->p2;
+    const int lo = (int)(R->op == 2 ? R->p1 : R->p0), hi = (int)R->p2;
     int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
     if (k >= hi - lo) k = hi - lo - 1;
+    double width = (R->op == 1) ? R->p1 : (double)(lo + k) - R->p0;
+    if (R->op == 3) {   // DelayedRule(start = <callable>, duration = <callable>), timing.py:84-86: the start above, then the duration
+      const int lo2 = (int)R->p1, hi2 = R->i0;
+      int k2 = (int)(next_uniform(e) * (hi2 - lo2));
+      if (k2 >= hi2 - lo2) k2 = hi2 - lo2 - 1;
+      width = (double)(lo2 + k2);
+    }
     wsync();
     if (e.lane == 0) {
-      e.f[e.L.o_rule + ri] = (R->op == 1) ? (double)(lo + k) : R->p0;
-      e.f[e.L.o_rule2 + ri] = (R->op == 1) ? R->p1 : (double)(lo + k) - R->p0;
+      e.f[e.L.o_rule + ri] = (R->op == 2) ? R->p0 : (double)(lo + k);
+      e.f[e.L.o_rule2 + ri] = width;
     }
     wsync();
   }

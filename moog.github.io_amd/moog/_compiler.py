@@ -1141,7 +1141,9 @@ def compile_config(state_initializer, physics, task, action_space, observers, ga
             R.kind = _abi.MOOG_RULE_TIMED
             R.p0, R.p1 = r._step_interval
             if r._random is not None:   # a callable interval: one np.random.randint draw per reset (game_rules.TimedRule)
-                R.op, R.p0, R.p1, R.p2 = r._random
+                R.op, R.p0, R.p1, R.p2 = r._random[:4]
+                if R.op == 3:   # two draws: start = randint(p0, p2), then width = randint(p1, i0)
+                    R.i0 = int(r._random[4])
                 P.rule_state2 = 1
         elif isinstance(r, rules_lib.ConditionalRule):
             R.kind = _abi.MOOG_RULE_CONDITIONAL

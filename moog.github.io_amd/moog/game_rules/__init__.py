@@ -258,9 +258,11 @@ class CreateSprites(AbstractRule):
         self._without_overlapping = tuple(without_overlapping)
 
 
-def _probe_randint(fn):
+def _probe_randint(fn, patterns=None):
     """Calls fn() twice with np.random.randint replaced -- once returning its low bound, once its highest value -- and
-    returns ([(low, high) of every draw], value at the low bounds, value at the high bounds).
+    returns ([(low, high) of every draw], value at the low bounds, value at the high bounds).  `patterns` (a list of tuples
+    of 0 / 1, one entry per draw: low bound / highest value; draws beyond a tuple's end take the low bound): fn() is called
+    once per pattern instead and the values come back as a list -- how a caller checks which draw a value depends on.
 
     The reference calls fn() at every reset (timing.py:47): a callable may only be lowered when everything random in it
     is seen here.  So every other entry point of np.random and of the `random` module raises while fn runs, and a
@@ -285,16 +287,17 @@ def _probe_randint(fn):
     try:
         for mod, n, _ in saved:
             setattr(mod, n, refuse(('np.random.' if mod is np.random else 'random.') + n))
-        for pick_high in (False, True):
+        for pattern in (patterns if patterns is not None else ((0,) * 64, (1,) * 64)):
             seen = []
 
-            def probe(low, high=None, size=None, dtype=int, _seen=seen, _hi=pick_high):
+            def probe(low, high=None, size=None, dtype=int, _seen=seen, _pat=pattern):
                 if high is None:
                     low, high = 0, low
                 if size is not None:
                     raise NotImplementedError('np.random.randint with a size in a rule\'s interval')
+                hi_pick = len(_seen) < len(_pat) and bool(_pat[len(_seen)])
                 _seen.append((int(low), int(high)))
-                return int(high) - 1 if _hi else int(low)
+                return int(high) - 1 if hi_pick else int(low)
             np.random.randint = probe
             try:
                 value = fn()
@@ -310,8 +313,10 @@ def _probe_randint(fn):
     if moved:
         raise NotImplementedError('a rule interval that draws from the host\'s random generators other than through '
                                   'np.random.randint is not lowered')
-    if out[0][0] != out[1][0]:
+    if any(o[0] != out[0][0] for o in out[1:]):
         raise NotImplementedError('a rule interval whose draws depend on each other')
+    if patterns is not None:
+        return out[0][0], [o[1] for o in out]
     if not out[0][0]:
         v0, v1 = np.asarray(out[0][1], float), np.asarray(out[1][1], float)
         if v0.shape != v1.shape or not np.array_equal(v0, v1):
@@ -323,9 +328,11 @@ def _probe_randint(fn):
 class TimedRule(AbstractRule):
     """timing.py:18-59: steps `rules` while _steps_until_start <= 0 < _steps_until_stop;
     both count down once per call.  A callable `step_interval` (timing.py:28-31,47) is drawn whenever the rule is reset;
-    the forms that are lowered take ONE np.random.randint draw: a random start with a fixed width (stop - start does not
+    the forms that are lowered: ONE np.random.randint draw -- a random start with a fixed width (stop - start does not
     depend on the draw; DelayedRule(lambda: np.random.randint(a, b), ...)) or a fixed start with a random stop
-    (TemporaryRule(lambda: np.random.randint(a, b), ...)) -- the draw is made on the device."""
+    (TemporaryRule(lambda: np.random.randint(a, b), ...)) -- and TWO: a random start and a random duration
+    (DelayedRule(lambda: np.random.randint(a, b), ..., duration=lambda: np.random.randint(c, d)), timing.py:84-86).  The
+    draws are made on the device, in the reference's order."""
 
     def __init__(self, step_interval, rules):
         self._random = None   # (op, p0, p1, p2) of MOOG_RULE_TIMED
@@ -335,8 +342,19 @@ class TimedRule(AbstractRule):
             hi = (float(hi[0]), float(hi[1]))
             if not draws:
                 step_interval = lo
+            elif len(draws) == 2:
+                # timing.py:84-86 DelayedRule(start=<callable>, duration=<callable>): the start is drawn first, then the duration;
+                # lowered when the start is the first draw itself and stop - start the second (checked on all four corners)
+                (a, b), (c, d) = draws
+                _, corners = _probe_randint(step_interval, patterns=((0, 0), (1, 1), (1, 0), (0, 1)))
+                want = [(a, a + c), (b - 1, b - 1 + d - 1), (b - 1, b - 1 + c), (a, a + d - 1)]
+                if [(float(v[0]), float(v[1])) for v in corners] != [(float(x), float(y)) for x, y in want]:
+                    raise NotImplementedError('a callable step_interval with two np.random.randint draws other than '
+                                              '(randint, randint + randint) is not lowered')
+                self._random = (3, float(a), float(c), float(b), int(d))   # start = randint(a, b), stop = start + randint(c, d)
+                step_interval = lo
             elif len(draws) != 1:
-                raise NotImplementedError('a callable step_interval with more than one np.random.randint draw is not lowered')
+                raise NotImplementedError('a callable step_interval with more than two np.random.randint draws is not lowered')
             else:
                 a, b = draws[0]
                 if lo[0] == a and hi[0] == b - 1 and (lo[1] - lo[0] == hi[1] - hi[0] or (np.isinf(lo[1]) and np.isinf(hi[1]))):

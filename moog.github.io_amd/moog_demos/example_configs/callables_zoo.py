@@ -8,6 +8,7 @@
     expressions must be selected for the reward alone
   * level 1: Reset(condition = <sprites named by position>) while the state's FIRST layer is empty: the condition is
     anchored to slots, not to a layer's first live sprite
+  * level 3: DelayedRule(start=<callable>, ..., duration=<callable>): two np.random.randint draws per reset (timing.py:84-86)
   * level 2: PILRenderer(color_to_rgb=<a Python function>) (pil_renderer.py:72-76,108): branches, int(), components that
     Pillow clips to 0 .. 255 -- evaluated on the host per distinct colour (moog_engine_set_color_override)
 """
@@ -69,7 +70,9 @@ def get_config(level=0):
         meta_state_phase_name_key='phase')
     rules = (
         phases,
-        game_rules.DelayedRule(lambda: np.random.randint(3, 9), game_rules.ModifySprites('prey', _tint), duration=4),
+        # (level 3: the duration is a callable too -- two draws per reset, the start first: timing.py:84-86)
+        game_rules.DelayedRule(lambda: np.random.randint(3, 9), game_rules.ModifySprites('prey', _tint),
+                               duration=(lambda: np.random.randint(2, 7)) if level == 3 else 4),
         game_rules.TemporaryRule(lambda: np.random.randint(5, 12), game_rules.ModifySprites('agent', _speed_up)),
         game_rules.TimedRule(lambda: (2, np.random.randint(10, 20)), game_rules.ModifySprites('magnet', _tint)),
         game_rules.VanishOnContact('prey', 'agent'),

@@ -860,6 +860,7 @@ def main():
         ('callables_zoo', 70, {}, (0, 1)),      # round 4: traced force_fn, callable rule intervals, ContactReward with meta_state
         ('callables_zoo_l1', 50, {}, (0,)),
         ('callables_zoo_l2', 40, {}, (0,)),     # PILRenderer(color_to_rgb=<a Python function>)
+        ('callables_zoo_l3', 60, {}, (0, 1)),   # round 6: DelayedRule with a callable start AND a callable duration (two draws per reset)
     ]
     for name, n_calls, caps, seeds in plan:
         for seed in seeds:

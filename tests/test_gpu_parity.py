@@ -20,7 +20,7 @@ RUNS = [('pong', 0), ('pong', 1), ('chase_avoid_torus', 0), ('chase_avoid_torus'
         ('lambda_zoo', 0), ('lambda_zoo', 1), ('rules_zoo_l2', 0),
         ('first_person_predators_prey', 0), ('cond_zoo', 0), ('cond_zoo', 1), ('phase_zoo', 0), ('phase_zoo', 1), ('phase_zoo_l1', 0), ('phase_zoo_l1', 1), ('match_to_sample_l3', 0), ('match_to_sample_l3', 1), ('match_to_sample_l4', 0), ('match_to_sample_l2', 0), ('predators_arena_l2', 0), ('predators_arena_l2', 1), ('predators_arena_l1', 0), ('predators_arena_l3', 0), ('bounce_box_contact_prediction', 0), ('bounce_box_contact_prediction_l1', 0), ('red_green_l1', 0), ('red_green', 0), ('red_green_l3', 0), ('lookahead_zoo', 0), ('lookahead_zoo', 1), ('lookahead_zoo_l1', 0), ('lookahead_zoo_l1', 1), ('tracing_zoo', 0), ('tracing_zoo', 1), ('tracing_zoo_l1', 0), ('tracing_zoo_l1', 1), ('combo_zoo', 0), ('combo_zoo', 1),
         ('actions_zoo', 0), ('actions_zoo', 1), ('actions_zoo_l1', 0), ('cleanup', 0), ('cleanup', 1),
-        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('callables_zoo', 0), ('callables_zoo', 1), ('callables_zoo_l1', 0), ('callables_zoo_l2', 0), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
+        ('aa_zoo', 0), ('aa_zoo_l1', 0), ('aa_zoo_l2', 0), ('aa_zoo_l3', 0), ('aa_zoo_l4', 0), ('aa_zoo_l5', 0), ('callables_zoo', 0), ('callables_zoo', 1), ('callables_zoo_l1', 0), ('callables_zoo_l2', 0), ('callables_zoo_l3', 0), ('callables_zoo_l3', 1), ('maze_zoo', 0), ('maze_zoo', 1), ('maze_zoo_l1', 0), ('maze_zoo_l2', 0), ('maze_zoo_l2', 1),
         ('pacman', 0), ('pacman', 1), ('pacman_l1', 0),
         ('sampler_zoo', 0), ('sampler_zoo', 1), ('sampler_zoo_l1', 0),
         ('parallelogram_catch', 0), ('parallelogram_catch', 1), ('parallelogram_catch_l1', 0), ('parallelogram_catch_l1', 1),

@@ -667,6 +667,10 @@ def test_rule_interval_probe_sees_every_draw():
     assert gr.DelayedRule(lambda: np.random.randint(10, 100), [])._random == (1, 10.0, np.inf, 100.0)
     assert gr.TemporaryRule(lambda: np.random.randint(5, 9), [])._random == (2, 0.0, 5.0, 9.0)
     assert gr.DelayedRule(lambda: 7, [])._step_interval == (7.0, np.inf)
+    # two draws: a random start, then a random duration (timing.py:84-86); other two-draw forms stay refused
+    assert gr.DelayedRule(lambda: np.random.randint(3, 9), [], duration=lambda: np.random.randint(2, 7))._random == (3, 3.0, 2.0, 9.0, 7)
+    with pytest.raises(NotImplementedError):
+        gr.TimedRule(lambda: (np.random.randint(0, 4), np.random.randint(10, 20)), [])   # (the stop is not start + a draw)
     for fn in (lambda: int(np.random.uniform(10, 100)), lambda: np.random.choice([3, 5]), lambda: py_random.randint(1, 5),
                lambda: captured(10, 100), lambda: np.random.randint(0, 3) + np.random.randint(0, 3)):
         with pytest.raises(NotImplementedError):
