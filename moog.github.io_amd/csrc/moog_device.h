@@ -126,13 +126,24 @@ struct Env {
   double xarg;             // the argument of the function being evaluated (MOOG_X_ARG)
 };
 
-#define PX(s) (e.f[e.L.o_pos + 2 * (s)])
-#define PY(s) (e.f[e.L.o_pos + 2 * (s) + 1])
-#define VELX(s) (e.f[e.L.o_vel + 2 * (s)])
-#define VELY(s) (e.f[e.L.o_vel + 2 * (s) + 1])
-#define ANG(s) (e.f[e.L.o_angle + (s)])
-#define ANGV(s) (e.f[e.L.o_angvel + (s)])
-#define MASS(s) (e.f[e.L.o_mass + (s)])
+// How the step path reads the env's program and (hot) layout.  Generic kernels: members of the env's descriptor (registers; scratch
+// memory in the functions the every-component variants leave out of line).  Program-specialised builds: the constants themselves --
+// also inside those out-of-line functions, which took them by reference through the descriptor until round 6.
+#ifdef MOOG_SPEC_PROGRAM_INC
+__device__ __forceinline__ moog_layout_t moog_spec_hot_layout_fn();   // (moog_kernels.h: hot_layout(moog_layout(&MOOG_SPEC_PROGRAM)).L, folded at compile time)
+#define EL(e_) (moog_spec_hot_layout_fn())
+#define EP(e_) ((PProg)&MOOG_SPEC_PROGRAM)
+#else
+#define EL(e_) ((e_).L)
+#define EP(e_) ((e_).P)
+#endif
+#define PX(s) (e.f[EL(e).o_pos + 2 * (s)])
+#define PY(s) (e.f[EL(e).o_pos + 2 * (s) + 1])
+#define VELX(s) (e.f[EL(e).o_vel + 2 * (s)])
+#define VELY(s) (e.f[EL(e).o_vel + 2 * (s) + 1])
+#define ANG(s) (e.f[EL(e).o_angle + (s)])
+#define ANGV(s) (e.f[EL(e).o_angvel + (s)])
+#define MASS(s) (e.f[EL(e).o_mass + (s)])
 // Colours, opacities, shape ids and Portal bits may live in HBM (fields the step path hardly ever touches): they are READ
 // through COL / OPAC / SHAPEID / TELE and WRITTEN through the *_SET forms.
 #define COL(s, c) (static_cast<const double*>(e.gcol)[3 * (s) + (c)])
@@ -140,19 +151,19 @@ struct Env {
 #define OPAC_SET(s, v) (e.gopa[(s)] = (v))
 #define SHAPEID_SET(s, v) (e.gshape[(s)] = (v))
 #define TELE_SET(s, v) (e.gtele[(s)] = (v))
-#define INER(s, c) (e.f[e.L.o_inertia + 2 * (s) + (c)])
-#define MAXR(s) (e.f[e.L.o_maxr + (s)])
-#define FLAGS(s) (e.q[e.L.o_flags + (s)])
-#define NV(s) (e.q[e.L.o_nverts + (s)])
+#define INER(s, c) (e.f[EL(e).o_inertia + 2 * (s) + (c)])
+#define MAXR(s) (e.f[EL(e).o_maxr + (s)])
+#define FLAGS(s) (e.q[EL(e).o_flags + (s)])
+#define NV(s) (e.q[EL(e).o_nverts + (s)])
 #define OPAC(s) (static_cast<const int32_t*>(e.gopa)[(s)])
 #define SHAPEID(s) (static_cast<const int32_t*>(e.gshape)[(s)])
 #define TELE(s) (static_cast<const int32_t*>(e.gtele)[(s)])
-#define VERT(s) (&e.f[e.L.o_verts + 2 * e.voff[s]])
+#define VERT(s) (&e.f[EL(e).o_verts + 2 * e.voff[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
-#define VALIAS(s) (e.q[e.L.o_valias + (s)])
-#define SCALE(s) (e.f[e.L.o_scale + (s)])
-#define ASPECT(s) (e.f[e.L.o_aspect + (s)])
-#define FMASK(s) (e.q[e.L.o_fmask + (s)])
+#define VALIAS(s) (e.q[EL(e).o_valias + (s)])
+#define SCALE(s) (e.f[EL(e).o_scale + (s)])
+#define ASPECT(s) (e.f[EL(e).o_aspect + (s)])
+#define FMASK(s) (e.q[EL(e).o_fmask + (s)])
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -243,13 +254,13 @@ __device__ inline void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 // Wave-uniform draw: every lane computes the same value; lane 0 commits the counter.
 __device__ inline double next_uniform(Env& e) {
-  int32_t* r = &e.q[e.L.o_rng];
+  int32_t* r = &e.q[EL(e).o_rng];
   double out;
   if (e.inj) {
     int cur = r[2];
     if (cur >= e.inj_n) {
       wsync();
-      if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+      if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
       wsync();
       return 0.0;
     }
@@ -273,7 +284,7 @@ __device__ inline double next_uniform(Env& e) {
 // The next n <= 64 draws at once: lane i returns draw i (the same values, in the same order, that n calls
 // of next_uniform would give); the counter advances by n.  One Philox latency instead of n.
 __device__ inline double next_uniforms_lanes(Env& e, int n) {
-  int32_t* r = &e.q[e.L.o_rng];
+  int32_t* r = &e.q[EL(e).o_rng];
   if (e.inj) {
     const int cur = r[2];
     const int have = e.inj_n - cur < n ? (e.inj_n - cur < 0 ? 0 : e.inj_n - cur) : n;
@@ -281,7 +292,7 @@ __device__ inline double next_uniforms_lanes(Env& e, int n) {
     wsync();
     if (e.lane == 0) {
       r[2] = cur + have;
-      if (have < n) e.q[e.L.o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+      if (have < n) e.q[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
     }
     wsync();
     return out;
@@ -514,7 +525,7 @@ __device__ inline void bbox_exact_wave(Env& e, int s) {
 
 // lanes = sprites; each lane scans its own vertex list (kernel prologue)
 __device__ inline void bbox_build_all(Env& e) {
-  PProg P = e.P;
+  PProg P = EP(e);
   for (int s = e.lane; s < P->n_slots; s += 64) dop_scan(VERT(s), NV(s), &BB(s, 0));
   wsync();
 }
@@ -752,7 +763,7 @@ __device__ __forceinline__ double rdlane_d(double v, int lane) {   // lane: wave
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 __device__ inline void integrate_all(Env& e, double dt) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const int S = P->n_slots;
   wsync();
   for (int sbase = 0; sbase < S; sbase += 64) {
@@ -852,7 +863,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
     const int s = sbase + sl;
     const bool on = sl < nchunk && mode != 0 && !((coopm >> sl) & 1ull);
     const int n = on ? NV(s) : 0;
-    double* v = on ? VERT(s) : &e.f[e.L.o_verts];
+    double* v = on ? VERT(s) : &e.f[EL(e).o_verts];
     const float FINF = __builtin_inff();
     float l0 = FINF, l1 = FINF, l2 = FINF, l3 = FINF, h0 = -FINF, h1 = -FINF, h2 = -FINF, h3 = -FINF;
     int fin = 0;
@@ -906,17 +917,17 @@ __device__ inline void integrate_all(Env& e, double dt) {
 // in-place update the value is copied to the other members.  Programs without such a
 // tether (vel_alias == 0, a scalar branch) have no o_valias words at all.
 __device__ inline void vel_share(Env& e, int s) {
-  if (!e.P->vel_alias) return;
+  if (!EP(e)->vel_alias) return;
   const int g = VALIAS(s);
   if (!g) return;
   const double vx = VELX(s), vy = VELY(s);
-  const int S = e.P->n_slots;
+  const int S = EP(e)->n_slots;
   for (int t = e.lane; t < S; t += 64)
     if (t != s && ALIVE(t) && VALIAS(t) == g) { VELX(t) = vx; VELY(t) = vy; }
   wsync();
 }
 __device__ inline void vel_unshare(Env& e, int s) {   // caller: lane 0
-  if (e.P->vel_alias) VALIAS(s) = 0;
+  if (EP(e)->vel_alias) VALIAS(s) = 0;
 }
 
 __device__ inline void vel_iadd(Env& e, int s, double dx, double dy) {
@@ -1253,7 +1264,7 @@ __device__ inline void collide_without_update_angle_vel(Env& e, int s0, int s1, 
   double nn = npnorm(nx, ny);
   if (!(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.)) {
     wsync();
-    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
     wsync();
     return;
   }
@@ -1453,7 +1464,7 @@ __device__ inline void resolve_contact(Env& e, double elasticity, int s0, int s1
   }
   if (!fault) {   // in-place adds with the reference's float32 rounding (see vel_iadd)
     if (f0 & MOOG_F_VEL_F32) { v0x = f32r(v0x + a0x); v0y = f32r(v0y + a0y); } else { v0x = v0x + a0x; v0y = v0y + a0y; }
-    if (e.P->vel_alias && VALIAS(s0) && VALIAS(s0) == VALIAS(s1)) { v1x = v0x; v1y = v0y; }   // one shared ndarray
+    if (EP(e)->vel_alias && VALIAS(s0) && VALIAS(s0) == VALIAS(s1)) { v1x = v0x; v1y = v0y; }   // one shared ndarray
     if (f1 & MOOG_F_VEL_F32) { v1x = f32r(v1x + a1x); v1y = f32r(v1y + a1y); } else { v1x = v1x + a1x; v1y = v1y + a1y; }
     if (upd) {
       w0 = (f0 & MOOG_F_ANGVEL_F32) ? f32r(w0 + dw0) : w0 + dw0;
@@ -1471,14 +1482,14 @@ __device__ inline void resolve_contact(Env& e, double elasticity, int s0, int s1
     PX(s0) = n0x; PY(s0) = n0y;
     dop_translate(&BB(s0, 0), d0x, d0y);
     if (symmetric) { PX(s1) = n1x; PY(s1) = n1y; dop_translate(&BB(s1, 0), d1x, d1y); }
-    if (fault) e.q[e.L.o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    if (fault) e.q[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
     else {
       VELX(s0) = v0x; VELY(s0) = v0y; VELX(s1) = v1x; VELY(s1) = v1y;
       if (upd) { ANGV(s0) = w0; ANGV(s1) = w1; }
     }
   }
   wsync();
-  if (e.P->vel_alias && !fault) {
+  if (EP(e)->vel_alias && !fault) {
     if (VALIAS(s0) != VALIAS(s1)) vel_share(e, s0);
     vel_share(e, s1);
   }
@@ -1649,7 +1660,7 @@ __device__ inline void force_pair_newton(Env& e, PForce F, int s0, int s1, int K
 // ---- rigid tethers (tether_physics.py:16-201) ----------------------------------------------
 // The i-th live sprite of layer l (list order), or -1.
 __device__ inline int nth_alive(Env& e, int l, int i) {
-  PProg P = e.P;
+  PProg P = EP(e);
   for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
     if (ALIVE(s) && i-- == 0) return s;
   return -1;
@@ -1659,7 +1670,7 @@ __device__ inline int nth_alive(Env& e, int l, int i) {
 // the layers (Tether, :129-131) or the zi-th live sprite of each layer (zipped, :199).
 template <class F>
 __device__ inline void tether_members(Env& e, PCorr C, int zi, F f) {
-  PProg P = e.P;
+  PProg P = EP(e);
   if (C->kind == MOOG_CORR_TETHER) {
     for (int a = 0; a < C->n_layers; ++a) {
       int l = C->layers[a];
@@ -1749,7 +1760,7 @@ __device__ __forceinline__ void tether_group(Env& e, PCorr C, int zi, int K, int
 
 // Tether.apply_physics (:122-136), TetherZippedLayers.apply_physics (:176-201)
 __device__ inline void tether(Env& e, PCorr C, int ci) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const int K = P->updates_per_env_step;
   wsync();
   if (e.lane == 0) {
@@ -1763,7 +1774,7 @@ __device__ inline void tether(Env& e, PCorr C, int ci) {
         for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) cnt += ALIVE(s) ? 1 : 0;
         if (a == 0) cnt0 = cnt; else same = same && (cnt == cnt0);
       }
-      if (!same) e.q[e.L.o_fault] |= MOOG_FAULT_TETHER_ZIP;
+      if (!same) e.q[EL(e).o_fault] |= MOOG_FAULT_TETHER_ZIP;
       else for (int i = 0; i < cnt0; ++i) tether_group(e, C, i, K, 1 + ci * MOOG_MAX_SLOTS + i);
     }
   }
@@ -1772,7 +1783,7 @@ __device__ inline void tether(Env& e, PCorr C, int ci) {
 
 // constant_speed.py:34-46
 __device__ inline void constant_speed(Env& e, PCorr C) {
-  PProg P = e.P;
+  PProg P = EP(e);
   for (int a = 0; a < C->n_layers; ++a) {
     int l = C->layers[a];
     int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
@@ -1836,10 +1847,10 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
 // maze.py:107-112 open_vertex(i, j): inside the matrix and not a wall (maze[j, i])
 // row j of the maze: a program constant, or (a maze drawn per reset) part of the env's record
 __device__ __forceinline__ uint32_t maze_row(const Env& e, int j) {
-  return e.P->maze.random ? (uint32_t)e.q[e.L.o_maze + j] : e.P->maze.rows[j];
+  return EP(e)->maze.random ? (uint32_t)e.q[EL(e).o_maze + j] : EP(e)->maze.rows[j];
 }
 __device__ __forceinline__ int maze_open(const Env& e, long i, long j) {
-  const int n = e.P->maze.size;
+  const int n = EP(e)->maze.size;
   if (i < 0 || j < 0 || i >= n || j >= n) return 0;
   return !((maze_row(e, (int)j) >> i) & 1u);
 }
@@ -1875,7 +1886,7 @@ __device__ inline void maze_set_velocity(Env& e, int s, double vx, double vy) {
 
 // maze_walk.py:149-193 RandomMazeWalk._step_sprite (with :52-79 _get_pos_vel and :81-93 _get_nearest_point)
 __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
-  PProg P = e.P;
+  PProg P = EP(e);
   if (isinf(MASS(s))) return;
   const double speed = F->p0, gs = 1. / P->maze.size, half = 0.5 * gs;
   const double px = PX(s), py = PY(s);
@@ -1932,7 +1943,7 @@ __device__ inline void maze_walk_step(Env& e, PForce F, int s, int K) {
 // MOOG_RULE_STATE_SLOT entry.  A prescribed velocity with a different sign pattern sets the velocity to
 // np.clip(..., -speed, -speed) = (-speed, -speed) (NaN where the sum is NaN); otherwise the velocity is left alone.
 __device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const double speed = F->p0, gs = 1. / P->maze.size, half = 0.5 * gs;
   const double px = PX(s), py = PY(s);
   const double vel[2] = {speed * np_sign(VELX(s)), speed * np_sign(VELY(s))};
@@ -1944,7 +1955,7 @@ __device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K) {
   const double d_int_cur = (0 + fabs(nx - ix)) + fabs(ny - iy);   // (measured from next_position, as in the reference)
   const bool entering = d_next_cur > d_int_cur && d_next_cur > d_int_next;
   if (!(entering || (vel[0] == 0. && vel[1] == 0.))) return;
-  const int slot = e.L.o_rule + uni(F->symmetric);
+  const int slot = EL(e).o_rule + uni(F->symmetric);
   const int k = (int)e.f[slot];
   if (k >= F->i1) return;   // `if len(self._step_velocities) > 0`
   const double new0 = P->cand[F->i0 + 2 * k], new1 = P->cand[F->i0 + 2 * k + 1];
@@ -1959,7 +1970,7 @@ __device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K) {
 
 // maze_physics.py:48-109 _get_position_affordances (the position itself is returned unchanged)
 __device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[2][2]) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const double gs = 1. / P->maze.size, half = 0.5 * gs;
   long nearest[2], inds[2];
   bool on[2];
@@ -1973,7 +1984,7 @@ __device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[
   aff[0][0] = aff[0][1] = aff[1][0] = aff[1][1] = 0;
   if (!on[0] && !on[1]) {
     wsync();
-    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_OFF_GRID;
+    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
     wsync();
     return false;
   }
@@ -1995,7 +2006,7 @@ template <int D>
 __device__ inline bool maze_new_velocity(Env& e, double pos[2], double v[2], double aff[2][2], int axis, double out[2]) {
   if constexpr (D == 0) {
     wsync();
-    if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_OFF_GRID;
+    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
     wsync();
     out[0] = out[1] = 0;
     return false;
@@ -2075,7 +2086,7 @@ __device__ inline void maze_update_sprite(Env& e, PCorr C, int s) {
 
 // maze_physics.py:205-211 MazePhysics.apply_physics
 __device__ inline void maze_physics(Env& e, PCorr C) {
-  PProg P = e.P;
+  PProg P = EP(e);
   for (int a = 0; a < C->n_layers; ++a) {
     const int l = C->layers[a];
     for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s)
@@ -2193,7 +2204,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
   // visits both orders (physics.py:103-108); in the contact-heavy envs that set the kernel's duration three searches in
   // four end "future contact", and a pair that overlaps without colliding does so twice in every sub-step.
   unsigned long long skipbits = 0ull;
-  const bool use_skip = !uni(e.P->vel_alias);   // (velocity arrays shared across sprites: a contact elsewhere may touch the pair)
+  const bool use_skip = !uni(EP(e)->vel_alias);   // (velocity arrays shared across sprites: a contact elsewhere may touch the pair)
   int start = 0;
   while (start < total) {
     // ---- the ordered list of candidates with flattened index >= start, as many whole rows as fit --------
@@ -2305,7 +2316,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
 // walk / MazePhysics, whose scratch frame must not weigh on the plain step kernel).
 template <bool DYN>
 __device__ __forceinline__ void apply_physics(Env& e) {   // (forced: see the note at moog_step_kernel)
-  PProg P = e.P;
+  PProg P = EP(e);
   const int K = uni(P->updates_per_env_step);
   const int n_fops = e.n_fops;
   for (int k = 0; k < n_fops; ++k) {
@@ -2370,7 +2381,7 @@ __device__ inline double np_remainder1(double a) {
 struct XStores { unsigned mask; unsigned tags; };   // tags: 2 bits per attribute
 
 __device__ inline double xattr(Env& e, int s, int a, int& tag) {
-  const bool has = e.P->sprite_factors != 0;
+  const bool has = EP(e)->sprite_factors != 0;
   const int fm = has ? FMASK(s) : 0;
   const int fl = FLAGS(s);
   switch (a) {
@@ -2411,7 +2422,7 @@ __device__ inline float np_remf(float a, float b) {
 // (program.xstack_depth entries per lane); only pure one-sprite expressions take this path (MOOG_FILTER_EXPR_LANES).
 template <bool LANES>
 __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
-  PProg P = e.P;
+  PProg P = EP(e);
   double* vbase = LANES ? e.xstack + e.lane : reinterpret_cast<double*>(e.cand);   // [MOOG_X_STACK] (x 64 lanes, lane-minor)
   double* sv = reinterpret_cast<double*>(e.cand) + MOOG_X_STACK;   // pending writes [13] (never with LANES)
   constexpr int VS = LANES ? 64 : 1;
@@ -2427,14 +2438,14 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
     if (op == MOOG_X_END) break;
     if (op == MOOG_X_CONST) { v(n) = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v(n) = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
-    if (op == MOOG_X_RULE_STATE) { v(n) = e.f[e.L.o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE) { v(n) = e.f[EL(e).o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_SLOT_CONST) { v(n) = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
-    if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[e.L.o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[EL(e).o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_ARG) { v(n) = e.xarg; XSETTAG(n, 2); ++n; continue; }   // (np.linalg.norm gives a float64)
     // (values an initializer left in the record, read by rules and tasks while stepping: in every kernel, so that a program
     //  whose INITIALIZER needs the kernels that carry every component can still be stepped by the others, moog_kernels.h
     //  "late reset")
-    if (op == MOOG_X_HDRAW_T) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, (int)e.f[e.L.o_hdraw + I->a + 1]); ++n; continue; }
+    if (op == MOOG_X_HDRAW_T) { v(n) = e.f[EL(e).o_hdraw + I->a]; XSETTAG(n, (int)e.f[EL(e).o_hdraw + I->a + 1]); ++n; continue; }
     if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
       const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
       int t; v(n) = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
@@ -2449,7 +2460,7 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
       XSETTAG(n - 1, any2 ? 2 : (any1 ? 1 : 0));
       continue;
     }
-    if (op == MOOG_X_HDRAW) { v(n) = e.f[e.L.o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
+    if (op == MOOG_X_HDRAW) { v(n) = e.f[EL(e).o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
     if (op == MOOG_X_SLOT_ATTR) { int t; v(n) = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
     if constexpr (MOOG_WITH_MAZE != 0) {   // expressions about the sprite being created: only in the kernels that carry every component
       if (op == MOOG_X_STORE_VERT) {   // raw shape coordinate -> the vertex area of the slot being created
@@ -2558,7 +2569,7 @@ __device__ __forceinline__ void apply_light_stores(Env& e, int s, const XStores&
                                                    double c0, double c1, double c2, double op) {
   auto tag = [&](int a) { return (int)((st.tags >> (2 * a)) & 3u); };
   auto has = [&](int a) { return ((st.mask >> a) & 1u) != 0; };
-  const bool sf = e.P->sprite_factors != 0;
+  const bool sf = EP(e)->sprite_factors != 0;
   int fl = FLAGS(s);
   if (has(MOOG_XA_XVEL) || has(MOOG_XA_YVEL)) {   // a fresh ndarray
     VELX(s) = vx; VELY(s) = vy;
@@ -2611,7 +2622,7 @@ __device__ inline void run_modifier(Env& e, int xmod, int s) {
 //      Python lists.  Live sprites stay packed at the front of the layer's slots, in list order.
 __device__ inline void move_slot(Env& e, int dst, int src) {
   wsync();
-  const moog_layout_t& L = e.L;
+  const moog_layout_t& L = EL(e);
   const int n2 = 2 * NV(src);
   double* vd = VERT(dst);
   const double* vs = VERT(src);
@@ -2627,8 +2638,8 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
     ANG(dst) = ANG(src); ANGV(dst) = ANGV(src); MASS(dst) = MASS(src); MAXR(dst) = MAXR(src);
     FLAGS(dst) = FLAGS(src); NV(dst) = NV(src); OPAC_SET(dst, OPAC(src)); SHAPEID_SET(dst, SHAPEID(src));
     TELE_SET(dst, TELE(src));
-    if (e.P->vel_alias) VALIAS(dst) = VALIAS(src);
-    if (e.P->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
+    if (EP(e)->vel_alias) VALIAS(dst) = VALIAS(src);
+    if (EP(e)->sprite_factors) { SCALE(dst) = SCALE(src); ASPECT(dst) = ASPECT(src); FMASK(dst) = FMASK(src); }
     FLAGS(src) = 0; NV(src) = 0;
   }
   wave_global_fence();
@@ -2636,7 +2647,7 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
 }
 
 __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the vanished entries
-  PProg P = e.P;
+  PProg P = EP(e);
   if (!P->layer_dynamic[l]) return;
   const int s0 = P->layer_slot0[l], s1 = s0 + P->layer_nslots[l];
   // nothing to do when the live sprites already are a prefix of the layer
@@ -2673,8 +2684,8 @@ __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the van
   // 2. the per-sprite fields, lanes = sprites, 64 slots at a time in list order: every lane reads its sprite (some
   //    fields live in HBM: one round trip for all of them instead of one per field per sprite), the moved-from slots
   //    are cleared, then every lane writes its sprite to its new slot
-  const moog_layout_t& L = e.L;
-  const bool alias = e.P->vel_alias != 0, facs = e.P->sprite_factors != 0;
+  const moog_layout_t& L = EL(e);
+  const bool alias = EP(e)->vel_alias != 0, facs = EP(e)->sprite_factors != 0;
   int j0 = s0;
   for (int base = s0; base < s1; base += 64) {
     const int t = base + e.lane;
@@ -2715,7 +2726,7 @@ __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the van
 }
 
 __device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the slot after the last entry
-  PProg P = e.P;
+  PProg P = EP(e);
   int n = 0;
   for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) n += ALIVE(s) ? 1 : 0;
   if (e.layer_hw && e.lane == 0)   // sizing hint for layer_capacity (the reference's lists are unbounded)
@@ -2723,7 +2734,7 @@ __device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the
   if (n >= P->layer_nslots[l]) {
     wsync();
     if (e.lane == 0) {
-      e.q[e.L.o_fault] |= MOOG_FAULT_LAYER_FULL;
+      e.q[EL(e).o_fault] |= MOOG_FAULT_LAYER_FULL;
       if (e.layer_hw) __hip_atomic_fetch_add(&e.layer_hw[MOOG_MAX_LAYERS + l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wsync();
@@ -2750,14 +2761,14 @@ __device__ inline int genop_count(Env& e, PGenop op);
 // compiled without them so that the common configs do not carry the sampler.
 template <bool DYN>
 __device__ inline void rule_leaf_step(Env& e, int ri) {
-  PProg P = e.P;
+  PProg P = EP(e);
   PRule R = &P->rules[ri];
   if constexpr (DYN) {
     if (R->kind == MOOG_RULE_DRAWS) {   // the np.random calls at the top of a config-local rule's step
       const double u0 = next_uniform(e);
       const double u1 = R->i0 > 1 ? next_uniform(e) : 0.0;
       wsync();
-      if (e.lane == 0) { e.f[e.L.o_rule + ri] = u0; e.f[e.L.o_rule2 + ri] = u1; }
+      if (e.lane == 0) { e.f[EL(e).o_rule + ri] = u0; e.f[EL(e).o_rule2 + ri] = u1; }
       wsync();
       return;
     }
@@ -2929,7 +2940,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             wsync();
             if (e.lane == 0) {
               if (op->fail_gracefully) { FLAGS(s) = 0; NV(s) = 0; }   // the generator returns what it has (:93-95)
-              else e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+              else e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
             }
             wsync();
             gave_up = op->fail_gracefully != 0;
@@ -2976,9 +2987,9 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       if (a < 0 || t < 0) break;   // (state[layer][0] of an empty layer raises IndexError in the reference)
       const double dx = PX(a) - PX(t), dy = PY(a) - PY(t);
       const double dist = npnorm(dx, dy);   // np.linalg.norm (1-D)
-      const double cnt = e.f[e.L.o_rule + ri];
+      const double cnt = e.f[EL(e).o_rule + ri];
       wsync();
-      if (e.lane == 0) e.f[e.L.o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
+      if (e.lane == 0) e.f[EL(e).o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
       wsync();
       break;
     }
@@ -3013,7 +3024,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       for (int s = p0; s < p1; ++s) if (ALIVE(s)) ++np_;
       if (np_ % 2 != 0) {
         wsync();
-        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_ODD_PORTALS;
+        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_ODD_PORTALS;
         wsync();
         break;
       }
@@ -3052,7 +3063,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       break;
     }
     case MOOG_RULE_BOOSTER: {
-      double cnt = e.f[e.L.o_rule + ri] - 1;
+      double cnt = e.f[EL(e).o_rule + ri] - 1;
       int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
       int agent = -1;
       for (int s = a0; s < a1 && agent < 0; ++s) if (ALIVE(s)) agent = s;
@@ -3080,7 +3091,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         }
       }
       wsync();
-      if (e.lane == 0) e.f[e.L.o_rule + ri] = cnt;
+      if (e.lane == 0) e.f[EL(e).o_rule + ri] = cnt;
       wsync();
       break;
     }
@@ -3090,13 +3101,13 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
 
 // rule.reset() of one table entry, without the random duration of a PHASE (rule_reset_tree draws it, in the reference's order)
 __device__ inline void rule_reset(Env& e, int ri) {
-  PRule R = &e.P->rules[ri];
+  PRule R = &EP(e)->rules[ri];
   wsync();
   if (R->kind == MOOG_RULE_PORTAL)
-    for (int s = e.lane; s < e.P->n_slots; s += 64) TELE_SET(s, TELE(s) & ~(1 << ri));
+    for (int s = e.lane; s < EP(e)->n_slots; s += 64) TELE_SET(s, TELE(s) & ~(1 << ri));
   wave_global_fence();
   if (e.lane == 0 && R->kind != MOOG_RULE_STATE_SLOT)   // (a state slot lives as long as the environment)
-    e.f[e.L.o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
+    e.f[EL(e).o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
   if (R->kind == MOOG_RULE_TIMED && R->op != 0) {   // a callable interval: drawn here, before the children are reset (timing.py:47)
@@ -3112,8 +3123,8 @@ __device__ inline void rule_reset(Env& e, int ri) {
     }
     wsync();
     if (e.lane == 0) {
-      e.f[e.L.o_rule + ri] = (R->op == 2) ? R->p0 : (double)(lo + k);
-      e.f[e.L.o_rule2 + ri] = width;
+      e.f[EL(e).o_rule + ri] = (R->op == 2) ? R->p0 : (double)(lo + k);
+      e.f[EL(e).o_rule2 + ri] = width;
     }
     wsync();
   }
@@ -3123,13 +3134,13 @@ __device__ inline void rule_reset(Env& e, int ri) {
 // self._duration()` comes last -- so a Phase with a random duration draws AFTER everything in its subtree has (a nested
 // random-duration Phase draws before the one that contains it).
 __device__ inline void rule_draw_duration(Env& e, int ri) {
-  PRule R = &e.P->rules[ri];
+  PRule R = &EP(e)->rules[ri];
   if (!(R->kind == MOOG_RULE_PHASE && R->op == 1)) return;
   const int lo = (int)R->p0, hi = (int)R->p2;
   int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
   if (k >= hi - lo) k = hi - lo - 1;
   wsync();
-  if (e.lane == 0) e.f[e.L.o_rule2 + ri] = (double)(lo + k);
+  if (e.lane == 0) e.f[EL(e).o_rule2 + ri] = (double)(lo + k);
   wsync();
 }
 
@@ -3137,7 +3148,7 @@ __device__ inline void rule_draw_duration(Env& e, int ri) {
 // whole subtree of a top-level rule is the contiguous run of entries that follows it (pre-order).  Scalars are reset in
 // that order; a subtree's duration is drawn when its last entry has been reset (post-order), innermost first.
 __device__ inline void rule_reset_tree(Env& e, int ri) {
-  PProg P = e.P;
+  PProg P = EP(e);
   int end = ri + 1;
   while (end < P->n_rules && P->rules[end].parent >= ri) ++end;
   for (int c = ri; c < end; ++c) {
@@ -3153,7 +3164,7 @@ __device__ inline void rule_reset_tree(Env& e, int ri) {
 // all(pred(s) ...) / any(pred(s) ...) over a layer, or expr(layer[0]) (conditions traced by
 // moog/_symbolic.py trace_state_condition; MOOG_COND_* and MOOG_RCOND_* share the numbering)
 __device__ inline double layer_condition(Env& e, int kind, int layer, int xoff) {
-  PProg P = e.P;
+  PProg P = EP(e);
   if (kind == MOOG_COND_STATE_EXPR) return eval_expr(e, xoff, 0, 0, nullptr, nullptr);   // (no sprite of its own: s0 / s1 unused)
   const int a0 = P->layer_slot0[layer], a1 = a0 + P->layer_nslots[layer];
   if (kind == MOOG_COND_FIRST_EXPR) {
@@ -3176,7 +3187,7 @@ __device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
   if (R->cond == MOOG_RCOND_BERNOULLI) return next_uniform(e) < p_bernoulli ? 1 : 0;
   if constexpr (!DYN) return 0;   // the other conditions make the host pick the DYN kernel
   if (R->cond == MOOG_RCOND_CONTACT_COUNT) {   // contact_rules.py:28-56
-    PProg P = e.P;
+    PProg P = EP(e);
     int n = 0;
     for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0]; ++s)
       if (ALIVE(s))
@@ -3187,7 +3198,7 @@ __device__ inline int rule_condition(Env& e, PRule R, double p_bernoulli) {
   if ((R->cond >= MOOG_RCOND_ALL_EXPR && R->cond <= MOOG_RCOND_FIRST_EXPR) || R->cond == MOOG_RCOND_STATE_EXPR)
     return (int)layer_condition(e, R->cond, R->l0, R->xfilter);
   if (R->cond == MOOG_RCOND_COUNT_EXPR) {   // accumulated per-sprite terms
-    PProg P = e.P;
+    PProg P = EP(e);
     double acc = 0;
     for (int s = P->layer_slot0[R->l0]; s < P->layer_slot0[R->l0] + P->layer_nslots[R->l0]; ++s)
       if (ALIVE(s)) acc += eval_expr(e, R->xfilter, s, s, nullptr, nullptr);
@@ -3207,7 +3218,7 @@ __device__ __forceinline__ bool is_combinator(int k) {
 struct RuleGate { int n, only, i0; bool first; };
 
 __device__ inline int n_children(Env& e, int ri) {
-  PProg P = e.P;
+  PProg P = EP(e);
   int n = 0;
   for (int c = ri + 1; c < P->n_rules && P->rules[c].parent >= ri; ++c) n += (P->rules[c].parent == ri) ? 1 : 0;
   return n;
@@ -3215,15 +3226,15 @@ __device__ inline int n_children(Env& e, int ri) {
 
 template <bool DYN>
 __device__ inline RuleGate rule_open(Env& e, int ri) {
-  PRule R = &e.P->rules[ri];
+  PRule R = &EP(e)->rules[ri];
   RuleGate g = {0, -1, 0, true};
-  const double st = e.f[e.L.o_rule + ri];
+  const double st = e.f[EL(e).o_rule + ri];
   if (R->kind == MOOG_RULE_TIMED) {
-    const double width = R->op != 0 ? e.f[e.L.o_rule2 + ri] : (R->p1 - R->p0);
+    const double width = R->op != 0 ? e.f[EL(e).o_rule2 + ri] : (R->p1 - R->p0);
     g.n = (st <= 0 && st + width > 0) ? 1 : 0;
     // the countdown happens after the children in the reference; they never read it
     wsync();
-    if (e.lane == 0) e.f[e.L.o_rule + ri] = st - 1;
+    if (e.lane == 0) e.f[EL(e).o_rule + ri] = st - 1;
     wsync();
   } else if (R->kind == MOOG_RULE_CONDITIONAL) {
     g.n = rule_condition<DYN>(e, R, R->p0);
@@ -3237,7 +3248,7 @@ __device__ inline RuleGate rule_open(Env& e, int ri) {
     if (g.only >= n_children(e, ri)) {
       g.n = 0;
       wsync();
-      if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_PHASE_END;
+      if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;
       wsync();
     }
   }
@@ -3246,15 +3257,15 @@ __device__ inline RuleGate rule_open(Env& e, int ri) {
 
 template <bool DYN>
 __device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
-  PProg P = e.P;
+  PProg P = EP(e);
   PRule R = &P->rules[ri];
   if (g.n == 0) return;
   if (R->kind == MOOG_RULE_PHASE) {
-    double st = e.f[e.L.o_rule + ri] + 1;
-    const double duration = (R->op == 1) ? e.f[e.L.o_rule2 + ri] : R->p0;
+    double st = e.f[EL(e).o_rule + ri] + 1;
+    const double duration = (R->op == 1) ? e.f[EL(e).o_rule2 + ri] : R->p0;
     if (st >= duration || (R->cond && rule_condition<DYN>(e, R, R->p1) != 0)) st = -1;
     wsync();
-    if (e.lane == 0) e.f[e.L.o_rule + ri] = st;
+    if (e.lane == 0) e.f[EL(e).o_rule + ri] = st;
     wsync();
   } else if (R->kind == MOOG_RULE_PHASE_SEQUENCE) {
     int k = 0, cur = -1;
@@ -3263,11 +3274,11 @@ __device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
       if (k == g.only) cur = c;
       ++k;
     }
-    if (cur >= 0 && e.f[e.L.o_rule + cur] < 0) {   // the current phase ended: move on
+    if (cur >= 0 && e.f[EL(e).o_rule + cur] < 0) {   // the current phase ended: move on
       wsync();
       if (e.lane == 0) {
-        e.f[e.L.o_rule + ri] = (double)(g.only + 1);
-        if (g.only + 1 >= k) e.q[e.L.o_fault] |= MOOG_FAULT_PHASE_END;   // self._phases[ind]: IndexError
+        e.f[EL(e).o_rule + ri] = (double)(g.only + 1);
+        if (g.only + 1 >= k) e.q[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;   // self._phases[ind]: IndexError
       }
       wsync();
     }
@@ -3284,7 +3295,7 @@ __device__ __forceinline__ bool child_selected(const RuleGate& g, int parent_kin
 // three explicit levels (no device recursion).
 template <bool DYN>
 __device__ inline void rule_step(Env& e, int ri) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const int k0 = P->rules[ri].kind;
   if (!is_combinator(k0)) { rule_leaf_step<DYN>(e, ri); return; }
   const int nr = P->n_rules;
@@ -3316,7 +3327,7 @@ __device__ inline void rule_step(Env& e, int ri) {
 
 // ---- tasks ---------------------------------------------------------------------------------
 __device__ inline bool task_condition(const Env& e, PTask T) {
-  PProg P = e.P;
+  PProg P = EP(e);
   int l = T->cond_layer;
   int a0 = P->layer_slot0[l], a1 = a0 + P->layer_nslots[l];
   if (T->cond == MOOG_COND_LAYER_EMPTY) {
@@ -3338,13 +3349,13 @@ __device__ inline bool task_condition_x(Env& e, PTask T) {
 
 template <bool DYN>
 __device__ inline double task_reward(Env& e, int step_count, int* should_reset) {
-  PProg P = e.P;
+  PProg P = EP(e);
   double reward = 0;
   int reward_t = 0;   // numpy dtype tag of the running sum (composite_task.py:36-40)
   int sr = ((double)step_count >= P->timeout_steps);
   for (int ti = 0; ti < P->n_tasks; ++ti) {
     PTask T = &P->tasks[ti];
-    double cnt = e.f[e.L.o_task + ti];
+    double cnt = e.f[EL(e).o_task + ti];
     double r = 0;
     int tsr = 0, rt = 0;
     if (T->kind == MOOG_TASK_CONTACT_REWARD) {
@@ -3391,7 +3402,7 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
       r = ((step_count + 1) % T->i0 == 0) ? T->p0 : 0;
     }
     wsync();
-    if (e.lane == 0) e.f[e.L.o_task + ti] = cnt;
+    if (e.lane == 0) e.f[EL(e).o_task + ti] = cnt;
     wsync();
     if (reward_t == 2 || rt == 2) { reward = reward + r; reward_t = 2; }
     else if (reward_t == 1 || rt == 1) { reward = (double)((float)reward + (float)r); reward_t = 1; }
@@ -3405,9 +3416,9 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
 // ---- action spaces ---------------------------------------------------------------------------
 // f32: the caller's actions are float32 (joystick.py:42-43): `scaling_factor * action` is then a float32 product
 __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, int grid_action, bool f32 = false) {
-  PProg P = e.P;
+  PProg P = EP(e);
   PAction A = (k == 0) ? &P->action : &P->more_actions[k - 1];
-  const int om = e.L.o_action + 2 * k;
+  const int om = EL(e).o_action + 2 * k;
   if (A->kind == MOOG_ACTION_SET_POSITION) {   // set_position.py:48-58 (`momentum` = inertia)
     for (int a = 0; a < A->n_layers; ++a) {
       const int l = A->layers[a];
@@ -3458,7 +3469,7 @@ __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, in
 // ---- reset path (sprite.py:261-424, distributions.py, sprite_generators.py:77-105) ----------
 template <bool X>   // X: computed shapes possible (rare-components kernels only)
 __device__ inline void create_sprite(Env& e, int s, const double* fac, int vel_f32, int angvel_f32) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const int sid = (int)fac[MOOG_FAC_SHAPE];
   const bool computed = X && sid < 0;   // MOOG_DIST_EXPR_SHAPE: the centred path is staged in the slot's vertex area
   PShape sh = &P->shapes[computed ? 0 : sid];
@@ -3573,11 +3584,11 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
   } else if (kind == MOOG_DIST_DISCRETE) {
     int idx = (int)(u * n_cand);
     if (idx >= n_cand) idx = n_cand - 1;
-    val = e.P->cand[cand_off + idx];
+    val = EP(e)->cand[cand_off + idx];
   } else if (kind == MOOG_DIST_MAZE_COORD) {   // factors read off the maze cell the sprite sits on (pacman.py:47-65, maze.py:98-111)
-    val = e.P->cand[cand_off + (n_cand ? e.cell_j : e.cell_i)];
+    val = EP(e)->cand[cand_off + (n_cand ? e.cell_j : e.cell_i)];
   } else if (kind == MOOG_DIST_MAZE_SHAPE) {
-    val = fa + (double)(e.cell_j * e.P->maze.size + e.cell_i);
+    val = fa + (double)(e.cell_j * EP(e)->maze.size + e.cell_i);
   }
 #pragma unroll
   for (int q = 0; q < MOOG_NUM_FACTORS; ++q) fac[q] = shfl_d(val, q);
@@ -3589,7 +3600,7 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
         if (fi >= MOOG_NUM_FACTORS) {
           const double uh = shfl_d(draws, kd);
           wsync();
-          if (e.lane == 0) e.f[e.L.o_hdraw + fi - MOOG_NUM_FACTORS] = uh;
+          if (e.lane == 0) e.f[EL(e).o_hdraw + fi - MOOG_NUM_FACTORS] = uh;
           wsync();
           ++kd;
         } else {
@@ -3654,7 +3665,7 @@ __device__ inline void fac_set(double* fac, int a, double v) {
 
 // numpy legacy choice(n, p): searchsorted(cumsum(p) / cumsum(p)[-1], u, side='right')
 __device__ inline int choice_p(Env& e, int poff, int n, double u) {
-  PProg P = e.P;
+  PProg P = EP(e);
   double last = 0;
   for (int i = 0; i < n; ++i) last = (i == 0) ? P->cand[poff] : last + P->cand[poff + i];
   double acc = 0;
@@ -3667,7 +3678,7 @@ __device__ inline int choice_p(Env& e, int poff, int n, double u) {
 }
 
 __device__ inline int dist_pred(Env& e, int off, int len, const double* fac, unsigned f32mask) {
-  PProg P = e.P;
+  PProg P = EP(e);
   unsigned stack = 0;
   for (int pc = off; pc < off + len; ++pc) {
     PDinstr I = &P->dcode[pc];
@@ -3697,7 +3708,7 @@ __device__ inline int dist_pred(Env& e, int off, int len, const double* fac, uns
 }
 
 __device__ inline void run_dist_program(Env& e, int pc, double* fac, unsigned& f32mask) {
-  PProg P = e.P;
+  PProg P = EP(e);
   int tries0 = 0, tries1 = 0;
   for (;;) {
     PDinstr I = &P->dcode[pc];
@@ -3729,7 +3740,7 @@ __device__ inline void run_dist_program(Env& e, int pc, double* fac, unsigned& f
       int t = (a == 0) ? ++tries0 : ++tries1;
       if (dist_pred(e, I->c, b, fac, f32mask) == I->d) { ++pc; }
       else if (t >= MOOG_DIST_MAX_TRIES) {
-        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_DIST_EXHAUSTED;
+        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_DIST_EXHAUSTED;
         ++pc;
       } else pc = (int)I->x;
     } else {
@@ -3782,7 +3793,7 @@ __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& ve
 // followed by loads need no barrier.  Draws are fetched up to 64 at a time (one Philox latency per batch).
 // maze_generators.py:96-171 generate_random_maze_matrix + np.flip(axis=0) -> rows in the record.
 __device__ inline void maze_generate(Env& e) {
-  PProg P = e.P;
+  PProg P = EP(e);
   const int n = P->maze.gen_size, N = P->maze.size;
   uint32_t* m = reinterpret_cast<uint32_t*>(e.rowm);   // [16] row masks of the size x size matrix (bit b of row a = wall)
   uint32_t* inl = m + MOOG_MAX_MAZE_GEN;               // [16] "is in closed_neighbors"
@@ -3861,7 +3872,7 @@ __device__ inline void maze_generate(Env& e) {
     const int a = (P->maze.flip ? N - 1 - r : r) - start;
     uint32_t bits = fullN;
     if (a >= 0 && a < n) bits = (fullN & ~(full << start)) | ((m[a] & full) << start);
-    if (e.lane == 0) e.q[e.L.o_maze + r] = (int32_t)bits;
+    if (e.lane == 0) e.q[EL(e).o_maze + r] = (int32_t)bits;
   }
   wsync();
   // rank -> cell tables for the one-sprite ops that follow (each used to re-scan the matrix: a quarter of a pacman
@@ -3895,7 +3906,7 @@ __device__ inline void maze_generate(Env& e) {
 
 // k-th (0-based) open cell of the maze in np.argwhere order (rows outer); -1 when there are fewer
 __device__ inline int maze_open_cell(const Env& e, int k) {
-  const int N = e.P->maze.size;
+  const int N = EP(e)->maze.size;
   const uint32_t fullN = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
   for (int i = 0; i < N; ++i) {
     uint32_t open = ~maze_row(e, i) & fullN;
@@ -3912,7 +3923,7 @@ __device__ inline int maze_open_cell(const Env& e, int k) {
 // maze.py:200-214 sample_distinct_open_points(k): the first k steps of a forward Fisher-Yates shuffle of the open
 // cells' ranks (make_golden.py _choice): the permutation is tracked as the few displaced entries only
 __device__ inline void maze_sample_points(Env& e, int k) {
-  const int N = e.P->maze.size;
+  const int N = EP(e)->maze.size;
   const uint32_t fullN = (N >= 32) ? 0xffffffffu : ((1u << N) - 1u);
   int n = 0;
   for (int i = 0; i < N; ++i) n += __popc(~maze_row(e, i) & fullN);
@@ -3940,7 +3951,7 @@ __device__ inline void maze_sample_points(Env& e, int k) {
       moved_pos[t] = upd ? -1 : j; moved_val[t] = vt;
       point = maze_open_cell(e, vj);
     } else { moved_pos[t] = -1; moved_val[t] = 0; }
-    if (e.lane == 0) e.q[e.L.o_maze + MOOG_MAX_MAZE + t] = point;
+    if (e.lane == 0) e.q[EL(e).o_maze + MOOG_MAX_MAZE + t] = point;
   }
   wsync();
 }
@@ -3948,7 +3959,7 @@ __device__ inline void maze_sample_points(Env& e, int k) {
 // the cell a one-sprite op sits on; false when the maze has no such cell (the slot stays dead)
 __device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
   int p = -1;
-  if (sel == MOOG_CELL_SAMPLED) p = e.q[e.L.o_maze + MOOG_MAX_MAZE + arg];
+  if (sel == MOOG_CELL_SAMPLED) p = e.q[EL(e).o_maze + MOOG_MAX_MAZE + arg];
   else if (e.cell_tab_n > 0) {   // the tables maze_generate left in LDS
     const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
     if (sel == MOOG_CELL_WALL_RANK) p = arg < e.cell_nw ? (int)tab[arg] : -1;
@@ -3956,7 +3967,7 @@ __device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
   }
   else if (sel == MOOG_CELL_OPEN_RANK) p = maze_open_cell(e, arg);   // np.argwhere(maze.maze == 0), pacman.py:62
   else {   // Maze.to_sprites: x (column) outer, y (row) inner, maze.py:101-103
-    const int N = e.P->maze.size;
+    const int N = EP(e)->maze.size;
     int seen = 0;
     for (int j = 0; j < N && p < 0; ++j) {
       uint32_t col = 0u;
@@ -3976,13 +3987,13 @@ __device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
 
 template <bool DYN>
 __device__ inline void run_genop(Env& e, int oi) {
-  PProg P = e.P;
+  PProg P = EP(e);
   PGenop op = &P->ops[oi];
   if (op->runtime) return;   // CreateSprites generators run at rule time
   constexpr bool FULL = DYN && (MOOG_WITH_MAZE != 0);   // maze ops and reset-time expressions: the m3 / m4 kernels only
   if constexpr (FULL) {
     // an alternative of a sample_generator runs only when it was the one picked (sprite_generators.py:131-154)
-    if (op->cond_hdraw > 0 && (int)e.f[e.L.o_hdraw + op->cond_hdraw - 1] != op->cond_value) return;
+    if (op->cond_hdraw > 0 && (int)e.f[EL(e).o_hdraw + op->cond_hdraw - 1] != op->cond_value) return;
     if (op->cell_sel == MOOG_CELL_CHOICE) {   // np.random.choice(generators, p=p)
       const int n = op->count_max, off = op->factors[0].cand_off;
       int idx = 0;
@@ -3995,7 +4006,7 @@ __device__ inline void run_genop(Env& e, int oi) {
         if (idx >= n) idx = n - 1;
       }
       wsync();
-      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = (double)idx;
+      if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = (double)idx;
       wsync();
       return;
     }
@@ -4007,29 +4018,29 @@ __device__ inline void run_genop(Env& e, int oi) {
       for (int tries = 0;; ++tries) {
         const double u = next_uniform(e);
         wsync();
-        if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = u;
+        if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = u;
         wsync();
         if (op->code_off < 0) break;   // (no rejection loop around it)
         if (eval_expr(e, op->code_off, 0, 0, nullptr, nullptr) != 0.0) break;
-        if (tries >= MOOG_DIST_MAX_TRIES) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+        if (tries >= MOOG_DIST_MAX_TRIES) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
       }
       return;
     }
     if (op->cell_sel == MOOG_CELL_SIMULATE) {   // the initializer's look-ahead: physics steps until one of its exits holds
       bbox_build_all(e);
-      const int K = uni(e.P->updates_per_env_step);
+      const int K = uni(EP(e)->updates_per_env_step);
       int exit_k = 0;
       for (int it = 0;; ++it) {
         wsync();
-        if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg + 1] = (double)it;   // `for step in range(n)`: the loop counter
+        if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg + 1] = (double)it;   // `for step in range(n)`: the loop counter
         wsync();
         exit_k = (int)eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
         if (exit_k != 0) break;
-        if (it >= op->count_max) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+        if (it >= op->count_max) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
         for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
       }
       wsync();
-      if (e.lane == 0) e.f[e.L.o_hdraw + op->cell_arg] = (double)exit_k;
+      if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = (double)exit_k;
       wsync();
       if (exit_k > 0 && exit_k < 31 && ((op->max_tries >> exit_k) & 1)) e.restart = 1;   // `return state_initializer()`
       return;
@@ -4041,10 +4052,10 @@ __device__ inline void run_genop(Env& e, int oi) {
     }
     if (op->cell_sel == MOOG_CELL_PSTATE) {   // a number the initializer keeps across episodes (never cleared by resets)
       const int ri = op->cell_arg;
-      const bool first = e.f[e.L.o_rule2 + ri] == 0.0;
+      const bool first = e.f[EL(e).o_rule2 + ri] == 0.0;
       const double v = first ? op->factors[0].a : eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
       wsync();
-      if (e.lane == 0) { e.f[e.L.o_rule + ri] = v; e.f[e.L.o_rule2 + ri] = 1.0; }
+      if (e.lane == 0) { e.f[EL(e).o_rule + ri] = v; e.f[EL(e).o_rule2 + ri] = 1.0; }
       wsync();
       return;
     }
@@ -4053,8 +4064,8 @@ __device__ inline void run_genop(Env& e, int oi) {
       const double v = eval_expr(e, op->code_off, 0, 0, &tag, nullptr);
       wsync();
       if (e.lane == 0) {
-        e.f[e.L.o_hdraw + op->cell_arg] = v;
-        if (op->count_min) e.f[e.L.o_hdraw + op->cell_arg + 1] = (double)tag;   // (np.copy keeps the dtype)
+        e.f[EL(e).o_hdraw + op->cell_arg] = v;
+        if (op->count_min) e.f[EL(e).o_hdraw + op->cell_arg + 1] = (double)tag;   // (np.copy keeps the dtype)
       }
       wsync();
       return;
@@ -4150,7 +4161,7 @@ __device__ inline void run_genop(Env& e, int oi) {
           if (graceful == 2) e.restart = 1;   // the config measures the result and starts over (red_green.py:152-155)
           return;
         }
-        if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
         wsync();
         break;
       }
@@ -4169,7 +4180,7 @@ __device__ inline void run_genop(Env& e, int oi) {
 // ~30 k cycles of dependent constant-memory reads on its own).  Needs the rank -> cell tables of this reset in LDS when
 // cells are selected by rank (otherwise the caller takes the ordinary path).
 __device__ inline void run_static_batch(Env& e, int oi0, int nb) {
-  PProg P = e.P;
+  PProg P = EP(e);
   wsync();
   if (e.lane < nb) {
     PGenop op = &P->ops[oi0 + e.lane];
@@ -4178,7 +4189,7 @@ __device__ inline void run_static_batch(Env& e, int oi0, int nb) {
     int ci = 0, cj = 0;
     if (op->cell_sel != MOOG_CELL_NONE) {
       int p = -1;
-      if (op->cell_sel == MOOG_CELL_SAMPLED) p = e.q[e.L.o_maze + MOOG_MAX_MAZE + op->cell_arg];
+      if (op->cell_sel == MOOG_CELL_SAMPLED) p = e.q[EL(e).o_maze + MOOG_MAX_MAZE + op->cell_arg];
       else {
         const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
         if (op->cell_sel == MOOG_CELL_WALL_RANK) p = op->cell_arg < e.cell_nw ? (int)tab[op->cell_arg] : -1;
@@ -4247,13 +4258,13 @@ __device__ inline void run_static_batch(Env& e, int oi0, int nb) {
 // environment.py:82-96
 template <bool DYN>
 __device__ inline void env_reset(Env& e) {
-  PProg P = e.P;
+  PProg P = EP(e);
   wsync();
   // sprites the config built outside its initializer are not rebuilt once the env has been reset before (program.born_rule)
-  bool born = P->born_rule > 0 && e.f[e.L.o_rule + P->born_rule - 1] != 0.0;
+  bool born = P->born_rule > 0 && e.f[EL(e).o_rule + P->born_rule - 1] != 0.0;
   // every episode draws from its own segment of the env's stream (counter = episode << 32 | draw): a reset's draws do not
   // depend on how many the previous episode took, so episode E + 1 can be built while E is running (the reset pool)
-  if (e.lane == 0) { e.q[e.L.o_rng + 1] = (int32_t)((uint32_t)e.q[e.L.o_rng + 1] + 1u); e.q[e.L.o_rng] = 0; }
+  if (e.lane == 0) { e.q[EL(e).o_rng + 1] = (int32_t)((uint32_t)e.q[EL(e).o_rng + 1] + 1u); e.q[EL(e).o_rng] = 0; }
   wsync();
   for (int attempt = 0;; ++attempt) {   // (an initializer may start over: `return state_initializer()`, red_green.py:155,203)
     for (int s = e.lane; s < P->n_slots; s += 64) {
@@ -4261,7 +4272,7 @@ __device__ inline void env_reset(Env& e) {
       FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s);
     }
     wave_global_fence();
-    if (e.lane == 0) { e.q[e.L.o_step_count] = 0; }
+    if (e.lane == 0) { e.q[EL(e).o_step_count] = 0; }
     wsync();
     if (born) bbox_build_all(e);   // the kept sprites' boxes (scratch, normally made when a sprite is built): the sampler tests against them
     e.restart = 0;
@@ -4281,16 +4292,16 @@ __device__ inline void env_reset(Env& e) {
       run_genop<DYN>(e, oi);
     }
     if (!e.restart) break;
-    if (attempt >= 10000) { if (e.lane == 0) e.q[e.L.o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+    if (attempt >= 10000) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
     // the sprites built outside the initializer exist from the first pass on: a second pass keeps them as a later episode does
     if (P->born_rule > 0) born = true;
   }
-  if (P->born_rule > 0) { wsync(); if (e.lane == 0) e.f[e.L.o_rule + P->born_rule - 1] = 1.0; wsync(); }
+  if (P->born_rule > 0) { wsync(); if (e.lane == 0) e.f[EL(e).o_rule + P->born_rule - 1] = 1.0; wsync(); }
   wave_global_fence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {
-    for (int t = 0; t < P->n_tasks; ++t) e.f[e.L.o_task + t] = DINF;
-    for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) e.f[e.L.o_action + k] = 0;
+    for (int t = 0; t < P->n_tasks; ++t) e.f[EL(e).o_task + t] = DINF;
+    for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) e.f[EL(e).o_action + k] = 0;
   }
   wsync();
   { PROF_T0;

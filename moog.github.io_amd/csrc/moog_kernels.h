@@ -65,6 +65,14 @@ __host__ __device__ inline HotLayout hot_layout(const moog_layout_t& G) {
   return h;   // o_color / o_opacity / o_shape keep their values: valid in LDS when nothing was cut
 }
 
+#ifdef MOOG_SPEC_PROGRAM_INC
+__device__ __forceinline__ moog_layout_t moog_spec_hot_layout_fn() {
+  moog_layout_t L;
+  moog_layout(&MOOG_SPEC_PROGRAM, &L);
+  return hot_layout(L).L;
+}
+#endif
+
 // =====================================================================================
 // record staging: HBM <-> LDS, 16 bytes per lane, coalesced
 // =====================================================================================
@@ -84,7 +92,7 @@ __device__ inline void load_record(const Env& e, const HotLayout& h, const moog_
     if (i < ia) dsti[i] = srci[i];
     else if (i >= ib) dsti[i - (ib - ia)] = srci[i];
   }
-  for (int i = e.lane; i < e.L.S; i += 64) e.voff[i] = e.P->slot_voff[i];
+  for (int i = e.lane; i < EL(e).S; i += 64) e.voff[i] = EP(e)->slot_voff[i];
   wsync();
 }
 
@@ -92,7 +100,7 @@ __device__ inline void store_record(const Env& e, const HotLayout& h, const moog
                                     double* gf, int32_t* gq, int32_t* fault_flag = nullptr) {
   wsync();
   if (fault_flag && e.lane == 0) {   // rare: tell the host without waiting for it to look at every record
-    const int32_t fw = e.q[e.L.o_fault];
+    const int32_t fw = e.q[EL(e).o_fault];
     if (fw) __hip_atomic_fetch_or(fault_flag, fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   double2* dst = reinterpret_cast<double2*>(gf);
@@ -234,15 +242,15 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
 struct RmSrcEnv {
   static constexpr bool kGlobalRecord = false;   // (the record is in LDS)
   const Env* e; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8 (KArgs::draw_vinfo)
-  __device__ __forceinline__ int flags(int s) const { return e->q[e->L.o_flags + s]; }
-  __device__ __forceinline__ int nv(int s) const { return e->q[e->L.o_nverts + s]; }
+  __device__ __forceinline__ int flags(int s) const { return e->q[EL(*e).o_flags + s]; }
+  __device__ __forceinline__ int nv(int s) const { return e->q[EL(*e).o_nverts + s]; }
   __device__ __forceinline__ int opa(int s) const { return static_cast<const int32_t*>(e->gopa)[s]; }
   __device__ __forceinline__ int voff(int s) const { return e->voff[s]; }
-  __device__ __forceinline__ int vcap(int s) const { return e->P->slot_vcap[s]; }
+  __device__ __forceinline__ int vcap(int s) const { return EP(*e)->slot_vcap[s]; }
   __device__ __forceinline__ double col(int s, int c) const { return static_cast<const double*>(e->gcol)[3 * s + c]; }
   __device__ __forceinline__ uint32_t vinfo(int idx) const { return vi[idx]; }
-  __device__ __forceinline__ const double* vbase() const { return &e->f[e->L.o_verts]; }
-  __device__ __forceinline__ const double* pos(int s) const { return &e->f[e->L.o_pos + 2 * s]; }
+  __device__ __forceinline__ const double* vbase() const { return &e->f[EL(*e).o_verts]; }
+  __device__ __forceinline__ const double* pos(int s) const { return &e->f[EL(*e).o_pos + 2 * s]; }
 };
 // Beside store_record: the frame the rasteriser is about to draw, from the record in LDS (what the reset path wrote straight
 // to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
@@ -258,7 +266,7 @@ __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, i
   RmEmitScratch sc;
   rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(e.cand) : reinterpret_cast<int32_t*>(e.bb), a.draw.slots, a.draw.ncopy, &sc);
   long long clk[5];
-  rm_emit(a.draw, src, env, e.lane, sc, e.L.TOTV, (a.dbg & 256) ? clk : nullptr);
+  rm_emit(a.draw, src, env, e.lane, sc, EL(e).TOTV, (a.dbg & 256) ? clk : nullptr);
   if ((a.dbg & 256) && e.lane == 0 && a.step_type) {   // (the emitter's cycles, and phase by phase: prefix | slots | vertex slots | items)
     a.step_type[env] = (int32_t)(clock64() - t_emit);
     if (a.discount) a.discount[env] = (double)(clk[1] - clk[0]) + 65536.0 * (double)(clk[2] - clk[1]);
@@ -287,7 +295,7 @@ __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, i
 // the per-slot words of two records (HBM layout) agree, for every slot the reset keeps
 __device__ inline bool pool_inputs_equal(const Env& e, const moog_layout_t& G, const double* af, const int32_t* aq,
                                          const double* bf, const int32_t* bq) {
-  PProg P = e.P;
+  PProg P = EP(e);
   bool same = true;
   const bool born = P->born_rule > 0;
   if (born) {
@@ -335,7 +343,7 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
   *held = 0;
   if (!a.pool_state || e.inj) return false;
   *held = 1;
-  const unsigned episode = (unsigned)e.q[e.L.o_rng + 1] + 1u;
+  const unsigned episode = (unsigned)e.q[EL(e).o_rng + 1] + 1u;
   int pick = -1, waited = 0;
   if (e.lane == 0) {
     __hip_atomic_store(&a.pool_lock[env], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -383,24 +391,24 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
     return false;
   }
   // what outlives a reset: sticky fault bits, the state slots (never reset; a reset that reads one is not eligible)
-  const int32_t fault = e.q[e.L.o_fault];
+  const int32_t fault = e.q[EL(e).o_fault];
   const int r = e.lane < a.L.R ? e.lane : 0;
-  const double keep = e.f[e.L.o_rule + r];
-  const double keep2 = e.L.o_rule2 >= 0 ? e.f[e.L.o_rule2 + r] : 0.0;
+  const double keep = e.f[EL(e).o_rule + r];
+  const double keep2 = EL(e).o_rule2 >= 0 ? e.f[EL(e).o_rule2 + r] : 0.0;
   wsync();
   load_record(e, a.H, a.L, post_f, post_q);
   if (a.H.f_cut1 > a.H.f_cut0)
     for (int i = a.H.f_cut0 + e.lane; i < a.H.f_cut1; i += 64) gf[i] = post_f[i];
   if (a.H.i_cut1 > a.H.i_cut0)
     for (int i = a.H.i_cut0 + e.lane; i < a.H.i_cut1; i += 64) gq[i] = post_q[i];
-  if (e.lane < a.L.R && e.P->rules[e.lane].kind == MOOG_RULE_STATE_SLOT) {
-    e.f[e.L.o_rule + e.lane] = keep;
-    if (e.L.o_rule2 >= 0) e.f[e.L.o_rule2 + e.lane] = keep2;
+  if (e.lane < a.L.R && EP(e)->rules[e.lane].kind == MOOG_RULE_STATE_SLOT) {
+    e.f[EL(e).o_rule + e.lane] = keep;
+    if (EL(e).o_rule2 >= 0) e.f[EL(e).o_rule2 + e.lane] = keep2;
   }
   wave_global_fence();
   wsync();
   if (e.lane == 0) {
-    e.q[e.L.o_fault] |= fault;
+    e.q[EL(e).o_fault] |= fault;
     __hip_atomic_store(&a.pool_state[rec], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the lock keeps the fills off the env)
     atomicAdd(&a.pool_stats[0], 1ull);
     if (waited) atomicAdd(&a.pool_stats[3], 1ull);
@@ -499,13 +507,13 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   }
 #endif
   load_record(e, a.H, a.L, gf, gq);
-  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
+  if (e.inj && e.lane == 0) e.q[EL(e).o_rng + 2] = 0;
   wsync();
   env_reset<true>(e);
   wsync();
 #if MOOG_WITH_MAZE
   if (a.mode == MODE_FILL) {
-    if (e.lane == 0) e.q[e.L.o_reset_next] = 0;
+    if (e.lane == 0) e.q[EL(e).o_reset_next] = 0;
     store_record(e, a.H, a.L, gf, gq, nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record (and what the reset wrote straight to HBM) before the flag
     if (e.lane == 0) __hip_atomic_store(&a.pool_state[rec], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   }
 #endif
   if (e.lane == 0) {
-    e.q[e.L.o_reset_next] = 0;
+    e.q[EL(e).o_reset_next] = 0;
     if (a.reward) a.reward[env] = __builtin_nan("");
     if (a.discount) a.discount[env] = __builtin_nan("");
     if (a.step_type) a.step_type[env] = 0;
@@ -632,10 +640,10 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   { PROF_T0; load_record(e, a.H, a.L, gf, gq); PROF_ADD(e, 9); }
-  if (e.inj && e.lane == 0) e.q[e.L.o_rng + 2] = 0;
+  if (e.inj && e.lane == 0) e.q[EL(e).o_rng + 2] = 0;
   wsync();
 #ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
-  if (a.mode == MODE_STEP && uni(e.q[e.L.o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
+  if (a.mode == MODE_STEP && uni(e.q[EL(e).o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
     int held = 0;
     if (!(DYN && pool_adopt(e, a, env, gf, gq, &held))) {   // (the next episode may be waiting in the reset pool)
       if (DYN && a.late_mask) {
@@ -650,7 +658,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
     }
     wsync();
     if (e.lane == 0) {
-      e.q[e.L.o_reset_next] = 0;
+      e.q[EL(e).o_reset_next] = 0;
       if (a.reward) a.reward[env] = __builtin_nan("");
       if (a.discount) a.discount[env] = __builtin_nan("");
       if (a.step_type) a.step_type[env] = 0;
@@ -709,16 +717,16 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   }
   { PROF_T0; for (int k = 0; k < K; ++k) apply_physics<DYN>(e); PROF_ADD(e, 6); }
   SEC(e, SEC_TASK);
-  int sc = e.q[e.L.o_step_count] + 1;
+  int sc = e.q[EL(e).o_step_count] + 1;
   wsync();
-  if (e.lane == 0) e.q[e.L.o_step_count] = sc;
+  if (e.lane == 0) e.q[EL(e).o_step_count] = sc;
   wsync();
   int sr = 0;
   double r;
   { PROF_T0; r = task_reward<DYN>(e, sc, &sr); PROF_ADD(e, 11); }
   wsync();
   if (e.lane == 0) {
-    if (sr) e.q[e.L.o_reset_next] = 1;
+    if (sr) e.q[EL(e).o_reset_next] = 1;
     if (a.reward) a.reward[env] = r;
     if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
