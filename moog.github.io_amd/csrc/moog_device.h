@@ -129,21 +129,44 @@ struct Env {
 // How the step path reads the env's program and (hot) layout.  Generic kernels: members of the env's descriptor (registers; scratch
 // memory in the functions the every-component variants leave out of line).  Program-specialised builds: the constants themselves --
 // also inside those out-of-line functions, which took them by reference through the descriptor until round 6.
+#define CAND_CAP 128   // entries of the candidate list (collision_same_layer / collision_layer_pair); a full list is consumed before the scan continues
+// Likewise the places of the record and of the scratch areas in the wavefront's LDS: pointers in the descriptor for the generic
+// kernels; in a specialised build -- the step kernel only, one wavefront per workgroup, the record at the start of its LDS --
+// addresses the compiler knows (an LDS access then carries its offset as an immediate and the pointers cost no registers).
 #ifdef MOOG_SPEC_PROGRAM_INC
 __device__ __forceinline__ moog_layout_t moog_spec_hot_layout_fn();   // (moog_kernels.h: hot_layout(moog_layout(&MOOG_SPEC_PROGRAM)).L, folded at compile time)
+extern __shared__ __attribute__((aligned(16))) unsigned char moog_lds[];
 #define EL(e_) (moog_spec_hot_layout_fn())
 #define EP(e_) ((PProg)&MOOG_SPEC_PROGRAM)
+#define MOOG_SPEC_LDS_Q ((size_t)EL(0).f64_per_env * 8)
+#define MOOG_SPEC_LDS_BB (MOOG_SPEC_LDS_Q + (size_t)EL(0).i32_per_env * 4)
+#define MOOG_SPEC_LDS_VOFF (MOOG_SPEC_LDS_BB + (size_t)EL(0).S * 32)
+#define MOOG_SPEC_LDS_CAND (MOOG_SPEC_LDS_VOFF + (size_t)((EL(0).S + 3) & ~3) * 4)
+#define EF(e_) (reinterpret_cast<double*>(moog_lds))
+#define EQ(e_) (reinterpret_cast<int32_t*>(moog_lds + MOOG_SPEC_LDS_Q))
+#define EBB(e_) (reinterpret_cast<float*>(moog_lds + MOOG_SPEC_LDS_BB))
+#define EVOFF(e_) (reinterpret_cast<int32_t*>(moog_lds + MOOG_SPEC_LDS_VOFF))
+#define ECAND(e_) (reinterpret_cast<uint16_t*>(moog_lds + MOOG_SPEC_LDS_CAND))
+#define ELST(e_) (reinterpret_cast<uint8_t*>(moog_lds + MOOG_SPEC_LDS_CAND + CAND_CAP * 2))
+#define EROWM(e_) (reinterpret_cast<unsigned long long*>(moog_lds + MOOG_SPEC_LDS_CAND + CAND_CAP * 2 + 128))
 #else
 #define EL(e_) ((e_).L)
 #define EP(e_) ((e_).P)
+#define EF(e_) ((e_).f)
+#define EQ(e_) ((e_).q)
+#define EBB(e_) ((e_).bb)
+#define EVOFF(e_) ((e_).voff)
+#define ECAND(e_) ((e_).cand)
+#define ELST(e_) ((e_).lst)
+#define EROWM(e_) ((e_).rowm)
 #endif
-#define PX(s) (e.f[EL(e).o_pos + 2 * (s)])
-#define PY(s) (e.f[EL(e).o_pos + 2 * (s) + 1])
-#define VELX(s) (e.f[EL(e).o_vel + 2 * (s)])
-#define VELY(s) (e.f[EL(e).o_vel + 2 * (s) + 1])
-#define ANG(s) (e.f[EL(e).o_angle + (s)])
-#define ANGV(s) (e.f[EL(e).o_angvel + (s)])
-#define MASS(s) (e.f[EL(e).o_mass + (s)])
+#define PX(s) (EF(e)[EL(e).o_pos + 2 * (s)])
+#define PY(s) (EF(e)[EL(e).o_pos + 2 * (s) + 1])
+#define VELX(s) (EF(e)[EL(e).o_vel + 2 * (s)])
+#define VELY(s) (EF(e)[EL(e).o_vel + 2 * (s) + 1])
+#define ANG(s) (EF(e)[EL(e).o_angle + (s)])
+#define ANGV(s) (EF(e)[EL(e).o_angvel + (s)])
+#define MASS(s) (EF(e)[EL(e).o_mass + (s)])
 // Colours, opacities, shape ids and Portal bits may live in HBM (fields the step path hardly ever touches): they are READ
 // through COL / OPAC / SHAPEID / TELE and WRITTEN through the *_SET forms.
 #define COL(s, c) (static_cast<const double*>(e.gcol)[3 * (s) + (c)])
@@ -151,19 +174,19 @@ __device__ __forceinline__ moog_layout_t moog_spec_hot_layout_fn();   // (moog_k
 #define OPAC_SET(s, v) (e.gopa[(s)] = (v))
 #define SHAPEID_SET(s, v) (e.gshape[(s)] = (v))
 #define TELE_SET(s, v) (e.gtele[(s)] = (v))
-#define INER(s, c) (e.f[EL(e).o_inertia + 2 * (s) + (c)])
-#define MAXR(s) (e.f[EL(e).o_maxr + (s)])
-#define FLAGS(s) (e.q[EL(e).o_flags + (s)])
-#define NV(s) (e.q[EL(e).o_nverts + (s)])
+#define INER(s, c) (EF(e)[EL(e).o_inertia + 2 * (s) + (c)])
+#define MAXR(s) (EF(e)[EL(e).o_maxr + (s)])
+#define FLAGS(s) (EQ(e)[EL(e).o_flags + (s)])
+#define NV(s) (EQ(e)[EL(e).o_nverts + (s)])
 #define OPAC(s) (static_cast<const int32_t*>(e.gopa)[(s)])
 #define SHAPEID(s) (static_cast<const int32_t*>(e.gshape)[(s)])
 #define TELE(s) (static_cast<const int32_t*>(e.gtele)[(s)])
-#define VERT(s) (&e.f[EL(e).o_verts + 2 * e.voff[s]])
+#define VERT(s) (&EF(e)[EL(e).o_verts + 2 * EVOFF(e)[s]])
 #define ALIVE(s) (FLAGS(s) & MOOG_F_ALIVE)
-#define VALIAS(s) (e.q[EL(e).o_valias + (s)])
-#define SCALE(s) (e.f[EL(e).o_scale + (s)])
-#define ASPECT(s) (e.f[EL(e).o_aspect + (s)])
-#define FMASK(s) (e.q[EL(e).o_fmask + (s)])
+#define VALIAS(s) (EQ(e)[EL(e).o_valias + (s)])
+#define SCALE(s) (EF(e)[EL(e).o_scale + (s)])
+#define ASPECT(s) (EF(e)[EL(e).o_aspect + (s)])
+#define FMASK(s) (EQ(e)[EL(e).o_fmask + (s)])
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
@@ -254,13 +277,13 @@ __device__ inline void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
 
 // Wave-uniform draw: every lane computes the same value; lane 0 commits the counter.
 __device__ inline double next_uniform(Env& e) {
-  int32_t* r = &e.q[EL(e).o_rng];
+  int32_t* r = &EQ(e)[EL(e).o_rng];
   double out;
   if (e.inj) {
     int cur = r[2];
     if (cur >= e.inj_n) {
       wsync();
-      if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+      if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
       wsync();
       return 0.0;
     }
@@ -284,7 +307,7 @@ __device__ inline double next_uniform(Env& e) {
 // The next n <= 64 draws at once: lane i returns draw i (the same values, in the same order, that n calls
 // of next_uniform would give); the counter advances by n.  One Philox latency instead of n.
 __device__ inline double next_uniforms_lanes(Env& e, int n) {
-  int32_t* r = &e.q[EL(e).o_rng];
+  int32_t* r = &EQ(e)[EL(e).o_rng];
   if (e.inj) {
     const int cur = r[2];
     const int have = e.inj_n - cur < n ? (e.inj_n - cur < 0 ? 0 : e.inj_n - cur) : n;
@@ -292,7 +315,7 @@ __device__ inline double next_uniforms_lanes(Env& e, int n) {
     wsync();
     if (e.lane == 0) {
       r[2] = cur + have;
-      if (have < n) e.q[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
+      if (have < n) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_INJECT_UNDERRUN;
     }
     wsync();
     return out;
@@ -433,15 +456,15 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
   int total = ca * cb;
   if (total > 0) {
     unsigned long long below = (1ull << e.lane) - 1ull;
-    if (ka) e.lst[__popcll(ma & below)] = (uint8_t)e.lane;
-    if (kb) e.lst[64 + __popcll(mb & below)] = (uint8_t)e.lane;
+    if (ka) ELST(e)[__popcll(ma & below)] = (uint8_t)e.lane;
+    if (kb) ELST(e)[64 + __popcll(mb & below)] = (uint8_t)e.lane;
     wsync();
     for (int base = 0; base < total; base += 64) {
       int idx = base + e.lane;
       int hit = 0;
       if (idx < total) {
         int ia = (total <= 4096) ? div_small(idx, cb) : idx / cb, ib = idx - ia * cb;
-        int i = e.lst[ia], j = e.lst[64 + ib];
+        int i = ELST(e)[ia], j = ELST(e)[64 + ib];
         int i2 = (i + 1 == na) ? 0 : i + 1, j2 = (j + 1 == nb) ? 0 : j + 1;
         double x11 = va[2 * i], y11 = va[2 * i + 1], x12 = va[2 * i2], y12 = va[2 * i2 + 1];
         double x21 = vb[2 * j], y21 = vb[2 * j + 1], x22 = vb[2 * j2], y22 = vb[2 * j2 + 1];
@@ -487,7 +510,7 @@ __device__ inline bool paths_intersect_filled(const Env& e, const double* va, in
 // It is built from the cached vertices at kernel start and after every rotation, and
 // follows translations.  On the headline workload the two diagonal axes reject 44 % of
 // the pairs whose axis-aligned boxes overlap.
-#define BB(s, c) (e.bb[8 * (s) + (c)])
+#define BB(s, c) (EBB(e)[8 * (s) + (c)])
 
 // extents of n vertices (one lane scans them); NaN vertices are ignored by fmin / fmax
 __device__ inline void dop_scan(const double* v, int n, float* d) {
@@ -640,7 +663,7 @@ __device__ inline int narrow_reject_prefix_g(const Env& e, int c, int n) {
   constexpr int SH = G == 16 ? 4 : 5;
   constexpr unsigned long long GM = G == 16 ? 0xffffull : 0xffffffffull;
   const int grp = e.lane >> SH, gl = e.lane & (G - 1);
-  const int pr0 = grp < n ? (int)e.cand[c + grp] : CAND_SKIP;
+  const int pr0 = grp < n ? (int)ECAND(e)[c + grp] : CAND_SKIP;
   const bool active = pr0 != CAND_SKIP;
   const int pr = active ? pr0 : 0;
   const int s0 = pr >> 8, t = pr & 255;
@@ -863,7 +886,7 @@ __device__ inline void integrate_all(Env& e, double dt) {
     const int s = sbase + sl;
     const bool on = sl < nchunk && mode != 0 && !((coopm >> sl) & 1ull);
     const int n = on ? NV(s) : 0;
-    double* v = on ? VERT(s) : &e.f[EL(e).o_verts];
+    double* v = on ? VERT(s) : &EF(e)[EL(e).o_verts];
     const float FINF = __builtin_inff();
     float l0 = FINF, l1 = FINF, l2 = FINF, l3 = FINF, h0 = -FINF, h1 = -FINF, h2 = -FINF, h3 = -FINF;
     int fin = 0;
@@ -1264,7 +1287,7 @@ __device__ inline void collide_without_update_angle_vel(Env& e, int s0, int s1, 
   double nn = npnorm(nx, ny);
   if (!(fabs(nn - 1.) <= 1e-4 + 1e-5 * 1.)) {
     wsync();
-    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
     wsync();
     return;
   }
@@ -1482,7 +1505,7 @@ __device__ inline void resolve_contact(Env& e, double elasticity, int s0, int s1
     PX(s0) = n0x; PY(s0) = n0y;
     dop_translate(&BB(s0, 0), d0x, d0y);
     if (symmetric) { PX(s1) = n1x; PY(s1) = n1y; dop_translate(&BB(s1, 0), d1x, d1y); }
-    if (fault) e.q[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
+    if (fault) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_BAD_NORMAL;
     else {
       VELX(s0) = v0x; VELY(s0) = v0y; VELX(s1) = v1x; VELY(s1) = v1y;
       if (upd) { ANGV(s0) = w0; ANGV(s1) = w1; }
@@ -1774,7 +1797,7 @@ __device__ inline void tether(Env& e, PCorr C, int ci) {
         for (int s = P->layer_slot0[l]; s < P->layer_slot0[l] + P->layer_nslots[l]; ++s) cnt += ALIVE(s) ? 1 : 0;
         if (a == 0) cnt0 = cnt; else same = same && (cnt == cnt0);
       }
-      if (!same) e.q[EL(e).o_fault] |= MOOG_FAULT_TETHER_ZIP;
+      if (!same) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_TETHER_ZIP;
       else for (int i = 0; i < cnt0; ++i) tether_group(e, C, i, K, 1 + ci * MOOG_MAX_SLOTS + i);
     }
   }
@@ -1847,7 +1870,7 @@ __device__ __forceinline__ bool broad_pair(const Env& e, int s0, int t, bool in)
 // maze.py:107-112 open_vertex(i, j): inside the matrix and not a wall (maze[j, i])
 // row j of the maze: a program constant, or (a maze drawn per reset) part of the env's record
 __device__ __forceinline__ uint32_t maze_row(const Env& e, int j) {
-  return EP(e)->maze.random ? (uint32_t)e.q[EL(e).o_maze + j] : EP(e)->maze.rows[j];
+  return EP(e)->maze.random ? (uint32_t)EQ(e)[EL(e).o_maze + j] : EP(e)->maze.rows[j];
 }
 __device__ __forceinline__ int maze_open(const Env& e, long i, long j) {
   const int n = EP(e)->maze.size;
@@ -1956,11 +1979,11 @@ __device__ inline void maze_walk_det_step(Env& e, PForce F, int s, int K) {
   const bool entering = d_next_cur > d_int_cur && d_next_cur > d_int_next;
   if (!(entering || (vel[0] == 0. && vel[1] == 0.))) return;
   const int slot = EL(e).o_rule + uni(F->symmetric);
-  const int k = (int)e.f[slot];
+  const int k = (int)EF(e)[slot];
   if (k >= F->i1) return;   // `if len(self._step_velocities) > 0`
   const double new0 = P->cand[F->i0 + 2 * k], new1 = P->cand[F->i0 + 2 * k + 1];
   wsync();
-  if (e.lane == 0) e.f[slot] = (double)(k + 1);
+  if (e.lane == 0) EF(e)[slot] = (double)(k + 1);
   wsync();
   if (np_sign(new0) != np_sign(vel[0]) || np_sign(new1) != np_sign(vel[1])) {   // np.any(np.sign(new) != np.sign(velocity))
     const double t0 = (1 - MAZE_EPS) * vel[0] + new0, t1 = (1 - MAZE_EPS) * vel[1] + new1;
@@ -1984,7 +2007,7 @@ __device__ inline bool maze_affordances(Env& e, const double pos[2], double aff[
   aff[0][0] = aff[0][1] = aff[1][0] = aff[1][1] = 0;
   if (!on[0] && !on[1]) {
     wsync();
-    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
+    if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
     wsync();
     return false;
   }
@@ -2006,7 +2029,7 @@ template <int D>
 __device__ inline bool maze_new_velocity(Env& e, double pos[2], double v[2], double aff[2][2], int axis, double out[2]) {
   if constexpr (D == 0) {
     wsync();
-    if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
+    if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_OFF_GRID;
     wsync();
     out[0] = out[1] = 0;
     return false;
@@ -2102,7 +2125,6 @@ __device__ inline void maze_physics(Env& e, PCorr C) {
 // reference order, to a candidate list in LDS.  The list is consumed sequentially by
 // the narrow phase; as soon as a pair actually overlapped (state may have changed),
 // the list is discarded and rebuilt from the next pair on.
-#define CAND_CAP 128   // list entries; a full list is consumed before the scan continues
 __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int a1, int b0,
                                             int b1, int K) {
   const int nB = b1 - b0, total = (a1 - a0) * nB;
@@ -2125,7 +2147,7 @@ __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int 
       const int s0 = a0 + i, t = b0 + (idc - i * nB);
       const bool cand = broad_pair(e, s0, t, in);
       uint64_t m = __ballot(cand);
-      if (cand) e.cand[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (uint16_t)((s0 << 8) | t);
+      if (cand) ECAND(e)[count + __popcll(m & ((1ull << e.lane) - 1ull))] = (uint16_t)((s0 << 8) | t);
       count += __popcll(m);
       scanned += 64;
     }
@@ -2151,7 +2173,7 @@ __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int 
         c += r;
         if (rr & 1024) { --c; continue; }   // all of them: on to the next batch
       }
-      int pr = uni((int)e.cand[c]);
+      int pr = uni((int)ECAND(e)[c]);
       int s0 = pr >> 8, t = pr & 255;
       if (!(e.dbg & 4) && collision_step(e, F, s0, t, K, known_hit)) {
         start = (s0 - a0) * nB + (t - b0) + 1;
@@ -2176,7 +2198,7 @@ __device__ inline void collision_layer_pair(Env& e, const CollP& F, int a0, int 
 __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int a1, int K) {
   const int n = a1 - a0, total = n * n;
   const int symmetric = F.symmetric;
-  unsigned long long* rowm = e.rowm;
+  unsigned long long* rowm = EROWM(e);
   wsync();
   PROF_T0;
   SEC(e, SEC_BROAD);
@@ -2238,7 +2260,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
       while (b) {
         const int j = __ffsll((long long)b) - 1;
         b &= b - 1ull;
-        e.cand[pos++] = (uint16_t)(((a0 + e.lane) << 8) | (a0 + j));
+        ECAND(e)[pos++] = (uint16_t)(((a0 + e.lane) << 8) | (a0 + j));
       }
     }
     const int scanned = rows_end >= n ? total : rows_end * n;
@@ -2255,7 +2277,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
       // the list builder's per-row offsets alive for this instead cost the kernels that carry the expression VM 200 VGPR spills
       const int key = (tk << 8) | s0k;
       for (int k = e.lane; k < count; k += 64)
-        if ((int)e.cand[k] == key) e.cand[k] = (uint16_t)CAND_SKIP;
+        if ((int)ECAND(e)[k] == key) ECAND(e)[k] = (uint16_t)CAND_SKIP;
     };
     for (int c = 0; c < count; ++c) {
       bool known_hit = false, proper_hit = false;
@@ -2275,7 +2297,7 @@ __device__ inline void collision_same_layer(Env& e, const CollP& F, int a0, int 
         c += r;
         if (rr & 1024) { --c; continue; }   // all of them: on to the next batch
       }
-      const int pr = uni((int)e.cand[c]);
+      const int pr = uni((int)ECAND(e)[c]);
       if (pr == CAND_SKIP) continue;
       const int s0 = pr >> 8, t = pr & 255;
       if (e.dbg & 4) continue;
@@ -2423,8 +2445,8 @@ __device__ inline float np_remf(float a, float b) {
 template <bool LANES>
 __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_tag, XStores* st) {
   PProg P = EP(e);
-  double* vbase = LANES ? e.xstack + e.lane : reinterpret_cast<double*>(e.cand);   // [MOOG_X_STACK] (x 64 lanes, lane-minor)
-  double* sv = reinterpret_cast<double*>(e.cand) + MOOG_X_STACK;   // pending writes [13] (never with LANES)
+  double* vbase = LANES ? e.xstack + e.lane : reinterpret_cast<double*>(ECAND(e));   // [MOOG_X_STACK] (x 64 lanes, lane-minor)
+  double* sv = reinterpret_cast<double*>(ECAND(e)) + MOOG_X_STACK;   // pending writes [13] (never with LANES)
   constexpr int VS = LANES ? 64 : 1;
 #define v(i) vbase[(i) * VS]
   unsigned tags = 0;                                       // 2 bits per stack entry
@@ -2438,14 +2460,14 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
     if (op == MOOG_X_END) break;
     if (op == MOOG_X_CONST) { v(n) = I->x; XSETTAG(n, I->b ? 2 : 0); ++n; continue; }
     if (op == MOOG_X_ATTR) { int t; v(n) = xattr(e, I->b ? s1 : s0, I->a, t); XSETTAG(n, t); ++n; continue; }
-    if (op == MOOG_X_RULE_STATE) { v(n) = e.f[EL(e).o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE) { v(n) = EF(e)[EL(e).o_rule + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_SLOT_CONST) { v(n) = P->cand[I->a + (I->b ? s1 : s0)]; XSETTAG(n, 0); ++n; continue; }   // sprite.metadata[key]
-    if (op == MOOG_X_RULE_STATE2) { v(n) = e.f[EL(e).o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
+    if (op == MOOG_X_RULE_STATE2) { v(n) = EF(e)[EL(e).o_rule2 + I->a]; XSETTAG(n, 0); ++n; continue; }
     if (op == MOOG_X_ARG) { v(n) = e.xarg; XSETTAG(n, 2); ++n; continue; }   // (np.linalg.norm gives a float64)
     // (values an initializer left in the record, read by rules and tasks while stepping: in every kernel, so that a program
     //  whose INITIALIZER needs the kernels that carry every component can still be stepped by the others, moog_kernels.h
     //  "late reset")
-    if (op == MOOG_X_HDRAW_T) { v(n) = e.f[EL(e).o_hdraw + I->a]; XSETTAG(n, (int)e.f[EL(e).o_hdraw + I->a + 1]); ++n; continue; }
+    if (op == MOOG_X_HDRAW_T) { v(n) = EF(e)[EL(e).o_hdraw + I->a]; XSETTAG(n, (int)EF(e)[EL(e).o_hdraw + I->a + 1]); ++n; continue; }
     if (op == MOOG_X_ZIP_ATTR) {   // the sprite at s0's list position in layer b (zip(state[A], state[B]) in a config-local rule)
       const int partner = P->layer_slot0[I->b] + (s0 - P->layer_slot0[P->slot_layer[s0]]);
       int t; v(n) = xattr(e, partner, I->a, t); XSETTAG(n, t); ++n; continue;
@@ -2460,7 +2482,7 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
       XSETTAG(n - 1, any2 ? 2 : (any1 ? 1 : 0));
       continue;
     }
-    if (op == MOOG_X_HDRAW) { v(n) = e.f[EL(e).o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
+    if (op == MOOG_X_HDRAW) { v(n) = EF(e)[EL(e).o_hdraw + I->a]; XSETTAG(n, 0); ++n; continue; }   // (a Python float)
     if (op == MOOG_X_SLOT_ATTR) { int t; v(n) = xattr(e, I->b, I->a, t); XSETTAG(n, t); ++n; continue; }
     if constexpr (MOOG_WITH_MAZE != 0) {   // expressions about the sprite being created: only in the kernels that carry every component
       if (op == MOOG_X_STORE_VERT) {   // raw shape coordinate -> the vertex area of the slot being created
@@ -2469,7 +2491,7 @@ __device__ inline double eval_expr_t(Env& e, int off, int s0, int s1, int* out_t
         continue;
       }
       if (op == MOOG_X_FACTOR) {   // a factor of the sprite being created, staged by sample_factors
-        v(n) = reinterpret_cast<const double*>(e.lst)[I->a];
+        v(n) = reinterpret_cast<const double*>(ELST(e))[I->a];
         XSETTAG(n, ((e.fac_f32 >> I->a) & 1u) ? 1 : 0);
         ++n;
         continue;
@@ -2595,7 +2617,7 @@ __device__ __forceinline__ void apply_light_stores(Env& e, int s, const XStores&
 __device__ inline void run_modifier(Env& e, int xmod, int s) {
   XStores st = {0u, 0u};
   eval_expr(e, xmod, s, s, nullptr, &st);
-  const double* sv = reinterpret_cast<const double*>(e.cand) + MOOG_X_STACK;
+  const double* sv = reinterpret_cast<const double*>(ECAND(e)) + MOOG_X_STACK;
   auto tag = [&](int a) { return (int)((st.tags >> (2 * a)) & 3u); };
   auto has = [&](int a) { return ((st.mask >> a) & 1u) != 0; };
   const double vx = sv[MOOG_XA_XVEL], vy = sv[MOOG_XA_YVEL], w = sv[MOOG_XA_ANGVEL];
@@ -2630,9 +2652,9 @@ __device__ inline void move_slot(Env& e, int dst, int src) {
   if (e.lane < 8) BB(dst, e.lane) = BB(src, e.lane);
   if (e.lane == 0) {
     for (int c = 0; c < 2; ++c) {
-      e.f[L.o_pos + 2 * dst + c] = e.f[L.o_pos + 2 * src + c];
-      e.f[L.o_vel + 2 * dst + c] = e.f[L.o_vel + 2 * src + c];
-      e.f[L.o_inertia + 2 * dst + c] = e.f[L.o_inertia + 2 * src + c];
+      EF(e)[L.o_pos + 2 * dst + c] = EF(e)[L.o_pos + 2 * src + c];
+      EF(e)[L.o_vel + 2 * dst + c] = EF(e)[L.o_vel + 2 * src + c];
+      EF(e)[L.o_inertia + 2 * dst + c] = EF(e)[L.o_inertia + 2 * src + c];
     }
     for (int c = 0; c < 3; ++c) COL_SET(dst, c, COL(src, c));
     ANG(dst) = ANG(src); ANGV(dst) = ANGV(src); MASS(dst) = MASS(src); MAXR(dst) = MAXR(src);
@@ -2696,9 +2718,9 @@ __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the van
     double px = 0, py = 0, vx = 0, vy = 0, ix = 0, iy = 0, c0 = 0, c1 = 0, c2 = 0, an = 0, av = 0, ms = 0, mr = 0, sc = 0, as = 0;
     int fl = 0, nv = 0, op = 0, sh = 0, te = 0, va = 0, fm = 0;
     if (mv) {
-      px = e.f[L.o_pos + 2 * t]; py = e.f[L.o_pos + 2 * t + 1];
-      vx = e.f[L.o_vel + 2 * t]; vy = e.f[L.o_vel + 2 * t + 1];
-      ix = e.f[L.o_inertia + 2 * t]; iy = e.f[L.o_inertia + 2 * t + 1];
+      px = EF(e)[L.o_pos + 2 * t]; py = EF(e)[L.o_pos + 2 * t + 1];
+      vx = EF(e)[L.o_vel + 2 * t]; vy = EF(e)[L.o_vel + 2 * t + 1];
+      ix = EF(e)[L.o_inertia + 2 * t]; iy = EF(e)[L.o_inertia + 2 * t + 1];
       c0 = COL(t, 0); c1 = COL(t, 1); c2 = COL(t, 2);
       an = ANG(t); av = ANGV(t); ms = MASS(t); mr = MAXR(t);
       fl = FLAGS(t); nv = NV(t); op = OPAC(t); sh = SHAPEID(t); te = TELE(t);
@@ -2710,9 +2732,9 @@ __device__ inline void layer_compact(Env& e, int l) {   // list.pop() of the van
     if (mv) { FLAGS(t) = 0; NV(t) = 0; }
     wsync();
     if (mv) {
-      e.f[L.o_pos + 2 * dst] = px; e.f[L.o_pos + 2 * dst + 1] = py;
-      e.f[L.o_vel + 2 * dst] = vx; e.f[L.o_vel + 2 * dst + 1] = vy;
-      e.f[L.o_inertia + 2 * dst] = ix; e.f[L.o_inertia + 2 * dst + 1] = iy;
+      EF(e)[L.o_pos + 2 * dst] = px; EF(e)[L.o_pos + 2 * dst + 1] = py;
+      EF(e)[L.o_vel + 2 * dst] = vx; EF(e)[L.o_vel + 2 * dst + 1] = vy;
+      EF(e)[L.o_inertia + 2 * dst] = ix; EF(e)[L.o_inertia + 2 * dst + 1] = iy;
       COL_SET(dst, 0, c0); COL_SET(dst, 1, c1); COL_SET(dst, 2, c2);
       ANG(dst) = an; ANGV(dst) = av; MASS(dst) = ms; MAXR(dst) = mr;
       FLAGS(dst) = fl; NV(dst) = nv; OPAC_SET(dst, op); SHAPEID_SET(dst, sh); TELE_SET(dst, te);
@@ -2734,7 +2756,7 @@ __device__ inline int layer_append_slot(Env& e, int l) {   // list.append(): the
   if (n >= P->layer_nslots[l]) {
     wsync();
     if (e.lane == 0) {
-      e.q[EL(e).o_fault] |= MOOG_FAULT_LAYER_FULL;
+      EQ(e)[EL(e).o_fault] |= MOOG_FAULT_LAYER_FULL;
       if (e.layer_hw) __hip_atomic_fetch_add(&e.layer_hw[MOOG_MAX_LAYERS + l], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     wsync();
@@ -2768,7 +2790,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       const double u0 = next_uniform(e);
       const double u1 = R->i0 > 1 ? next_uniform(e) : 0.0;
       wsync();
-      if (e.lane == 0) { e.f[EL(e).o_rule + ri] = u0; e.f[EL(e).o_rule2 + ri] = u1; }
+      if (e.lane == 0) { EF(e)[EL(e).o_rule + ri] = u0; EF(e)[EL(e).o_rule2 + ri] = u1; }
       wsync();
       return;
     }
@@ -2833,7 +2855,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       if (first < 0) return;
       XStores st = {0u, 0u};
       eval_expr(e, R->xmod, first, first, nullptr, &st);
-      const double* sv = reinterpret_cast<const double*>(e.cand) + MOOG_X_STACK;
+      const double* sv = reinterpret_cast<const double*>(ECAND(e)) + MOOG_X_STACK;
       const double vx = sv[MOOG_XA_XVEL], vy = sv[MOOG_XA_YVEL], w = sv[MOOG_XA_ANGVEL], m = sv[MOOG_XA_MASS];
       const double c0 = sv[MOOG_XA_C0], c1 = sv[MOOG_XA_C1], c2 = sv[MOOG_XA_C2], op = sv[MOOG_XA_OPACITY];
       wsync();
@@ -2940,7 +2962,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
             wsync();
             if (e.lane == 0) {
               if (op->fail_gracefully) { FLAGS(s) = 0; NV(s) = 0; }   // the generator returns what it has (:93-95)
-              else e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+              else EQ(e)[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
             }
             wsync();
             gave_up = op->fail_gracefully != 0;
@@ -2987,9 +3009,9 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       if (a < 0 || t < 0) break;   // (state[layer][0] of an empty layer raises IndexError in the reference)
       const double dx = PX(a) - PX(t), dy = PY(a) - PY(t);
       const double dist = npnorm(dx, dy);   // np.linalg.norm (1-D)
-      const double cnt = e.f[EL(e).o_rule + ri];
+      const double cnt = EF(e)[EL(e).o_rule + ri];
       wsync();
-      if (e.lane == 0) e.f[EL(e).o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
+      if (e.lane == 0) EF(e)[EL(e).o_rule + ri] = dist < R->p0 ? cnt + 1 : 0;
       wsync();
       break;
     }
@@ -3024,7 +3046,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       for (int s = p0; s < p1; ++s) if (ALIVE(s)) ++np_;
       if (np_ % 2 != 0) {
         wsync();
-        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_ODD_PORTALS;
+        if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_ODD_PORTALS;
         wsync();
         break;
       }
@@ -3063,7 +3085,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
       break;
     }
     case MOOG_RULE_BOOSTER: {
-      double cnt = e.f[EL(e).o_rule + ri] - 1;
+      double cnt = EF(e)[EL(e).o_rule + ri] - 1;
       int a0 = P->layer_slot0[R->l0], a1 = a0 + P->layer_nslots[R->l0];
       int agent = -1;
       for (int s = a0; s < a1 && agent < 0; ++s) if (ALIVE(s)) agent = s;
@@ -3091,7 +3113,7 @@ __device__ inline void rule_leaf_step(Env& e, int ri) {
         }
       }
       wsync();
-      if (e.lane == 0) e.f[EL(e).o_rule + ri] = cnt;
+      if (e.lane == 0) EF(e)[EL(e).o_rule + ri] = cnt;
       wsync();
       break;
     }
@@ -3107,7 +3129,7 @@ __device__ inline void rule_reset(Env& e, int ri) {
     for (int s = e.lane; s < EP(e)->n_slots; s += 64) TELE_SET(s, TELE(s) & ~(1 << ri));
   wave_global_fence();
   if (e.lane == 0 && R->kind != MOOG_RULE_STATE_SLOT)   // (a state slot lives as long as the environment)
-    e.f[EL(e).o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
+    EF(e)[EL(e).o_rule + ri] = (R->kind == MOOG_RULE_TIMED) ? R->p0 :   // timing.py:47
         ((R->kind == MOOG_RULE_PHASE || R->kind == MOOG_RULE_PHASE_SEQUENCE || R->kind == MOOG_RULE_FIXATION) ? 0.0 : DINF);
   wsync();
   if (R->kind == MOOG_RULE_TIMED && R->op != 0) {   // a callable interval: drawn here, before the children are reset (timing.py:47)
@@ -3123,8 +3145,8 @@ __device__ inline void rule_reset(Env& e, int ri) {
     }
     wsync();
     if (e.lane == 0) {
-      e.f[EL(e).o_rule + ri] = (R->op == 2) ? R->p0 : (double)(lo + k);
-      e.f[EL(e).o_rule2 + ri] = width;
+      EF(e)[EL(e).o_rule + ri] = (R->op == 2) ? R->p0 : (double)(lo + k);
+      EF(e)[EL(e).o_rule2 + ri] = width;
     }
     wsync();
   }
@@ -3140,7 +3162,7 @@ __device__ inline void rule_draw_duration(Env& e, int ri) {
   int k = (int)(next_uniform(e) * (hi - lo));   // np.random.randint(lo, hi)
   if (k >= hi - lo) k = hi - lo - 1;
   wsync();
-  if (e.lane == 0) e.f[EL(e).o_rule2 + ri] = (double)(lo + k);
+  if (e.lane == 0) EF(e)[EL(e).o_rule2 + ri] = (double)(lo + k);
   wsync();
 }
 
@@ -3228,13 +3250,13 @@ template <bool DYN>
 __device__ inline RuleGate rule_open(Env& e, int ri) {
   PRule R = &EP(e)->rules[ri];
   RuleGate g = {0, -1, 0, true};
-  const double st = e.f[EL(e).o_rule + ri];
+  const double st = EF(e)[EL(e).o_rule + ri];
   if (R->kind == MOOG_RULE_TIMED) {
-    const double width = R->op != 0 ? e.f[EL(e).o_rule2 + ri] : (R->p1 - R->p0);
+    const double width = R->op != 0 ? EF(e)[EL(e).o_rule2 + ri] : (R->p1 - R->p0);
     g.n = (st <= 0 && st + width > 0) ? 1 : 0;
     // the countdown happens after the children in the reference; they never read it
     wsync();
-    if (e.lane == 0) e.f[EL(e).o_rule + ri] = st - 1;
+    if (e.lane == 0) EF(e)[EL(e).o_rule + ri] = st - 1;
     wsync();
   } else if (R->kind == MOOG_RULE_CONDITIONAL) {
     g.n = rule_condition<DYN>(e, R, R->p0);
@@ -3248,7 +3270,7 @@ __device__ inline RuleGate rule_open(Env& e, int ri) {
     if (g.only >= n_children(e, ri)) {
       g.n = 0;
       wsync();
-      if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;
+      if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;
       wsync();
     }
   }
@@ -3261,11 +3283,11 @@ __device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
   PRule R = &P->rules[ri];
   if (g.n == 0) return;
   if (R->kind == MOOG_RULE_PHASE) {
-    double st = e.f[EL(e).o_rule + ri] + 1;
-    const double duration = (R->op == 1) ? e.f[EL(e).o_rule2 + ri] : R->p0;
+    double st = EF(e)[EL(e).o_rule + ri] + 1;
+    const double duration = (R->op == 1) ? EF(e)[EL(e).o_rule2 + ri] : R->p0;
     if (st >= duration || (R->cond && rule_condition<DYN>(e, R, R->p1) != 0)) st = -1;
     wsync();
-    if (e.lane == 0) e.f[EL(e).o_rule + ri] = st;
+    if (e.lane == 0) EF(e)[EL(e).o_rule + ri] = st;
     wsync();
   } else if (R->kind == MOOG_RULE_PHASE_SEQUENCE) {
     int k = 0, cur = -1;
@@ -3274,11 +3296,11 @@ __device__ inline void rule_close(Env& e, int ri, const RuleGate& g) {
       if (k == g.only) cur = c;
       ++k;
     }
-    if (cur >= 0 && e.f[EL(e).o_rule + cur] < 0) {   // the current phase ended: move on
+    if (cur >= 0 && EF(e)[EL(e).o_rule + cur] < 0) {   // the current phase ended: move on
       wsync();
       if (e.lane == 0) {
-        e.f[EL(e).o_rule + ri] = (double)(g.only + 1);
-        if (g.only + 1 >= k) e.q[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;   // self._phases[ind]: IndexError
+        EF(e)[EL(e).o_rule + ri] = (double)(g.only + 1);
+        if (g.only + 1 >= k) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_PHASE_END;   // self._phases[ind]: IndexError
       }
       wsync();
     }
@@ -3355,7 +3377,7 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
   int sr = ((double)step_count >= P->timeout_steps);
   for (int ti = 0; ti < P->n_tasks; ++ti) {
     PTask T = &P->tasks[ti];
-    double cnt = e.f[EL(e).o_task + ti];
+    double cnt = EF(e)[EL(e).o_task + ti];
     double r = 0;
     int tsr = 0, rt = 0;
     if (T->kind == MOOG_TASK_CONTACT_REWARD) {
@@ -3402,7 +3424,7 @@ __device__ inline double task_reward(Env& e, int step_count, int* should_reset) 
       r = ((step_count + 1) % T->i0 == 0) ? T->p0 : 0;
     }
     wsync();
-    if (e.lane == 0) e.f[EL(e).o_task + ti] = cnt;
+    if (e.lane == 0) EF(e)[EL(e).o_task + ti] = cnt;
     wsync();
     if (reward_t == 2 || rt == 2) { reward = reward + r; reward_t = 2; }
     else if (reward_t == 1 || rt == 1) { reward = (double)((float)reward + (float)r); reward_t = 1; }
@@ -3429,7 +3451,7 @@ __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, in
     }
     return;
   }
-  double m0 = e.f[om], m1 = e.f[om + 1];
+  double m0 = EF(e)[om], m1 = EF(e)[om + 1];
   if (A->kind == MOOG_ACTION_JOYSTICK) {
     double ax = ax_in, ay = A->constrained_lr ? 0. : ay_in;
     m0 *= A->momentum; m1 *= A->momentum;
@@ -3447,7 +3469,7 @@ __device__ inline void action_step(Env& e, int k, double ax_in, double ay_in, in
   if (m1 < -sc) m1 = -sc;
   if (m1 > sc) m1 = sc;
   wsync();
-  if (e.lane == 0) { e.f[om] = m0; e.f[om + 1] = m1; }
+  if (e.lane == 0) { EF(e)[om] = m0; EF(e)[om + 1] = m1; }
   wsync();
   for (int a = 0; a < A->n_layers; ++a) {
     int l = A->layers[a];
@@ -3600,7 +3622,7 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
         if (fi >= MOOG_NUM_FACTORS) {
           const double uh = shfl_d(draws, kd);
           wsync();
-          if (e.lane == 0) e.f[EL(e).o_hdraw + fi - MOOG_NUM_FACTORS] = uh;
+          if (e.lane == 0) EF(e)[EL(e).o_hdraw + fi - MOOG_NUM_FACTORS] = uh;
           wsync();
           ++kd;
         } else {
@@ -3623,7 +3645,7 @@ __device__ inline void sample_factors(Env& e, PGenop op, double* fac) {
     wsync();
 #pragma unroll
     for (int q = 0; q < MOOG_NUM_FACTORS; ++q) {
-      if (e.lane == 0) reinterpret_cast<double*>(e.lst)[q] = fac[q];
+      if (e.lane == 0) reinterpret_cast<double*>(ELST(e))[q] = fac[q];
     }
     f32m = e.flat_f32;
     wsync();
@@ -3740,7 +3762,7 @@ __device__ inline void run_dist_program(Env& e, int pc, double* fac, unsigned& f
       int t = (a == 0) ? ++tries0 : ++tries1;
       if (dist_pred(e, I->c, b, fac, f32mask) == I->d) { ++pc; }
       else if (t >= MOOG_DIST_MAX_TRIES) {
-        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_DIST_EXHAUSTED;
+        if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_DIST_EXHAUSTED;
         ++pc;
       } else pc = (int)I->x;
     } else {
@@ -3795,7 +3817,7 @@ __device__ inline void sample_op_factors(Env& e, PGenop op, double* fac, int& ve
 __device__ inline void maze_generate(Env& e) {
   PProg P = EP(e);
   const int n = P->maze.gen_size, N = P->maze.size;
-  uint32_t* m = reinterpret_cast<uint32_t*>(e.rowm);   // [16] row masks of the size x size matrix (bit b of row a = wall)
+  uint32_t* m = reinterpret_cast<uint32_t*>(EROWM(e));   // [16] row masks of the size x size matrix (bit b of row a = wall)
   uint32_t* inl = m + MOOG_MAX_MAZE_GEN;               // [16] "is in closed_neighbors"
   uint8_t* list = reinterpret_cast<uint8_t*>(inl + MOOG_MAX_MAZE_GEN);   // [256] closed_neighbors as a << 4 | b
   const uint32_t full = (n >= 32) ? 0xffffffffu : ((1u << n) - 1u);
@@ -3872,7 +3894,7 @@ __device__ inline void maze_generate(Env& e) {
     const int a = (P->maze.flip ? N - 1 - r : r) - start;
     uint32_t bits = fullN;
     if (a >= 0 && a < n) bits = (fullN & ~(full << start)) | ((m[a] & full) << start);
-    if (e.lane == 0) e.q[EL(e).o_maze + r] = (int32_t)bits;
+    if (e.lane == 0) EQ(e)[EL(e).o_maze + r] = (int32_t)bits;
   }
   wsync();
   // rank -> cell tables for the one-sprite ops that follow (each used to re-scan the matrix: a quarter of a pacman
@@ -3880,7 +3902,7 @@ __device__ inline void maze_generate(Env& e) {
   // outer) behind them, as i << 8 | j, in the scratch the generator no longer needs.  Lanes = cells.
   e.cell_tab_n = 0;
   if (N * N <= 256) {
-    unsigned short* tab = reinterpret_cast<unsigned short*>(e.rowm);
+    unsigned short* tab = reinterpret_cast<unsigned short*>(EROWM(e));
     int nw = 0;
     for (int c0 = 0; c0 < N * N; c0 += 64) {
       const int c = c0 + e.lane;
@@ -3951,7 +3973,7 @@ __device__ inline void maze_sample_points(Env& e, int k) {
       moved_pos[t] = upd ? -1 : j; moved_val[t] = vt;
       point = maze_open_cell(e, vj);
     } else { moved_pos[t] = -1; moved_val[t] = 0; }
-    if (e.lane == 0) e.q[EL(e).o_maze + MOOG_MAX_MAZE + t] = point;
+    if (e.lane == 0) EQ(e)[EL(e).o_maze + MOOG_MAX_MAZE + t] = point;
   }
   wsync();
 }
@@ -3959,9 +3981,9 @@ __device__ inline void maze_sample_points(Env& e, int k) {
 // the cell a one-sprite op sits on; false when the maze has no such cell (the slot stays dead)
 __device__ inline bool maze_select_cell(Env& e, int sel, int arg) {
   int p = -1;
-  if (sel == MOOG_CELL_SAMPLED) p = e.q[EL(e).o_maze + MOOG_MAX_MAZE + arg];
+  if (sel == MOOG_CELL_SAMPLED) p = EQ(e)[EL(e).o_maze + MOOG_MAX_MAZE + arg];
   else if (e.cell_tab_n > 0) {   // the tables maze_generate left in LDS
-    const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
+    const unsigned short* tab = reinterpret_cast<const unsigned short*>(EROWM(e));
     if (sel == MOOG_CELL_WALL_RANK) p = arg < e.cell_nw ? (int)tab[arg] : -1;
     else p = arg < e.cell_tab_n - e.cell_nw ? (int)tab[e.cell_nw + arg] : -1;
   }
@@ -3993,7 +4015,7 @@ __device__ inline void run_genop(Env& e, int oi) {
   constexpr bool FULL = DYN && (MOOG_WITH_MAZE != 0);   // maze ops and reset-time expressions: the m3 / m4 kernels only
   if constexpr (FULL) {
     // an alternative of a sample_generator runs only when it was the one picked (sprite_generators.py:131-154)
-    if (op->cond_hdraw > 0 && (int)e.f[EL(e).o_hdraw + op->cond_hdraw - 1] != op->cond_value) return;
+    if (op->cond_hdraw > 0 && (int)EF(e)[EL(e).o_hdraw + op->cond_hdraw - 1] != op->cond_value) return;
     if (op->cell_sel == MOOG_CELL_CHOICE) {   // np.random.choice(generators, p=p)
       const int n = op->count_max, off = op->factors[0].cand_off;
       int idx = 0;
@@ -4006,7 +4028,7 @@ __device__ inline void run_genop(Env& e, int oi) {
         if (idx >= n) idx = n - 1;
       }
       wsync();
-      if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = (double)idx;
+      if (e.lane == 0) EF(e)[EL(e).o_hdraw + op->cell_arg] = (double)idx;
       wsync();
       return;
     }
@@ -4018,11 +4040,11 @@ __device__ inline void run_genop(Env& e, int oi) {
       for (int tries = 0;; ++tries) {
         const double u = next_uniform(e);
         wsync();
-        if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = u;
+        if (e.lane == 0) EF(e)[EL(e).o_hdraw + op->cell_arg] = u;
         wsync();
         if (op->code_off < 0) break;   // (no rejection loop around it)
         if (eval_expr(e, op->code_off, 0, 0, nullptr, nullptr) != 0.0) break;
-        if (tries >= MOOG_DIST_MAX_TRIES) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+        if (tries >= MOOG_DIST_MAX_TRIES) { if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
       }
       return;
     }
@@ -4032,15 +4054,15 @@ __device__ inline void run_genop(Env& e, int oi) {
       int exit_k = 0;
       for (int it = 0;; ++it) {
         wsync();
-        if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg + 1] = (double)it;   // `for step in range(n)`: the loop counter
+        if (e.lane == 0) EF(e)[EL(e).o_hdraw + op->cell_arg + 1] = (double)it;   // `for step in range(n)`: the loop counter
         wsync();
         exit_k = (int)eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
         if (exit_k != 0) break;
-        if (it >= op->count_max) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+        if (it >= op->count_max) { if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
         for (int k = 0; k < K; ++k) apply_physics<DYN>(e);
       }
       wsync();
-      if (e.lane == 0) e.f[EL(e).o_hdraw + op->cell_arg] = (double)exit_k;
+      if (e.lane == 0) EF(e)[EL(e).o_hdraw + op->cell_arg] = (double)exit_k;
       wsync();
       if (exit_k > 0 && exit_k < 31 && ((op->max_tries >> exit_k) & 1)) e.restart = 1;   // `return state_initializer()`
       return;
@@ -4052,10 +4074,10 @@ __device__ inline void run_genop(Env& e, int oi) {
     }
     if (op->cell_sel == MOOG_CELL_PSTATE) {   // a number the initializer keeps across episodes (never cleared by resets)
       const int ri = op->cell_arg;
-      const bool first = e.f[EL(e).o_rule2 + ri] == 0.0;
+      const bool first = EF(e)[EL(e).o_rule2 + ri] == 0.0;
       const double v = first ? op->factors[0].a : eval_expr(e, op->code_off, 0, 0, nullptr, nullptr);
       wsync();
-      if (e.lane == 0) { e.f[EL(e).o_rule + ri] = v; e.f[EL(e).o_rule2 + ri] = 1.0; }
+      if (e.lane == 0) { EF(e)[EL(e).o_rule + ri] = v; EF(e)[EL(e).o_rule2 + ri] = 1.0; }
       wsync();
       return;
     }
@@ -4064,8 +4086,8 @@ __device__ inline void run_genop(Env& e, int oi) {
       const double v = eval_expr(e, op->code_off, 0, 0, &tag, nullptr);
       wsync();
       if (e.lane == 0) {
-        e.f[EL(e).o_hdraw + op->cell_arg] = v;
-        if (op->count_min) e.f[EL(e).o_hdraw + op->cell_arg + 1] = (double)tag;   // (np.copy keeps the dtype)
+        EF(e)[EL(e).o_hdraw + op->cell_arg] = v;
+        if (op->count_min) EF(e)[EL(e).o_hdraw + op->cell_arg + 1] = (double)tag;   // (np.copy keeps the dtype)
       }
       wsync();
       return;
@@ -4161,7 +4183,7 @@ __device__ inline void run_genop(Env& e, int oi) {
           if (graceful == 2) e.restart = 1;   // the config measures the result and starts over (red_green.py:152-155)
           return;
         }
-        if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
+        if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED;
         wsync();
         break;
       }
@@ -4189,9 +4211,9 @@ __device__ inline void run_static_batch(Env& e, int oi0, int nb) {
     int ci = 0, cj = 0;
     if (op->cell_sel != MOOG_CELL_NONE) {
       int p = -1;
-      if (op->cell_sel == MOOG_CELL_SAMPLED) p = e.q[EL(e).o_maze + MOOG_MAX_MAZE + op->cell_arg];
+      if (op->cell_sel == MOOG_CELL_SAMPLED) p = EQ(e)[EL(e).o_maze + MOOG_MAX_MAZE + op->cell_arg];
       else {
-        const unsigned short* tab = reinterpret_cast<const unsigned short*>(e.rowm);
+        const unsigned short* tab = reinterpret_cast<const unsigned short*>(EROWM(e));
         if (op->cell_sel == MOOG_CELL_WALL_RANK) p = op->cell_arg < e.cell_nw ? (int)tab[op->cell_arg] : -1;
         else p = op->cell_arg < e.cell_tab_n - e.cell_nw ? (int)tab[e.cell_nw + op->cell_arg] : -1;
       }
@@ -4261,10 +4283,10 @@ __device__ inline void env_reset(Env& e) {
   PProg P = EP(e);
   wsync();
   // sprites the config built outside its initializer are not rebuilt once the env has been reset before (program.born_rule)
-  bool born = P->born_rule > 0 && e.f[EL(e).o_rule + P->born_rule - 1] != 0.0;
+  bool born = P->born_rule > 0 && EF(e)[EL(e).o_rule + P->born_rule - 1] != 0.0;
   // every episode draws from its own segment of the env's stream (counter = episode << 32 | draw): a reset's draws do not
   // depend on how many the previous episode took, so episode E + 1 can be built while E is running (the reset pool)
-  if (e.lane == 0) { e.q[EL(e).o_rng + 1] = (int32_t)((uint32_t)e.q[EL(e).o_rng + 1] + 1u); e.q[EL(e).o_rng] = 0; }
+  if (e.lane == 0) { EQ(e)[EL(e).o_rng + 1] = (int32_t)((uint32_t)EQ(e)[EL(e).o_rng + 1] + 1u); EQ(e)[EL(e).o_rng] = 0; }
   wsync();
   for (int attempt = 0;; ++attempt) {   // (an initializer may start over: `return state_initializer()`, red_green.py:155,203)
     for (int s = e.lane; s < P->n_slots; s += 64) {
@@ -4272,7 +4294,7 @@ __device__ inline void env_reset(Env& e) {
       FLAGS(s) = 0; NV(s) = 0; TELE_SET(s, 0); vel_unshare(e, s);
     }
     wave_global_fence();
-    if (e.lane == 0) { e.q[EL(e).o_step_count] = 0; }
+    if (e.lane == 0) { EQ(e)[EL(e).o_step_count] = 0; }
     wsync();
     if (born) bbox_build_all(e);   // the kept sprites' boxes (scratch, normally made when a sprite is built): the sampler tests against them
     e.restart = 0;
@@ -4292,16 +4314,16 @@ __device__ inline void env_reset(Env& e) {
       run_genop<DYN>(e, oi);
     }
     if (!e.restart) break;
-    if (attempt >= 10000) { if (e.lane == 0) e.q[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
+    if (attempt >= 10000) { if (e.lane == 0) EQ(e)[EL(e).o_fault] |= MOOG_FAULT_SAMPLER_EXHAUSTED; break; }
     // the sprites built outside the initializer exist from the first pass on: a second pass keeps them as a later episode does
     if (P->born_rule > 0) born = true;
   }
-  if (P->born_rule > 0) { wsync(); if (e.lane == 0) e.f[EL(e).o_rule + P->born_rule - 1] = 1.0; wsync(); }
+  if (P->born_rule > 0) { wsync(); if (e.lane == 0) EF(e)[EL(e).o_rule + P->born_rule - 1] = 1.0; wsync(); }
   wave_global_fence();   // create_sprite wrote colours / opacity / shape ids to HBM; rules read them
   wsync();
   if (e.lane == 0) {
-    for (int t = 0; t < P->n_tasks; ++t) e.f[EL(e).o_task + t] = DINF;
-    for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) e.f[EL(e).o_action + k] = 0;
+    for (int t = 0; t < P->n_tasks; ++t) EF(e)[EL(e).o_task + t] = DINF;
+    for (int k = 0; k < 2 * (P->n_actions > 1 ? P->n_actions : 1); ++k) EF(e)[EL(e).o_action + k] = 0;
   }
   wsync();
   { PROF_T0;

@@ -79,20 +79,20 @@ __device__ __forceinline__ moog_layout_t moog_spec_hot_layout_fn() {
 __device__ inline void load_record(const Env& e, const HotLayout& h, const moog_layout_t& G,
                                    const double* gf, const int32_t* gq) {
   const double2* src = reinterpret_cast<const double2*>(gf);
-  double2* dst = reinterpret_cast<double2*>(e.f);
+  double2* dst = reinterpret_cast<double2*>(EF(e));
   const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
   for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
     if (i < fa) dst[i] = src[i];
     else if (i >= fb) dst[i - (fb - fa)] = src[i];
   }
   const int4* srci = reinterpret_cast<const int4*>(gq);
-  int4* dsti = reinterpret_cast<int4*>(e.q);
+  int4* dsti = reinterpret_cast<int4*>(EQ(e));
   const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
   for (int i = e.lane; i < G.i32_per_env / 4; i += 64) {
     if (i < ia) dsti[i] = srci[i];
     else if (i >= ib) dsti[i - (ib - ia)] = srci[i];
   }
-  for (int i = e.lane; i < EL(e).S; i += 64) e.voff[i] = EP(e)->slot_voff[i];
+  for (int i = e.lane; i < EL(e).S; i += 64) EVOFF(e)[i] = EP(e)->slot_voff[i];
   wsync();
 }
 
@@ -100,14 +100,14 @@ __device__ inline void store_record(const Env& e, const HotLayout& h, const moog
                                     double* gf, int32_t* gq, int32_t* fault_flag = nullptr) {
   wsync();
   if (fault_flag && e.lane == 0) {   // rare: tell the host without waiting for it to look at every record
-    const int32_t fw = e.q[EL(e).o_fault];
+    const int32_t fw = EQ(e)[EL(e).o_fault];
     if (fw) __hip_atomic_fetch_or(fault_flag, fw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   double2* dst = reinterpret_cast<double2*>(gf);
-  const double2* src = reinterpret_cast<const double2*>(e.f);
+  const double2* src = reinterpret_cast<const double2*>(EF(e));
   const int fa = h.f_cut0 / 2, fb = h.f_cut1 / 2;
   int4* dsti = reinterpret_cast<int4*>(gq);
-  const int4* srci = reinterpret_cast<const int4*>(e.q);
+  const int4* srci = reinterpret_cast<const int4*>(EQ(e));
   const int ia = h.i_cut0 / 4, ib = h.i_cut1 / 4;
   for (int i = e.lane; i < G.f64_per_env / 2; i += 64) {
     if (i < fa) dst[i] = src[i];
@@ -204,24 +204,24 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
   e.f = reinterpret_cast<double*>(lds);
   e.q = reinterpret_cast<int32_t*>(lds + (size_t)H.f64_per_env * 8);
   e.bb = reinterpret_cast<float*>(lds + (size_t)H.f64_per_env * 8 + (size_t)H.i32_per_env * 4);
-  e.voff = reinterpret_cast<int32_t*>(e.bb + 8 * H.S);
-  e.cand = reinterpret_cast<uint16_t*>(e.voff + ((H.S + 3) & ~3));
-  e.lst = reinterpret_cast<uint8_t*>(e.cand + CAND_CAP);
-  e.rowm = reinterpret_cast<unsigned long long*>(e.lst + 128);
+  e.voff = reinterpret_cast<int32_t*>((e).bb + 8 * H.S);
+  e.cand = reinterpret_cast<uint16_t*>((e).voff + ((H.S + 3) & ~3));
+  e.lst = reinterpret_cast<uint8_t*>((e).cand + CAND_CAP);
+  e.rowm = reinterpret_cast<unsigned long long*>((e).lst + 128);
   e.xstack = a.xstack_off > 0 ? reinterpret_cast<double*>(lds + a.xstack_off) : nullptr;
 #ifdef MOOG_WATCH
   e.secw = a.watch ? reinterpret_cast<int32_t*>(__builtin_assume_aligned(lds + a.watch_off, 16)) : nullptr;
 #endif
   if (a.H.f_cut1 > a.H.f_cut0) e.gcol = a.f64 + (size_t)env * a.L.f64_per_env + a.L.o_color;
-  else e.gcol = e.f + H.o_color;
+  else e.gcol = EF(e) + H.o_color;
   if (a.H.i_cut1 > a.H.i_cut0) {
     e.gopa = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_opacity;
     e.gshape = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_shape;
     e.gtele = a.i32 + (size_t)env * a.L.i32_per_env + a.L.o_tele;
   } else {
-    e.gopa = e.q + H.o_opacity;
-    e.gshape = e.q + H.o_shape;
-    e.gtele = e.q + H.o_tele;
+    e.gopa = EQ(e) + H.o_opacity;
+    e.gshape = EQ(e) + H.o_shape;
+    e.gtele = EQ(e) + H.o_tele;
   }
   e.vslot = a.vslot;
   e.dbg = a.dbg;
@@ -242,15 +242,15 @@ __device__ inline void bind_env(Env& e, const KArgs& a, int env, unsigned char* 
 struct RmSrcEnv {
   static constexpr bool kGlobalRecord = false;   // (the record is in LDS)
   const Env* e; const uint32_t* vi;   // vi: vertex slot -> sprite slot | index within the sprite << 8 (KArgs::draw_vinfo)
-  __device__ __forceinline__ int flags(int s) const { return e->q[EL(*e).o_flags + s]; }
-  __device__ __forceinline__ int nv(int s) const { return e->q[EL(*e).o_nverts + s]; }
+  __device__ __forceinline__ int flags(int s) const { return EQ(*e)[EL(*e).o_flags + s]; }
+  __device__ __forceinline__ int nv(int s) const { return EQ(*e)[EL(*e).o_nverts + s]; }
   __device__ __forceinline__ int opa(int s) const { return static_cast<const int32_t*>(e->gopa)[s]; }
-  __device__ __forceinline__ int voff(int s) const { return e->voff[s]; }
+  __device__ __forceinline__ int voff(int s) const { return EVOFF(*e)[s]; }
   __device__ __forceinline__ int vcap(int s) const { return EP(*e)->slot_vcap[s]; }
   __device__ __forceinline__ double col(int s, int c) const { return static_cast<const double*>(e->gcol)[3 * s + c]; }
   __device__ __forceinline__ uint32_t vinfo(int idx) const { return vi[idx]; }
-  __device__ __forceinline__ const double* vbase() const { return &e->f[EL(*e).o_verts]; }
-  __device__ __forceinline__ const double* pos(int s) const { return &e->f[EL(*e).o_pos + 2 * s]; }
+  __device__ __forceinline__ const double* vbase() const { return &EF(*e)[EL(*e).o_verts]; }
+  __device__ __forceinline__ const double* pos(int s) const { return &EF(*e)[EL(*e).o_pos + 2 * s]; }
 };
 // Beside store_record: the frame the rasteriser is about to draw, from the record in LDS (what the reset path wrote straight
 // to HBM -- colours, opacities -- is read back from there: same wavefront, stores and loads in order behind wsync).
@@ -264,7 +264,7 @@ __device__ __forceinline__ void emit_draw_record(const Env& e, const KArgs& a, i
   // last sub-step); the nine copies of a torus -- 46 words per slot -- in the candidate list / list / row mask area behind the
   // vertex offsets (CAND_CAP * 2 + 128 + 64 * 8 bytes: the engine checks that they fit, step_emits_draw)
   RmEmitScratch sc;
-  rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(e.cand) : reinterpret_cast<int32_t*>(e.bb), a.draw.slots, a.draw.ncopy, &sc);
+  rm_emit_scratch(a.draw.ncopy > 1 ? reinterpret_cast<int32_t*>(ECAND(e)) : reinterpret_cast<int32_t*>(EBB(e)), a.draw.slots, a.draw.ncopy, &sc);
   long long clk[5];
   rm_emit(a.draw, src, env, e.lane, sc, EL(e).TOTV, (a.dbg & 256) ? clk : nullptr);
   if ((a.dbg & 256) && e.lane == 0 && a.step_type) {   // (the emitter's cycles, and phase by phase: prefix | slots | vertex slots | items)
@@ -343,7 +343,7 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
   *held = 0;
   if (!a.pool_state || e.inj) return false;
   *held = 1;
-  const unsigned episode = (unsigned)e.q[EL(e).o_rng + 1] + 1u;
+  const unsigned episode = (unsigned)EQ(e)[EL(e).o_rng + 1] + 1u;
   int pick = -1, waited = 0;
   if (e.lane == 0) {
     __hip_atomic_store(&a.pool_lock[env], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -391,10 +391,10 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
     return false;
   }
   // what outlives a reset: sticky fault bits, the state slots (never reset; a reset that reads one is not eligible)
-  const int32_t fault = e.q[EL(e).o_fault];
+  const int32_t fault = EQ(e)[EL(e).o_fault];
   const int r = e.lane < a.L.R ? e.lane : 0;
-  const double keep = e.f[EL(e).o_rule + r];
-  const double keep2 = EL(e).o_rule2 >= 0 ? e.f[EL(e).o_rule2 + r] : 0.0;
+  const double keep = EF(e)[EL(e).o_rule + r];
+  const double keep2 = EL(e).o_rule2 >= 0 ? EF(e)[EL(e).o_rule2 + r] : 0.0;
   wsync();
   load_record(e, a.H, a.L, post_f, post_q);
   if (a.H.f_cut1 > a.H.f_cut0)
@@ -402,13 +402,13 @@ __device__ inline bool pool_adopt(Env& e, const KArgs& a, int env, double* gf, i
   if (a.H.i_cut1 > a.H.i_cut0)
     for (int i = a.H.i_cut0 + e.lane; i < a.H.i_cut1; i += 64) gq[i] = post_q[i];
   if (e.lane < a.L.R && EP(e)->rules[e.lane].kind == MOOG_RULE_STATE_SLOT) {
-    e.f[EL(e).o_rule + e.lane] = keep;
-    if (EL(e).o_rule2 >= 0) e.f[EL(e).o_rule2 + e.lane] = keep2;
+    EF(e)[EL(e).o_rule + e.lane] = keep;
+    if (EL(e).o_rule2 >= 0) EF(e)[EL(e).o_rule2 + e.lane] = keep2;
   }
   wave_global_fence();
   wsync();
   if (e.lane == 0) {
-    e.q[EL(e).o_fault] |= fault;
+    EQ(e)[EL(e).o_fault] |= fault;
     __hip_atomic_store(&a.pool_state[rec], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the lock keeps the fills off the env)
     atomicAdd(&a.pool_stats[0], 1ull);
     if (waited) atomicAdd(&a.pool_stats[3], 1ull);
@@ -507,13 +507,13 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   }
 #endif
   load_record(e, a.H, a.L, gf, gq);
-  if (e.inj && e.lane == 0) e.q[EL(e).o_rng + 2] = 0;
+  if (e.inj && e.lane == 0) EQ(e)[EL(e).o_rng + 2] = 0;
   wsync();
   env_reset<true>(e);
   wsync();
 #if MOOG_WITH_MAZE
   if (a.mode == MODE_FILL) {
-    if (e.lane == 0) e.q[EL(e).o_reset_next] = 0;
+    if (e.lane == 0) EQ(e)[EL(e).o_reset_next] = 0;
     store_record(e, a.H, a.L, gf, gq, nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the record (and what the reset wrote straight to HBM) before the flag
     if (e.lane == 0) __hip_atomic_store(&a.pool_state[rec], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64) void moog_reset_kernel(KArgs a) {
   }
 #endif
   if (e.lane == 0) {
-    e.q[EL(e).o_reset_next] = 0;
+    EQ(e)[EL(e).o_reset_next] = 0;
     if (a.reward) a.reward[env] = __builtin_nan("");
     if (a.discount) a.discount[env] = __builtin_nan("");
     if (a.step_type) a.step_type[env] = 0;
@@ -640,10 +640,10 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   const long long t_begin = (a.dbg & 128) ? clock64() : 0;
   double* gf = a.f64 + (size_t)env * a.L.f64_per_env;
   { PROF_T0; load_record(e, a.H, a.L, gf, gq); PROF_ADD(e, 9); }
-  if (e.inj && e.lane == 0) e.q[EL(e).o_rng + 2] = 0;
+  if (e.inj && e.lane == 0) EQ(e)[EL(e).o_rng + 2] = 0;
   wsync();
 #ifndef MOOG_NO_FUSED_RESET   // (A/B builds only: the step path without the sampler compiled in)
-  if (a.mode == MODE_STEP && uni(e.q[EL(e).o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
+  if (a.mode == MODE_STEP && uni(EQ(e)[EL(e).o_reset_next]) == 1) {   // auto-reset (environment.py:100-101)
     int held = 0;
     if (!(DYN && pool_adopt(e, a, env, gf, gq, &held))) {   // (the next episode may be waiting in the reset pool)
       if (DYN && a.late_mask) {
@@ -658,7 +658,7 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
     }
     wsync();
     if (e.lane == 0) {
-      e.q[EL(e).o_reset_next] = 0;
+      EQ(e)[EL(e).o_reset_next] = 0;
       if (a.reward) a.reward[env] = __builtin_nan("");
       if (a.discount) a.discount[env] = __builtin_nan("");
       if (a.step_type) a.step_type[env] = 0;
@@ -717,16 +717,16 @@ __device__ __forceinline__ void step_env(const KArgs& a, const int env, unsigned
   }
   { PROF_T0; for (int k = 0; k < K; ++k) apply_physics<DYN>(e); PROF_ADD(e, 6); }
   SEC(e, SEC_TASK);
-  int sc = e.q[EL(e).o_step_count] + 1;
+  int sc = EQ(e)[EL(e).o_step_count] + 1;
   wsync();
-  if (e.lane == 0) e.q[EL(e).o_step_count] = sc;
+  if (e.lane == 0) EQ(e)[EL(e).o_step_count] = sc;
   wsync();
   int sr = 0;
   double r;
   { PROF_T0; r = task_reward<DYN>(e, sc, &sr); PROF_ADD(e, 11); }
   wsync();
   if (e.lane == 0) {
-    if (sr) e.q[EL(e).o_reset_next] = 1;
+    if (sr) EQ(e)[EL(e).o_reset_next] = 1;
     if (a.reward) a.reward[env] = r;
     if (a.discount) a.discount[env] = sr ? 0.0 : 1.0;
     if (a.step_type) a.step_type[env] = sr ? 2 : 1;
